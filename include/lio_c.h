@@ -1,0 +1,235 @@
+/* lio_c.h — C-ABI of the MI355X-native sliding-window LiDAR-inertial estimator.
+ *
+ * The reference (hyye/lio-mapping) has no FFI: estimator_node links the C++ classes directly.
+ * This header flattens the public surface of those classes to POD so a host such as
+ * estimator_node can bind it.  It is implemented twice, with identical symbols:
+ *   - lio-mapping_amd/csrc  -> liblio_hip.so     (the product: HIP kernels for gfx950 + C++ host)
+ *   - oracle/               -> liblio_oracle.so  (CPU restatement; test infrastructure only)
+ *
+ * Conventions: every function returns int (LIO_OK or a negative code) unless it returns a handle,
+ * a count or void; nothing throws; no caller pointer is retained past the call; one caller thread
+ * per handle (like the reference's estimator thread B, src/estimator_node.cc:153).
+ * Points are float[4] = x,y,z,intensity (pcl::PointXYZI's useful 16 bytes).
+ * Poses are double[7] = px,py,pz,qx,qy,qz,qw (Estimator.cc:2445-2452); speed-bias double[9] =
+ * v,ba,bg (Estimator.cc:2454-2464); rotation matrices are row-major double[9].
+ */
+#ifndef LIO_C_H_
+#define LIO_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIO_OK 0
+#define LIO_ERR_ARG (-1)      /* null / out-of-range argument */
+#define LIO_ERR_STATE (-2)    /* call order violated (e.g. solve before the window is full) */
+#define LIO_ERR_DEVICE (-3)   /* HIP runtime failure or no GPU: the product never falls back to CPU */
+#define LIO_ERR_CAPACITY (-4) /* a fixed-capacity device buffer would overflow */
+
+/* Twist<float> (include/utils/Twist.h:39-97): rotation quaternion x,y,z,w + translation */
+typedef struct {
+  float q[4];
+  float p[3];
+} lio_transform_f;
+
+/* Which implementation is behind the symbols: "hip-gfx950" or "oracle-cpu". */
+const char *lio_backend(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * PointProcessor (include/point_processor/PointProcessor.h:127-165; §8a a1-a5)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  double scan_period;          /* 0.1   PointProcessor.h:106 */
+  int num_scan_subregions;     /* 8     :107 */
+  int num_curvature_regions;   /* 5     :108 */
+  float surf_curv_th;          /* 0.1f  :109 */
+  int max_corner_sharp;        /* 2     :110 */
+  int max_corner_less_sharp;   /* 20    :111 */
+  int max_surf_flat;           /* 4     :112 */
+  float less_flat_filter_size; /* 0.2f  :113 */
+} lio_pp_config;
+
+typedef struct lio_pp lio_pp;
+
+enum {
+  LIO_PP_RINGS = 0,       /* laser_scans concatenated: intensity = ring + rel_time */
+  LIO_PP_SHARP = 1,       /* corner_points_sharp_ */
+  LIO_PP_LESS_SHARP = 2,  /* corner_points_less_sharp_ */
+  LIO_PP_FLAT = 3,        /* surface_points_flat_ */
+  LIO_PP_LESS_FLAT = 4    /* surface_points_less_flat_ (per-ring voxel-downsampled) */
+};
+
+void lio_pp_default_config(lio_pp_config *cfg);
+/* PointProcessor(float lower, float upper, int rings) — PointProcessor.cc:75; uneven=false only */
+lio_pp *lio_pp_create(float lower_deg, float upper_deg, int rings, const lio_pp_config *cfg_or_null);
+void lio_pp_destroy(lio_pp *);
+/* SetInputCloud + PointToRing + ExtractFeaturePoints (PointProcessor.cc:96-100, test_point_processor.cc:103-106) */
+int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
+size_t lio_pp_count(const lio_pp *, int which);
+int lio_pp_get_cloud(const lio_pp *, int which, float *xyzi_out);
+/* parity object of §8a a4: ordered (ring, in-ring index) per picked class; which in {SHARP,LESS_SHARP,FLAT} */
+int lio_pp_get_indices(const lio_pp *, int which, int32_t *ring_out, int32_t *idx_out);
+/* scan_ranges as rings+1 exclusive offsets into the LIO_PP_RINGS cloud (PointProcessor.cc:193-201) */
+int lio_pp_get_ring_offsets(const lio_pp *, int32_t *offsets_out);
+/* per-point curvature of the LIO_PP_RINGS cloud (0 outside [5, n-5) of a ring) and final pick mask */
+int lio_pp_get_curvature(const lio_pp *, float *curv_out, int32_t *mask_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stateless building blocks (third-party semantics restated)
+ * ---------------------------------------------------------------------------------------------- */
+/* pcl::VoxelGrid<PointXYZI> (B.1): centroids in ascending voxel index; out capacity n points.   */
+int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *xyzi_out, size_t *n_out);
+/* pcl::KdTreeFLANN::nearestKSearch (B.2): exact K-NN, ascending squared distance, index tiebreak.
+ * idx_out / sqd_out are m*k.  The product restricts the search to radius_sq (entries beyond it
+ * come back as idx -1 / sqd +inf); pass radius_sq <= 0 for an unbounded search (oracle only).  */
+int lio_knn(const float *map_xyzi, size_t n_map, const float *query_xyzi, size_t m, int k,
+            float radius_sq, int32_t *idx_out, float *sqd_out);
+/* Estimator::CalculateFeatures, surf branch (Estimator.cc:1014-1097) for one stack against one
+ * filtered local map.  Outputs per stack point: valid flag, coeff[4] (s*pa,s*pb,s*pc,s*pd), score. */
+int lio_calculate_features(const float *map_xyzi, size_t n_map, const float *stack_xyzi, size_t m,
+                           const lio_transform_f *local_transform, float min_match_sq_dis,
+                           float min_plane_dis, uint8_t *valid_out, float *coeff_out, float *score_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * IntegrationBase (include/imu_processor/IntegrationBase.h:77-357; §8a a9-a10)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lio_pim lio_pim;
+lio_pim *lio_pim_create(const double acc0[3], const double gyr0[3], const double ba[3],
+                        const double bg[3], double acc_n, double gyr_n, double acc_w, double gyr_w,
+                        double g_norm);
+void lio_pim_destroy(lio_pim *);
+int lio_pim_push_back(lio_pim *, double dt, const double acc[3], const double gyr[3]);
+int lio_pim_repropagate(lio_pim *, const double ba[3], const double bg[3]);
+/* any output pointer may be null; dq = x,y,z,w; jacobian / covariance 15x15 row-major */
+int lio_pim_get(const lio_pim *, double *sum_dt, double *delta_p, double *delta_q, double *delta_v,
+                double *jacobian, double *covariance);
+int lio_pim_evaluate(const lio_pim *, const double *pose_i, const double *sb_i,
+                     const double *pose_j, const double *sb_j, double *residual15);
+
+/* ------------------------------------------------------------------------------------------------
+ * Factors (ceres::SizedCostFunction::Evaluate restated; §8a a11, a15, a24).  Jacobians are
+ * row-major in the ambient (7/9 column) layout exactly as the reference writes them; null = skip.
+ * ---------------------------------------------------------------------------------------------- */
+/* ImuFactor::Evaluate (include/factor/ImuFactor.h:53-168): <15,7,9,7,9> */
+int lio_factor_imu(const lio_pim *, const double *pose_i, const double *sb_i, const double *pose_j,
+                   const double *sb_j, double *residual15, double *j_pose_i, double *j_sb_i,
+                   double *j_pose_j, double *j_sb_j);
+/* PivotPointPlaneFactor::Evaluate (src/factor/PivotPointPlaneFactor.cc:43-137): <1,7,7,7> */
+int lio_factor_pivot_point_plane(const double point[3], const double coeff[4],
+                                 const double *pose_pivot, const double *pose_i,
+                                 const double *pose_ex, double *residual1, double *j_pivot,
+                                 double *j_i, double *j_ex);
+/* PriorFactor::Evaluate (src/factor/PriorFactor.cc:35-67): <6,7>; rot0 = x,y,z,w */
+int lio_factor_prior(const double pos0[3], const double rot0[4], const double *pose,
+                     double *residual6, double *j_pose);
+/* PoseLocalParameterization::Plus (src/factor/PoseLocalParameterization.cc:35-50) */
+int lio_pose_plus(const double *pose, const double *delta6, double *pose_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Estimator (include/imu_processor/Estimator.h:110-299; §8a a12-a27, §8b)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int window_size;            /* 15   Estimator.h:78  */
+  int opt_window_size;        /* 5    :79             */
+  float corner_filter_size;   /* 0.2  :83             */
+  float surf_filter_size;     /* 0.4  :84             */
+  float min_match_sq_dis;     /* 1.0  :87             */
+  float min_plane_dis;        /* 0.2  :88             */
+  lio_transform_f transform_lb; /* :89 */
+  int opt_extrinsic;          /* :91 */
+  int imu_factor;             /* :97 */
+  int point_distance_factor;  /* :98 */
+  int prior_factor;           /* :99 */
+  int marginalization_factor; /* :100 */
+  int enable_deskew;          /* :103 */
+  int cutoff_deskew;          /* :104 */
+  int keep_features;          /* :105 */
+  double acc_n, gyr_n, acc_w, gyr_w, g_norm; /* IntegrationBaseConfig, IntegrationBase.h:64-70 */
+  int max_num_iterations;     /* ceres options, Estimator.cc:1916 (10) */
+  double max_solver_time;     /* Estimator.cc:1921 (0.10 s); <= 0 disables the cap (parity runs) */
+  int extrinsic_stage;        /* Estimator.h extrinsic_stage_: 0 = fixed (SetParameterBlockConstant) */
+} lio_est_config;
+
+/* Named after the reference's TicToc stages so CPU/GPU tables line up. */
+typedef struct {
+  int iterations;             /* trust-region iterations taken (successful + unsuccessful) */
+  int successful_steps;
+  int termination;            /* 0 no-convergence(max it), 1 param tol, 2 function tol, 3 gradient tol, 4 time, 5 failure */
+  int n_lidar_residuals;
+  int n_local_map;            /* filtered local map points */
+  int laser_odom_iterations;  /* CalculateLaserOdom rounds on the newest frame */
+  int turn_off;               /* Estimator.cc:1655,1938-1942 */
+  int convergence_flag;       /* Estimator.cc:1960-1962 */
+  int marginalized;           /* 1 if a new prior was produced */
+  double cost_pim_before, cost_ppp_before, cost_marg_before; /* Estimator.cc:1924-1954 */
+  double initial_cost, final_cost;
+  double cost_trace[32];      /* cost after iteration k (k = 0 initial) */
+  double ms_build_map;        /* "t_build_map cost"  Estimator.cc:1531 */
+  double ms_features;         /* sum of "feature cost" :1643 */
+  double ms_prepare;          /* "prepare for ceres" :1907 (minus the two above) */
+  double ms_opt;              /* "t_opt" :1993 */
+  double ms_marg;             /* "whole marginalization costs" :2247 */
+  double ms_total;            /* "tic_toc_opt" :2436 */
+} lio_solve_report;
+
+typedef struct lio_est lio_est;
+
+void lio_est_default_config(lio_est_config *cfg);
+lio_est *lio_est_create(const lio_est_config *cfg);
+void lio_est_destroy(lio_est *);
+
+/* Estimator::ProcessImu (Estimator.cc:338-427) */
+int lio_est_process_imu(lio_est *, double dt, const double acc[3], const double gyr[3], double stamp);
+/* Estimator::ProcessLaserOdom, INITED branch (Estimator.cc:430-488,620-774): push the frame,
+ * (deskew), VoxelGrid the surf/corner clouds, SolveOptimization, SlideWindow.  The clouds are the
+ * implicit inputs the reference keeps in laser_cloud_{surf,corner}_last_ (Estimator.cc:467-487). */
+int lio_est_process_laser_odom(lio_est *, const lio_transform_f *transform_in, const float *surf_xyzi,
+                               size_t n_surf, const float *corner_xyzi, size_t n_corner, double stamp,
+                               lio_solve_report *report_or_null);
+/* Estimator::SolveOptimization (Estimator.cc:1648-2438) */
+int lio_est_solve_optimization(lio_est *, lio_solve_report *report_or_null);
+/* Estimator::SlideWindow (Estimator.cc:2570-2666) */
+int lio_est_slide_window(lio_est *);
+
+/* ---- test hooks (no reference counterpart): inject / read a window ---- */
+/* n_frames must be window_size+1.  Marks the estimator INITED with a full window. */
+int lio_est_set_window(lio_est *, int n_frames, const double *Ps, const double *Rs, const double *Vs,
+                       const double *Bas, const double *Bgs, const double g_vec[3]);
+int lio_est_get_window(const lio_est *, int n_frames, double *Ps, double *Rs, double *Vs, double *Bas,
+                       double *Bgs, lio_transform_f *transform_lb_out);
+/* surf_stack_[frame] (already voxel-filtered, lidar frame); also sets size_surf_stack_[frame] */
+int lio_est_set_surf_stack(lio_est *, int frame, const float *xyzi, size_t n);
+size_t lio_est_get_surf_stack(const lio_est *, int frame, float *xyzi_or_null);
+/* pre_integrations_[frame] rebuilt from raw samples (frame >= 1) */
+int lio_est_set_preintegration(lio_est *, int frame, const double acc0[3], const double gyr0[3],
+                               const double ba[3], const double bg[3], const double *dt,
+                               const double *acc, const double *gyr, size_t n_samples);
+/* acc_last_/gyr_last_ + tmp_pre_integration_ restart, as after a ProcessLaserOdom push */
+int lio_est_begin_frame(lio_est *, const double acc_last[3], const double gyr_last[3]);
+
+/* Estimator::BuildLocalMap alone (Estimator.cc:1361-1646): local map + per-frame features */
+int lio_est_build_local_map(lio_est *);
+size_t lio_est_get_local_map(const lio_est *, float *xyzi_or_null);
+size_t lio_est_get_features(const lio_est *, int frame, double *point3_or_null,
+                            double *coeff4_or_null, double *score_or_null);
+/* newest-frame transform after CalculateLaserOdom (Estimator.cc:1242-1359) */
+int lio_est_get_laser_odom_transform(const lio_est *, lio_transform_f *out);
+
+/* Marginalization prior (MarginalizationInfo after Marginalize, MarginalizationFactor.cc:185-311),
+ * in the canonical kept order pose1,sb1,pose2..poseWo,ex.  Returns n (0 = none).
+ * JtJ = linearized_jacobians^T linearized_jacobians (n*n), Jtr = linearized_jacobians^T
+ * linearized_residuals (n), x0 = kept parameter blocks concatenated in ambient layout.           */
+int lio_est_get_prior(const lio_est *, double *JtJ_or_null, double *Jtr_or_null, double *x0_or_null,
+                      int *x0_len_or_null);
+
+/* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
+int lio_est_snapshot(lio_est *);
+int lio_est_restore(lio_est *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIO_C_H_ */

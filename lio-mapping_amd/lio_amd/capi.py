@@ -1,0 +1,466 @@
+"""ctypes view of include/lio_c.h.
+
+`load_hip()` opens the product (liblio_hip.so next to csrc/) and raises if it is missing: there is no
+CPU fallback.  Tests additionally open the oracle with `LioLib(path_to_liblio_oracle)`; product code
+never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "liblio_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class TransformF(C.Structure):
+    _fields_ = [("q", C.c_float * 4), ("p", C.c_float * 3)]
+
+    @staticmethod
+    def make(q_xyzw, p):
+        t = TransformF()
+        for i in range(4):
+            t.q[i] = float(q_xyzw[i])
+        for i in range(3):
+            t.p[i] = float(p[i])
+        return t
+
+    def to_np(self):
+        return np.array(list(self.q), dtype=np.float32), np.array(list(self.p), dtype=np.float32)
+
+
+class PPConfig(C.Structure):
+    _fields_ = [
+        ("scan_period", C.c_double),
+        ("num_scan_subregions", C.c_int),
+        ("num_curvature_regions", C.c_int),
+        ("surf_curv_th", C.c_float),
+        ("max_corner_sharp", C.c_int),
+        ("max_corner_less_sharp", C.c_int),
+        ("max_surf_flat", C.c_int),
+        ("less_flat_filter_size", C.c_float),
+    ]
+
+
+class EstConfig(C.Structure):
+    _fields_ = [
+        ("window_size", C.c_int),
+        ("opt_window_size", C.c_int),
+        ("corner_filter_size", C.c_float),
+        ("surf_filter_size", C.c_float),
+        ("min_match_sq_dis", C.c_float),
+        ("min_plane_dis", C.c_float),
+        ("transform_lb", TransformF),
+        ("opt_extrinsic", C.c_int),
+        ("imu_factor", C.c_int),
+        ("point_distance_factor", C.c_int),
+        ("prior_factor", C.c_int),
+        ("marginalization_factor", C.c_int),
+        ("enable_deskew", C.c_int),
+        ("cutoff_deskew", C.c_int),
+        ("keep_features", C.c_int),
+        ("acc_n", C.c_double),
+        ("gyr_n", C.c_double),
+        ("acc_w", C.c_double),
+        ("gyr_w", C.c_double),
+        ("g_norm", C.c_double),
+        ("max_num_iterations", C.c_int),
+        ("max_solver_time", C.c_double),
+        ("extrinsic_stage", C.c_int),
+    ]
+
+
+class SolveReport(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("successful_steps", C.c_int),
+        ("termination", C.c_int),
+        ("n_lidar_residuals", C.c_int),
+        ("n_local_map", C.c_int),
+        ("laser_odom_iterations", C.c_int),
+        ("turn_off", C.c_int),
+        ("convergence_flag", C.c_int),
+        ("marginalized", C.c_int),
+        ("cost_pim_before", C.c_double),
+        ("cost_ppp_before", C.c_double),
+        ("cost_marg_before", C.c_double),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("cost_trace", C.c_double * 32),
+        ("ms_build_map", C.c_double),
+        ("ms_features", C.c_double),
+        ("ms_prepare", C.c_double),
+        ("ms_opt", C.c_double),
+        ("ms_marg", C.c_double),
+        ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if name == "cost_trace" else v
+        return d
+
+
+# every symbol include/lio_c.h declares (checked by tests/test_abi.py against the header text)
+_SIGS = {
+    "lio_backend": (C.c_char_p, []),
+    "lio_pp_default_config": (None, [C.POINTER(PPConfig)]),
+    "lio_pp_create": (C.c_void_p, [C.c_float, C.c_float, C.c_int, C.POINTER(PPConfig)]),
+    "lio_pp_destroy": (None, [C.c_void_p]),
+    "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "lio_pp_get_cloud": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_pp_get_indices": (C.c_int, [C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
+    "lio_pp_get_ring_offsets": (C.c_int, [C.c_void_p, c_int32_p]),
+    "lio_pp_get_curvature": (C.c_int, [C.c_void_p, c_float_p, c_int32_p]),
+    "lio_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_size_t)]),
+    "lio_knn": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_int, C.c_float, c_int32_p, c_float_p]),
+    "lio_calculate_features": (
+        C.c_int,
+        [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.POINTER(TransformF), C.c_float, C.c_float, c_uint8_p, c_float_p, c_float_p],
+    ),
+    "lio_pim_create": (C.c_void_p, [c_double_p] * 4 + [C.c_double] * 5),
+    "lio_pim_destroy": (None, [C.c_void_p]),
+    "lio_pim_push_back": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p]),
+    "lio_pim_repropagate": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "lio_pim_get": (C.c_int, [C.c_void_p] + [c_double_p] * 6),
+    "lio_pim_evaluate": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
+    "lio_factor_imu": (C.c_int, [C.c_void_p] + [c_double_p] * 9),
+    "lio_factor_pivot_point_plane": (C.c_int, [c_double_p] * 9),
+    "lio_factor_prior": (C.c_int, [c_double_p] * 5),
+    "lio_pose_plus": (C.c_int, [c_double_p] * 3),
+    "lio_est_default_config": (None, [C.POINTER(EstConfig)]),
+    "lio_est_create": (C.c_void_p, [C.POINTER(EstConfig)]),
+    "lio_est_destroy": (None, [C.c_void_p]),
+    "lio_est_process_imu": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, C.c_double]),
+    "lio_est_process_laser_odom": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double, C.POINTER(SolveReport)],
+    ),
+    "lio_est_solve_optimization": (C.c_int, [C.c_void_p, C.POINTER(SolveReport)]),
+    "lio_est_slide_window": (C.c_int, [C.c_void_p]),
+    "lio_est_set_window": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 6),
+    "lio_est_get_window": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 5 + [C.POINTER(TransformF)]),
+    "lio_est_set_surf_stack": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_size_t]),
+    "lio_est_get_surf_stack": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_est_set_preintegration": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 7 + [C.c_size_t]),
+    "lio_est_begin_frame": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "lio_est_build_local_map": (C.c_int, [C.c_void_p]),
+    "lio_est_get_local_map": (C.c_size_t, [C.c_void_p, c_float_p]),
+    "lio_est_get_features": (C.c_size_t, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "lio_est_get_laser_odom_transform": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
+    "lio_est_get_prior": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
+    "lio_est_snapshot": (C.c_int, [C.c_void_p]),
+    "lio_est_restore": (C.c_int, [C.c_void_p]),
+}
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(c_float_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class LioError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise LioError(f"{what} failed with code {rc}")
+
+
+class LioLib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise LioError(f"{path} is missing — build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+        self.backend = self.dll.lio_backend().decode()
+
+    # ---- stateless blocks
+    def voxel_grid(self, xyzi, leaf):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        out = np.zeros_like(xyzi)
+        n = C.c_size_t(0)
+        _chk(self.dll.lio_voxel_grid(_fp(xyzi), xyzi.shape[0], leaf, _fp(out), C.byref(n)), "lio_voxel_grid")
+        return out[: n.value].copy()
+
+    def knn(self, map_xyzi, query_xyzi, k, radius_sq=0.0):
+        m_ = _f32(map_xyzi).reshape(-1, 4)
+        q_ = _f32(query_xyzi).reshape(-1, 4)
+        idx = np.zeros((q_.shape[0], k), dtype=np.int32)
+        sqd = np.zeros((q_.shape[0], k), dtype=np.float32)
+        _chk(
+            self.dll.lio_knn(_fp(m_), m_.shape[0], _fp(q_), q_.shape[0], k, radius_sq, idx.ctypes.data_as(c_int32_p), _fp(sqd)), "lio_knn"
+        )
+        return idx, sqd
+
+    def calculate_features(self, map_xyzi, stack_xyzi, T: TransformF, min_match_sq_dis=1.0, min_plane_dis=0.2):
+        m_ = _f32(map_xyzi).reshape(-1, 4)
+        s_ = _f32(stack_xyzi).reshape(-1, 4)
+        valid = np.zeros(s_.shape[0], dtype=np.uint8)
+        coeff = np.zeros((s_.shape[0], 4), dtype=np.float32)
+        score = np.zeros(s_.shape[0], dtype=np.float32)
+        _chk(
+            self.dll.lio_calculate_features(
+                _fp(m_), m_.shape[0], _fp(s_), s_.shape[0], C.byref(T), min_match_sq_dis, min_plane_dis, valid.ctypes.data_as(c_uint8_p), _fp(coeff), _fp(score)
+            ),
+            "lio_calculate_features",
+        )
+        return valid, coeff, score
+
+    # ---- factors
+    def factor_ppp(self, point, coeff, pose_p, pose_i, pose_ex, jac=True):
+        res = np.zeros(1)
+        js = [np.zeros(7) for _ in range(3)] if jac else [None] * 3
+        _chk(
+            self.dll.lio_factor_pivot_point_plane(
+                _dp(_f64(point)), _dp(_f64(coeff)), _dp(_f64(pose_p)), _dp(_f64(pose_i)), _dp(_f64(pose_ex)), _dp(res), *[_dp(j) for j in js]
+            ),
+            "lio_factor_pivot_point_plane",
+        )
+        return res[0], js
+
+    def factor_prior(self, pos0, rot0, pose, jac=True):
+        res = np.zeros(6)
+        J = np.zeros((6, 7)) if jac else None
+        _chk(self.dll.lio_factor_prior(_dp(_f64(pos0)), _dp(_f64(rot0)), _dp(_f64(pose)), _dp(res), _dp(J)), "lio_factor_prior")
+        return res, J
+
+    def pose_plus(self, pose, delta):
+        out = np.zeros(7)
+        _chk(self.dll.lio_pose_plus(_dp(_f64(pose)), _dp(_f64(delta)), _dp(out)), "lio_pose_plus")
+        return out
+
+    def default_est_config(self) -> EstConfig:
+        c = EstConfig()
+        self.dll.lio_est_default_config(C.byref(c))
+        return c
+
+
+class Pim:
+    def __init__(self, lib: LioLib, acc0, gyr0, ba, bg, acc_n=0.1, gyr_n=0.01, acc_w=0.0002, gyr_w=2.0e-5, g_norm=9.805):
+        self.lib = lib
+        self.h = lib.dll.lio_pim_create(_dp(_f64(acc0)), _dp(_f64(gyr0)), _dp(_f64(ba)), _dp(_f64(bg)), acc_n, gyr_n, acc_w, gyr_w, g_norm)
+        if not self.h:
+            raise LioError("lio_pim_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_pim_destroy(self.h)
+            self.h = None
+
+    def push_back(self, dt, acc, gyr):
+        _chk(self.lib.dll.lio_pim_push_back(self.h, dt, _dp(_f64(acc)), _dp(_f64(gyr))), "lio_pim_push_back")
+
+    def repropagate(self, ba, bg):
+        _chk(self.lib.dll.lio_pim_repropagate(self.h, _dp(_f64(ba)), _dp(_f64(bg))), "lio_pim_repropagate")
+
+    def get(self):
+        sum_dt = np.zeros(1)
+        dp, dq, dv = np.zeros(3), np.zeros(4), np.zeros(3)
+        jac, cov = np.zeros((15, 15)), np.zeros((15, 15))
+        _chk(self.lib.dll.lio_pim_get(self.h, _dp(sum_dt), _dp(dp), _dp(dq), _dp(dv), _dp(jac), _dp(cov)), "lio_pim_get")
+        return dict(sum_dt=sum_dt[0], dp=dp, dq=dq, dv=dv, jac=jac, cov=cov)
+
+    def evaluate(self, pose_i, sb_i, pose_j, sb_j):
+        res = np.zeros(15)
+        _chk(self.lib.dll.lio_pim_evaluate(self.h, _dp(_f64(pose_i)), _dp(_f64(sb_i)), _dp(_f64(pose_j)), _dp(_f64(sb_j)), _dp(res)), "lio_pim_evaluate")
+        return res
+
+    def factor(self, pose_i, sb_i, pose_j, sb_j, jac=True):
+        res = np.zeros(15)
+        js = [np.zeros((15, 7)), np.zeros((15, 9)), np.zeros((15, 7)), np.zeros((15, 9))] if jac else [None] * 4
+        _chk(
+            self.lib.dll.lio_factor_imu(self.h, _dp(_f64(pose_i)), _dp(_f64(sb_i)), _dp(_f64(pose_j)), _dp(_f64(sb_j)), _dp(res), *[_dp(j) for j in js]),
+            "lio_factor_imu",
+        )
+        return res, js
+
+
+class PointProcessor:
+    RINGS, SHARP, LESS_SHARP, FLAT, LESS_FLAT = range(5)
+
+    def __init__(self, lib: LioLib, lower, upper, rings, cfg: PPConfig | None = None):
+        self.lib = lib
+        self.rings = rings
+        self.h = lib.dll.lio_pp_create(lower, upper, rings, C.byref(cfg) if cfg is not None else None)
+        if not self.h:
+            raise LioError("lio_pp_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_pp_destroy(self.h)
+            self.h = None
+
+    def process(self, xyzi):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        _chk(self.lib.dll.lio_pp_process(self.h, _fp(xyzi), xyzi.shape[0]), "lio_pp_process")
+
+    def cloud(self, which):
+        n = self.lib.dll.lio_pp_count(self.h, which)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            _chk(self.lib.dll.lio_pp_get_cloud(self.h, which, _fp(out)), "lio_pp_get_cloud")
+        return out
+
+    def indices(self, which):
+        n = self.lib.dll.lio_pp_count(self.h, which)
+        ring = np.zeros(n, dtype=np.int32)
+        idx = np.zeros(n, dtype=np.int32)
+        if n:
+            _chk(self.lib.dll.lio_pp_get_indices(self.h, which, ring.ctypes.data_as(c_int32_p), idx.ctypes.data_as(c_int32_p)), "lio_pp_get_indices")
+        return ring, idx
+
+    def ring_offsets(self):
+        out = np.zeros(self.rings + 1, dtype=np.int32)
+        _chk(self.lib.dll.lio_pp_get_ring_offsets(self.h, out.ctypes.data_as(c_int32_p)), "lio_pp_get_ring_offsets")
+        return out
+
+    def curvature(self):
+        n = self.lib.dll.lio_pp_count(self.h, 0)
+        curv = np.zeros(n, dtype=np.float32)
+        mask = np.zeros(n, dtype=np.int32)
+        _chk(self.lib.dll.lio_pp_get_curvature(self.h, _fp(curv), mask.ctypes.data_as(c_int32_p)), "lio_pp_get_curvature")
+        return curv, mask
+
+
+class Estimator:
+    def __init__(self, lib: LioLib, cfg: EstConfig):
+        self.lib = lib
+        self.cfg = cfg
+        self.W = cfg.window_size
+        self.h = lib.dll.lio_est_create(C.byref(cfg))
+        if not self.h:
+            raise LioError("lio_est_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_est_destroy(self.h)
+            self.h = None
+
+    def process_imu(self, dt, acc, gyr, stamp):
+        _chk(self.lib.dll.lio_est_process_imu(self.h, dt, _dp(_f64(acc)), _dp(_f64(gyr)), stamp), "lio_est_process_imu")
+
+    def process_laser_odom(self, T: TransformF, surf, corner, stamp):
+        surf = _f32(surf).reshape(-1, 4)
+        corner = _f32(corner).reshape(-1, 4)
+        rep = SolveReport()
+        _chk(
+            self.lib.dll.lio_est_process_laser_odom(self.h, C.byref(T), _fp(surf), surf.shape[0], _fp(corner), corner.shape[0], stamp, C.byref(rep)),
+            "lio_est_process_laser_odom",
+        )
+        return rep
+
+    def solve(self):
+        rep = SolveReport()
+        _chk(self.lib.dll.lio_est_solve_optimization(self.h, C.byref(rep)), "lio_est_solve_optimization")
+        return rep
+
+    def slide(self):
+        _chk(self.lib.dll.lio_est_slide_window(self.h), "lio_est_slide_window")
+
+    def set_window(self, Ps, Rs, Vs, Bas, Bgs, g_vec):
+        n = self.W + 1
+        Ps, Rs, Vs, Bas, Bgs = (_f64(a) for a in (Ps, Rs, Vs, Bas, Bgs))
+        assert Ps.shape == (n, 3) and Rs.shape == (n, 3, 3)
+        _chk(self.lib.dll.lio_est_set_window(self.h, n, _dp(Ps), _dp(Rs), _dp(Vs), _dp(Bas), _dp(Bgs), _dp(_f64(g_vec))), "lio_est_set_window")
+
+    def get_window(self):
+        n = self.W + 1
+        Ps, Rs, Vs, Bas, Bgs = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        T = TransformF()
+        _chk(self.lib.dll.lio_est_get_window(self.h, n, _dp(Ps), _dp(Rs), _dp(Vs), _dp(Bas), _dp(Bgs), C.byref(T)), "lio_est_get_window")
+        q, p = T.to_np()
+        return dict(Ps=Ps, Rs=Rs, Vs=Vs, Bas=Bas, Bgs=Bgs, q_lb=q, t_lb=p)
+
+    def set_surf_stack(self, frame, xyzi):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        _chk(self.lib.dll.lio_est_set_surf_stack(self.h, frame, _fp(xyzi), xyzi.shape[0]), "lio_est_set_surf_stack")
+
+    def get_surf_stack(self, frame):
+        n = self.lib.dll.lio_est_get_surf_stack(self.h, frame, None)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_est_get_surf_stack(self.h, frame, _fp(out))
+        return out
+
+    def set_preintegration(self, frame, acc0, gyr0, ba, bg, dt, acc, gyr):
+        dt, acc, gyr = _f64(dt), _f64(acc), _f64(gyr)
+        _chk(
+            self.lib.dll.lio_est_set_preintegration(
+                self.h, frame, _dp(_f64(acc0)), _dp(_f64(gyr0)), _dp(_f64(ba)), _dp(_f64(bg)), _dp(dt), _dp(acc), _dp(gyr), dt.shape[0]
+            ),
+            "lio_est_set_preintegration",
+        )
+
+    def begin_frame(self, acc_last, gyr_last):
+        _chk(self.lib.dll.lio_est_begin_frame(self.h, _dp(_f64(acc_last)), _dp(_f64(gyr_last))), "lio_est_begin_frame")
+
+    def build_local_map(self):
+        _chk(self.lib.dll.lio_est_build_local_map(self.h), "lio_est_build_local_map")
+
+    def local_map(self):
+        n = self.lib.dll.lio_est_get_local_map(self.h, None)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_est_get_local_map(self.h, _fp(out))
+        return out
+
+    def features(self, frame):
+        n = self.lib.dll.lio_est_get_features(self.h, frame, None, None, None)
+        pt, co, sc = np.zeros((n, 3)), np.zeros((n, 4)), np.zeros(n)
+        if n:
+            self.lib.dll.lio_est_get_features(self.h, frame, _dp(pt), _dp(co), _dp(sc))
+        return pt, co, sc
+
+    def laser_odom_transform(self):
+        T = TransformF()
+        _chk(self.lib.dll.lio_est_get_laser_odom_transform(self.h, C.byref(T)), "lio_est_get_laser_odom_transform")
+        return T.to_np()
+
+    def prior(self):
+        n = self.lib.dll.lio_est_get_prior(self.h, None, None, None, None)
+        if n <= 0:
+            return None
+        JtJ, Jtr = np.zeros((n, n)), np.zeros(n)
+        ln = C.c_int(0)
+        self.lib.dll.lio_est_get_prior(self.h, None, None, None, C.byref(ln))
+        x0 = np.zeros(ln.value)
+        self.lib.dll.lio_est_get_prior(self.h, _dp(JtJ), _dp(Jtr), _dp(x0), C.byref(ln))
+        return dict(n=n, JtJ=JtJ, Jtr=Jtr, x0=x0)
+
+    def snapshot(self):
+        _chk(self.lib.dll.lio_est_snapshot(self.h), "lio_est_snapshot")
+
+    def restore(self):
+        _chk(self.lib.dll.lio_est_restore(self.h), "lio_est_restore")
+
+
+def load_hip() -> LioLib:
+    """The product library.  Fails loudly when it has not been built; never substitutes the oracle."""
+    return LioLib(HIP_LIB_PATH)

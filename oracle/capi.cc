@@ -1,0 +1,367 @@
+// oracle/capi.cc — TEST INFRASTRUCTURE ONLY (CPU oracle).  Not part of the product.
+// Implements include/lio_c.h on top of the CPU restatement so tests/ can drive both back ends
+// through the same symbols.  Built by oracle/Makefile into oracle/liblio_oracle.so.
+#include <cstring>
+#include <new>
+
+#include "../include/lio_c.h"
+#include "estimator.h"
+#include "pointproc.h"
+
+using namespace orc;
+
+struct lio_pp { PointProcessor pp; lio_pp(float a, float b, int r) : pp(a, b, r) {} };
+struct lio_pim { IntegrationBase pim; lio_pim(const V3d &a, const V3d &g, const V3d &ba, const V3d &bg, const PimConfig &c) : pim(a, g, ba, bg, c) {} };
+struct lio_est {
+  Estimator est;
+  std::unique_ptr<Estimator> snap;
+  explicit lio_est(const EstimatorConfig &c) : est(c) {}
+};
+
+static V3d v3(const double *p) { return V3d(p[0], p[1], p[2]); }
+static Transformf toT(const lio_transform_f &t) { return Transformf(Q<float>(t.q[3], t.q[0], t.q[1], t.q[2]), V3<float>(t.p[0], t.p[1], t.p[2])); }
+static void fromT(const Transformf &T, lio_transform_f *o) { o->q[0] = T.rot.x; o->q[1] = T.rot.y; o->q[2] = T.rot.z; o->q[3] = T.rot.w; o->p[0] = T.pos.x; o->p[1] = T.pos.y; o->p[2] = T.pos.z; }
+static Cloud toCloud(const float *xyzi, size_t n) { Cloud c(n); if (n) std::memcpy(c.data(), xyzi, n * sizeof(P4)); return c; }
+
+extern "C" {
+
+const char *lio_backend(void) { return "oracle-cpu"; }
+
+// ---------------------------------------------------------------- PointProcessor
+void lio_pp_default_config(lio_pp_config *c) {
+  if (!c) return;
+  c->scan_period = 0.1; c->num_scan_subregions = 8; c->num_curvature_regions = 5; c->surf_curv_th = 0.1f;
+  c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
+}
+lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
+  if (rings <= 0 || !(up > lo)) return nullptr;
+  lio_pp *h = new (std::nothrow) lio_pp(lo, up, rings);
+  if (h && c) {
+    PPConfig &k = h->pp.config_;
+    k.scan_period = c->scan_period; k.num_scan_subregions = c->num_scan_subregions; k.num_curvature_regions = c->num_curvature_regions;
+    k.surf_curv_th = c->surf_curv_th; k.max_corner_sharp = c->max_corner_sharp; k.max_corner_less_sharp = c->max_corner_less_sharp;
+    k.max_surf_flat = c->max_surf_flat; k.less_flat_filter_size = c->less_flat_filter_size;
+  }
+  return h;
+}
+void lio_pp_destroy(lio_pp *h) { delete h; }
+int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
+  if (!h || (!xyzi && n)) return LIO_ERR_ARG;
+  h->pp.Process(xyzi, n);
+  return LIO_OK;
+}
+static const Cloud *ppCloud(const lio_pp *h, int which) {
+  switch (which) {
+    case LIO_PP_RINGS: return &h->pp.cloud_rings;
+    case LIO_PP_SHARP: return &h->pp.sharp;
+    case LIO_PP_LESS_SHARP: return &h->pp.less_sharp;
+    case LIO_PP_FLAT: return &h->pp.flat;
+    case LIO_PP_LESS_FLAT: return &h->pp.less_flat;
+  }
+  return nullptr;
+}
+size_t lio_pp_count(const lio_pp *h, int which) { const Cloud *c = h ? ppCloud(h, which) : nullptr; return c ? c->size() : 0; }
+int lio_pp_get_cloud(const lio_pp *h, int which, float *out) {
+  const Cloud *c = h ? ppCloud(h, which) : nullptr;
+  if (!c || !out) return LIO_ERR_ARG;
+  if (!c->empty()) std::memcpy(out, c->data(), c->size() * sizeof(P4));
+  return LIO_OK;
+}
+int lio_pp_get_indices(const lio_pp *h, int which, int32_t *ring, int32_t *idx) {
+  if (!h || which < 1 || which > 3 || !ring || !idx) return LIO_ERR_ARG;
+  for (size_t k = 0; k < h->pp.pick_ring[which].size(); ++k) { ring[k] = h->pp.pick_ring[which][k]; idx[k] = h->pp.pick_idx[which][k]; }
+  return LIO_OK;
+}
+int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  for (size_t k = 0; k < h->pp.ring_offsets.size(); ++k) out[k] = h->pp.ring_offsets[k];
+  return LIO_OK;
+}
+int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
+  if (!h) return LIO_ERR_ARG;
+  if (curv) std::memcpy(curv, h->pp.curvature.data(), h->pp.curvature.size() * sizeof(float));
+  if (mask) for (size_t k = 0; k < h->pp.mask.size(); ++k) mask[k] = h->pp.mask[k];
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- stateless blocks
+int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
+  if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
+  Cloud in = toCloud(xyzi, n), o;
+  VoxelGrid(in, leaf, o);
+  if (!o.empty()) std::memcpy(out, o.data(), o.size() * sizeof(P4));
+  *n_out = o.size();
+  return LIO_OK;
+}
+int lio_knn(const float *map, size_t n_map, const float *query, size_t m, int k, float radius_sq, int32_t *idx, float *sqd) {
+  if ((!map && n_map) || (!query && m) || k <= 0 || k > 16 || !idx || !sqd) return LIO_ERR_ARG;
+  Cloud c = toCloud(map, n_map);
+  KdTree t;
+  t.Build(c);
+  for (size_t i = 0; i < m; ++i) {
+    P4 q{query[4 * i], query[4 * i + 1], query[4 * i + 2], 0};
+    int id[16]; float sd[16];
+    int f = t.Search(q, k, id, sd);
+    for (int j = 0; j < k; ++j) {
+      bool ok = j < f && !(radius_sq > 0 && !(sd[j] < radius_sq));
+      idx[i * k + j] = ok ? id[j] : -1;
+      sqd[i * k + j] = ok ? sd[j] : std::numeric_limits<float>::infinity();
+    }
+  }
+  return LIO_OK;
+}
+int lio_calculate_features(const float *map, size_t n_map, const float *stack, size_t m, const lio_transform_f *T, float mm, float mp,
+                           uint8_t *valid, float *coeff, float *score) {
+  if ((!map && n_map) || (!stack && m) || !T || !valid || !coeff || !score) return LIO_ERR_ARG;
+  Cloud c = toCloud(map, n_map), s = toCloud(stack, m);
+  KdTree t;
+  t.Build(c);
+  std::vector<PlaneFeature> feats;
+  std::vector<uint8_t> v;
+  std::vector<std::array<float, 5>> raw;
+  Estimator::CalculateFeatures(t, c, s, toT(*T), mm, mp, false, feats, &v, &raw);
+  for (size_t i = 0; i < m; ++i) { valid[i] = v[i]; for (int k = 0; k < 4; ++k) coeff[4 * i + k] = raw[i][k]; score[i] = raw[i][4]; }
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- pre-integration
+lio_pim *lio_pim_create(const double acc0[3], const double gyr0[3], const double ba[3], const double bg[3], double acc_n, double gyr_n,
+                        double acc_w, double gyr_w, double g_norm) {
+  if (!acc0 || !gyr0 || !ba || !bg) return nullptr;
+  PimConfig c; c.acc_n = acc_n; c.gyr_n = gyr_n; c.acc_w = acc_w; c.gyr_w = gyr_w; c.g_norm = g_norm;
+  return new (std::nothrow) lio_pim(v3(acc0), v3(gyr0), v3(ba), v3(bg), c);
+}
+void lio_pim_destroy(lio_pim *h) { delete h; }
+int lio_pim_push_back(lio_pim *h, double dt, const double acc[3], const double gyr[3]) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->pim.push_back(dt, v3(acc), v3(gyr));
+  return LIO_OK;
+}
+int lio_pim_repropagate(lio_pim *h, const double ba[3], const double bg[3]) {
+  if (!h || !ba || !bg) return LIO_ERR_ARG;
+  h->pim.Repropagate(v3(ba), v3(bg));
+  return LIO_OK;
+}
+int lio_pim_get(const lio_pim *h, double *sum_dt, double *dp, double *dq, double *dv, double *jac, double *cov) {
+  if (!h) return LIO_ERR_ARG;
+  const IntegrationBase &p = h->pim;
+  if (sum_dt) *sum_dt = p.sum_dt_;
+  if (dp) { dp[0] = p.delta_p_.x; dp[1] = p.delta_p_.y; dp[2] = p.delta_p_.z; }
+  if (dq) { dq[0] = p.delta_q_.x; dq[1] = p.delta_q_.y; dq[2] = p.delta_q_.z; dq[3] = p.delta_q_.w; }
+  if (dv) { dv[0] = p.delta_v_.x; dv[1] = p.delta_v_.y; dv[2] = p.delta_v_.z; }
+  if (jac) std::memcpy(jac, p.jacobian_.a.data(), 225 * sizeof(double));
+  if (cov) std::memcpy(cov, p.covariance_.a.data(), 225 * sizeof(double));
+  return LIO_OK;
+}
+int lio_pim_evaluate(const lio_pim *h, const double *pi, const double *sbi, const double *pj, const double *sbj, double *res) {
+  if (!h || !pi || !sbi || !pj || !sbj || !res) return LIO_ERR_ARG;
+  V3d Pi, Pj; Qd Qi, Qj;
+  unpackPose(pi, Pi, Qi); unpackPose(pj, Pj, Qj);
+  h->pim.Evaluate(Pi, Qi, v3(sbi), v3(sbi + 3), v3(sbi + 6), Pj, Qj, v3(sbj), v3(sbj + 3), v3(sbj + 6), res);
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- factors
+int lio_factor_imu(const lio_pim *h, const double *pi, const double *sbi, const double *pj, const double *sbj, double *res, double *j0,
+                   double *j1, double *j2, double *j3) {
+  if (!h || !pi || !sbi || !pj || !sbj || !res) return LIO_ERR_ARG;
+  const double *par[4] = {pi, sbi, pj, sbj};
+  double *jac[4] = {j0, j1, j2, j3};
+  bool any = j0 || j1 || j2 || j3;
+  return ImuFactorEvaluate(h->pim, par, res, any ? jac : nullptr) ? LIO_OK : LIO_ERR_STATE;
+}
+int lio_factor_pivot_point_plane(const double point[3], const double coeff[4], const double *pp, const double *pi, const double *pex,
+                                 double *res, double *j0, double *j1, double *j2) {
+  if (!point || !coeff || !pp || !pi || !pex || !res) return LIO_ERR_ARG;
+  const double *par[3] = {pp, pi, pex};
+  double *jac[3] = {j0, j1, j2};
+  bool any = j0 || j1 || j2;
+  PivotPointPlaneEvaluate(v3(point), coeff, par, res, any ? jac : nullptr);
+  return LIO_OK;
+}
+int lio_factor_prior(const double pos0[3], const double rot0[4], const double *pose, double *res, double *j) {
+  if (!pos0 || !rot0 || !pose || !res) return LIO_ERR_ARG;
+  PriorFactorEvaluate(v3(pos0), Qd(rot0[3], rot0[0], rot0[1], rot0[2]), pose, res, j);
+  return LIO_OK;
+}
+int lio_pose_plus(const double *pose, const double *d, double *out) {
+  if (!pose || !d || !out) return LIO_ERR_ARG;
+  PosePlus(pose, d, out);
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- estimator
+void lio_est_default_config(lio_est_config *c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->window_size = 15; c->opt_window_size = 5; c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f;
+  c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f;
+  c->transform_lb.q[3] = 1.f; c->transform_lb.p[2] = -0.1f;
+  c->opt_extrinsic = 0; c->imu_factor = 1; c->point_distance_factor = 0; c->prior_factor = 0; c->marginalization_factor = 1;
+  c->enable_deskew = 1; c->cutoff_deskew = 0; c->keep_features = 0;
+  c->acc_n = 0.1; c->gyr_n = 0.01; c->acc_w = 0.0002; c->gyr_w = 2.0e-5; c->g_norm = 9.805;
+  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2;
+}
+lio_est *lio_est_create(const lio_est_config *c) {
+  if (!c || c->window_size < 1 || c->opt_window_size < 1 || c->opt_window_size > c->window_size) return nullptr;
+  EstimatorConfig e;
+  e.window_size = c->window_size; e.opt_window_size = c->opt_window_size;
+  e.corner_filter_size = c->corner_filter_size; e.surf_filter_size = c->surf_filter_size;
+  e.min_match_sq_dis = c->min_match_sq_dis; e.min_plane_dis = c->min_plane_dis;
+  e.transform_lb = toT(c->transform_lb);
+  e.opt_extrinsic = c->opt_extrinsic; e.imu_factor = c->imu_factor; e.point_distance_factor = c->point_distance_factor;
+  e.prior_factor = c->prior_factor; e.marginalization_factor = c->marginalization_factor;
+  e.enable_deskew = c->enable_deskew; e.cutoff_deskew = c->cutoff_deskew; e.keep_features = c->keep_features;
+  e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
+  e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
+  return new (std::nothrow) lio_est(e);
+}
+void lio_est_destroy(lio_est *h) { delete h; }
+
+int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double gyr[3], double stamp) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->est.ProcessImu(dt, v3(acc), v3(gyr), stamp);
+  return LIO_OK;
+}
+static void fillReport(const SolveReport &R, lio_solve_report *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->iterations = R.iterations; o->successful_steps = R.successful; o->termination = R.termination;
+  o->n_lidar_residuals = R.n_lidar; o->n_local_map = R.n_local_map; o->laser_odom_iterations = R.laser_odom_iters;
+  o->turn_off = R.turn_off; o->convergence_flag = R.convergence_flag; o->marginalized = R.marginalized;
+  o->cost_pim_before = R.cost_pim; o->cost_ppp_before = R.cost_ppp; o->cost_marg_before = R.cost_marg;
+  o->initial_cost = R.initial_cost; o->final_cost = R.final_cost;
+  for (size_t k = 0; k < R.trace.size() && k < 32; ++k) o->cost_trace[k] = R.trace[k];
+  o->ms_build_map = R.ms_build_map; o->ms_features = R.ms_features; o->ms_prepare = R.ms_prepare; o->ms_opt = R.ms_opt;
+  o->ms_marg = R.ms_marg; o->ms_total = R.ms_total;
+}
+int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp,
+                               lio_solve_report *rep) {
+  if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  SolveReport R;
+  if (!h->est.ProcessLaserOdom(toT(*T), toCloud(surf, ns), toCloud(corner, nc), stamp, &R)) return LIO_ERR_STATE;
+  fillReport(R, rep);
+  return LIO_OK;
+}
+int lio_est_solve_optimization(lio_est *h, lio_solve_report *rep) {
+  if (!h) return LIO_ERR_ARG;
+  SolveReport R;
+  if (!h->est.inited || !h->est.SolveOptimization(&R)) return LIO_ERR_STATE;
+  fillReport(R, rep);
+  return LIO_OK;
+}
+int lio_est_slide_window(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->est.inited) return LIO_ERR_STATE;
+  h->est.SlideWindow();
+  return LIO_OK;
+}
+int lio_est_set_window(lio_est *h, int n, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,
+                       const double g[3]) {
+  if (!h || !Ps || !Rs || !Vs || !Bas || !Bgs || !g) return LIO_ERR_ARG;
+  Estimator &e = h->est;
+  if (n != e.W + 1) return LIO_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    e.Ps[i] = v3(Ps + 3 * i); e.Vs[i] = v3(Vs + 3 * i); e.Bas[i] = v3(Bas + 3 * i); e.Bgs[i] = v3(Bgs + 3 * i);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) e.Rs[i](r, c) = Rs[9 * i + 3 * r + c];
+  }
+  e.g_vec = v3(g);
+  e.inited = true; e.first_imu = true; e.cir_buf_count = e.W;
+  return LIO_OK;
+}
+int lio_est_get_window(const lio_est *h, int n, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, lio_transform_f *Tlb) {
+  if (!h) return LIO_ERR_ARG;
+  const Estimator &e = h->est;
+  if (n != e.W + 1) return LIO_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      if (Ps) Ps[3 * i + k] = e.Ps[i][k];
+      if (Vs) Vs[3 * i + k] = e.Vs[i][k];
+      if (Bas) Bas[3 * i + k] = e.Bas[i][k];
+      if (Bgs) Bgs[3 * i + k] = e.Bgs[i][k];
+    }
+    if (Rs) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rs[9 * i + 3 * r + c] = e.Rs[i](r, c);
+  }
+  if (Tlb) fromT(e.transform_lb, Tlb);
+  return LIO_OK;
+}
+int lio_est_set_surf_stack(lio_est *h, int frame, const float *xyzi, size_t n) {
+  if (!h || frame < 0 || frame > h->est.W || (!xyzi && n)) return LIO_ERR_ARG;
+  h->est.surf_stack[frame] = toCloud(xyzi, n);
+  h->est.size_surf_stack[frame] = n;
+  return LIO_OK;
+}
+size_t lio_est_get_surf_stack(const lio_est *h, int frame, float *out) {
+  if (!h || frame < 0 || frame > h->est.W) return 0;
+  const Cloud &c = h->est.surf_stack[frame];
+  if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
+  return c.size();
+}
+int lio_est_set_preintegration(lio_est *h, int frame, const double acc0[3], const double gyr0[3], const double ba[3], const double bg[3],
+                               const double *dt, const double *acc, const double *gyr, size_t ns) {
+  if (!h || frame < 0 || frame > h->est.W || !acc0 || !gyr0 || !ba || !bg || (ns && (!dt || !acc || !gyr))) return LIO_ERR_ARG;
+  auto p = std::make_shared<IntegrationBase>(v3(acc0), v3(gyr0), v3(ba), v3(bg), h->est.cfg.pim);
+  for (size_t k = 0; k < ns; ++k) p->push_back(dt[k], v3(acc + 3 * k), v3(gyr + 3 * k));
+  h->est.pre_integrations[frame] = p;
+  return LIO_OK;
+}
+int lio_est_begin_frame(lio_est *h, const double acc[3], const double gyr[3]) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->est.BeginFrame(v3(acc), v3(gyr));
+  return LIO_OK;
+}
+int lio_est_build_local_map(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->est.inited) return LIO_ERR_STATE;
+  h->est.BuildLocalMap(nullptr);
+  return LIO_OK;
+}
+size_t lio_est_get_local_map(const lio_est *h, float *out) {
+  if (!h) return 0;
+  const Cloud &c = h->est.local_map_filtered;
+  if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
+  return c.size();
+}
+size_t lio_est_get_features(const lio_est *h, int frame, double *pt, double *co, double *sc) {
+  if (!h || frame < 0 || frame >= int(h->est.feature_frames.size())) return 0;
+  const auto &f = h->est.feature_frames[frame];
+  for (size_t k = 0; k < f.size(); ++k) {
+    if (pt) { pt[3 * k] = f[k].point.x; pt[3 * k + 1] = f[k].point.y; pt[3 * k + 2] = f[k].point.z; }
+    if (co) for (int j = 0; j < 4; ++j) co[4 * k + j] = f[k].coeffs[j];
+    if (sc) sc[k] = f[k].score;
+  }
+  return f.size();
+}
+int lio_est_get_laser_odom_transform(const lio_est *h, lio_transform_f *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  fromT(h->est.laser_odom_transform, out);
+  return LIO_OK;
+}
+int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, int *x0_len) {
+  if (!h) return LIO_ERR_ARG;
+  const auto &pr = h->est.last_marg;
+  if (!pr) return 0;
+  int n = pr->n;
+  if (JtJ) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += pr->lin_jac(k, i) * pr->lin_jac(k, j); JtJ[i * n + j] = s; }
+  if (Jtr) for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < n; ++k) s += pr->lin_jac(k, i) * pr->lin_res[k]; Jtr[i] = s; }
+  int len = 0;
+  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+  if (x0_len) *x0_len = len;
+  return n;
+}
+int lio_est_snapshot(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  h->snap.reset(new Estimator(h->est));
+  // deep-copy the mutable pre-integration in flight (the window ones are immutable once pushed)
+  if (h->est.tmp_pre_integration) h->snap->tmp_pre_integration = std::make_shared<IntegrationBase>(*h->est.tmp_pre_integration);
+  return LIO_OK;
+}
+int lio_est_restore(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->snap) return LIO_ERR_STATE;
+  h->est = *h->snap;
+  if (h->snap->tmp_pre_integration) h->est.tmp_pre_integration = std::make_shared<IntegrationBase>(*h->snap->tmp_pre_integration);
+  return LIO_OK;
+}
+
+}  // extern "C"

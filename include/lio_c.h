@@ -189,6 +189,11 @@ int lio_est_process_imu(lio_est *, double dt, const double acc[3], const double 
 int lio_est_process_laser_odom(lio_est *, const lio_transform_f *transform_in, const float *surf_xyzi,
                                size_t n_surf, const float *corner_xyzi, size_t n_corner, double stamp,
                                lio_solve_report *report_or_null);
+/* First half of ProcessLaserOdom only (Estimator.cc:441-488,620-693): push the pre-integration, deskew,
+ * VoxelGrid and push the clouds — everything up to, not including, SolveOptimization.
+ * lio_est_process_laser_odom == lio_est_push_frame + lio_est_solve_optimization + lio_est_slide_window. */
+int lio_est_push_frame(lio_est *, const lio_transform_f *transform_in, const float *surf_xyzi, size_t n_surf,
+                       const float *corner_xyzi, size_t n_corner, double stamp);
 /* Estimator::SolveOptimization (Estimator.cc:1648-2438) */
 int lio_est_solve_optimization(lio_est *, lio_solve_report *report_or_null);
 /* Estimator::SlideWindow (Estimator.cc:2570-2666) */
@@ -228,6 +233,14 @@ int lio_est_get_prior(const lio_est *, double *JtJ_or_null, double *Jtr_or_null,
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);
+
+/* Per-kernel timing with HIP events on the estimator's own stream (bench.py's roofline block).
+ * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
+ * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat".
+ * get returns the number of launches accumulated since timing was enabled (0 for an unknown name or
+ * for the oracle), total_ms their summed duration, algorithmic_bytes the summed SURVEY.md §8d bytes. */
+int lio_est_enable_kernel_timing(lio_est *, int on);
+int lio_est_get_kernel_timing(lio_est *, const char *name, double *total_ms, double *algorithmic_bytes);
 
 #ifdef __cplusplus
 }

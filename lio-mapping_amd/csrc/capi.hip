@@ -1,0 +1,404 @@
+// capi.hip — include/lio_c.h implemented by the product (liblio_hip.so).  Every entry point that touches
+// point data runs on the GPU; a missing device or a HIP failure is reported as LIO_ERR_DEVICE — there is
+// no CPU fallback.  Pure-host entry points (pre-integration, single-factor evaluation) are the host
+// half of the estimator and also back the `-m "not gpu"` ABI tests.
+#include <cstring>
+#include <new>
+
+#include "../../include/lio_c.h"
+#include "estimator.h"
+#include "pointproc.h"
+
+using namespace lio;
+
+struct lio_pim { std::shared_ptr<Preintegration> p; };
+struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; };
+struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
+
+static V3d v3(const double *p) { return V3d(p[0], p[1], p[2]); }
+static Rigidf toT(const lio_transform_f &t) { return Rigidf(Quat<float>(t.q[3], t.q[0], t.q[1], t.q[2]), Vec3<float>(t.p[0], t.p[1], t.p[2])); }
+static void fromT(const Rigidf &T, lio_transform_f *o) {
+  o->q[0] = T.rot.x; o->q[1] = T.rot.y; o->q[2] = T.rot.z; o->q[3] = T.rot.w; o->p[0] = T.pos.x; o->p[1] = T.pos.y; o->p[2] = T.pos.z;
+}
+
+static thread_local char g_last_error[512];
+template <typename F> static int guarded(F &&f) {
+  try {
+    return f();
+  } catch (const DeviceError &e) {
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s", e.what());
+    std::fprintf(stderr, "[lio_hip] %s\n", e.what());
+    return LIO_ERR_DEVICE;
+  } catch (const std::exception &e) {
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s", e.what());
+    std::fprintf(stderr, "[lio_hip] %s\n", e.what());
+    return LIO_ERR_STATE;
+  }
+}
+
+extern "C" {
+
+const char *lio_backend(void) { return "hip-gfx950"; }
+
+// ---------------------------------------------------------------- PointProcessor
+void lio_pp_default_config(lio_pp_config *c) {
+  if (!c) return;
+  c->scan_period = 0.1; c->num_scan_subregions = 8; c->num_curvature_regions = 5; c->surf_curv_th = 0.1f;
+  c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
+}
+lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
+  if (rings <= 0 || rings > LIO_PP_MAX_RINGS || !(up > lo)) return nullptr;
+  lio_pp_config cfg;
+  if (c) cfg = *c; else lio_pp_default_config(&cfg);
+  if (cfg.num_scan_subregions < 1 || cfg.num_scan_subregions > 16 || cfg.num_curvature_regions < 1 || cfg.num_curvature_regions > 8) return nullptr;
+  lio_pp *h = new (std::nothrow) lio_pp;
+  if (!h) return nullptr;
+  int rc = guarded([&] { h->pp.reset(new PointProcessorDev(lo, up, rings, cfg)); return LIO_OK; });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  return h;
+}
+void lio_pp_destroy(lio_pp *h) { delete h; }
+int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
+  if (!h || (!xyzi && n)) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->Process(xyzi, n); return LIO_OK; });
+}
+size_t lio_pp_count(const lio_pp *h, int which) { return (h && which >= 0 && which <= 4) ? h->pp->Count(which) : 0; }
+int lio_pp_get_cloud(const lio_pp *h, int which, float *out) {
+  if (!h || which < 0 || which > 4 || !out) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->GetCloud(which, out); return LIO_OK; });
+}
+int lio_pp_get_indices(const lio_pp *h, int which, int32_t *ring, int32_t *idx) {
+  if (!h || which < 1 || which > 3 || !ring || !idx) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->GetIndices(which, ring, idx); return LIO_OK; });
+}
+int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->GetRingOffsets(out); return LIO_OK; });
+}
+int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->GetCurvature(curv, mask); return LIO_OK; });
+}
+
+// ---------------------------------------------------------------- stateless blocks
+struct Scratch {
+  hipStream_t s = nullptr;
+  DBuf<float4> a, b, c;
+  VoxelGridDev vox;
+  KnnGrid grid;
+  DBuf<uint8_t> valid;
+  DBuf<float4> coef;
+  DBuf<float> score, tf;
+  DBuf<int32_t> idx;
+  DBuf<float> sqd;
+  DBuf<float> bounds;
+};
+static Scratch &scratch() {
+  static thread_local Scratch sc;
+  if (!sc.s) {
+    int nd = 0;
+    LIO_HIP(hipGetDeviceCount(&nd));
+    if (nd <= 0) throw DeviceError("no HIP device: the product has no CPU path");
+    LIO_HIP(hipStreamCreate(&sc.s));
+  }
+  return sc;
+}
+static void host_bounds(const float *xyzi, size_t n, float mn[3], float mx[3]) {
+  for (int d = 0; d < 3; ++d) { mn[d] = 3.4e38f; mx[d] = -3.4e38f; }
+  for (size_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) { float v = xyzi[4 * i + d]; if (std::isfinite(v)) { mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); } }
+}
+
+int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
+  if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
+  return guarded([&] {
+    Scratch &sc = scratch();
+    sc.a.reserve(std::max<size_t>(n, 1));
+    if (n) LIO_HIP(hipMemcpyAsync(sc.a.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, sc.s));
+    size_t m = sc.vox.run(sc.a.p, n, leaf, sc.b, sc.s);
+    if (m) LIO_HIP(hipMemcpyAsync(out, sc.b.p, m * sizeof(float4), hipMemcpyDeviceToHost, sc.s));
+    LIO_HIP(hipStreamSynchronize(sc.s));
+    *n_out = m;
+    return LIO_OK;
+  });
+}
+
+int lio_knn(const float *map, size_t n_map, const float *query, size_t m, int k, float radius_sq, int32_t *idx, float *sqd) {
+  if ((!map && n_map) || (!query && m) || !(k == 1 || k == 5) || !idx || !sqd) return LIO_ERR_ARG;
+  if (!(radius_sq > 0)) return LIO_ERR_ARG;  // the GPU search is radius-bounded by construction
+  return guarded([&] {
+    Scratch &sc = scratch();
+    sc.a.reserve(std::max<size_t>(n_map, 1)); sc.b.reserve(std::max<size_t>(m, 1));
+    sc.idx.reserve(std::max<size_t>(m * k, 1)); sc.sqd.reserve(std::max<size_t>(m * k, 1));
+    if (n_map) LIO_HIP(hipMemcpyAsync(sc.a.p, map, n_map * sizeof(float4), hipMemcpyHostToDevice, sc.s));
+    if (m) LIO_HIP(hipMemcpyAsync(sc.b.p, query, m * sizeof(float4), hipMemcpyHostToDevice, sc.s));
+    float mn[3], mx[3];
+    host_bounds(map, n_map, mn, mx);
+    if (n_map == 0) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
+    sc.grid.build(sc.a.p, n_map, mn, mx, std::sqrt(radius_sq) * 1.0001f + 1e-6f, sc.s);
+    launch_knn(sc.b.p, int(m), k, radius_sq, sc.grid.sorted(), sc.grid.cells(), sc.grid.desc(), sc.idx.p, sc.sqd.p, sc.s);
+    if (m) {
+      LIO_HIP(hipMemcpyAsync(idx, sc.idx.p, m * k * sizeof(int32_t), hipMemcpyDeviceToHost, sc.s));
+      LIO_HIP(hipMemcpyAsync(sqd, sc.sqd.p, m * k * sizeof(float), hipMemcpyDeviceToHost, sc.s));
+    }
+    LIO_HIP(hipStreamSynchronize(sc.s));
+    return LIO_OK;
+  });
+}
+
+int lio_calculate_features(const float *map, size_t n_map, const float *stack, size_t m, const lio_transform_f *T, float mm, float mp,
+                           uint8_t *valid, float *coeff, float *score) {
+  if ((!map && n_map) || (!stack && m) || !T || !valid || !coeff || !score || !(mm > 0)) return LIO_ERR_ARG;
+  return guarded([&] {
+    Scratch &sc = scratch();
+    sc.a.reserve(std::max<size_t>(n_map, 1)); sc.b.reserve(std::max<size_t>(m, 1));
+    sc.valid.reserve(std::max<size_t>(m, 1)); sc.coef.reserve(std::max<size_t>(m, 1)); sc.score.reserve(std::max<size_t>(m, 1)); sc.tf.reserve(8);
+    if (n_map) LIO_HIP(hipMemcpyAsync(sc.a.p, map, n_map * sizeof(float4), hipMemcpyHostToDevice, sc.s));
+    if (m) LIO_HIP(hipMemcpyAsync(sc.b.p, stack, m * sizeof(float4), hipMemcpyHostToDevice, sc.s));
+    float tf[8] = {T->q[0], T->q[1], T->q[2], T->q[3], T->p[0], T->p[1], T->p[2], 0.f};
+    LIO_HIP(hipMemcpyAsync(sc.tf.p, tf, sizeof(tf), hipMemcpyHostToDevice, sc.s));
+    float mn[3], mx[3];
+    host_bounds(map, n_map, mn, mx);
+    if (n_map == 0) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
+    sc.grid.build(sc.a.p, n_map, mn, mx, std::sqrt(mm) * 1.0001f + 1e-6f, sc.s);
+    FeatArgs fa{};
+    fa.nframes = 1; fa.max_M = int(m); fa.min_match_sq_dis = mm; fa.min_plane_dis = mp;
+    fa.fr[0].stack = sc.b.p; fa.fr[0].M = int(m); fa.fr[0].slot_off = 0; fa.fr[0].tf_index = 0;
+    launch_features(fa, sc.tf.p, sc.grid.sorted(), sc.grid.cells(), sc.grid.desc(), sc.valid.p, sc.coef.p, sc.score.p, nullptr, sc.s);
+    if (m) {
+      LIO_HIP(hipMemcpyAsync(valid, sc.valid.p, m, hipMemcpyDeviceToHost, sc.s));
+      LIO_HIP(hipMemcpyAsync(coeff, sc.coef.p, m * sizeof(float4), hipMemcpyDeviceToHost, sc.s));
+      LIO_HIP(hipMemcpyAsync(score, sc.score.p, m * sizeof(float), hipMemcpyDeviceToHost, sc.s));
+    }
+    LIO_HIP(hipStreamSynchronize(sc.s));
+    return LIO_OK;
+  });
+}
+
+// ---------------------------------------------------------------- pre-integration (host)
+lio_pim *lio_pim_create(const double acc0[3], const double gyr0[3], const double ba[3], const double bg[3], double acc_n, double gyr_n,
+                        double acc_w, double gyr_w, double g_norm) {
+  if (!acc0 || !gyr0 || !ba || !bg) return nullptr;
+  PimNoise n; n.acc_n = acc_n; n.gyr_n = gyr_n; n.acc_w = acc_w; n.gyr_w = gyr_w; n.g_norm = g_norm;
+  lio_pim *h = new (std::nothrow) lio_pim;
+  if (h) h->p = std::make_shared<Preintegration>(v3(acc0), v3(gyr0), v3(ba), v3(bg), n);
+  return h;
+}
+void lio_pim_destroy(lio_pim *h) { delete h; }
+int lio_pim_push_back(lio_pim *h, double dt, const double acc[3], const double gyr[3]) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->p->push_back(dt, v3(acc), v3(gyr));
+  return LIO_OK;
+}
+int lio_pim_repropagate(lio_pim *h, const double ba[3], const double bg[3]) {
+  if (!h || !ba || !bg) return LIO_ERR_ARG;
+  h->p->repropagate(v3(ba), v3(bg));
+  return LIO_OK;
+}
+int lio_pim_get(const lio_pim *h, double *sum_dt, double *dp, double *dq, double *dv, double *jac, double *cov) {
+  if (!h) return LIO_ERR_ARG;
+  const Preintegration &p = *h->p;
+  if (sum_dt) *sum_dt = p.sum_dt;
+  if (dp) { dp[0] = p.dp.x; dp[1] = p.dp.y; dp[2] = p.dp.z; }
+  if (dq) { dq[0] = p.dq.x; dq[1] = p.dq.y; dq[2] = p.dq.z; dq[3] = p.dq.w; }
+  if (dv) { dv[0] = p.dv.x; dv[1] = p.dv.y; dv[2] = p.dv.z; }
+  if (jac) std::memcpy(jac, p.jac, sizeof(p.jac));
+  if (cov) std::memcpy(cov, p.cov, sizeof(p.cov));
+  return LIO_OK;
+}
+int lio_pim_evaluate(const lio_pim *h, const double *pi, const double *sbi, const double *pj, const double *sbj, double *res) {
+  if (!h || !pi || !sbi || !pj || !sbj || !res) return LIO_ERR_ARG;
+  V3d Pi, Pj; Qd Qi, Qj;
+  unpack_pose(pi, Pi, Qi); unpack_pose(pj, Pj, Qj);
+  h->p->evaluate(Pi, Qi, v3(sbi), v3(sbi + 3), v3(sbi + 6), Pj, Qj, v3(sbj), v3(sbj + 3), v3(sbj + 6), res);
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- factors (host)
+int lio_factor_imu(const lio_pim *h, const double *pi, const double *sbi, const double *pj, const double *sbj, double *res, double *j0,
+                   double *j1, double *j2, double *j3) {
+  if (!h || !pi || !sbi || !pj || !sbj || !res) return LIO_ERR_ARG;
+  return imu_factor(*h->p, pi, sbi, pj, sbj, res, j0, j1, j2, j3) ? LIO_OK : LIO_ERR_STATE;
+}
+int lio_factor_pivot_point_plane(const double point[3], const double coeff[4], const double *pp, const double *pi, const double *pex,
+                                 double *res, double *j0, double *j1, double *j2) {
+  if (!point || !coeff || !pp || !pi || !pex || !res) return LIO_ERR_ARG;
+  ppp_factor(v3(point), coeff, pp, pi, pex, res, j0, j1, j2);
+  return LIO_OK;
+}
+int lio_factor_prior(const double pos0[3], const double rot0[4], const double *pose, double *res, double *j) {
+  if (!pos0 || !rot0 || !pose || !res) return LIO_ERR_ARG;
+  prior_factor(v3(pos0), Qd(rot0[3], rot0[0], rot0[1], rot0[2]), pose, res, j);
+  return LIO_OK;
+}
+int lio_pose_plus(const double *pose, const double *d, double *out) {
+  if (!pose || !d || !out) return LIO_ERR_ARG;
+  pose_plus(pose, d, out);
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- estimator
+void lio_est_default_config(lio_est_config *c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->window_size = 15; c->opt_window_size = 5; c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f;
+  c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f;
+  c->transform_lb.q[3] = 1.f; c->transform_lb.p[2] = -0.1f;
+  c->opt_extrinsic = 0; c->imu_factor = 1; c->point_distance_factor = 0; c->prior_factor = 0; c->marginalization_factor = 1;
+  c->enable_deskew = 1; c->cutoff_deskew = 0; c->keep_features = 0;
+  c->acc_n = 0.1; c->gyr_n = 0.01; c->acc_w = 0.0002; c->gyr_w = 2.0e-5; c->g_norm = 9.805;
+  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2;
+}
+lio_est *lio_est_create(const lio_est_config *c) {
+  if (!c || c->window_size < 1 || c->opt_window_size < 1 || c->opt_window_size > c->window_size || c->window_size + 1 > LIO_MAX_FRAMES) return nullptr;
+  lio_est *h = new (std::nothrow) lio_est;
+  if (!h) return nullptr;
+  EstConfig &e = h->cfg;
+  e.W = c->window_size; e.Wo = c->opt_window_size;
+  e.corner_filter_size = c->corner_filter_size; e.surf_filter_size = c->surf_filter_size;
+  e.min_match_sq_dis = c->min_match_sq_dis; e.min_plane_dis = c->min_plane_dis;
+  e.transform_lb = toT(c->transform_lb);
+  e.opt_extrinsic = c->opt_extrinsic; e.imu_factor = c->imu_factor; e.point_distance_factor = c->point_distance_factor;
+  e.prior_factor = c->prior_factor; e.marginalization_factor = c->marginalization_factor;
+  e.enable_deskew = c->enable_deskew; e.cutoff_deskew = c->cutoff_deskew; e.keep_features = c->keep_features;
+  e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
+  e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
+  int rc = guarded([&] { h->e.reset(new Estimator(e)); return LIO_OK; });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  return h;
+}
+void lio_est_destroy(lio_est *h) { delete h; }
+
+int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double gyr[3], double stamp) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->e->ProcessImu(dt, v3(acc), v3(gyr), stamp);
+  return LIO_OK;
+}
+int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp,
+                               lio_solve_report *rep) {
+  if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  return guarded([&] { return h->e->ProcessLaserOdom(toT(*T), surf, ns, corner, nc, stamp, rep) ? LIO_OK : LIO_ERR_STATE; });
+}
+int lio_est_push_frame(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp) {
+  if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  return guarded([&] { return h->e->PushFrame(toT(*T), surf, ns, corner, nc, stamp) ? LIO_OK : LIO_ERR_STATE; });
+}
+int lio_est_solve_optimization(lio_est *h, lio_solve_report *rep) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->e->inited_) return LIO_ERR_STATE;
+  return guarded([&] { return h->e->SolveOptimization(rep) ? LIO_OK : LIO_ERR_STATE; });
+}
+int lio_est_slide_window(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->e->inited_) return LIO_ERR_STATE;
+  return guarded([&] { h->e->SlideWindow(); return LIO_OK; });
+}
+int lio_est_set_window(lio_est *h, int n, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,
+                       const double g[3]) {
+  if (!h || !Ps || !Rs || !Vs || !Bas || !Bgs || !g || n != h->e->W_ + 1) return LIO_ERR_ARG;
+  h->e->SetWindow(Ps, Rs, Vs, Bas, Bgs, g);
+  return LIO_OK;
+}
+int lio_est_get_window(const lio_est *h, int n, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, lio_transform_f *Tlb) {
+  if (!h || n != h->e->W_ + 1) return LIO_ERR_ARG;
+  const Estimator &e = *h->e;
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      if (Ps) Ps[3 * i + k] = e.Ps_[i][k];
+      if (Vs) Vs[3 * i + k] = e.Vs_[i][k];
+      if (Bas) Bas[3 * i + k] = e.Bas_[i][k];
+      if (Bgs) Bgs[3 * i + k] = e.Bgs_[i][k];
+    }
+    if (Rs) for (int k = 0; k < 9; ++k) Rs[9 * i + k] = e.Rs_[i].m[k];
+  }
+  if (Tlb) fromT(e.transform_lb_, Tlb);
+  return LIO_OK;
+}
+int lio_est_set_surf_stack(lio_est *h, int frame, const float *xyzi, size_t n) {
+  if (!h || frame < 0 || frame > h->e->W_ || (!xyzi && n)) return LIO_ERR_ARG;
+  return guarded([&] { h->e->SetSurfStack(frame, xyzi, n); return LIO_OK; });
+}
+size_t lio_est_get_surf_stack(const lio_est *h, int frame, float *out) {
+  if (!h || frame < 0 || frame > h->e->W_) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->e->GetSurfStack(frame, out); return LIO_OK; });
+  return n;
+}
+int lio_est_set_preintegration(lio_est *h, int frame, const double acc0[3], const double gyr0[3], const double ba[3], const double bg[3],
+                               const double *dt, const double *acc, const double *gyr, size_t ns) {
+  if (!h || frame < 0 || frame > h->e->W_ || !acc0 || !gyr0 || !ba || !bg || (ns && (!dt || !acc || !gyr))) return LIO_ERR_ARG;
+  auto p = std::make_shared<Preintegration>(v3(acc0), v3(gyr0), v3(ba), v3(bg), h->cfg.pim);
+  for (size_t k = 0; k < ns; ++k) p->push_back(dt[k], v3(acc + 3 * k), v3(gyr + 3 * k));
+  h->e->SetPreintegration(frame, p);
+  return LIO_OK;
+}
+int lio_est_begin_frame(lio_est *h, const double acc[3], const double gyr[3]) {
+  if (!h || !acc || !gyr) return LIO_ERR_ARG;
+  h->e->BeginFrame(v3(acc), v3(gyr));
+  return LIO_OK;
+}
+int lio_est_build_local_map(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  if (!h->e->inited_) return LIO_ERR_STATE;
+  return guarded([&] { h->e->BuildLocalMap(nullptr); return LIO_OK; });
+}
+size_t lio_est_get_local_map(const lio_est *h, float *out) {
+  if (!h) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->e->GetLocalMap(out); return LIO_OK; });
+  return n;
+}
+size_t lio_est_get_features(const lio_est *h, int frame, double *pt, double *co, double *sc) {
+  if (!h) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->e->GetFeatures(frame, pt, co, sc); return LIO_OK; });
+  return n;
+}
+int lio_est_get_laser_odom_transform(const lio_est *h, lio_transform_f *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  fromT(h->e->laser_odom_transform_, out);
+  return LIO_OK;
+}
+int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, int *x0_len) {
+  if (!h) return LIO_ERR_ARG;
+  const auto &pr = h->e->last_marg_;
+  if (!pr) return 0;
+  const int n = pr->n;
+  if (JtJ) std::memcpy(JtJ, pr->JtJ.a.data(), sizeof(double) * size_t(n) * n);
+  if (Jtr) std::memcpy(Jtr, pr->Jtr0.data(), sizeof(double) * n);
+  int len = 0;
+  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+  if (x0_len) *x0_len = len;
+  return n;
+}
+int lio_est_snapshot(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { h->e->Snapshot(); return LIO_OK; });
+}
+int lio_est_restore(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { return h->e->Restore() ? LIO_OK : LIO_ERR_STATE; });
+}
+
+int lio_est_enable_kernel_timing(lio_est *h, int on) {
+  if (!h) return LIO_ERR_ARG;
+  h->e->timers_.on = on != 0;
+  h->e->timers_.reset();
+  return LIO_OK;
+}
+int lio_est_get_kernel_timing(lio_est *h, const char *name, double *total_ms, double *bytes) {
+  if (total_ms) *total_ms = 0;
+  if (bytes) *bytes = 0;
+  if (!h || !name) return 0;
+  static const char *names[KT_COUNT] = {"features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"};
+  for (int k = 0; k < KT_COUNT; ++k)
+    if (std::strcmp(name, names[k]) == 0) {
+      const KernelTimers::Acc &a = h->e->timers_.acc[k];
+      if (total_ms) *total_ms = a.ms;
+      if (bytes) *bytes = a.bytes;
+      return a.n;
+    }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// cloud_kernels.h — device-side point-cloud stages of the estimator (host-callable launchers).
+//   rigid transform / concat    : pcl::transformPointCloud call sites Estimator.cc:1425,1498,2602
+//   VoxelGridDev                : pcl::VoxelGrid<PointXYZI> call sites Estimator.cc:678-687,1518-1519
+//   KnnGrid + feature kernels   : pcl::KdTreeFLANN + Estimator::CalculateFeatures (Estimator.cc:970-1097)
+//   laser-odom rows/update      : Estimator::CalculateLaserOdom (Estimator.cc:1242-1359)
+//   deskew                      : TransformToEnd (Estimator.cc:62-103)
+#pragma once
+#include <cstdint>
+
+#include "dev.h"
+
+namespace lio {
+
+struct VoxParams {
+  float mn[3], mx[3];
+  int minb[3], divb[3];
+  int overflow;  // PCL's "leaf size too small" guard: output = input
+  int n_valid;
+};
+
+struct Affine3f { float m[12]; };  // row-major 3x4: [R | t]
+
+#define LIO_MAX_FRAMES 32
+
+struct ConcatSeg { const float4 *src; int n; int dst_off; int set_intensity; float intensity; Affine3f tf; int identity; };
+struct ConcatArgs { ConcatSeg seg[LIO_MAX_FRAMES]; int nseg; int total; };
+// dst[seg.dst_off + k] = tf * src[k] (or src[k] when identity); intensity optionally overwritten
+void launch_transform_concat(const ConcatArgs &a, float4 *dst, hipStream_t s);
+
+// TransformToEnd (Estimator.cc:62-103) in place; tes = q(xyzw), p
+void launch_deskew_to_end(float4 *pts, int n, const float q[4], const float p[3], float time_factor, hipStream_t s);
+
+class VoxelGridDev {
+ public:
+  // Filters `in` (device, n points) with cubic leaf; result in `out`; returns the output count (host sync).
+  // host_params (optional) receives the bounds used.
+  size_t run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params = nullptr);
+
+ private:
+  DBuf<float> partial_;
+  DBuf<VoxParams> params_;
+  DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
+  DBuf<int> flags_, pos_, count_;
+  DBuf<char> tmp_;
+};
+
+struct GridDesc {
+  int origin[3];   // cell coordinate of cell (0,0,0)
+  int dims[3];
+  float inv_cell;
+  int n_points;
+};
+
+class KnnGrid {
+ public:
+  // Uniform grid over `pts` (device, n points).  bounds = min/max of the cloud (host values).
+  void build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s);
+  const float4 *sorted() const { return sorted_.p; }   // xyz + original index in .w (int bits)
+  const int2 *cells() const { return cells_.p; }        // [start,end) per cell
+  const GridDesc &desc() const { return desc_; }
+
+ private:
+  GridDesc desc_{};
+  DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
+  DBuf<float4> sorted_;
+  DBuf<int2> cells_;
+  DBuf<char> tmp_;
+};
+
+struct FeatFrame { const float4 *stack; int M; int slot_off; int tf_index; };
+struct FeatArgs {
+  FeatFrame fr[LIO_MAX_FRAMES];
+  int nframes;
+  int max_M;
+  float min_match_sq_dis, min_plane_dis;
+};
+// transforms: device array of 8 floats per entry (qx,qy,qz,qw,px,py,pz,pad).  skip_flag: optional device int;
+// when *skip_flag != 0 the launch is a no-op (converged laser-odom loop).
+void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s);
+
+// stateless K-NN (lio_knn entry point): idx/sqd are m*k
+void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+                int32_t *idx, float *sqd, hipStream_t s);
+
+struct OdomState {
+  float T[8];        // qx,qy,qz,qw,px,py,pz,pad : local_transform of the newest frame
+  int converged;
+  int iters;
+  int degenerate;
+  int kz;            // number of leading components masked (A.6)
+};
+// rows of mat_A / mat_B (Estimator.cc:1272-1301) over slots [0,nslots) of the newest frame, reduced to
+// per-block partials (28 doubles each).  Point of slot s = stack[s % M].
+void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
+                      double *partials, int nblocks, hipStream_t s);
+// reduce + 6x6 solve + degeneracy mask + transform update + convergence test (Estimator.cc:1303-1357)
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s);
+int odom_rows_blocks(int nslots);
+
+}  // namespace lio

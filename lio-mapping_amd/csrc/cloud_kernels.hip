@@ -1,0 +1,523 @@
+// cloud_kernels.hip — gfx950 kernels for the point-cloud stages (see cloud_kernels.h for the reference
+// call sites).  fp32 arithmetic mirrors the CPU operation order (no FMA contraction: -ffp-contract=off)
+// so neighbour sets, validity flags and coefficients are reproducible bit for bit.
+//
+// Layout: clouds are float4 AoS (x,y,z,intensity) — 16 B per lane per load, the coalescing sweet spot
+// (cdna_hip_programming.md §2); the K-NN grid stores points cell-sorted so a 3-cell x-run is one
+// contiguous stream per lane, served out of L2 (maps are a few MB).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <climits>
+
+#include "cloud_kernels.h"
+#include "hmath.h"
+
+namespace lio {
+
+// ------------------------------------------------------------------------------------------------
+// rigid transform + concat
+// ------------------------------------------------------------------------------------------------
+__global__ void k_transform_concat(ConcatArgs a, float4 *__restrict__ dst) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= a.total) return;
+  int sidx = 0;
+  for (int k = 1; k < a.nseg; ++k)
+    if (gid >= a.seg[k].dst_off) sidx = k;
+  const ConcatSeg &sg = a.seg[sidx];
+  int local = gid - sg.dst_off;
+  float4 p = sg.src[local];
+  float4 o;
+  if (sg.identity) {
+    o = p;
+  } else {
+    const float *m = sg.tf.m;
+    // pcl::transformPointCloud: m00*x + m01*y + m02*z + m03
+    o.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    o.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    o.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    o.w = p.w;
+  }
+  if (sg.set_intensity) o.w = sg.intensity;
+  dst[gid] = o;
+}
+
+void launch_transform_concat(const ConcatArgs &a, float4 *dst, hipStream_t s) {
+  if (a.total <= 0) return;
+  hipLaunchKernelGGL(k_transform_concat, dim3(cdiv(a.total, 256)), dim3(256), 0, s, a, dst);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// deskew (TransformToEnd)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_deskew_to_end(float4 *pts, int n, Quat<float> qe, Vec3<float> te, float time_factor) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  float s = time_factor * (p.w - int(p.w));
+  p.x -= s * te.x; p.y -= s * te.y; p.z -= s * te.z;
+  p.w -= int(p.w);
+  Quat<float> qid;
+  Quat<float> qs = slerp(qid, s, qe, FLT_EPSILON);
+  Vec3<float> v = rotate(normalized(conj(qs)), Vec3<float>(p.x, p.y, p.z));
+  v = rotate(qe, v);
+  p.x = v.x + te.x; p.y = v.y + te.y; p.z = v.z + te.z;
+  pts[i] = p;
+}
+void launch_deskew_to_end(float4 *pts, int n, const float q[4], const float p[3], float time_factor, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_deskew_to_end, dim3(cdiv(n, 256)), dim3(256), 0, s, pts, n, Quat<float>(q[3], q[0], q[1], q[2]),
+                     Vec3<float>(p[0], p[1], p[2]), time_factor);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel grid
+// ------------------------------------------------------------------------------------------------
+__device__ inline bool finite3(const float4 &p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+
+__global__ void k_bounds_partial(const float4 *__restrict__ pts, int n, float *__restrict__ partial) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    if (!finite3(p)) continue;
+    ++cnt;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ float sm[7][256];
+  int t = threadIdx.x;
+  for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+  sm[6][t] = float(cnt);
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) {
+      for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+      sm[6][t] += sm[6][t + st];
+    }
+    __syncthreads();
+  }
+  if (t < 7) partial[blockIdx.x * 8 + t] = sm[t][0];
+}
+
+__global__ void k_bounds_final(const float *__restrict__ partial, int nb, float inv_leaf, VoxParams *out) {
+  if (threadIdx.x != 0) return;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float cnt = 0;
+  for (int b = 0; b < nb; ++b) {
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], partial[b * 8 + d]); mx[d] = fmaxf(mx[d], partial[b * 8 + 3 + d]); }
+    cnt += partial[b * 8 + 6];
+  }
+  VoxParams v;
+  long long dd[3];
+  for (int d = 0; d < 3; ++d) {
+    v.mn[d] = mn[d]; v.mx[d] = mx[d];
+    dd[d] = (long long)((mx[d] - mn[d]) * inv_leaf) + 1;
+    v.minb[d] = int(floorf(mn[d] * inv_leaf));
+    int maxb = int(floorf(mx[d] * inv_leaf));
+    v.divb[d] = maxb - v.minb[d] + 1;
+  }
+  v.overflow = (cnt > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+  v.n_valid = int(cnt);
+  *out = v;
+}
+
+__global__ void k_vox_keys(const float4 *__restrict__ pts, int n, float inv_leaf, const VoxParams *__restrict__ vp,
+                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  uint32_t key = 0xFFFFFFFFu;
+  if (finite3(p)) {
+    int i0 = int(floorf(p.x * inv_leaf) - float(vp->minb[0]));
+    int i1 = int(floorf(p.y * inv_leaf) - float(vp->minb[1]));
+    int i2 = int(floorf(p.z * inv_leaf) - float(vp->minb[2]));
+    key = uint32_t(i0 + i1 * vp->divb[0] + i2 * vp->divb[0] * vp->divb[1]);
+  }
+  keys[i] = key;
+  vals[i] = uint32_t(i);
+}
+
+__global__ void k_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = keys[i];
+  flags[i] = (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+__global__ void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                            const int *__restrict__ flags, const int *__restrict__ pos, int n, float4 *__restrict__ out,
+                            int *__restrict__ count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) *count = pos[i] + flags[i];
+  if (!flags[i]) return;
+  uint32_t k = keys[i];
+  float ax = 0, ay = 0, az = 0, ai = 0;
+  int e = i;
+  // stable sort => ascending original index inside the run: the within-voxel order the oracle fixes
+  while (e < n && keys[e] == k) {
+    float4 p = pts[vals[e]];
+    ax += p.x; ay += p.y; az += p.z; ai += p.w;
+    ++e;
+  }
+  float cnt = float(e - i);
+  out[pos[i]] = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
+}
+
+size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params) {
+  if (n == 0) {
+    if (host_params) std::memset(host_params, 0, sizeof(*host_params));
+    return 0;
+  }
+  const int ni = int(n);
+  const float inv_leaf = 1.0f / leaf;
+  const int nb = std::min(cdiv(ni, 256), 512);
+  partial_.reserve(size_t(nb) * 8);
+  params_.reserve(1);
+  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n);
+  flags_.reserve(n); pos_.reserve(n); count_.reserve(1);
+  out.reserve(n);
+  hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, in, ni, partial_.p);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial_.p, nb, inv_leaf, params_.p);
+  hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, ni, inv_leaf, params_.p, keys_.p, vals_.p);
+  size_t tmp_bytes = 0;
+  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  size_t scan_bytes = 0;
+  LIO_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
+  tmp_.reserve(std::max(tmp_bytes, scan_bytes) + 256);
+  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  hipLaunchKernelGGL(k_heads, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, flags_.p);
+  LIO_HIP(rocprim::exclusive_scan(tmp_.p, scan_bytes, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
+  hipLaunchKernelGGL(k_centroids, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, keys2_.p, vals2_.p, flags_.p, pos_.p, ni, out.p, count_.p);
+  LIO_HIP(hipGetLastError());
+  int count = 0;
+  VoxParams hp;
+  LIO_HIP(hipMemcpyAsync(&count, count_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(&hp, params_.p, sizeof(VoxParams), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
+  if (hp.overflow) {  // PCL: "Leaf size is too small for the input dataset" -> output = input
+    LIO_HIP(hipMemcpyAsync(out.p, in, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    count = ni;
+  }
+  if (host_params) *host_params = hp;
+  return size_t(count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-NN grid
+// ------------------------------------------------------------------------------------------------
+__device__ inline int cell_coord(float v, float inv_cell) { return int(floorf(v * inv_cell)); }
+
+__global__ void k_cell_keys(const float4 *__restrict__ pts, int n, GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  int cx = cell_coord(p.x, g.inv_cell) - g.origin[0];
+  int cy = cell_coord(p.y, g.inv_cell) - g.origin[1];
+  int cz = cell_coord(p.z, g.inv_cell) - g.origin[2];
+  cx = min(max(cx, 0), g.dims[0] - 1); cy = min(max(cy, 0), g.dims[1] - 1); cz = min(max(cz, 0), g.dims[2] - 1);
+  keys[i] = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
+  vals[i] = uint32_t(i);
+}
+
+__global__ void k_cell_scatter(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, int n,
+                               float4 *__restrict__ sorted, int2 *__restrict__ cells) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = keys[i];
+  uint32_t src = vals[i];
+  float4 p = pts[src];
+  p.w = __int_as_float(int(src));
+  sorted[i] = p;
+  if (i == 0 || keys[i - 1] != k) cells[k].x = i;
+  if (i == n - 1 || keys[i + 1] != k) cells[k].y = i + 1;
+}
+
+void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s) {
+  desc_.inv_cell = 1.0f / cell;
+  desc_.n_points = int(n);
+  size_t ncells = 1;
+  for (int d = 0; d < 3; ++d) {
+    int lo = int(std::floor(mn[d] * desc_.inv_cell)) - 1;
+    int hi = int(std::floor(mx[d] * desc_.inv_cell)) + 1;
+    desc_.origin[d] = lo;
+    desc_.dims[d] = hi - lo + 1;
+    ncells *= size_t(desc_.dims[d]);
+  }
+  if (ncells > (size_t(1) << 31)) throw DeviceError("KnnGrid: cell table too large");
+  cells_.reserve(ncells);
+  LIO_HIP(hipMemsetAsync(cells_.p, 0, ncells * sizeof(int2), s));
+  if (n == 0) return;
+  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); sorted_.reserve(n);
+  const int ni = int(n);
+  hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, ni, desc_, keys_.p, vals_.p);
+  int bits = 1;
+  while ((size_t(1) << bits) < ncells && bits < 32) ++bits;
+  size_t tmp_bytes = 0;
+  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
+  tmp_.reserve(tmp_bytes + 256);
+  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
+  hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys2_.p, vals2_.p, ni, sorted_.p, cells_.p);
+  LIO_HIP(hipGetLastError());
+}
+
+// K nearest (K <= 5 kept in registers) over the 27 neighbouring cells; total order (d2, original index).
+template <int K>
+__device__ inline void knn_scan(const Vec3<float> &q, const float4 *__restrict__ map, const int2 *__restrict__ cells, const GridDesc &g,
+                                float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bj[k] = 0; }
+  int cx = cell_coord(q.x, g.inv_cell) - g.origin[0];
+  int cy = cell_coord(q.y, g.inv_cell) - g.origin[1];
+  int cz = cell_coord(q.z, g.inv_cell) - g.origin[2];
+  if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dims[0] || cy >= g.dims[1] || cz >= g.dims[2]) return;
+  for (int dz = -1; dz <= 1; ++dz) {
+    int z = cz + dz;
+    if (z < 0 || z >= g.dims[2]) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      int y = cy + dy;
+      if (y < 0 || y >= g.dims[1]) continue;
+      int row = g.dims[0] * (y + g.dims[1] * z);
+      for (int dx = -1; dx <= 1; ++dx) {
+        int x = cx + dx;
+        if (x < 0 || x >= g.dims[0]) continue;
+        int2 ce = cells[row + x];
+        for (int j = ce.x; j < ce.y; ++j) {
+          float4 p = map[j];
+          float ddx = p.x - q.x, ddy = p.y - q.y, ddz = p.z - q.z;
+          float d = ddx * ddx;
+          d += ddy * ddy;
+          d += ddz * ddz;
+          int idx = __float_as_int(p.w);
+          if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
+            // sorted insertion, fully unrolled so the arrays stay in registers
+            bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = j;
+#pragma unroll
+            for (int k = K - 1; k > 0; --k) {
+              bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
+              float td = sw ? bd[k - 1] : bd[k];
+              int ti = sw ? bi[k - 1] : bi[k];
+              int tj = sw ? bj[k - 1] : bj[k];
+              bd[k - 1] = sw ? bd[k] : bd[k - 1];
+              bi[k - 1] = sw ? bi[k] : bi[k - 1];
+              bj[k - 1] = sw ? bj[k] : bj[k - 1];
+              bd[k] = td; bi[k] = ti; bj[k] = tj;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ void k_knn(const float4 *__restrict__ query, int m, float radius_sq, const float4 *__restrict__ map,
+                      const int2 *__restrict__ cells, GridDesc g, int32_t *__restrict__ idx, float *__restrict__ sqd, int kout) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  float4 q4 = query[i];
+  float bd[K]; int bi[K], bj[K];
+  knn_scan<K>(Vec3<float>(q4.x, q4.y, q4.z), map, cells, g, bd, bi, bj);
+  for (int k = 0; k < kout; ++k) {
+    bool ok = bi[k] != INT_MAX && bd[k] < radius_sq;
+    idx[i * kout + k] = ok ? bi[k] : -1;
+    sqd[i * kout + k] = ok ? bd[k] : INFINITY;
+  }
+}
+
+void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+                int32_t *idx, float *sqd, hipStream_t s) {
+  if (m <= 0) return;
+  if (k == 1) hipLaunchKernelGGL(k_knn<1>, dim3(cdiv(m, 128)), dim3(128), 0, s, query, m, radius_sq, map_sorted, cells, g, idx, sqd, k);
+  else hipLaunchKernelGGL(k_knn<5>, dim3(cdiv(m, 128)), dim3(128), 0, s, query, m, radius_sq, map_sorted, cells, g, idx, sqd, k);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// CalculateFeatures (surf branch)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                                 const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const FeatFrame fr = a.fr[blockIdx.y];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fr.M) return;
+  const float *tp = transforms + 8 * fr.tf_index;
+  Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  Vec3<float> t(tp[4], tp[5], tp[6]);
+  float4 po = fr.stack[i];
+  Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+  Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+  float bd[5]; int bi[5], bj[5];
+  knn_scan<5>(sel, map, cells, g, bd, bi, bj);
+  const int slot = fr.slot_off + i;
+  uint8_t ok = 0;
+  float4 c = make_float4(0, 0, 0, 0);
+  float sc = 0;
+  if (bi[4] != INT_MAX && bd[4] < a.min_match_sq_dis) {
+    float A[15], B[5] = {-1, -1, -1, -1, -1}, X[3];
+    float nx[5], ny[5], nz[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 pn = map[bj[j]];
+      nx[j] = pn.x; ny[j] = pn.y; nz[j] = pn.z;
+      A[j * 3 + 0] = pn.x; A[j * 3 + 1] = pn.y; A[j * 3 + 2] = pn.z;
+    }
+    qr_solve<float, 5, 3>(A, B, X, FLT_EPSILON);
+    float pa = X[0], pb = X[1], pc = X[2], pd = 1;
+    float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+    pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+    bool plane_valid = true;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (fabsf(pa * nx[j] + pb * ny[j] + pc * nz[j] + pd) > a.min_plane_dis) plane_valid = false;
+    if (plane_valid) {
+      float pd2 = pa * sel.x + pb * sel.y + pc * sel.z + pd;
+      float s = 1 - 0.9f * fabsf(pd2) / sqrtf(sqrtf(sel.x * sel.x + sel.y * sel.y + sel.z * sel.z));
+      // FOV test (+-60 deg about the sensor z axis, Estimator.cc:1063-1086)
+      Vec3<float> rz = rotate(q, Vec3<float>(0.f, 0.f, 10.f));
+      Vec3<float> pz(rz.x + t.x, rz.y + t.y, rz.z + t.z);
+      float dx1 = t.x - sel.x, dy1 = t.y - sel.y, dz1 = t.z - sel.z;
+      float side1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+      float dx2 = pz.x - sel.x, dy2 = pz.y - sel.y, dz2 = pz.z - sel.z;
+      float side2 = dx2 * dx2 + dy2 * dy2 + dz2 * dz2;
+      float check1 = 100.0f + side1 - side2 - 10.0f * sqrtf(3.0f) * sqrtf(side1);
+      float check2 = 100.0f + side1 - side2 + 10.0f * sqrtf(3.0f) * sqrtf(side1);
+      bool in_fov = check1 < 0 && check2 > 0;
+      if (double(s) > 0.1 && in_fov) {
+        ok = 1;
+        c = make_float4(s * pa, s * pb, s * pc, s * pd);
+        sc = s;
+      }
+    }
+  }
+  valid[slot] = ok; coef[slot] = c; score[slot] = sc;
+}
+
+void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s) {
+  if (a.nframes <= 0 || a.max_M <= 0) return;
+  hipLaunchKernelGGL(k_features, dim3(cdiv(a.max_M, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef,
+                     score, skip_flag);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// CalculateLaserOdom: rows of (mat_A | mat_B), reduced; then the 6x6 step
+// ------------------------------------------------------------------------------------------------
+#define ODOM_ROW_THREADS 256
+int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM_ROW_THREADS * 2), 256)); }
+
+__global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__restrict__ stack, int M, int nslots,
+                                                                const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                                                const OdomState *__restrict__ st, double *__restrict__ partials) {
+  if (st->converged) return;
+  Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
+  Vec3<float> t(st->T[4], st->T[5], st->T[6]);
+  Mat3<float> Rm = toRot(q);
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0;
+  for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < nslots; sidx += gridDim.x * blockDim.x) {
+    if (!valid[sidx]) continue;
+    float4 po = stack[sidx % M];
+    float4 c = coef[sidx];
+    Vec3<float> p(po.x, po.y, po.z), w(c.x, c.y, c.z);
+    Mat3<float> RS = Rm * skew(p);
+    float a[6];
+    a[0] = -(w.x * RS(0, 0) + w.y * RS(1, 0) + w.z * RS(2, 0));
+    a[1] = -(w.x * RS(0, 1) + w.y * RS(1, 1) + w.z * RS(2, 1));
+    a[2] = -(w.x * RS(0, 2) + w.y * RS(1, 2) + w.z * RS(2, 2));
+    a[3] = w.x; a[4] = w.y; a[5] = w.z;
+    Vec3<float> rp = rotate(q, p);
+    float d2 = w.x * (rp.x + t.x) + w.y * (rp.y + t.y) + w.z * (rp.z + t.z) + c.w;
+    float bb = -d2;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) acc[k++] += double(a[r] * a[cc]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] += double(a[r] * bb);
+    acc[27] += 1.0;
+  }
+  // wave reduce (64 lanes) then cross-wave through LDS
+  __shared__ double sm[ODOM_ROW_THREADS / 64][28];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    double v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sm[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double v = 0;
+    for (int w = 0; w < ODOM_ROW_THREADS / 64; ++w) v += sm[w][threadIdx.x];
+    partials[blockIdx.x * 28 + threadIdx.x] = v;
+  }
+}
+
+void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
+                      double *partials, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_odom_rows, dim3(nblocks), dim3(ODOM_ROW_THREADS), 0, s, stack, M, nslots, valid, coef, st, partials);
+  LIO_HIP(hipGetLastError());
+}
+
+__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
+  if (threadIdx.x != 0 || st->converged) return;
+  double sum[28];
+  for (int k = 0; k < 28; ++k) sum[k] = 0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int k = 0; k < 28; ++k) sum[k] += partials[b * 28 + k];
+  float AtA[36], AtB[6];
+  int k = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) { AtA[r * 6 + c] = float(sum[k]); AtA[c * 6 + r] = float(sum[k]); ++k; }
+  for (int r = 0; r < 6; ++r) AtB[r] = float(sum[21 + r]);
+  float Ac[36], Bc[6], X[6];
+  for (int i = 0; i < 36; ++i) Ac[i] = AtA[i];
+  for (int i = 0; i < 6; ++i) Bc[i] = AtB[i];
+  qr_solve<float, 6, 6>(Ac, Bc, X, FLT_EPSILON);
+  if (iter == 0) {
+    float E[6];
+    sym_eigvals<6>(AtA, E);
+    int kz = 0;
+    for (int i = 0; i < 6; ++i) { if (E[i] < 100.f) ++kz; else break; }
+    st->kz = kz;
+    st->degenerate = kz > 0;
+  }
+  if (st->degenerate)
+    for (int i = 0; i < st->kz; ++i) X[i] = 0.f;  // matP = diag(0..0,1..1) (A.6)
+  Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
+  Quat<float> R0 = normalized(q);
+  Vec3<float> t(st->T[4], st->T[5], st->T[6]);
+  t.x += X[3]; t.y += X[4]; t.z += X[5];
+  q = q * deltaQ(Vec3<float>(X[0], X[1], X[2]));
+  if (!isfinite(t.x)) t.x = 0;
+  if (!isfinite(t.y)) t.y = 0;
+  if (!isfinite(t.z)) t.z = 0;
+  st->T[0] = q.x; st->T[1] = q.y; st->T[2] = q.z; st->T[3] = q.w; st->T[4] = t.x; st->T[5] = t.y; st->T[6] = t.z;
+  // angularDistance(R0, q): 2*atan2(|vec(R0 * conj(q))|, |w|)
+  Quat<float> d = R0 * conj(q);
+  float ang = 2.f * atan2f(norm(d.vec()), fabsf(d.w));
+  float delta_r = float(double(ang) * 180.0 / M_PI);
+  // std::pow(float, int) promotes to double in the reference (Estimator.cc:1352)
+  double dt0 = double(X[3] * 100), dt1 = double(X[4] * 100), dt2 = double(X[5] * 100);
+  float delta_t = float(sqrt(dt0 * dt0 + dt1 * dt1 + dt2 * dt2));
+  st->iters = iter + 1;
+  if (double(delta_r) < 0.05 && double(delta_t) < 0.05) st->converged = 1;
+}
+
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s) {
+  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter);
+  LIO_HIP(hipGetLastError());
+}
+
+}  // namespace lio

@@ -1,0 +1,138 @@
+// estimator.h — the product's mirror of lio::Estimator's post-initialisation surface
+// (include/imu_processor/Estimator.h:110-299): ProcessImu, ProcessLaserOdom (INITED branch),
+// BuildLocalMap, SolveOptimization, SlideWindow.  Clouds live in HBM for the life of the window;
+// the host keeps only the (W+1) x {P,R,V,Ba,Bg} states, the pre-integrations and the prior.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "../../include/lio_c.h"
+#include "cloud_kernels.h"
+#include "host_solver.h"
+
+namespace lio {
+
+typedef Rigid<float> Rigidf;
+typedef Rigid<double> Rigidd;
+
+struct EstConfig {
+  int W = 15, Wo = 5;
+  float corner_filter_size = 0.2f, surf_filter_size = 0.4f, min_match_sq_dis = 1.0f, min_plane_dis = 0.2f;
+  Rigidf transform_lb;
+  bool opt_extrinsic = false, imu_factor = true, point_distance_factor = false, prior_factor = false, marginalization_factor = true,
+       enable_deskew = true, cutoff_deskew = false, keep_features = false;
+  PimNoise pim;
+  int max_num_iterations = 10;
+  double max_solver_time = 0.10;
+  int extrinsic_stage = 2;
+};
+
+struct DeviceCloud {
+  DBuf<float4> buf;
+  size_t n = 0;
+};
+
+struct StampedPose { double time; Rigidf T; };
+
+// HIP-event kernel timing on the estimator's stream (lio_est_enable_kernel_timing)
+enum { KT_FEATURES = 0, KT_ODOM_FEATURES, KT_ODOM_ROWS, KT_ODOM_UPDATE, KT_MOMENTS, KT_VOXEL, KT_KNN_GRID, KT_CONCAT, KT_COUNT };
+struct KernelTimers {
+  bool on = false;
+  struct Rec { hipEvent_t a, b; int id; double bytes; };
+  struct Acc { int n = 0; double ms = 0, bytes = 0; };
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  Acc acc[KT_COUNT];
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; LIO_HIP(hipEventCreate(&e)); return e;
+  }
+  int begin(int id, double bytes, hipStream_t s) {
+    if (!on) return -1;
+    Rec r{get(), get(), id, bytes};
+    LIO_HIP(hipEventRecord(r.a, s));
+    pending.push_back(r);
+    return int(pending.size()) - 1;
+  }
+  void end(int h, hipStream_t s) { if (h >= 0) LIO_HIP(hipEventRecord(pending[h].b, s)); }
+  void resolve() {  // call after the stream has been synchronised
+    for (Rec &r : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { acc[r.id].n++; acc[r.id].ms += ms; acc[r.id].bytes += r.bytes; }
+      pool.push_back(r.a); pool.push_back(r.b);
+    }
+    pending.clear();
+  }
+  void reset() { for (Acc &a : acc) a = Acc(); }
+  ~KernelTimers() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); for (Rec &r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
+};
+
+class Estimator {
+ public:
+  explicit Estimator(const EstConfig &cfg);
+  ~Estimator();
+
+  void ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp);
+  bool ProcessLaserOdom(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner, double stamp,
+                        lio_solve_report *rep);
+  bool PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner, double stamp);
+  bool SolveOptimization(lio_solve_report *rep);
+  void SlideWindow();
+  void BuildLocalMap(lio_solve_report *rep);
+
+  // test hooks
+  void SetWindow(const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs, const double g[3]);
+  void SetSurfStack(int frame, const float *xyzi, size_t n);
+  size_t GetSurfStack(int frame, float *out);
+  void SetPreintegration(int frame, std::shared_ptr<Preintegration> p) { pre_integrations_[frame] = std::move(p); }
+  void BeginFrame(const V3d &acc, const V3d &gyr);
+  size_t GetLocalMap(float *out);
+  size_t GetFeatures(int frame, double *pt, double *co, double *sc);
+  void Snapshot();
+  bool Restore();
+
+  EstConfig cfg_;
+  int W_, Wo_;
+  std::vector<V3d> Ps_, Vs_, Bas_, Bgs_;
+  std::vector<M3d> Rs_;
+  V3d g_vec_, acc_last_, gyr_last_;
+  Rigidf transform_lb_, laser_odom_transform_;
+  bool inited_ = false, first_imu_ = false, init_local_map_ = false, convergence_flag_ = false;
+  int cir_buf_count_ = 0;
+  std::shared_ptr<MargPrior> last_marg_;
+  std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
+  std::shared_ptr<Preintegration> tmp_pre_integration_;
+  int laser_odom_iters_ = 0;
+  KernelTimers timers_;
+
+ private:
+  struct HostState;  // snapshot payload
+  Rigidd LidarPose(int i, const Rigidd &lb) const;
+  Rigidf RelTransform(int i, const Rigidd &T_pivot, const Rigidd &lb) const;
+  void VectorToParams(WindowParams &P) const;
+  void ParamsToVector(const WindowParams &P);
+  void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
+  void PushCloud(DeviceCloud &&c, size_t n);
+
+  hipStream_t stream_ = nullptr;
+  std::vector<DeviceCloud> stacks_;
+  std::vector<size_t> size_surf_stack_;
+  std::vector<StampedPose> imu_stamped_;
+  DeviceCloud local_, local_filtered_, scratch_cloud_, upload_;
+  VoxelGridDev vox_;
+  KnnGrid grid_;
+  // feature slots
+  DBuf<uint8_t> f_valid_;
+  DBuf<float4> f_coef_;
+  DBuf<float> f_score_;
+  std::vector<int> slot_off_, nslots_;
+  size_t total_slots_ = 0;
+  DBuf<float> d_transforms_;
+  DBuf<OdomState> d_odom_;
+  DBuf<double> d_odom_partials_, d_moment_partials_, d_moment_out_;
+  double *h_moment_out_ = nullptr;  // pinned
+  std::unique_ptr<HostState> snap_;
+  std::vector<DeviceCloud> snap_stacks_;
+};
+
+}  // namespace lio

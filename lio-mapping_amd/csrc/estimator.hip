@@ -1,0 +1,591 @@
+// estimator.hip — host orchestration of the product's sliding-window step (see estimator.h).
+// Reference call structure: Estimator.cc:430-774 (ProcessLaserOdom), :1361-1646 (BuildLocalMap),
+// :1648-2438 (SolveOptimization), :2440-2568 (VectorToDouble/DoubleToVector), :2570-2666 (SlideWindow).
+#include "estimator.h"
+
+#include <cfloat>
+#include <chrono>
+#include <cstring>
+
+namespace lio {
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// math_utils.h:186-232 (degrees)
+static V3d R2ypr(const M3d &R) {
+  V3d n(R(0, 0), R(1, 0), R(2, 0)), o(R(0, 1), R(1, 1), R(2, 1)), a(R(0, 2), R(1, 2), R(2, 2));
+  double y = atan2(n.y, n.x);
+  double p = atan2(-n.z, n.x * cos(y) + n.y * sin(y));
+  double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+  return V3d(y, p, r) / M_PI * 180.0;
+}
+static M3d ypr2R(const V3d &ypr) {
+  double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+  M3d Rz, Ry, Rx;
+  Rz(0, 0) = cos(y); Rz(0, 1) = -sin(y); Rz(1, 0) = sin(y); Rz(1, 1) = cos(y); Rz(2, 2) = 1;
+  Ry(0, 0) = cos(p); Ry(0, 2) = sin(p); Ry(1, 1) = 1; Ry(2, 0) = -sin(p); Ry(2, 2) = cos(p);
+  Rx(0, 0) = 1; Rx(1, 1) = cos(r); Rx(1, 2) = -sin(r); Rx(2, 1) = sin(r); Rx(2, 2) = cos(r);
+  return Rz * Ry * Rx;
+}
+template <typename T, typename U> static Quat<U> qcast(const Quat<T> &q) { return Quat<U>(U(q.w), U(q.x), U(q.y), U(q.z)); }
+template <typename T, typename U> static Vec3<U> vcast(const Vec3<T> &v) { return Vec3<U>(U(v.x), U(v.y), U(v.z)); }
+static Rigidd toDouble(const Rigidf &t) { return Rigidd(qcast<float, double>(t.rot), vcast<float, double>(t.pos)); }
+static Rigidf toFloat(const Rigidd &t) { return Rigidf(qcast<double, float>(t.rot), vcast<double, float>(t.pos)); }
+static Affine3f affineOf(const Rigidf &tf) {
+  Mat3<float> R = linearOf(tf);
+  Affine3f a;
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) a.m[4 * r + c] = R(r, c); }
+  a.m[3] = tf.pos.x; a.m[7] = tf.pos.y; a.m[11] = tf.pos.z;
+  return a;
+}
+
+struct Estimator::HostState {
+  std::vector<V3d> Ps, Vs, Bas, Bgs;
+  std::vector<M3d> Rs;
+  V3d g_vec, acc_last, gyr_last;
+  Rigidf transform_lb;
+  bool inited, first_imu, init_local_map, convergence_flag;
+  int cir_buf_count;
+  std::shared_ptr<MargPrior> last_marg;
+  std::vector<std::shared_ptr<Preintegration>> pre_integrations;
+  std::shared_ptr<Preintegration> tmp_pre_integration;
+  std::vector<size_t> size_surf_stack;
+  std::vector<StampedPose> imu_stamped;
+};
+
+Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
+  int ndev = 0;
+  LIO_HIP(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) throw DeviceError("no HIP device: the product has no CPU path");
+  LIO_HIP(hipStreamCreate(&stream_));
+  transform_lb_ = cfg.transform_lb;
+  Ps_.assign(W_ + 1, V3d()); Vs_ = Bas_ = Bgs_ = Ps_;
+  Rs_.assign(W_ + 1, M3d::identity());
+  pre_integrations_.assign(W_ + 1, nullptr);
+  stacks_.resize(W_ + 1);
+  size_surf_stack_.assign(W_ + 1, 0);
+  slot_off_.assign(W_ + 1, 0); nslots_.assign(W_ + 1, 0);
+  g_vec_ = V3d(0, 0, -cfg.pim.g_norm);
+  d_odom_.reserve(1);
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));
+}
+
+Estimator::~Estimator() {
+  if (h_moment_out_) (void)hipHostFree(h_moment_out_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+template <typename T> static void push_full(std::vector<T> &buf, T v) {
+  for (size_t i = 0; i + 1 < buf.size(); ++i) buf[i] = std::move(buf[i + 1]);
+  buf.back() = std::move(v);
+}
+
+void Estimator::ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp) {
+  if (!first_imu_) { first_imu_ = true; acc_last_ = acc; gyr_last_ = gyr; }
+  if (cir_buf_count_ != 0) {
+    if (tmp_pre_integration_) tmp_pre_integration_->push_back(dt, acc, gyr);
+    const int j = cir_buf_count_;
+    V3d un_acc_0 = Rs_[j] * (acc_last_ - Bas_[j]) + g_vec_;
+    V3d un_gyr = 0.5 * (gyr_last_ + gyr) - Bgs_[j];
+    Rs_[j] = Rs_[j] * toRot(deltaQ(un_gyr * dt));
+    V3d un_acc_1 = Rs_[j] * (acc - Bas_[j]) + g_vec_;
+    V3d un_acc = 0.5 * (un_acc_0 + un_acc_1);
+    Ps_[j] = Ps_[j] + (dt * Vs_[j] + 0.5 * dt * dt * un_acc);
+    Vs_[j] = Vs_[j] + dt * un_acc;
+    StampedPose tt;
+    tt.time = stamp;
+    tt.T.pos = vcast<double, float>(Ps_[j]);
+    Mat3<float> Rf;
+    for (int k = 0; k < 9; ++k) Rf.m[k] = float(Rs_[j].m[k]);
+    tt.T.rot = fromRot(Rf);
+    if (imu_stamped_.size() >= 100) imu_stamped_.erase(imu_stamped_.begin());
+    imu_stamped_.push_back(tt);
+  }
+  acc_last_ = acc; gyr_last_ = gyr;
+}
+
+void Estimator::BeginFrame(const V3d &acc, const V3d &gyr) {
+  acc_last_ = acc; gyr_last_ = gyr; first_imu_ = true;
+  tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[cir_buf_count_], Bgs_[cir_buf_count_], cfg_.pim);
+}
+
+void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs, const double g[3]) {
+  for (int i = 0; i <= W_; ++i) {
+    Ps_[i] = V3d(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]); Vs_[i] = V3d(Vs[3 * i], Vs[3 * i + 1], Vs[3 * i + 2]);
+    Bas_[i] = V3d(Bas[3 * i], Bas[3 * i + 1], Bas[3 * i + 2]); Bgs_[i] = V3d(Bgs[3 * i], Bgs[3 * i + 1], Bgs[3 * i + 2]);
+    for (int k = 0; k < 9; ++k) Rs_[i].m[k] = Rs[9 * i + k];
+  }
+  g_vec_ = V3d(g[0], g[1], g[2]);
+  inited_ = true; first_imu_ = true; cir_buf_count_ = W_;
+}
+
+void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
+  DeviceCloud &c = stacks_[frame];
+  c.buf.reserve(std::max<size_t>(n, 1));
+  if (n) LIO_HIP(hipMemcpyAsync(c.buf.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  c.n = n;
+  size_surf_stack_[frame] = n;
+}
+size_t Estimator::GetSurfStack(int frame, float *out) {
+  const DeviceCloud &c = stacks_[frame];
+  if (out && c.n) { LIO_HIP(hipMemcpyAsync(out, c.buf.p, c.n * sizeof(float4), hipMemcpyDeviceToHost, stream_)); LIO_HIP(hipStreamSynchronize(stream_)); }
+  return c.n;
+}
+size_t Estimator::GetLocalMap(float *out) {
+  if (out && local_filtered_.n) {
+    LIO_HIP(hipMemcpyAsync(out, local_filtered_.buf.p, local_filtered_.n * sizeof(float4), hipMemcpyDeviceToHost, stream_));
+    LIO_HIP(hipStreamSynchronize(stream_));
+  }
+  return local_filtered_.n;
+}
+
+size_t Estimator::GetFeatures(int frame, double *pt, double *co, double *sc) {
+  if (frame < 0 || frame > W_ || nslots_[frame] == 0) return 0;
+  const int off = slot_off_[frame], ns = nslots_[frame];
+  const size_t M = stacks_[frame].n;
+  std::vector<uint8_t> v(ns);
+  std::vector<float4> c(ns), p(M);
+  std::vector<float> s(ns);
+  LIO_HIP(hipMemcpyAsync(v.data(), f_valid_.p + off, ns, hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(c.data(), f_coef_.p + off, ns * sizeof(float4), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(s.data(), f_score_.p + off, ns * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(p.data(), stacks_[frame].buf.p, M * sizeof(float4), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  size_t k = 0;
+  for (int i = 0; i < ns; ++i) {
+    if (!v[i]) continue;
+    const float4 &pp = p[i % M];
+    if (pt) { pt[3 * k] = pp.x; pt[3 * k + 1] = pp.y; pt[3 * k + 2] = pp.z; }
+    if (co) { co[4 * k] = c[i].x; co[4 * k + 1] = c[i].y; co[4 * k + 2] = c[i].z; co[4 * k + 3] = c[i].w; }
+    if (sc) sc[k] = s[i];
+    ++k;
+  }
+  return k;
+}
+
+Rigidd Estimator::LidarPose(int i, const Rigidd &lb) const {
+  // Quaterniond rot_li(Rs_i * transform_lb.rot.inverse()); pos_li = Ps_i - rot_li * transform_lb.pos  (Estimator.cc:1448-1449)
+  Qd rot = fromRot(Rs_[i] * toRot(qinverse(lb.rot)));
+  V3d pos = Ps_[i] - rotate(rot, lb.pos);
+  return Rigidd(rot, pos);
+}
+Rigidf Estimator::RelTransform(int i, const Rigidd &T_pivot, const Rigidd &lb) const {
+  return toFloat(compose(rinverse(T_pivot), LidarPose(i, lb)));
+}
+
+void Estimator::PushCloud(DeviceCloud &&c, size_t n) {
+  push_full(stacks_, std::move(c));
+  push_full(size_surf_stack_, n);
+}
+
+bool Estimator::ProcessLaserOdom(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner,
+                                 double stamp, lio_solve_report *rep) {
+  if (!PushFrame(transform_in, surf, n_surf, corner, n_corner, stamp)) return false;
+  bool ok = SolveOptimization(rep);
+  SlideWindow();
+  return ok;
+}
+
+bool Estimator::PushFrame(const Rigidf & /*transform_in*/, const float *surf, size_t n_surf, const float * /*corner*/, size_t /*n_corner*/,
+                          double /*stamp*/) {
+  if (!inited_) return false;
+  push_full(pre_integrations_, tmp_pre_integration_);
+  tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[cir_buf_count_], Bgs_[cir_buf_count_], cfg_.pim);
+  // host -> HBM (the only PCIe traffic of the step besides the small state/moment exchanges)
+  upload_.buf.reserve(std::max<size_t>(n_surf, 1));
+  if (n_surf) LIO_HIP(hipMemcpyAsync(upload_.buf.p, surf, n_surf * sizeof(float4), hipMemcpyHostToDevice, stream_));
+  upload_.n = n_surf;
+  DeviceCloud fresh = std::move(stacks_[0]);  // recycle the buffer that falls out of the window
+  if (cfg_.enable_deskew || cfg_.cutoff_deskew) {
+    if (!cfg_.cutoff_deskew) {
+      if (imu_stamped_.empty()) return false;
+      double time_e = imu_stamped_.back().time;
+      Rigidf T_e = imu_stamped_.back().T;
+      double time_s = time_e;
+      Rigidf T_s = T_e;
+      for (int i = int(imu_stamped_.size()) - 1; i >= 0; --i) {
+        time_s = imu_stamped_[i].time;
+        T_s = imu_stamped_[i].T;
+        if (time_e - imu_stamped_[i].time >= 0.1) break;
+      }
+      Rigidf body_es = compose(rinverse(T_e), T_s);
+      float s = float(0.1 / (time_e - time_s));
+      Quat<float> qid;
+      body_es.rot = slerp(qid, s, body_es.rot, FLT_EPSILON);
+      body_es.pos = s * body_es.pos;
+      Rigidf tes = compose(compose(transform_lb_, body_es), rinverse(transform_lb_));
+      float q[4] = {tes.rot.x, tes.rot.y, tes.rot.z, tes.rot.w}, p[3] = {tes.pos.x, tes.pos.y, tes.pos.z};
+      launch_deskew_to_end(upload_.buf.p, int(n_surf), q, p, 10.f, stream_);
+    }
+    // corner clouds are only consumed under USE_CORNER (off in the shipped build, Estimator.h:55): not processed
+    fresh.n = vox_.run(upload_.buf.p, n_surf, cfg_.surf_filter_size, fresh.buf, stream_);
+  } else {
+    fresh.buf.reserve(std::max<size_t>(n_surf, 1));
+    if (n_surf) LIO_HIP(hipMemcpyAsync(fresh.buf.p, upload_.buf.p, n_surf * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    fresh.n = n_surf;
+  }
+  size_t nfresh = fresh.n;
+  PushCloud(std::move(fresh), nfresh);
+  return true;
+}
+
+void Estimator::BuildLocalMap(lio_solve_report *rep) {
+  const double t0 = now_ms();
+  const int pivot = W_ - Wo_;
+  const Rigidd lb = toDouble(transform_lb_);
+  const Rigidd T_pivot = LidarPose(pivot, lb);
+  if (!init_local_map_) {  // A.15: fuse frames 0..pivot into the pivot's stack, once
+    ConcatArgs ca{};
+    int total = 0;
+    for (int i = 0; i <= pivot; ++i) {
+      ConcatSeg &sg = ca.seg[ca.nseg++];
+      sg.src = stacks_[i].buf.p; sg.n = int(stacks_[i].n); sg.dst_off = total; sg.set_intensity = 0; sg.intensity = 0; sg.identity = 0;
+      sg.tf = affineOf(RelTransform(i, T_pivot, lb));
+      total += sg.n;
+    }
+    ca.total = total;
+    scratch_cloud_.buf.reserve(std::max(total, 1));
+    launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
+    scratch_cloud_.n = size_t(total);
+    std::swap(stacks_[pivot], scratch_cloud_);
+    init_local_map_ = true;
+  }
+  std::vector<Rigidf> local_transforms(W_ + 1);
+  ConcatArgs ca{};
+  int total = 0;
+  for (int i = 0; i <= W_; ++i) {
+    Rigidf tf = RelTransform(i, T_pivot, lb);
+    local_transforms[i] = fromAffine(linearOf(tf), tf.pos);
+    if (i < pivot || i == W_) continue;
+    ConcatSeg &sg = ca.seg[ca.nseg++];
+    sg.src = stacks_[i].buf.p; sg.n = int(stacks_[i].n); sg.dst_off = total;
+    if (i == pivot) { sg.identity = 1; sg.set_intensity = 0; sg.intensity = 0; }
+    else { sg.identity = 0; sg.set_intensity = 1; sg.intensity = float(i); sg.tf = affineOf(tf); }
+    total += sg.n;
+  }
+  ca.total = total;
+  local_.buf.reserve(std::max(total, 1));
+  int th = timers_.begin(KT_CONCAT, 32.0 * total, stream_);
+  launch_transform_concat(ca, local_.buf.p, stream_);
+  timers_.end(th, stream_);
+  local_.n = size_t(total);
+  VoxParams vp;
+  th = timers_.begin(KT_VOXEL, 32.0 * total, stream_);
+  local_filtered_.n = vox_.run(local_.buf.p, local_.n, cfg_.surf_filter_size, local_filtered_.buf, stream_, &vp);
+  timers_.end(th, stream_);
+  const double t1 = now_ms();
+  // K-NN grid: cell edge >= sqrt(min_match_sq_dis) so the 27-cell neighbourhood holds every point that can
+  // pass the d2[4] < min_match_sq_dis gate (Estimator.cc:1021); beyond it the reference rejects anyway.
+  const float cell = std::sqrt(cfg_.min_match_sq_dis) * 1.0001f + 1e-6f;
+  th = timers_.begin(KT_KNN_GRID, 32.0 * double(local_filtered_.n), stream_);
+  grid_.build(local_filtered_.buf.p, local_filtered_.n, vp.mn, vp.mx, cell, stream_);
+  timers_.end(th, stream_);
+  // slot layout
+  const int keep_mult = (cfg_.keep_features && cfg_.imu_factor) ? 10 : 1;
+  total_slots_ = 0;
+  for (int i = 0; i <= W_; ++i) {
+    slot_off_[i] = int(total_slots_);
+    nslots_[i] = 0;
+    if (i > pivot) { nslots_[i] = int(stacks_[i].n) * ((i == W_) ? keep_mult : 1); total_slots_ += size_t(nslots_[i]); }
+  }
+  f_valid_.reserve(std::max<size_t>(total_slots_, 1)); f_coef_.reserve(std::max<size_t>(total_slots_, 1)); f_score_.reserve(std::max<size_t>(total_slots_, 1));
+  if (total_slots_) LIO_HIP(hipMemsetAsync(f_valid_.p, 0, total_slots_, stream_));
+  // transforms -> device
+  std::vector<float> tfs(size_t(W_ + 1) * 8, 0.f);
+  for (int i = 0; i <= W_; ++i) {
+    const Rigidf &T = local_transforms[i];
+    float *o = &tfs[size_t(i) * 8];
+    o[0] = T.rot.x; o[1] = T.rot.y; o[2] = T.rot.z; o[3] = T.rot.w; o[4] = T.pos.x; o[5] = T.pos.y; o[6] = T.pos.z;
+  }
+  d_transforms_.reserve(tfs.size());
+  LIO_HIP(hipMemcpyAsync(d_transforms_.p, tfs.data(), tfs.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  // frames pivot+1 .. W-1 (and W when the IMU factor is off): one batched launch
+  FeatArgs fa{};
+  fa.min_match_sq_dis = cfg_.min_match_sq_dis; fa.min_plane_dis = cfg_.min_plane_dis;
+  const int last_static = cfg_.imu_factor ? W_ - 1 : W_;
+  for (int i = pivot + 1; i <= last_static; ++i) {
+    FeatFrame &f = fa.fr[fa.nframes++];
+    f.stack = stacks_[i].buf.p; f.M = int(stacks_[i].n); f.slot_off = slot_off_[i]; f.tf_index = i;
+    fa.max_M = std::max(fa.max_M, f.M);
+  }
+  {
+    double mq = 0;
+    for (int k = 0; k < fa.nframes; ++k) mq += fa.fr[k].M;
+    // 16(M+N) + 8*K*M + 32*M bytes per call, K = 5
+    th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, stream_);
+    launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, stream_);
+    timers_.end(th, stream_);
+  }
+  laser_odom_iters_ = 0;
+  if (cfg_.imu_factor) {
+    // CalculateLaserOdom: <= 10 dependent rounds, no host round trip inside (the device carries the
+    // transform and the convergence flag; later launches turn into no-ops)
+    OdomState st{};
+    std::memcpy(st.T, &tfs[size_t(W_) * 8], 8 * sizeof(float));
+    LIO_HIP(hipMemcpyAsync(d_odom_.p, &st, sizeof(st), hipMemcpyHostToDevice, stream_));
+    const int M = int(stacks_[W_].n);
+    if (M > 0) {
+      const int nb = odom_rows_blocks(M * keep_mult);
+      d_odom_partials_.reserve(size_t(nb) * 28);
+      for (int iter = 0; iter < 10; ++iter) {
+        FeatArgs fo{};
+        fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
+        fo.nframes = 1; fo.max_M = M;
+        fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0;
+        fo.fr[0].slot_off = slot_off_[W_] + (keep_mult > 1 ? iter * M : 0);
+        int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M, stream_);
+        launch_features(fo, reinterpret_cast<const float *>(d_odom_.p), grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
+                        f_score_.p, &d_odom_.p->converged, stream_);
+        timers_.end(t1h, stream_);
+        const int ns = keep_mult > 1 ? (iter + 1) * M : M;
+        int t2h = timers_.begin(KT_ODOM_ROWS, 33.0 * ns, stream_);
+        launch_odom_rows(stacks_[W_].buf.p, M, ns, f_valid_.p + slot_off_[W_], f_coef_.p + slot_off_[W_], d_odom_.p, d_odom_partials_.p, nb,
+                         stream_);
+        timers_.end(t2h, stream_);
+        int t3h = timers_.begin(KT_ODOM_UPDATE, 28.0 * 8 * nb, stream_);
+        launch_odom_update(d_odom_partials_.p, nb, d_odom_.p, iter, stream_);
+        timers_.end(t3h, stream_);
+      }
+    }
+    LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+    LIO_HIP(hipStreamSynchronize(stream_));
+    timers_.resolve();
+    laser_odom_iters_ = st.iters;
+    laser_odom_transform_ = Rigidf(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));
+    if (keep_mult > 1) nslots_[W_] = int(stacks_[W_].n) * std::max(1, st.iters);
+  } else {
+    LIO_HIP(hipStreamSynchronize(stream_));
+    timers_.resolve();
+  }
+  const double t2 = now_ms();
+  if (rep) {
+    rep->ms_build_map = t1 - t0; rep->ms_features = t2 - t1; rep->n_local_map = int(local_filtered_.n);
+    rep->laser_odom_iterations = laser_odom_iters_;
+  }
+}
+
+void Estimator::VectorToParams(WindowParams &P) const {
+  const int pivot = W_ - Wo_;
+  P.Wo = Wo_;
+  P.pose.resize(Wo_ + 1); P.sb.resize(Wo_ + 1);
+  for (int i = 0, oi = pivot; i <= Wo_; ++i, ++oi) {
+    Qd q = fromRot(Rs_[oi]);
+    P.pose[i] = {Ps_[oi].x, Ps_[oi].y, Ps_[oi].z, q.x, q.y, q.z, q.w};
+    P.sb[i] = {Vs_[oi].x, Vs_[oi].y, Vs_[oi].z, Bas_[oi].x, Bas_[oi].y, Bas_[oi].z, Bgs_[oi].x, Bgs_[oi].y, Bgs_[oi].z};
+  }
+  P.ex = {transform_lb_.pos.x, transform_lb_.pos.y, transform_lb_.pos.z, transform_lb_.rot.x, transform_lb_.rot.y, transform_lb_.rot.z,
+          transform_lb_.rot.w};
+}
+
+void Estimator::ParamsToVector(const WindowParams &P) {  // DoubleToVector with yaw re-anchoring (Estimator.cc:2479-2568)
+  const int pivot = W_ - Wo_;
+  const V3d origin_P0 = Ps_[pivot];
+  const V3d origin_R0 = R2ypr(Rs_[pivot]);
+  const M3d R00 = toRot(normalized(Qd(P.pose[0][6], P.pose[0][3], P.pose[0][4], P.pose[0][5])));
+  const V3d origin_R00 = R2ypr(R00);
+  const double y_diff = origin_R0.x - origin_R00.x;
+  M3d rot_diff = ypr2R(V3d(y_diff, 0, 0));
+  if (std::fabs(std::fabs(origin_R0.y) - 90) < 1.0 || std::fabs(std::fabs(origin_R00.y) - 90) < 1.0) rot_diff = Rs_[pivot] * transpose(R00);
+  {
+    Rigidd trans_pivot(fromRot(Rs_[pivot]), Ps_[pivot]);
+    Rigidd trans_opt_pivot(fromRot(rot_diff * R00), origin_P0);
+    for (int idx = 0; idx < pivot; ++idx) {
+      Rigidd trans_idx(fromRot(Rs_[idx]), Ps_[idx]);
+      Rigidd t = compose(compose(trans_opt_pivot, rinverse(trans_pivot)), trans_idx);
+      Ps_[idx] = t.pos;
+      Rs_[idx] = toRot(normalized(t.rot));
+    }
+  }
+  for (int i = 0, oi = pivot; i <= Wo_; ++i, ++oi) {
+    Qd qi(P.pose[i][6], P.pose[i][3], P.pose[i][4], P.pose[i][5]);
+    Rs_[oi] = rot_diff * toRot(normalized(qi));
+    Ps_[oi] = rot_diff * V3d(P.pose[i][0] - P.pose[0][0], P.pose[i][1] - P.pose[0][1], P.pose[i][2] - P.pose[0][2]) + origin_P0;
+    Vs_[oi] = rot_diff * V3d(P.sb[i][0], P.sb[i][1], P.sb[i][2]);
+    Bas_[oi] = V3d(P.sb[i][3], P.sb[i][4], P.sb[i][5]);
+    Bgs_[oi] = V3d(P.sb[i][6], P.sb[i][7], P.sb[i][8]);
+  }
+  transform_lb_.pos = Vec3<float>(float(P.ex[0]), float(P.ex[1]), float(P.ex[2]));
+  transform_lb_.rot = Quat<float>(float(P.ex[6]), float(P.ex[3]), float(P.ex[4]), float(P.ex[5]));
+}
+
+void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
+  const int pivot = W_ - Wo_;
+  MomentArgs ma{};
+  int max_slots = 0;
+  for (int i = 1; i <= Wo_; ++i) {
+    MomentFrame &f = ma.fr[ma.nframes++];
+    const int idx = pivot + i;
+    f.stack = stacks_[idx].buf.p; f.M = std::max<int>(1, int(stacks_[idx].n)); f.slot_off = slot_off_[idx]; f.nslots = nslots_[idx];
+    relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), f.R, f.t);
+    max_slots = std::max(max_slots, f.nslots);
+  }
+  ma.blocks_per_frame = moment_blocks_per_frame(max_slots);
+  d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
+  d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
+  double nres = 0;
+  for (int k = 0; k < ma.nframes; ++k) nres += ma.fr[k].nslots;
+  int th = timers_.begin(KT_MOMENTS, 60.0 * nres, stream_);  // 60 B read per lidar residual
+  launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, d_moment_out_.p, stream_);
+  timers_.end(th, stream_);
+  LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * size_t(ma.nframes) * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  timers_.resolve();
+  for (int i = 1; i <= Wo_; ++i) {
+    const double *src = h_moment_out_ + size_t(i - 1) * LIO_MOMENT_OUT;
+    std::memcpy(m[i].S, src, 256 * sizeof(double));
+    m[i].cost = src[256]; m[i].count = src[257];
+  }
+}
+
+bool Estimator::SolveOptimization(lio_solve_report *rep) {
+  if (cir_buf_count_ < W_ && cfg_.imu_factor) return false;
+  const double t_total0 = now_ms();
+  lio_solve_report local{};
+  lio_solve_report &R = rep ? *rep : local;
+  std::memset(&R, 0, sizeof(R));
+  bool turn_off = true;
+  BuildLocalMap(&R);
+  const double t_prep0 = now_ms();
+  const int pivot = W_ - Wo_;
+  WindowParams P;
+  VectorToParams(P);
+  P.ex_constant = (cfg_.extrinsic_stage == 0 || !cfg_.opt_extrinsic);
+  WindowSystem sys;
+  sys.Wo = Wo_;
+  sys.use_lidar = cfg_.point_distance_factor;
+  sys.pim.assign(Wo_, nullptr);
+  if (cfg_.imu_factor)
+    for (int i = 0; i < Wo_; ++i) {
+      auto &pi = pre_integrations_[pivot + i + 1];
+      if (pi && pi->sum_dt <= 10.0) sys.pim[i] = pi;
+    }
+  if (cfg_.marginalization_factor && last_marg_) sys.prior = last_marg_;
+  if (cfg_.prior_factor) {
+    sys.use_prior_factor = true;
+    Rigidd t = toDouble(transform_lb_);
+    sys.prior_pos = t.pos; sys.prior_rot = t.rot;
+  }
+  sys.lidar_eval = [this](const WindowParams &Pq, std::vector<FrameMoments> &m) { LidarEval(Pq, m); };
+  R.ms_prepare = now_ms() - t_prep0;
+  // group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984)
+  {
+    Layout lay = WindowSystem::solve_layout(P);
+    WindowSystem::Costs gc = sys.evaluate(P, lay, 1 | 2 | 4, false, nullptr, nullptr);
+    R.cost_pim_before = gc.pim; R.cost_ppp_before = gc.ppp; R.cost_marg_before = gc.marg;
+    if (cfg_.imu_factor) turn_off = gc.pim > 1e3;
+    const double ratio = gc.marg / (gc.ppp + gc.pim);
+    if (!convergence_flag_ && !turn_off && ratio <= 2 && ratio != 0) convergence_flag_ = true;
+    if (!convergence_flag_) {
+      P.ex_constant = true;
+      last_marg_.reset();
+      sys.prior.reset();
+    }
+  }
+  // lidar slot count for the report
+  {
+    int nres = 0;
+    if (cfg_.point_distance_factor) {
+      std::vector<FrameMoments> m(Wo_ + 1);
+      // counts come back with every evaluation; take them from the first linearisation below
+      (void)m;
+    }
+    R.n_lidar_residuals = nres;
+  }
+  const double t_opt0 = now_ms();
+  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, cfg_.max_solver_time);
+  R.ms_opt = now_ms() - t_opt0;
+  R.iterations = s.iterations; R.successful_steps = s.successful; R.termination = s.termination;
+  R.initial_cost = s.initial_cost; R.final_cost = s.final_cost;
+  for (size_t k = 0; k < s.trace.size() && k < 32; ++k) R.cost_trace[k] = s.trace[k];
+  ParamsToVector(P);
+  R.turn_off = turn_off; R.convergence_flag = convergence_flag_;
+  if (cfg_.marginalization_factor && !turn_off) {
+    const double tm0 = now_ms();
+    WindowParams M;
+    VectorToParams(M);
+    M.ex_constant = false;
+    WindowSystem msys;
+    msys.Wo = Wo_;
+    msys.use_lidar = cfg_.point_distance_factor;
+    msys.pim.assign(Wo_, nullptr);
+    if (cfg_.imu_factor) {
+      auto &pi = pre_integrations_[pivot + 1];
+      if (pi && pi->sum_dt < 10.0) msys.pim[0] = pi;
+    }
+    msys.prior = last_marg_;
+    msys.lidar_eval = sys.lidar_eval;
+    last_marg_ = marginalize(msys, M);
+    R.marginalized = 1;
+    R.ms_marg = now_ms() - tm0;
+  }
+  // residual count of the last device evaluation (valid feature slots of frames 1..Wo)
+  {
+    double cnt = 0;
+    for (int i = 1; i <= Wo_; ++i) cnt += h_moment_out_[size_t(i - 1) * LIO_MOMENT_OUT + 257];
+    R.n_lidar_residuals = cfg_.point_distance_factor ? int(cnt) : 0;
+  }
+  R.ms_total = now_ms() - t_total0;
+  return true;
+}
+
+void Estimator::SlideWindow() {
+  if (init_local_map_) {
+    const int pivot = W_ - Wo_;
+    const Rigidd lb = toDouble(transform_lb_);
+    const Rigidd T_pivot = LidarPose(pivot, lb);
+    const int i = pivot + 1;
+    const Rigidd T_li = LidarPose(i, lb);
+    const Rigidf tf = toFloat(compose(rinverse(T_li), T_pivot));
+    const size_t drop = std::min(size_surf_stack_[0], stacks_[pivot].n);
+    ConcatArgs ca{};
+    ca.nseg = 2;
+    ca.seg[0].src = stacks_[pivot].buf.p + drop; ca.seg[0].n = int(stacks_[pivot].n - drop); ca.seg[0].dst_off = 0;
+    ca.seg[0].identity = 0; ca.seg[0].set_intensity = 0; ca.seg[0].intensity = 0; ca.seg[0].tf = affineOf(tf);
+    ca.seg[1].src = stacks_[i].buf.p; ca.seg[1].n = int(stacks_[i].n); ca.seg[1].dst_off = ca.seg[0].n;
+    ca.seg[1].identity = 1; ca.seg[1].set_intensity = 0; ca.seg[1].intensity = 0;
+    ca.total = ca.seg[0].n + ca.seg[1].n;
+    scratch_cloud_.buf.reserve(std::max(ca.total, 1));
+    launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
+    scratch_cloud_.n = size_t(ca.total);
+    LIO_HIP(hipStreamSynchronize(stream_));
+    std::swap(stacks_[i], scratch_cloud_);
+  }
+  push_full(Ps_, Ps_[cir_buf_count_]); push_full(Vs_, Vs_[cir_buf_count_]); push_full(Rs_, Rs_[cir_buf_count_]);
+  push_full(Bas_, Bas_[cir_buf_count_]); push_full(Bgs_, Bgs_[cir_buf_count_]);
+}
+
+void Estimator::Snapshot() {
+  snap_.reset(new HostState{Ps_, Vs_, Bas_, Bgs_, Rs_, g_vec_, acc_last_, gyr_last_, transform_lb_, inited_, first_imu_, init_local_map_,
+                            convergence_flag_, cir_buf_count_, last_marg_, pre_integrations_,
+                            tmp_pre_integration_ ? std::make_shared<Preintegration>(*tmp_pre_integration_) : nullptr, size_surf_stack_,
+                            imu_stamped_});
+  snap_stacks_.resize(stacks_.size());
+  for (size_t i = 0; i < stacks_.size(); ++i) {
+    snap_stacks_[i].buf.reserve(std::max<size_t>(stacks_[i].n, 1));
+    if (stacks_[i].n)
+      LIO_HIP(hipMemcpyAsync(snap_stacks_[i].buf.p, stacks_[i].buf.p, stacks_[i].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    snap_stacks_[i].n = stacks_[i].n;
+  }
+  LIO_HIP(hipStreamSynchronize(stream_));
+}
+
+bool Estimator::Restore() {
+  if (!snap_) return false;
+  const HostState &h = *snap_;
+  Ps_ = h.Ps; Vs_ = h.Vs; Bas_ = h.Bas; Bgs_ = h.Bgs; Rs_ = h.Rs; g_vec_ = h.g_vec; acc_last_ = h.acc_last; gyr_last_ = h.gyr_last;
+  transform_lb_ = h.transform_lb; inited_ = h.inited; first_imu_ = h.first_imu; init_local_map_ = h.init_local_map;
+  convergence_flag_ = h.convergence_flag; cir_buf_count_ = h.cir_buf_count; last_marg_ = h.last_marg; pre_integrations_ = h.pre_integrations;
+  tmp_pre_integration_ = h.tmp_pre_integration ? std::make_shared<Preintegration>(*h.tmp_pre_integration) : nullptr;
+  size_surf_stack_ = h.size_surf_stack; imu_stamped_ = h.imu_stamped;
+  for (size_t i = 0; i < stacks_.size(); ++i) {
+    stacks_[i].buf.reserve(std::max<size_t>(snap_stacks_[i].n, 1));
+    if (snap_stacks_[i].n)
+      LIO_HIP(hipMemcpyAsync(stacks_[i].buf.p, snap_stacks_[i].buf.p, snap_stacks_[i].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    stacks_[i].n = snap_stacks_[i].n;
+  }
+  LIO_HIP(hipStreamSynchronize(stream_));
+  return true;
+}
+
+}  // namespace lio

@@ -1,0 +1,204 @@
+// hlinalg.h — host-side dense linear algebra for the small systems of the solve (D <= 246, n <= 120):
+// Cholesky, Gauss-Jordan inverse, symmetric eigendecomposition (Householder tridiagonalisation +
+// implicit-shift QL).  Row-major double.  These replace the Eigen calls at ImuFactor.h:74-75 and
+// MarginalizationFactor.cc:276-302 and Ceres' dense solve (Estimator.cc:1911).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace lio {
+
+struct DMat {
+  int r = 0, c = 0;
+  std::vector<double> a;
+  DMat() = default;
+  DMat(int r_, int c_) : r(r_), c(c_), a(size_t(r_) * size_t(c_), 0.0) {}
+  double &operator()(int i, int j) { return a[size_t(i) * c + j]; }
+  double operator()(int i, int j) const { return a[size_t(i) * c + j]; }
+  void zero() { std::fill(a.begin(), a.end(), 0.0); }
+};
+
+// In-place lower Cholesky of the leading n x n of A (row-major, stride lda).  false on a non-positive pivot.
+inline bool chol_factor(double *A, int n, int lda) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * lda + j];
+    for (int k = 0; k < j; ++k) d -= A[j * lda + k] * A[j * lda + k];
+    if (!(d > 0.0)) return false;
+    double l = std::sqrt(d);
+    A[j * lda + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i * lda + j];
+      const double *ri = A + i * lda, *rj = A + j * lda;
+      for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+      A[i * lda + j] = s / l;
+    }
+  }
+  return true;
+}
+inline void chol_solve_inplace(const double *L, int n, int lda, double *b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i * lda + k] * b[k];
+    b[i] = s / L[i * lda + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * lda + i] * b[k];
+    b[i] = s / L[i * lda + i];
+  }
+}
+
+// Gauss-Jordan inverse with partial pivoting, n x n.
+inline bool gj_inverse(const double *Ain, int n, double *Ainv) {
+  std::vector<double> M(Ain, Ain + size_t(n) * n);
+  for (int i = 0; i < n * n; ++i) Ainv[i] = 0;
+  for (int i = 0; i < n; ++i) Ainv[i * n + i] = 1;
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    double best = std::fabs(M[col * n + col]);
+    for (int i = col + 1; i < n; ++i)
+      if (std::fabs(M[i * n + col]) > best) { best = std::fabs(M[i * n + col]); piv = i; }
+    if (best == 0.0) return false;
+    if (piv != col)
+      for (int j = 0; j < n; ++j) { std::swap(M[piv * n + j], M[col * n + j]); std::swap(Ainv[piv * n + j], Ainv[col * n + j]); }
+    double d = M[col * n + col];
+    for (int j = 0; j < n; ++j) { M[col * n + j] /= d; Ainv[col * n + j] /= d; }
+    for (int i = 0; i < n; ++i) {
+      if (i == col) continue;
+      double f = M[i * n + col];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; ++j) { M[i * n + j] -= f * M[col * n + j]; Ainv[i * n + j] -= f * Ainv[col * n + j]; }
+    }
+  }
+  return true;
+}
+
+// Symmetric eigendecomposition: A (n x n, symmetric) -> eigenvalues ascending in w, eigenvectors as the
+// COLUMNS of V (row-major n x n).  Householder reduction to tridiagonal form followed by the implicit
+// QL algorithm (the classical tred2/tql2 pair).
+inline bool sym_eig(const double *A, int n, double *w, double *V) {
+  std::vector<double> e(n, 0.0);
+  for (int i = 0; i < n * n; ++i) V[i] = A[i];
+  double *d = w;
+  // --- tred2
+  for (int j = 0; j < n; ++j) d[j] = V[(n - 1) * n + j];
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0.0, h = 0.0;
+    for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+    if (scale == 0.0) {
+      e[i] = d[i - 1];
+      for (int j = 0; j < i; ++j) { d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0; V[j * n + i] = 0.0; }
+    } else {
+      for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+      double f = d[i - 1];
+      double g = std::sqrt(h);
+      if (f > 0) g = -g;
+      e[i] = scale * g;
+      h -= f * g;
+      d[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0.0;
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        V[j * n + i] = f;
+        g = e[j] + V[j * n + j] * f;
+        for (int k = j + 1; k <= i - 1; ++k) { g += V[k * n + j] * d[k]; e[k] += V[k * n + j] * f; }
+        e[j] = g;
+      }
+      f = 0.0;
+      for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+      double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+      for (int j = 0; j < i; ++j) {
+        f = d[j]; g = e[j];
+        for (int k = j; k <= i - 1; ++k) V[k * n + j] -= (f * e[k] + g * d[k]);
+        d[j] = V[(i - 1) * n + j];
+        V[i * n + j] = 0.0;
+      }
+    }
+    d[i] = h;
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    V[(n - 1) * n + i] = V[i * n + i];
+    V[i * n + i] = 1.0;
+    double h = d[i + 1];
+    if (h != 0.0) {
+      for (int k = 0; k <= i; ++k) d[k] = V[k * n + i + 1] / h;
+      for (int j = 0; j <= i; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= i; ++k) g += V[k * n + i + 1] * V[k * n + j];
+        for (int k = 0; k <= i; ++k) V[k * n + j] -= g * d[k];
+      }
+    }
+    for (int k = 0; k <= i; ++k) V[k * n + i + 1] = 0.0;
+  }
+  for (int j = 0; j < n; ++j) { d[j] = V[(n - 1) * n + j]; V[(n - 1) * n + j] = 0.0; }
+  V[(n - 1) * n + n - 1] = 1.0;
+  e[0] = 0.0;
+  // --- tql2
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  double f = 0.0, tst1 = 0.0;
+  const double eps = std::pow(2.0, -52.0);
+  for (int l = 0; l < n; ++l) {
+    tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+    int m = l;
+    while (m < n) {
+      if (std::fabs(e[m]) <= eps * tst1) break;
+      ++m;
+    }
+    if (m > l) {
+      int iter = 0;
+      do {
+        if (++iter > 200) return false;
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2.0 * e[l]);
+        double r = std::hypot(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        f += h;
+        p = d[m];
+        double c = 1.0, c2 = c, c3 = c, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2; c2 = c; s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = std::hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          for (int k = 0; k < n; ++k) {
+            h = V[k * n + i + 1];
+            V[k * n + i + 1] = s * V[k * n + i] + c * h;
+            V[k * n + i] = c * V[k * n + i] - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst1);
+    }
+    d[l] = d[l] + f;
+    e[l] = 0.0;
+  }
+  // sort ascending
+  for (int i = 0; i < n - 1; ++i) {
+    int k = i;
+    double p = d[i];
+    for (int j = i + 1; j < n; ++j)
+      if (d[j] < p) { k = j; p = d[j]; }
+    if (k != i) {
+      d[k] = d[i]; d[i] = p;
+      for (int j = 0; j < n; ++j) std::swap(V[j * n + i], V[j * n + k]);
+    }
+  }
+  return true;
+}
+
+}  // namespace lio

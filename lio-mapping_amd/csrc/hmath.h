@@ -1,0 +1,300 @@
+// hmath.h — small fixed-size math shared by the host side and the HIP kernels of the product.
+//
+// Semantics follow the reference's use of Eigen (quaternion product order, v + 2w(u x v) + 2u x (u x v)
+// rotation, Shepperd matrix->quaternion, unnormalised DeltaQ; include/utils/math_utils.h:116-185,
+// include/utils/Twist.h:39-97) so that fp32 feature extraction reproduces the same operation order
+// as a CPU run of the reference built without FMA contraction.  Compile with -ffp-contract=off.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LIO_HD __host__ __device__ inline
+#else
+#define LIO_HD inline
+#endif
+
+namespace lio {
+
+template <typename T>
+struct Vec3 {
+  T x, y, z;
+  LIO_HD Vec3() : x(0), y(0), z(0) {}
+  LIO_HD Vec3(T a, T b, T c) : x(a), y(b), z(c) {}
+  LIO_HD T operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+  LIO_HD T &at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+template <typename T> LIO_HD Vec3<T> operator+(const Vec3<T> &a, const Vec3<T> &b) { return Vec3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> LIO_HD Vec3<T> operator-(const Vec3<T> &a, const Vec3<T> &b) { return Vec3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> LIO_HD Vec3<T> operator-(const Vec3<T> &a) { return Vec3<T>(-a.x, -a.y, -a.z); }
+template <typename T> LIO_HD Vec3<T> operator*(const Vec3<T> &a, T s) { return Vec3<T>(a.x * s, a.y * s, a.z * s); }
+template <typename T> LIO_HD Vec3<T> operator*(T s, const Vec3<T> &a) { return Vec3<T>(a.x * s, a.y * s, a.z * s); }
+template <typename T> LIO_HD Vec3<T> operator/(const Vec3<T> &a, T s) { return Vec3<T>(a.x / s, a.y / s, a.z / s); }
+template <typename T> LIO_HD T dot(const Vec3<T> &a, const Vec3<T> &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> LIO_HD Vec3<T> cross(const Vec3<T> &a, const Vec3<T> &b) {
+  return Vec3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename T> LIO_HD T norm(const Vec3<T> &a) { return sqrt(dot(a, a)); }
+
+template <typename T>
+struct Mat3 {
+  T m[9];  // row-major
+  LIO_HD Mat3() { for (int i = 0; i < 9; ++i) m[i] = 0; }
+  LIO_HD static Mat3 identity() { Mat3 r; r.m[0] = r.m[4] = r.m[8] = 1; return r; }
+  LIO_HD T operator()(int i, int j) const { return m[3 * i + j]; }
+  LIO_HD T &operator()(int i, int j) { return m[3 * i + j]; }
+};
+template <typename T> LIO_HD Mat3<T> operator*(const Mat3<T> &a, const Mat3<T> &b) {
+  Mat3<T> r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      T s = a(i, 0) * b(0, j);
+      s += a(i, 1) * b(1, j);
+      s += a(i, 2) * b(2, j);
+      r(i, j) = s;
+    }
+  return r;
+}
+template <typename T> LIO_HD Vec3<T> operator*(const Mat3<T> &a, const Vec3<T> &v) {
+  return Vec3<T>(a(0, 0) * v.x + a(0, 1) * v.y + a(0, 2) * v.z, a(1, 0) * v.x + a(1, 1) * v.y + a(1, 2) * v.z,
+                 a(2, 0) * v.x + a(2, 1) * v.y + a(2, 2) * v.z);
+}
+template <typename T> LIO_HD Mat3<T> operator*(const Mat3<T> &a, T s) { Mat3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] * s; return r; }
+template <typename T> LIO_HD Mat3<T> operator+(const Mat3<T> &a, const Mat3<T> &b) { Mat3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] + b.m[i]; return r; }
+template <typename T> LIO_HD Mat3<T> operator-(const Mat3<T> &a, const Mat3<T> &b) { Mat3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] - b.m[i]; return r; }
+template <typename T> LIO_HD Mat3<T> operator-(const Mat3<T> &a) { Mat3<T> r; for (int i = 0; i < 9; ++i) r.m[i] = -a.m[i]; return r; }
+template <typename T> LIO_HD Mat3<T> transpose(const Mat3<T> &a) { Mat3<T> r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = a(j, i); return r; }
+template <typename T> LIO_HD T trace(const Mat3<T> &a) { return a(0, 0) + a(1, 1) + a(2, 2); }
+template <typename T> LIO_HD Mat3<T> skew(const Vec3<T> &v) {
+  Mat3<T> s;
+  s(0, 1) = -v.z; s(0, 2) = v.y; s(1, 0) = v.z; s(1, 2) = -v.x; s(2, 0) = -v.y; s(2, 1) = v.x;
+  return s;
+}
+// v^T M as a vector
+template <typename T> LIO_HD Vec3<T> rowmul(const Vec3<T> &v, const Mat3<T> &M) {
+  return Vec3<T>(v.x * M(0, 0) + v.y * M(1, 0) + v.z * M(2, 0), v.x * M(0, 1) + v.y * M(1, 1) + v.z * M(2, 1),
+                 v.x * M(0, 2) + v.y * M(1, 2) + v.z * M(2, 2));
+}
+// cofactor inverse (Affine::inverse() on a 3x3 linear part)
+template <typename T> LIO_HD Mat3<T> inverse(const Mat3<T> &a) {
+  Mat3<T> c;
+  c(0, 0) = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+  c(0, 1) = a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2);
+  c(0, 2) = a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1);
+  c(1, 0) = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
+  c(1, 1) = a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0);
+  c(1, 2) = a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2);
+  c(2, 0) = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  c(2, 1) = a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1);
+  c(2, 2) = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+  T det = a(0, 0) * c(0, 0) + a(0, 1) * c(1, 0) + a(0, 2) * c(2, 0);
+  return c * (T(1) / det);
+}
+
+template <typename T>
+struct Quat {
+  T x, y, z, w;
+  LIO_HD Quat() : x(0), y(0), z(0), w(1) {}
+  LIO_HD Quat(T w_, T x_, T y_, T z_) : x(x_), y(y_), z(z_), w(w_) {}
+  LIO_HD Vec3<T> vec() const { return Vec3<T>(x, y, z); }
+};
+template <typename T> LIO_HD Quat<T> operator*(const Quat<T> &a, const Quat<T> &b) {
+  return Quat<T>(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                 a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+template <typename T> LIO_HD Quat<T> conj(const Quat<T> &q) { return Quat<T>(q.w, -q.x, -q.y, -q.z); }
+template <typename T> LIO_HD T sqnorm(const Quat<T> &q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+template <typename T> LIO_HD Quat<T> normalized(const Quat<T> &q) {
+  T n2 = sqnorm(q);
+  if (n2 > T(0)) { T n = sqrt(n2); return Quat<T>(q.w / n, q.x / n, q.y / n, q.z / n); }
+  return q;
+}
+template <typename T> LIO_HD Quat<T> qinverse(const Quat<T> &q) {
+  T n2 = sqnorm(q);
+  if (n2 > T(0)) return Quat<T>(q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2);
+  return Quat<T>(0, 0, 0, 0);
+}
+// rotate: v + w*(2 u x v) + u x (2 u x v)
+template <typename T> LIO_HD Vec3<T> rotate(const Quat<T> &q, const Vec3<T> &v) {
+  Vec3<T> u = q.vec();
+  Vec3<T> uv = cross(u, v);
+  uv = uv + uv;
+  Vec3<T> a = v + uv * q.w;
+  return a + cross(u, uv);
+}
+template <typename T> LIO_HD Mat3<T> toRot(const Quat<T> &q) {
+  Mat3<T> r;
+  const T tx = T(2) * q.x, ty = T(2) * q.y, tz = T(2) * q.z;
+  const T twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const T txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const T tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  r(0, 0) = T(1) - (tyy + tzz); r(0, 1) = txy - twz;          r(0, 2) = txz + twy;
+  r(1, 0) = txy + twz;          r(1, 1) = T(1) - (txx + tzz); r(1, 2) = tyz - twx;
+  r(2, 0) = txz - twy;          r(2, 1) = tyz + twx;          r(2, 2) = T(1) - (txx + tyy);
+  return r;
+}
+template <typename T> LIO_HD Quat<T> fromRot(const Mat3<T> &m) {
+  Quat<T> q;
+  T t = trace(m);
+  if (t > T(0)) {
+    t = sqrt(t + T(1));
+    q.w = T(0.5) * t;
+    t = T(0.5) / t;
+    q.x = (m(2, 1) - m(1, 2)) * t;
+    q.y = (m(0, 2) - m(2, 0)) * t;
+    q.z = (m(1, 0) - m(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (m(1, 1) > m(0, 0)) i = 1;
+    if (m(2, 2) > m(i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m(i, i) - m(j, j) - m(k, k) + T(1));
+    T c[3];
+    c[i] = T(0.5) * t;
+    t = T(0.5) / t;
+    q.w = (m(k, j) - m(j, k)) * t;
+    c[j] = (m(j, i) + m(i, j)) * t;
+    c[k] = (m(k, i) + m(i, k)) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+template <typename T> LIO_HD Quat<T> deltaQ(const Vec3<T> &th) { return Quat<T>(T(1), th.x / T(2), th.y / T(2), th.z / T(2)); }
+
+template <typename T> LIO_HD Quat<T> slerp(const Quat<T> &a, T t, const Quat<T> &b, T eps) {
+  const T one = T(1) - eps;
+  T d = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  T ad = fabs(d);
+  T s0, s1;
+  if (ad >= one) { s0 = T(1) - t; s1 = t; }
+  else {
+    T th = acos(ad);
+    T st = sin(th);
+    s0 = sin((T(1) - t) * th) / st;
+    s1 = sin((t * th)) / st;
+  }
+  if (d < T(0)) s1 = -s1;
+  return Quat<T>(s0 * a.w + s1 * b.w, s0 * a.x + s1 * b.x, s0 * a.y + s1 * b.y, s0 * a.z + s1 * b.z);
+}
+
+// Rigid transform as Twist<T> (rotation + translation) with the reference's composition rules.
+template <typename T>
+struct Rigid {
+  Quat<T> rot;
+  Vec3<T> pos;
+  LIO_HD Rigid() {}
+  LIO_HD Rigid(const Quat<T> &r, const Vec3<T> &p) : rot(r), pos(p) {}
+};
+template <typename T> LIO_HD Mat3<T> linearOf(const Rigid<T> &t) { return toRot(normalized(t.rot)); }
+template <typename T> LIO_HD Rigid<T> fromAffine(const Mat3<T> &lin, const Vec3<T> &tr) { return Rigid<T>(normalized(fromRot(lin)), tr); }
+template <typename T> LIO_HD Rigid<T> rinverse(const Rigid<T> &t) {
+  Mat3<T> li = inverse(linearOf(t));
+  return Rigid<T>(fromRot(li), -(li * t.pos));
+}
+template <typename T> LIO_HD Rigid<T> compose(const Rigid<T> &a, const Rigid<T> &b) {
+  Mat3<T> la = linearOf(a), lb = linearOf(b);
+  return fromAffine(la * lb, la * b.pos + a.pos);
+}
+
+// 5x3 / 6x6 column-pivoted Householder QR solve in scalar type T (m <= 6, n <= 6).
+// A row-major m x n (destroyed), b (destroyed), x out.
+template <typename T, int M, int N>
+LIO_HD void qr_solve(T *A, T *b, T *x, T eps) {
+  int perm[N];
+  for (int j = 0; j < N; ++j) perm[j] = j;
+  T maxnorm0 = 0;
+  for (int j = 0; j < N; ++j) {
+    T s = 0;
+    for (int i = 0; i < M; ++i) s += A[i * N + j] * A[i * N + j];
+    maxnorm0 = s > maxnorm0 ? s : maxnorm0;
+  }
+  const T thresh = eps * eps * maxnorm0 * T(M);
+  int rank = 0;
+  const int steps = M < N ? M : N;
+  for (int k = 0; k < steps; ++k) {
+    int piv = k;
+    T best = -1;
+    for (int j = k; j < N; ++j) {
+      T s = 0;
+      for (int i = k; i < M; ++i) s += A[i * N + j] * A[i * N + j];
+      if (s > best) { best = s; piv = j; }
+    }
+    if (!(best > thresh)) break;
+    if (piv != k) {
+      for (int i = 0; i < M; ++i) { T tmp = A[i * N + piv]; A[i * N + piv] = A[i * N + k]; A[i * N + k] = tmp; }
+      int tp = perm[piv]; perm[piv] = perm[k]; perm[k] = tp;
+    }
+    T alpha = A[k * N + k];
+    T sigma = 0;
+    for (int i = k + 1; i < M; ++i) sigma += A[i * N + k] * A[i * N + k];
+    T normx = sqrt(alpha * alpha + sigma);
+    if (normx == T(0)) break;
+    T beta = (alpha >= T(0)) ? -normx : normx;
+    T v0 = alpha - beta;
+    T vtv = v0 * v0 + sigma;
+    if (vtv > T(0)) {
+      for (int j = k + 1; j < N; ++j) {
+        T s = v0 * A[k * N + j];
+        for (int i = k + 1; i < M; ++i) s += A[i * N + k] * A[i * N + j];
+        T f = T(2) * s / vtv;
+        A[k * N + j] -= f * v0;
+        for (int i = k + 1; i < M; ++i) A[i * N + j] -= f * A[i * N + k];
+      }
+      T s = v0 * b[k];
+      for (int i = k + 1; i < M; ++i) s += A[i * N + k] * b[i];
+      T f = T(2) * s / vtv;
+      b[k] -= f * v0;
+      for (int i = k + 1; i < M; ++i) b[i] -= f * A[i * N + k];
+    }
+    A[k * N + k] = beta;
+    for (int i = k + 1; i < M; ++i) A[i * N + k] = T(0);
+    ++rank;
+  }
+  T y[N];
+  for (int j = 0; j < N; ++j) y[j] = T(0);
+  for (int i = rank - 1; i >= 0; --i) {
+    T s = b[i];
+    for (int j = i + 1; j < rank; ++j) s -= A[i * N + j] * y[j];
+    y[i] = s / A[i * N + i];
+  }
+  for (int j = 0; j < N; ++j) x[perm[j]] = y[j];
+}
+
+// Cyclic-Jacobi eigenvalues of a symmetric NxN (N <= 6) matrix, ascending.  Accumulates in double.
+template <int N>
+LIO_HD void sym_eigvals(const float *Ain, float *evals) {
+  double A[N * N];
+  for (int i = 0; i < N * N; ++i) A[i] = double(Ain[i]);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < N; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        double apq = A[p * N + q];
+        if (apq == 0.0) continue;
+        double app = A[p * N + p], aqq = A[q * N + q];
+        double tau = (aqq - app) / (2.0 * apq);
+        double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < N; ++k) {
+          double akp = A[k * N + p], akq = A[k * N + q];
+          A[k * N + p] = c * akp - s * akq;
+          A[k * N + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < N; ++k) {
+          double apk = A[p * N + k], aqk = A[q * N + k];
+          A[p * N + k] = c * apk - s * aqk;
+          A[q * N + k] = s * apk + c * aqk;
+        }
+      }
+  }
+  double d[N];
+  for (int i = 0; i < N; ++i) d[i] = A[i * N + i];
+  for (int i = 0; i < N; ++i)
+    for (int j = i + 1; j < N; ++j)
+      if (d[j] < d[i]) { double t = d[i]; d[i] = d[j]; d[j] = t; }
+  for (int i = 0; i < N; ++i) evals[i] = float(d[i]);
+}
+
+}  // namespace lio

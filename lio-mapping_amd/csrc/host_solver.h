@@ -1,0 +1,481 @@
+// host_solver.h — host half of Estimator::SolveOptimization (Estimator.cc:1648-2438) in the product.
+//
+// The GPU returns, per optimised frame i, the 16x16 moment matrix S_i = sum rho' z z^T and the robust
+// cost (solve_kernels.hip).  Here:
+//   * L_i (18x13) / l_i (13) are read off ppp_factor at basis inputs, H_i = L S L^T, g_i = L S l;
+//   * the Wo IMU factors, the marginalization prior and the extrinsic prior are added on the host
+//     (a few 15x30 blocks: microseconds);
+//   * the trust-region loop is Ceres 1.14's TrustRegionMinimizer with the traditional dogleg strategy
+//     and Jacobi scaling, working from (H, g) only — every quantity Ceres forms from J (column norms,
+//     ||J v||^2, model cost change) is a quadratic form in H;
+//   * Marginalize(): Schur complement + sqrt factor, MarginalizationFactor.cc:185-311, canonical block
+//     order.
+#pragma once
+#include <array>
+#include <chrono>
+#include <functional>
+#include <memory>
+
+#include "host_factors.h"
+#include "solve_kernels.h"
+
+namespace lio {
+
+struct KeepBlock { int kind; int index; int size; int idx; };  // kind 0 pose, 1 speed-bias, 2 extrinsic
+
+struct MargPrior {
+  int n = 0;
+  std::vector<KeepBlock> keep;
+  std::vector<std::vector<double>> x0;
+  DMat lin_jac;                 // n x n
+  std::vector<double> lin_res;  // n
+  DMat JtJ;                     // cached lin_jac^T lin_jac
+  std::vector<double> Jtr0;     // cached lin_jac^T lin_res
+  void finalize() {
+    JtJ = DMat(n, n); Jtr0.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      for (int j = i; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += lin_jac(k, i) * lin_jac(k, j); JtJ(i, j) = s; JtJ(j, i) = s; }
+      double s = 0; for (int k = 0; k < n; ++k) s += lin_jac(k, i) * lin_res[k];
+      Jtr0[i] = s;
+    }
+  }
+};
+
+struct WindowParams {
+  int Wo = 0;
+  std::vector<std::array<double, 7>> pose;
+  std::vector<std::array<double, 9>> sb;
+  std::array<double, 7> ex{};
+  bool ex_constant = true;
+};
+
+struct Layout {
+  std::vector<int> pose, sb;
+  int ex = -1, dim = 0;
+};
+
+struct FrameMoments { double S[256]; double cost; double count; };
+
+// T_{pivot<-i} in fp64 from the parameter blocks (PivotPointPlaneFactor.cc:58-70)
+inline void relative_lidar_pose(const double *pose_p, const double *pose_i, const double *pose_ex, double R[9], double t[3]) {
+  V3d Pp, Pi, tlb; Qd Qp, Qi, qlb;
+  unpack_pose(pose_p, Pp, Qp); unpack_pose(pose_i, Pi, Qi); unpack_pose(pose_ex, tlb, qlb);
+  Qd Qlp = Qp * conj(qlb);
+  V3d Plp = Pp - rotate(Qlp, tlb);
+  Qd Qli = Qi * conj(qlb);
+  V3d Pli = Pi - rotate(Qli, tlb);
+  Qd Qlpi = conj(Qlp) * Qli;
+  V3d Plpi = rotate(conj(Qlp), Pli - Plp);
+  // rotate(q, v) for a (near-)unit q equals toRot(q) v up to rounding; the residual kernel needs a matrix.
+  // Build it column by column from rotate() so it is the SAME map the factor applies.
+  V3d c0 = rotate(Qlpi, V3d(1, 0, 0)), c1 = rotate(Qlpi, V3d(0, 1, 0)), c2 = rotate(Qlpi, V3d(0, 0, 1));
+  R[0] = c0.x; R[1] = c1.x; R[2] = c2.x; R[3] = c0.y; R[4] = c1.y; R[5] = c2.y; R[6] = c0.z; R[7] = c1.z; R[8] = c2.z;
+  t[0] = Plpi.x; t[1] = Plpi.y; t[2] = Plpi.z;
+}
+
+// L (18 x 13, row-major) and l (13): j = L z, r = l^T z, z = [w0*(p,1), w1*(p,1), w2*(p,1), d]
+inline void lidar_linear_maps(const double *pose_p, const double *pose_i, const double *pose_ex, double L[18 * 13], double l[13]) {
+  std::memset(L, 0, sizeof(double) * 18 * 13);
+  std::memset(l, 0, sizeof(double) * 13);
+  double j0[3][18], r0[3];
+  for (int a = 0; a < 3; ++a) {
+    double coeff[4] = {0, 0, 0, 0};
+    coeff[a] = 1.0;
+    double Jp[7], Ji[7], Jx[7];
+    ppp_factor(V3d(0, 0, 0), coeff, pose_p, pose_i, pose_ex, &r0[a], Jp, Ji, Jx);
+    for (int k = 0; k < 6; ++k) { j0[a][k] = Jp[k]; j0[a][6 + k] = Ji[k]; j0[a][12 + k] = Jx[k]; }
+    for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + 3] = j0[a][k];
+    l[4 * a + 3] = r0[a];
+    for (int b = 0; b < 3; ++b) {
+      V3d p(b == 0, b == 1, b == 2);
+      double r, Jp2[7], Ji2[7], Jx2[7];
+      ppp_factor(p, coeff, pose_p, pose_i, pose_ex, &r, Jp2, Ji2, Jx2);
+      for (int k = 0; k < 6; ++k) {
+        L[k * 13 + 4 * a + b] = Jp2[k] - j0[a][k];
+        L[(6 + k) * 13 + 4 * a + b] = Ji2[k] - j0[a][6 + k];
+        L[(12 + k) * 13 + 4 * a + b] = Jx2[k] - j0[a][12 + k];
+      }
+      l[4 * a + b] = r - r0[a];
+    }
+  }
+  l[12] = 1.0;
+}
+
+class WindowSystem {
+ public:
+  int Wo = 0;
+  std::vector<std::shared_ptr<Preintegration>> pim;  // [i] links opt i -> i+1 (null = skipped)
+  std::shared_ptr<MargPrior> prior;
+  bool use_prior_factor = false, use_lidar = true;
+  V3d prior_pos; Qd prior_rot;
+  // lidar evaluation on the device: fills m[1..Wo] for the given parameters
+  std::function<void(const WindowParams &, std::vector<FrameMoments> &)> lidar_eval;
+
+  struct Costs { double marg = 0, pim = 0, ppp = 0, prior = 0; double total() const { return marg + pim + ppp + prior; } };
+
+  static Layout solve_layout(const WindowParams &P) {
+    Layout l;
+    l.pose.resize(P.Wo + 1); l.sb.resize(P.Wo + 1);
+    for (int i = 0; i <= P.Wo; ++i) { l.pose[i] = 15 * i; l.sb[i] = 15 * i + 6; }
+    l.ex = P.ex_constant ? -1 : 15 * (P.Wo + 1);
+    l.dim = 15 * (P.Wo + 1) + (P.ex_constant ? 0 : 6);
+    return l;
+  }
+
+  static void add_block(DMat &H, std::vector<double> &g, const int *cols, const int *sizes, int nb, const double *Hb, const double *gb, int ld) {
+    // Hb: (sum sizes)^2 dense, gb: sum sizes; blocks with col < 0 are constants
+    int off_a = 0;
+    for (int a = 0; a < nb; off_a += sizes[a], ++a) {
+      if (cols[a] < 0) continue;
+      int off_b = 0;
+      for (int b = 0; b < nb; off_b += sizes[b], ++b) {
+        if (cols[b] < 0) continue;
+        for (int i = 0; i < sizes[a]; ++i)
+          for (int j = 0; j < sizes[b]; ++j) H(cols[a] + i, cols[b] + j) += Hb[(off_a + i) * ld + off_b + j];
+      }
+      for (int i = 0; i < sizes[a]; ++i) g[cols[a] + i] += gb[off_a + i];
+    }
+  }
+
+  // prior residual r = r0 + J0 dx  (MarginalizationFactor.cc:343-393); returns dx too
+  static void prior_dx(const MargPrior &pr, const WindowParams &P, std::vector<double> &dx) {
+    dx.assign(pr.n, 0.0);
+    for (size_t b = 0; b < pr.keep.size(); ++b) {
+      const KeepBlock &kb = pr.keep[b];
+      const double *x = kb.kind == 0 ? P.pose[kb.index].data() : (kb.kind == 1 ? P.sb[kb.index].data() : P.ex.data());
+      const double *x0 = pr.x0[b].data();
+      if (kb.size != 7) { for (int k = 0; k < kb.size; ++k) dx[kb.idx + k] = x[k] - x0[k]; }
+      else {
+        for (int k = 0; k < 3; ++k) dx[kb.idx + k] = x[k] - x0[k];
+        Qd q0(x0[6], x0[3], x0[4], x0[5]), q(x[6], x[3], x[4], x[5]);
+        Qd dq = qinverse(q0) * q;
+        V3d v = 2.0 * normalized(dq).vec();
+        if (dq.w < 0) v = -v;
+        for (int k = 0; k < 3; ++k) dx[kb.idx + 3 + k] = v[k];
+      }
+    }
+  }
+
+  // which: bit0 prior, bit1 imu, bit2 lidar, bit3 extrinsic prior.  H/g may be null (cost only).
+  Costs evaluate(const WindowParams &P, const Layout &lay, int which, bool imu_only_first, DMat *H, std::vector<double> *g) {
+    Costs c;
+    if (H) { *H = DMat(lay.dim, lay.dim); g->assign(lay.dim, 0.0); }
+    if ((which & 1) && prior) {
+      const MargPrior &pr = *prior;
+      std::vector<double> dx;
+      prior_dx(pr, P, dx);
+      // r = r0 + J0 dx;  cost = 0.5 |r|^2;  J^T r = Jtr0 + JtJ dx
+      double cost = 0;
+      for (int i = 0; i < pr.n; ++i) { double s = pr.lin_res[i]; for (int j = 0; j < pr.n; ++j) s += pr.lin_jac(i, j) * dx[j]; cost += s * s; }
+      c.marg = 0.5 * cost;
+      if (H) {
+        std::vector<double> gb(pr.n);
+        for (int i = 0; i < pr.n; ++i) { double s = pr.Jtr0[i]; for (int j = 0; j < pr.n; ++j) s += pr.JtJ(i, j) * dx[j]; gb[i] = s; }
+        for (size_t a = 0; a < pr.keep.size(); ++a) {
+          const KeepBlock &ka = pr.keep[a];
+          int ca = ka.kind == 0 ? lay.pose[ka.index] : (ka.kind == 1 ? lay.sb[ka.index] : lay.ex);
+          if (ca < 0) continue;
+          int la = ka.size == 7 ? 6 : ka.size;
+          for (size_t b = 0; b < pr.keep.size(); ++b) {
+            const KeepBlock &kb = pr.keep[b];
+            int cb = kb.kind == 0 ? lay.pose[kb.index] : (kb.kind == 1 ? lay.sb[kb.index] : lay.ex);
+            if (cb < 0) continue;
+            int lb = kb.size == 7 ? 6 : kb.size;
+            for (int i = 0; i < la; ++i) for (int j = 0; j < lb; ++j) (*H)(ca + i, cb + j) += pr.JtJ(ka.idx + i, kb.idx + j);
+          }
+          for (int i = 0; i < la; ++i) (*g)[ca + i] += gb[ka.idx + i];
+        }
+      }
+    }
+    if (which & 2) {
+      int last = imu_only_first ? 1 : Wo;
+      for (int i = 0; i < last; ++i) {
+        if (!pim[i]) continue;
+        double r[15], J0[105], J1[135], J2[105], J3[135];
+        imu_factor(*pim[i], P.pose[i].data(), P.sb[i].data(), P.pose[i + 1].data(), P.sb[i + 1].data(), r, H ? J0 : nullptr, H ? J1 : nullptr,
+                   H ? J2 : nullptr, H ? J3 : nullptr);
+        double cost = 0;
+        for (int k = 0; k < 15; ++k) cost += r[k] * r[k];
+        c.pim += 0.5 * cost;
+        if (H) {
+          double J[15 * 30];
+          for (int k = 0; k < 15; ++k) {
+            for (int q = 0; q < 6; ++q) { J[k * 30 + q] = J0[k * 7 + q]; J[k * 30 + 15 + q] = J2[k * 7 + q]; }
+            for (int q = 0; q < 9; ++q) { J[k * 30 + 6 + q] = J1[k * 9 + q]; J[k * 30 + 21 + q] = J3[k * 9 + q]; }
+          }
+          double Hb[900], gb[30];
+          for (int a = 0; a < 30; ++a) {
+            for (int b = a; b < 30; ++b) { double s = 0; for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b]; Hb[a * 30 + b] = s; Hb[b * 30 + a] = s; }
+            double s = 0; for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * r[k];
+            gb[a] = s;
+          }
+          int cols[4] = {lay.pose[i], lay.sb[i], lay.pose[i + 1], lay.sb[i + 1]}, sizes[4] = {6, 9, 6, 9};
+          add_block(*H, *g, cols, sizes, 4, Hb, gb, 30);
+        }
+      }
+    }
+    if ((which & 4) && use_lidar && lidar_eval) {
+      std::vector<FrameMoments> m(Wo + 1);
+      lidar_eval(P, m);
+      for (int i = 1; i <= Wo; ++i) {
+        c.ppp += m[i].cost;
+        if (!H || m[i].count == 0) continue;
+        double L[18 * 13], l[13];
+        lidar_linear_maps(P.pose[0].data(), P.pose[i].data(), P.ex.data(), L, l);
+        // S13 = leading 13x13 of the 16x16 moments
+        double LS[18 * 13], Hb[18 * 18], gb[18];
+        for (int a = 0; a < 18; ++a)
+          for (int b = 0; b < 13; ++b) { double s = 0; for (int k = 0; k < 13; ++k) s += L[a * 13 + k] * m[i].S[k * 16 + b]; LS[a * 13 + b] = s; }
+        for (int a = 0; a < 18; ++a) {
+          for (int b = 0; b < 18; ++b) { double s = 0; for (int k = 0; k < 13; ++k) s += LS[a * 13 + k] * L[b * 13 + k]; Hb[a * 18 + b] = s; }
+          double s = 0; for (int k = 0; k < 13; ++k) s += LS[a * 13 + k] * l[k];
+          gb[a] = s;
+        }
+        int cols[3] = {lay.pose[0], lay.pose[i], lay.ex}, sizes[3] = {6, 6, 6};
+        add_block(*H, *g, cols, sizes, 3, Hb, gb, 18);
+      }
+    }
+    if ((which & 8) && use_prior_factor) {
+      double r[6], J[42];
+      prior_factor(prior_pos, prior_rot, P.ex.data(), r, H ? J : nullptr);
+      double cost = 0;
+      for (int k = 0; k < 6; ++k) cost += r[k] * r[k];
+      c.prior = 0.5 * cost;
+      if (H && lay.ex >= 0) {
+        double Hb[36], gb[6];
+        for (int a = 0; a < 6; ++a) {
+          for (int b = 0; b < 6; ++b) { double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * J[k * 7 + b]; Hb[a * 6 + b] = s; }
+          double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * r[k];
+          gb[a] = s;
+        }
+        int cols[1] = {lay.ex}, sizes[1] = {6};
+        add_block(*H, *g, cols, sizes, 1, Hb, gb, 6);
+      }
+    }
+    return c;
+  }
+};
+
+struct SolveSummary {
+  int iterations = 0, successful = 0, termination = 0;
+  double initial_cost = 0, final_cost = 0;
+  std::vector<double> trace;
+  WindowSystem::Costs initial_costs;
+};
+
+inline void plus_all(const WindowParams &P, const Layout &lay, const std::vector<double> &delta, WindowParams &out) {
+  out = P;
+  for (int i = 0; i <= P.Wo; ++i) {
+    pose_plus(P.pose[i].data(), &delta[lay.pose[i]], out.pose[i].data());
+    for (int k = 0; k < 9; ++k) out.sb[i][k] = P.sb[i][k] + delta[lay.sb[i] + k];
+  }
+  if (lay.ex >= 0) pose_plus(P.ex.data(), &delta[lay.ex], out.ex.data());
+}
+inline double ambient_norm(const WindowParams &P, const WindowParams *o, double *maxabs = nullptr) {
+  double s = 0, mx = 0;
+  auto acc = [&](const double *a, const double *b, int n) {
+    for (int k = 0; k < n; ++k) { double d = b ? a[k] - b[k] : a[k]; s += d * d; mx = std::max(mx, std::fabs(d)); }
+  };
+  for (int i = 0; i <= P.Wo; ++i) { acc(P.pose[i].data(), o ? o->pose[i].data() : nullptr, 7); acc(P.sb[i].data(), o ? o->sb[i].data() : nullptr, 9); }
+  if (!P.ex_constant) acc(P.ex.data(), o ? o->ex.data() : nullptr, 7);
+  if (maxabs) *maxabs = mx;
+  return std::sqrt(s);
+}
+
+// Ceres 1.14 TrustRegionMinimizer + DoglegStrategy (TRADITIONAL_DOGLEG), jacobi_scaling = true.
+// first_eval (optional) lets the caller reuse the linearisation it already made for the group costs.
+inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_iterations, double max_time_s) {
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  SolveSummary sum;
+  const int which = 1 | 2 | 4 | 8;
+  Layout lay = WindowSystem::solve_layout(P);
+  const int n = lay.dim;
+  DMat H; std::vector<double> g;
+  WindowSystem::Costs c0 = sys.evaluate(P, lay, which, false, &H, &g);
+  sum.initial_costs = c0;
+  double x_cost = c0.total();
+  sum.initial_cost = x_cost; sum.trace.push_back(x_cost);
+  std::vector<double> scale(n);
+  for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H(i, i)));
+  auto grad_max = [&](const std::vector<double> &gu) {
+    std::vector<double> neg(n);
+    for (int i = 0; i < n; ++i) neg[i] = -gu[i];
+    WindowParams Pp; plus_all(P, lay, neg, Pp);
+    double mx = 0; ambient_norm(P, &Pp, &mx);
+    return mx;
+  };
+  auto apply_scale = [&](DMat &Hs, std::vector<double> &gs) {
+    for (int i = 0; i < n; ++i) { gs[i] *= scale[i]; double si = scale[i]; double *row = &Hs.a[size_t(i) * n]; for (int j = 0; j < n; ++j) row[j] *= si * scale[j]; }
+  };
+  double gmax = grad_max(g);
+  apply_scale(H, g);
+  double x_norm = ambient_norm(P, nullptr);
+  double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
+  const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
+  bool reuse = false;
+  std::vector<double> diag(n), grad(n), gn(n), step(n), tmp(n);
+  std::vector<double> A(size_t(n) * n);
+  int invalid = 0, it = 0;
+  while (true) {
+    if (it >= max_iterations) { sum.termination = 0; break; }
+    if (max_time_s > 0 && std::chrono::duration<double>(clock::now() - t0).count() >= max_time_s) { sum.termination = 4; break; }
+    if (gmax <= 1e-10) { sum.termination = 3; break; }
+    if (radius <= 1e-32) { sum.termination = 1; break; }
+    ++it;
+    bool lin_ok = true;
+    if (!reuse) {
+      reuse = true;
+      for (int i = 0; i < n; ++i) diag[i] = std::sqrt(std::min(std::max(H(i, i), 1e-6), 1e32));
+      double g2 = 0, Jg2 = 0;
+      for (int i = 0; i < n; ++i) { grad[i] = g[i] / diag[i]; tmp[i] = grad[i] / diag[i]; g2 += grad[i] * grad[i]; }
+      for (int i = 0; i < n; ++i) { double s = 0; const double *row = &H.a[size_t(i) * n]; for (int j = 0; j < n; ++j) s += row[j] * tmp[j]; Jg2 += tmp[i] * s; }
+      alpha = g2 / Jg2;
+      lin_ok = false;
+      while (mu < max_mu) {
+        A = H.a;
+        for (int i = 0; i < n; ++i) A[size_t(i) * n + i] += diag[i] * diag[i] * mu;
+        bool ok = chol_factor(A.data(), n, n);
+        if (ok) {
+          gn = g;
+          chol_solve_inplace(A.data(), n, n, gn.data());
+          for (int i = 0; i < n; ++i) if (!std::isfinite(gn[i])) ok = false;
+        }
+        if (!ok) { mu *= mu_inc; continue; }
+        lin_ok = true;
+        break;
+      }
+      if (lin_ok) for (int i = 0; i < n; ++i) gn[i] *= -diag[i];
+    }
+    bool valid = lin_ok;
+    double model_change = 0;
+    if (lin_ok) {
+      double gnorm = 0, gnn = 0, gdot = 0;
+      for (int i = 0; i < n; ++i) { gnorm += grad[i] * grad[i]; gnn += gn[i] * gn[i]; gdot += grad[i] * gn[i]; }
+      gnorm = std::sqrt(gnorm); gnn = std::sqrt(gnn);
+      if (gnn <= radius) { step = gn; dogleg_norm = gnn; }
+      else if (gnorm * alpha >= radius) { for (int i = 0; i < n; ++i) step[i] = -(radius / gnorm) * grad[i]; dogleg_norm = radius; }
+      else {
+        const double b_dot_a = -alpha * gdot, a_sq = std::pow(alpha * gnorm, 2.0);
+        const double bma = a_sq - 2 * b_dot_a + std::pow(gnn, 2);
+        const double cc = b_dot_a - a_sq;
+        const double d = std::sqrt(cc * cc + bma * (std::pow(radius, 2.0) - a_sq));
+        const double beta = (cc <= 0) ? (d - cc) / bma : (radius * radius - a_sq) / (d + cc);
+        double sn = 0;
+        for (int i = 0; i < n; ++i) { step[i] = (-alpha * (1.0 - beta)) * grad[i] + beta * gn[i]; sn += step[i] * step[i]; }
+        dogleg_norm = std::sqrt(sn);
+      }
+      double sg = 0, sHs = 0;
+      for (int i = 0; i < n; ++i) step[i] /= diag[i];
+      for (int i = 0; i < n; ++i) { double s = 0; const double *row = &H.a[size_t(i) * n]; for (int j = 0; j < n; ++j) s += row[j] * step[j]; sHs += step[i] * s; sg += step[i] * g[i]; }
+      model_change = -(sg + 0.5 * sHs);
+      if (!(model_change > 0)) valid = false;
+    }
+    if (!valid) {
+      if (++invalid >= 5) { sum.termination = 5; break; }
+      mu *= mu_inc; reuse = false;
+      sum.trace.push_back(x_cost);
+      continue;
+    }
+    invalid = 0;
+    std::vector<double> delta(n);
+    for (int i = 0; i < n; ++i) delta[i] = step[i] * scale[i];
+    WindowParams cand;
+    plus_all(P, lay, delta, cand);
+    // Evaluate cost AND linearisation at the candidate in one device pass: if the step is accepted the
+    // Jacobian evaluation Ceres performs next (HandleSuccessfulStep) is already done.
+    DMat Hc; std::vector<double> gc;
+    double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc).total();
+    double step_norm = ambient_norm(P, &cand);
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 1; sum.trace.push_back(x_cost); break; }
+    double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= 1e-6 * x_cost) { sum.termination = 2; sum.trace.push_back(x_cost); break; }
+    double rho = cost_change / model_change;
+    if (rho > 1e-3) {
+      P = cand;
+      x_norm = ambient_norm(P, nullptr);
+      x_cost = cand_cost;
+      H = std::move(Hc); g = std::move(gc);
+      gmax = grad_max(g);
+      apply_scale(H, g);
+      ++sum.successful;
+      if (rho < 0.25) radius *= 0.5;
+      if (rho > 0.75) radius = std::max(radius, 3.0 * dogleg_norm);
+      mu = std::max(min_mu, 2.0 * mu / mu_inc);
+      reuse = false;
+    } else {
+      radius *= 0.5; reuse = true;
+    }
+    sum.trace.push_back(x_cost);
+  }
+  sum.iterations = it;
+  sum.final_cost = x_cost;
+  return sum;
+}
+
+// MarginalizationInfo::{PreMarginalize, Marginalize, GetParameterBlocks}.  `sys` must carry the OLD prior,
+// pim[0] (or null) and the lidar evaluator; P are the parameters after DoubleToVector/VectorToDouble.
+inline std::shared_ptr<MargPrior> marginalize(WindowSystem &sys, const WindowParams &Pin) {
+  const double eps = 1e-8;
+  const int Wo = Pin.Wo;
+  WindowParams P = Pin;
+  P.ex_constant = false;
+  const bool has_imu = sys.pim[0] != nullptr;
+  const bool sb0_present = has_imu || sys.prior != nullptr;
+  Layout lay;
+  lay.pose.assign(Wo + 1, -1); lay.sb.assign(Wo + 1, -1);
+  int pos = 0;
+  lay.pose[0] = pos; pos += 6;
+  if (sb0_present) { lay.sb[0] = pos; pos += 9; }
+  const int m = pos;
+  std::vector<KeepBlock> keep;
+  lay.pose[1] = pos; keep.push_back({0, 0, 7, pos - m}); pos += 6;
+  if (has_imu) { lay.sb[1] = pos; keep.push_back({1, 0, 9, pos - m}); pos += 9; }
+  for (int i = 2; i <= Wo; ++i) { lay.pose[i] = pos; keep.push_back({0, i - 1, 7, pos - m}); pos += 6; }
+  lay.ex = pos; keep.push_back({2, 0, 7, pos - m}); pos += 6;
+  lay.dim = pos;
+  const int n = pos - m;
+  DMat A; std::vector<double> b;
+  bool saved = sys.use_prior_factor;
+  sys.use_prior_factor = false;
+  sys.evaluate(P, lay, 1 | 2 | 4, true, &A, &b);
+  sys.use_prior_factor = saved;
+  std::vector<double> Amm(size_t(m) * m), ev(m), V(size_t(m) * m);
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm[size_t(i) * m + j] = 0.5 * (A(i, j) + A(j, i));
+  sym_eig(Amm.data(), m, ev.data(), V.data());
+  DMat Ainv(m, m);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      double s = 0;
+      for (int k = 0; k < m; ++k) s += V[size_t(i) * m + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[size_t(j) * m + k];
+      Ainv(i, j) = s;
+    }
+  // T = Arm * Amm_inv  (n x m)
+  DMat T(n, m);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) { double s = 0; for (int k = 0; k < m; ++k) s += A(m + i, k) * Ainv(k, j); T(i, j) = s; }
+  std::vector<double> S(size_t(n) * n), bs(n);
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < m; ++k) s += T(i, k) * A(k, m + j); S[size_t(i) * n + j] = A(m + i, m + j) - s; }
+    double s = 0; for (int k = 0; k < m; ++k) s += T(i, k) * b[k];
+    bs[i] = b[m + i] - s;
+  }
+  std::vector<double> ev2(n), V2(size_t(n) * n);
+  sym_eig(S.data(), n, ev2.data(), V2.data());
+  auto pr = std::make_shared<MargPrior>();
+  pr->n = n; pr->keep = keep;
+  pr->lin_jac = DMat(n, n); pr->lin_res.assign(n, 0.0);
+  for (int k = 0; k < n; ++k) {
+    double Sk = ev2[k] > eps ? ev2[k] : 0.0, Sik = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
+    double ss = std::sqrt(Sk), sis = std::sqrt(Sik), vb = 0;
+    for (int i = 0; i < n; ++i) { pr->lin_jac(k, i) = ss * V2[size_t(i) * n + k]; vb += V2[size_t(i) * n + k] * bs[i]; }
+    pr->lin_res[k] = sis * vb;
+  }
+  for (const KeepBlock &kb : keep) {
+    const double *src = kb.kind == 0 ? Pin.pose[kb.index + 1].data() : (kb.kind == 1 ? Pin.sb[kb.index + 1].data() : Pin.ex.data());
+    pr->x0.emplace_back(src, src + kb.size);
+  }
+  pr->finalize();
+  return pr;
+}
+
+}  // namespace lio

@@ -1,0 +1,485 @@
+// pointproc.hip — gfx950 kernels of the PointProcessor path (see pointproc.h).
+//
+// HBM traffic per input point: 16 B read + 16 B ring-ordered write + 4 B curvature +
+// 4 B label/mask = 40 B.  The ring stage keeps the whole ring (xyz SoA, mask, labels, curvature and the
+// 8 x 512 sort slots) in LDS — one workgroup of 8 waves per ring, wave w sorting subregion w — because
+// picks are serially dependent through the ring mask and everything they touch must be
+// a few cycles away.  fp32 arithmetic is the reference's, operation for operation (A.1); index lists are
+// bit-exact by construction, not by tolerance.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <climits>
+
+#include "pointproc.h"
+
+namespace lio {
+
+#define PP_PICK_THREADS 512
+#define PP_SORT_SLOTS 512
+
+// ------------------------------------------------------------------------------------------------
+// ring binning
+// ------------------------------------------------------------------------------------------------
+__device__ inline float azimuth_of(float x, float y) {
+  float az = float(2 * M_PI - double(atan2f(y, x)));
+  if (double(az) >= 2 * M_PI) az = float(double(az) - 2 * M_PI);
+  return az;
+}
+
+__global__ void k_ring_bin(const float4 *__restrict__ in, int n, float lower, float factor, int rings, uint32_t *__restrict__ keys,
+                           uint32_t *__restrict__ vals, float *__restrict__ azi, int *first_valid) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = in[i];
+  uint32_t key = uint32_t(rings);
+  float az = 0.f;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    float dis = sqrtf(p.x * p.x + p.y * p.y);
+    float ele = atan2f(p.z, dis);
+    az = azimuth_of(p.x, p.y);
+    float deg = float(double(ele) * 180.0 / M_PI);  // RadToDeg<float>
+    int scan_id = int(double((deg - lower) * factor) + 0.5);
+    if (scan_id >= 0 && scan_id < rings) {
+      key = uint32_t(scan_id);
+      atomicMin(first_valid, i);
+    }
+  }
+  keys[i] = key; vals[i] = uint32_t(i); azi[i] = az;
+}
+
+__global__ void k_ring_offsets(const uint32_t *__restrict__ keys, int n, int rings, int *__restrict__ offsets) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int k = int(keys[i]);
+  int kp = i > 0 ? int(keys[i - 1]) : -1;
+  for (int r = kp + 1; r <= k && r <= rings; ++r) offsets[r] = i;
+  if (i == n - 1)
+    for (int r = k + 1; r <= rings; ++r) offsets[r] = n;
+}
+
+__global__ void k_ring_finalize(const float4 *__restrict__ in, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                const float *__restrict__ azi, const int *__restrict__ offsets, const int *__restrict__ first_valid, int rings,
+                                double scan_period, float4 *__restrict__ ring_cloud) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= offsets[rings]) return;
+  uint32_t src = vals[s];
+  int ring = int(keys[s]);
+  float start_ori = azi[*first_valid];
+  float rel = azi[src] - start_ori;
+  if (rel < 0) rel = float(double(rel) + 2 * M_PI);
+  float rel_time = float(scan_period * double(rel) / (2 * M_PI));
+  float4 p = in[src];
+  p.w = float(ring) + rel_time;
+  ring_cloud[s] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ring feature picking
+// ------------------------------------------------------------------------------------------------
+struct PickCfg {
+  int rings, nc, ns, max_sharp, max_less_sharp, max_flat;
+  float curv_th;
+};
+
+__device__ inline float sqdiff(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, PickCfg c,
+                                                               float *__restrict__ g_curv, int *__restrict__ g_mask, int8_t *__restrict__ g_label,
+                                                               int *__restrict__ pick_idx, int *__restrict__ pick_cnt,
+                                                               PPDeviceCounts *counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int r = blockIdx.x;
+  const int base = offsets[r];
+  const int n = offsets[r + 1] - base;
+  const int tid = threadIdx.x;
+  const int cap_sharp = c.ns * c.max_sharp, cap_less = c.ns * c.max_less_sharp, cap_flat = c.ns * c.max_flat;
+  const int cap_all = cap_sharp + cap_less + cap_flat;
+  int *my_pick = pick_idx + size_t(r) * cap_all;
+  if (tid < 3) pick_cnt[r * 3 + tid] = 0;
+  // every ring point gets defaults in the global arrays
+  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = 0.f; g_mask[base + i] = 0; g_label[base + i] = 127; }
+  if (n <= 2 * c.nc + 1) return;                         // PointProcessor.cc:660-662
+  if (n > LIO_PP_MAX_RING_POINTS) { if (tid == 0) atomicExch(&counts->overflow, 1); return; }
+  // LDS carve (all offsets multiples of 16)
+  const int NP = (n + 63) & ~63;
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem);               // 8 * 512 * 8 B
+  float *sx = reinterpret_cast<float *>(smem + 8 * PP_SORT_SLOTS * 8);
+  float *sy = sx + NP, *sz = sy + NP, *scurv = sz + NP;
+  signed char *smask = reinterpret_cast<signed char *>(scurv + NP);
+  signed char *slabel = smask + NP;
+  for (int i = tid; i < n; i += PP_PICK_THREADS) {
+    float4 p = ring_cloud[base + i];
+    sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; scurv[i] = 0.f; smask[i] = 0; slabel[i] = 127;
+  }
+  __syncthreads();
+  // ---- PrepareRing (:542-585): writes are idempotent stores of 1, so the i-loop parallelises as is
+  for (int i = c.nc + tid; i < n - c.nc; i += PP_PICK_THREADS) {
+    float cx = sx[i], cy = sy[i], cz = sz[i];
+    float nx = sx[i + 1], ny = sy[i + 1], nz = sz[i + 1];
+    float diff_next2 = sqdiff(cx, cy, cz, nx, ny, nz);
+    bool done = false;
+    if (double(diff_next2) > 0.1) {
+      float depth = sqrtf(cx * cx + cy * cy + cz * cz);
+      float depth_next = sqrtf(nx * nx + ny * ny + nz * nz);
+      if (depth > depth_next) {
+        float wb = depth_next / depth;
+        float dx = nx - cx * wb, dy = ny - cy * wb, dz = nz - cz * wb;
+        float wd = sqrtf(dx * dx + dy * dy + dz * dz) / depth_next;
+        if (double(wd) < 0.1) {
+          for (int k = 0; k <= c.nc; ++k) smask[i - c.nc + k] = 1;
+          done = true;
+        }
+      } else {
+        float wb = depth / depth_next;
+        float dx = cx - nx * wb, dy = cy - ny * wb, dz = cz - nz * wb;
+        float wd = sqrtf(dx * dx + dy * dy + dz * dz) / depth;
+        if (double(wd) < 0.1) {
+          for (int k = 0; k <= c.nc; ++k) if (i + 1 + k < n) smask[i + 1 + k] = 1;
+          done = true;
+        }
+      }
+    }
+    if (!done) {
+      float diff_prev2 = sqdiff(cx, cy, cz, sx[i - 1], sy[i - 1], sz[i - 1]);
+      float dis2 = cx * cx + cy * cy + cz * cz;
+      if (double(diff_next2) > 0.0002 * double(dis2) && double(diff_prev2) > 0.0002 * double(dis2)) smask[i] = 1;
+    }
+  }
+  __syncthreads();
+  const int wv = tid >> 6, lane = tid & 63;
+  int n_sharp = 0, n_less = 0, n_flat = 0;  // thread 0 only
+  for (int jg = 0; jg < c.ns; jg += 8) {
+    // ---- PrepareSubregion for subregion j = jg + wave: curvature + sort slots
+    const int j = jg + wv;
+    unsigned long long *wk = skey + wv * PP_SORT_SLOTS;
+    int sp = 0, ep = -1;
+    bool active = j < c.ns;
+    if (active) {
+      sp = int((size_t(c.nc) * size_t(c.ns - j) + size_t(n - c.nc) * size_t(j)) / size_t(c.ns));
+      ep = int((size_t(c.nc) * size_t(c.ns - 1 - j) + size_t(n - c.nc) * size_t(j + 1)) / size_t(c.ns)) - 1;
+      if (ep <= sp) active = false;
+    }
+    const int region = active ? ep - sp + 1 : 0;
+    if (region > PP_SORT_SLOTS) { if (lane == 0) atomicExch(&counts->overflow, 1); }
+    for (int k = lane; k < PP_SORT_SLOTS; k += 64) {
+      unsigned long long key = ~0ull;
+      if (k < region && region <= PP_SORT_SLOTS) {
+        const int i = sp + k;
+        const int npn = 2 * c.nc;
+        float dx = float(-npn) * sx[i], dy = float(-npn) * sy[i], dz = float(-npn) * sz[i];
+        for (int q = 1; q <= c.nc; ++q) {
+          dx += sx[i + q] + sx[i - q];
+          dy += sy[i + q] + sy[i - q];
+          dz += sz[i + q] + sz[i - q];
+        }
+        float cv = dx * dx + dy * dy + dz * dz;
+        scurv[i] = cv;
+        slabel[i] = 0;
+        key = (static_cast<unsigned long long>(__float_as_uint(cv)) << 32) | static_cast<unsigned int>(i);
+      }
+      wk[k] = key;
+    }
+    __syncthreads();
+    // ---- bitonic sort, ascending, all 8 waves in lockstep: total order (curvature, index) == std::sort on pair<float,size_t>
+    for (int size = 2; size <= PP_SORT_SLOTS; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = lane; t < PP_SORT_SLOTS / 2; t += 64) {
+          int lo = 2 * t - (t & (stride - 1));
+          int hi = lo + stride;
+          bool up = ((lo & size) == 0);
+          unsigned long long a = wk[lo], b = wk[hi];
+          if ((a > b) == up) { wk[lo] = b; wk[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- serial picks (:685-725): the mask is shared by the ring's subregions, so j ascends on one lane
+    if (tid == 0) {
+      for (int w = 0; w < 8 && jg + w < c.ns; ++w) {
+        const int jj = jg + w;
+        int sp2 = int((size_t(c.nc) * size_t(c.ns - jj) + size_t(n - c.nc) * size_t(jj)) / size_t(c.ns));
+        int ep2 = int((size_t(c.nc) * size_t(c.ns - 1 - jj) + size_t(n - c.nc) * size_t(jj + 1)) / size_t(c.ns)) - 1;
+        if (ep2 <= sp2) continue;
+        const int region2 = ep2 - sp2 + 1;
+        if (region2 > PP_SORT_SLOTS) continue;
+        const unsigned long long *kk = skey + w * PP_SORT_SLOTS;
+        int num_largest = 0;
+        for (int k = region2; k > 0 && num_largest < c.max_less_sharp;) {
+          unsigned long long e = kk[--k];
+          float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+          if (!(cv > c.curv_th)) break;  // sorted ascending: nothing below can pass either
+          int idx = int(static_cast<unsigned int>(e));
+          if (smask[idx] == 0) {
+            ++num_largest;
+            if (num_largest <= c.max_sharp) { slabel[idx] = 2; my_pick[n_sharp++] = idx; }
+            else slabel[idx] = 1;
+            my_pick[cap_sharp + n_less++] = idx;
+            smask[idx] = 1;
+            for (int q = 1; q <= c.nc; ++q) {
+              if (double(sqdiff(sx[idx + q], sy[idx + q], sz[idx + q], sx[idx + q - 1], sy[idx + q - 1], sz[idx + q - 1])) > 0.05) break;
+              smask[idx + q] = 1;
+            }
+            for (int q = 1; q <= c.nc; ++q) {
+              if (double(sqdiff(sx[idx - q], sy[idx - q], sz[idx - q], sx[idx - q + 1], sy[idx - q + 1], sz[idx - q + 1])) > 0.05) break;
+              smask[idx - q] = 1;
+            }
+          }
+        }
+        int num_smallest = 0;
+        for (int k = 0; k < region2 && num_smallest < c.max_flat; ++k) {
+          unsigned long long e = kk[k];
+          float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+          if (!(cv < c.curv_th)) break;
+          int idx = int(static_cast<unsigned int>(e));
+          if (smask[idx] == 0) {
+            ++num_smallest;
+            slabel[idx] = -1;
+            my_pick[cap_sharp + cap_less + n_flat++] = idx;
+            smask[idx] = 1;
+            for (int q = 1; q <= c.nc; ++q) {
+              if (double(sqdiff(sx[idx + q], sy[idx + q], sz[idx + q], sx[idx + q - 1], sy[idx + q - 1], sz[idx + q - 1])) > 0.05) break;
+              smask[idx + q] = 1;
+            }
+            for (int q = 1; q <= c.nc; ++q) {
+              if (double(sqdiff(sx[idx - q], sy[idx - q], sz[idx - q], sx[idx - q + 1], sy[idx - q + 1], sz[idx - q + 1])) > 0.05) break;
+              smask[idx - q] = 1;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { pick_cnt[r * 3 + 0] = n_sharp; pick_cnt[r * 3 + 1] = n_less; pick_cnt[r * 3 + 2] = n_flat; }
+  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = scurv[i]; g_mask[base + i] = int(smask[i]); g_label[base + i] = slabel[i]; }
+}
+
+// prefix of the per-ring pick counts -> compact, ring-major lists (the order the reference pushes them)
+__global__ void k_class_offsets(const int *__restrict__ pick_cnt, int rings, int *__restrict__ class_off, PPDeviceCounts *counts) {
+  int cls = threadIdx.x;
+  if (cls >= 3) return;
+  int acc = 0;
+  for (int r = 0; r < rings; ++r) { class_off[cls * (rings + 1) + r] = acc; acc += pick_cnt[r * 3 + cls]; }
+  class_off[cls * (rings + 1) + rings] = acc;
+  counts->n_class[cls + 1] = acc;
+}
+
+__global__ void k_class_gather(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int *__restrict__ pick_idx,
+                               const int *__restrict__ pick_cnt, const int *__restrict__ class_off, PickCfg c, int *__restrict__ class_ring,
+                               int *__restrict__ class_idx, float4 *__restrict__ cloud1, float4 *__restrict__ cloud2, float4 *__restrict__ cloud3,
+                               int cap_total) {
+  const int r = blockIdx.x;
+  const int cap_sharp = c.ns * c.max_sharp, cap_less = c.ns * c.max_less_sharp, cap_flat = c.ns * c.max_flat;
+  const int cap_all = cap_sharp + cap_less + cap_flat;
+  const int *mp = pick_idx + size_t(r) * cap_all;
+  const int src_off[3] = {0, cap_sharp, cap_sharp + cap_less};
+  float4 *clouds[3] = {cloud1, cloud2, cloud3};
+  for (int cls = 0; cls < 3; ++cls) {
+    int cnt = pick_cnt[r * 3 + cls];
+    int dst = class_off[cls * (c.rings + 1) + r];
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+      int idx = mp[src_off[cls] + k];
+      class_ring[cls * cap_total + dst + k] = r;
+      class_idx[cls * cap_total + dst + k] = idx;
+      clouds[cls][dst + k] = ring_cloud[offsets[r] + idx];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// less-flat: per-ring VoxelGrid, batched over rings
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lf_bounds(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int8_t *__restrict__ label,
+                            float *__restrict__ bounds) {
+  const int r = blockIdx.x;
+  const int base = offsets[r], n = offsets[r + 1] - base;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (label[base + i] > 0) continue;  // corners (1,2) and untouched (127) are not less-flat (A.5)
+    float4 p = ring_cloud[base + i];
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  __shared__ float sm[6][256];
+  int t = threadIdx.x;
+  for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+    __syncthreads();
+  }
+  if (t < 6) bounds[r * 8 + t] = sm[t][0];
+}
+
+__global__ void k_lf_keys(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int8_t *__restrict__ label,
+                          const float *__restrict__ bounds, float inv_leaf, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int r = blockIdx.y;
+  const int base = offsets[r], n = offsets[r + 1] - base;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key = ~0ull;
+  if (label[base + i] <= 0) {
+    const float *b = bounds + r * 8;
+    int minb0 = int(floorf(b[0] * inv_leaf)), minb1 = int(floorf(b[1] * inv_leaf)), minb2 = int(floorf(b[2] * inv_leaf));
+    int div0 = int(floorf(b[3] * inv_leaf)) - minb0 + 1, div1 = int(floorf(b[4] * inv_leaf)) - minb1 + 1;
+    float4 p = ring_cloud[base + i];
+    int i0 = int(floorf(p.x * inv_leaf) - float(minb0));
+    int i1 = int(floorf(p.y * inv_leaf) - float(minb1));
+    int i2 = int(floorf(p.z * inv_leaf) - float(minb2));
+    unsigned int vk = static_cast<unsigned int>(i0 + i1 * div0 + i2 * div0 * div1);
+    key = (static_cast<unsigned long long>(r) << 32) | vk;
+  }
+  keys[base + i] = key;
+  vals[base + i] = uint32_t(base + i);
+}
+
+__global__ void k_lf_heads(const unsigned long long *__restrict__ keys, int n, int *__restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long k = keys[i];
+  flags[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+__global__ void k_lf_centroids(const float4 *__restrict__ ring_cloud, const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+                               const int *__restrict__ flags, const int *__restrict__ pos, int n, const float *__restrict__ azi,
+                               const int *__restrict__ first_valid, double scan_period, float4 *__restrict__ out, PPDeviceCounts *counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) counts->n_less_flat = pos[i] + flags[i];
+  if (!flags[i]) return;
+  unsigned long long k = keys[i];
+  float ax = 0, ay = 0, az = 0, ai = 0;
+  int e = i;
+  while (e < n && keys[e] == k) {
+    float4 p = ring_cloud[vals[e]];
+    ax += p.x; ay += p.y; az += p.z; ai += p.w;
+    ++e;
+  }
+  float cnt = float(e - i);
+  float4 o = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
+  // rel-time recompute on the averaged point (:755-778)
+  float a = azimuth_of(o.x, o.y);
+  float rel = a - azi[*first_valid];
+  if (rel < 0) rel = float(double(rel) + 2 * M_PI);
+  float rel_time = float(scan_period * double(rel) / (2 * M_PI));
+  o.w = float(int(o.w)) + rel_time;
+  out[pos[i]] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg)
+    : lower_(lower), upper_(upper), rings_(rings), cfg_(cfg) {
+  factor_ = (rings - 1) / (upper - lower);
+  int nd = 0;
+  LIO_HIP(hipGetDeviceCount(&nd));
+  if (nd <= 0) throw DeviceError("no HIP device: the product has no CPU path");
+  LIO_HIP(hipStreamCreate(&stream_));
+  ring_offsets_.assign(rings + 1, 0);
+  // the pick kernel needs up to ~104 KB of dynamic LDS
+  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+PointProcessorDev::~PointProcessorDev() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void PointProcessorDev::Process(const float *xyzi, size_t n) {
+  std::memset(&counts_, 0, sizeof(counts_));
+  std::fill(ring_offsets_.begin(), ring_offsets_.end(), 0);
+  if (n == 0) return;
+  const int ni = int(n);
+  hipStream_t s = stream_;
+  in_.reserve(n); ring_cloud_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
+  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); k64_.reserve(n); k64b_.reserve(n);
+  flags_.reserve(n); pos_.reserve(n); less_flat_.reserve(n);
+  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(1); d_counts_.reserve(1); lf_bounds_.reserve(size_t(rings_) * 8);
+  PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
+             cfg_.max_surf_flat, cfg_.surf_curv_th};
+  const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
+  const int cap_all = cap_sharp + cap_less + cap_flat;
+  const int cap_total = rings_ * std::max(cap_less, std::max(cap_sharp, cap_flat));
+  pick_idx_.reserve(size_t(rings_) * cap_all); pick_cnt_.reserve(size_t(rings_) * 3); class_off_.reserve(size_t(3) * (rings_ + 1));
+  class_ring_.reserve(size_t(3) * cap_total); class_idx_.reserve(size_t(3) * cap_total);
+  for (int cidx = 1; cidx <= 3; ++cidx) class_cloud_[cidx].reserve(cap_total);
+
+  LIO_HIP(hipMemcpyAsync(in_.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, s));
+  LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
+  int big = INT_MAX;
+  LIO_HIP(hipMemcpyAsync(first_valid_.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_ring_bin, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, ni, lower_, factor_, rings_, keys_.p, vals_.p, azi_.p, first_valid_.p);
+  int bits = 1;
+  while ((1 << bits) < rings_ + 1) ++bits;
+  size_t tb = 0, tb2 = 0, tb3 = 0;
+  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
+  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tb2, k64_.p, k64b_.p, vals_.p, vals2_.p, n, 0, 40, s));
+  LIO_HIP(rocprim::exclusive_scan(nullptr, tb3, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
+  tmp_.reserve(std::max(tb, std::max(tb2, tb3)) + 256);
+  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
+  hipLaunchKernelGGL(k_ring_offsets, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, rings_, d_ring_offsets_.p);
+  hipLaunchKernelGGL(k_ring_finalize, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, keys2_.p, vals2_.p, azi_.p, d_ring_offsets_.p, first_valid_.p,
+                     rings_, cfg_.scan_period, ring_cloud_.p);
+  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 2);
+  hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
+                     pick_idx_.p, pick_cnt_.p, d_counts_.p);
+  hipLaunchKernelGGL(k_class_offsets, dim3(1), dim3(64), 0, s, pick_cnt_.p, rings_, class_off_.p, d_counts_.p);
+  hipLaunchKernelGGL(k_class_gather, dim3(rings_), dim3(64), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, class_off_.p, pc,
+                     class_ring_.p, class_idx_.p, class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total);
+  // less-flat
+  const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
+  hipLaunchKernelGGL(k_lf_bounds, dim3(rings_), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, lf_bounds_.p);
+  LIO_HIP(hipMemsetAsync(k64_.p, 0xFF, n * sizeof(uint64_t), s));
+  hipLaunchKernelGGL(k_lf_keys, dim3(cdiv(LIO_PP_MAX_RING_POINTS, 256), rings_), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, label_.p,
+                     lf_bounds_.p, inv_leaf, reinterpret_cast<unsigned long long *>(k64_.p), vals_.p);
+  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tb2, k64_.p, k64b_.p, vals_.p, vals2_.p, n, 0, 40, s));
+  hipLaunchKernelGGL(k_lf_heads, dim3(cdiv(ni, 256)), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(k64b_.p), ni, flags_.p);
+  LIO_HIP(rocprim::exclusive_scan(tmp_.p, tb3, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
+  hipLaunchKernelGGL(k_lf_centroids, dim3(cdiv(ni, 256)), dim3(256), 0, s, ring_cloud_.p, reinterpret_cast<unsigned long long *>(k64b_.p), vals2_.p,
+                     flags_.p, pos_.p, ni, azi_.p, first_valid_.p, cfg_.scan_period, less_flat_.p, d_counts_.p);
+  LIO_HIP(hipGetLastError());
+  LIO_HIP(hipMemcpyAsync(&counts_, d_counts_.p, sizeof(counts_), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(ring_offsets_.data(), d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
+  counts_.n_ring_points = ring_offsets_[rings_];
+  if (counts_.overflow) throw std::runtime_error("PointProcessor: a ring exceeds LIO_PP_MAX_RING_POINTS");
+}
+
+size_t PointProcessorDev::Count(int which) const {
+  switch (which) {
+    case LIO_PP_RINGS: return size_t(counts_.n_ring_points);
+    case LIO_PP_LESS_FLAT: return size_t(counts_.n_less_flat);
+    default: return size_t(counts_.n_class[which]);
+  }
+}
+void PointProcessorDev::GetCloud(int which, float *out) {
+  size_t n = Count(which);
+  if (!n) return;
+  const float4 *src = which == LIO_PP_RINGS ? ring_cloud_.p : (which == LIO_PP_LESS_FLAT ? less_flat_.p : class_cloud_[which].p);
+  LIO_HIP(hipMemcpyAsync(out, src, n * sizeof(float4), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+}
+void PointProcessorDev::GetIndices(int which, int32_t *ring, int32_t *idx) {
+  size_t n = Count(which);
+  if (!n) return;
+  const int cap_total = rings_ * std::max(cfg_.num_scan_subregions * cfg_.max_corner_less_sharp,
+                                          std::max(cfg_.num_scan_subregions * cfg_.max_corner_sharp, cfg_.num_scan_subregions * cfg_.max_surf_flat));
+  LIO_HIP(hipMemcpyAsync(ring, class_ring_.p + size_t(which - 1) * cap_total, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(idx, class_idx_.p + size_t(which - 1) * cap_total, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+}
+void PointProcessorDev::GetRingOffsets(int32_t *out) {
+  for (int r = 0; r <= rings_; ++r) out[r] = ring_offsets_[r];
+}
+void PointProcessorDev::GetCurvature(float *curv, int32_t *mask) {
+  size_t n = size_t(counts_.n_ring_points);
+  if (!n) return;
+  if (curv) LIO_HIP(hipMemcpyAsync(curv, curv_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if (mask) LIO_HIP(hipMemcpyAsync(mask, mask_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace lio

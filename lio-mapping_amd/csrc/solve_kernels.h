@@ -1,0 +1,37 @@
+// solve_kernels.h — device side of the Gauss-Newton normal-equation build for the lidar factors
+// (PivotPointPlaneFactor, src/factor/PivotPointPlaneFactor.cc:43-137, with CauchyLoss(1.0),
+// Estimator.cc:1664,1867-1876) — the one dense contraction of the solve, on the fp64 matrix cores.
+#pragma once
+#include <cstdint>
+
+#include "cloud_kernels.h"
+
+namespace lio {
+
+// Per residual the 18 Jacobian entries and the residual are LINEAR in z = [w (x) [p;1]; d] (13 values):
+// j = L z, r = l^T z with L, l depending only on the (pivot, frame i, extrinsic) poses.  Hence
+//   sum rho' j j^T = L (sum rho' z z^T) L^T ,   sum rho' j r = L (sum rho' z z^T) l
+// and the K = N_res contraction is S_i = sum_k rho'_k z_k z_k^T — a 16x16xK product (13 padded to 16)
+// that maps onto v_mfma_f64_16x16x4_f64 with no wasted tiles.  rho'_k needs the residual at the current
+// poses, computed per lane in fp64 from T_{pivot<-i}.
+#define LIO_MOMENT_OUT 260  // 256 S entries (row-major 16x16) + cost + count + 2 pad
+
+struct MomentFrame {
+  const float4 *stack;
+  int M;
+  int slot_off;
+  int nslots;
+  double R[9];  // R_{lp,i} row-major
+  double t[3];  // P_{lp,i}
+};
+struct MomentArgs {
+  MomentFrame fr[LIO_MAX_FRAMES];
+  int nframes;
+  int blocks_per_frame;
+};
+
+// partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles
+void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s);
+int moment_blocks_per_frame(int max_slots);
+
+}  // namespace lio

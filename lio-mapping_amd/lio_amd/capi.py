@@ -146,6 +146,7 @@ _SIGS = {
         C.c_int,
         [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double, C.POINTER(SolveReport)],
     ),
+    "lio_est_push_frame": (C.c_int, [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double]),
     "lio_est_solve_optimization": (C.c_int, [C.c_void_p, C.POINTER(SolveReport)]),
     "lio_est_slide_window": (C.c_int, [C.c_void_p]),
     "lio_est_set_window": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 6),
@@ -161,6 +162,8 @@ _SIGS = {
     "lio_est_get_prior": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
+    "lio_est_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "lio_est_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, c_double_p]),
 }
 
 
@@ -376,6 +379,11 @@ class Estimator:
         )
         return rep
 
+    def push_frame(self, T: TransformF, surf, corner, stamp):
+        surf = _f32(surf).reshape(-1, 4)
+        corner = _f32(corner).reshape(-1, 4)
+        _chk(self.lib.dll.lio_est_push_frame(self.h, C.byref(T), _fp(surf), surf.shape[0], _fp(corner), corner.shape[0], stamp), "lio_est_push_frame")
+
     def solve(self):
         rep = SolveReport()
         _chk(self.lib.dll.lio_est_solve_optimization(self.h, C.byref(rep)), "lio_est_solve_optimization")
@@ -453,6 +461,14 @@ class Estimator:
         x0 = np.zeros(ln.value)
         self.lib.dll.lio_est_get_prior(self.h, _dp(JtJ), _dp(Jtr), _dp(x0), C.byref(ln))
         return dict(n=n, JtJ=JtJ, Jtr=Jtr, x0=x0)
+
+    def enable_kernel_timing(self, on=True):
+        _chk(self.lib.dll.lio_est_enable_kernel_timing(self.h, 1 if on else 0), "lio_est_enable_kernel_timing")
+
+    def kernel_timing(self, name):
+        t, b = np.zeros(1), np.zeros(1)
+        n = self.lib.dll.lio_est_get_kernel_timing(self.h, name.encode(), _dp(t), _dp(b))
+        return dict(launches=int(n), total_ms=float(t[0]), algorithmic_bytes=float(b[0]))
 
     def snapshot(self):
         _chk(self.lib.dll.lio_est_snapshot(self.h), "lio_est_snapshot")

@@ -243,6 +243,10 @@ int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float
   fillReport(R, rep);
   return LIO_OK;
 }
+int lio_est_push_frame(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp) {
+  if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  return h->est.PushFrame(toT(*T), toCloud(surf, ns), toCloud(corner, nc), stamp) ? LIO_OK : LIO_ERR_STATE;
+}
 int lio_est_solve_optimization(lio_est *h, lio_solve_report *rep) {
   if (!h) return LIO_ERR_ARG;
   SolveReport R;
@@ -363,5 +367,8 @@ int lio_est_restore(lio_est *h) {
   if (h->snap->tmp_pre_integration) h->est.tmp_pre_integration = std::make_shared<IntegrationBase>(*h->snap->tmp_pre_integration);
   return LIO_OK;
 }
+
+int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }
+int lio_est_get_kernel_timing(lio_est *, const char *, double *t, double *b) { if (t) *t = 0; if (b) *b = 0; return 0; }
 
 }  // extern "C"

@@ -133,7 +133,13 @@ struct Estimator {
   }
 
   // ---- Estimator.cc:430-488 + INITED branch :620-774
-  bool ProcessLaserOdom(const Transformf & /*transform_in*/, Cloud surf_last, Cloud corner_last, double /*stamp*/, SolveReport *rep) {
+  bool ProcessLaserOdom(const Transformf &transform_in, Cloud surf_last, Cloud corner_last, double stamp, SolveReport *rep) {
+    if (!PushFrame(transform_in, std::move(surf_last), std::move(corner_last), stamp)) return false;
+    SolveOptimization(rep);
+    SlideWindow();
+    return true;
+  }
+  bool PushFrame(const Transformf & /*transform_in*/, Cloud surf_last, Cloud corner_last, double /*stamp*/) {
     if (!inited) return false;
     pushFull(pre_integrations, tmp_pre_integration);
     tmp_pre_integration = std::make_shared<IntegrationBase>(acc_last, gyr_last, Bas[cir_buf_count], Bgs[cir_buf_count], cfg.pim);
@@ -171,8 +177,6 @@ struct Estimator {
       pushFull(size_surf_stack, surf_last.size()); pushFull(surf_stack, surf_last);
       pushFull(size_corner_stack, corner_last.size()); pushFull(corner_stack, corner_last);
     }
-    SolveOptimization(rep);
-    SlideWindow();
     return true;
   }
 

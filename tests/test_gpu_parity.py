@@ -103,7 +103,7 @@ def test_point_processor_matches_oracle(hip, oracle, kind):
     np.testing.assert_array_equal(pa.ring_offsets(), pb.ring_offsets())
     ra, rb = pa.cloud(0), pb.cloud(0)
     np.testing.assert_array_equal(ra[:, :3], rb[:, :3])               # stable per-ring order: identical points
-    np.testing.assert_allclose(ra[:, 3], rb[:, 3], rtol=0, atol=2e-6)  # ring + rel_time: atan2f ulp differences
+    np.testing.assert_allclose(ra[:, 3], rb[:, 3], rtol=0, atol=8e-6)  # ring + rel_time: atan2f ulp differences (1 ulp at 64 = 7.6e-6)
     ca, ma = pa.curvature()
     cb, mb = pb.curvature()
     np.testing.assert_array_equal(ca, cb)                              # curvature: pure fp32 arithmetic, bit-exact
@@ -116,7 +116,7 @@ def test_point_processor_matches_oracle(hip, oracle, kind):
     la, lb = pa.cloud(4), pb.cloud(4)
     assert la.shape == lb.shape and la.shape[0] > 1000
     np.testing.assert_array_equal(la[:, :3], lb[:, :3])                # same voxel order and summation order
-    np.testing.assert_allclose(la[:, 3], lb[:, 3], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(la[:, 3], lb[:, 3], rtol=0, atol=8e-6)
 
 
 def test_point_processor_edge_cases(hip, oracle):

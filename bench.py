@@ -23,12 +23,13 @@ sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
 import numpy as np  # noqa: E402
 
 
-def build_window(lib, kind, W, Wo, extra_frames, seed_shift=0.0, lidar=None):
+def build_window(lib, kind, W, Wo, extra_frames, seed_shift=0.0, lidar=None, ds=None):
     from lio_amd import capi, pipeline, synth
 
     n_frames = W + 1 + extra_frames
     frame_dt = 0.3 if kind == "outdoor" else 0.2  # odom_io = 3 (HDL-64) / 2 (VLP-16) x 0.1 s
-    ds = synth.make_dataset(kind, n_frames, frame_dt, t0=1.0 + seed_shift, lidar=lidar)
+    if ds is None:
+        ds = synth.make_dataset(kind, n_frames, frame_dt, t0=1.0 + seed_shift, lidar=lidar)
     t0 = time.time()
     pp = capi.PointProcessor(lib, ds.lidar.lower_deg, ds.lidar.upper_deg, ds.lidar.rings)
     clouds = []
@@ -142,7 +143,7 @@ def main():
         }
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(kind, W, Wo, args.cpu_steps)
+            cpu = cpu_baseline(kind, W, Wo, args.cpu_steps, ds)
         out = {
             "metric": "sliding-window solves/sec, 64-line 130k-pt scans, window=15 (opt_window=5)",
             "value": round(value, 3),
@@ -191,7 +192,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(kind, W, Wo, steps):
+def cpu_baseline(kind, W, Wo, steps, ds=None):
     """The CPU oracle on the same workload, on this box's host cores (solve single-threaded like Ceres with
     num_threads=1, marginalization on 4 threads like the reference).  Bounded sample: `steps` solves."""
     import subprocess
@@ -202,7 +203,7 @@ def cpu_baseline(kind, W, Wo, steps):
     if not os.path.exists(so):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     orc = capi.LioLib(so)
-    ds, clouds, est, k_last, _, _ = build_window(orc, kind, W, Wo, extra_frames=4)
+    ds, clouds, est, k_last, _, _ = build_window(orc, kind, W, Wo, extra_frames=4, ds=ds)
     T = capi.TransformF.make([0, 0, 0, 1], [0, 0, 0])
     est.push_frame(T, clouds[k_last][0], clouds[k_last][1], ds.frames[k_last].t)
     est.snapshot()

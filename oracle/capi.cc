@@ -368,6 +368,11 @@ int lio_est_restore(lio_est *h) {
   return LIO_OK;
 }
 
+// oracle-only probes (not part of lio_c.h): include/utils/math_utils.h:44-64, pinned by the reference's own
+// assertions at test/test_point_processor/test_point_processor.cc:57-61
+double orc_normalize_rad(double r) { return NormalizeRad(r); }
+double orc_normalize_deg(double d) { return NormalizeDeg(d); }
+
 int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_est_get_kernel_timing(lio_est *, const char *, double *t, double *b) { if (t) *t = 0; if (b) *b = 0; return 0; }
 

@@ -131,7 +131,9 @@ def test_marginalization_identities(oracle):
     pipeline.set_extrinsic(cfg, ds)
     est = capi.Estimator(oracle, cfg)
     pipeline.init_window(est, oracle, ds, [c[0] for c in clouds], pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
-    rep = est.solve()
+    est.solve()   # first solve: IMU cost > 1e3 => turn_off => no prior yet (Estimator.cc:1938-1942,2040)
+    est.slide()
+    rep = pipeline.feed_frame(est, ds, 5, clouds[5][0], clouds[5][1])
     assert rep.marginalized == 1
     pr = est.prior()
     n = pr["n"]

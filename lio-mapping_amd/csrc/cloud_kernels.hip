@@ -104,14 +104,28 @@ __global__ void k_bounds_partial(const float4 *__restrict__ pts, int n, float *_
   if (t < 7) partial[blockIdx.x * 8 + t] = sm[t][0];
 }
 
-__global__ void k_bounds_final(const float *__restrict__ partial, int nb, float inv_leaf, VoxParams *out) {
-  if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(256) k_bounds_final(const float *__restrict__ partial, int nb, float inv_leaf, VoxParams *out) {
+  __shared__ float sm[7][256];
+  const int t = threadIdx.x;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   float cnt = 0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = t; b < nb; b += 256) {
     for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], partial[b * 8 + d]); mx[d] = fmaxf(mx[d], partial[b * 8 + 3 + d]); }
     cnt += partial[b * 8 + 6];
   }
+  for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+  sm[6][t] = cnt;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) {
+      for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+      sm[6][t] += sm[6][t + st];
+    }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  for (int d = 0; d < 3; ++d) { mn[d] = sm[d][0]; mx[d] = sm[3 + d][0]; }
+  cnt = sm[6][0];
   VoxParams v;
   long long dd[3];
   for (int d = 0; d < 3; ++d) {
@@ -183,7 +197,7 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
   flags_.reserve(n); pos_.reserve(n); count_.reserve(1);
   out.reserve(n);
   hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, in, ni, partial_.p);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, partial_.p, nb, inv_leaf, params_.p);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, s, partial_.p, nb, inv_leaf, params_.p);
   hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, ni, inv_leaf, params_.p, keys_.p, vals_.p);
   size_t tmp_bytes = 0;
   LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
@@ -341,21 +355,108 @@ void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4
 // ------------------------------------------------------------------------------------------------
 // CalculateFeatures (surf branch)
 // ------------------------------------------------------------------------------------------------
+// LPQ lanes cooperate on one query: sub-lane `sub` scans candidates sub, sub+LPQ, ... of each 3-cell x-run
+// (one contiguous, coalesced stream per query group), keeps its own top-K, then the LPQ partial lists are
+// merged by xor-shuffles.  The total order (d2, original index) makes the result independent of the split:
+// bit-identical to the single-lane scan.  The serial dependent-load chain per lane shrinks LPQ-fold, which
+// is what bounds this kernel (a query touches ~100 candidates; maps are L2-resident).
+#define FEAT_LPQ 8
+template <int K, int LPQ>
+__device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub, const float4 *__restrict__ map,
+                                      const int2 *__restrict__ cells, const GridDesc &g, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bj[k] = 0; }
+  int cx = cell_coord(q.x, g.inv_cell) - g.origin[0];
+  int cy = cell_coord(q.y, g.inv_cell) - g.origin[1];
+  int cz = cell_coord(q.z, g.inv_cell) - g.origin[2];
+  if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dims[0] || cy >= g.dims[1] || cz >= g.dims[2]) active = false;
+  if (active) {
+    for (int dz = -1; dz <= 1; ++dz) {
+      int z = cz + dz;
+      if (z < 0 || z >= g.dims[2]) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        int y = cy + dy;
+        if (y < 0 || y >= g.dims[1]) continue;
+        int row = g.dims[0] * (y + g.dims[1] * z);
+        // cells x-1..x+1 have consecutive ids => their points are one contiguous run of the cell-sorted array
+        int rs = INT_MAX, re = 0;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          int x = cx + dx;
+          if (x < 0 || x >= g.dims[0]) continue;
+          int2 ce = cells[row + x];
+          if (ce.y > ce.x) { rs = min(rs, ce.x); re = max(re, ce.y); }
+        }
+        if (re <= rs) continue;  // all three cells empty (rs is still INT_MAX)
+        for (int j = rs + sub; j < re; j += LPQ) {
+          float4 p = map[j];
+          float ddx = p.x - q.x, ddy = p.y - q.y, ddz = p.z - q.z;
+          float d = ddx * ddx;
+          d += ddy * ddy;
+          d += ddz * ddz;
+          int idx = __float_as_int(p.w);
+          if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
+            bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = j;
+#pragma unroll
+            for (int k = K - 1; k > 0; --k) {
+              bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
+              float td = sw ? bd[k - 1] : bd[k];
+              int ti = sw ? bi[k - 1] : bi[k];
+              int tj = sw ? bj[k - 1] : bj[k];
+              bd[k - 1] = sw ? bd[k] : bd[k - 1];
+              bi[k - 1] = sw ? bi[k] : bi[k - 1];
+              bj[k - 1] = sw ? bj[k] : bj[k - 1];
+              bd[k] = td; bi[k] = ti; bj[k] = tj;
+            }
+          }
+        }
+      }
+    }
+  }
+  // butterfly merge of the LPQ partial lists (every lane of the wave takes part in the shuffles)
+#pragma unroll
+  for (int m = 1; m < LPQ; m <<= 1) {
+    float od[K]; int oi[K], oj[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { od[k] = __shfl_xor(bd[k], m, 64); oi[k] = __shfl_xor(bi[k], m, 64); oj[k] = __shfl_xor(bj[k], m, 64); }
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      float d = od[c]; int idx = oi[c];
+      if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
+        bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = oj[c];
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) {
+          bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
+          float td = sw ? bd[k - 1] : bd[k];
+          int ti = sw ? bi[k - 1] : bi[k];
+          int tj = sw ? bj[k - 1] : bj[k];
+          bd[k - 1] = sw ? bd[k] : bd[k - 1];
+          bi[k - 1] = sw ? bi[k] : bi[k - 1];
+          bj[k - 1] = sw ? bj[k] : bj[k - 1];
+          bd[k] = td; bi[k] = ti; bj[k] = tj;
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                  const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
                                                  float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   const FeatFrame fr = a.fr[blockIdx.y];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= fr.M) return;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
+  const bool active = i < fr.M;
   const float *tp = transforms + 8 * fr.tf_index;
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   Vec3<float> t(tp[4], tp[5], tp[6]);
-  float4 po = fr.stack[i];
+  float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
   Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
   Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   float bd[5]; int bi[5], bj[5];
-  knn_scan<5>(sel, map, cells, g, bd, bi, bj);
+  knn_scan_group<5, FEAT_LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+  if (!active || sub != 0) return;
   const int slot = fr.slot_off + i;
   uint8_t ok = 0;
   float4 c = make_float4(0, 0, 0, 0);
@@ -403,8 +504,8 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
 void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
                      uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s) {
   if (a.nframes <= 0 || a.max_M <= 0) return;
-  hipLaunchKernelGGL(k_features, dim3(cdiv(a.max_M, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef,
-                     score, skip_flag);
+  hipLaunchKernelGGL(k_features, dim3(cdiv((long long)a.max_M * FEAT_LPQ, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g,
+                     valid, coef, score, skip_flag);
   LIO_HIP(hipGetLastError());
 }
 

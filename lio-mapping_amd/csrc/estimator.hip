@@ -328,7 +328,17 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     if (M > 0) {
       const int nb = odom_rows_blocks(M * keep_mult);
       d_odom_partials_.reserve(size_t(nb) * 28);
+      // Launch in chunks and peek at the device-side convergence flag between them: a peek costs one small
+      // D2H (~10 us) and saves the ~3 no-op launches of every skipped round.
+      const int chunk_end[4] = {3, 5, 7, 10};
+      int chunk = 0;
       for (int iter = 0; iter < 10; ++iter) {
+        if (iter == chunk_end[chunk]) {
+          LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+          LIO_HIP(hipStreamSynchronize(stream_));
+          if (st.converged) break;
+          ++chunk;
+        }
         FeatArgs fo{};
         fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
         fo.nframes = 1; fo.max_M = M;
@@ -410,6 +420,8 @@ void Estimator::ParamsToVector(const WindowParams &P) {  // DoubleToVector with 
 }
 
 void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
+  const double t_dbg0 = now_ms();
+  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
   const int pivot = W_ - Wo_;
   MomentArgs ma{};
   int max_slots = 0;
@@ -468,33 +480,30 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   }
   sys.lidar_eval = [this](const WindowParams &Pq, std::vector<FrameMoments> &m) { LidarEval(Pq, m); };
   R.ms_prepare = now_ms() - t_prep0;
-  // group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984)
+  // Group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984).
+  // The reference evaluates the three groups, then Ceres linearises again at the same point; here ONE device
+  // pass yields both — unless the flag logic changes the problem (prior dropped / extrinsic frozen).
+  Linearization first;
   {
     Layout lay = WindowSystem::solve_layout(P);
-    WindowSystem::Costs gc = sys.evaluate(P, lay, 1 | 2 | 4, false, nullptr, nullptr);
+    first.costs = sys.evaluate(P, lay, 1 | 2 | 4 | 8, false, &first.H, &first.g);
+    first.valid = true;
+    const WindowSystem::Costs &gc = first.costs;
     R.cost_pim_before = gc.pim; R.cost_ppp_before = gc.ppp; R.cost_marg_before = gc.marg;
     if (cfg_.imu_factor) turn_off = gc.pim > 1e3;
     const double ratio = gc.marg / (gc.ppp + gc.pim);
     if (!convergence_flag_ && !turn_off && ratio <= 2 && ratio != 0) convergence_flag_ = true;
     if (!convergence_flag_) {
+      if (!P.ex_constant || sys.prior) first.valid = false;
       P.ex_constant = true;
       last_marg_.reset();
       sys.prior.reset();
     }
   }
-  // lidar slot count for the report
-  {
-    int nres = 0;
-    if (cfg_.point_distance_factor) {
-      std::vector<FrameMoments> m(Wo_ + 1);
-      // counts come back with every evaluation; take them from the first linearisation below
-      (void)m;
-    }
-    R.n_lidar_residuals = nres;
-  }
   const double t_opt0 = now_ms();
-  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, cfg_.max_solver_time);
+  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, cfg_.max_solver_time, &first);
   R.ms_opt = now_ms() - t_opt0;
+  if (getenv("LIO_DEBUG_TIMING")) std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms\n", s.ms_chol, s.ms_eval);
   R.iterations = s.iterations; R.successful_steps = s.successful; R.termination = s.termination;
   R.initial_cost = s.initial_cost; R.final_cost = s.final_cost;
   for (size_t k = 0; k < s.trace.size() && k < 32; ++k) R.cost_trace[k] = s.trace[k];
@@ -526,6 +535,11 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     R.n_lidar_residuals = cfg_.point_distance_factor ? int(cnt) : 0;
   }
   R.ms_total = now_ms() - t_total0;
+  if (getenv("LIO_DEBUG_TIMING")) {
+    std::fprintf(stderr, "[lio_hip timing] total %.3f map %.3f feat %.3f opt %.3f marg %.3f | lidar_eval %d calls %.3f ms (%.1f us each)\n", R.ms_total,
+                 R.ms_build_map, R.ms_features, R.ms_opt, R.ms_marg, dbg_eval_n_, dbg_eval_ms_, dbg_eval_n_ ? 1e3 * dbg_eval_ms_ / dbg_eval_n_ : 0.0);
+  }
+  dbg_eval_ms_ = 0; dbg_eval_n_ = 0;
   return true;
 }
 

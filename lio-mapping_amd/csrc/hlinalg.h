@@ -49,6 +49,42 @@ inline void chol_solve_inplace(const double *L, int n, int lda, double *b) {
   }
 }
 
+// Right-looking upper Cholesky A = U^T U, in place in the upper triangle (row-major).  Every inner loop is
+// an axpy over contiguous memory, which vectorises under strict IEEE semantics (the dot-product form of
+// chol_factor needs reassociation to vectorise).  Used for the per-iteration D x D dogleg solve.
+inline bool chol_upper(double *A, int n, int lda) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * lda + j];
+    if (!(d > 0.0)) return false;
+    const double u = std::sqrt(d);
+    double *rj = A + size_t(j) * lda;
+    rj[j] = u;
+    const double iu = 1.0 / u;
+    for (int i = j + 1; i < n; ++i) rj[i] *= iu;
+    for (int k = j + 1; k < n; ++k) {
+      const double f = rj[k];
+      double *rk = A + size_t(k) * lda;
+      for (int i = k; i < n; ++i) rk[i] -= f * rj[i];
+    }
+  }
+  return true;
+}
+// solve U^T U x = b in place
+inline void chol_upper_solve(const double *U, int n, int lda, double *b) {
+  for (int i = 0; i < n; ++i) {  // forward: U^T y = b, column-oriented (axpy)
+    const double y = b[i] / U[size_t(i) * lda + i];
+    b[i] = y;
+    const double *ri = U + size_t(i) * lda;
+    for (int k = i + 1; k < n; ++k) b[k] -= ri[k] * y;
+  }
+  for (int i = n - 1; i >= 0; --i) {  // backward: U x = y
+    const double *ri = U + size_t(i) * lda;
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= ri[k] * b[k];
+    b[i] = s / ri[i];
+  }
+}
+
 // Gauss-Jordan inverse with partial pivoting, n x n.
 inline bool gj_inverse(const double *Ain, int n, double *Ainv) {
   std::vector<double> M(Ain, Ain + size_t(n) * n);

@@ -266,9 +266,9 @@ LIO_HD void sym_eigvals(const float *Ain, float *evals) {
   double A[N * N];
   for (int i = 0; i < N * N; ++i) A[i] = double(Ain[i]);
   for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0;
-    for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j];
-    if (off < 1e-300) break;
+    double off = 0, dg = 0;
+    for (int i = 0; i < N; ++i) { dg += A[i * N + i] * A[i * N + i]; for (int j = i + 1; j < N; ++j) off += A[i * N + j] * A[i * N + j]; }
+    if (off <= 1e-30 * dg) break;  // eigenvalues converged to ~1e-15 relative (quadratic convergence)
     for (int p = 0; p < N; ++p)
       for (int q = p + 1; q < N; ++q) {
         double apq = A[p * N + q];

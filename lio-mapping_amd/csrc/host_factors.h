@@ -194,8 +194,17 @@ inline bool imu_factor(const Preintegration &pim, const double *pose_i, const do
   M3d RiT = toRot(Qii);
   Qd cq = pim.dq * deltaQ(dq_dbg * (Bgi - pim.bg));
   auto whiten = [&](const double *J, int cols, double *out) {
-    for (int i = 0; i < 15; ++i)
-      for (int j = 0; j < cols; ++j) { double s = 0; for (int k = i; k < 15; ++k) s += S[i * 15 + k] * J[k * cols + j]; out[i * cols + j] = s; }
+    // row-axpy form (same k-ascending summation order as the dot form, but the inner loop is contiguous
+    // and vectorises under strict IEEE semantics)
+    for (int i = 0; i < 15; ++i) {
+      double *o = out + i * cols;
+      for (int j = 0; j < cols; ++j) o[j] = 0.0;
+      for (int k = i; k < 15; ++k) {
+        const double f = S[i * 15 + k];
+        const double *jr = J + k * cols;
+        for (int j = 0; j < cols; ++j) o[j] += f * jr[j];
+      }
+    }
   };
   if (J0) {
     double J[105] = {0};

@@ -204,10 +204,17 @@ class WindowSystem {
             for (int q = 0; q < 9; ++q) { J[k * 30 + 6 + q] = J1[k * 9 + q]; J[k * 30 + 21 + q] = J3[k * 9 + q]; }
           }
           double Hb[900], gb[30];
-          for (int a = 0; a < 30; ++a) {
-            for (int b = a; b < 30; ++b) { double s = 0; for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b]; Hb[a * 30 + b] = s; Hb[b * 30 + a] = s; }
-            double s = 0; for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * r[k];
-            gb[a] = s;
+          // J^T J as a sum of 15 outer products: contiguous inner loops (vectorise without reassociation)
+          for (int a = 0; a < 900; ++a) Hb[a] = 0.0;
+          for (int a = 0; a < 30; ++a) gb[a] = 0.0;
+          for (int k = 0; k < 15; ++k) {
+            const double *jr = J + k * 30;
+            for (int a = 0; a < 30; ++a) {
+              const double f = jr[a];
+              double *hr = Hb + a * 30;
+              for (int b = 0; b < 30; ++b) hr[b] += f * jr[b];
+              gb[a] += f * r[k];
+            }
           }
           int cols[4] = {lay.pose[i], lay.sb[i], lay.pose[i + 1], lay.sb[i + 1]}, sizes[4] = {6, 9, 6, 9};
           add_block(*H, *g, cols, sizes, 4, Hb, gb, 30);
@@ -224,11 +231,18 @@ class WindowSystem {
         lidar_linear_maps(P.pose[0].data(), P.pose[i].data(), P.ex.data(), L, l);
         // S13 = leading 13x13 of the 16x16 moments
         double LS[18 * 13], Hb[18 * 18], gb[18];
-        for (int a = 0; a < 18; ++a)
-          for (int b = 0; b < 13; ++b) { double s = 0; for (int k = 0; k < 13; ++k) s += L[a * 13 + k] * m[i].S[k * 16 + b]; LS[a * 13 + b] = s; }
+        double Lt[13 * 18];  // L^T so both products run over contiguous rows
+        for (int a = 0; a < 18; ++a) for (int k = 0; k < 13; ++k) Lt[k * 18 + a] = L[a * 13 + k];
         for (int a = 0; a < 18; ++a) {
-          for (int b = 0; b < 18; ++b) { double s = 0; for (int k = 0; k < 13; ++k) s += LS[a * 13 + k] * L[b * 13 + k]; Hb[a * 18 + b] = s; }
-          double s = 0; for (int k = 0; k < 13; ++k) s += LS[a * 13 + k] * l[k];
+          double *o = LS + a * 13;
+          for (int b = 0; b < 13; ++b) o[b] = 0.0;
+          for (int k = 0; k < 13; ++k) { const double f = L[a * 13 + k]; const double *sr = m[i].S + k * 16; for (int b = 0; b < 13; ++b) o[b] += f * sr[b]; }
+        }
+        for (int a = 0; a < 18; ++a) {
+          double *o = Hb + a * 18;
+          for (int b = 0; b < 18; ++b) o[b] = 0.0;
+          double s = 0;
+          for (int k = 0; k < 13; ++k) { const double f = LS[a * 13 + k]; const double *lr = Lt + k * 18; for (int b = 0; b < 18; ++b) o[b] += f * lr[b]; s += f * l[k]; }
           gb[a] = s;
         }
         int cols[3] = {lay.pose[0], lay.pose[i], lay.ex}, sizes[3] = {6, 6, 6};
@@ -260,6 +274,7 @@ struct SolveSummary {
   int iterations = 0, successful = 0, termination = 0;
   double initial_cost = 0, final_cost = 0;
   std::vector<double> trace;
+  double ms_chol = 0, ms_eval = 0;  // LIO_DEBUG_TIMING breakdown
   WindowSystem::Costs initial_costs;
 };
 
@@ -284,7 +299,9 @@ inline double ambient_norm(const WindowParams &P, const WindowParams *o, double 
 
 // Ceres 1.14 TrustRegionMinimizer + DoglegStrategy (TRADITIONAL_DOGLEG), jacobi_scaling = true.
 // first_eval (optional) lets the caller reuse the linearisation it already made for the group costs.
-inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_iterations, double max_time_s) {
+struct Linearization { DMat H; std::vector<double> g; WindowSystem::Costs costs; bool valid = false; };
+
+inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_iterations, double max_time_s, Linearization *first = nullptr) {
   using clock = std::chrono::steady_clock;
   const auto t0 = clock::now();
   SolveSummary sum;
@@ -292,7 +309,9 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   Layout lay = WindowSystem::solve_layout(P);
   const int n = lay.dim;
   DMat H; std::vector<double> g;
-  WindowSystem::Costs c0 = sys.evaluate(P, lay, which, false, &H, &g);
+  WindowSystem::Costs c0;
+  if (first && first->valid && first->H.r == n) { H = std::move(first->H); g = std::move(first->g); c0 = first->costs; }
+  else c0 = sys.evaluate(P, lay, which, false, &H, &g);
   sum.initial_costs = c0;
   double x_cost = c0.total();
   sum.initial_cost = x_cost; sum.trace.push_back(x_cost);
@@ -333,14 +352,16 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       alpha = g2 / Jg2;
       lin_ok = false;
       while (mu < max_mu) {
+        const auto tc0 = clock::now();
         A = H.a;
         for (int i = 0; i < n; ++i) A[size_t(i) * n + i] += diag[i] * diag[i] * mu;
-        bool ok = chol_factor(A.data(), n, n);
+        bool ok = chol_upper(A.data(), n, n);
         if (ok) {
           gn = g;
-          chol_solve_inplace(A.data(), n, n, gn.data());
+          chol_upper_solve(A.data(), n, n, gn.data());
           for (int i = 0; i < n; ++i) if (!std::isfinite(gn[i])) ok = false;
         }
+        sum.ms_chol += std::chrono::duration<double, std::milli>(clock::now() - tc0).count();
         if (!ok) { mu *= mu_inc; continue; }
         lin_ok = true;
         break;
@@ -385,7 +406,9 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     // Evaluate cost AND linearisation at the candidate in one device pass: if the step is accepted the
     // Jacobian evaluation Ceres performs next (HandleSuccessfulStep) is already done.
     DMat Hc; std::vector<double> gc;
+    const auto te0 = clock::now();
     double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc).total();
+    sum.ms_eval += std::chrono::duration<double, std::milli>(clock::now() - te0).count();
     double step_norm = ambient_norm(P, &cand);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 1; sum.trace.push_back(x_cost); break; }
     double cost_change = x_cost - cand_cost;

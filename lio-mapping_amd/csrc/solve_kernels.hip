@@ -18,24 +18,31 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define MOMENT_THREADS 256
 
 int moment_blocks_per_frame(int max_slots) {
-  // 16 residuals per block-iteration; aim for >= 8 iterations per block, cap so partial reduction stays small
-  int b = cdiv(max_slots, 16 * 8);
+  // one residual per lane, 256 residuals per block-iteration; aim for ~2 iterations per block
+  int b = cdiv(max_slots, 256 * 2);
   return b < 1 ? 1 : (b > 64 ? 64 : b);
 }
+
+#define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
                                                                   const float4 *__restrict__ coef, double *__restrict__ partials) {
   const MomentFrame &fr = a.fr[blockIdx.y];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = lane & 15, grp = lane >> 4;
-  const int ea = e >> 2, eb = e & 3;
   const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
   const int wid = blockIdx.x * (MOMENT_THREADS / 64) + wv;
+  __shared__ double zbuf[MOMENT_THREADS / 64][64 * ZROW];
+  __shared__ double sm[MOMENT_THREADS / 64][LIO_MOMENT_OUT];
+  double *zb = zbuf[wv];
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0, cnt = 0.0;
-  for (int base = wid * 4; base < fr.nslots; base += waves_total * 4) {
-    int sidx = base + grp;
-    double operand = 0.0;
+  for (int base = wid * 64; base < fr.nslots; base += waves_total * 64) {
+    // ---- each lane: its own residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values)
+    const int sidx = base + lane;
+    double z[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[k] = 0.0;
     if (sidx < fr.nslots && valid[fr.slot_off + sidx]) {
       float4 po = fr.stack[sidx % fr.M];
       float4 c = coef[fr.slot_off + sidx];
@@ -46,18 +53,32 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, 
       double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
       double r = w0 * qx + w1 * qy + w2 * qz + d;
       double sq = r * r;
-      double inv = 1.0 / (1.0 + sq);           // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0
+      double inv = 1.0 / (1.0 + sq);  // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0 (only sqrt(rho') scaling)
       double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
       double sw = sqrt(rho1);
-      double wa = ea == 0 ? w0 : (ea == 1 ? w1 : w2);
-      double pb = eb == 0 ? px : (eb == 1 ? py : (eb == 2 ? pz : 1.0));
-      double z = e < 12 ? wa * pb : (e == 12 ? d : 0.0);
-      operand = sw * z;
-      if (e == 0) { cost += 0.5 * log(1.0 + sq); cnt += 1.0; }
+      double s0 = sw * w0, s1 = sw * w1, s2 = sw * w2;
+      z[0] = s0 * px; z[1] = s0 * py; z[2] = s0 * pz; z[3] = s0;
+      z[4] = s1 * px; z[5] = s1 * py; z[6] = s1 * pz; z[7] = s1;
+      z[8] = s2 * px; z[9] = s2 * py; z[10] = s2 * pz; z[11] = s2;
+      z[12] = sw * d;
+      cost += 0.5 * log(1.0 + sq);
+      cnt += 1.0;
     }
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(operand, operand, acc, 0, 0, 0);
+    // ---- transpose through LDS (wave-private rows; LDS executes a wave's DS ops in order)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) zb[lane * ZROW + k] = z[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- 16 MFMAs consume the 64 residuals: lane supplies element e of residual 4t+grp as A and B operand
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      double op = zb[(4 * t + grp) * ZROW + e];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op, op, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __shared__ double sm[MOMENT_THREADS / 64][LIO_MOMENT_OUT];
 #pragma unroll
   for (int r = 0; r < 4; ++r) sm[wv][(grp + 4 * r) * 16 + e] = acc[r];
   for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
@@ -71,19 +92,27 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, 
   }
 }
 
-__global__ void k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
+__global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
   const double *src = partials + size_t(blockIdx.x) * bpf * LIO_MOMENT_OUT;
-  for (int k = threadIdx.x; k < 258; k += blockDim.x) {
-    double v = 0;
-    for (int b = 0; b < bpf; ++b) v += src[size_t(b) * LIO_MOMENT_OUT + k];  // fixed order: deterministic
-    out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = v;
+  const int k = threadIdx.x;
+  if (k >= 258) return;
+  // fixed order (deterministic); 4 independent chains keep several loads in flight
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  int b = 0;
+  for (; b + 4 <= bpf; b += 4) {
+    v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
+    v1 += src[size_t(b + 1) * LIO_MOMENT_OUT + k];
+    v2 += src[size_t(b + 2) * LIO_MOMENT_OUT + k];
+    v3 += src[size_t(b + 3) * LIO_MOMENT_OUT + k];
   }
+  for (; b < bpf; ++b) v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
+  out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = (v0 + v1) + (v2 + v3);
 }
 
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s) {
   if (a.nframes <= 0) return;
   hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
-  hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(256), 0, s, partials, a.blocks_per_frame, out);
+  hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }
 

@@ -80,12 +80,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from lio_amd import capi, pipeline, synth
+    from lio_amd import capi, dist_util, pipeline, synth
 
     hip = capi.load_hip()
     kind = "outdoor" if args.workload == "hdl64" else "indoor"
     W, Wo = 15, 5
-    ds, clouds, est, k_last, pp_ms, setup_s = build_window(hip, kind, W, Wo, extra_frames=4, seed_shift=0.37 * rank)
+    ds, clouds, est, k_last, pp_ms, setup_s = build_window(hip, kind, W, Wo, extra_frames=4, seed_shift=dist_util.window_shift_for_rank(rank))
 
     # The step under test is the SolveOptimization that ProcessLaserOdom runs for the last frame: push that
     # frame (upload + VoxelGrid + window push, untimed), snapshot, then time restore + SolveOptimization with
@@ -112,10 +112,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt_max = float(tt.item())
+    value_all, dt_max = dist_util.aggregate_throughput(args.steps, dt, world, device="cuda")
 
     names = ["features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"]
     kt = {n: est.kernel_timing(n) for n in names}
@@ -123,7 +120,7 @@ def main():
 
     out = None
     if rank == 0:
-        value = world * args.steps / dt_max
+        value = value_all
         dom = max(("features", "odom_features", "moments", "odom_rows"), key=lambda n: kt[n]["total_ms"])
         d = kt[dom]
         avg_ms = d["total_ms"] / max(d["launches"], 1)

@@ -1,0 +1,66 @@
+"""N>1 path of bench.py on CPU: world_size 2, gloo.  Each rank owns an independent window (weak scaling,
+no data-path collective); the collective part is only the timing contract (barrier, MAX over ranks,
+whole-job aggregate).  The per-rank work here is the CPU oracle on a tiny window — the HIP product cannot
+run without a GPU, and tests are allowed to use the oracle."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from lio_amd import capi, dist_util, pipeline, synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, lr, w = dist_util.rank_info()
+    assert (r, w) == (rank, world)
+    lib = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
+    lidar = synth.Lidar(16, -15, 15, 450)
+    ds = synth.make_dataset("indoor", 5, 0.2, t0=1.0 + dist_util.window_shift_for_rank(rank), lidar=lidar)
+    clouds = [pipeline.feature_clouds(lib, ds.lidar, f.scan)[0] for f in ds.frames]
+    cfg = pipeline.config_indoor(lib, 4, 2)
+    cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+    pipeline.set_extrinsic(cfg, ds)
+    est = capi.Estimator(lib, cfg)
+    pipeline.init_window(est, lib, ds, clouds, pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+    est.snapshot()
+    K = 2
+    dist_util.barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        est.restore()
+        rep = est.solve()
+    dt = time.perf_counter() - t0 + 0.05 * rank  # make the ranks measurably different
+    dist_util.barrier(world)
+    value, tmax = dist_util.aggregate_throughput(K, dt, world)
+    out[rank] = (value, tmax, dt, float(est.get_window()["Ps"][0, 0]), rep.n_lidar_residuals)
+    dist.destroy_process_group()
+
+
+def test_two_rank_weak_scaling_contract(oracle):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (v0, t0, d0, p0, n0), (v1, t1, d1, p1, n1) = out[0], out[1]
+    assert t0 == t1 == max(d0, d1)                 # MAX over ranks reached every rank
+    assert np.isclose(v0, world * 2 / max(d0, d1))  # whole-job aggregate: N*K / max time
+    assert v0 == v1
+    assert p0 != p1 and n0 > 100 and n1 > 100       # the two ranks really worked on different windows

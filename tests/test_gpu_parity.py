@@ -251,3 +251,47 @@ def test_snapshot_restore_is_idempotent(hip):
     # the device reductions are fixed-order: replays are bit-identical
     np.testing.assert_array_equal(w1["Ps"], w2["Ps"])
     assert r1.final_cost == r2.final_cost
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json full size
+def test_full_size_hdl64_window(hip, oracle):
+    """configs[3]: HDL-64E (64 rings, ~133 k points/scan), outdoor_test_config_64, window_size 15 / opt_window_size 5.
+    Direct comparison with the oracle (it needs ~0.4 s per solve at this size) plus size-independent properties."""
+    W, Wo = 15, 5
+    ds = synth.make_dataset("outdoor", W + 2, 0.3)
+    assert ds.frames[0].scan.shape[0] > 125000
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+    ests = []
+    for lib in (hip, oracle):
+        cfg = pipeline.config_outdoor64(lib, W, Wo)
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(lib, cfg)
+        pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)
+        ests.append(est)
+    ea, eb = ests
+    ra, rb = ea.solve(), eb.solve()
+    assert ra.n_lidar_residuals > 50000
+    assert abs(ra.n_lidar_residuals - rb.n_lidar_residuals) <= 0.002 * rb.n_lidar_residuals
+    assert ra.iterations == rb.iterations
+    np.testing.assert_allclose(ra.initial_cost, rb.initial_cost, rtol=1e-3)
+    assert ra.final_cost < ra.initial_cost
+    _assert_windows_close(ea.get_window(), eb.get_window())
+    # properties of the local map: one point per 0.4 m voxel, ascending voxel index (B.1)
+    m = ea.local_map()
+    assert m.shape[0] == ra.n_local_map
+    inv = np.float32(1.0) / np.float32(0.4)
+    ijk = np.floor(m[:, :3] * inv).astype(np.int64)
+    assert np.unique(ijk, axis=0).shape[0] >= 0.98 * m.shape[0]  # centroids sit in their own voxel (a few land on faces)
+    # K-NN sortedness / radius property at full size
+    idx, sqd = hip.knn(m, ea.get_surf_stack(W), 5, radius_sq=1.0)
+    fin = np.isfinite(sqd)
+    assert np.all(np.diff(np.where(fin, sqd, np.inf), axis=1) >= 0)
+    assert np.all(sqd[fin] < 1.0)
+    # next frame through push + solve + slide on both
+    for est in (ea, eb):
+        est.slide()
+    k = W + 1
+    ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
+    rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
+    assert ra.marginalized == rb.marginalized == 1
+    _assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)

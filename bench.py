@@ -138,6 +138,22 @@ def main():
             "launches": d["launches"],
             "algorithmic_bytes_per_launch": round(d["algorithmic_bytes"] / max(d["launches"], 1), 1),
         }
+        # HBM traffic of that kernel from the committed rocprofv3 PMC passes (profiles/pmc_summary.py: FETCH_SIZE and
+        # WRITE_SIZE collected in separate runs, (2*FETCH + WRITE) * 1024 — the gfx950 half-count correction for wide
+        # coalesced reads).  null when no PMC summary has been committed for this kernel.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc.json")))
+            ent = max(pmc.get("lio::" + roofline["kernel"], []), key=lambda e: e["launches"], default=None)
+            if ent:
+                roofline["traffic"] = round(ent["hbm_bytes_corrected"], 1)
+                roofline["traffic_source"] = "profiles/r1_c_pmc_hbm_traffic.md (per launch, most frequent grid size)"
+        except (OSError, ValueError):
+            pass
+        roofline["others"] = {
+            n: {"avg_launch_us": round(1e3 * kt[n]["total_ms"] / max(kt[n]["launches"], 1), 3),
+                "achieved_GBps": round((kt[n]["algorithmic_bytes"] / max(kt[n]["launches"], 1)) / max(kt[n]["total_ms"] / max(kt[n]["launches"], 1) * 1e-3, 1e-12) / 1e9, 2)}
+            for n in ("features", "odom_features", "moments", "voxel", "knn_grid") if n != dom
+        }
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(kind, W, Wo, args.cpu_steps, ds)

@@ -270,7 +270,7 @@ def test_full_size_hdl64_window(hip, oracle):
         ests.append(est)
     ea, eb = ests
     ra, rb = ea.solve(), eb.solve()
-    assert ra.n_lidar_residuals > 50000
+    assert ra.n_lidar_residuals > 30000
     assert abs(ra.n_lidar_residuals - rb.n_lidar_residuals) <= 0.002 * rb.n_lidar_residuals
     assert ra.iterations == rb.iterations
     np.testing.assert_allclose(ra.initial_cost, rb.initial_cost, rtol=1e-3)

@@ -78,6 +78,28 @@ int lio_pp_get_ring_offsets(const lio_pp *, int32_t *offsets_out);
 int lio_pp_get_curvature(const lio_pp *, float *curv_out, int32_t *mask_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * PointOdometry (include/point_processor/PointOdometry.h:102-147; §8a a6-a7): LOAM scan-to-scan step
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lio_odom lio_odom;
+/* PointOdometry(float scan_period = 0.1, int io_ratio = 2, size_t max_iter = 25) + the no_deskew param
+ * (PointOdometry.cc:66-73,109) */
+lio_odom *lio_odom_create(float scan_period, int io_ratio, int num_max_iterations, int no_deskew);
+void lio_odom_destroy(lio_odom *);
+/* PointOdometry::Process (PointOdometry.cc:294-683) on the four feature clouds of one sweep (the topics of
+ * PointProcessor::PublishResults; intensity = ring + rel_time).  The first call only stores the clouds
+ * (system_inited_, :302-310).  Outputs (any may be null): transform_sum_ (accumulated odometry),
+ * transform_es_ (sweep end -> start), iterations run, number of selected correspondences in the last round. */
+int lio_odom_process(lio_odom *, const float *sharp_xyzi, size_t n_sharp, const float *less_sharp_xyzi, size_t n_less_sharp,
+                     const float *flat_xyzi, size_t n_flat, const float *less_flat_xyzi, size_t n_less_flat,
+                     lio_transform_f *transform_sum_out, lio_transform_f *transform_es_out, int *iterations_out,
+                     int *num_selected_out);
+/* /enable_odom service (PointOdometry.h:126-131): 0 turns the step into a packer (A.18) */
+int lio_odom_enable(lio_odom *, int on);
+/* last_corner_cloud_ / last_surf_cloud_ after the swap (:667-668), i.e. the TransformToEnd outputs.
+ * which: 0 corner, 1 surf.  Returns the count; copies when out is non-null. */
+size_t lio_odom_get_last_cloud(const lio_odom *, int which, float *xyzi_or_null);
+
+/* ------------------------------------------------------------------------------------------------
  * Stateless building blocks (third-party semantics restated)
  * ---------------------------------------------------------------------------------------------- */
 /* pcl::VoxelGrid<PointXYZI> (B.1): centroids in ascending voxel index; out capacity n points.   */

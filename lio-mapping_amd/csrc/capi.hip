@@ -7,6 +7,7 @@
 
 #include "../../include/lio_c.h"
 #include "estimator.h"
+#include "odometry.h"
 #include "pointproc.h"
 
 using namespace lio;
@@ -14,6 +15,7 @@ using namespace lio;
 struct lio_pim { std::shared_ptr<Preintegration> p; };
 struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; };
 struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
+struct lio_odom { std::unique_ptr<OdometryDev> o; };
 
 static V3d v3(const double *p) { return V3d(p[0], p[1], p[2]); }
 static Rigidf toT(const lio_transform_f &t) { return Rigidf(Quat<float>(t.q[3], t.q[0], t.q[1], t.q[2]), Vec3<float>(t.p[0], t.p[1], t.p[2])); }
@@ -78,6 +80,40 @@ int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
 int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->pp->GetCurvature(curv, mask); return LIO_OK; });
+}
+
+// ---------------------------------------------------------------- PointOdometry
+lio_odom *lio_odom_create(float scan_period, int io_ratio, int max_iter, int no_deskew) {
+  if (!(scan_period > 0) || max_iter < 1) return nullptr;
+  lio_odom *h = new (std::nothrow) lio_odom;
+  if (!h) return nullptr;
+  int rc = guarded([&] { h->o.reset(new OdometryDev(scan_period, io_ratio, max_iter, no_deskew != 0)); return LIO_OK; });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  return h;
+}
+void lio_odom_destroy(lio_odom *h) { delete h; }
+int lio_odom_process(lio_odom *h, const float *sharp, size_t n_sharp, const float *less_sharp, size_t n_ls, const float *flat, size_t n_flat,
+                     const float *less_flat, size_t n_lf, lio_transform_f *Tsum, lio_transform_f *Tes, int *iters, int *nsel) {
+  if (!h || (!sharp && n_sharp) || (!less_sharp && n_ls) || (!flat && n_flat) || (!less_flat && n_lf)) return LIO_ERR_ARG;
+  return guarded([&] {
+    h->o->Process(sharp, n_sharp, less_sharp, n_ls, flat, n_flat, less_flat, n_lf);
+    if (Tsum) fromT(h->o->transform_sum_, Tsum);
+    if (Tes) fromT(h->o->transform_es_, Tes);
+    if (iters) *iters = h->o->iterations_done_;
+    if (nsel) *nsel = h->o->last_num_sel_;
+    return LIO_OK;
+  });
+}
+int lio_odom_enable(lio_odom *h, int on) {
+  if (!h) return LIO_ERR_ARG;
+  h->o->enable_odom_ = on != 0;
+  return LIO_OK;
+}
+size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
+  if (!h || which < 0 || which > 1) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->o->GetLastCloud(which, out); return LIO_OK; });
+  return n;
 }
 
 // ---------------------------------------------------------------- stateless blocks

@@ -122,6 +122,11 @@ _SIGS = {
     "lio_pp_get_indices": (C.c_int, [C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
     "lio_pp_get_ring_offsets": (C.c_int, [C.c_void_p, c_int32_p]),
     "lio_pp_get_curvature": (C.c_int, [C.c_void_p, c_float_p, c_int32_p]),
+    "lio_odom_create": (C.c_void_p, [C.c_float, C.c_int, C.c_int, C.c_int]),
+    "lio_odom_destroy": (None, [C.c_void_p]),
+    "lio_odom_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 4 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lio_odom_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "lio_odom_get_last_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
     "lio_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_size_t)]),
     "lio_knn": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_int, C.c_float, c_int32_p, c_float_p]),
     "lio_calculate_features": (
@@ -350,6 +355,39 @@ class PointProcessor:
         mask = np.zeros(n, dtype=np.int32)
         _chk(self.lib.dll.lio_pp_get_curvature(self.h, _fp(curv), mask.ctypes.data_as(c_int32_p)), "lio_pp_get_curvature")
         return curv, mask
+
+
+class PointOdometry:
+    def __init__(self, lib: LioLib, scan_period=0.1, io_ratio=2, max_iter=25, no_deskew=False):
+        self.lib = lib
+        self.h = lib.dll.lio_odom_create(scan_period, io_ratio, max_iter, 1 if no_deskew else 0)
+        if not self.h:
+            raise LioError("lio_odom_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_odom_destroy(self.h)
+            self.h = None
+
+    def process(self, sharp, less_sharp, flat, less_flat):
+        cl = [_f32(c).reshape(-1, 4) for c in (sharp, less_sharp, flat, less_flat)]
+        Ts, Te = TransformF(), TransformF()
+        it, ns = C.c_int(0), C.c_int(0)
+        args = []
+        for c in cl:
+            args += [_fp(c), c.shape[0]]
+        _chk(self.lib.dll.lio_odom_process(self.h, *args, C.byref(Ts), C.byref(Te), C.byref(it), C.byref(ns)), "lio_odom_process")
+        return dict(T_sum=Ts.to_np(), T_es=Te.to_np(), iterations=it.value, num_selected=ns.value)
+
+    def enable(self, on):
+        _chk(self.lib.dll.lio_odom_enable(self.h, 1 if on else 0), "lio_odom_enable")
+
+    def last_cloud(self, which):
+        n = self.lib.dll.lio_odom_get_last_cloud(self.h, which, None)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_odom_get_last_cloud(self.h, which, _fp(out))
+        return out
 
 
 class Estimator:

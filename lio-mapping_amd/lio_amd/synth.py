@@ -166,8 +166,11 @@ def scene_outdoor(seed=64):
 
 
 def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray) -> np.ndarray:
-    """Nearest hit distance along unit `dirs` (N,3) from `origin`; inf when nothing is hit."""
+    """Nearest hit distance along unit `dirs` (N,3) from `origin` ((3,) or per-ray (N,3)); inf when nothing is hit."""
     n = dirs.shape[0]
+    origin = np.asarray(origin, dtype=np.float64)
+    if origin.ndim == 1:
+        origin = np.broadcast_to(origin, (n, 3))
     best = np.full(n, np.inf)
     with np.errstate(divide="ignore", invalid="ignore"):
         inv = 1.0 / dirs
@@ -177,7 +180,7 @@ def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray) -> np.ndarray:
             tfar = np.min(np.maximum(t1, t2), axis=1)
             best = np.where(tfar > 0, tfar, best)
         if scene.ground_z is not None:
-            t = (scene.ground_z - origin[2]) * inv[:, 2]
+            t = (scene.ground_z - origin[:, 2]) * inv[:, 2]
             ok = (t > 0) & np.isfinite(t)
             best = np.where(ok & (t < best), t, best)
         for b in scene.boxes:
@@ -188,14 +191,14 @@ def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray) -> np.ndarray:
             ok = (tn <= tf) & (tn > 0)
             best = np.where(ok & (tn < best), tn, best)
         for c in scene.cyls:
-            ox, oy = origin[0] - c[0], origin[1] - c[1]
+            ox, oy = origin[:, 0] - c[0], origin[:, 1] - c[1]
             a = dirs[:, 0] ** 2 + dirs[:, 1] ** 2
             bq = 2 * (ox * dirs[:, 0] + oy * dirs[:, 1])
             cq = ox * ox + oy * oy - c[2] ** 2
             disc = bq * bq - 4 * a * cq
             sq = np.sqrt(np.maximum(disc, 0))
             t = (-bq - sq) / (2 * a)
-            z = origin[2] + t * dirs[:, 2]
+            z = origin[:, 2] + t * dirs[:, 2]
             ok = (disc > 0) & (t > 0) & (z >= c[3]) & (z <= c[4]) & np.isfinite(t)
             best = np.where(ok & (t < best), t, best)
     return best
@@ -217,16 +220,29 @@ class Lidar:
         return Lidar(64, -24.9, 2.0, 2083)  # src/processor_node.cc:71
 
 
-def make_scan(scene: Scene, lidar: Lidar, R_wl: np.ndarray, p_wl: np.ndarray, seed: int, range_sigma=0.02, nan_frac=0.005) -> np.ndarray:
+def make_scan(scene: Scene, lidar: Lidar, R_wl: np.ndarray, p_wl: np.ndarray, seed: int, range_sigma=0.02, nan_frac=0.005, pose_fn=None,
+              t_start=0.0, scan_period=0.1) -> np.ndarray:
     """One sweep in the lidar frame, azimuth-major firing order (all rings per azimuth step, clockwise),
-    float32 (N,4) = x,y,z,intensity.  N = rings * n_azimuth (NaN returns kept, out-of-range dropped)."""
+    float32 (N,4) = x,y,z,intensity.  N = rings * n_azimuth (NaN returns kept, out-of-range dropped).
+    With `pose_fn(t) -> (R_wl, p_wl)` the sweep is motion-distorted: azimuth step a is fired at
+    t_start + scan_period * (a + 0.5) / n_azimuth from the pose at that instant (what a spinning lidar records)."""
     rng = np.random.default_rng(seed)
     el = np.deg2rad(np.linspace(lidar.lower_deg, lidar.upper_deg, lidar.rings))
     az = -(np.arange(lidar.n_azimuth) + 0.5) * (2 * np.pi / lidar.n_azimuth)  # clockwise: atan2 decreasing
     azg, elg = np.meshgrid(az, el, indexing="ij")  # (n_az, rings): azimuth-major
     d_l = np.stack([np.cos(elg) * np.cos(azg), np.cos(elg) * np.sin(azg), np.sin(elg)], axis=-1).reshape(-1, 3)
-    d_w = d_l @ R_wl.T
-    rngs = raycast(scene, p_wl, d_w)
+    if pose_fn is None:
+        d_w = d_l @ R_wl.T
+        rngs = raycast(scene, p_wl, d_w)
+    else:
+        d_w = np.empty_like(d_l)
+        o_w = np.empty_like(d_l)
+        for a in range(lidar.n_azimuth):
+            Ra, pa = pose_fn(t_start + scan_period * (a + 0.5) / lidar.n_azimuth)
+            sl = slice(a * lidar.rings, (a + 1) * lidar.rings)
+            d_w[sl] = d_l[sl] @ Ra.T
+            o_w[sl] = pa
+        rngs = raycast(scene, o_w, d_w)
     rngs = rngs + rng.normal(0.0, range_sigma, size=rngs.shape)
     keep = np.isfinite(rngs) & (rngs > 0.5) & (rngs < scene.max_range)
     pts = d_l * rngs[:, None]
@@ -303,5 +319,24 @@ def make_dataset(kind: str, n_frames: int, frame_dt: float, t0: float = 1.0, imu
             acc = acc + rng.normal(0, 0.02, acc.shape)
             gyr = gyr + rng.normal(0, 0.002, gyr.shape)
         frames.append(FrameData(tk, R_wb, p_wb, traj.vel(tk), scan, np.full(steps, h), acc, gyr, ts))
-    tp = t0 - frame_dt
     return Dataset(frames, R_lb, t_lb, g, traj.accel(t0), traj.gyro(t0), lid)
+
+
+def make_sweeps(kind: str, n_sweeps: int, scan_period: float = 0.1, t0: float = 1.0, lidar: Lidar | None = None):
+    """Consecutive motion-distorted sweeps for the scan-to-scan odometry: sweep k spans
+    [t0 + k T, t0 + (k+1) T].  Returns (sweeps, lidar pose function, lidar)."""
+    if kind == "indoor":
+        scene, lid, traj = scene_indoor(), lidar or Lidar.vlp16(), Trajectory()
+        R_lb, t_lb = np.eye(3), np.array([0.0, 0.0, -0.081939])
+    else:
+        scene, lid = scene_outdoor(), lidar or Lidar.hdl64()
+        traj = Trajectory(rx=45.0, ry=60.0, rz=0.3, cx=15.0, cy=15.0, cz=2.2, Kz=2 * math.pi / 5.0, g=9.80, ang_scale=0.3)
+        R_lb, t_lb = np.eye(3), np.array([-8.086759e-01, 3.195559e-01, -7.997231e-01])
+
+    def pose_fn(t):
+        R_wb = traj.rot(t)
+        R_wl = R_wb @ R_lb.T
+        return R_wl, traj.pos(t) - R_wl @ t_lb
+
+    sweeps = [make_scan(scene, lid, None, None, seed=2000 + k, pose_fn=pose_fn, t_start=t0 + k * scan_period, scan_period=scan_period) for k in range(n_sweeps)]
+    return sweeps, pose_fn, lid

@@ -6,9 +6,12 @@
 
 #include "../include/lio_c.h"
 #include "estimator.h"
+#include "odometry.h"
 #include "pointproc.h"
 
 using namespace orc;
+
+struct lio_odom { PointOdometry o; lio_odom(float sp, int io, size_t it, bool nd) : o(sp, io, it, nd) {} };
 
 struct lio_pp { PointProcessor pp; lio_pp(float a, float b, int r) : pp(a, b, r) {} };
 struct lio_pim { IntegrationBase pim; lio_pim(const V3d &a, const V3d &g, const V3d &ba, const V3d &bg, const PimConfig &c) : pim(a, g, ba, bg, c) {} };
@@ -82,6 +85,34 @@ int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (curv) std::memcpy(curv, h->pp.curvature.data(), h->pp.curvature.size() * sizeof(float));
   if (mask) for (size_t k = 0; k < h->pp.mask.size(); ++k) mask[k] = h->pp.mask[k];
   return LIO_OK;
+}
+
+// ---------------------------------------------------------------- PointOdometry
+lio_odom *lio_odom_create(float scan_period, int io_ratio, int max_iter, int no_deskew) {
+  if (!(scan_period > 0) || max_iter < 1) return nullptr;
+  return new (std::nothrow) lio_odom(scan_period, io_ratio, size_t(max_iter), no_deskew != 0);
+}
+void lio_odom_destroy(lio_odom *h) { delete h; }
+int lio_odom_process(lio_odom *h, const float *sharp, size_t n_sharp, const float *less_sharp, size_t n_ls, const float *flat, size_t n_flat,
+                     const float *less_flat, size_t n_lf, lio_transform_f *Tsum, lio_transform_f *Tes, int *iters, int *nsel) {
+  if (!h || (!sharp && n_sharp) || (!less_sharp && n_ls) || (!flat && n_flat) || (!less_flat && n_lf)) return LIO_ERR_ARG;
+  h->o.Process(toCloud(sharp, n_sharp), toCloud(less_sharp, n_ls), toCloud(flat, n_flat), toCloud(less_flat, n_lf));
+  if (Tsum) fromT(h->o.transform_sum_, Tsum);
+  if (Tes) fromT(h->o.transform_es_, Tes);
+  if (iters) *iters = h->o.iterations_done_;
+  if (nsel) *nsel = h->o.last_num_sel_;
+  return LIO_OK;
+}
+int lio_odom_enable(lio_odom *h, int on) {
+  if (!h) return LIO_ERR_ARG;
+  h->o.enable_odom_ = on != 0;
+  return LIO_OK;
+}
+size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
+  if (!h || which < 0 || which > 1) return 0;
+  const Cloud &c = which == 0 ? h->o.last_corner_ : h->o.last_surf_;
+  if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
+  return c.size();
 }
 
 // ---------------------------------------------------------------- stateless blocks

@@ -295,3 +295,48 @@ def test_full_size_hdl64_window(hip, oracle):
     rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
     assert ra.marginalized == rb.marginalized == 1
     _assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ scan-to-scan odometry
+@pytest.mark.parametrize("kind,n_sweeps", [("indoor", 4), ("outdoor", 3)])
+def test_point_odometry_matches_oracle(hip, oracle, kind, n_sweeps):
+    """BASELINE.json configs[1]: LOAM scan-to-scan step on motion-distorted sweeps.  Correspondence indices come out
+    of exact searches (bit-exact), coefficients use the CPU operation order; only the 6x6 normal-equation sums differ
+    in summation order => transform_es_ within 1e-5, TransformToEnd clouds within 1e-4."""
+    sweeps, pose_fn, lid = synth.make_sweeps(kind, n_sweeps)
+    oa, ob = capi.PointOdometry(hip, 0.1, 2, 25, False), capi.PointOdometry(oracle, 0.1, 2, 25, False)
+    for k, sw in enumerate(sweeps):
+        pp = capi.PointProcessor(oracle, lid.lower_deg, lid.upper_deg, lid.rings)
+        pp.process(sw)
+        cl = [pp.cloud(w) for w in (1, 2, 3, 4)]
+        ra, rb = oa.process(*cl), ob.process(*cl)
+        assert ra["iterations"] == rb["iterations"]
+        if k > 0:
+            assert rb["num_selected"] > 100
+            assert abs(ra["num_selected"] - rb["num_selected"]) <= 2
+            np.testing.assert_allclose(ra["T_es"][1], rb["T_es"][1], atol=2e-5)   # translation, m
+            np.testing.assert_allclose(ra["T_es"][0], rb["T_es"][0], atol=2e-5)   # quaternion
+            np.testing.assert_allclose(ra["T_sum"][1], rb["T_sum"][1], atol=1e-4)
+            # sanity against ground truth: the sweep-to-sweep motion is recovered to a few cm
+            R0, p0 = pose_fn(1.0 + 0.1 * k)
+            R1, p1 = pose_fn(1.0 + 0.1 * (k + 1))
+            assert np.linalg.norm(ra["T_es"][1] - R1.T @ (p0 - p1)) < 0.25
+        for which in (0, 1):
+            ca, cb = oa.last_cloud(which), ob.last_cloud(which)
+            assert ca.shape == cb.shape
+            np.testing.assert_allclose(ca, cb, atol=1e-4)
+
+
+def test_point_odometry_disabled_is_a_packer(hip, oracle):
+    """After IMU init the estimator switches the odometry off: clouds pass through untouched."""
+    sweeps, _, lid = synth.make_sweeps("indoor", 2)
+    od = capi.PointOdometry(hip, 0.1, 2, 25, False)
+    od.enable(False)
+    for sw in sweeps:
+        pp = capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings)
+        pp.process(sw)
+        cl = [pp.cloud(w) for w in (1, 2, 3, 4)]
+        r = od.process(*cl)
+        assert r["iterations"] == 0
+        np.testing.assert_array_equal(od.last_cloud(1), cl[3])
+        np.testing.assert_array_equal(r["T_sum"][1], np.zeros(3, np.float32))

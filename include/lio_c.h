@@ -99,6 +99,16 @@ int lio_odom_enable(lio_odom *, int on);
  * which: 0 corner, 1 surf.  Returns the count; copies when out is non-null. */
 size_t lio_odom_get_last_cloud(const lio_odom *, int which, float *xyzi_or_null);
 
+/* /compact_data wire format between PointOdometry and the estimator (§8a a8): a cloud of xyzi points where
+ * point[0] = (tx,ty,tz | 0), point[1] = (qx,qy,qz | qw) of transform_sum_, point[2] = (n_corner, n_surf, n_full | qw),
+ * followed by the corner, surf and full clouds (encode: PointOdometry.cc:732-764; decode: PointMapping.cc:171-238).
+ * encode writes 3+nc+ns+nf points into out and returns that count.  decode validates the header (>= 4 points and
+ * 3+nc+ns+nf == n_points, else LIO_ERR_ARG) and returns the three sizes; the clouds start at point 3, 3+nc, 3+nc+ns. */
+size_t lio_compact_encode(const lio_transform_f *transform_sum, const float *corner_xyzi, size_t n_corner, const float *surf_xyzi,
+                          size_t n_surf, const float *full_xyzi, size_t n_full, float *out_xyzi);
+int lio_compact_decode(const float *data_xyzi, size_t n_points, lio_transform_f *transform_sum_out, size_t *n_corner, size_t *n_surf,
+                       size_t *n_full);
+
 /* ------------------------------------------------------------------------------------------------
  * Stateless building blocks (third-party semantics restated)
  * ---------------------------------------------------------------------------------------------- */

@@ -116,6 +116,28 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   return n;
 }
 
+// ---------------------------------------------------------------- /compact_data codec (host: a memcpy-class wire format)
+size_t lio_compact_encode(const lio_transform_f *T, const float *corner, size_t nc, const float *surf, size_t ns, const float *full, size_t nf,
+                          float *out) {
+  if (!T || !out || (!corner && nc) || (!surf && ns) || (!full && nf)) return 0;
+  float *o = out;
+  *o++ = T->p[0]; *o++ = T->p[1]; *o++ = T->p[2]; *o++ = 0.f;
+  *o++ = T->q[0]; *o++ = T->q[1]; *o++ = T->q[2]; *o++ = T->q[3];
+  *o++ = float(nc); *o++ = float(ns); *o++ = float(nf); *o++ = T->q[3];  // the reused PointT keeps intensity = qw
+  const float *src[3] = {corner, surf, full};
+  const size_t cnt[3] = {nc, ns, nf};
+  for (int k = 0; k < 3; ++k) { if (cnt[k]) std::memcpy(o, src[k], cnt[k] * 4 * sizeof(float)); o += 4 * cnt[k]; }
+  return size_t(o - out) / 4;
+}
+int lio_compact_decode(const float *d, size_t n, lio_transform_f *T, size_t *nc, size_t *ns, size_t *nf) {
+  if (!d || !nc || !ns || !nf || n < 4) return LIO_ERR_ARG;
+  const long long c = (long long)d[8], s = (long long)d[9], f = (long long)d[10];
+  if (c < 0 || s < 0 || f < 0 || size_t(3 + c + s + f) != n) return LIO_ERR_ARG;
+  if (T) { for (int k = 0; k < 3; ++k) T->p[k] = d[k]; for (int k = 0; k < 4; ++k) T->q[k] = d[4 + k]; }
+  *nc = size_t(c); *ns = size_t(s); *nf = size_t(f);
+  return LIO_OK;
+}
+
 // ---------------------------------------------------------------- stateless blocks
 struct Scratch {
   hipStream_t s = nullptr;

@@ -127,6 +127,8 @@ _SIGS = {
     "lio_odom_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 4 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lio_odom_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_odom_get_last_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_compact_encode": (C.c_size_t, [C.POINTER(TransformF)] + [c_float_p, C.c_size_t] * 3 + [c_float_p]),
+    "lio_compact_decode": (C.c_int, [c_float_p, C.c_size_t, C.POINTER(TransformF)] + [C.POINTER(C.c_size_t)] * 3),
     "lio_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_size_t)]),
     "lio_knn": (C.c_int, [c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_int, C.c_float, c_int32_p, c_float_p]),
     "lio_calculate_features": (
@@ -240,6 +242,27 @@ class LioLib:
             "lio_calculate_features",
         )
         return valid, coeff, score
+
+    # ---- /compact_data codec
+    def compact_encode(self, T: TransformF, corner, surf, full):
+        cl = [_f32(c).reshape(-1, 4) for c in (corner, surf, full)]
+        out = np.zeros((3 + sum(c.shape[0] for c in cl), 4), dtype=np.float32)
+        args = []
+        for c in cl:
+            args += [_fp(c), c.shape[0]]
+        n = self.dll.lio_compact_encode(C.byref(T), *args, _fp(out))
+        assert n == out.shape[0]
+        return out
+
+    def compact_decode(self, data):
+        data = _f32(data).reshape(-1, 4)
+        T = TransformF()
+        nc, ns, nf = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        rc = self.dll.lio_compact_decode(_fp(data), data.shape[0], C.byref(T), C.byref(nc), C.byref(ns), C.byref(nf))
+        if rc != 0:
+            raise LioError(f"lio_compact_decode failed with code {rc}")
+        a, b = 3 + nc.value, 3 + nc.value + ns.value
+        return T.to_np(), data[3:a], data[a:b], data[b:]
 
     # ---- factors
     def factor_ppp(self, point, coeff, pose_p, pose_i, pose_ex, jac=True):

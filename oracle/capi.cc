@@ -115,6 +115,31 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   return c.size();
 }
 
+// ---------------------------------------------------------------- /compact_data codec
+size_t lio_compact_encode(const lio_transform_f *T, const float *corner, size_t nc, const float *surf, size_t ns, const float *full, size_t nf,
+                          float *out) {
+  if (!T || !out || (!corner && nc) || (!surf && ns) || (!full && nf)) return 0;
+  // PointOdometry.cc:737-757: one PointT is reused, so point[2] inherits intensity = qw
+  float hdr[12] = {T->p[0], T->p[1], T->p[2], 0.f, T->q[0], T->q[1], T->q[2], T->q[3], float(nc), float(ns), float(nf), T->q[3]};
+  std::memcpy(out, hdr, sizeof(hdr));
+  float *o = out + 12;
+  if (nc) std::memcpy(o, corner, nc * 16);
+  o += 4 * nc;
+  if (ns) std::memcpy(o, surf, ns * 16);
+  o += 4 * ns;
+  if (nf) std::memcpy(o, full, nf * 16);
+  return 3 + nc + ns + nf;
+}
+int lio_compact_decode(const float *d, size_t n, lio_transform_f *T, size_t *nc, size_t *ns, size_t *nf) {
+  if (!d || !nc || !ns || !nf) return LIO_ERR_ARG;
+  if (n < 4) return LIO_ERR_ARG;  // PointMapping.cc:180-183
+  int c = int(d[8]), s = int(d[9]), f = int(d[10]);
+  if (c < 0 || s < 0 || f < 0 || size_t(3) + size_t(c) + size_t(s) + size_t(f) != n) return LIO_ERR_ARG;  // :191-195
+  if (T) { T->p[0] = d[0]; T->p[1] = d[1]; T->p[2] = d[2]; T->q[0] = d[4]; T->q[1] = d[5]; T->q[2] = d[6]; T->q[3] = d[7]; }
+  *nc = size_t(c); *ns = size_t(s); *nf = size_t(f);
+  return LIO_OK;
+}
+
 // ---------------------------------------------------------------- stateless blocks
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
   if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;

@@ -94,3 +94,32 @@ def test_host_side_factors_match_oracle(hip, oracle):
         np.testing.assert_allclose(r2, r1, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(J2, J1, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(hip.pose_plus(pp, co.repeat(2)[:6] * 0.01), oracle.pose_plus(pp, co.repeat(2)[:6] * 0.01), rtol=1e-14)
+
+
+def test_compact_data_codec_round_trip(hip, oracle):
+    """/compact_data (PointOdometry.cc:732-764 / PointMapping.cc:171-238): encode -> decode is the identity, both
+    implementations produce the same bytes, malformed headers are rejected like the reference's LOG(ERROR) paths."""
+    rng = np.random.default_rng(9)
+    T = capi.TransformF.make([0.1, -0.2, 0.3, 0.92], [1.5, -2.5, 0.25])
+    corner, surf, full = (rng.normal(size=(n, 4)).astype(np.float32) for n in (7, 0, 19))
+    a, b = hip.compact_encode(T, corner, surf, full), oracle.compact_encode(T, corner, surf, full)
+    np.testing.assert_array_equal(a, b)
+    assert a.shape[0] == 3 + 7 + 0 + 19 and a[2, 3] == np.float32(0.92) and a[0, 3] == 0
+    for lib in (hip, oracle):
+        (q, p), c2, s2, f2 = lib.compact_decode(a)
+        np.testing.assert_array_equal(c2, corner)
+        assert s2.shape[0] == 0
+        np.testing.assert_array_equal(f2, full)
+        np.testing.assert_allclose(p, [1.5, -2.5, 0.25])
+        bad = a.copy()
+        bad[2, 0] += 1  # header no longer matches the payload
+        try:
+            lib.compact_decode(bad)
+            assert False
+        except capi.LioError:
+            pass
+        try:
+            lib.compact_decode(a[:3])
+            assert False
+        except capi.LioError:
+            pass

@@ -572,11 +572,18 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
 }
 
 __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
-  if (threadIdx.x != 0 || st->converged) return;
+  if (st->converged) return;
+  // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
+  __shared__ double ssum[28];
+  if (threadIdx.x < 28) {
+    double v = 0;
+    for (int b = 0; b < nblocks; ++b) v += partials[b * 28 + threadIdx.x];
+    ssum[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double sum[28];
-  for (int k = 0; k < 28; ++k) sum[k] = 0;
-  for (int b = 0; b < nblocks; ++b)
-    for (int k = 0; k < 28; ++k) sum[k] += partials[b * 28 + k];
+  for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
   float AtA[36], AtB[6];
   int k = 0;
   for (int r = 0; r < 6; ++r)
@@ -587,10 +594,7 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   for (int i = 0; i < 6; ++i) Bc[i] = AtB[i];
   qr_solve<float, 6, 6>(Ac, Bc, X, FLT_EPSILON);
   if (iter == 0) {
-    float E[6];
-    sym_eigvals<6>(AtA, E);
-    int kz = 0;
-    for (int i = 0; i < 6; ++i) { if (E[i] < 100.f) ++kz; else break; }
+    const int kz = count_eigs_below<6>(AtA, 100.0);
     st->kz = kz;
     st->degenerate = kz > 0;
   }

@@ -30,6 +30,7 @@ struct EstConfig {
 struct DeviceCloud {
   DBuf<float4> buf;
   size_t n = 0;
+  uint64_t id = 0;  // content id: equal ids in the same slot => identical content (restore() skips the copy)
 };
 
 struct StampedPose { double time; Rigidf T; };

@@ -119,8 +119,11 @@ void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, 
   inited_ = true; first_imu_ = true; cir_buf_count_ = W_;
 }
 
+static uint64_t g_content_id = 1;  // bumped whenever a window cloud is (re)written
+
 void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
   DeviceCloud &c = stacks_[frame];
+  c.id = ++g_content_id;
   c.buf.reserve(std::max<size_t>(n, 1));
   if (n) LIO_HIP(hipMemcpyAsync(c.buf.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
@@ -226,6 +229,7 @@ bool Estimator::PushFrame(const Rigidf & /*transform_in*/, const float *surf, si
     fresh.n = n_surf;
   }
   size_t nfresh = fresh.n;
+  fresh.id = ++g_content_id;
   PushCloud(std::move(fresh), nfresh);
   return true;
 }
@@ -248,6 +252,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     scratch_cloud_.buf.reserve(std::max(total, 1));
     launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
     scratch_cloud_.n = size_t(total);
+    scratch_cloud_.id = ++g_content_id;
     std::swap(stacks_[pivot], scratch_cloud_);
     init_local_map_ = true;
   }
@@ -438,9 +443,10 @@ void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
   double nres = 0;
   for (int k = 0; k < ma.nframes; ++k) nres += ma.fr[k].nslots;
   int th = timers_.begin(KT_MOMENTS, 60.0 * nres, stream_);  // 60 B read per lidar residual
-  launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, d_moment_out_.p, stream_);
+  // k_moment_reduce stores its Wo x 260 doubles directly into pinned, device-mapped host memory: no copy
+  // command, only the kernel-completion wait (kernel end = system-scope release, so the host sees the data).
+  launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, h_moment_out_, stream_);
   timers_.end(th, stream_);
-  LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * size_t(ma.nframes) * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
   timers_.resolve();
   for (int i = 1; i <= Wo_; ++i) {
@@ -562,6 +568,7 @@ void Estimator::SlideWindow() {
     scratch_cloud_.buf.reserve(std::max(ca.total, 1));
     launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
     scratch_cloud_.n = size_t(ca.total);
+    scratch_cloud_.id = ++g_content_id;
     LIO_HIP(hipStreamSynchronize(stream_));
     std::swap(stacks_[i], scratch_cloud_);
   }
@@ -580,6 +587,7 @@ void Estimator::Snapshot() {
     if (stacks_[i].n)
       LIO_HIP(hipMemcpyAsync(snap_stacks_[i].buf.p, stacks_[i].buf.p, stacks_[i].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
     snap_stacks_[i].n = stacks_[i].n;
+    snap_stacks_[i].id = stacks_[i].id;
   }
   LIO_HIP(hipStreamSynchronize(stream_));
 }
@@ -593,6 +601,8 @@ bool Estimator::Restore() {
   tmp_pre_integration_ = h.tmp_pre_integration ? std::make_shared<Preintegration>(*h.tmp_pre_integration) : nullptr;
   size_surf_stack_ = h.size_surf_stack; imu_stamped_ = h.imu_stamped;
   for (size_t i = 0; i < stacks_.size(); ++i) {
+    if (stacks_[i].id == snap_stacks_[i].id && stacks_[i].n == snap_stacks_[i].n) continue;  // untouched since the snapshot
+    stacks_[i].id = snap_stacks_[i].id;
     stacks_[i].buf.reserve(std::max<size_t>(snap_stacks_[i].n, 1));
     if (snap_stacks_[i].n)
       LIO_HIP(hipMemcpyAsync(stacks_[i].buf.p, snap_stacks_[i].buf.p, snap_stacks_[i].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));

@@ -53,18 +53,47 @@ inline void chol_solve_inplace(const double *L, int n, int lda, double *b) {
 // an axpy over contiguous memory, which vectorises under strict IEEE semantics (the dot-product form of
 // chol_factor needs reassociation to vectorise).  Used for the per-iteration D x D dogleg solve.
 inline bool chol_upper(double *A, int n, int lda) {
-  for (int j = 0; j < n; ++j) {
-    double d = A[j * lda + j];
-    if (!(d > 0.0)) return false;
-    const double u = std::sqrt(d);
-    double *rj = A + size_t(j) * lda;
-    rj[j] = u;
-    const double iu = 1.0 / u;
-    for (int i = j + 1; i < n; ++i) rj[i] *= iu;
-    for (int k = j + 1; k < n; ++k) {
-      const double f = rj[k];
-      double *rk = A + size_t(k) * lda;
-      for (int i = k; i < n; ++i) rk[i] -= f * rj[i];
+  // Panels of 4 pivot rows: the panel is factored with the plain recurrence, then every trailing row takes the
+  // four rank-1 updates in one pass (5 loads + 1 store per 4 multiply-subtracts instead of 2 + 1 per one).
+  // The subtractions stay in pivot order, so the result is bit-identical to the unblocked recurrence.
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    const int jb = (n - j0 < 4) ? n - j0 : 4;
+    for (int j = j0; j < j0 + jb; ++j) {
+      double *rj = A + size_t(j) * lda;
+      const double d = rj[j];
+      if (!(d > 0.0)) return false;
+      const double u = std::sqrt(d);
+      rj[j] = u;
+      const double iu = 1.0 / u;
+      for (int i = j + 1; i < n; ++i) rj[i] *= iu;
+      for (int k = j + 1; k < j0 + jb; ++k) {
+        const double f = rj[k];
+        double *rk = A + size_t(k) * lda;
+        for (int i = k; i < n; ++i) rk[i] -= f * rj[i];
+      }
+    }
+    if (jb < 4) {
+      for (int j = j0; j < j0 + jb; ++j) {
+        const double *rj = A + size_t(j) * lda;
+        for (int k = j0 + jb; k < n; ++k) { const double f = rj[k]; double *rk = A + size_t(k) * lda; for (int i = k; i < n; ++i) rk[i] -= f * rj[i]; }
+      }
+      continue;
+    }
+    const double *__restrict__ r0 = A + size_t(j0) * lda;
+    const double *__restrict__ r1 = r0 + lda;
+    const double *__restrict__ r2 = r1 + lda;
+    const double *__restrict__ r3 = r2 + lda;
+    for (int k = j0 + 4; k < n; ++k) {
+      const double f0 = r0[k], f1 = r1[k], f2 = r2[k], f3 = r3[k];
+      double *__restrict__ rk = A + size_t(k) * lda;
+      for (int i = k; i < n; ++i) {
+        double v = rk[i];
+        v -= f0 * r0[i];
+        v -= f1 * r1[i];
+        v -= f2 * r2[i];
+        v -= f3 * r3[i];
+        rk[i] = v;
+      }
     }
   }
   return true;

@@ -260,6 +260,28 @@ LIO_HD void qr_solve(T *A, T *b, T *x, T eps) {
   for (int j = 0; j < N; ++j) x[perm[j]] = y[j];
 }
 
+// Number of eigenvalues of the symmetric NxN matrix A that are < tau, by Sylvester's law of inertia: the count of
+// negative pivots of the LDL^T factorisation of (A - tau I).  Replaces a full eigendecomposition where only the
+// degeneracy count is needed (Estimator.cc:1313-1333, PointOdometry.cc:589-608: leading eigenvalues below the
+// threshold; eigenvalues are ascending, so "leading ones below" == "all below").
+template <int N>
+LIO_HD int count_eigs_below(const float *Ain, double tau) {
+  double A[N * N];
+  for (int i = 0; i < N * N; ++i) A[i] = double(Ain[i]);
+  for (int i = 0; i < N; ++i) A[i * N + i] -= tau;
+  int neg = 0;
+  for (int k = 0; k < N; ++k) {
+    double d = A[k * N + k];
+    if (d == 0.0) d = 1e-300;  // exactly singular shift: nudge (measure-zero event)
+    if (d < 0.0) ++neg;
+    for (int i = k + 1; i < N; ++i) {
+      double f = A[i * N + k] / d;
+      for (int j = k + 1; j < N; ++j) A[i * N + j] -= f * A[k * N + j];
+    }
+  }
+  return neg;
+}
+
 // Cyclic-Jacobi eigenvalues of a symmetric NxN (N <= 6) matrix, ascending.  Accumulates in double.
 template <int N>
 LIO_HD void sym_eigvals(const float *Ain, float *evals) {

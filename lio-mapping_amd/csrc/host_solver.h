@@ -33,10 +33,16 @@ struct MargPrior {
   std::vector<double> Jtr0;     // cached lin_jac^T lin_res
   void finalize() {
     JtJ = DMat(n, n); Jtr0.assign(n, 0.0);
-    for (int i = 0; i < n; ++i) {
-      for (int j = i; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += lin_jac(k, i) * lin_jac(k, j); JtJ(i, j) = s; JtJ(j, i) = s; }
-      double s = 0; for (int k = 0; k < n; ++k) s += lin_jac(k, i) * lin_res[k];
-      Jtr0[i] = s;
+    // sum of n outer products of the rows of lin_jac: contiguous inner loops
+    for (int k = 0; k < n; ++k) {
+      const double *jr = &lin_jac.a[size_t(k) * n];
+      const double rk = lin_res[k];
+      for (int i = 0; i < n; ++i) {
+        const double f = jr[i];
+        double *hr = &JtJ.a[size_t(i) * n];
+        for (int j = 0; j < n; ++j) hr[j] += f * jr[j];
+        Jtr0[i] += f * rk;
+      }
     }
   }
 };

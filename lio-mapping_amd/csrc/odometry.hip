@@ -224,11 +224,17 @@ __global__ void __launch_bounds__(ODO_ROW_THREADS) k_odo_rows(OdoArgs a, const O
 }
 
 __global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
-  if (threadIdx.x != 0 || st->converged) return;
+  if (st->converged) return;
+  __shared__ double ssum[28];
+  if (threadIdx.x < 28) {
+    double v = 0;
+    for (int b = 0; b < nblocks; ++b) v += partials[b * 28 + threadIdx.x];
+    ssum[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double sum[28];
-  for (int k = 0; k < 28; ++k) sum[k] = 0;
-  for (int b = 0; b < nblocks; ++b)
-    for (int k = 0; k < 28; ++k) sum[k] += partials[b * 28 + k];
+  for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
   st->iters = iter + 1;
   st->kz = st->kz;  // (kept from round 0)
   const int nsel = int(sum[27]);
@@ -244,10 +250,7 @@ __global__ void k_odo_update(const double *__restrict__ partials, int nblocks, O
   for (int i = 0; i < 6; ++i) Bc[i] = AtB[i];
   qr_solve<float, 6, 6>(Ac, Bc, X, FLT_EPSILON);
   if (iter == 0) {
-    float E[6];
-    sym_eigvals<6>(AtA, E);
-    int kz = 0;
-    for (int i = 0; i < 6; ++i) { if (E[i] < 10.f) ++kz; else break; }
+    const int kz = count_eigs_below<6>(AtA, 10.0);
     st->kz = kz;
     st->degenerate = kz > 0;
   }

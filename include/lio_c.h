@@ -266,6 +266,14 @@ int lio_est_get_prior(const lio_est *, double *JtJ_or_null, double *Jtr_or_null,
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);
 
+/* Multi-GPU factor sharding (the reference's own 4-thread split of ThreadsConstructA,
+ * MarginalizationFactor.cc:245-269, extended across ranks): rank r of `world` evaluates only its contiguous share of
+ * every frame's lidar factors; `allreduce` (in-place SUM over ranks of `count` doubles, returns 0) is called once per
+ * linearisation on the per-shard normal-equation moments; every rank then takes the same trust-region step, so the
+ * replicas stay in lockstep without a broadcast.  world = 1 or a null callback switches sharding off. */
+typedef int (*lio_allreduce_fn)(double *inout, int count, void *user);
+int lio_est_set_factor_sharding(lio_est *, int rank, int world, lio_allreduce_fn allreduce, void *user);
+
 /* Per-kernel timing with HIP events on the estimator's own stream (bench.py's roofline block).
  * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
  * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat".

@@ -438,6 +438,11 @@ int lio_est_restore(lio_est *h) {
   return guarded([&] { return h->e->Restore() ? LIO_OK : LIO_ERR_STATE; });
 }
 
+int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_fn fn, void *user) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return LIO_ERR_ARG;
+  h->e->shard_rank_ = rank; h->e->shard_world_ = world; h->e->allreduce_ = fn; h->e->allreduce_user_ = user;
+  return LIO_OK;
+}
 int lio_est_enable_kernel_timing(lio_est *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->e->timers_.on = on != 0;

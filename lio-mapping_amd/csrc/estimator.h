@@ -106,6 +106,10 @@ class Estimator {
   int laser_odom_iters_ = 0;
   double dbg_eval_ms_ = 0; int dbg_eval_n_ = 0;  // LIO_DEBUG_TIMING: time inside LidarEval (launch + D2H + sync)
   KernelTimers timers_;
+  // factor sharding across ranks (lio_est_set_factor_sharding)
+  int shard_rank_ = 0, shard_world_ = 1;
+  lio_allreduce_fn allreduce_ = nullptr;
+  void *allreduce_user_ = nullptr;
 
  private:
   struct HostState;  // snapshot payload

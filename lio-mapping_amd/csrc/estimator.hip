@@ -434,6 +434,11 @@ void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
     MomentFrame &f = ma.fr[ma.nframes++];
     const int idx = pivot + i;
     f.stack = stacks_[idx].buf.p; f.M = std::max<int>(1, int(stacks_[idx].n)); f.slot_off = slot_off_[idx]; f.nslots = nslots_[idx];
+    f.slot_begin = 0; f.slot_end = f.nslots;
+    if (shard_world_ > 1 && allreduce_) {  // contiguous share of this frame's factor slots
+      f.slot_begin = int((long long)f.nslots * shard_rank_ / shard_world_);
+      f.slot_end = int((long long)f.nslots * (shard_rank_ + 1) / shard_world_);
+    }
     relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), f.R, f.t);
     max_slots = std::max(max_slots, f.nslots);
   }
@@ -449,6 +454,10 @@ void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
   timers_.end(th, stream_);
   LIO_HIP(hipStreamSynchronize(stream_));
   timers_.resolve();
+  if (shard_world_ > 1 && allreduce_) {
+    // per-shard moments -> whole-window moments (SUM over ranks; RCCL over xGMI on a GPU node, 10 KB per call)
+    if (allreduce_(h_moment_out_, ma.nframes * LIO_MOMENT_OUT, allreduce_user_) != 0) throw std::runtime_error("factor-sharding all-reduce failed");
+  }
   for (int i = 1; i <= Wo_; ++i) {
     const double *src = h_moment_out_ + size_t(i - 1) * LIO_MOMENT_OUT;
     std::memcpy(m[i].S, src, 256 * sizeof(double));

@@ -21,6 +21,7 @@ struct MomentFrame {
   int M;
   int slot_off;
   int nslots;
+  int slot_begin, slot_end;  // this rank's share of [0, nslots) (factor sharding); the whole range on one GPU
   double R[9];  // R_{lp,i} row-major
   double t[3];  // P_{lp,i}
 };

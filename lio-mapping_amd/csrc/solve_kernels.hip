@@ -37,13 +37,13 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, 
   double *zb = zbuf[wv];
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0, cnt = 0.0;
-  for (int base = wid * 64; base < fr.nslots; base += waves_total * 64) {
+  for (int base = fr.slot_begin + wid * 64; base < fr.slot_end; base += waves_total * 64) {
     // ---- each lane: its own residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values)
     const int sidx = base + lane;
     double z[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) z[k] = 0.0;
-    if (sidx < fr.nslots && valid[fr.slot_off + sidx]) {
+    if (sidx < fr.slot_end && valid[fr.slot_off + sidx]) {
       float4 po = fr.stack[sidx % fr.M];
       float4 c = coef[fr.slot_off + sidx];
       double px = po.x, py = po.y, pz = po.z;

@@ -169,6 +169,7 @@ _SIGS = {
     "lio_est_get_prior": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
+    "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lio_est_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_est_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, c_double_p]),
 }
@@ -522,6 +523,22 @@ class Estimator:
         x0 = np.zeros(ln.value)
         self.lib.dll.lio_est_get_prior(self.h, _dp(JtJ), _dp(Jtr), _dp(x0), C.byref(ln))
         return dict(n=n, JtJ=JtJ, Jtr=Jtr, x0=x0)
+
+    def set_factor_sharding(self, rank, world, allreduce_numpy):
+        """`allreduce_numpy(buf: np.ndarray[float64])` must sum `buf` in place over all ranks (e.g. torch.distributed)."""
+        ALLREDUCE = C.CFUNCTYPE(C.c_int, c_double_p, C.c_int, C.c_void_p)
+
+        def _cb(ptr, count, _user):
+            try:
+                buf = np.ctypeslib.as_array(ptr, shape=(count,))
+                allreduce_numpy(buf)
+                return 0
+            except Exception:  # noqa: BLE001 - must not propagate through the C frame
+                return 1
+
+        self._allreduce_cb = ALLREDUCE(_cb) if (world > 1 and allreduce_numpy is not None) else None  # keep alive
+        fn = C.cast(self._allreduce_cb, C.c_void_p) if self._allreduce_cb else None
+        _chk(self.lib.dll.lio_est_set_factor_sharding(self.h, rank, world, fn, None), "lio_est_set_factor_sharding")
 
     def enable_kernel_timing(self, on=True):
         _chk(self.lib.dll.lio_est_enable_kernel_timing(self.h, 1 if on else 0), "lio_est_enable_kernel_timing")

@@ -37,3 +37,28 @@ def aggregate_throughput(steps_per_rank: int, seconds_this_rank: float, world: i
     """(units/s over the whole job, max-over-ranks seconds): value = world * K / max_r(t_r)."""
     t = max_over_ranks(seconds_this_rank, world, device)
     return world * steps_per_rank / t, t
+
+
+def make_allreduce(device: str = "cpu"):
+    """In-place SUM all-reduce of a float64 numpy buffer through torch.distributed (RCCL when device='cuda':
+    the buffer is staged through a persistent device tensor; gloo on CPU)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    stage = {}
+
+    def allreduce(buf: np.ndarray):
+        n = buf.shape[0]
+        if device == "cpu":
+            t = torch.from_numpy(buf)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return
+        t = stage.get(n)
+        if t is None:
+            t = stage[n] = torch.empty(n, dtype=torch.float64, device=device)
+        t.copy_(torch.from_numpy(buf), non_blocking=False)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        buf[:] = t.cpu().numpy()
+
+    return allreduce

@@ -429,6 +429,11 @@ int lio_est_restore(lio_est *h) {
 double orc_normalize_rad(double r) { return NormalizeRad(r); }
 double orc_normalize_deg(double d) { return NormalizeDeg(d); }
 
+int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_fn fn, void *user) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return LIO_ERR_ARG;
+  h->est.shard_rank = rank; h->est.shard_world = world; h->est.allreduce = fn; h->est.allreduce_user = user;
+  return LIO_OK;
+}
 int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_est_get_kernel_timing(lio_est *, const char *, double *t, double *b) { if (t) *t = 0; if (b) *b = 0; return 0; }
 

@@ -88,6 +88,9 @@ struct Estimator {
   Transformf laser_odom_transform;
   int laser_odom_iters = 0;
   double ms_features_acc = 0;
+  int shard_rank = 0, shard_world = 1;
+  int (*allreduce)(double *, int, void *) = nullptr;
+  void *allreduce_user = nullptr;
 
   explicit Estimator(const EstimatorConfig &c) : cfg(c), W(c.window_size), Wo(c.opt_window_size) {
     transform_lb = c.transform_lb;
@@ -430,6 +433,7 @@ struct Estimator {
     P.ex_constant = (cfg.extrinsic_stage == 0 || !cfg.opt_extrinsic);
     P.use_imu = cfg.imu_factor;
     P.use_lidar = cfg.point_distance_factor;
+    P.shard_rank = shard_rank; P.shard_world = shard_world; P.allreduce = allreduce; P.allreduce_user = allreduce_user;
     P.pim.assign(Wo, nullptr);
     if (cfg.imu_factor)
       for (int i = 0; i < Wo; ++i) {
@@ -476,6 +480,7 @@ struct Estimator {
       VectorToProblem(M);
       M.ex_constant = false;
       M.use_imu = cfg.imu_factor; M.use_lidar = cfg.point_distance_factor;
+      M.shard_rank = shard_rank; M.shard_world = shard_world; M.allreduce = allreduce; M.allreduce_user = allreduce_user;
       M.pim.assign(Wo, nullptr);
       if (cfg.imu_factor) {
         auto &pi = pre_integrations[pivot + 1];

@@ -60,6 +60,10 @@ struct WindowProblem {
   bool use_prior_factor = false;
   V3d prior_pos; Qd prior_rot;
   bool use_lidar = true, use_imu = true;
+  // factor sharding across ranks (lio_est_set_factor_sharding): this rank evaluates items [lo, hi) of each frame
+  int shard_rank = 0, shard_world = 1;
+  int (*allreduce)(double *, int, void *) = nullptr;
+  void *allreduce_user = nullptr;
 
   int D() const { return 15 * (Wo + 1) + (ex_constant ? 0 : 6); }
   int colPose(int i) const { return 15 * i; }
@@ -210,7 +214,38 @@ static inline double EvaluateProblem(const WindowProblem &P, const Layout &lay, 
     // thread order 3,2,1,0).  `threads` selects which.
     struct Item { int frame; const PlaneFeature *f; };
     std::vector<Item> items;
-    for (int i = 1; i <= P.Wo; ++i) for (const PlaneFeature &f : P.feats[i]) items.push_back({i, &f});
+    const bool sharded = P.shard_world > 1 && P.allreduce;
+    for (int i = 1; i <= P.Wo; ++i) {
+      const size_t nf = P.feats[i].size();
+      size_t lo = 0, hi = nf;
+      if (sharded) { lo = nf * size_t(P.shard_rank) / size_t(P.shard_world); hi = nf * size_t(P.shard_rank + 1) / size_t(P.shard_world); }
+      for (size_t k = lo; k < hi; ++k) items.push_back({i, &P.feats[i][k]});
+    }
+    if (sharded) {
+      // per-shard lidar normal equations, summed over ranks, then added to the (replicated) rest of the system
+      Mat Hl(H ? lay.dim : 0, H ? lay.dim : 0);
+      std::vector<double> gl(H ? lay.dim : 0, 0.0);
+      double cl = 0;
+      std::vector<std::vector<double>> Js(3, std::vector<double>(7));
+      for (const Item &it : items) {
+        const double *par[3] = {P.pose[0].data(), P.pose[it.frame].data(), P.ex.data()};
+        double r[1];
+        double *jp[3] = {Js[0].data(), Js[1].data(), Js[2].data()};
+        PivotPointPlaneEvaluate(it.f->point, it.f->coeffs, par, r, H ? jp : nullptr);
+        std::vector<BlockRef> blocks = {{lay.pose[0], 6, 7, nullptr}, {lay.pose[it.frame], 6, 7, nullptr}, {lay.ex, 6, 7, nullptr}};
+        cl += AccumulateBlock(1, r, blocks, Js, true, H ? &Hl : nullptr, H ? &gl : nullptr);
+      }
+      std::vector<double> buf;
+      if (H) { buf = Hl.a; buf.insert(buf.end(), gl.begin(), gl.end()); }
+      buf.push_back(cl);
+      P.allreduce(buf.data(), int(buf.size()), P.allreduce_user);
+      if (H) {
+        for (size_t k = 0; k < H->a.size(); ++k) H->a[k] += buf[k];
+        for (int k = 0; k < lay.dim; ++k) (*g)[k] += buf[H->a.size() + k];
+      }
+      cost += buf.back(); if (gc) gc->ppp += buf.back();
+      items.clear();
+    }
     auto work = [&](int tid, int nth, Mat *Hl, std::vector<double> *gl, double *cl) {
       std::vector<std::vector<double>> Js(3, std::vector<double>(7));
       for (size_t k = tid; k < items.size(); k += nth) {
@@ -224,7 +259,9 @@ static inline double EvaluateProblem(const WindowProblem &P, const Layout &lay, 
         *cl += AccumulateBlock(1, r, blocks, Js, true, Hl, gl);
       }
     };
-    if (threads <= 1 || !H) {
+    if (sharded) {
+      // already accumulated above
+    } else if (threads <= 1 || !H) {
       double c = 0;
       work(0, 1, H, g, &c);
       cost += c; if (gc) gc->ppp += c;

@@ -64,3 +64,56 @@ def test_two_rank_weak_scaling_contract(oracle):
     assert np.isclose(v0, world * 2 / max(d0, d1))  # whole-job aggregate: N*K / max time
     assert v0 == v1
     assert p0 != p1 and n0 > 100 and n1 > 100       # the two ranks really worked on different windows
+
+
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from lio_amd import capi, dist_util, pipeline, synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
+    ds = synth.make_dataset("indoor", 6, 0.2, lidar=synth.Lidar(16, -15, 15, 450))  # the SAME window on every rank
+    clouds = [pipeline.feature_clouds(lib, ds.lidar, f.scan) for f in ds.frames]
+    cfg = pipeline.config_indoor(lib, 4, 2)
+    cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+    pipeline.set_extrinsic(cfg, ds)
+    est = capi.Estimator(lib, cfg)
+    pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+    est.set_factor_sharding(rank, world, dist_util.make_allreduce("cpu"))
+    r1 = est.solve()
+    est.slide()
+    r2 = pipeline.feed_frame(est, ds, 5, clouds[5][0], clouds[5][1])
+    w = est.get_window()
+    out[rank] = (w["Ps"].copy(), r1.final_cost, r2.final_cost, r2.marginalized, est.prior()["JtJ"].copy())
+    dist.destroy_process_group()
+
+
+def test_factor_sharding_allreduce_matches_single_rank(oracle):
+    """residuals partitioned over ranks, [H|g] summed by all-reduce, every rank takes the same step.
+    Two gloo ranks must (a) agree bit for bit with each other and (b) reproduce the unsharded solve."""
+    from lio_amd import capi, pipeline, synth
+
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (p0, c0, d0, m0, j0), (p1, c1, d1, m1, j1) = out[0], out[1]
+    np.testing.assert_array_equal(p0, p1)       # lockstep replicas
+    assert c0 == c1 and d0 == d1 and m0 == m1 == 1
+    # unsharded reference run
+    ds = synth.make_dataset("indoor", 6, 0.2, lidar=synth.Lidar(16, -15, 15, 450))
+    clouds = [pipeline.feature_clouds(oracle, ds.lidar, f.scan) for f in ds.frames]
+    cfg = pipeline.config_indoor(oracle, 4, 2)
+    cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+    pipeline.set_extrinsic(cfg, ds)
+    est = capi.Estimator(oracle, cfg)
+    pipeline.init_window(est, oracle, ds, [c[0] for c in clouds], pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+    r1 = est.solve()
+    est.slide()
+    r2 = pipeline.feed_frame(est, ds, 5, clouds[5][0], clouds[5][1])
+    np.testing.assert_allclose(p0, est.get_window()["Ps"], atol=1e-7)   # summation order differs across shards only
+    np.testing.assert_allclose([c0, d0], [r1.final_cost, r2.final_cost], rtol=1e-7)
+    np.testing.assert_allclose(j0, est.prior()["JtJ"], rtol=1e-5, atol=1e-6 * np.abs(j0).max())

@@ -344,3 +344,59 @@ def test_point_odometry_disabled_is_a_packer(hip, oracle):
         assert r["iterations"] == 0
         np.testing.assert_array_equal(od.last_cloud(1), cl[3])
         np.testing.assert_array_equal(r["T_sum"][1], np.zeros(3, np.float32))
+
+
+# ------------------------------------------------------------------------------------------------ factor sharding (two "ranks" on one GPU)
+def test_factor_sharding_two_ranks_on_one_gpu(hip):
+    """lio_est_set_factor_sharding on the HIP path: two estimators play rank 0 / rank 1 of the same window in two host
+    threads; the all-reduce callback is an in-process exchange.  Both must stay in lockstep and reproduce the
+    unsharded solve (only the summation order of the moments changes)."""
+    import threading
+
+    ds = synth.make_dataset("indoor", 6, 0.2)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+
+    def make():
+        cfg = pipeline.config_indoor(hip, 4, 2)
+        cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(hip, cfg)
+        pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+        return est
+
+    ref = make()
+    ref.solve()
+    ref.slide()
+    r_ref = pipeline.feed_frame(ref, ds, 5, clouds[5][0], clouds[5][1])
+
+    world = 2
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    results = [None] * world
+
+    def run(rank):
+        est = make()
+
+        def allreduce(buf):
+            slots[rank] = buf.copy()
+            bar.wait()
+            total = slots[0] + slots[1]
+            bar.wait()
+            buf[:] = total
+
+        est.set_factor_sharding(rank, world, allreduce)
+        est.solve()
+        est.slide()
+        r = pipeline.feed_frame(est, ds, 5, clouds[5][0], clouds[5][1])
+        results[rank] = (est.get_window()["Ps"].copy(), r.final_cost, r.n_lidar_residuals)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert all(r is not None for r in results)
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    assert results[0][2] == r_ref.n_lidar_residuals  # the all-reduced count covers every factor exactly once
+    np.testing.assert_allclose(results[0][0], ref.get_window()["Ps"], atol=1e-7)
+    np.testing.assert_allclose(results[0][1], r_ref.final_cost, rtol=1e-7)

@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hdl64", choices=["hdl64", "vlp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-factors", action="store_true",
+                    help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-equation "
+                         "moments per linearisation (SURVEY.md §8e).  Default is weak scaling: one independent window per rank, no collective.")
     ap.add_argument("--cpu-steps", type=int, default=8)
     args = ap.parse_args()
 
@@ -85,7 +88,9 @@ def main():
     hip = capi.load_hip()
     kind = "outdoor" if args.workload == "hdl64" else "indoor"
     W, Wo = 15, 5
-    ds, clouds, est, k_last, pp_ms, setup_s = build_window(hip, kind, W, Wo, extra_frames=4, seed_shift=dist_util.window_shift_for_rank(rank))
+    ds, clouds, est, k_last, pp_ms, setup_s = build_window(hip, kind, W, Wo, extra_frames=4, seed_shift=0.0 if args.shard_factors else dist_util.window_shift_for_rank(rank))
+    if args.shard_factors and world > 1:
+        est.set_factor_sharding(rank, world, dist_util.make_allreduce("cuda"))
 
     # The step under test is the SolveOptimization that ProcessLaserOdom runs for the last frame: push that
     # frame (upload + VoxelGrid + window push, untimed), snapshot, then time restore + SolveOptimization with
@@ -113,6 +118,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     value_all, dt_max = dist_util.aggregate_throughput(args.steps, dt, world, device="cuda")
+    if args.shard_factors:
+        value_all = args.steps / dt_max  # one window solved cooperatively: total work is fixed
 
     names = ["features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"]
     kt = {n: est.kernel_timing(n) for n in names}
@@ -166,7 +173,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.shard_factors else "weak",
             "vs_baseline": None,
             "dtype": "f64 (solve) / f32 (features)",
             "data": "synthetic",
@@ -180,7 +187,7 @@ def main():
                 "surf_stack_points": int(new_stack_n),
                 "solver_iterations": int(rep.iterations),
                 "laser_odom_iterations": int(rep.laser_odom_iterations),
-                "parallelism": f"{world} independent windows" if world > 1 else "1 window",
+                "parallelism": (f"1 window, factors sharded over {world} ranks + all-reduce" if args.shard_factors else f"{world} independent windows") if world > 1 else "1 window",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

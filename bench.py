@@ -4,17 +4,23 @@
 One "step" = one Estimator::SolveOptimization (BuildLocalMap + kNN/plane features + newest-frame GN +
 <= 10 dogleg iterations + marginalization; Estimator.cc:1648-2438) on a steady-state window snapshot of
 synthetic HDL-64E data (64 rings, ~133 k points/scan), window_size 15 / opt_window_size 5, with the
-clouds already resident in HBM.  N > 1: every rank owns an independent window (weak scaling, no
-data-path collective — SURVEY.md §8e: the all-reduce of normal equations does not pay at this factor
-count); value = N * K / max-over-ranks time.
+clouds already resident in HBM.
+
+N > 1 (default): every rank owns an independent window (weak scaling, no data-path collective — SURVEY.md
+§8e: the all-reduce of normal equations does not pay at this factor count); value = N * K / max-over-ranks
+time.  `--shard-factors` instead solves ONE window cooperatively (factors sharded, RCCL all-reduce of the
+moments per linearisation; strong scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (HIP events on the
-estimator's stream), `cpu_baseline` = the CPU oracle timed on this box's host cores on the same window.
+estimator's stream), `cpu_baseline` = the CPU oracle timed on this box's host cores on the same window,
+`batched` = throughput with several independent windows in flight on the one GPU (the single-window path
+is latency-bound; this shows how far the same kernels go when the GPU is given more to do).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,23 +28,36 @@ sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
 
 import numpy as np  # noqa: E402
 
+EXTRA_FRAMES = 4
 
-def build_window(lib, kind, W, Wo, extra_frames, seed_shift=0.0, lidar=None, ds=None):
-    from lio_amd import capi, pipeline, synth
 
-    n_frames = W + 1 + extra_frames
+def make_dataset(kind, W, seed_shift=0.0):
+    from lio_amd import synth
+
     frame_dt = 0.3 if kind == "outdoor" else 0.2  # odom_io = 3 (HDL-64) / 2 (VLP-16) x 0.1 s
-    if ds is None:
-        ds = synth.make_dataset(kind, n_frames, frame_dt, t0=1.0 + seed_shift, lidar=lidar)
-    t0 = time.time()
+    return synth.make_dataset(kind, W + 1 + EXTRA_FRAMES, frame_dt, t0=1.0 + seed_shift)
+
+
+def feature_clouds(lib, ds):
+    """PointProcessor on every sweep -> [(less_flat 'surf_last', less_sharp 'corner_last')], per-scan wall ms."""
+    from lio_amd import capi
+
     pp = capi.PointProcessor(lib, ds.lidar.lower_deg, ds.lidar.upper_deg, ds.lidar.rings)
-    clouds = []
-    pp_ms = []
+    clouds, ms = [], []
     for f in ds.frames:
         t = time.perf_counter()
         pp.process(f.scan)
-        pp_ms.append((time.perf_counter() - t) * 1e3)
+        ms.append((time.perf_counter() - t) * 1e3)
         clouds.append((pp.cloud(4), pp.cloud(2)))
+    return clouds, ms
+
+
+def make_estimator(lib, ds, clouds, kind, W, Wo):
+    """Window initialised from ground truth + noise, EXTRA_FRAMES-1 frames fed through ProcessLaserOdom so a
+    marginalization prior exists, then the last frame pushed (upload + VoxelGrid + window push) — the state right
+    before the SolveOptimization under test — and snapshotted."""
+    from lio_amd import capi, pipeline
+
     cfg = pipeline.config_outdoor64(lib, W, Wo) if kind == "outdoor" else pipeline.config_indoor(lib, W, Wo)
     if kind != "outdoor":
         cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
@@ -47,15 +66,22 @@ def build_window(lib, kind, W, Wo, extra_frames, seed_shift=0.0, lidar=None, ds=
     pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)
     est.solve()
     est.slide()
-    last = None
+    n_frames = len(ds.frames)
     for k in range(W + 1, n_frames - 1):
-        last = pipeline.feed_frame(est, ds, k, clouds[k][0], clouds[k][1])
-    # stop right before the last frame's solve: push it, then snapshot the full window
+        pipeline.feed_frame(est, ds, k, clouds[k][0], clouds[k][1])
     k = n_frames - 1
     f = ds.frames[k]
     for j in range(f.imu_dt.shape[0]):
         est.process_imu(float(f.imu_dt[j]), f.imu_acc[j], f.imu_gyr[j], float(f.imu_t[j]))
-    return ds, clouds, est, k, pp_ms, time.time() - t0
+    T = capi.TransformF.make([0, 0, 0, 1], [0, 0, 0])
+    est.push_frame(T, clouds[k][0], clouds[k][1], f.t)
+    est.snapshot()
+    return est
+
+
+def one_step(est):
+    est.restore()
+    return est.solve()
 
 
 def main():
@@ -65,10 +91,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hdl64", choices=["hdl64", "vlp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard-factors", action="store_true",
-                    help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-equation "
-                         "moments per linearisation (SURVEY.md §8e).  Default is weak scaling: one independent window per rank, no collective.")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--windows", type=int, default=4, help="independent windows in flight for the `batched` extra (0 = skip)")
+    ap.add_argument("--shard-factors", action="store_true",
+                    help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
+                         "equation moments per linearisation (SURVEY.md §8e).  Default: one independent window per rank, no collective.")
     args = ap.parse_args()
 
     import torch
@@ -83,55 +110,49 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from lio_amd import capi, dist_util, pipeline, synth
+    from lio_amd import capi, dist_util
 
     hip = capi.load_hip()
     kind = "outdoor" if args.workload == "hdl64" else "indoor"
     W, Wo = 15, 5
-    ds, clouds, est, k_last, pp_ms, setup_s = build_window(hip, kind, W, Wo, extra_frames=4, seed_shift=0.0 if args.shard_factors else dist_util.window_shift_for_rank(rank))
+    t_setup = time.time()
+    ds = make_dataset(kind, W, 0.0 if args.shard_factors else dist_util.window_shift_for_rank(rank))
+    clouds, pp_ms = feature_clouds(hip, ds)
+    est = make_estimator(hip, ds, clouds, kind, W, Wo)
+    setup_s = time.time() - t_setup
     if args.shard_factors and world > 1:
         est.set_factor_sharding(rank, world, dist_util.make_allreduce("cuda"))
-
-    # The step under test is the SolveOptimization that ProcessLaserOdom runs for the last frame: push that
-    # frame (upload + VoxelGrid + window push, untimed), snapshot, then time restore + SolveOptimization with
-    # every cloud already resident in HBM.
-    T = capi.TransformF.make([0, 0, 0, 1], [0, 0, 0])
-    est.push_frame(T, clouds[k_last][0], clouds[k_last][1], ds.frames[k_last].t)
     new_stack_n = est.get_surf_stack(W).shape[0]
-    est.snapshot()
-
-    def one_step():
-        est.restore()
-        return est.solve()
 
     for _ in range(args.warmup):
-        rep = one_step()
+        rep = one_step(est)
     est.enable_kernel_timing(True)
-    if world > 1:
-        dist.barrier()
+    dist_util.barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rep = one_step()
+        rep = one_step(est)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist_util.barrier(world)
     dt = time.perf_counter() - t0
-    value_all, dt_max = dist_util.aggregate_throughput(args.steps, dt, world, device="cuda")
+    value, dt_max = dist_util.aggregate_throughput(args.steps, dt, world, device="cuda")
     if args.shard_factors:
-        value_all = args.steps / dt_max  # one window solved cooperatively: total work is fixed
+        value = args.steps / dt_max  # one window solved cooperatively: total work is fixed
 
     names = ["features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"]
     kt = {n: est.kernel_timing(n) for n in names}
     est.enable_kernel_timing(False)
 
-    out = None
     if rank == 0:
-        value = value_all
+        def per_launch(n):
+            k = kt[n]
+            L = max(k["launches"], 1)
+            avg_ms = k["total_ms"] / L
+            gbps = (k["algorithmic_bytes"] / L) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            return avg_ms, gbps, k["algorithmic_bytes"] / L
+
         dom = max(("features", "odom_features", "moments", "odom_rows"), key=lambda n: kt[n]["total_ms"])
-        d = kt[dom]
-        avg_ms = d["total_ms"] / max(d["launches"], 1)
-        achieved = (d["algorithmic_bytes"] / max(d["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        avg_ms, achieved, alg_bytes = per_launch(dom)
         roofline = {
             "kernel": {"features": "k_features", "odom_features": "k_features", "moments": "k_lidar_moments", "odom_rows": "k_odom_rows"}[dom],
             "stage": dom,
@@ -142,8 +163,8 @@ def main():
             "frac": round(achieved / 8000.0, 6),
             "traffic": None,
             "avg_launch_us": round(avg_ms * 1e3, 3),
-            "launches": d["launches"],
-            "algorithmic_bytes_per_launch": round(d["algorithmic_bytes"] / max(d["launches"], 1), 1),
+            "launches": kt[dom]["launches"],
+            "algorithmic_bytes_per_launch": round(alg_bytes, 1),
         }
         # HBM traffic of that kernel from the committed rocprofv3 PMC passes (profiles/pmc_summary.py: FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, (2*FETCH + WRITE) * 1024 — the gfx950 half-count correction for wide
@@ -157,13 +178,18 @@ def main():
         except (OSError, ValueError):
             pass
         roofline["others"] = {
-            n: {"avg_launch_us": round(1e3 * kt[n]["total_ms"] / max(kt[n]["launches"], 1), 3),
-                "achieved_GBps": round((kt[n]["algorithmic_bytes"] / max(kt[n]["launches"], 1)) / max(kt[n]["total_ms"] / max(kt[n]["launches"], 1) * 1e-3, 1e-12) / 1e9, 2)}
+            n: {"avg_launch_us": round(per_launch(n)[0] * 1e3, 3), "achieved_GBps": round(per_launch(n)[1], 2)}
             for n in ("features", "odom_features", "moments", "voxel", "knn_grid") if n != dom
         }
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(kind, W, Wo, args.cpu_steps, ds)
+
+        batched = None
+        if args.windows > 1 and not args.shard_factors:
+            batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
+
+        odom_ms = odometry_ms_per_scan(hip, ds) if kind == "outdoor" else None
+        cpu = None if args.no_cpu_baseline else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)
+        odom_io = 3 if kind == "outdoor" else 2
+        pp_med = float(np.median(pp_ms[1:]))
         out = {
             "metric": "sliding-window solves/sec, 64-line 130k-pt scans, window=15 (opt_window=5)",
             "value": round(value, 3),
@@ -179,8 +205,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "HDL-64E outdoor_test_config_64, S_outdoor ray-cast scans, window_size=15 opt_window_size=5, one SolveOptimization per step, clouds resident in HBM"
-                if kind == "outdoor"
-                else "VLP-16 indoor, window_size=15 opt_window_size=5",
+                if kind == "outdoor" else "VLP-16 indoor, window_size=15 opt_window_size=5",
                 "points_per_scan": int(ds.frames[0].scan.shape[0]),
                 "n_lidar_residuals": int(rep.n_lidar_residuals),
                 "local_map_points": int(rep.n_local_map),
@@ -191,6 +216,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "batched": batched,
             "stages_ms": {
                 "t_build_map": round(rep.ms_build_map, 4),
                 "feature_cost": round(rep.ms_features, 4),
@@ -201,9 +227,11 @@ def main():
             },
             "kernels": {n: {"launches": kt[n]["launches"], "total_ms": round(kt[n]["total_ms"], 4)} for n in names},
             "ms_per_scan": {
-                "point_processor_incl_h2d_d2h": round(float(np.median(pp_ms[1:])), 4),
-                "estimator_step_amortised_over_odom_io": round(1e3 * dt_max / args.steps / (3 if kind == "outdoor" else 2), 4),
-                "note": "PointOdometry (scan-to-scan) is not part of this round; after IMU init the reference disables it (SURVEY.md A.18)",
+                "point_processor_incl_h2d_d2h": round(pp_med, 4),
+                "point_odometry_incl_h2d": odom_ms,
+                "estimator_step_amortised_over_odom_io": round(1e3 * dt_max / args.steps / odom_io, 4),
+                "total": round(pp_med + (odom_ms or 0.0) + 1e3 * dt_max / args.steps / odom_io, 4),
+                "note": "per 10 Hz sweep: PointProcessor + PointOdometry (pre-init role; the estimator disables it after IMU init, SURVEY.md A.18) + 1/odom_io of a SolveOptimization",
             },
             "setup_s": round(setup_s, 2),
         }
@@ -212,7 +240,50 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(kind, W, Wo, steps, ds=None):
+def batched_throughput(hip, ds, clouds, kind, W, Wo, est0, n_windows, steps):
+    """B independent windows (same data, separate estimators / HIP streams / host threads) in flight on ONE GPU."""
+    ests = [est0] + [make_estimator(hip, ds, clouds, kind, W, Wo) for _ in range(n_windows - 1)]
+    for e in ests:
+        one_step(e)
+    bar = threading.Barrier(n_windows + 1)
+
+    def run(e):
+        bar.wait()
+        for _ in range(steps):
+            one_step(e)
+        bar.wait()
+
+    ts = [threading.Thread(target=run, args=(e,)) for e in ests]
+    for t in ts:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    dt = time.perf_counter() - t0
+    for t in ts:
+        t.join()
+    return {"windows": n_windows, "steps_per_window": steps, "value": round(n_windows * steps / dt, 3), "unit": "solves/s",
+            "note": "independent windows, one HIP stream + host thread each, same GPU"}
+
+
+def odometry_ms_per_scan(hip, ds):
+    """Scan-to-scan odometry step on consecutive sweeps of the same scene (its role before IMU initialisation)."""
+    from lio_amd import capi, synth
+
+    sweeps, _, lid = synth.make_sweeps("outdoor", 4)
+    od = capi.PointOdometry(hip, 0.1, 3, 25, False)
+    pp = capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings)
+    ms = []
+    for sw in sweeps:
+        pp.process(sw)
+        cl = [pp.cloud(w) for w in (1, 2, 3, 4)]
+        t = time.perf_counter()
+        od.process(*cl)
+        ms.append((time.perf_counter() - t) * 1e3)
+    return round(float(np.median(ms[1:])), 4)
+
+
+def cpu_baseline(kind, W, Wo, steps, ds):
     """The CPU oracle on the same workload, on this box's host cores (solve single-threaded like Ceres with
     num_threads=1, marginalization on 4 threads like the reference).  Bounded sample: `steps` solves."""
     import subprocess
@@ -223,10 +294,9 @@ def cpu_baseline(kind, W, Wo, steps, ds=None):
     if not os.path.exists(so):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     orc = capi.LioLib(so)
-    ds, clouds, est, k_last, _, _ = build_window(orc, kind, W, Wo, extra_frames=4, ds=ds)
-    T = capi.TransformF.make([0, 0, 0, 1], [0, 0, 0])
-    est.push_frame(T, clouds[k_last][0], clouds[k_last][1], ds.frames[k_last].t)
-    est.snapshot()
+    t = time.perf_counter()
+    clouds, pp_ms = feature_clouds(orc, ds)
+    est = make_estimator(orc, ds, clouds, kind, W, Wo)
     ts = []
     rep = None
     for _ in range(steps):
@@ -235,7 +305,6 @@ def cpu_baseline(kind, W, Wo, steps, ds=None):
         rep = est.solve()
         ts.append(time.perf_counter() - t)
     med = float(np.median(ts))
-    ncpu = os.cpu_count()
     model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -250,9 +319,10 @@ def cpu_baseline(kind, W, Wo, steps, ds=None):
         "unit": "solves/s",
         "cores": 4,
         "kind": "port",
-        "sample": f"{steps} SolveOptimization calls of the CPU oracle on the same window (median {med * 1e3:.1f} ms; solve 1 thread, marginalization 4 threads); host has {ncpu} logical cores, {model}",
+        "sample": f"{steps} SolveOptimization calls of the CPU oracle on the same window (median {med * 1e3:.1f} ms; solve 1 thread, marginalization 4 threads); host has {os.cpu_count()} logical cores, {model}",
         "n_lidar_residuals": int(rep.n_lidar_residuals),
         "stages_ms": {"t_build_map": round(rep.ms_build_map, 3), "feature_cost": round(rep.ms_features, 3), "t_opt": round(rep.ms_opt, 3), "whole_marginalization": round(rep.ms_marg, 3)},
+        "point_processor_ms_per_scan": round(float(np.median(pp_ms[1:])), 3),
         "note": "the oracle has none of the reference's ROS/PCL/Ceres/heap overheads: a faster-than-reference, conservative baseline; the reference itself cannot be built here (Eigen/PCL/Ceres/ROS absent)",
     }
 

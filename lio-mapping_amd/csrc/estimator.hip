@@ -3,6 +3,7 @@
 // :1648-2438 (SolveOptimization), :2440-2568 (VectorToDouble/DoubleToVector), :2570-2666 (SlideWindow).
 #include "estimator.h"
 
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cstring>
@@ -119,7 +120,7 @@ void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, 
   inited_ = true; first_imu_ = true; cir_buf_count_ = W_;
 }
 
-static uint64_t g_content_id = 1;  // bumped whenever a window cloud is (re)written
+static std::atomic<uint64_t> g_content_id{1};  // bumped whenever a window cloud is (re)written (estimators may live on several host threads)
 
 void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
   DeviceCloud &c = stacks_[frame];

@@ -199,8 +199,32 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         __syncthreads();
       }
     }
-    // ---- serial picks (:685-725): the mask is shared by the ring's subregions, so j ascends on one lane
-    if (tid == 0) {
+    // ---- picks (:685-725).  The mask is shared by the ring's subregions (A.4), so subregions are taken in order and
+    // picks inside one are sequentially dependent — but only through the mask: wave 0 examines 64 sorted candidates at
+    // a time, a ballot finds the first still-eligible one (exactly the one the serial loop would reach next), the
+    // +-5 neighbour walk of MaskPickedInRing runs on 2*nc lanes, and the ballot is retaken.  Work per subregion is
+    // O(#picks + #chunks) wave steps instead of O(#candidates) dependent LDS round trips on one lane.
+    if (wv == 0) {
+      volatile signed char *vmask = smask;
+      auto mask_picked = [&](int pidx) {
+        bool fwd_brk = false, bwd_brk = false;
+        if (lane < c.nc) {
+          const int q = lane + 1;
+          fwd_brk = double(sqdiff(sx[pidx + q], sy[pidx + q], sz[pidx + q], sx[pidx + q - 1], sy[pidx + q - 1], sz[pidx + q - 1])) > 0.05;
+        } else if (lane < 2 * c.nc) {
+          const int q = lane - c.nc + 1;
+          bwd_brk = double(sqdiff(sx[pidx - q], sy[pidx - q], sz[pidx - q], sx[pidx - q + 1], sy[pidx - q + 1], sz[pidx - q + 1])) > 0.05;
+        }
+        const unsigned long long fb = __ballot(fwd_brk), bb = __ballot(bwd_brk);
+        const int nf = fb ? (__ffsll((long long)fb) - 1) : c.nc;
+        const int nb = bb ? (__ffsll((long long)bb) - 1 - c.nc) : c.nc;
+        if (lane == 0) vmask[pidx] = 1;
+        if (lane < nf) vmask[pidx + lane + 1] = 1;
+        if (lane >= c.nc && lane - c.nc < nb) vmask[pidx - (lane - c.nc) - 1] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      };
       for (int w = 0; w < 8 && jg + w < c.ns; ++w) {
         const int jj = jg + w;
         int sp2 = int((size_t(c.nc) * size_t(c.ns - jj) + size_t(n - c.nc) * size_t(jj)) / size_t(c.ns));
@@ -209,48 +233,60 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         const int region2 = ep2 - sp2 + 1;
         if (region2 > PP_SORT_SLOTS) continue;
         const unsigned long long *kk = skey + w * PP_SORT_SLOTS;
+        // corners: descending curvature
         int num_largest = 0;
-        for (int k = region2; k > 0 && num_largest < c.max_less_sharp;) {
-          unsigned long long e = kk[--k];
-          float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
-          if (!(cv > c.curv_th)) break;  // sorted ascending: nothing below can pass either
-          int idx = int(static_cast<unsigned int>(e));
-          if (smask[idx] == 0) {
+        bool stop = false;
+        for (int pos = region2; pos > 0 && num_largest < c.max_less_sharp && !stop; pos -= 64) {
+          const int k = pos - 1 - lane;
+          const bool in = k >= 0;
+          const unsigned long long e = in ? kk[k] : 0ull;
+          const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+          const int idx = int(static_cast<unsigned int>(e));
+          const bool above = in && (cv > c.curv_th);
+          int consumed = -1;
+          while (num_largest < c.max_less_sharp) {
+            const bool elig = above && lane > consumed && vmask[idx] == 0;
+            const unsigned long long bm = __ballot(elig);
+            if (!bm) break;
+            const int L = __ffsll((long long)bm) - 1;
+            const int pidx = __shfl(idx, L, 64);
             ++num_largest;
-            if (num_largest <= c.max_sharp) { slabel[idx] = 2; my_pick[n_sharp++] = idx; }
-            else slabel[idx] = 1;
-            my_pick[cap_sharp + n_less++] = idx;
-            smask[idx] = 1;
-            for (int q = 1; q <= c.nc; ++q) {
-              if (double(sqdiff(sx[idx + q], sy[idx + q], sz[idx + q], sx[idx + q - 1], sy[idx + q - 1], sz[idx + q - 1])) > 0.05) break;
-              smask[idx + q] = 1;
+            if (lane == 0) {
+              if (num_largest <= c.max_sharp) { slabel[pidx] = 2; my_pick[n_sharp] = pidx; }
+              else slabel[pidx] = 1;
+              my_pick[cap_sharp + n_less] = pidx;
             }
-            for (int q = 1; q <= c.nc; ++q) {
-              if (double(sqdiff(sx[idx - q], sy[idx - q], sz[idx - q], sx[idx - q + 1], sy[idx - q + 1], sz[idx - q + 1])) > 0.05) break;
-              smask[idx - q] = 1;
-            }
+            if (num_largest <= c.max_sharp) ++n_sharp;
+            ++n_less;
+            mask_picked(pidx);
+            consumed = L;
           }
+          if (__ballot(in && !above)) stop = true;  // sorted: nothing further down exceeds the threshold
         }
+        // flats: ascending curvature
         int num_smallest = 0;
-        for (int k = 0; k < region2 && num_smallest < c.max_flat; ++k) {
-          unsigned long long e = kk[k];
-          float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
-          if (!(cv < c.curv_th)) break;
-          int idx = int(static_cast<unsigned int>(e));
-          if (smask[idx] == 0) {
+        stop = false;
+        for (int pos = 0; pos < region2 && num_smallest < c.max_flat && !stop; pos += 64) {
+          const int k = pos + lane;
+          const bool in = k < region2;
+          const unsigned long long e = in ? kk[k] : 0ull;
+          const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+          const int idx = int(static_cast<unsigned int>(e));
+          const bool below = in && (cv < c.curv_th);
+          int consumed = -1;
+          while (num_smallest < c.max_flat) {
+            const bool elig = below && lane > consumed && vmask[idx] == 0;
+            const unsigned long long bm = __ballot(elig);
+            if (!bm) break;
+            const int L = __ffsll((long long)bm) - 1;
+            const int pidx = __shfl(idx, L, 64);
             ++num_smallest;
-            slabel[idx] = -1;
-            my_pick[cap_sharp + cap_less + n_flat++] = idx;
-            smask[idx] = 1;
-            for (int q = 1; q <= c.nc; ++q) {
-              if (double(sqdiff(sx[idx + q], sy[idx + q], sz[idx + q], sx[idx + q - 1], sy[idx + q - 1], sz[idx + q - 1])) > 0.05) break;
-              smask[idx + q] = 1;
-            }
-            for (int q = 1; q <= c.nc; ++q) {
-              if (double(sqdiff(sx[idx - q], sy[idx - q], sz[idx - q], sx[idx - q + 1], sy[idx - q + 1], sz[idx - q + 1])) > 0.05) break;
-              smask[idx - q] = 1;
-            }
+            if (lane == 0) { slabel[pidx] = -1; my_pick[cap_sharp + cap_less + n_flat] = pidx; }
+            ++n_flat;
+            mask_picked(pidx);
+            consumed = L;
           }
+          if (__ballot(in && !below)) stop = true;
         }
       }
     }

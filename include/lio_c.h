@@ -110,6 +110,58 @@ int lio_compact_decode(const float *data_xyzi, size_t n_points, lio_transform_f 
                        size_t *n_full);
 
 /* ------------------------------------------------------------------------------------------------
+ * PointMapping — LOAM scan-to-map step and the 21x21x11 cube map of 50 m cubes (§8a a26, §8f 2).
+ * Reference: src/point_processor/PointMapping.cc:325-753 (OptimizeTransformTobeMapped), :755-763,
+ * :765-1110 (Process), :1112-1208 (UpdateMapDatabase); include/point_processor/PointMapping.h:112-253.
+ * The estimator runs it for every sweep until the IMU is initialised (Estimator.cc:823-826).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float corner_filter_size;   /* 0.2  down_size_filter_corner_ (PointMapping.cc:122; Estimator.cc:189) */
+  float surf_filter_size;     /* 0.4  down_size_filter_surf_   (:123; Estimator.cc:190)               */
+  float min_match_sq_dis;     /* 1.0  PointMapping.h:245 */
+  float min_plane_dis;        /* 0.2  :246               */
+  int num_max_iterations;     /* 10   :171               */
+} lio_map_config;
+
+typedef struct lio_map lio_map;
+
+enum {
+  LIO_MAP_CORNER_STACK_DS = 0,  /* laser_cloud_corner_stack_downsampled_ (sensor frame) */
+  LIO_MAP_SURF_STACK_DS = 1,    /* laser_cloud_surf_stack_downsampled_                  */
+  LIO_MAP_CORNER_FROM_MAP = 2,  /* laser_cloud_corner_from_map_ of the last Process     */
+  LIO_MAP_SURF_FROM_MAP = 3     /* laser_cloud_surf_from_map_                           */
+};
+
+void lio_map_default_config(lio_map_config *cfg);
+/* PointMapping(float scan_period, size_t num_max_iterations) (PointMapping.cc:65-126) */
+lio_map *lio_map_create(const lio_map_config *cfg_or_null);
+void lio_map_destroy(lio_map *);
+/* Handlers + PointMapping::Process (:765-1110) for one sweep: corner_last / surf_last are the odometry's
+ * last_corner_cloud_/last_surf_cloud_, transform_sum the accumulated odometry.  Outputs (any may be null):
+ * transform_aft_mapped_, iterations run, rows selected in the last round. */
+int lio_map_process(lio_map *, const float *corner_last_xyzi, size_t n_corner, const float *surf_last_xyzi, size_t n_surf,
+                    const lio_transform_f *transform_sum, lio_transform_f *transform_aft_mapped_out, int *iterations_out,
+                    int *num_selected_out);
+/* SetInitFlag (:299-301): once set, Process neither applies the odometry increment nor updates the map */
+int lio_map_set_init_flag(lio_map *, int imu_inited);
+/* transform_tobe_mapped_ accessors (the estimator overwrites it after init, Estimator.cc:796-797) */
+int lio_map_set_transform_tobe_mapped(lio_map *, const lio_transform_f *);
+int lio_map_get_transform_tobe_mapped(const lio_map *, lio_transform_f *out);
+/* UpdateMapDatabase (:1112-1208): add the down-sampled stacks (sensor frame) at `transform`, then VoxelGrid every
+ * cube of valid_idx (indices relative to cube_center, re-based on the current centre as :1171-1186 does). */
+int lio_map_update_map_database(lio_map *, const float *corner_ds_xyzi, size_t n_corner, const float *surf_ds_xyzi, size_t n_surf,
+                                const uint32_t *valid_idx, size_t n_valid, const lio_transform_f *transform,
+                                const int cube_center[3]);
+/* clouds of the last Process; returns the count, copies when out is non-null */
+size_t lio_map_get_cloud(const lio_map *, int which, float *xyzi_or_null);
+/* one cube of laser_cloud_corner_array_ (cls 0) / laser_cloud_surf_array_ (cls 1); cube_idx = ToIndex(i,j,k) */
+size_t lio_map_get_cube(const lio_map *, int cls, uint32_t cube_idx, float *xyzi_or_null);
+/* laser_cloud_cen_{length,width,height}_ and laser_cloud_valid_idx_ (<= 125 entries); returns the valid count */
+size_t lio_map_get_cube_state(const lio_map *, int cube_center_out[3], uint32_t *valid_idx_or_null);
+/* score_point_coeff_ (:725-750): descending score; point = p_ori (xyzi), coeff = abs_coeff (4 floats). Returns the count. */
+size_t lio_map_get_score_point_coeff(const lio_map *, float *score_or_null, float *point_xyzi_or_null, float *coeff_or_null);
+
+/* ------------------------------------------------------------------------------------------------
  * Stateless building blocks (third-party semantics restated)
  * ---------------------------------------------------------------------------------------------- */
 /* pcl::VoxelGrid<PointXYZI> (B.1): centroids in ascending voxel index; out capacity n points.   */

@@ -7,6 +7,7 @@
 
 #include "../../include/lio_c.h"
 #include "estimator.h"
+#include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
 
@@ -16,6 +17,7 @@ struct lio_pim { std::shared_ptr<Preintegration> p; };
 struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; };
 struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
+struct lio_map { std::unique_ptr<MappingDev> m; };
 
 static V3d v3(const double *p) { return V3d(p[0], p[1], p[2]); }
 static Rigidf toT(const lio_transform_f &t) { return Rigidf(Quat<float>(t.q[3], t.q[0], t.q[1], t.q[2]), Vec3<float>(t.p[0], t.p[1], t.p[2])); }
@@ -113,6 +115,80 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   if (!h || which < 0 || which > 1) return 0;
   size_t n = 0;
   guarded([&] { n = h->o->GetLastCloud(which, out); return LIO_OK; });
+  return n;
+}
+
+// ---------------------------------------------------------------- PointMapping
+void lio_map_default_config(lio_map_config *c) {
+  if (!c) return;
+  c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f; c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f; c->num_max_iterations = 10;
+}
+lio_map *lio_map_create(const lio_map_config *c) {
+  lio_map_config cfg;
+  if (c) cfg = *c; else lio_map_default_config(&cfg);
+  if (!(cfg.corner_filter_size > 0) || !(cfg.surf_filter_size > 0) || cfg.num_max_iterations < 1) return nullptr;
+  lio_map *h = new (std::nothrow) lio_map;
+  if (!h) return nullptr;
+  int rc = guarded([&] { h->m.reset(new MappingDev(cfg)); return LIO_OK; });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  return h;
+}
+void lio_map_destroy(lio_map *h) { delete h; }
+int lio_map_process(lio_map *h, const float *corner, size_t nc, const float *surf, size_t ns, const lio_transform_f *Tsum, lio_transform_f *Taft,
+                    int *iters, int *nsel) {
+  if (!h || !Tsum || (!corner && nc) || (!surf && ns)) return LIO_ERR_ARG;
+  return guarded([&] {
+    h->m->Process(corner, nc, surf, ns, toT(*Tsum));
+    if (Taft) fromT(h->m->transform_aft_mapped_, Taft);
+    if (iters) *iters = h->m->iterations_;
+    if (nsel) *nsel = h->m->num_selected_;
+    return LIO_OK;
+  });
+}
+int lio_map_set_init_flag(lio_map *h, int on) {
+  if (!h) return LIO_ERR_ARG;
+  h->m->imu_inited_ = on != 0;
+  return LIO_OK;
+}
+int lio_map_set_transform_tobe_mapped(lio_map *h, const lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  h->m->transform_tobe_mapped_ = toT(*T);
+  return LIO_OK;
+}
+int lio_map_get_transform_tobe_mapped(const lio_map *h, lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  fromT(h->m->transform_tobe_mapped_, T);
+  return LIO_OK;
+}
+int lio_map_update_map_database(lio_map *h, const float *corner, size_t nc, const float *surf, size_t ns, const uint32_t *valid, size_t nv,
+                                const lio_transform_f *T, const int cen[3]) {
+  if (!h || !T || !cen || (!corner && nc) || (!surf && ns) || (!valid && nv)) return LIO_ERR_ARG;
+  for (size_t i = 0; i < nv; ++i)
+    if (valid[i] >= uint32_t(MappingDev::L * MappingDev::Wd * MappingDev::H)) return LIO_ERR_ARG;
+  return guarded([&] { h->m->UpdateMapDatabase(corner, nc, surf, ns, valid, nv, toT(*T), cen); return LIO_OK; });
+}
+size_t lio_map_get_cloud(const lio_map *h, int which, float *out) {
+  if (!h || which < 0 || which > 3) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->m->GetCloud(which, out); return LIO_OK; });
+  return n;
+}
+size_t lio_map_get_cube(const lio_map *h, int cls, uint32_t idx, float *out) {
+  if (!h || cls < 0 || cls > 1 || idx >= uint32_t(MappingDev::L * MappingDev::Wd * MappingDev::H)) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->m->GetCube(cls, idx, out); return LIO_OK; });
+  return n;
+}
+size_t lio_map_get_cube_state(const lio_map *h, int cen[3], uint32_t *valid) {
+  if (!h) return 0;
+  if (cen) for (int d = 0; d < 3; ++d) cen[d] = h->m->cen_[d];
+  if (valid) for (size_t i = 0; i < h->m->valid_idx_.size(); ++i) valid[i] = h->m->valid_idx_[i];
+  return h->m->valid_idx_.size();
+}
+size_t lio_map_get_score_point_coeff(const lio_map *h, float *score, float *point, float *coeff) {
+  if (!h) return 0;
+  size_t n = 0;
+  guarded([&] { n = h->m->GetScorePointCoeff(score, point, coeff); return LIO_OK; });
   return n;
 }
 

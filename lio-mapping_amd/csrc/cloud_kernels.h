@@ -30,6 +30,9 @@ void launch_transform_concat(const ConcatArgs &a, float4 *dst, hipStream_t s);
 // TransformToEnd (Estimator.cc:62-103) in place; tes = q(xyzw), p
 void launch_deskew_to_end(float4 *pts, int n, const float q[4], const float p[3], float time_factor, hipStream_t s);
 
+// min/max (VoxParams.mn/.mx, n_valid) of a device cloud; `partial` is scratch.  No host sync.
+void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxParams *d_out, hipStream_t s);
+
 class VoxelGridDev {
  public:
   // Filters `in` (device, n points) with cubic leaf; result in `out`; returns the output count (host sync).
@@ -53,7 +56,8 @@ struct GridDesc {
 
 class KnnGrid {
  public:
-  // Uniform grid over `pts` (device, n points).  bounds = min/max of the cloud (host values).
+  // Uniform grid over `pts` (device, n points).  bounds = min/max of the region to index (host values); points
+  // outside it are clamped into the border cells (still compared by true distance).
   void build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s);
   const float4 *sorted() const { return sorted_.p; }   // xyz + original index in .w (int bits)
   const int2 *cells() const { return cells_.p; }        // [start,end) per cell
@@ -73,11 +77,21 @@ struct FeatArgs {
   int nframes;
   int max_M;
   float min_match_sq_dis, min_plane_dis;
+  // scan-to-map variant (PointMapping.cc:519-619): coefficient sign follows pd2, coef.w = s*pd2, the FOV apex
+  // point_on_z_axis_ is the one fixed before the iterations (:803-806), abs_coeff is written when requested
+  int mapping_mode;
+  float fixed_pz[3];
 };
 // transforms: device array of 8 floats per entry (qx,qy,qz,qw,px,py,pz,pad).  skip_flag: optional device int;
 // when *skip_flag != 0 the launch is a no-op (converged laser-odom loop).
 void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
-                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s);
+                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef = nullptr);
+
+// Corner branch of PointMapping::OptimizeTransformTobeMapped (PointMapping.cc:377-517): 5-NN in the corner map, 3x3
+// covariance eigen-decomposition, line residual; slots [slot_off, slot_off+M).  transform: device, 8 floats.
+void launch_line_features(const float4 *stack, int M, int slot_off, const float *transform, const float fixed_pz[3], float min_match_sq_dis,
+                          const float4 *map_sorted, const int2 *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
+                          const int *skip_flag, hipStream_t s);
 
 // stateless K-NN (lio_knn entry point): idx/sqd are m*k
 void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
@@ -89,13 +103,16 @@ struct OdomState {
   int iters;
   int degenerate;
   int kz;            // number of leading components masked (A.6)
+  int nsel;          // rows selected in the last round
 };
 // rows of mat_A / mat_B (Estimator.cc:1272-1301) over slots [0,nslots) of the newest frame, reduced to
 // per-block partials (28 doubles each).  Point of slot s = stack[s % M].
+// b_from_coef != 0: mat_B = -coef.w (the distance stored at feature time, PointMapping.cc:640,650).
 void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
-                      double *partials, int nblocks, hipStream_t s);
+                      double *partials, int nblocks, hipStream_t s, int b_from_coef = 0);
 // reduce + 6x6 solve + degeneracy mask + transform update + convergence test (Estimator.cc:1303-1357)
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s);
+// min_rows > 0: a round with fewer selected rows leaves the transform untouched (`continue`, PointMapping.cc:623-626).
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0);
 int odom_rows_blocks(int nslots);
 
 }  // namespace lio

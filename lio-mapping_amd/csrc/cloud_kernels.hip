@@ -183,6 +183,14 @@ __global__ void k_centroids(const float4 *__restrict__ pts, const uint32_t *__re
   out[pos[i]] = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
 }
 
+void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxParams *d_out, hipStream_t s) {
+  const int nb = std::max(1, std::min(cdiv(n, 256), 512));
+  partial.reserve(size_t(nb) * 8);
+  hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, pts, n, partial.p);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, s, partial.p, nb, 1.0f, d_out);
+  LIO_HIP(hipGetLastError());
+}
+
 size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params) {
   if (n == 0) {
     if (host_params) std::memset(host_params, 0, sizeof(*host_params));
@@ -442,7 +450,8 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
 
 __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                  const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag) {
+                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
+                                                 float4 *__restrict__ abs_coef) {
   if (skip_flag && *skip_flag) return;
   const FeatFrame fr = a.fr[blockIdx.y];
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,6 +493,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
       // FOV test (+-60 deg about the sensor z axis, Estimator.cc:1063-1086)
       Vec3<float> rz = rotate(q, Vec3<float>(0.f, 0.f, 10.f));
       Vec3<float> pz(rz.x + t.x, rz.y + t.y, rz.z + t.z);
+      if (a.mapping_mode) pz = Vec3<float>(a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]);
       float dx1 = t.x - sel.x, dy1 = t.y - sel.y, dz1 = t.z - sel.z;
       float side1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
       float dx2 = pz.x - sel.x, dy2 = pz.y - sel.y, dz2 = pz.z - sel.z;
@@ -495,17 +505,101 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
         ok = 1;
         c = make_float4(s * pa, s * pb, s * pc, s * pd);
         sc = s;
+        if (a.mapping_mode) {  // PointMapping.cc:572-592
+          const bool pos = pd2 > 0;
+          c = pos ? make_float4(s * pa, s * pb, s * pc, s * pd2) : make_float4(-s * pa, -s * pb, -s * pc, -s * pd2);
+          if (abs_coef) abs_coef[slot] = pos ? make_float4(pa, pb, pc, pd) : make_float4(-pa, -pb, -pc, -pd);
+        }
       }
     }
   }
-  valid[slot] = ok; coef[slot] = c; score[slot] = sc;
+  valid[slot] = ok; coef[slot] = c;
+  if (score) score[slot] = sc;
+}
+
+// Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
+// direction = eigenvector of the largest eigenvalue (accepted when it dominates 3x the middle one).
+__global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
+                                                      Vec3<float> pz, float min_match_sq_dis, const float4 *__restrict__ map,
+                                                      const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                      float4 *__restrict__ coef, const int *__restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
+  const bool active = i < M;
+  Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  Vec3<float> t(tp[4], tp[5], tp[6]);
+  float4 po = active ? stack[i] : make_float4(0, 0, 0, 0);
+  Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+  Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+  float bd[5]; int bi[5], bj[5];
+  knn_scan_group<5, FEAT_LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+  if (!active || sub != 0) return;
+  const int slot = slot_off + i;
+  uint8_t ok = 0;
+  float4 c = make_float4(0, 0, 0, 0);
+  if (bi[4] != INT_MAX && bd[4] < min_match_sq_dis) {
+    float nx[5], ny[5], nz[5];
+    Vec3<float> vc(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 pn = map[bj[j]];
+      nx[j] = pn.x; ny[j] = pn.y; nz[j] = pn.z;
+      vc.x += pn.x; vc.y += pn.y; vc.z += pn.z;
+    }
+    vc.x /= 5.0f; vc.y /= 5.0f; vc.z /= 5.0f;
+    float a00 = 0, a10 = 0, a20 = 0, a11 = 0, a21 = 0, a22 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float ax = nx[j] - vc.x, ay = ny[j] - vc.y, az = nz[j] - vc.z;
+      a00 += ax * ax; a10 += ax * ay; a20 += ax * az; a11 += ay * ay; a21 += ay * az; a22 += az * az;
+    }
+    a00 /= 5.0f; a10 /= 5.0f; a20 /= 5.0f; a11 /= 5.0f; a21 /= 5.0f; a22 /= 5.0f;
+    const float A1[9] = {a00, a10, a20, a10, a11, a21, a20, a21, a22};
+    float D1[3]; double v[3];
+    sym_eig3_top(A1, D1, v);
+    if (D1[2] > 3 * D1[1]) {
+      const float x0 = sel.x, y0 = sel.y, z0 = sel.z;
+      const float v0 = float(v[0]), v1 = float(v[1]), v2 = float(v[2]);  // mat_V1 is a float matrix
+      const float x1 = float(double(vc.x) + 0.1 * double(v0)), y1 = float(double(vc.y) + 0.1 * double(v1)), z1 = float(double(vc.z) + 0.1 * double(v2));
+      const float x2 = float(double(vc.x) - 0.1 * double(v0)), y2 = float(double(vc.y) - 0.1 * double(v1)), z2 = float(double(vc.z) - 0.1 * double(v2));
+      Vec3<float> X0(x0, y0, z0), X1(x1, y1, z1), X2(x2, y2, z2);
+      Vec3<float> a012v = cross(X0 - X1, X0 - X2);
+      Vec3<float> nt = cross(X1 - X2, a012v);
+      const float n2 = dot(nt, nt);
+      if (n2 > 0.f) nt = nt / sqrtf(n2);
+      const float a012 = norm(a012v), l12 = norm(X1 - X2);
+      const float ld2 = a012 / l12;
+      const float s = 1 - 0.9f * fabsf(ld2);
+      float dx1 = t.x - sel.x, dy1 = t.y - sel.y, dz1 = t.z - sel.z;
+      float side1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+      float dx2 = pz.x - sel.x, dy2 = pz.y - sel.y, dz2 = pz.z - sel.z;
+      float side2 = dx2 * dx2 + dy2 * dy2 + dz2 * dz2;
+      float check1 = 100.0f + side1 - side2 - 10.0f * sqrtf(3.0f) * sqrtf(side1);
+      float check2 = 100.0f + side1 - side2 + 10.0f * sqrtf(3.0f) * sqrtf(side1);
+      if (double(s) > 0.1 && check1 < 0 && check2 > 0) {
+        ok = 1;
+        c = make_float4(s * nt.x, s * nt.y, s * nt.z, s * ld2);
+      }
+    }
+  }
+  valid[slot] = ok; coef[slot] = c;
+}
+
+void launch_line_features(const float4 *stack, int M, int slot_off, const float *transform, const float fixed_pz[3], float min_match_sq_dis,
+                          const float4 *map_sorted, const int2 *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
+                          const int *skip_flag, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(k_line_features, dim3(cdiv((long long)M * FEAT_LPQ, 128)), dim3(128), 0, s, stack, M, slot_off, transform,
+                     Vec3<float>(fixed_pz[0], fixed_pz[1], fixed_pz[2]), min_match_sq_dis, map_sorted, cells, g, valid, coef, skip_flag);
+  LIO_HIP(hipGetLastError());
 }
 
 void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
-                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s) {
+                     uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef) {
   if (a.nframes <= 0 || a.max_M <= 0) return;
   hipLaunchKernelGGL(k_features, dim3(cdiv((long long)a.max_M * FEAT_LPQ, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g,
-                     valid, coef, score, skip_flag);
+                     valid, coef, score, skip_flag, abs_coef);
   LIO_HIP(hipGetLastError());
 }
 
@@ -517,7 +611,8 @@ int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM
 
 __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__restrict__ stack, int M, int nslots,
                                                                 const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                                const OdomState *__restrict__ st, double *__restrict__ partials) {
+                                                                const OdomState *__restrict__ st, double *__restrict__ partials,
+                                                                int b_from_coef) {
   if (st->converged) return;
   Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
   Vec3<float> t(st->T[4], st->T[5], st->T[6]);
@@ -538,7 +633,7 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
     a[3] = w.x; a[4] = w.y; a[5] = w.z;
     Vec3<float> rp = rotate(q, p);
     float d2 = w.x * (rp.x + t.x) + w.y * (rp.y + t.y) + w.z * (rp.z + t.z) + c.w;
-    float bb = -d2;
+    float bb = b_from_coef ? -c.w : -d2;
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -566,12 +661,12 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
 }
 
 void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
-                      double *partials, int nblocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_odom_rows, dim3(nblocks), dim3(ODOM_ROW_THREADS), 0, s, stack, M, nslots, valid, coef, st, partials);
+                      double *partials, int nblocks, hipStream_t s, int b_from_coef) {
+  hipLaunchKernelGGL(k_odom_rows, dim3(nblocks), dim3(ODOM_ROW_THREADS), 0, s, stack, M, nslots, valid, coef, st, partials, b_from_coef);
   LIO_HIP(hipGetLastError());
 }
 
-__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
+__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows) {
   if (st->converged) return;
   // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
   __shared__ double ssum[28];
@@ -584,6 +679,8 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   if (threadIdx.x != 0) return;
   double sum[28];
   for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
+  st->nsel = int(sum[27]);
+  if (min_rows > 0 && st->nsel < min_rows) { st->iters = iter + 1; return; }
   float AtA[36], AtB[6];
   int k = 0;
   for (int r = 0; r < 6; ++r)
@@ -620,8 +717,8 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   if (double(delta_r) < 0.05 && double(delta_t) < 0.05) st->converged = 1;
 }
 
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s) {
-  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter);
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows) {
+  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter, min_rows);
   LIO_HIP(hipGetLastError());
 }
 

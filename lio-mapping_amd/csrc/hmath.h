@@ -282,6 +282,49 @@ LIO_HD int count_eigs_below(const float *Ain, double tau) {
   return neg;
 }
 
+// Symmetric 3x3: eigenvalues (ascending, float) and the unit eigenvector of the LARGEST one (double), by cyclic
+// Jacobi in double.  Used for the line fit of the corner features (PointMapping.cc:411-423: mat_D1, mat_V1 col 2).
+LIO_HD void sym_eig3_top(const float *Ain, float *evals, double *vtop) {
+  double A[9], U[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = double(Ain[i]);
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * dg || off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        double app = A[p * 3 + p], aqq = A[q * 3 + q];
+        double tau = (aqq - app) / (2.0 * apq);
+        double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double ukp = U[k * 3 + p], ukq = U[k * 3 + q];
+          U[k * 3 + p] = c * ukp - s * ukq;
+          U[k * 3 + q] = s * ukp + c * ukq;
+        }
+      }
+  }
+  int o0 = 0, o1 = 1, o2 = 2;
+  double d0 = A[0], d1 = A[4], d2 = A[8];
+  if (d1 < d0) { double t = d0; d0 = d1; d1 = t; int ti = o0; o0 = o1; o1 = ti; }
+  if (d2 < d1) { double t = d1; d1 = d2; d2 = t; int ti = o1; o1 = o2; o2 = ti; }
+  if (d1 < d0) { double t = d0; d0 = d1; d1 = t; int ti = o0; o0 = o1; o1 = ti; }
+  evals[0] = float(d0); evals[1] = float(d1); evals[2] = float(d2);
+  vtop[0] = U[0 * 3 + o2]; vtop[1] = U[1 * 3 + o2]; vtop[2] = U[2 * 3 + o2];
+}
+
 // Cyclic-Jacobi eigenvalues of a symmetric NxN (N <= 6) matrix, ascending.  Accumulates in double.
 template <int N>
 LIO_HD void sym_eigvals(const float *Ain, float *evals) {

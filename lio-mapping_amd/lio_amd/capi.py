@@ -49,6 +49,16 @@ class PPConfig(C.Structure):
     ]
 
 
+class MapConfig(C.Structure):
+    _fields_ = [
+        ("corner_filter_size", C.c_float),
+        ("surf_filter_size", C.c_float),
+        ("min_match_sq_dis", C.c_float),
+        ("min_plane_dis", C.c_float),
+        ("num_max_iterations", C.c_int),
+    ]
+
+
 class EstConfig(C.Structure):
     _fields_ = [
         ("window_size", C.c_int),
@@ -127,6 +137,18 @@ _SIGS = {
     "lio_odom_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 4 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lio_odom_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_odom_get_last_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_map_default_config": (None, [C.POINTER(MapConfig)]),
+    "lio_map_create": (C.c_void_p, [C.POINTER(MapConfig)]),
+    "lio_map_destroy": (None, [C.c_void_p]),
+    "lio_map_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 2 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lio_map_set_init_flag": (C.c_int, [C.c_void_p, C.c_int]),
+    "lio_map_set_transform_tobe_mapped": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
+    "lio_map_get_transform_tobe_mapped": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
+    "lio_map_update_map_database": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 2 + [C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(TransformF), C.POINTER(C.c_int)]),
+    "lio_map_get_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_map_get_cube": (C.c_size_t, [C.c_void_p, C.c_int, C.c_uint32, c_float_p]),
+    "lio_map_get_cube_state": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "lio_map_get_score_point_coeff": (C.c_size_t, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
     "lio_compact_encode": (C.c_size_t, [C.POINTER(TransformF)] + [c_float_p, C.c_size_t] * 3 + [c_float_p]),
     "lio_compact_decode": (C.c_int, [c_float_p, C.c_size_t, C.POINTER(TransformF)] + [C.POINTER(C.c_size_t)] * 3),
     "lio_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_size_t)]),
@@ -379,6 +401,86 @@ class PointProcessor:
         mask = np.zeros(n, dtype=np.int32)
         _chk(self.lib.dll.lio_pp_get_curvature(self.h, _fp(curv), mask.ctypes.data_as(c_int32_p)), "lio_pp_get_curvature")
         return curv, mask
+
+
+class PointMapping:
+    """PointMapping (scan-to-map + cube map) — reference src/point_processor/PointMapping.cc."""
+
+    CORNER_STACK_DS, SURF_STACK_DS, CORNER_FROM_MAP, SURF_FROM_MAP = 0, 1, 2, 3
+
+    def __init__(self, lib: LioLib, **overrides):
+        self.lib = lib
+        cfg = MapConfig()
+        lib.dll.lio_map_default_config(C.byref(cfg))
+        for k, v in overrides.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = lib.dll.lio_map_create(C.byref(cfg))
+        if not self.h:
+            raise LioError("lio_map_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_map_destroy(self.h)
+            self.h = None
+
+    def process(self, corner_last, surf_last, T_sum):
+        c, s = _f32(corner_last).reshape(-1, 4), _f32(surf_last).reshape(-1, 4)
+        Ts = TransformF.make(*T_sum)
+        Ta = TransformF()
+        it, ns = C.c_int(0), C.c_int(0)
+        _chk(self.lib.dll.lio_map_process(self.h, _fp(c), c.shape[0], _fp(s), s.shape[0], C.byref(Ts), C.byref(Ta), C.byref(it), C.byref(ns)),
+             "lio_map_process")
+        return dict(T_aft=Ta.to_np(), iterations=it.value, num_selected=ns.value)
+
+    def set_init_flag(self, on):
+        _chk(self.lib.dll.lio_map_set_init_flag(self.h, 1 if on else 0), "lio_map_set_init_flag")
+
+    def set_transform_tobe_mapped(self, q_xyzw, p):
+        T = TransformF.make(q_xyzw, p)
+        _chk(self.lib.dll.lio_map_set_transform_tobe_mapped(self.h, C.byref(T)), "lio_map_set_transform_tobe_mapped")
+
+    def transform_tobe_mapped(self):
+        T = TransformF()
+        _chk(self.lib.dll.lio_map_get_transform_tobe_mapped(self.h, C.byref(T)), "lio_map_get_transform_tobe_mapped")
+        return T.to_np()
+
+    def update_map_database(self, corner_ds, surf_ds, valid_idx, T, cube_center):
+        c, s = _f32(corner_ds).reshape(-1, 4), _f32(surf_ds).reshape(-1, 4)
+        v = np.ascontiguousarray(valid_idx, dtype=np.uint32)
+        Tt = TransformF.make(*T)
+        cen = (C.c_int * 3)(*[int(x) for x in cube_center])
+        _chk(self.lib.dll.lio_map_update_map_database(self.h, _fp(c), c.shape[0], _fp(s), s.shape[0], v.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      v.shape[0], C.byref(Tt), cen), "lio_map_update_map_database")
+
+    def cloud(self, which):
+        n = self.lib.dll.lio_map_get_cloud(self.h, which, None)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_map_get_cloud(self.h, which, _fp(out))
+        return out
+
+    def cube(self, cls, cube_idx):
+        n = self.lib.dll.lio_map_get_cube(self.h, cls, int(cube_idx), None)
+        out = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_map_get_cube(self.h, cls, int(cube_idx), _fp(out))
+        return out
+
+    def cube_state(self):
+        cen = (C.c_int * 3)()
+        valid = np.zeros(125, dtype=np.uint32)
+        n = self.lib.dll.lio_map_get_cube_state(self.h, cen, valid.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return list(cen), valid[:n].copy()
+
+    def score_point_coeff(self):
+        n = self.lib.dll.lio_map_get_score_point_coeff(self.h, None, None, None)
+        score = np.zeros(n, dtype=np.float32)
+        point = np.zeros((n, 4), dtype=np.float32)
+        coeff = np.zeros((n, 4), dtype=np.float32)
+        if n:
+            self.lib.dll.lio_map_get_score_point_coeff(self.h, _fp(score), _fp(point), _fp(coeff))
+        return score, point, coeff
 
 
 class PointOdometry:

@@ -6,11 +6,13 @@
 
 #include "../include/lio_c.h"
 #include "estimator.h"
+#include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
 
 using namespace orc;
 
+struct lio_map { PointMapping m; explicit lio_map(const MappingConfig &c) : m(c) {} };
 struct lio_odom { PointOdometry o; lio_odom(float sp, int io, size_t it, bool nd) : o(sp, io, it, nd) {} };
 
 struct lio_pp { PointProcessor pp; lio_pp(float a, float b, int r) : pp(a, b, r) {} };
@@ -113,6 +115,85 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   const Cloud &c = which == 0 ? h->o.last_corner_ : h->o.last_surf_;
   if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
   return c.size();
+}
+
+// ---------------------------------------------------------------- PointMapping
+void lio_map_default_config(lio_map_config *c) {
+  if (!c) return;
+  c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f; c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f; c->num_max_iterations = 10;
+}
+lio_map *lio_map_create(const lio_map_config *c) {
+  lio_map_config cfg;
+  if (c) cfg = *c; else lio_map_default_config(&cfg);
+  if (!(cfg.corner_filter_size > 0) || !(cfg.surf_filter_size > 0) || cfg.num_max_iterations < 1) return nullptr;
+  MappingConfig mc;
+  mc.corner_filter_size = cfg.corner_filter_size; mc.surf_filter_size = cfg.surf_filter_size;
+  mc.min_match_sq_dis = cfg.min_match_sq_dis; mc.min_plane_dis = cfg.min_plane_dis; mc.num_max_iterations = cfg.num_max_iterations;
+  return new (std::nothrow) lio_map(mc);
+}
+void lio_map_destroy(lio_map *h) { delete h; }
+int lio_map_process(lio_map *h, const float *corner, size_t nc, const float *surf, size_t ns, const lio_transform_f *Tsum, lio_transform_f *Taft,
+                    int *iters, int *nsel) {
+  if (!h || !Tsum || (!corner && nc) || (!surf && ns)) return LIO_ERR_ARG;
+  h->m.Process(toCloud(corner, nc), toCloud(surf, ns), toT(*Tsum));
+  if (Taft) fromT(h->m.transform_aft_mapped, Taft);
+  if (iters) *iters = h->m.last_iterations;
+  if (nsel) *nsel = h->m.last_selected;
+  return LIO_OK;
+}
+int lio_map_set_init_flag(lio_map *h, int on) {
+  if (!h) return LIO_ERR_ARG;
+  h->m.imu_inited = on != 0;
+  return LIO_OK;
+}
+int lio_map_set_transform_tobe_mapped(lio_map *h, const lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  h->m.transform_tobe_mapped = toT(*T);
+  return LIO_OK;
+}
+int lio_map_get_transform_tobe_mapped(const lio_map *h, lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  fromT(h->m.transform_tobe_mapped, T);
+  return LIO_OK;
+}
+int lio_map_update_map_database(lio_map *h, const float *corner, size_t nc, const float *surf, size_t ns, const uint32_t *valid, size_t nv,
+                                const lio_transform_f *T, const int cen[3]) {
+  if (!h || !T || !cen || (!corner && nc) || (!surf && ns) || (!valid && nv)) return LIO_ERR_ARG;
+  std::vector<size_t> vi(nv);
+  for (size_t i = 0; i < nv; ++i) {
+    if (valid[i] >= uint32_t(PointMapping::L * PointMapping::Wd * PointMapping::H)) return LIO_ERR_ARG;
+    vi[i] = valid[i];
+  }
+  h->m.UpdateMapDatabase(toCloud(corner, nc), toCloud(surf, ns), vi, toT(*T), cen);
+  return LIO_OK;
+}
+size_t lio_map_get_cloud(const lio_map *h, int which, float *out) {
+  if (!h || which < 0 || which > 3) return 0;
+  const Cloud *c[4] = {&h->m.corner_stack_ds, &h->m.surf_stack_ds, &h->m.corner_from_map, &h->m.surf_from_map};
+  if (out && !c[which]->empty()) std::memcpy(out, c[which]->data(), c[which]->size() * sizeof(P4));
+  return c[which]->size();
+}
+size_t lio_map_get_cube(const lio_map *h, int cls, uint32_t idx, float *out) {
+  if (!h || cls < 0 || cls > 1 || idx >= uint32_t(PointMapping::L * PointMapping::Wd * PointMapping::H)) return 0;
+  const Cloud &c = cls == 0 ? h->m.corner_array[idx] : h->m.surf_array[idx];
+  if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
+  return c.size();
+}
+size_t lio_map_get_cube_state(const lio_map *h, int cen[3], uint32_t *valid) {
+  if (!h) return 0;
+  if (cen) for (int d = 0; d < 3; ++d) cen[d] = h->m.cen[d];
+  if (valid) for (size_t i = 0; i < h->m.valid_idx.size(); ++i) valid[i] = uint32_t(h->m.valid_idx[i]);
+  return h->m.valid_idx.size();
+}
+size_t lio_map_get_score_point_coeff(const lio_map *h, float *score, float *point, float *coeff) {
+  if (!h) return 0;
+  const auto &v = h->m.score_point_coeff;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (score) score[i] = v[i].score;
+    if (point) std::memcpy(point + 4 * i, &v[i].point, sizeof(P4));
+    if (coeff) std::memcpy(coeff + 4 * i, &v[i].coeff, sizeof(P4));
+  }
+  return v.size();
 }
 
 // ---------------------------------------------------------------- /compact_data codec

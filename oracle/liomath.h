@@ -34,6 +34,7 @@ struct V3 {
   V3 cross(const V3 &o) const { return {y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x}; }
   T squaredNorm() const { return x * x + y * y + z * z; }
   T norm() const { return std::sqrt(squaredNorm()); }
+  V3 normalized() const { T n2 = squaredNorm(); return n2 > T(0) ? *this / std::sqrt(n2) : *this; }
   template <typename U> V3<U> cast() const { return {U(x), U(y), U(z)}; }
 };
 template <typename T> inline V3<T> operator*(T s, const V3<T> &v) { return v * s; }

@@ -187,6 +187,7 @@ def main():
             batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
 
         odom_ms = odometry_ms_per_scan(hip, ds) if kind == "outdoor" else None
+        map_stats = mapping_ms_per_scan(hip, ds, clouds)
         cpu = None if args.no_cpu_baseline else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)
         odom_io = 3 if kind == "outdoor" else 2
         pp_med = float(np.median(pp_ms[1:]))
@@ -229,9 +230,10 @@ def main():
             "ms_per_scan": {
                 "point_processor_incl_h2d_d2h": round(pp_med, 4),
                 "point_odometry_incl_h2d": odom_ms,
+                "point_mapping_incl_h2d": map_stats,
                 "estimator_step_amortised_over_odom_io": round(1e3 * dt_max / args.steps / odom_io, 4),
                 "total": round(pp_med + (odom_ms or 0.0) + 1e3 * dt_max / args.steps / odom_io, 4),
-                "note": "per 10 Hz sweep: PointProcessor + PointOdometry (pre-init role; the estimator disables it after IMU init, SURVEY.md A.18) + 1/odom_io of a SolveOptimization",
+                "note": "total = per 10 Hz sweep after IMU init: PointProcessor + PointOdometry (pre-init role; the estimator disables it after IMU init, SURVEY.md A.18) + 1/odom_io of a SolveOptimization.  point_mapping is the pre-init scan-to-map step (one per sweep until the IMU is initialised), reported separately",
             },
             "setup_s": round(setup_s, 2),
         }
@@ -283,6 +285,36 @@ def odometry_ms_per_scan(hip, ds):
     return round(float(np.median(ms[1:])), 4)
 
 
+def mapping_ms_per_scan(lib, ds, clouds, n_frames=8):
+    """Scan-to-map step (PointMapping::Process: from-map extraction, stack VoxelGrid, <=10 Gauss-Newton rounds against the
+    cube map, map update) on consecutive sweeps; transform_sum = ground truth + a growing drift.  Median wall ms per sweep
+    and the map sizes of the last one."""
+    from lio_amd import capi, synth
+
+    mp = capi.PointMapping(lib)
+    f0 = ds.frames[0]
+    R0 = f0.R_wb @ ds.R_lb.T
+    p0 = f0.p_wb - R0 @ ds.t_lb
+    ms = []
+    r = None
+    for k, f in enumerate(ds.frames[:n_frames]):
+        R = f.R_wb @ ds.R_lb.T
+        p = f.p_wb - R @ ds.t_lb
+        q = synth.quat_from_rot(R0.T @ R @ synth.small_rot(np.array([0.002, -0.001, 0.003]) * k))
+        T = (q, R0.T @ (p - p0) + np.array([0.05, -0.03, 0.02]) * k)
+        surf, corner = clouds[k]
+        t = time.perf_counter()
+        r = mp.process(corner, surf, T)
+        ms.append((time.perf_counter() - t) * 1e3)
+    return {
+        "ms_per_scan": round(float(np.median(ms[2:])), 4),
+        "from_map_points": int(mp.cloud(2).shape[0] + mp.cloud(3).shape[0]),
+        "stack_points": int(mp.cloud(0).shape[0] + mp.cloud(1).shape[0]),
+        "iterations_last": int(r["iterations"]),
+        "rows_last": int(r["num_selected"]),
+    }
+
+
 def cpu_baseline(kind, W, Wo, steps, ds):
     """The CPU oracle on the same workload, on this box's host cores (solve single-threaded like Ceres with
     num_threads=1, marginalization on 4 threads like the reference).  Bounded sample: `steps` solves."""
@@ -323,6 +355,7 @@ def cpu_baseline(kind, W, Wo, steps, ds):
         "n_lidar_residuals": int(rep.n_lidar_residuals),
         "stages_ms": {"t_build_map": round(rep.ms_build_map, 3), "feature_cost": round(rep.ms_features, 3), "t_opt": round(rep.ms_opt, 3), "whole_marginalization": round(rep.ms_marg, 3)},
         "point_processor_ms_per_scan": round(float(np.median(pp_ms[1:])), 3),
+        "point_mapping": mapping_ms_per_scan(orc, ds, clouds, n_frames=5),
         "note": "the oracle has none of the reference's ROS/PCL/Ceres/heap overheads: a faster-than-reference, conservative baseline; the reference itself cannot be built here (Eigen/PCL/Ceres/ROS absent)",
     }
 

@@ -448,6 +448,7 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
   }
 }
 
+template <bool MAPPING>
 __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                  const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
                                                  float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
       // FOV test (+-60 deg about the sensor z axis, Estimator.cc:1063-1086)
       Vec3<float> rz = rotate(q, Vec3<float>(0.f, 0.f, 10.f));
       Vec3<float> pz(rz.x + t.x, rz.y + t.y, rz.z + t.z);
-      if (a.mapping_mode) pz = Vec3<float>(a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]);
+      if (MAPPING) pz = Vec3<float>(a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]);
       float dx1 = t.x - sel.x, dy1 = t.y - sel.y, dz1 = t.z - sel.z;
       float side1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
       float dx2 = pz.x - sel.x, dy2 = pz.y - sel.y, dz2 = pz.z - sel.z;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
         ok = 1;
         c = make_float4(s * pa, s * pb, s * pc, s * pd);
         sc = s;
-        if (a.mapping_mode) {  // PointMapping.cc:572-592
+        if (MAPPING) {  // PointMapping.cc:572-592
           const bool pos = pd2 > 0;
           c = pos ? make_float4(s * pa, s * pb, s * pc, s * pd2) : make_float4(-s * pa, -s * pb, -s * pc, -s * pd2);
           if (abs_coef) abs_coef[slot] = pos ? make_float4(pa, pb, pc, pd) : make_float4(-pa, -pb, -pc, -pd);
@@ -598,8 +599,11 @@ void launch_line_features(const float4 *stack, int M, int slot_off, const float 
 void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
                      uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef) {
   if (a.nframes <= 0 || a.max_M <= 0) return;
-  hipLaunchKernelGGL(k_features, dim3(cdiv((long long)a.max_M * FEAT_LPQ, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g,
-                     valid, coef, score, skip_flag, abs_coef);
+  const dim3 grid(cdiv((long long)a.max_M * FEAT_LPQ, 128), a.nframes);
+  if (a.mapping_mode)
+    hipLaunchKernelGGL(k_features<true>, grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
+  else
+    hipLaunchKernelGGL(k_features<false>, grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
   LIO_HIP(hipGetLastError());
 }
 

@@ -194,6 +194,23 @@ int lio_pim_evaluate(const lio_pim *, const double *pose_i, const double *sb_i,
                      const double *pose_j, const double *sb_j, double *residual15);
 
 /* ------------------------------------------------------------------------------------------------
+ * ImuInitializer (src/imu_processor/ImuInitializer.cc:49-436; include/imu_processor/ImuInitializer.h:73-91) — host
+ * math on <= window_size+1 frames (§8f 3).  `laser_transforms[i]` / `pims[i]` are all_laser_transforms_[i]'s
+ * transform and pre_integration (pims[0] is never read for its motion, may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+/* EstimateExtrinsicRotation (:331-397): writes transform_lb->q; returns 1 when the second-smallest singular value
+ * exceeds 0.25 (calibration accepted), 0 when not, < 0 on error. */
+int lio_imu_estimate_extrinsic_rotation(size_t n, const lio_transform_f *laser_transforms, lio_pim *const *pims,
+                                        lio_transform_f *transform_lb);
+/* Initialization (:399-436) = EstimateGyroBias + ApproximateGravity + RefineGravityAccBias.  Bgs (3n doubles) is
+ * updated in place, the pims are re-propagated with the new gyro bias (:86-89), Vs_out gets 3n doubles, g_out the
+ * refined gravity in the laser world frame, R_WI_out (row-major 3x3) the inertial->laser-world rotation.
+ * Returns 1 on success, 0 when the gravity estimate is rejected (:175) or n < 6, < 0 on error. */
+int lio_imu_initialization(size_t n, const lio_transform_f *laser_transforms, lio_pim *const *pims,
+                           const lio_transform_f *transform_lb, double *Vs_out, double *Bgs_inout, double g_out[3],
+                           double R_WI_out[9]);
+
+/* ------------------------------------------------------------------------------------------------
  * Factors (ceres::SizedCostFunction::Evaluate restated; §8a a11, a15, a24).  Jacobians are
  * row-major in the ambient (7/9 column) layout exactly as the reference writes them; null = skip.
  * ---------------------------------------------------------------------------------------------- */

@@ -7,6 +7,7 @@
 
 #include "../../include/lio_c.h"
 #include "estimator.h"
+#include "host_init.h"
 #include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
@@ -116,6 +117,49 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   size_t n = 0;
   guarded([&] { n = h->o->GetLastCloud(which, out); return LIO_OK; });
   return n;
+}
+
+// ---------------------------------------------------------------- ImuInitializer (host)
+static bool gatherLaserFrames(size_t n, const lio_transform_f *T, lio_pim *const *pims, std::vector<LaserFrame> &all) {
+  all.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    all[i].transform = toT(T[i]);
+    if (pims[i]) all[i].pim = pims[i]->p;
+    else if (i != 0) return false;
+  }
+  return true;
+}
+int lio_imu_estimate_extrinsic_rotation(size_t n, const lio_transform_f *T, lio_pim *const *pims, lio_transform_f *lb) {
+  if (n < 2 || !T || !pims || !lb) return LIO_ERR_ARG;
+  std::vector<LaserFrame> all;
+  if (!gatherLaserFrames(n, T, pims, all)) return LIO_ERR_ARG;
+  return guarded([&] {
+    Rigidf tlb = toT(*lb);
+    const bool ok = estimate_extrinsic_rotation(all, tlb);
+    fromT(tlb, lb);
+    return ok ? 1 : 0;
+  });
+}
+int lio_imu_initialization(size_t n, const lio_transform_f *T, lio_pim *const *pims, const lio_transform_f *lb, double *Vs, double *Bgs, double g[3],
+                           double R_WI[9]) {
+  if (n < 2 || !T || !pims || !lb || !Vs || !Bgs || !g || !R_WI) return LIO_ERR_ARG;
+  std::vector<LaserFrame> all;
+  if (!gatherLaserFrames(n, T, pims, all)) return LIO_ERR_ARG;
+  return guarded([&] {
+    std::vector<V3d> vs(n), bgs(n);
+    for (size_t i = 0; i < n; ++i) bgs[i] = v3(Bgs + 3 * i);
+    V3d gv;
+    M3d R;
+    R(0, 0) = R(1, 1) = R(2, 2) = 1.0;
+    const bool ok = imu_initialization(all, vs, bgs, gv, toT(*lb), R);
+    for (size_t i = 0; i < n; ++i) {
+      Vs[3 * i] = vs[i].x; Vs[3 * i + 1] = vs[i].y; Vs[3 * i + 2] = vs[i].z;
+      Bgs[3 * i] = bgs[i].x; Bgs[3 * i + 1] = bgs[i].y; Bgs[3 * i + 2] = bgs[i].z;
+    }
+    g[0] = gv.x; g[1] = gv.y; g[2] = gv.z;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_WI[r * 3 + c] = R(r, c);
+    return ok ? 1 : 0;
+  });
 }
 
 // ---------------------------------------------------------------- PointMapping

@@ -137,6 +137,8 @@ _SIGS = {
     "lio_odom_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 4 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lio_odom_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_odom_get_last_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_imu_estimate_extrinsic_rotation": (C.c_int, [C.c_size_t, C.POINTER(TransformF), C.POINTER(C.c_void_p), C.POINTER(TransformF)]),
+    "lio_imu_initialization": (C.c_int, [C.c_size_t, C.POINTER(TransformF), C.POINTER(C.c_void_p), C.POINTER(TransformF), c_double_p, c_double_p, c_double_p, c_double_p]),
     "lio_map_default_config": (None, [C.POINTER(MapConfig)]),
     "lio_map_create": (C.c_void_p, [C.POINTER(MapConfig)]),
     "lio_map_destroy": (None, [C.c_void_p]),
@@ -233,6 +235,35 @@ class LioLib:
             fn.restype = res
             fn.argtypes = args
         self.backend = self.dll.lio_backend().decode()
+
+    # ---- ImuInitializer (host math)
+    @staticmethod
+    def _laser_frames(transforms, pims):
+        n = len(transforms)
+        T = (TransformF * n)(*[TransformF.make(q, p) for q, p in transforms])
+        P = (C.c_void_p * n)(*[(p.h if p is not None else None) for p in pims])
+        return n, T, P
+
+    def imu_estimate_extrinsic_rotation(self, transforms, pims, T_lb):
+        """ImuInitializer::EstimateExtrinsicRotation -> (accepted, q_lb xyzw)."""
+        n, T, P = self._laser_frames(transforms, pims)
+        lb = TransformF.make(*T_lb)
+        rc = self.dll.lio_imu_estimate_extrinsic_rotation(n, T, P, C.byref(lb))
+        if rc < 0:
+            raise LioError(f"lio_imu_estimate_extrinsic_rotation -> {rc}")
+        return bool(rc), lb.to_np()[0]
+
+    def imu_initialization(self, transforms, pims, T_lb, Bgs=None):
+        """ImuInitializer::Initialization -> dict(ok, Vs, Bgs, g, R_WI); re-propagates the pims."""
+        n, T, P = self._laser_frames(transforms, pims)
+        lb = TransformF.make(*T_lb)
+        Vs = np.zeros((n, 3))
+        bgs = np.zeros((n, 3)) if Bgs is None else _f64(Bgs).reshape(n, 3).copy()
+        g, R = np.zeros(3), np.zeros((3, 3))
+        rc = self.dll.lio_imu_initialization(n, T, P, C.byref(lb), _dp(Vs), _dp(bgs), _dp(g), _dp(R))
+        if rc < 0:
+            raise LioError(f"lio_imu_initialization -> {rc}")
+        return dict(ok=bool(rc), Vs=Vs, Bgs=bgs, g=g, R_WI=R)
 
     # ---- stateless blocks
     def voxel_grid(self, xyzi, leaf):

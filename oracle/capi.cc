@@ -6,6 +6,7 @@
 
 #include "../include/lio_c.h"
 #include "estimator.h"
+#include "imu_init.h"
 #include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
@@ -115,6 +116,43 @@ size_t lio_odom_get_last_cloud(const lio_odom *h, int which, float *out) {
   const Cloud &c = which == 0 ? h->o.last_corner_ : h->o.last_surf_;
   if (out && !c.empty()) std::memcpy(out, c.data(), c.size() * sizeof(P4));
   return c.size();
+}
+
+// ---------------------------------------------------------------- ImuInitializer
+static bool gatherLaserTransforms(size_t n, const lio_transform_f *T, lio_pim *const *pims, std::vector<LaserTransform> &all) {
+  all.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    all[i].transform = toT(T[i]);
+    if (pims[i]) all[i].pre_integration = std::shared_ptr<IntegrationBase>(&pims[i]->pim, [](IntegrationBase *) {});
+    else if (i != 0) return false;
+  }
+  return true;
+}
+int lio_imu_estimate_extrinsic_rotation(size_t n, const lio_transform_f *T, lio_pim *const *pims, lio_transform_f *lb) {
+  if (n < 2 || !T || !pims || !lb) return LIO_ERR_ARG;
+  std::vector<LaserTransform> all;
+  if (!gatherLaserTransforms(n, T, pims, all)) return LIO_ERR_ARG;
+  Transformf tlb = toT(*lb);
+  bool ok = EstimateExtrinsicRotation(all, tlb);
+  fromT(tlb, lb);
+  return ok ? 1 : 0;
+}
+int lio_imu_initialization(size_t n, const lio_transform_f *T, lio_pim *const *pims, const lio_transform_f *lb, double *Vs, double *Bgs, double g[3],
+                           double R_WI[9]) {
+  if (n < 2 || !T || !pims || !lb || !Vs || !Bgs || !g || !R_WI) return LIO_ERR_ARG;
+  std::vector<LaserTransform> all;
+  if (!gatherLaserTransforms(n, T, pims, all)) return LIO_ERR_ARG;
+  std::vector<V3d> vs(n), bgs(n);
+  for (size_t i = 0; i < n; ++i) bgs[i] = v3(Bgs + 3 * i);
+  V3d gv;
+  M3d R = M3d::Identity();
+  bool ok = Initialization(all, vs, bgs, gv, toT(*lb), R);
+  for (size_t i = 0; i < n; ++i) {
+    for (int d = 0; d < 3; ++d) { Vs[3 * i + d] = vs[i][d]; Bgs[3 * i + d] = bgs[i][d]; }
+  }
+  for (int d = 0; d < 3; ++d) g[d] = gv[d];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_WI[r * 3 + c] = R(r, c);
+  return ok ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- PointMapping

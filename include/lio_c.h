@@ -251,7 +251,9 @@ typedef struct {
   double acc_n, gyr_n, acc_w, gyr_w, g_norm; /* IntegrationBaseConfig, IntegrationBase.h:64-70 */
   int max_num_iterations;     /* ceres options, Estimator.cc:1916 (10) */
   double max_solver_time;     /* Estimator.cc:1921 (0.10 s); <= 0 disables the cap (parity runs) */
-  int extrinsic_stage;        /* Estimator.h extrinsic_stage_: 0 = fixed (SetParameterBlockConstant) */
+  int extrinsic_stage;        /* estimate_extrinsic / extrinsic_stage_ (Estimator.h:81,174): 0 = fixed (SetParameterBlockConstant),
+                                 1 = refine in the window, 2 = calibrate the rotation first (EstimateExtrinsicRotation) */
+  int init_window_factor;     /* 3    Estimator.h:80: only every n-th frame enters the window until the IMU is initialised */
 } lio_est_config;
 
 /* Named after the reference's TicToc stages so CPU/GPU tables line up. */
@@ -284,12 +286,29 @@ void lio_est_destroy(lio_est *);
 
 /* Estimator::ProcessImu (Estimator.cc:338-427) */
 int lio_est_process_imu(lio_est *, double dt, const double acc[3], const double gyr[3], double stamp);
-/* Estimator::ProcessLaserOdom, INITED branch (Estimator.cc:430-488,620-774): push the frame,
- * (deskew), VoxelGrid the surf/corner clouds, SolveOptimization, SlideWindow.  The clouds are the
- * implicit inputs the reference keeps in laser_cloud_{surf,corner}_last_ (Estimator.cc:467-487). */
+/* Estimator::ProcessLaserOdom (Estimator.cc:430-774).  Until the IMU is initialised (NOT_INITED, :490-618): every
+ * init_window_factor-th frame is pushed (the clouds are then PointMapping's down-sampled stacks, :474-481); once
+ * window_size+1 frames are held, EstimateExtrinsicRotation / RunInitialization (:858-958) are tried and on success
+ * the first SolveOptimization + SlideWindow run.  INITED branch (:620-774): push the frame, (deskew), VoxelGrid the
+ * surf/corner clouds, SolveOptimization, SlideWindow; the clouds are the implicit inputs the reference keeps in
+ * laser_cloud_{surf,corner}_last_ (Estimator.cc:467-487).  lio_est_get_stage tells which of these happened. */
 int lio_est_process_laser_odom(lio_est *, const lio_transform_f *transform_in, const float *surf_xyzi,
                                size_t n_surf, const float *corner_xyzi, size_t n_corner, double stamp,
                                lio_solve_report *report_or_null);
+/* Estimator::ProcessCompactData (Estimator.cc:776-856): decode one /compact_data message (lio_compact_encode layout),
+ * run the PointMapping base (scan-to-map + cube map) until the IMU is initialised or, afterwards, predict
+ * transform_tobe_mapped_ from the IMU-propagated body motion (:780-803), then ProcessLaserOdom with
+ * transform_aft_mapped_.  transform_to_init_out (may be null) receives that transform.  After initialisation the
+ * caller switches the scan-to-scan odometry to its packer mode (lio_odom_enable(.., 0); the reference does it
+ * through the /enable_odom service, :549-558).  Not reproduced: the post-init map-database refresh (:703-708),
+ * which only feeds the published surround map. */
+int lio_est_process_compact(lio_est *, const float *compact_xyzi, size_t n_points, double stamp,
+                            lio_transform_f *transform_to_init_out, lio_solve_report *report_or_null);
+/* stage_flag_ (0 NOT_INITED, 1 INITED), cir_buf_count_, extrinsic_stage_, what the last ProcessLaserOdom did
+ * (0 frame skipped by init_window_factor, 1 window filling, 2 initialisation tried and failed, 3 initialised + first
+ * solve, 4 regular solve), R_WI_ (row-major 3x3) and g_vec_.  Any output may be null. */
+int lio_est_get_stage(const lio_est *, int *stage_flag, int *cir_buf_count, int *extrinsic_stage, int *last_event,
+                      double *R_WI_or_null, double *g_vec_or_null);
 /* First half of ProcessLaserOdom only (Estimator.cc:441-488,620-693): push the pre-integration, deskew,
  * VoxelGrid and push the clouds — everything up to, not including, SolveOptimization.
  * lio_est_process_laser_odom == lio_est_push_frame + lio_est_solve_optimization + lio_est_slide_window. */

@@ -15,7 +15,7 @@
 using namespace lio;
 
 struct lio_pim { std::shared_ptr<Preintegration> p; };
-struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; };
+struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; };
 struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
 struct lio_map { std::unique_ptr<MappingDev> m; };
@@ -425,7 +425,7 @@ void lio_est_default_config(lio_est_config *c) {
   c->opt_extrinsic = 0; c->imu_factor = 1; c->point_distance_factor = 0; c->prior_factor = 0; c->marginalization_factor = 1;
   c->enable_deskew = 1; c->cutoff_deskew = 0; c->keep_features = 0;
   c->acc_n = 0.1; c->gyr_n = 0.01; c->acc_w = 0.0002; c->gyr_w = 2.0e-5; c->g_norm = 9.805;
-  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2;
+  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2; c->init_window_factor = 3;
 }
 lio_est *lio_est_create(const lio_est_config *c) {
   if (!c || c->window_size < 1 || c->opt_window_size < 1 || c->opt_window_size > c->window_size || c->window_size + 1 > LIO_MAX_FRAMES) return nullptr;
@@ -441,6 +441,10 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.enable_deskew = c->enable_deskew; e.cutoff_deskew = c->cutoff_deskew; e.keep_features = c->keep_features;
   e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
   e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
+  e.init_window_factor = c->init_window_factor > 0 ? c->init_window_factor : 1;
+  // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
+  h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
+  h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;
   int rc = guarded([&] { h->e.reset(new Estimator(e)); return LIO_OK; });
   if (rc != LIO_OK) { delete h; return nullptr; }
   return h;
@@ -457,8 +461,57 @@ int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float
   if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
   return guarded([&] { return h->e->ProcessLaserOdom(toT(*T), surf, ns, corner, nc, stamp, rep) ? LIO_OK : LIO_ERR_STATE; });
 }
+// ProcessCompactData (Estimator.cc:776-856).  The post-initialisation map-database refresh (:703-708) only feeds the
+// published surround map and is not reproduced.
+int lio_est_process_compact(lio_est *h, const float *data, size_t n, double stamp, lio_transform_f *T_out, lio_solve_report *rep) {
+  if (!h || !data) return LIO_ERR_ARG;
+  lio_transform_f Tsum;
+  size_t nc = 0, ns = 0, nf = 0;
+  int rc = lio_compact_decode(data, n, &Tsum, &nc, &ns, &nf);
+  if (rc != LIO_OK) return rc;
+  return guarded([&] {
+    Estimator &e = *h->e;
+    if (e.inited_ && !e.cfg_.imu_factor) return LIO_ERR_STATE;  // LOAM-only operation after init is not part of this path
+    if (!h->map) h->map.reset(new MappingDev(h->map_cfg));
+    MappingDev &m = *h->map;
+    const float *corner = data + 4 * 3, *surf = data + 4 * (3 + nc);
+    if (e.inited_) {  // :780-803: predict transform_tobe_mapped_ with the IMU-propagated body motion
+      const int W = e.W_;
+      auto bodyPose = [&](int i) {
+        // Quaterniond(R).cast<float>(): build the quaternion in double, then cast
+        const Quat<double> qd = fromRot(e.Rs_[i]);
+        return Rigidf(Quat<float>(float(qd.w), float(qd.x), float(qd.y), float(qd.z)), Vec3<float>(float(e.Ps_[i].x), float(e.Ps_[i].y), float(e.Ps_[i].z)));
+      };
+      const Rigidf d_trans = compose(rinverse(bodyPose(W - 1)), bodyPose(W));
+      m.transform_tobe_mapped_ = compose(compose(compose(m.transform_tobe_mapped_, e.transform_lb_), d_trans), rinverse(e.transform_lb_));
+      m.transform_sum_ = toT(Tsum);
+    } else {
+      m.Process(corner, nc, surf, ns, toT(Tsum));
+    }
+    const Rigidf T_to_init = m.transform_aft_mapped_;
+    if (T_out) fromT(T_to_init, T_out);
+    const bool was_inited = e.inited_;
+    const bool ok = was_inited ? e.ProcessLaserOdom(T_to_init, reinterpret_cast<const float4 *>(surf), ns, false, stamp, rep)
+                               : e.ProcessLaserOdom(T_to_init, m.StackDevice(1), m.StackSize(1), true, stamp, rep);
+    if (!ok) return LIO_ERR_STATE;
+    if (!was_inited && e.inited_) m.imu_inited_ = true;  // SetInitFlag(true) (:545)
+    return LIO_OK;
+  });
+}
+int lio_est_get_stage(const lio_est *h, int *stage, int *cir_buf_count, int *extrinsic_stage, int *last_event, double *R_WI, double *g_vec) {
+  if (!h) return LIO_ERR_ARG;
+  const Estimator &e = *h->e;
+  if (stage) *stage = e.inited_ ? 1 : 0;
+  if (cir_buf_count) *cir_buf_count = e.cir_buf_count_;
+  if (extrinsic_stage) *extrinsic_stage = e.extrinsic_stage_;
+  if (last_event) *last_event = e.last_event_;
+  if (R_WI) for (int k = 0; k < 9; ++k) R_WI[k] = e.R_WI_.m[k];
+  if (g_vec) { g_vec[0] = e.g_vec_.x; g_vec[1] = e.g_vec_.y; g_vec[2] = e.g_vec_.z; }
+  return LIO_OK;
+}
 int lio_est_push_frame(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp) {
   if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  if (!h->e->inited_) return LIO_ERR_STATE;
   return guarded([&] { return h->e->PushFrame(toT(*T), surf, ns, corner, nc, stamp) ? LIO_OK : LIO_ERR_STATE; });
 }
 int lio_est_solve_optimization(lio_est *h, lio_solve_report *rep) {

@@ -8,6 +8,7 @@
 
 #include "../../include/lio_c.h"
 #include "cloud_kernels.h"
+#include "host_init.h"
 #include "host_solver.h"
 
 namespace lio {
@@ -25,6 +26,7 @@ struct EstConfig {
   int max_num_iterations = 10;
   double max_solver_time = 0.10;
   int extrinsic_stage = 2;
+  int init_window_factor = 3;
 };
 
 struct DeviceCloud {
@@ -76,7 +78,12 @@ class Estimator {
   void ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp);
   bool ProcessLaserOdom(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner, double stamp,
                         lio_solve_report *rep);
-  bool PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner, double stamp);
+  // surf_on_device: the surf cloud already lives in HBM (the scan-to-map stage's down-sampled stack before initialisation)
+  bool ProcessLaserOdom(const Rigidf &transform_in, const float4 *surf, size_t n_surf, bool surf_on_device, double stamp, lio_solve_report *rep);
+  bool PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner, double stamp,
+                 bool surf_on_device = false);
+  bool RunInitialization();
+  void SetStatesFromLaser();
   bool SolveOptimization(lio_solve_report *rep);
   void SlideWindow();
   void BuildLocalMap(lio_solve_report *rep);
@@ -100,6 +107,15 @@ class Estimator {
   Rigidf transform_lb_, laser_odom_transform_;
   bool inited_ = false, first_imu_ = false, init_local_map_ = false, convergence_flag_ = false;
   int cir_buf_count_ = 0;
+  // initialisation stage (Estimator.cc:430-618, 858-958)
+  std::vector<LaserFrame> all_laser_transforms_;
+  int n_state_ = 0;    // CircularBuffer size of Ps_/Rs_/Vs_/Bas_/Bgs_
+  int n_frames_ = 0;   // CircularBuffer size of pre_integrations_/all_laser_transforms_/the stacks
+  int laser_odom_recv_count_ = 0, extrinsic_stage_ = 2;
+  double initial_time_ = -1;
+  M3d R_WI_;
+  enum { EV_SKIPPED = 0, EV_FILLING = 1, EV_INIT_FAILED = 2, EV_INITIALISED = 3, EV_SOLVED = 4 };
+  int last_event_ = EV_SKIPPED;
   std::shared_ptr<MargPrior> last_marg_;
   std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
   std::shared_ptr<Preintegration> tmp_pre_integration_;
@@ -118,7 +134,8 @@ class Estimator {
   void VectorToParams(WindowParams &P) const;
   void ParamsToVector(const WindowParams &P);
   void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
-  void PushCloud(DeviceCloud &&c, size_t n);
+  void PushCloud(DeviceCloud &&c, size_t n, int n_before);
+  void PushState(int from);
 
   hipStream_t stream_ = nullptr;
   std::vector<DeviceCloud> stacks_;

@@ -47,6 +47,10 @@ struct Estimator::HostState {
   Rigidf transform_lb;
   bool inited, first_imu, init_local_map, convergence_flag;
   int cir_buf_count;
+  std::vector<LaserFrame> all_laser_transforms;
+  int n_state, n_frames, laser_odom_recv_count, extrinsic_stage, last_event;
+  double initial_time;
+  M3d R_WI;
   std::shared_ptr<MargPrior> last_marg;
   std::vector<std::shared_ptr<Preintegration>> pre_integrations;
   std::shared_ptr<Preintegration> tmp_pre_integration;
@@ -67,6 +71,11 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   size_surf_stack_.assign(W_ + 1, 0);
   slot_off_.assign(W_ + 1, 0); nslots_.assign(W_ + 1, 0);
   g_vec_ = V3d(0, 0, -cfg.pim.g_norm);
+  all_laser_transforms_.assign(W_ + 1, LaserFrame());
+  extrinsic_stage_ = cfg.extrinsic_stage;
+  R_WI_ = M3d::identity();
+  // ClearState (Estimator.cc:234-288): the running pre-integration exists before the first IMU sample
+  tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[0], Bgs_[0], cfg_.pim);
   d_odom_.reserve(1);
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));
 }
@@ -80,9 +89,23 @@ template <typename T> static void push_full(std::vector<T> &buf, T v) {
   for (size_t i = 0; i + 1 < buf.size(); ++i) buf[i] = std::move(buf[i + 1]);
   buf.back() = std::move(v);
 }
+// CircularBuffer::push (include/utils/CircularBuffer.h:164-172) with `size` elements held
+template <typename T> static void push_at(std::vector<T> &buf, int size, T v) {
+  if (size < int(buf.size())) buf[size] = std::move(v); else push_full(buf, std::move(v));
+}
+
+void Estimator::PushState(int from) {  // Ps_.push(Ps_[from]) ... (Estimator.cc:2646-2651)
+  const V3d p = Ps_[from], v = Vs_[from], ba = Bas_[from], bg = Bgs_[from];
+  const M3d r = Rs_[from];
+  push_at(Ps_, n_state_, p); push_at(Vs_, n_state_, v); push_at(Rs_, n_state_, r); push_at(Bas_, n_state_, ba); push_at(Bgs_, n_state_, bg);
+  if (n_state_ < W_ + 1) ++n_state_;
+}
 
 void Estimator::ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp) {
-  if (!first_imu_) { first_imu_ = true; acc_last_ = acc; gyr_last_ = gyr; }
+  if (!first_imu_) {
+    first_imu_ = true; acc_last_ = acc; gyr_last_ = gyr;
+    if (n_state_ == 0) n_state_ = 1;  // the zero state pushed at :347-354 (the buffers already hold it)
+  }
   if (cir_buf_count_ != 0) {
     if (tmp_pre_integration_) tmp_pre_integration_->push_back(dt, acc, gyr);
     const int j = cir_buf_count_;
@@ -118,6 +141,7 @@ void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, 
   }
   g_vec_ = V3d(g[0], g[1], g[2]);
   inited_ = true; first_imu_ = true; cir_buf_count_ = W_;
+  n_state_ = n_frames_ = W_ + 1;
 }
 
 static std::atomic<uint64_t> g_content_id{1};  // bumped whenever a window cloud is (re)written (estimators may live on several host threads)
@@ -178,29 +202,123 @@ Rigidf Estimator::RelTransform(int i, const Rigidd &T_pivot, const Rigidd &lb) c
   return toFloat(compose(rinverse(T_pivot), LidarPose(i, lb)));
 }
 
-void Estimator::PushCloud(DeviceCloud &&c, size_t n) {
-  push_full(stacks_, std::move(c));
-  push_full(size_surf_stack_, n);
+void Estimator::PushCloud(DeviceCloud &&c, size_t n, int n_before) {
+  push_at(stacks_, n_before, std::move(c));
+  push_at(size_surf_stack_, n_before, n);
 }
 
 bool Estimator::ProcessLaserOdom(const Rigidf &transform_in, const float *surf, size_t n_surf, const float *corner, size_t n_corner,
                                  double stamp, lio_solve_report *rep) {
-  if (!PushFrame(transform_in, surf, n_surf, corner, n_corner, stamp)) return false;
+  (void)corner; (void)n_corner;
+  return ProcessLaserOdom(transform_in, reinterpret_cast<const float4 *>(surf), n_surf, false, stamp, rep);
+}
+
+// Estimator.cc:430-774
+bool Estimator::ProcessLaserOdom(const Rigidf &transform_in, const float4 *surf, size_t n_surf, bool surf_on_device, double stamp,
+                                 lio_solve_report *rep) {
+  ++laser_odom_recv_count_;
+  if (!inited_ && laser_odom_recv_count_ % cfg_.init_window_factor != 0) { last_event_ = EV_SKIPPED; return true; }  // :436-439
+  if (!PushFrame(transform_in, reinterpret_cast<const float *>(surf), n_surf, nullptr, 0, stamp, surf_on_device)) return false;
+  if (!inited_) {
+    if (cir_buf_count_ == W_) {
+      bool init_result = false;
+      if (!cfg_.imu_factor) {
+        init_result = true;
+        SetStatesFromLaser();
+      } else {
+        if (extrinsic_stage_ == 2 && estimate_extrinsic_rotation(all_laser_transforms_, transform_lb_)) extrinsic_stage_ = 1;
+        if (extrinsic_stage_ != 2 && (stamp - initial_time_) > 0.1) {
+          init_result = RunInitialization();
+          initial_time_ = stamp;
+        }
+      }
+      if (init_result) {
+        inited_ = true;
+        SolveOptimization(rep);
+        SlideWindow();
+        last_event_ = EV_INITIALISED;
+      } else {
+        SlideWindow();
+        last_event_ = EV_INIT_FAILED;
+      }
+    } else {
+      SlideWindow();
+      ++cir_buf_count_;
+      last_event_ = EV_FILLING;
+    }
+    return true;
+  }
   bool ok = SolveOptimization(rep);
   SlideWindow();
+  last_event_ = EV_SOLVED;
   return ok;
 }
 
-bool Estimator::PushFrame(const Rigidf & /*transform_in*/, const float *surf, size_t n_surf, const float * /*corner*/, size_t /*n_corner*/,
-                          double /*stamp*/) {
-  if (!inited_) return false;
-  push_full(pre_integrations_, tmp_pre_integration_);
+void Estimator::SetStatesFromLaser() {  // :507-513, :892-906
+  for (int i = 0; i <= W_; ++i) {
+    const Rigidf bi = compose(all_laser_transforms_[i].transform, transform_lb_);
+    Ps_[i] = vcast<float, double>(bi.pos);
+    const Mat3<float> Rf = toRot(normalized(bi.rot));
+    for (int k = 0; k < 9; ++k) Rs_[i].m[k] = double(Rf.m[k]);
+  }
+}
+
+// Estimator.cc:858-958
+bool Estimator::RunInitialization() {
+  {
+    V3d sum_g;
+    for (int i = 0; i < W_; ++i) {
+      const Preintegration &pim = *all_laser_transforms_[i + 1].pim;
+      sum_g = sum_g + pim.dv / pim.sum_dt;
+    }
+    const V3d aver_g = sum_g * (1.0 / W_);
+    double var = 0;
+    for (int i = 0; i < W_; ++i) {
+      const Preintegration &pim = *all_laser_transforms_[i + 1].pim;
+      const V3d d = pim.dv / pim.sum_dt - aver_g;
+      var += dot(d, d);
+    }
+    var = std::sqrt(var / W_);
+    if (var < 0.25) return false;  // "IMU excitation not enough!"
+  }
+  V3d g_in_laser;
+  const bool init_result = imu_initialization(all_laser_transforms_, Vs_, Bgs_, g_in_laser, transform_lb_, R_WI_);
+  SetStatesFromLaser();
+  M3d R0 = transpose(R_WI_);
+  const double yaw = R2ypr(R0 * Rs_[0]).x;
+  R0 = ypr2R(V3d(-yaw, 0, 0)) * R0;
+  R_WI_ = transpose(R0);
+  g_vec_ = R0 * g_in_laser;
+  for (int i = 0; i <= cir_buf_count_; ++i) pre_integrations_[i]->repropagate(Bas_[i], Bgs_[i]);
+  for (int i = 0; i <= cir_buf_count_; ++i) { Ps_[i] = R0 * Ps_[i]; Rs_[i] = R0 * Rs_[i]; Vs_[i] = R0 * Vs_[i]; }
+  return init_result;
+}
+
+bool Estimator::PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float * /*corner*/, size_t /*n_corner*/,
+                          double stamp, bool surf_on_device) {
+  LaserFrame lf;
+  lf.time = stamp; lf.transform = transform_in; lf.pim = tmp_pre_integration_;
+  push_at(pre_integrations_, n_frames_, tmp_pre_integration_);
+  push_at(all_laser_transforms_, n_frames_, lf);
   tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[cir_buf_count_], Bgs_[cir_buf_count_], cfg_.pim);
+  const int n_before = n_frames_;
+  if (n_frames_ < W_ + 1) ++n_frames_;
+  DeviceCloud fresh = std::move(stacks_[n_before < W_ + 1 ? n_before : 0]);  // recycle the buffer of the slot being (re)written
+  if (!inited_) {  // :474-481: the stacks are the scan-to-map stage's down-sampled clouds, pushed as they are
+    fresh.buf.reserve(std::max<size_t>(n_surf, 1));
+    if (n_surf)
+      LIO_HIP(hipMemcpyAsync(fresh.buf.p, surf, n_surf * sizeof(float4), surf_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
+    fresh.n = n_surf;
+    fresh.id = ++g_content_id;
+    LIO_HIP(hipStreamSynchronize(stream_));  // the source may be reused by the caller right after the call
+    PushCloud(std::move(fresh), n_surf, n_before);
+    return true;
+  }
   // host -> HBM (the only PCIe traffic of the step besides the small state/moment exchanges)
   upload_.buf.reserve(std::max<size_t>(n_surf, 1));
-  if (n_surf) LIO_HIP(hipMemcpyAsync(upload_.buf.p, surf, n_surf * sizeof(float4), hipMemcpyHostToDevice, stream_));
+  if (n_surf)
+    LIO_HIP(hipMemcpyAsync(upload_.buf.p, surf, n_surf * sizeof(float4), surf_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
   upload_.n = n_surf;
-  DeviceCloud fresh = std::move(stacks_[0]);  // recycle the buffer that falls out of the window
   if (cfg_.enable_deskew || cfg_.cutoff_deskew) {
     if (!cfg_.cutoff_deskew) {
       if (imu_stamped_.empty()) return false;
@@ -231,7 +349,7 @@ bool Estimator::PushFrame(const Rigidf & /*transform_in*/, const float *surf, si
   }
   size_t nfresh = fresh.n;
   fresh.id = ++g_content_id;
-  PushCloud(std::move(fresh), nfresh);
+  PushCloud(std::move(fresh), nfresh, n_before);
   return true;
 }
 
@@ -582,13 +700,13 @@ void Estimator::SlideWindow() {
     LIO_HIP(hipStreamSynchronize(stream_));
     std::swap(stacks_[i], scratch_cloud_);
   }
-  push_full(Ps_, Ps_[cir_buf_count_]); push_full(Vs_, Vs_[cir_buf_count_]); push_full(Rs_, Rs_[cir_buf_count_]);
-  push_full(Bas_, Bas_[cir_buf_count_]); push_full(Bgs_, Bgs_[cir_buf_count_]);
+  PushState(cir_buf_count_);
 }
 
 void Estimator::Snapshot() {
   snap_.reset(new HostState{Ps_, Vs_, Bas_, Bgs_, Rs_, g_vec_, acc_last_, gyr_last_, transform_lb_, inited_, first_imu_, init_local_map_,
-                            convergence_flag_, cir_buf_count_, last_marg_, pre_integrations_,
+                            convergence_flag_, cir_buf_count_, all_laser_transforms_, n_state_, n_frames_, laser_odom_recv_count_,
+                            extrinsic_stage_, last_event_, initial_time_, R_WI_, last_marg_, pre_integrations_,
                             tmp_pre_integration_ ? std::make_shared<Preintegration>(*tmp_pre_integration_) : nullptr, size_surf_stack_,
                             imu_stamped_});
   snap_stacks_.resize(stacks_.size());
@@ -608,6 +726,8 @@ bool Estimator::Restore() {
   Ps_ = h.Ps; Vs_ = h.Vs; Bas_ = h.Bas; Bgs_ = h.Bgs; Rs_ = h.Rs; g_vec_ = h.g_vec; acc_last_ = h.acc_last; gyr_last_ = h.gyr_last;
   transform_lb_ = h.transform_lb; inited_ = h.inited; first_imu_ = h.first_imu; init_local_map_ = h.init_local_map;
   convergence_flag_ = h.convergence_flag; cir_buf_count_ = h.cir_buf_count; last_marg_ = h.last_marg; pre_integrations_ = h.pre_integrations;
+  all_laser_transforms_ = h.all_laser_transforms; n_state_ = h.n_state; n_frames_ = h.n_frames; laser_odom_recv_count_ = h.laser_odom_recv_count;
+  extrinsic_stage_ = h.extrinsic_stage; last_event_ = h.last_event; initial_time_ = h.initial_time; R_WI_ = h.R_WI;
   tmp_pre_integration_ = h.tmp_pre_integration ? std::make_shared<Preintegration>(*h.tmp_pre_integration) : nullptr;
   size_surf_stack_ = h.size_surf_stack; imu_stamped_ = h.imu_stamped;
   for (size_t i = 0; i < stacks_.size(); ++i) {

@@ -44,6 +44,10 @@ class MappingDev {
   size_t GetCloud(int which, float *out);
   size_t GetCube(int cls, uint32_t cube_idx, float *out);
   size_t GetScorePointCoeff(float *score, float *point, float *coeff);
+  // laser_cloud_{corner,surf}_stack_downsampled_ where they live (HBM), for the estimator's pre-initialisation pushes
+  const float4 *StackDevice(int cls) const { return cls_[cls].stack_ds.p; }
+  size_t StackSize(int cls) const { return cls_[cls].n_stack; }
+  void Sync() { LIO_HIP(hipStreamSynchronize(stream_)); }
 
   Rigid<float> transform_sum_, transform_tobe_mapped_, transform_bef_mapped_, transform_aft_mapped_;
   bool imu_inited_ = false;

@@ -84,6 +84,7 @@ class EstConfig(C.Structure):
         ("max_num_iterations", C.c_int),
         ("max_solver_time", C.c_double),
         ("extrinsic_stage", C.c_int),
+        ("init_window_factor", C.c_int),
     ]
 
 
@@ -177,6 +178,8 @@ _SIGS = {
         C.c_int,
         [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double, C.POINTER(SolveReport)],
     ),
+    "lio_est_process_compact": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t, C.c_double, C.POINTER(TransformF), C.POINTER(SolveReport)]),
+    "lio_est_get_stage": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4 + [c_double_p, c_double_p]),
     "lio_est_push_frame": (C.c_int, [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double]),
     "lio_est_solve_optimization": (C.c_int, [C.c_void_p, C.POINTER(SolveReport)]),
     "lio_est_slide_window": (C.c_int, [C.c_void_p]),
@@ -573,6 +576,22 @@ class Estimator:
             "lio_est_process_laser_odom",
         )
         return rep
+
+    def process_compact(self, compact, stamp):
+        """Estimator::ProcessCompactData -> (transform_to_init (q, p), SolveReport)."""
+        data = _f32(compact).reshape(-1, 4)
+        rep = SolveReport()
+        T = TransformF()
+        _chk(self.lib.dll.lio_est_process_compact(self.h, _fp(data), data.shape[0], stamp, C.byref(T), C.byref(rep)), "lio_est_process_compact")
+        return T.to_np(), rep
+
+    EVENTS = ("skipped", "filling", "init_failed", "initialised", "solved")
+
+    def stage(self):
+        st, cb, ex, ev = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        R, g = np.zeros((3, 3)), np.zeros(3)
+        _chk(self.lib.dll.lio_est_get_stage(self.h, C.byref(st), C.byref(cb), C.byref(ex), C.byref(ev), _dp(R), _dp(g)), "lio_est_get_stage")
+        return dict(inited=bool(st.value), cir_buf_count=cb.value, extrinsic_stage=ex.value, event=self.EVENTS[ev.value], R_WI=R, g_vec=g)
 
     def push_frame(self, T: TransformF, surf, corner, stamp):
         surf = _f32(surf).reshape(-1, 4)

@@ -21,7 +21,8 @@ struct lio_pim { IntegrationBase pim; lio_pim(const V3d &a, const V3d &g, const 
 struct lio_est {
   Estimator est;
   std::unique_ptr<Estimator> snap;
-  explicit lio_est(const EstimatorConfig &c) : est(c) {}
+  PointMapping map;  // the PointMapping base of the reference's Estimator (Estimator.h:110)
+  explicit lio_est(const EstimatorConfig &c, const MappingConfig &m) : est(c), map(m) {}
 };
 
 static V3d v3(const double *p) { return V3d(p[0], p[1], p[2]); }
@@ -375,7 +376,7 @@ void lio_est_default_config(lio_est_config *c) {
   c->opt_extrinsic = 0; c->imu_factor = 1; c->point_distance_factor = 0; c->prior_factor = 0; c->marginalization_factor = 1;
   c->enable_deskew = 1; c->cutoff_deskew = 0; c->keep_features = 0;
   c->acc_n = 0.1; c->gyr_n = 0.01; c->acc_w = 0.0002; c->gyr_w = 2.0e-5; c->g_norm = 9.805;
-  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2;
+  c->max_num_iterations = 10; c->max_solver_time = 0.10; c->extrinsic_stage = 2; c->init_window_factor = 3;
 }
 lio_est *lio_est_create(const lio_est_config *c) {
   if (!c || c->window_size < 1 || c->opt_window_size < 1 || c->opt_window_size > c->window_size) return nullptr;
@@ -389,7 +390,11 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.enable_deskew = c->enable_deskew; e.cutoff_deskew = c->cutoff_deskew; e.keep_features = c->keep_features;
   e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
   e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
-  return new (std::nothrow) lio_est(e);
+  e.init_window_factor = c->init_window_factor > 0 ? c->init_window_factor : 1;
+  MappingConfig m;  // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure the PointMapping base
+  m.corner_filter_size = c->corner_filter_size; m.surf_filter_size = c->surf_filter_size;
+  m.min_match_sq_dis = c->min_match_sq_dis; m.min_plane_dis = c->min_plane_dis;
+  return new (std::nothrow) lio_est(e, m);
 }
 void lio_est_destroy(lio_est *h) { delete h; }
 
@@ -418,8 +423,53 @@ int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float
   fillReport(R, rep);
   return LIO_OK;
 }
+// ProcessCompactData (Estimator.cc:776-856).  The post-initialisation map-database refresh (:703-708) only feeds the
+// published surround map and is not reproduced.
+int lio_est_process_compact(lio_est *h, const float *data, size_t n, double stamp, lio_transform_f *T_out, lio_solve_report *rep) {
+  if (!h || !data) return LIO_ERR_ARG;
+  lio_transform_f Tsum;
+  size_t nc = 0, ns = 0, nf = 0;
+  int rc = lio_compact_decode(data, n, &Tsum, &nc, &ns, &nf);
+  if (rc != LIO_OK) return rc;
+  Estimator &e = h->est;
+  PointMapping &m = h->map;
+  if (e.inited && !e.cfg.imu_factor) return LIO_ERR_STATE;  // LOAM-only operation after init is not part of this path
+  Cloud corner = toCloud(data + 4 * 3, nc), surf = toCloud(data + 4 * (3 + nc), ns);
+  if (e.inited) {  // :780-803: predict transform_tobe_mapped_ with the IMU-propagated body motion
+    const int W = e.W;
+    Transformf prev(Q<double>::FromMatrix(e.Rs[W - 1]).cast<float>(), e.Ps[W - 1].cast<float>());
+    Transformf curr(Q<double>::FromMatrix(e.Rs[W]).cast<float>(), e.Ps[W].cast<float>());
+    Transformf d_trans = prev.inverse() * curr;
+    m.transform_tobe_mapped = m.transform_tobe_mapped * e.transform_lb * d_trans * e.transform_lb.inverse();
+    m.transform_sum = toT(Tsum);
+  } else {
+    m.Process(corner, surf, toT(Tsum));
+  }
+  const Transformf T_to_init = m.transform_aft_mapped;
+  if (T_out) fromT(T_to_init, T_out);
+  SolveReport R;
+  const bool was_inited = e.inited;
+  bool ok = was_inited ? e.ProcessLaserOdom(T_to_init, surf, corner, stamp, &R)
+                       : e.ProcessLaserOdom(T_to_init, m.surf_stack_ds, m.corner_stack_ds, stamp, &R);
+  if (!ok) return LIO_ERR_STATE;
+  if (!was_inited && e.inited) m.imu_inited = true;  // SetInitFlag(true) (:545)
+  fillReport(R, rep);
+  return LIO_OK;
+}
+int lio_est_get_stage(const lio_est *h, int *stage, int *cir_buf_count, int *extrinsic_stage, int *last_event, double *R_WI, double *g_vec) {
+  if (!h) return LIO_ERR_ARG;
+  const Estimator &e = h->est;
+  if (stage) *stage = e.inited ? 1 : 0;
+  if (cir_buf_count) *cir_buf_count = e.cir_buf_count;
+  if (extrinsic_stage) *extrinsic_stage = e.extrinsic_stage;
+  if (last_event) *last_event = e.last_event;
+  if (R_WI) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R_WI[r * 3 + c] = e.R_WI(r, c);
+  if (g_vec) for (int d = 0; d < 3; ++d) g_vec[d] = e.g_vec[d];
+  return LIO_OK;
+}
 int lio_est_push_frame(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp) {
   if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;
+  if (!h->est.inited) return LIO_ERR_STATE;
   return h->est.PushFrame(toT(*T), toCloud(surf, ns), toCloud(corner, nc), stamp) ? LIO_OK : LIO_ERR_STATE;
 }
 int lio_est_solve_optimization(lio_est *h, lio_solve_report *rep) {
@@ -446,6 +496,7 @@ int lio_est_set_window(lio_est *h, int n, const double *Ps, const double *Rs, co
   }
   e.g_vec = v3(g);
   e.inited = true; e.first_imu = true; e.cir_buf_count = e.W;
+  e.n_state = e.n_frames = e.W + 1;
   return LIO_OK;
 }
 int lio_est_get_window(const lio_est *h, int n, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, lio_transform_f *Tlb) {

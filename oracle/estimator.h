@@ -13,6 +13,7 @@
 #include <array>
 
 #include "cloud.h"
+#include "imu_init.h"
 #include "solver.h"
 
 namespace orc {
@@ -29,7 +30,8 @@ struct EstimatorConfig {
   PimConfig pim;
   int max_num_iterations = 10;
   double max_solver_time = 0.10;
-  int extrinsic_stage = 2;
+  int extrinsic_stage = 2;        // estimate_extrinsic (Estimator.h:81)
+  int init_window_factor = 3;     // Estimator.h:80
 };
 
 struct SolveReport {
@@ -91,6 +93,15 @@ struct Estimator {
   int shard_rank = 0, shard_world = 1;
   int (*allreduce)(double *, int, void *) = nullptr;
   void *allreduce_user = nullptr;
+  // initialisation stage (Estimator.cc:430-618, 858-958)
+  std::vector<LaserTransform> all_laser_transforms;
+  int n_state = 0;   // CircularBuffer size of Ps_/Rs_/Vs_/Bas_/Bgs_
+  int n_frames = 0;  // CircularBuffer size of pre_integrations_/all_laser_transforms_/the stacks
+  int laser_odom_recv_count = 0, extrinsic_stage = 2;
+  double initial_time = -1;
+  M3d R_WI = M3d::Identity();
+  enum Event { EV_SKIPPED = 0, EV_FILLING = 1, EV_INIT_FAILED = 2, EV_INITIALISED = 3, EV_SOLVED = 4 };
+  int last_event = EV_SKIPPED;
 
   explicit Estimator(const EstimatorConfig &c) : cfg(c), W(c.window_size), Wo(c.opt_window_size) {
     transform_lb = c.transform_lb;
@@ -99,17 +110,34 @@ struct Estimator {
     pre_integrations.assign(W + 1, nullptr);
     surf_stack.assign(W + 1, Cloud()); corner_stack.assign(W + 1, Cloud());
     size_surf_stack.assign(W + 1, 0); size_corner_stack.assign(W + 1, 0);
+    all_laser_transforms.assign(W + 1, LaserTransform());
+    extrinsic_stage = c.extrinsic_stage;
     g_vec = V3d(0, 0, -c.pim.g_norm);
+    // ClearState (Estimator.cc:234-288): tmp_pre_integration_ exists from the start (acc/gyr zero until the first IMU)
+    tmp_pre_integration = std::make_shared<IntegrationBase>(acc_last, gyr_last, Bas[0], Bgs[0], cfg.pim);
   }
 
   template <typename T> static void pushFull(std::vector<T> &buf, const T &v) {  // CircularBuffer.h:164-172 on a full buffer
     for (size_t i = 0; i + 1 < buf.size(); ++i) buf[i] = buf[i + 1];
     buf.back() = v;
   }
+  // CircularBuffer::push with `size` elements held: append while there is room, else drop the oldest
+  template <typename T> static void pushAt(std::vector<T> &buf, int size, const T &v) {
+    if (size < int(buf.size())) buf[size] = v; else pushFull(buf, v);
+  }
+  void pushState(int from) {  // Ps_.push(Ps_[from]) ... (Estimator.cc:2646-2651)
+    const V3d p = Ps[from], v = Vs[from], ba = Bas[from], bg = Bgs[from];
+    const M3d r = Rs[from];
+    pushAt(Ps, n_state, p); pushAt(Vs, n_state, v); pushAt(Rs, n_state, r); pushAt(Bas, n_state, ba); pushAt(Bgs, n_state, bg);
+    if (n_state < W + 1) ++n_state;
+  }
 
   // ---- Estimator.cc:338-427 (steady state: buffers full, cir_buf_count == W)
   void ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp) {
-    if (!first_imu) { first_imu = true; acc_last = acc; gyr_last = gyr; }
+    if (!first_imu) {
+      first_imu = true; acc_last = acc; gyr_last = gyr;
+      if (n_state == 0) { Ps[0] = V3d(); Vs[0] = V3d(); Bas[0] = V3d(); Bgs[0] = V3d(); Rs[0] = M3d::Identity(); n_state = 1; }  // :342-354
+    }
     if (cir_buf_count != 0) {
       if (tmp_pre_integration) tmp_pre_integration->push_back(dt, acc, gyr);
       int j = cir_buf_count;
@@ -135,17 +163,97 @@ struct Estimator {
     tmp_pre_integration = std::make_shared<IntegrationBase>(acc_last, gyr_last, Bas[cir_buf_count], Bgs[cir_buf_count], cfg.pim);
   }
 
-  // ---- Estimator.cc:430-488 + INITED branch :620-774
+  // ---- Estimator.cc:430-774: frame push, initialisation stage, INITED branch
   bool ProcessLaserOdom(const Transformf &transform_in, Cloud surf_last, Cloud corner_last, double stamp, SolveReport *rep) {
+    ++laser_odom_recv_count;
+    if (!inited && laser_odom_recv_count % cfg.init_window_factor != 0) { last_event = EV_SKIPPED; return true; }  // :436-439
     if (!PushFrame(transform_in, std::move(surf_last), std::move(corner_last), stamp)) return false;
+    if (!inited) {
+      if (cir_buf_count == W) {
+        bool init_result = false;
+        if (!cfg.imu_factor) {
+          init_result = true;
+          SetStatesFromLaser();
+        } else {
+          if (extrinsic_stage == 2) {
+            if (EstimateExtrinsicRotation(all_laser_transforms, transform_lb)) extrinsic_stage = 1;
+          }
+          if (extrinsic_stage != 2 && (stamp - initial_time) > 0.1) {
+            init_result = RunInitialization();
+            initial_time = stamp;
+          }
+        }
+        if (init_result) {
+          inited = true;
+          SolveOptimization(rep);
+          SlideWindow();
+          last_event = EV_INITIALISED;
+        } else {
+          SlideWindow();
+          last_event = EV_INIT_FAILED;
+        }
+      } else {
+        SlideWindow();
+        ++cir_buf_count;
+        last_event = EV_FILLING;
+      }
+      return true;
+    }
     SolveOptimization(rep);
     SlideWindow();
+    last_event = EV_SOLVED;
     return true;
   }
-  bool PushFrame(const Transformf & /*transform_in*/, Cloud surf_last, Cloud corner_last, double /*stamp*/) {
-    if (!inited) return false;
-    pushFull(pre_integrations, tmp_pre_integration);
+  void SetStatesFromLaser() {  // :507-513, :892-906
+    for (int i = 0; i <= W; ++i) {
+      Transformf trans_bi = all_laser_transforms[i].transform * transform_lb;
+      Ps[i] = trans_bi.pos.cast<double>();
+      Rs[i] = trans_bi.rot.normalized().toRotationMatrix().cast<double>();
+    }
+  }
+  // ---- Estimator.cc:858-958
+  bool RunInitialization() {
+    {
+      V3d sum_g;  // the reference leaves it uninitialised (Estimator.cc:863); zero is the only meaningful reading
+      for (int i = 0; i < W; ++i) {
+        const IntegrationBase &pim = *all_laser_transforms[i + 1].pre_integration;
+        sum_g += pim.delta_v_ / pim.sum_dt_;
+      }
+      V3d aver_g = sum_g * (1.0 / W);
+      double var = 0;
+      for (int i = 0; i < W; ++i) {
+        const IntegrationBase &pim = *all_laser_transforms[i + 1].pre_integration;
+        V3d d = pim.delta_v_ / pim.sum_dt_ - aver_g;
+        var += d.dot(d);
+      }
+      var = std::sqrt(var / W);
+      if (var < 0.25) return false;  // "IMU excitation not enough!"
+    }
+    V3d g_vec_in_laser;
+    bool init_result = Initialization(all_laser_transforms, Vs, Bgs, g_vec_in_laser, transform_lb, R_WI);
+    SetStatesFromLaser();
+    M3d R0 = R_WI.transpose();
+    double yaw = R2ypr(R0 * Rs[0]).x;
+    R0 = ypr2R(V3d(-yaw, 0, 0)) * R0;
+    R_WI = R0.transpose();
+    g_vec = R0 * g_vec_in_laser;
+    for (int i = 0; i <= cir_buf_count; ++i) pre_integrations[i]->Repropagate(Bas[i], Bgs[i]);
+    for (int i = 0; i <= cir_buf_count; ++i) { Ps[i] = R0 * Ps[i]; Rs[i] = R0 * Rs[i]; Vs[i] = R0 * Vs[i]; }
+    return init_result;
+  }
+  bool PushFrame(const Transformf &transform_in, Cloud surf_last, Cloud corner_last, double stamp) {
+    LaserTransform lt;
+    lt.time = stamp; lt.transform = transform_in; lt.pre_integration = tmp_pre_integration;
+    pushAt(pre_integrations, n_frames, tmp_pre_integration);
+    pushAt(all_laser_transforms, n_frames, lt);
     tmp_pre_integration = std::make_shared<IntegrationBase>(acc_last, gyr_last, Bas[cir_buf_count], Bgs[cir_buf_count], cfg.pim);
+    const int n_before = n_frames;
+    if (n_frames < W + 1) ++n_frames;
+    if (!inited) {  // :474-481: the stacks are PointMapping's down-sampled clouds (sensor frame)
+      pushAt(size_surf_stack, n_before, surf_last.size()); pushAt(surf_stack, n_before, surf_last);
+      pushAt(size_corner_stack, n_before, corner_last.size()); pushAt(corner_stack, n_before, corner_last);
+      return true;
+    }
     if (cfg.enable_deskew || cfg.cutoff_deskew) {
       if (!cfg.cutoff_deskew) {
         if (imu_stamped.empty()) return false;
@@ -521,8 +629,7 @@ struct Estimator {
       filtered.insert(filtered.end(), surf_stack[i].begin(), surf_stack[i].end());
       surf_stack[i] = filtered;
     }
-    pushFull(Ps, Ps[cir_buf_count]); pushFull(Vs, Vs[cir_buf_count]); pushFull(Rs, Rs[cir_buf_count]);
-    pushFull(Bas, Bas[cir_buf_count]); pushFull(Bgs, Bgs[cir_buf_count]);
+    pushState(cir_buf_count);
   }
 };
 

@@ -1,0 +1,46 @@
+"""Drives lio_amd.replay.Replay from t = 0 over synthetic motion-distorted sweeps + analytic IMU (shared by the CPU
+end-to-end test of the oracle and the GPU parity test)."""
+import numpy as np
+
+from lio_amd import capi, pipeline, replay, synth
+
+
+def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kind="indoor", imu_rate=200.0, sweeps=None):
+    if sweeps is None:
+        sweeps = synth.make_sweeps(kind, n_sweeps)
+    sw, pose_fn, lid = sweeps
+    traj = synth.Trajectory()   # the indoor trajectory of make_sweeps
+    cfg = pipeline.config_indoor(lib, W, Wo)
+    cfg.init_window_factor = init_window_factor
+    cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
+    cfg.extrinsic_stage = 1
+    rp = replay.Replay(lib, cfg, lid, odom_io=odom_io)
+    h = 1.0 / imu_rate
+    t_imu = 1.0
+    for k, s in enumerate(sw[:n_sweeps]):
+        t_end = 1.0 + 0.1 * (k + 1)
+        while t_imu <= t_end + h + 1e-9:
+            rp.add_imu(t_imu, traj.accel(t_imu), traj.gyro(t_imu))
+            t_imu += h
+        n0 = len(rp.log)
+        rp.add_sweep(s, t_end)
+        for e in rp.log[n0:]:
+            e["window"] = rp.est.get_window() if e["inited"] else None
+    return rp, traj
+
+
+def window_vs_truth(rp, traj, W):
+    """Relative body motion between consecutive window slots against the analytic trajectory.  After SlideWindow slot i
+    holds the frame of the (W - i)-th last processed message and slot W duplicates slot W-1 (Estimator.cc:2646-2651)."""
+    w = rp.est.get_window()
+    stamps = [e["stamp"] for e in rp.log if e["event"] != "skipped"][-W:]
+    errs = []
+    for i in range(W - 1):
+        Ri, pi = traj.rot(stamps[i]), traj.pos(stamps[i])
+        Rj, pj = traj.rot(stamps[i + 1]), traj.pos(stamps[i + 1])
+        g = Ri.T @ (pj - pi)
+        e = w["Rs"][i].T @ (w["Ps"][i + 1] - w["Ps"][i])
+        Re, Rg = w["Rs"][i].T @ w["Rs"][i + 1], Ri.T @ Rj
+        ang = np.degrees(np.arccos(np.clip((np.trace(Re.T @ Rg) - 1) / 2, -1, 1)))
+        errs.append((np.linalg.norm(e - g), ang))
+    return np.array(errs), w

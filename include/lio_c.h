@@ -121,6 +121,13 @@ typedef struct {
   float min_match_sq_dis;     /* 1.0  PointMapping.h:245 */
   float min_plane_dis;        /* 0.2  :246               */
   int num_max_iterations;     /* 10   :171               */
+  /* MapBuilder (src/map_builder/MapBuilder.cc, include/map_builder/MapBuilder.h:52-70; §8f 4): the same stage driven
+   * as MapBuilder::ProcessMap — first call adopts transform_sum, Transform4DAssociateToMap (:55-75) keeps only the yaw
+   * of the increment, OptimizeMap (:624-1014) solves with the rotation Jacobian in the map frame weighted
+   * diag(5e-3, 5e-3, 1) and a left-multiplied update, every skip_count-th call optimises, the map is always updated. */
+  int map_builder;            /* 0 = PointMapping::Process, 1 = MapBuilder::ProcessMap */
+  int enable_4d;              /* 1    MapBuilder.h:66 */
+  int skip_count;             /* 2    MapBuilder.h:67 */
 } lio_map_config;
 
 typedef struct lio_map lio_map;

@@ -166,11 +166,13 @@ int lio_imu_initialization(size_t n, const lio_transform_f *T, lio_pim *const *p
 void lio_map_default_config(lio_map_config *c) {
   if (!c) return;
   c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f; c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f; c->num_max_iterations = 10;
+  c->map_builder = 0; c->enable_4d = 1; c->skip_count = 2;
 }
 lio_map *lio_map_create(const lio_map_config *c) {
   lio_map_config cfg;
   if (c) cfg = *c; else lio_map_default_config(&cfg);
   if (!(cfg.corner_filter_size > 0) || !(cfg.surf_filter_size > 0) || cfg.num_max_iterations < 1) return nullptr;
+  if (cfg.map_builder && cfg.skip_count < 1) return nullptr;
   lio_map *h = new (std::nothrow) lio_map;
   if (!h) return nullptr;
   int rc = guarded([&] { h->m.reset(new MappingDev(cfg)); return LIO_OK; });
@@ -445,6 +447,7 @@ lio_est *lio_est_create(const lio_est_config *c) {
   // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
   h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;
+  h->map_cfg.map_builder = 0; h->map_cfg.enable_4d = 1; h->map_cfg.skip_count = 2;
   int rc = guarded([&] { h->e.reset(new Estimator(e)); return LIO_OK; });
   if (rc != LIO_OK) { delete h; return nullptr; }
   return h;

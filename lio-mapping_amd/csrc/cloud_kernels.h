@@ -79,7 +79,7 @@ struct FeatArgs {
   float min_match_sq_dis, min_plane_dis;
   // scan-to-map variant (PointMapping.cc:519-619): coefficient sign follows pd2, coef.w = s*pd2, the FOV apex
   // point_on_z_axis_ is the one fixed before the iterations (:803-806), abs_coeff is written when requested
-  int mapping_mode;
+  int mapping_mode;   // 0 estimator, 1 PointMapping, 2 MapBuilder::OptimizeMap (no sign flip)
   float fixed_pz[3];
 };
 // transforms: device array of 8 floats per entry (qx,qy,qz,qw,px,py,pz,pad).  skip_flag: optional device int;
@@ -107,12 +107,14 @@ struct OdomState {
 };
 // rows of mat_A / mat_B (Estimator.cc:1272-1301) over slots [0,nslots) of the newest frame, reduced to
 // per-block partials (28 doubles each).  Point of slot s = stack[s % M].
-// b_from_coef != 0: mat_B = -coef.w (the distance stored at feature time, PointMapping.cc:640,650).
+// b_from_coef != 0: mat_B = -coef.w (the distance stored at feature time, PointMapping.cc:640,650); 2 additionally maps the
+// rotation columns into the map frame with the MapBuilder weights (MapBuilder.cc:903-914).
 void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
                       double *partials, int nblocks, hipStream_t s, int b_from_coef = 0);
 // reduce + 6x6 solve + degeneracy mask + transform update + convergence test (Estimator.cc:1303-1357)
 // min_rows > 0: a round with fewer selected rows leaves the transform untouched (`continue`, PointMapping.cc:623-626).
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0);
+// left_update != 0: rot = DeltaQ(x) * rot (MapBuilder.cc:978-979) instead of rot * DeltaQ(x).
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0, int left_update = 0);
 int odom_rows_blocks(int nslots);
 
 }  // namespace lio

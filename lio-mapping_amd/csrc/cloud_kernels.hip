@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
         c = make_float4(s * pa, s * pb, s * pc, s * pd);
         sc = s;
         if (MAPPING) {  // PointMapping.cc:572-592
-          const bool pos = pd2 > 0;
+          const bool pos = pd2 > 0 || a.mapping_mode == 2;  // MapBuilder::OptimizeMap keeps the fitted sign (MapBuilder.cc:786-789)
           c = pos ? make_float4(s * pa, s * pb, s * pc, s * pd2) : make_float4(-s * pa, -s * pb, -s * pc, -s * pd2);
           if (abs_coef) abs_coef[slot] = pos ? make_float4(pa, pb, pc, pd) : make_float4(-pa, -pb, -pc, -pd);
         }
@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
   Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
   Vec3<float> t(st->T[4], st->T[5], st->T[6]);
   Mat3<float> Rm = toRot(q);
+  Mat3<float> Rinv = toRot(qinverse(q));
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0;
@@ -634,6 +635,12 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
     a[0] = -(w.x * RS(0, 0) + w.y * RS(1, 0) + w.z * RS(2, 0));
     a[1] = -(w.x * RS(0, 1) + w.y * RS(1, 1) + w.z * RS(2, 1));
     a[2] = -(w.x * RS(0, 2) + w.y * RS(1, 2) + w.z * RS(2, 2));
+    if (b_from_coef == 2) {  // MapBuilder::OptimizeMap (MapBuilder.cc:903-914): (-w^T R skew(p)) R^-1 diag(5e-3, 5e-3, 1)
+      const float t0 = a[0], t1 = a[1], t2 = a[2];
+      a[0] = (t0 * Rinv(0, 0) + t1 * Rinv(1, 0) + t2 * Rinv(2, 0)) * 5e-3f;
+      a[1] = (t0 * Rinv(0, 1) + t1 * Rinv(1, 1) + t2 * Rinv(2, 1)) * 5e-3f;
+      a[2] = (t0 * Rinv(0, 2) + t1 * Rinv(1, 2) + t2 * Rinv(2, 2)) * 1.f;
+    }
     a[3] = w.x; a[4] = w.y; a[5] = w.z;
     Vec3<float> rp = rotate(q, p);
     float d2 = w.x * (rp.x + t.x) + w.y * (rp.y + t.y) + w.z * (rp.z + t.z) + c.w;
@@ -670,7 +677,7 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
   LIO_HIP(hipGetLastError());
 }
 
-__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows) {
+__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows, int left_update) {
   if (st->converged) return;
   // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
   __shared__ double ssum[28];
@@ -705,7 +712,7 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   Quat<float> R0 = normalized(q);
   Vec3<float> t(st->T[4], st->T[5], st->T[6]);
   t.x += X[3]; t.y += X[4]; t.z += X[5];
-  q = q * deltaQ(Vec3<float>(X[0], X[1], X[2]));
+  q = left_update ? deltaQ(Vec3<float>(X[0], X[1], X[2])) * q : q * deltaQ(Vec3<float>(X[0], X[1], X[2]));
   if (!isfinite(t.x)) t.x = 0;
   if (!isfinite(t.y)) t.y = 0;
   if (!isfinite(t.z)) t.z = 0;
@@ -721,8 +728,8 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   if (double(delta_r) < 0.05 && double(delta_t) < 0.05) st->converged = 1;
 }
 
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows) {
-  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter, min_rows);
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update) {
+  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter, min_rows, left_update);
   LIO_HIP(hipGetLastError());
 }
 

@@ -90,7 +90,7 @@ class MappingDev {
   void LayoutFinish(ClassMap &m, const MapValidSet &vs);   // after a stream sync
   void UpdateLaunch(ClassMap &m, const float4 *new_sensor_pts, size_t n_new, const MapValidSet &vs, const Rigid<float> &T, float leaf);
   void UpdateFinish(ClassMap &m);
-  void Optimize();
+  void Optimize(bool four_dof);
 
   lio_map_config cfg_;
   hipStream_t stream_ = nullptr;
@@ -106,6 +106,8 @@ class MappingDev {
   bool score_ready_ = false;
   size_t n_from_map_[2] = {0, 0};  // sizes of laser_cloud_{corner,surf}_from_map_ of the last Process
   bool from_map_in_u_ = false;      // the map update moved them into the work list
+  bool system_init_ = false;        // MapBuilder.h:65
+  int odom_count_ = 0;              // MapBuilder.h:69
 };
 
 }  // namespace lio

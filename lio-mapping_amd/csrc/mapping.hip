@@ -229,6 +229,15 @@ __global__ void k_stack_roundtrip(const float4 *__restrict__ in, int n, Quat<flo
   out[i] = make_float4(r.x, r.y, r.z, p.w);
 }
 
+// math_utils.h:186-203 (degrees)
+inline Vec3<double> r2ypr_deg(const Mat3<double> &R) {
+  const double y = std::atan2(R(1, 0), R(0, 0));
+  const double p = std::atan2(-R(2, 0), R(0, 0) * std::cos(y) + R(1, 0) * std::sin(y));
+  const double r = std::atan2(R(0, 2) * std::sin(y) - R(1, 2) * std::cos(y), -R(0, 1) * std::sin(y) + R(1, 1) * std::cos(y));
+  return Vec3<double>(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+inline Mat3<double> to_double(const Mat3<float> &m) { Mat3<double> r; for (int k = 0; k < 9; ++k) r.m[k] = double(m.m[k]); return r; }
+
 template <typename T> T *pinned_alloc() {
   T *p = nullptr;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(T), hipHostMallocDefault));
@@ -411,10 +420,27 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   transform_sum_ = sum;
   score_ready_ = false;
   iterations_ = 0; num_selected_ = 0; degenerate_ = false;
-  if (!imu_inited_) {  // TransformAssociateToMap (:755-758)
+  const bool builder = cfg_.map_builder != 0;
+  if (builder && !system_init_) {  // MapBuilder::ProcessMap (MapBuilder.cc:227-232)
+    system_init_ = true;
+    transform_bef_mapped_ = transform_tobe_mapped_ = transform_aft_mapped_ = transform_sum_;
+  }
+  if (builder || !imu_inited_) {  // TransformAssociateToMap (:755-758) / Transform4DAssociateToMap (MapBuilder.cc:55-75)
     const Rigid<float> sumT = fromAffine(linearOf(transform_sum_), transform_sum_.pos);
     const Rigid<float> incre = compose(rinverse(transform_bef_mapped_), sumT);
-    transform_tobe_mapped_ = compose(transform_tobe_mapped_, incre);
+    const Rigid<float> full = compose(transform_tobe_mapped_, incre);
+    if (builder && cfg_.enable_4d) {
+      // keep the odometry's roll/pitch, take only the yaw of the increment
+      const Vec3<double> r0 = r2ypr_deg(to_double(toRot(normalized(full.rot))));
+      const Vec3<double> r00 = r2ypr_deg(to_double(toRot(normalized(transform_sum_.rot))));
+      const float y = float(double(float(r0.x - r00.x)) / 180.0 * M_PI);
+      Mat3<float> Rz = Mat3<float>::identity();
+      Rz(0, 0) = std::cos(y); Rz(0, 1) = -std::sin(y); Rz(1, 0) = std::sin(y); Rz(1, 1) = std::cos(y);
+      transform_tobe_mapped_.pos = full.pos;
+      transform_tobe_mapped_.rot = fromRot(Rz * toRot(normalized(transform_sum_.rot)));
+    } else {
+      transform_tobe_mapped_ = full;
+    }
   }
   const Rigid<float> T0 = transform_tobe_mapped_;
   // stack clouds go up while the host does the cube bookkeeping
@@ -482,9 +508,18 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
     m.n_stack = cnt[c] ? m.vox.run(m.stack_raw.p, cnt[c], leaf[c], m.stack_ds, s) : 0;
   }
 
-  Optimize();
+  if (builder) {  // MapBuilder.cc:527-558: optimise every skip_count-th call, always update the map
+    if (odom_count_ % cfg_.skip_count == 0) Optimize(cfg_.enable_4d != 0);
+    else {
+      n_from_map_[0] = cls_[0].n_valid; n_from_map_[1] = cls_[1].n_valid; from_map_in_u_ = false;
+      transform_bef_mapped_ = transform_sum_; transform_aft_mapped_ = transform_tobe_mapped_;
+    }
+    ++odom_count_;
+  } else {
+    Optimize(false);
+  }
 
-  if (!imu_inited_) {
+  if (builder || !imu_inited_) {
     for (int c = 0; c < 2; ++c) UpdateLaunch(cls_[c], cls_[c].stack_ds.p, cls_[c].n_stack, vs, transform_tobe_mapped_, leaf[c]);
     LIO_HIP(hipStreamSynchronize(s));
     for (int c = 0; c < 2; ++c) UpdateFinish(cls_[c]);
@@ -492,7 +527,7 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   }
 }
 
-void MappingDev::Optimize() {
+void MappingDev::Optimize(bool four_dof) {
   hipStream_t s = stream_;
   ClassMap &mc = cls_[0], &ms = cls_[1];
   n_from_map_[0] = mc.n_valid; n_from_map_[1] = ms.n_valid;
@@ -531,7 +566,7 @@ void MappingDev::Optimize() {
   fa.nframes = 1; fa.max_M = Ms;
   fa.fr[0].stack = stack_all_.p + Mc; fa.fr[0].M = Ms; fa.fr[0].slot_off = Mc; fa.fr[0].tf_index = 0;
   fa.min_match_sq_dis = cfg_.min_match_sq_dis; fa.min_plane_dis = cfg_.min_plane_dis;
-  fa.mapping_mode = 1;
+  fa.mapping_mode = four_dof ? 2 : 1;
   for (int d = 0; d < 3; ++d) fa.fixed_pz[d] = pz_[d];
   const int max_it = cfg_.num_max_iterations;
   int iter = 0;
@@ -546,8 +581,8 @@ void MappingDev::Optimize() {
       launch_line_features(stack_all_.p, Mc, 0, d_T, pz_, cfg_.min_match_sq_dis, mc.grid.sorted(), mc.grid.cells(), mc.grid.desc(), f_valid_.p,
                            f_coef_.p, d_conv, s);
       launch_features(fa, d_T, ms.grid.sorted(), ms.grid.cells(), ms.grid.desc(), f_valid_.p, f_coef_.p, nullptr, d_conv, s, f_abs_.p);
-      launch_odom_rows(stack_all_.p, M, M, f_valid_.p, f_coef_.p, d_state_.p, d_partials_.p, nb, s, 1);
-      launch_odom_update(d_partials_.p, nb, d_state_.p, iter, s, 50);
+      launch_odom_rows(stack_all_.p, M, M, f_valid_.p, f_coef_.p, d_state_.p, d_partials_.p, nb, s, four_dof ? 2 : 1);
+      launch_odom_update(d_partials_.p, nb, d_state_.p, iter, s, 50, four_dof ? 1 : 0);
     }
     LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(OdomState), hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));
@@ -562,7 +597,7 @@ void MappingDev::Optimize() {
   transform_bef_mapped_ = transform_sum_;            // TransformUpdate (:760-763)
   transform_aft_mapped_ = transform_tobe_mapped_;
   n_score_slots_ = size_t(M);
-  score_ready_ = true;
+  score_ready_ = !four_dof;  // OptimizeMap keeps no score list
 }
 
 // ------------------------------------------------------------------------------------------------

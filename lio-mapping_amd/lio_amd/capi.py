@@ -56,6 +56,9 @@ class MapConfig(C.Structure):
         ("min_match_sq_dis", C.c_float),
         ("min_plane_dis", C.c_float),
         ("num_max_iterations", C.c_int),
+        ("map_builder", C.c_int),
+        ("enable_4d", C.c_int),
+        ("skip_count", C.c_int),
     ]
 
 

@@ -160,14 +160,17 @@ int lio_imu_initialization(size_t n, const lio_transform_f *T, lio_pim *const *p
 void lio_map_default_config(lio_map_config *c) {
   if (!c) return;
   c->corner_filter_size = 0.2f; c->surf_filter_size = 0.4f; c->min_match_sq_dis = 1.0f; c->min_plane_dis = 0.2f; c->num_max_iterations = 10;
+  c->map_builder = 0; c->enable_4d = 1; c->skip_count = 2;
 }
 lio_map *lio_map_create(const lio_map_config *c) {
   lio_map_config cfg;
   if (c) cfg = *c; else lio_map_default_config(&cfg);
   if (!(cfg.corner_filter_size > 0) || !(cfg.surf_filter_size > 0) || cfg.num_max_iterations < 1) return nullptr;
+  if (cfg.map_builder && cfg.skip_count < 1) return nullptr;
   MappingConfig mc;
   mc.corner_filter_size = cfg.corner_filter_size; mc.surf_filter_size = cfg.surf_filter_size;
   mc.min_match_sq_dis = cfg.min_match_sq_dis; mc.min_plane_dis = cfg.min_plane_dis; mc.num_max_iterations = cfg.num_max_iterations;
+  mc.map_builder = cfg.map_builder != 0; mc.enable_4d = cfg.enable_4d != 0; mc.skip_count = cfg.skip_count;
   return new (std::nothrow) lio_map(mc);
 }
 void lio_map_destroy(lio_map *h) { delete h; }

@@ -25,6 +25,10 @@ struct MappingConfig {
   float corner_filter_size = 0.2f, surf_filter_size = 0.4f;  // PointMapping.cc:122-123; Estimator.cc:189-191
   float min_match_sq_dis = 1.0f, min_plane_dis = 0.2f;       // PointMapping.h:245-246
   int num_max_iterations = 10;                               // PointMapping.h:171
+  // MapBuilder (src/map_builder/MapBuilder.cc): the same stage driven as ProcessMap / OptimizeMap
+  bool map_builder = false;
+  bool enable_4d = true;   // MapBuilder.h:66
+  int skip_count = 2;      // MapBuilder.h:67
 };
 
 struct ScorePointCoeff { float score; P4 point; P4 coeff; };
@@ -43,6 +47,8 @@ struct PointMapping {
   float matP[36];
   int last_iterations = 0, last_selected = 0;
   bool last_degenerate = false;
+  bool system_init = false;  // MapBuilder.h:65
+  int odom_count = 0;        // MapBuilder.h:69
 
   explicit PointMapping(const MappingConfig &c = MappingConfig()) : cfg(c) {
     corner_array.resize(size_t(L) * Wd * H);
@@ -84,6 +90,20 @@ struct PointMapping {
     transform_tobe_mapped = transform_tobe_mapped * incre;
   }
   void TransformUpdate() { transform_bef_mapped = transform_sum; transform_aft_mapped = transform_tobe_mapped; }
+  // MapBuilder::Transform4DAssociateToMap (MapBuilder.cc:55-75): position from the 6-DoF increment, rotation = the
+  // odometry's with only the yaw of the increment applied
+  void Transform4DAssociateToMap() {
+    Transformf sumT = Transformf::FromAffine(transform_sum.linear(), transform_sum.pos);
+    Transformf incre = transform_bef_mapped.inverse() * sumT;
+    Transformf full = transform_tobe_mapped * incre;
+    V3<double> r0 = R2ypr(full.rot.normalized().toRotationMatrix().cast<double>());
+    V3<double> r00 = R2ypr(transform_sum.rot.normalized().toRotationMatrix().cast<double>());
+    float y = float(double(float(r0.x - r00.x)) / 180.0 * M_PI);  // ypr2R<Vector3f>: Rz only, pitch = roll = 0
+    M3<float> Rz = M3<float>::Identity();
+    Rz(0, 0) = std::cos(y); Rz(0, 1) = -std::sin(y); Rz(1, 0) = std::sin(y); Rz(1, 1) = std::cos(y);
+    transform_tobe_mapped.pos = full.pos;
+    transform_tobe_mapped.rot = Q<float>::FromMatrix(Rz * transform_sum.rot.normalized().toRotationMatrix());
+  }
 
   static int CubeCoord(float v, int c) {
     int r = int((double(v) + 25.0) / 50.0) + c;
@@ -114,7 +134,12 @@ struct PointMapping {
 
   void Process(const Cloud &corner_last, const Cloud &surf_last, const Transformf &sum) {
     transform_sum = sum;
-    if (!imu_inited) TransformAssociateToMap();
+    if (cfg.map_builder) {  // MapBuilder::ProcessMap (MapBuilder.cc:220-247)
+      if (!system_init) { system_init = true; transform_bef_mapped = transform_tobe_mapped = transform_aft_mapped = transform_sum; }
+      if (cfg.enable_4d) Transform4DAssociateToMap(); else TransformAssociateToMap();
+    } else if (!imu_inited) {
+      TransformAssociateToMap();
+    }
     Cloud corner_stack, surf_stack;
     for (const P4 &p : corner_last) corner_stack.push_back(ToMap(p, transform_tobe_mapped));
     for (const P4 &p : surf_last) surf_stack.push_back(ToMap(p, transform_tobe_mapped));
@@ -158,12 +183,21 @@ struct PointMapping {
     VoxelGrid(corner_stack, cfg.corner_filter_size, corner_stack_ds);
     VoxelGrid(surf_stack, cfg.surf_filter_size, surf_stack_ds);
 
-    OptimizeTransformTobeMapped();
+    if (cfg.map_builder) {  // MapBuilder.cc:527-558
+      if (odom_count % cfg.skip_count == 0) OptimizeTransformTobeMapped(cfg.enable_4d);
+      else { last_iterations = 0; last_selected = 0; TransformUpdate(); }
+      ++odom_count;
+      UpdateMapDatabase(corner_stack_ds, surf_stack_ds, valid_idx, transform_tobe_mapped, cen);
+      return;
+    }
+    OptimizeTransformTobeMapped(false);
 
     if (!imu_inited) UpdateMapDatabase(corner_stack_ds, surf_stack_ds, valid_idx, transform_tobe_mapped, cen);
   }
 
-  void OptimizeTransformTobeMapped() {
+  // four_dof = MapBuilder::OptimizeMap (MapBuilder.cc:624-1014): no sign flip of the plane coefficients, rotation
+  // Jacobian in the map frame weighted diag(5e-3, 5e-3, 1), left-multiplied rotation update, no score list
+  void OptimizeTransformTobeMapped(bool four_dof) {
     last_iterations = 0; last_selected = 0; last_degenerate = false;
     if (corner_from_map.size() <= 10 || surf_from_map.size() <= 100) return;
     KdTree tree_corner, tree_surf;
@@ -234,7 +268,7 @@ struct PointMapping {
         float pd2 = pa * ps.x + pb * ps.y + pc * ps.z + pd;
         float s = 1 - 0.9f * std::fabs(pd2) / std::sqrt(std::sqrt(ps.x * ps.x + ps.y * ps.y + ps.z * ps.z));
         P4 coeff, abs_coeff;
-        if (pd2 > 0) { coeff = P4{s * pa, s * pb, s * pc, s * pd2}; abs_coeff = P4{pa, pb, pc, pd}; }
+        if (pd2 > 0 || four_dof) { coeff = P4{s * pa, s * pb, s * pc, s * pd2}; abs_coeff = P4{pa, pb, pc, pd}; }
         else { coeff = P4{-s * pa, -s * pb, -s * pc, -s * pd2}; abs_coeff = P4{-pa, -pb, -pc, -pd}; }
         if (s > 0.1 && InFov(tpos, ps)) {
           sel.push_back({po, coeff});
@@ -247,6 +281,7 @@ struct PointMapping {
       float AtA[36] = {0}, AtB[6] = {0};
       Q<float> R0 = T.rot.normalized();
       M3<float> Rm = T.rot.toRotationMatrix();
+      M3<float> Rinv = T.rot.inverse().toRotationMatrix();
       for (const Sel &f : sel) {
         V3<float> p(f.ori.x, f.ori.y, f.ori.z), w(f.coeff.x, f.coeff.y, f.coeff.z);
         M3<float> RS = Rm * Skew(p);
@@ -254,6 +289,12 @@ struct PointMapping {
         a[0] = -(w.x * RS(0, 0) + w.y * RS(1, 0) + w.z * RS(2, 0));
         a[1] = -(w.x * RS(0, 1) + w.y * RS(1, 1) + w.z * RS(2, 1));
         a[2] = -(w.x * RS(0, 2) + w.y * RS(1, 2) + w.z * RS(2, 2));
+        if (four_dof) {  // (-w^T R skew(p)) R^-1 diag(5e-3, 5e-3, 1)
+          const float t0 = a[0], t1 = a[1], t2 = a[2];
+          a[0] = (t0 * Rinv(0, 0) + t1 * Rinv(1, 0) + t2 * Rinv(2, 0)) * 5e-3f;
+          a[1] = (t0 * Rinv(0, 1) + t1 * Rinv(1, 1) + t2 * Rinv(2, 1)) * 5e-3f;
+          a[2] = (t0 * Rinv(0, 2) + t1 * Rinv(1, 2) + t2 * Rinv(2, 2)) * 1.f;
+        }
         a[3] = w.x; a[4] = w.y; a[5] = w.z;
         float bb = -f.coeff.i;
         for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) AtA[r * 6 + c] += a[r] * a[c]; AtB[r] += a[r] * bb; }
@@ -277,7 +318,7 @@ struct PointMapping {
       }
       last_degenerate = is_degenerate;
       T.pos.x += X[3]; T.pos.y += X[4]; T.pos.z += X[5];
-      T.rot = T.rot * DeltaQ(V3<float>(X[0], X[1], X[2]));
+      T.rot = four_dof ? DeltaQ(V3<float>(X[0], X[1], X[2])) * T.rot : T.rot * DeltaQ(V3<float>(X[0], X[1], X[2]));
       if (!std::isfinite(T.pos.x)) T.pos.x = 0;
       if (!std::isfinite(T.pos.y)) T.pos.y = 0;
       if (!std::isfinite(T.pos.z)) T.pos.z = 0;
@@ -287,7 +328,7 @@ struct PointMapping {
       if (delta_r < 0.05 && delta_t < 0.05) break;
     }
     TransformUpdate();
-    if (spc.size() >= 50) {
+    if (!four_dof && spc.size() >= 50) {
       for (size_t i = 0; i < spc.size(); ++i) {
         const P4 &c = spc_coeff[i];
         spc[i].score = std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z);

@@ -173,3 +173,19 @@ def test_mapping_after_imu_init_is_frozen(hip, oracle):
     _assert_pose_close(rh["T_aft"], ro["T_aft"])
     for i, c in before.items():
         np.testing.assert_array_equal(mh.cube(1, i), c)
+
+
+@pytest.mark.parametrize("enable_4d", [1, 0])
+def test_map_builder_matches_oracle(hip, oracle, enable_4d):
+    """MapBuilder::ProcessMap / OptimizeMap (MapBuilder.cc:55-75, 220-558, 624-1014) through lio_map_config.map_builder."""
+    frames = drifting_inputs(oracle, "indoor", 5)
+    kw = dict(map_builder=1, enable_4d=enable_4d, skip_count=2)
+    mh, mo = capi.PointMapping(hip, **kw), capi.PointMapping(oracle, **kw)
+    for k, (corner, surf, T_sum, _) in enumerate(frames):
+        rh, ro = mh.process(corner, surf, T_sum), mo.process(corner, surf, T_sum)
+        assert rh["iterations"] == ro["iterations"], (k, rh, ro)
+        _assert_pose_close(rh["T_aft"], ro["T_aft"])
+        _assert_pose_close(mh.transform_tobe_mapped(), mo.transform_tobe_mapped())
+    _, vo = mo.cube_state()
+    assert _compare_cubes(mh, mo, vo, atol=5e-4, strict=False) > 5000
+    assert len(mh.score_point_coeff()[0]) == len(mo.score_point_coeff()[0])

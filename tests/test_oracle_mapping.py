@@ -71,3 +71,24 @@ def test_oracle_window_shift_drops_far_cubes(oracle):
     mp.process(pts[:100], pts, ([0, 0, 0, 1], [1000, 0, 0]))
     cen, _ = mp.cube_state()
     assert cen[0] < 0 and sum(len(mp.cube(1, i)) for i in range(21 * 21 * 11)) == len(mp.cube(1, 17 + 21 * 10 + 441 * 5))
+
+
+def test_oracle_map_builder_4dof(oracle):
+    """MapBuilder::ProcessMap (MapBuilder.cc:220-558): the first call adopts the odometry pose, every skip_count-th
+    call optimises (4-DoF weighting), the others only commit the prediction; the map grows on every call."""
+    frames = drifting_inputs(oracle, "indoor", 5)
+    mb = capi.PointMapping(oracle, map_builder=1, enable_4d=1, skip_count=2)
+    its = []
+    for k, (corner, surf, T_sum, p_gt) in enumerate(frames):
+        r = mb.process(corner, surf, T_sum)
+        its.append(r["iterations"])
+        if k == 0:
+            np.testing.assert_allclose(mb.transform_tobe_mapped()[1], T_sum[1], atol=1e-6)
+            np.testing.assert_allclose(np.abs(mb.transform_tobe_mapped()[0]), np.abs(np.asarray(T_sum[0], np.float32)), atol=1e-6)
+    # call 0: map empty -> OptimizeMap returns early; calls 2, 4 optimise; calls 1, 3 are skipped
+    assert its[0] == 0 and its[1] == 0 and its[3] == 0 and its[2] > 0 and its[4] > 0
+    q, p = mb.transform_tobe_mapped()
+    assert np.linalg.norm(p[:2] - frames[-1][3][:2]) < 0.08      # pulled back from 0.23 m of injected drift
+    assert len(mb.score_point_coeff()[0]) == 0                   # OptimizeMap keeps no score list
+    _, valid = mb.cube_state()
+    assert sum(len(mb.cube(1, i)) for i in valid) > 10000

@@ -372,7 +372,9 @@ int lio_est_set_factor_sharding(lio_est *, int rank, int world, lio_allreduce_fn
 /* Per-kernel timing with HIP events on the estimator's own stream (bench.py's roofline block).
  * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
  * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat".
- * get returns the number of launches accumulated since timing was enabled (0 for an unknown name or
+ * `on` = 0 stops, 1 times every launch, N > 1 times every N-th launch of each kind (an event pair between two
+ * kernels costs a few microseconds of dispatch overlap; sampling keeps the timed region honest).
+ * get returns the number of launches TIMED since timing was enabled (0 for an unknown name or
  * for the oracle), total_ms their summed duration, algorithmic_bytes the summed SURVEY.md §8d bytes. */
 int lio_est_enable_kernel_timing(lio_est *, int on);
 int lio_est_get_kernel_timing(lio_est *, const char *name, double *total_ms, double *algorithmic_bytes);

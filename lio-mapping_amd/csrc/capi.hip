@@ -622,6 +622,7 @@ int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_f
 int lio_est_enable_kernel_timing(lio_est *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->e->timers_.on = on != 0;
+  h->e->timers_.sample = on > 1 ? on : 1;
   h->e->timers_.reset();
   return LIO_OK;
 }

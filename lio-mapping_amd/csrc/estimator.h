@@ -41,6 +41,8 @@ struct StampedPose { double time; Rigidf T; };
 enum { KT_FEATURES = 0, KT_ODOM_FEATURES, KT_ODOM_ROWS, KT_ODOM_UPDATE, KT_MOMENTS, KT_VOXEL, KT_KNN_GRID, KT_CONCAT, KT_COUNT };
 struct KernelTimers {
   bool on = false;
+  int sample = 1;            // record every sample-th launch of each kind (events between kernels cost ~10 % when all are timed)
+  int seen[KT_COUNT] = {0};
   struct Rec { hipEvent_t a, b; int id; double bytes; };
   struct Acc { int n = 0; double ms = 0, bytes = 0; };
   std::vector<Rec> pending;
@@ -52,6 +54,7 @@ struct KernelTimers {
   }
   int begin(int id, double bytes, hipStream_t s) {
     if (!on) return -1;
+    if ((seen[id]++ % sample) != 0) return -1;
     Rec r{get(), get(), id, bytes};
     LIO_HIP(hipEventRecord(r.a, s));
     pending.push_back(r);
@@ -66,7 +69,7 @@ struct KernelTimers {
     }
     pending.clear();
   }
-  void reset() { for (Acc &a : acc) a = Acc(); }
+  void reset() { for (Acc &a : acc) a = Acc(); for (int &v : seen) v = 0; }
   ~KernelTimers() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); for (Rec &r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
 };
 

@@ -696,7 +696,8 @@ class Estimator:
         _chk(self.lib.dll.lio_est_set_factor_sharding(self.h, rank, world, fn, None), "lio_est_set_factor_sharding")
 
     def enable_kernel_timing(self, on=True):
-        _chk(self.lib.dll.lio_est_enable_kernel_timing(self.h, 1 if on else 0), "lio_est_enable_kernel_timing")
+        """on: False/0 stop, True/1 every launch, N > 1 every N-th launch of each kernel kind."""
+        _chk(self.lib.dll.lio_est_enable_kernel_timing(self.h, int(on)), "lio_est_enable_kernel_timing")
 
     def kernel_timing(self, name):
         t, b = np.zeros(1), np.zeros(1)

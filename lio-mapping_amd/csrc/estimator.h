@@ -137,6 +137,8 @@ class Estimator {
   void VectorToParams(WindowParams &P) const;
   void ParamsToVector(const WindowParams &P);
   void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
+  void LidarLaunch(const WindowParams &P);             // asynchronous part: frame transforms + moments kernels
+  void LidarWait(std::vector<FrameMoments> &m);        // stream sync (+ all-reduce when sharded) + unpack
   void PushCloud(DeviceCloud &&c, size_t n, int n_before);
   void PushState(int from);
 

@@ -544,8 +544,13 @@ void Estimator::ParamsToVector(const WindowParams &P) {  // DoubleToVector with 
 }
 
 void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
+  LidarLaunch(P);
+  LidarWait(m);
+}
+
+void Estimator::LidarLaunch(const WindowParams &P) {
   const double t_dbg0 = now_ms();
-  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
+  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; } } dbg_acc{this, t_dbg0};
   const int pivot = W_ - Wo_;
   MomentArgs ma{};
   int max_slots = 0;
@@ -571,11 +576,16 @@ void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
   // command, only the kernel-completion wait (kernel end = system-scope release, so the host sees the data).
   launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, h_moment_out_, stream_);
   timers_.end(th, stream_);
+}
+
+void Estimator::LidarWait(std::vector<FrameMoments> &m) {
+  const double t_dbg0 = now_ms();
+  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
   LIO_HIP(hipStreamSynchronize(stream_));
   timers_.resolve();
   if (shard_world_ > 1 && allreduce_) {
     // per-shard moments -> whole-window moments (SUM over ranks; RCCL over xGMI on a GPU node, 10 KB per call)
-    if (allreduce_(h_moment_out_, ma.nframes * LIO_MOMENT_OUT, allreduce_user_) != 0) throw std::runtime_error("factor-sharding all-reduce failed");
+    if (allreduce_(h_moment_out_, Wo_ * LIO_MOMENT_OUT, allreduce_user_) != 0) throw std::runtime_error("factor-sharding all-reduce failed");
   }
   for (int i = 1; i <= Wo_; ++i) {
     const double *src = h_moment_out_ + size_t(i - 1) * LIO_MOMENT_OUT;
@@ -613,6 +623,8 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     sys.prior_pos = t.pos; sys.prior_rot = t.rot;
   }
   sys.lidar_eval = [this](const WindowParams &Pq, std::vector<FrameMoments> &m) { LidarEval(Pq, m); };
+  sys.lidar_launch = [this](const WindowParams &Pq) { LidarLaunch(Pq); };
+  sys.lidar_wait = [this](std::vector<FrameMoments> &m) { LidarWait(m); };
   R.ms_prepare = now_ms() - t_prep0;
   // Group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984).
   // The reference evaluates the three groups, then Ceres linearises again at the same point; here ONE device
@@ -657,7 +669,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
       if (pi && pi->sum_dt < 10.0) msys.pim[0] = pi;
     }
     msys.prior = last_marg_;
-    msys.lidar_eval = sys.lidar_eval;
+    msys.lidar_eval = sys.lidar_eval; msys.lidar_launch = sys.lidar_launch; msys.lidar_wait = sys.lidar_wait;
     last_marg_ = marginalize(msys, M);
     R.marginalized = 1;
     R.ms_marg = now_ms() - tm0;

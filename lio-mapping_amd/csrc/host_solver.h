@@ -116,6 +116,9 @@ class WindowSystem {
   V3d prior_pos; Qd prior_rot;
   // lidar evaluation on the device: fills m[1..Wo] for the given parameters
   std::function<void(const WindowParams &, std::vector<FrameMoments> &)> lidar_eval;
+  // split form: launch the device pass first, overlap the host-side prior / IMU factors with it, then collect
+  std::function<void(const WindowParams &)> lidar_launch;
+  std::function<void(std::vector<FrameMoments> &)> lidar_wait;
 
   struct Costs { double marg = 0, pim = 0, ppp = 0, prior = 0; double total() const { return marg + pim + ppp + prior; } };
 
@@ -165,6 +168,9 @@ class WindowSystem {
   // which: bit0 prior, bit1 imu, bit2 lidar, bit3 extrinsic prior.  H/g may be null (cost only).
   Costs evaluate(const WindowParams &P, const Layout &lay, int which, bool imu_only_first, DMat *H, std::vector<double> *g) {
     Costs c;
+    const bool lidar_on = (which & 4) && use_lidar;
+    const bool split = lidar_on && lidar_launch && lidar_wait;
+    if (split) lidar_launch(P);  // asynchronous: the kernels run while the host evaluates the prior and the IMU factors
     if (H) { *H = DMat(lay.dim, lay.dim); g->assign(lay.dim, 0.0); }
     if ((which & 1) && prior) {
       const MargPrior &pr = *prior;
@@ -227,9 +233,9 @@ class WindowSystem {
         }
       }
     }
-    if ((which & 4) && use_lidar && lidar_eval) {
+    if (lidar_on && (split || lidar_eval)) {
       std::vector<FrameMoments> m(Wo + 1);
-      lidar_eval(P, m);
+      if (split) lidar_wait(m); else lidar_eval(P, m);
       for (int i = 1; i <= Wo; ++i) {
         c.ppp += m[i].cost;
         if (!H || m[i].count == 0) continue;

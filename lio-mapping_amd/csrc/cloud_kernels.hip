@@ -681,12 +681,7 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   if (st->converged) return;
   // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
   __shared__ double ssum[28];
-  if (threadIdx.x < 28) {
-    double v = 0;
-    for (int b = 0; b < nblocks; ++b) v += partials[b * 28 + threadIdx.x];
-    ssum[threadIdx.x] = v;
-  }
-  __syncthreads();
+  reduce_partials28(partials, nblocks, ssum);
   if (threadIdx.x != 0) return;
   double sum[28];
   for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
@@ -729,7 +724,7 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
 }
 
 void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update) {
-  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(64), 0, s, partials, nblocks, st, iter, min_rows, left_update);
+  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(256), 0, s, partials, nblocks, st, iter, min_rows, left_update);
   LIO_HIP(hipGetLastError());
 }
 

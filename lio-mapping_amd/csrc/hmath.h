@@ -200,64 +200,100 @@ template <typename T> LIO_HD Rigid<T> compose(const Rigid<T> &a, const Rigid<T> 
 // A row-major m x n (destroyed), b (destroyed), x out.
 template <typename T, int M, int N>
 LIO_HD void qr_solve(T *A, T *b, T *x, T eps) {
+  // Every loop has compile-time bounds and every array index is a loop counter, so after unrolling the whole
+  // factorisation lives in registers on the device (a run-time pivot index would send A to scratch memory and
+  // cost ~20 us per 6x6 solve); the pivot column is moved with predicated swaps instead of indexed ones.
   int perm[N];
+#pragma unroll
   for (int j = 0; j < N; ++j) perm[j] = j;
   T maxnorm0 = 0;
+#pragma unroll
   for (int j = 0; j < N; ++j) {
     T s = 0;
+#pragma unroll
     for (int i = 0; i < M; ++i) s += A[i * N + j] * A[i * N + j];
     maxnorm0 = s > maxnorm0 ? s : maxnorm0;
   }
   const T thresh = eps * eps * maxnorm0 * T(M);
   int rank = 0;
-  const int steps = M < N ? M : N;
+  bool live = true;
+  constexpr int steps = M < N ? M : N;
+#pragma unroll
   for (int k = 0; k < steps; ++k) {
-    int piv = k;
-    T best = -1;
-    for (int j = k; j < N; ++j) {
-      T s = 0;
-      for (int i = k; i < M; ++i) s += A[i * N + j] * A[i * N + j];
-      if (s > best) { best = s; piv = j; }
-    }
-    if (!(best > thresh)) break;
-    if (piv != k) {
-      for (int i = 0; i < M; ++i) { T tmp = A[i * N + piv]; A[i * N + piv] = A[i * N + k]; A[i * N + k] = tmp; }
-      int tp = perm[piv]; perm[piv] = perm[k]; perm[k] = tp;
-    }
-    T alpha = A[k * N + k];
-    T sigma = 0;
-    for (int i = k + 1; i < M; ++i) sigma += A[i * N + k] * A[i * N + k];
-    T normx = sqrt(alpha * alpha + sigma);
-    if (normx == T(0)) break;
-    T beta = (alpha >= T(0)) ? -normx : normx;
-    T v0 = alpha - beta;
-    T vtv = v0 * v0 + sigma;
-    if (vtv > T(0)) {
-      for (int j = k + 1; j < N; ++j) {
-        T s = v0 * A[k * N + j];
-        for (int i = k + 1; i < M; ++i) s += A[i * N + k] * A[i * N + j];
-        T f = T(2) * s / vtv;
-        A[k * N + j] -= f * v0;
-        for (int i = k + 1; i < M; ++i) A[i * N + j] -= f * A[i * N + k];
+    if (live) {
+      int piv = k;
+      T best = -1;
+#pragma unroll
+      for (int j = k; j < N; ++j) {
+        T s = 0;
+#pragma unroll
+        for (int i = k; i < M; ++i) s += A[i * N + j] * A[i * N + j];
+        if (s > best) { best = s; piv = j; }
       }
-      T s = v0 * b[k];
-      for (int i = k + 1; i < M; ++i) s += A[i * N + k] * b[i];
-      T f = T(2) * s / vtv;
-      b[k] -= f * v0;
-      for (int i = k + 1; i < M; ++i) b[i] -= f * A[i * N + k];
+      if (!(best > thresh)) live = false;
+      if (live) {
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) {
+          if (j == piv) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) { T tmp = A[i * N + j]; A[i * N + j] = A[i * N + k]; A[i * N + k] = tmp; }
+            int tp = perm[j]; perm[j] = perm[k]; perm[k] = tp;
+          }
+        }
+        T alpha = A[k * N + k];
+        T sigma = 0;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) sigma += A[i * N + k] * A[i * N + k];
+        T normx = sqrt(alpha * alpha + sigma);
+        if (normx == T(0)) live = false;
+        if (live) {
+          T beta = (alpha >= T(0)) ? -normx : normx;
+          T v0 = alpha - beta;
+          T vtv = v0 * v0 + sigma;
+          if (vtv > T(0)) {
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) {
+              T s = v0 * A[k * N + j];
+#pragma unroll
+              for (int i = k + 1; i < M; ++i) s += A[i * N + k] * A[i * N + j];
+              T f = T(2) * s / vtv;
+              A[k * N + j] -= f * v0;
+#pragma unroll
+              for (int i = k + 1; i < M; ++i) A[i * N + j] -= f * A[i * N + k];
+            }
+            T s = v0 * b[k];
+#pragma unroll
+            for (int i = k + 1; i < M; ++i) s += A[i * N + k] * b[i];
+            T f = T(2) * s / vtv;
+            b[k] -= f * v0;
+#pragma unroll
+            for (int i = k + 1; i < M; ++i) b[i] -= f * A[i * N + k];
+          }
+          A[k * N + k] = beta;
+#pragma unroll
+          for (int i = k + 1; i < M; ++i) A[i * N + k] = T(0);
+          ++rank;
+        }
+      }
     }
-    A[k * N + k] = beta;
-    for (int i = k + 1; i < M; ++i) A[i * N + k] = T(0);
-    ++rank;
   }
   T y[N];
+#pragma unroll
   for (int j = 0; j < N; ++j) y[j] = T(0);
-  for (int i = rank - 1; i >= 0; --i) {
-    T s = b[i];
-    for (int j = i + 1; j < rank; ++j) s -= A[i * N + j] * y[j];
-    y[i] = s / A[i * N + i];
+#pragma unroll
+  for (int i = steps - 1; i >= 0; --i) {
+    if (i < rank) {
+      T s = b[i];
+#pragma unroll
+      for (int j = i + 1; j < steps; ++j) if (j < rank) s -= A[i * N + j] * y[j];
+      y[i] = s / A[i * N + i];
+    }
   }
-  for (int j = 0; j < N; ++j) x[perm[j]] = y[j];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) if (perm[j] == t) x[t] = y[j];
+  }
 }
 
 // Number of eigenvalues of the symmetric NxN matrix A that are < tau, by Sylvester's law of inertia: the count of

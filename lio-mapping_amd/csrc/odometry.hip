@@ -226,12 +226,7 @@ __global__ void __launch_bounds__(ODO_ROW_THREADS) k_odo_rows(OdoArgs a, const O
 __global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
   if (st->converged) return;
   __shared__ double ssum[28];
-  if (threadIdx.x < 28) {
-    double v = 0;
-    for (int b = 0; b < nblocks; ++b) v += partials[b * 28 + threadIdx.x];
-    ssum[threadIdx.x] = v;
-  }
-  __syncthreads();
+  reduce_partials28(partials, nblocks, ssum);
   if (threadIdx.x != 0) return;
   double sum[28];
   for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
@@ -345,7 +340,7 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
         }
         if (nq > 0 && iter % 5 == 0) hipLaunchKernelGGL(k_odo_corr, dim3(nq), dim3(64), 0, s, a, d_state_.p, idx_.p);
         hipLaunchKernelGGL(k_odo_rows, dim3(nb), dim3(ODO_ROW_THREADS), 0, s, a, d_state_.p, idx_.p, iter, d_partials_.p);
-        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(64), 0, s, d_partials_.p, nb, d_state_.p, iter);
+        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(256), 0, s, d_partials_.p, nb, d_state_.p, iter);
       }
       LIO_HIP(hipGetLastError());
     }

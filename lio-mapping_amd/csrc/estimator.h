@@ -142,7 +142,8 @@ class Estimator {
   void PushCloud(DeviceCloud &&c, size_t n, int n_before);
   void PushState(int from);
 
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::vector<DeviceCloud> stacks_;
   std::vector<size_t> size_surf_stack_;
   std::vector<StampedPose> imu_stamped_;

@@ -63,6 +63,9 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipGetDeviceCount(&ndev));
   if (ndev <= 0) throw DeviceError("no HIP device: the product has no CPU path");
   LIO_HIP(hipStreamCreate(&stream_));
+  LIO_HIP(hipStreamCreate(&stream2_));
+  LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   transform_lb_ = cfg.transform_lb;
   Ps_.assign(W_ + 1, V3d()); Vs_ = Bas_ = Bgs_ = Ps_;
   Rs_.assign(W_ + 1, M3d::identity());
@@ -82,6 +85,9 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
 
 Estimator::~Estimator() {
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -437,9 +443,17 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     double mq = 0;
     for (int k = 0; k < fa.nframes; ++k) mq += fa.fr[k].M;
     // 16(M+N) + 8*K*M + 32*M bytes per call, K = 5
-    th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, stream_);
-    launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, stream_);
-    timers_.end(th, stream_);
+    // The Wo-1 older frames do not depend on the newest frame's Gauss-Newton rounds: their batched launch goes to a second
+    // stream and fills the CUs the serial rows/update kernels of that loop leave idle; joined before the solve.
+    hipStream_t sf = cfg_.imu_factor ? stream2_ : stream_;
+    if (sf != stream_) {
+      LIO_HIP(hipEventRecord(ev_fork_, stream_));
+      LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
+    }
+    th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, sf);
+    launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, sf);
+    timers_.end(th, sf);
+    if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
   }
   laser_odom_iters_ = 0;
   if (cfg_.imu_factor) {
@@ -483,6 +497,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
       }
     }
     LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+    LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     LIO_HIP(hipStreamSynchronize(stream_));
     timers_.resolve();
     laser_odom_iters_ = st.iters;

@@ -448,7 +448,7 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
   }
 }
 
-template <bool MAPPING>
+template <bool MAPPING, int LPQ>
 __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                  const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
                                                  float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
   if (skip_flag && *skip_flag) return;
   const FeatFrame fr = a.fr[blockIdx.y];
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
+  const int i = gt / LPQ, sub = gt % LPQ;
   const bool active = i < fr.M;
   const float *tp = transforms + 8 * fr.tf_index;
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
   Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
   Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   float bd[5]; int bi[5], bj[5];
-  knn_scan_group<5, FEAT_LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+  knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
   if (!active || sub != 0) return;
   const int slot = fr.slot_off + i;
   uint8_t ok = 0;
@@ -599,11 +599,17 @@ void launch_line_features(const float4 *stack, int M, int slot_off, const float 
 void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
                      uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef) {
   if (a.nframes <= 0 || a.max_M <= 0) return;
-  const dim3 grid(cdiv((long long)a.max_M * FEAT_LPQ, 128), a.nframes);
+  // lanes per query: 8 when the launch is small (latency-bound: shorter per-lane candidate walks), 4 when it already fills
+  // the GPU several times over (throughput-bound: fewer shuffle-merge rounds per query)
+  const bool big = (long long)a.max_M * a.nframes >= 50000;
+  const dim3 grid(cdiv((long long)a.max_M * (big ? 4 : 8), 128), a.nframes);
   if (a.mapping_mode)
-    hipLaunchKernelGGL(k_features<true>, grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
+    hipLaunchKernelGGL((k_features<true, 8>), dim3(cdiv((long long)a.max_M * 8, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g,
+                       valid, coef, score, skip_flag, abs_coef);
+  else if (big)
+    hipLaunchKernelGGL((k_features<false, 4>), grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
   else
-    hipLaunchKernelGGL(k_features<false>, grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
+    hipLaunchKernelGGL((k_features<false, 8>), grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
   LIO_HIP(hipGetLastError());
 }
 

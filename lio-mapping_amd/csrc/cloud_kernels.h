@@ -97,6 +97,12 @@ void launch_line_features(const float4 *stack, int M, int slot_off, const float 
 void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
                 int32_t *idx, float *sqd, hipStream_t s);
 
+// Both branches of one scan-to-map round in a single launch (surf: FeatArgs with one frame, mapping_mode 1 or 2; corner: the
+// first Mc points of the concatenated stack, slots [0, Mc)).
+void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, const float *transform, const float4 *corner_map,
+                      const int2 *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int2 *surf_cells,
+                      const GridDesc &surf_grid, uint8_t *valid, float4 *coef, float4 *abs_coef, const int *skip_flag, hipStream_t s);
+
 struct OdomState {
   float T[8];        // qx,qy,qz,qw,px,py,pz,pad : local_transform of the newest frame
   int converged;

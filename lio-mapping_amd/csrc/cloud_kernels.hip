@@ -449,13 +449,12 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
 }
 
 template <bool MAPPING, int LPQ>
-__global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
-                                                 const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
-                                                 float4 *__restrict__ abs_coef) {
-  if (skip_flag && *skip_flag) return;
-  const FeatFrame fr = a.fr[blockIdx.y];
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void features_body(const FeatArgs &a, int frame, int block_x, const float *__restrict__ transforms,
+                                              const float4 *__restrict__ map, const int2 *__restrict__ cells, const GridDesc &g,
+                                              uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
+                                              float4 *__restrict__ abs_coef) {
+  const FeatFrame fr = a.fr[frame];
+  const int gt = block_x * blockDim.x + threadIdx.x;
   const int i = gt / LPQ, sub = gt % LPQ;
   const bool active = i < fr.M;
   const float *tp = transforms + 8 * fr.tf_index;
@@ -518,14 +517,22 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
   if (score) score[slot] = sc;
 }
 
+template <bool MAPPING, int LPQ>
+__global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                                 const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
+                                                 float4 *__restrict__ abs_coef) {
+  if (skip_flag && *skip_flag) return;
+  features_body<MAPPING, LPQ>(a, blockIdx.y, blockIdx.x, transforms, map, cells, g, valid, coef, score, abs_coef);
+}
+
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
 // direction = eigenvector of the largest eigenvalue (accepted when it dominates 3x the middle one).
-__global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
-                                                      Vec3<float> pz, float min_match_sq_dis, const float4 *__restrict__ map,
-                                                      const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                      float4 *__restrict__ coef, const int *__restrict__ skip_flag) {
-  if (skip_flag && *skip_flag) return;
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void line_features_body(int block_x, const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
+                                                   const Vec3<float> &pz, float min_match_sq_dis, const float4 *__restrict__ map,
+                                                   const int2 *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
+                                                   float4 *__restrict__ coef) {
+  const int gt = block_x * blockDim.x + threadIdx.x;
   const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
   const bool active = i < M;
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict_
     a00 /= 5.0f; a10 /= 5.0f; a20 /= 5.0f; a11 /= 5.0f; a21 /= 5.0f; a22 /= 5.0f;
     const float A1[9] = {a00, a10, a20, a10, a11, a21, a20, a21, a22};
     float D1[3]; double v[3];
-    sym_eig3_top(A1, D1, v);
+    sym_eig3_top_closed(A1, D1, v);
     if (D1[2] > 3 * D1[1]) {
       const float x0 = sel.x, y0 = sel.y, z0 = sel.z;
       const float v0 = float(v[0]), v1 = float(v[1]), v2 = float(v[2]);  // mat_V1 is a float matrix
@@ -585,6 +592,45 @@ __global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict_
     }
   }
   valid[slot] = ok; coef[slot] = c;
+}
+
+__global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
+                                                      Vec3<float> pz, float min_match_sq_dis, const float4 *__restrict__ map,
+                                                      const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                      float4 *__restrict__ coef, const int *__restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  line_features_body(blockIdx.x, stack, M, slot_off, tp, pz, min_match_sq_dis, map, cells, g, valid, coef);
+}
+
+// One round of the scan-to-map search in ONE launch: blockIdx.y = 0 runs the corner (line) branch against the corner map,
+// blockIdx.y = 1 the surf (plane) branch against the surf map.  No cross-stream events, one dispatch.
+struct MapRoundArgs {
+  const float4 *corner_stack; int Mc;
+  const float4 *corner_map; const int2 *corner_cells; GridDesc corner_grid;
+  const float4 *surf_map; const int2 *surf_cells; GridDesc surf_grid;
+  int blocks_corner, blocks_surf;
+};
+__global__ void __launch_bounds__(128) k_map_round(FeatArgs a, MapRoundArgs m, const float *__restrict__ tp, uint8_t *__restrict__ valid,
+                                                  float4 *__restrict__ coef, float4 *__restrict__ abs_coef, const int *__restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  if (blockIdx.y == 0) {
+    if (int(blockIdx.x) >= m.blocks_corner) return;
+    line_features_body(blockIdx.x, m.corner_stack, m.Mc, 0, tp, Vec3<float>(a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]), a.min_match_sq_dis,
+                       m.corner_map, m.corner_cells, m.corner_grid, valid, coef);
+  } else {
+    if (int(blockIdx.x) >= m.blocks_surf) return;
+    features_body<true, 8>(a, 0, blockIdx.x, tp, m.surf_map, m.surf_cells, m.surf_grid, valid, coef, nullptr, abs_coef);
+  }
+}
+
+void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, const float *transform, const float4 *corner_map,
+                      const int2 *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int2 *surf_cells,
+                      const GridDesc &surf_grid, uint8_t *valid, float4 *coef, float4 *abs_coef, const int *skip_flag, hipStream_t s) {
+  MapRoundArgs m{corner_stack, Mc, corner_map, corner_cells, corner_grid, surf_map, surf_cells, surf_grid, cdiv((long long)Mc * FEAT_LPQ, 128),
+                 cdiv((long long)surf.max_M * 8, 128)};
+  const int bx = std::max(1, std::max(m.blocks_corner, m.blocks_surf));
+  hipLaunchKernelGGL(k_map_round, dim3(bx, 2), dim3(128), 0, s, surf, m, transform, valid, coef, abs_coef, skip_flag);
+  LIO_HIP(hipGetLastError());
 }
 
 void launch_line_features(const float4 *stack, int M, int slot_off, const float *transform, const float fixed_pz[3], float min_match_sq_dis,

@@ -2,6 +2,9 @@
 // kernel or a rocPRIM primitive; the host only does the 6-DoF bookkeeping (transform algebra, cube-window shift,
 // FOV test of <= 125 cubes).
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -17,6 +20,8 @@
 namespace lio {
 
 namespace {
+
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 __host__ __device__ inline uint32_t pack_cube(int ai, int aj, int ak) {
   return (uint32_t(ai + 512) << 20) | (uint32_t(aj + 512) << 10) | uint32_t(ak + 512);
@@ -417,6 +422,8 @@ void MappingDev::UpdateMapDatabase(const float *corner_ds, size_t n_corner, cons
 // ------------------------------------------------------------------------------------------------
 void MappingDev::Process(const float *corner_last, size_t n_corner, const float *surf_last, size_t n_surf, const Rigid<float> &sum) {
   hipStream_t s = stream_;
+  const bool dbg = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  const double tt0 = now_ms();
   transform_sum_ = sum;
   score_ready_ = false;
   iterations_ = 0; num_selected_ = 0; degenerate_ = false;
@@ -501,6 +508,7 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   if (relayout[0] || relayout[1]) LIO_HIP(hipStreamSynchronize(s));
   for (int c = 0; c < 2; ++c) if (relayout[c]) LayoutFinish(cls_[c], vs);
 
+  const double tt1 = now_ms();
   // VoxelGrid of the stacks (:1005-1015)
   const float leaf[2] = {cfg_.corner_filter_size, cfg_.surf_filter_size};
   for (int c = 0; c < 2; ++c) {
@@ -508,6 +516,7 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
     m.n_stack = cnt[c] ? m.vox.run(m.stack_raw.p, cnt[c], leaf[c], m.stack_ds, s) : 0;
   }
 
+  const double tt2 = now_ms();
   if (builder) {  // MapBuilder.cc:527-558: optimise every skip_count-th call, always update the map
     if (odom_count_ % cfg_.skip_count == 0) Optimize(cfg_.enable_4d != 0);
     else {
@@ -519,12 +528,16 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
     Optimize(false);
   }
 
+  const double tt3 = now_ms();
   if (builder || !imu_inited_) {
     for (int c = 0; c < 2; ++c) UpdateLaunch(cls_[c], cls_[c].stack_ds.p, cls_[c].n_stack, vs, transform_tobe_mapped_, leaf[c]);
     LIO_HIP(hipStreamSynchronize(s));
     for (int c = 0; c < 2; ++c) UpdateFinish(cls_[c]);
     from_map_in_u_ = true;
   }
+  if (dbg)
+    std::fprintf(stderr, "[lio_hip map timing] upload+layout %.3f  stack voxel %.3f  optimise %.3f (%d rounds)  map update %.3f  total %.3f ms\n", tt1 - tt0,
+                 tt2 - tt1, tt3 - tt2, iterations_, now_ms() - tt3, now_ms() - tt0);
 }
 
 void MappingDev::Optimize(bool four_dof) {
@@ -570,7 +583,9 @@ void MappingDev::Optimize(bool four_dof) {
   for (int d = 0; d < 3; ++d) fa.fixed_pz[d] = pz_[d];
   const int max_it = cfg_.num_max_iterations;
   int iter = 0;
-  static const int kPeek[] = {3, 5, 7, 10};  // convergence is read back at these rounds only (each peek is a sync)
+  // Convergence is read back at these rounds only: a peek costs a sync + D2H + relaunch bubble (~35 us), a round that runs
+  // after convergence costs four no-op launches (~18 us), and the loop typically needs 5-7 rounds.
+  static const int kPeek[] = {6, 8, 10, 10};
   int peek_i = 0;
   bool done = false;
   while (iter < max_it && !done) {
@@ -578,9 +593,9 @@ void MappingDev::Optimize(bool four_dof) {
     while (peek_i < 4 && kPeek[peek_i] <= iter) ++peek_i;
     if (peek_i < 4) until = std::min(max_it, kPeek[peek_i]);
     for (; iter < until; ++iter) {
-      launch_line_features(stack_all_.p, Mc, 0, d_T, pz_, cfg_.min_match_sq_dis, mc.grid.sorted(), mc.grid.cells(), mc.grid.desc(), f_valid_.p,
-                           f_coef_.p, d_conv, s);
-      launch_features(fa, d_T, ms.grid.sorted(), ms.grid.cells(), ms.grid.desc(), f_valid_.p, f_coef_.p, nullptr, d_conv, s, f_abs_.p);
+      // the corner (line) and surf (plane) searches of a round are independent: one launch, blockIdx.y picks the branch
+      launch_map_round(fa, stack_all_.p, Mc, d_T, mc.grid.sorted(), mc.grid.cells(), mc.grid.desc(), ms.grid.sorted(), ms.grid.cells(), ms.grid.desc(),
+                       f_valid_.p, f_coef_.p, f_abs_.p, d_conv, s);
       launch_odom_rows(stack_all_.p, M, M, f_valid_.p, f_coef_.p, d_state_.p, d_partials_.p, nb, s, four_dof ? 2 : 1);
       launch_odom_update(d_partials_.p, nb, d_state_.p, iter, s, 50, four_dof ? 1 : 0);
     }

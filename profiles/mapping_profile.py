@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "lio-mapping_amd"); sys.path.insert(0, ".")
+sys.path.insert(0, "lio-mapping_amd"); sys.path.insert(0, ".")  # run from the repo root: python profiles/mapping_profile.py
 import bench
 from lio_amd import capi
 hip = capi.load_hip()

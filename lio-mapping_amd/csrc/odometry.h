@@ -28,6 +28,11 @@ class OdometryDev {
   DBuf<int> idx_;              // 2*nc + 3*ns correspondence indices
   DBuf<OdomState> d_state_;
   DBuf<double> d_partials_;
+  void BuildGrids();
+  KnnGrid grid_c_, grid_s_;
+  DBuf<float> partial_c_, partial_s_;
+  DBuf<VoxParams> bounds_;
+  VoxParams *h_bounds_ = nullptr;  // pinned
 };
 
 }  // namespace lio

@@ -26,6 +26,10 @@ struct OdoArgs {
   const float4 *lastc; int nlc;
   const float4 *lasts; int nls;
   float time_factor; int no_deskew;
+  // 5 m uniform grids over the previous sweep's clouds (cell-sorted copies, original index in .w): every point within the
+  // 25 m^2 acceptance gate of a query (PointOdometry.cc:349,448) lies in the 27 cells around it
+  const float4 *gc_sorted; const int2 *gc_cells; GridDesc gc;
+  const float4 *gs_sorted; const int2 *gs_cells; GridDesc gs;
 };
 
 __device__ inline bool odo_to_start(const float4 &pi, const Quat<float> &qe, const Vec3<float> &te, float time_factor, int no_deskew,
@@ -65,11 +69,36 @@ __global__ void __launch_bounds__(64) k_odo_corr(OdoArgs a, const OdomState *__r
   Vec3<float> te(st->T[4], st->T[5], st->T[6]);
   Vec3<float> sel;
   odo_to_start(pi, qe, te, a.time_factor, a.no_deskew, sel);
-  // ---- exact 1-NN, ties -> lower index
+  // ---- exact 1-NN inside the 25 m^2 gate, ties -> lower index: lanes stride over the nine x-runs of the 27 neighbouring
+  // cells (a nearest neighbour farther than one cell away is rejected by the gate anyway)
   float bd = INFINITY; int bi = INT_MAX;
-  for (int j = lane; j < n; j += 64) {
-    float d = odo_sqdiff(cloud[j], sel);
-    if (d < bd) { bd = d; bi = j; }
+  {
+    const float4 *gmap = corner ? a.gc_sorted : a.gs_sorted;
+    const int2 *gcells = corner ? a.gc_cells : a.gs_cells;
+    const GridDesc &g = corner ? a.gc : a.gs;
+    const int cx = int(floorf(sel.x * g.inv_cell)) - g.origin[0], cy = int(floorf(sel.y * g.inv_cell)) - g.origin[1],
+              cz = int(floorf(sel.z * g.inv_cell)) - g.origin[2];
+    if (cx >= 0 && cy >= 0 && cz >= 0 && cx < g.dims[0] && cy < g.dims[1] && cz < g.dims[2]) {
+      for (int r = 0; r < 9; ++r) {
+        const int z = cz + (r / 3 - 1), y = cy + (r % 3 - 1);
+        if (z < 0 || z >= g.dims[2] || y < 0 || y >= g.dims[1]) continue;
+        const int row = g.dims[0] * (y + g.dims[1] * z);
+        int rs = INT_MAX, re = 0;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int x = cx + dx;
+          if (x < 0 || x >= g.dims[0]) continue;
+          const int2 ce = gcells[row + x];
+          if (ce.y > ce.x) { rs = min(rs, ce.x); re = max(re, ce.y); }
+        }
+        if (re <= rs) continue;
+        for (int j = rs + lane; j < re; j += 64) {
+          const float4 p = gmap[j];
+          const float d = odo_sqdiff(p, sel);
+          const int id = __float_as_int(p.w);
+          if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
+        }
+      }
+    }
   }
   wave_argmin(bd, bi);
   int closest = -1, second = -1, third = -1;
@@ -296,7 +325,22 @@ OdometryDev::OdometryDev(float scan_period, int io_ratio, int max_iter, bool no_
   d_state_.reserve(1);
 }
 OdometryDev::~OdometryDev() {
+  if (h_bounds_) (void)hipHostFree(h_bounds_);
   if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// kdtree_corner_last_ / kdtree_surf_last_->setInputCloud (PointOdometry.cc:673-676) as 5 m grids over the previous sweep
+void OdometryDev::BuildGrids() {
+  hipStream_t s = stream_;
+  bounds_.reserve(2);
+  if (!h_bounds_) LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_bounds_), 2 * sizeof(VoxParams), hipHostMallocDefault));
+  launch_cloud_bounds(last_corner_.p, int(n_last_corner_), partial_c_, bounds_.p, s);
+  launch_cloud_bounds(last_surf_.p, int(n_last_surf_), partial_s_, bounds_.p + 1, s);
+  LIO_HIP(hipMemcpyAsync(h_bounds_, bounds_.p, 2 * sizeof(VoxParams), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
+  const float cell = 5.0f * 1.0001f;
+  grid_c_.build(last_corner_.p, n_last_corner_, h_bounds_[0].mn, h_bounds_[0].mx, cell, s);
+  grid_s_.build(last_surf_.p, n_last_surf_, h_bounds_[1].mn, h_bounds_[1].mx, cell, s);
 }
 
 static void upload(DBuf<float4> &b, const float *src, size_t n, hipStream_t s) {
@@ -328,8 +372,9 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
       const int nq = int(n_sharp + n_flat);
       idx_.reserve(std::max<size_t>(2 * n_sharp + 3 * n_flat, 1));
       LIO_HIP(hipMemsetAsync(idx_.p, 0xFF, (2 * n_sharp + 3 * n_flat) * sizeof(int), s));
+      BuildGrids();
       OdoArgs a{sharp_.p, int(n_sharp), flat_.p, int(n_flat), last_corner_.p, int(n_last_corner_), last_surf_.p, int(n_last_surf_), time_factor_,
-                no_deskew_ ? 1 : 0};
+                no_deskew_ ? 1 : 0, grid_c_.sorted(), grid_c_.cells(), grid_c_.desc(), grid_s_.sorted(), grid_s_.cells(), grid_s_.desc()};
       const int nb = std::max(1, std::min(cdiv(nq, ODO_ROW_THREADS), 64));
       d_partials_.reserve(size_t(nb) * 28);
       for (int iter = 0; iter < max_iter_; ++iter) {

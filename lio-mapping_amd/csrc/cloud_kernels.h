@@ -60,14 +60,14 @@ class KnnGrid {
   // outside it are clamped into the border cells (still compared by true distance).
   void build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s);
   const float4 *sorted() const { return sorted_.p; }   // xyz + original index in .w (int bits)
-  const int2 *cells() const { return cells_.p; }        // [start,end) per cell
+  const int *cells() const { return cells_.p; }         // ncells + 1 run starts: cell c holds sorted()[cells[c] .. cells[c + 1])
   const GridDesc &desc() const { return desc_; }
 
  private:
   GridDesc desc_{};
   DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
   DBuf<float4> sorted_;
-  DBuf<int2> cells_;
+  DBuf<int> cells_, cnt_;
   DBuf<char> tmp_;
 };
 
@@ -84,23 +84,23 @@ struct FeatArgs {
 };
 // transforms: device array of 8 floats per entry (qx,qy,qz,qw,px,py,pz,pad).  skip_flag: optional device int;
 // when *skip_flag != 0 the launch is a no-op (converged laser-odom loop).
-void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int *cells, const GridDesc &g,
                      uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef = nullptr);
 
 // Corner branch of PointMapping::OptimizeTransformTobeMapped (PointMapping.cc:377-517): 5-NN in the corner map, 3x3
 // covariance eigen-decomposition, line residual; slots [slot_off, slot_off+M).  transform: device, 8 floats.
 void launch_line_features(const float4 *stack, int M, int slot_off, const float *transform, const float fixed_pz[3], float min_match_sq_dis,
-                          const float4 *map_sorted, const int2 *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
+                          const float4 *map_sorted, const int *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
                           const int *skip_flag, hipStream_t s);
 
 // stateless K-NN (lio_knn entry point): idx/sqd are m*k
-void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int *cells, const GridDesc &g,
                 int32_t *idx, float *sqd, hipStream_t s);
 
 // Both branches of one scan-to-map round in a single launch (surf: FeatArgs with one frame, mapping_mode 1 or 2; corner: the
 // first Mc points of the concatenated stack, slots [0, Mc)).
 void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, const float *transform, const float4 *corner_map,
-                      const int2 *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int2 *surf_cells,
+                      const int *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int *surf_cells,
                       const GridDesc &surf_grid, uint8_t *valid, float4 *coef, float4 *abs_coef, const int *skip_flag, hipStream_t s);
 
 struct OdomState {

@@ -235,7 +235,13 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
 // ------------------------------------------------------------------------------------------------
 __device__ inline int cell_coord(float v, float inv_cell) { return int(floorf(v * inv_cell)); }
 
-__global__ void k_cell_keys(const float4 *__restrict__ pts, int n, GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// Counting sort by cell: a histogram with atomics hands every point a slot inside its cell, an exclusive scan over the
+// dense cell table turns the counts into run starts, and a scatter places the points.  The order INSIDE a cell depends on
+// the atomics and is not reproducible — by design: every consumer ranks candidates by the total order (distance, original
+// index), so results are identical whatever that order is.  (A radix/merge sort of the keys cost ~45 us of dependent
+// launches for 77 k points; this is three short kernels.)
+__global__ void k_cell_count(const float4 *__restrict__ pts, int n, GridDesc g, uint32_t *__restrict__ keys, uint32_t *__restrict__ slot,
+                             int *__restrict__ cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
@@ -243,21 +249,18 @@ __global__ void k_cell_keys(const float4 *__restrict__ pts, int n, GridDesc g, u
   int cy = cell_coord(p.y, g.inv_cell) - g.origin[1];
   int cz = cell_coord(p.z, g.inv_cell) - g.origin[2];
   cx = min(max(cx, 0), g.dims[0] - 1); cy = min(max(cy, 0), g.dims[1] - 1); cz = min(max(cz, 0), g.dims[2] - 1);
-  keys[i] = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
-  vals[i] = uint32_t(i);
+  const uint32_t c = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
+  keys[i] = c;
+  slot[i] = uint32_t(atomicAdd(&cnt[c], 1));
 }
 
-__global__ void k_cell_scatter(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, int n,
-                               float4 *__restrict__ sorted, int2 *__restrict__ cells) {
+__global__ void k_cell_place(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slot, int n,
+                             const int *__restrict__ starts, float4 *__restrict__ sorted) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t k = keys[i];
-  uint32_t src = vals[i];
-  float4 p = pts[src];
-  p.w = __int_as_float(int(src));
-  sorted[i] = p;
-  if (i == 0 || keys[i - 1] != k) cells[k].x = i;
-  if (i == n - 1 || keys[i + 1] != k) cells[k].y = i + 1;
+  float4 p = pts[i];
+  p.w = __int_as_float(i);
+  sorted[starts[keys[i]] + int(slot[i])] = p;
 }
 
 void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s) {
@@ -271,26 +274,23 @@ void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float 
     desc_.dims[d] = hi - lo + 1;
     ncells *= size_t(desc_.dims[d]);
   }
-  if (ncells > (size_t(1) << 31)) throw DeviceError("KnnGrid: cell table too large");
-  cells_.reserve(ncells);
-  LIO_HIP(hipMemsetAsync(cells_.p, 0, ncells * sizeof(int2), s));
-  if (n == 0) return;
-  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); sorted_.reserve(n);
+  if (ncells > (size_t(1) << 30)) throw DeviceError("KnnGrid: cell table too large");
+  cells_.reserve(ncells + 1); cnt_.reserve(ncells + 1);
+  LIO_HIP(hipMemsetAsync(cnt_.p, 0, (ncells + 1) * sizeof(int), s));
+  keys_.reserve(std::max<size_t>(n, 1)); vals_.reserve(std::max<size_t>(n, 1)); sorted_.reserve(std::max<size_t>(n, 1));
   const int ni = int(n);
-  hipLaunchKernelGGL(k_cell_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, ni, desc_, keys_.p, vals_.p);
-  int bits = 1;
-  while ((size_t(1) << bits) < ncells && bits < 32) ++bits;
+  if (ni) hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, ni, desc_, keys_.p, vals_.p, cnt_.p);
   size_t tmp_bytes = 0;
-  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
+  LIO_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_.p, cells_.p, 0, ncells + 1, rocprim::plus<int>(), s));
   tmp_.reserve(tmp_bytes + 256);
-  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
-  hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys2_.p, vals2_.p, ni, sorted_.p, cells_.p);
+  LIO_HIP(rocprim::exclusive_scan(tmp_.p, tmp_bytes, cnt_.p, cells_.p, 0, ncells + 1, rocprim::plus<int>(), s));
+  if (ni) hipLaunchKernelGGL(k_cell_place, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys_.p, vals_.p, ni, cells_.p, sorted_.p);
   LIO_HIP(hipGetLastError());
 }
 
 // K nearest (K <= 5 kept in registers) over the 27 neighbouring cells; total order (d2, original index).
 template <int K>
-__device__ inline void knn_scan(const Vec3<float> &q, const float4 *__restrict__ map, const int2 *__restrict__ cells, const GridDesc &g,
+__device__ inline void knn_scan(const Vec3<float> &q, const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
                                 float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
 #pragma unroll
   for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bj[k] = 0; }
@@ -308,8 +308,8 @@ __device__ inline void knn_scan(const Vec3<float> &q, const float4 *__restrict__
       for (int dx = -1; dx <= 1; ++dx) {
         int x = cx + dx;
         if (x < 0 || x >= g.dims[0]) continue;
-        int2 ce = cells[row + x];
-        for (int j = ce.x; j < ce.y; ++j) {
+        const int c0 = cells[row + x], c1 = cells[row + x + 1];
+        for (int j = c0; j < c1; ++j) {
           float4 p = map[j];
           float ddx = p.x - q.x, ddy = p.y - q.y, ddz = p.z - q.z;
           float d = ddx * ddx;
@@ -339,7 +339,7 @@ __device__ inline void knn_scan(const Vec3<float> &q, const float4 *__restrict__
 
 template <int K>
 __global__ void k_knn(const float4 *__restrict__ query, int m, float radius_sq, const float4 *__restrict__ map,
-                      const int2 *__restrict__ cells, GridDesc g, int32_t *__restrict__ idx, float *__restrict__ sqd, int kout) {
+                      const int *__restrict__ cells, GridDesc g, int32_t *__restrict__ idx, float *__restrict__ sqd, int kout) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   float4 q4 = query[i];
@@ -352,7 +352,7 @@ __global__ void k_knn(const float4 *__restrict__ query, int m, float radius_sq, 
   }
 }
 
-void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4 *map_sorted, const int *cells, const GridDesc &g,
                 int32_t *idx, float *sqd, hipStream_t s) {
   if (m <= 0) return;
   if (k == 1) hipLaunchKernelGGL(k_knn<1>, dim3(cdiv(m, 128)), dim3(128), 0, s, query, m, radius_sq, map_sorted, cells, g, idx, sqd, k);
@@ -371,7 +371,7 @@ void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4
 #define FEAT_LPQ 8
 template <int K, int LPQ>
 __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub, const float4 *__restrict__ map,
-                                      const int2 *__restrict__ cells, const GridDesc &g, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
+                                      const int *__restrict__ cells, const GridDesc &g, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
 #pragma unroll
   for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bj[k] = 0; }
   int cx = cell_coord(q.x, g.inv_cell) - g.origin[0];
@@ -387,15 +387,9 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
         if (y < 0 || y >= g.dims[1]) continue;
         int row = g.dims[0] * (y + g.dims[1] * z);
         // cells x-1..x+1 have consecutive ids => their points are one contiguous run of the cell-sorted array
-        int rs = INT_MAX, re = 0;
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          int x = cx + dx;
-          if (x < 0 || x >= g.dims[0]) continue;
-          int2 ce = cells[row + x];
-          if (ce.y > ce.x) { rs = min(rs, ce.x); re = max(re, ce.y); }
-        }
-        if (re <= rs) continue;  // all three cells empty (rs is still INT_MAX)
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dims[0] - 1);
+        const int rs = cells[row + x0], re = cells[row + x1 + 1];
+        if (re <= rs) continue;  // all three cells empty
         for (int j = rs + sub; j < re; j += LPQ) {
           float4 p = map[j];
           float ddx = p.x - q.x, ddy = p.y - q.y, ddz = p.z - q.z;
@@ -450,7 +444,7 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
 
 template <bool MAPPING, int LPQ>
 __device__ __forceinline__ void features_body(const FeatArgs &a, int frame, int block_x, const float *__restrict__ transforms,
-                                              const float4 *__restrict__ map, const int2 *__restrict__ cells, const GridDesc &g,
+                                              const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
                                               uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
                                               float4 *__restrict__ abs_coef) {
   const FeatFrame fr = a.fr[frame];
@@ -519,7 +513,7 @@ __device__ __forceinline__ void features_body(const FeatArgs &a, int frame, int 
 
 template <bool MAPPING, int LPQ>
 __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
-                                                 const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                 const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
                                                  float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
                                                  float4 *__restrict__ abs_coef) {
   if (skip_flag && *skip_flag) return;
@@ -530,7 +524,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
 // direction = eigenvector of the largest eigenvalue (accepted when it dominates 3x the middle one).
 __device__ __forceinline__ void line_features_body(int block_x, const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
                                                    const Vec3<float> &pz, float min_match_sq_dis, const float4 *__restrict__ map,
-                                                   const int2 *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
+                                                   const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
                                                    float4 *__restrict__ coef) {
   const int gt = block_x * blockDim.x + threadIdx.x;
   const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
@@ -596,7 +590,7 @@ __device__ __forceinline__ void line_features_body(int block_x, const float4 *__
 
 __global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
                                                       Vec3<float> pz, float min_match_sq_dis, const float4 *__restrict__ map,
-                                                      const int2 *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                      const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
                                                       float4 *__restrict__ coef, const int *__restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   line_features_body(blockIdx.x, stack, M, slot_off, tp, pz, min_match_sq_dis, map, cells, g, valid, coef);
@@ -606,8 +600,8 @@ __global__ void __launch_bounds__(128) k_line_features(const float4 *__restrict_
 // blockIdx.y = 1 the surf (plane) branch against the surf map.  No cross-stream events, one dispatch.
 struct MapRoundArgs {
   const float4 *corner_stack; int Mc;
-  const float4 *corner_map; const int2 *corner_cells; GridDesc corner_grid;
-  const float4 *surf_map; const int2 *surf_cells; GridDesc surf_grid;
+  const float4 *corner_map; const int *corner_cells; GridDesc corner_grid;
+  const float4 *surf_map; const int *surf_cells; GridDesc surf_grid;
   int blocks_corner, blocks_surf;
 };
 __global__ void __launch_bounds__(128) k_map_round(FeatArgs a, MapRoundArgs m, const float *__restrict__ tp, uint8_t *__restrict__ valid,
@@ -624,7 +618,7 @@ __global__ void __launch_bounds__(128) k_map_round(FeatArgs a, MapRoundArgs m, c
 }
 
 void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, const float *transform, const float4 *corner_map,
-                      const int2 *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int2 *surf_cells,
+                      const int *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int *surf_cells,
                       const GridDesc &surf_grid, uint8_t *valid, float4 *coef, float4 *abs_coef, const int *skip_flag, hipStream_t s) {
   MapRoundArgs m{corner_stack, Mc, corner_map, corner_cells, corner_grid, surf_map, surf_cells, surf_grid, cdiv((long long)Mc * FEAT_LPQ, 128),
                  cdiv((long long)surf.max_M * 8, 128)};
@@ -634,7 +628,7 @@ void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, 
 }
 
 void launch_line_features(const float4 *stack, int M, int slot_off, const float *transform, const float fixed_pz[3], float min_match_sq_dis,
-                          const float4 *map_sorted, const int2 *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
+                          const float4 *map_sorted, const int *cells, const GridDesc &g, uint8_t *valid, float4 *coef,
                           const int *skip_flag, hipStream_t s) {
   if (M <= 0) return;
   hipLaunchKernelGGL(k_line_features, dim3(cdiv((long long)M * FEAT_LPQ, 128)), dim3(128), 0, s, stack, M, slot_off, transform,
@@ -642,7 +636,7 @@ void launch_line_features(const float4 *stack, int M, int slot_off, const float 
   LIO_HIP(hipGetLastError());
 }
 
-void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int2 *cells, const GridDesc &g,
+void launch_features(const FeatArgs &a, const float *transforms, const float4 *map_sorted, const int *cells, const GridDesc &g,
                      uint8_t *valid, float4 *coef, float *score, const int *skip_flag, hipStream_t s, float4 *abs_coef) {
   if (a.nframes <= 0 || a.max_M <= 0) return;
   // lanes per query: 8 when the launch is small (latency-bound: shorter per-lane candidate walks), 4 when it already fills

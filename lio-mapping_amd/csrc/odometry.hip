@@ -28,8 +28,8 @@ struct OdoArgs {
   float time_factor; int no_deskew;
   // 5 m uniform grids over the previous sweep's clouds (cell-sorted copies, original index in .w): every point within the
   // 25 m^2 acceptance gate of a query (PointOdometry.cc:349,448) lies in the 27 cells around it
-  const float4 *gc_sorted; const int2 *gc_cells; GridDesc gc;
-  const float4 *gs_sorted; const int2 *gs_cells; GridDesc gs;
+  const float4 *gc_sorted; const int *gc_cells; GridDesc gc;
+  const float4 *gs_sorted; const int *gs_cells; GridDesc gs;
 };
 
 __device__ inline bool odo_to_start(const float4 &pi, const Quat<float> &qe, const Vec3<float> &te, float time_factor, int no_deskew,
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) k_odo_corr(OdoArgs a, const OdomState *__r
   float bd = INFINITY; int bi = INT_MAX;
   {
     const float4 *gmap = corner ? a.gc_sorted : a.gs_sorted;
-    const int2 *gcells = corner ? a.gc_cells : a.gs_cells;
+    const int *gcells = corner ? a.gc_cells : a.gs_cells;
     const GridDesc &g = corner ? a.gc : a.gs;
     const int cx = int(floorf(sel.x * g.inv_cell)) - g.origin[0], cy = int(floorf(sel.y * g.inv_cell)) - g.origin[1],
               cz = int(floorf(sel.z * g.inv_cell)) - g.origin[2];
@@ -83,13 +83,8 @@ __global__ void __launch_bounds__(64) k_odo_corr(OdoArgs a, const OdomState *__r
         const int z = cz + (r / 3 - 1), y = cy + (r % 3 - 1);
         if (z < 0 || z >= g.dims[2] || y < 0 || y >= g.dims[1]) continue;
         const int row = g.dims[0] * (y + g.dims[1] * z);
-        int rs = INT_MAX, re = 0;
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int x = cx + dx;
-          if (x < 0 || x >= g.dims[0]) continue;
-          const int2 ce = gcells[row + x];
-          if (ce.y > ce.x) { rs = min(rs, ce.x); re = max(re, ce.y); }
-        }
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dims[0] - 1);
+        const int rs = gcells[row + x0], re = gcells[row + x1 + 1];
         if (re <= rs) continue;
         for (int j = rs + lane; j < re; j += 64) {
           const float4 p = gmap[j];

@@ -186,6 +186,16 @@ def main():
             for n in ("features", "odom_features", "moments", "voxel", "knn_grid") if n != dom
         }
 
+        # the dominant kernel given B windows of work in one launch
+        batched_kernel = None
+        if not args.shard_factors:
+            batched_kernel = []
+            for B in (1, 8, 64, 512):
+                ms_b, bytes_b = est.bench_batched_moments(B, 20)
+                gbps = bytes_b / (ms_b * 1e-3) / 1e9
+                batched_kernel.append({"windows": B, "avg_launch_us": round(ms_b * 1e3, 2), "algorithmic_MB": round(bytes_b / 1e6, 2),
+                                       "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
+                                       "mfma_f64_GFLOPs": round(bytes_b / 60.0 * 684.0 / (ms_b * 1e-3) / 1e9, 1)})
         batched = None
         if args.windows > 1 and not args.shard_factors:
             batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
@@ -222,6 +232,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "batched": batched,
+            "batched_kernel_roofline": {"kernel": "k_lidar_moments_batched + k_moment_reduce", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
             "stages_ms": {
                 "t_build_map": round(rep.ms_build_map, 4),
                 "feature_cost": round(rep.ms_features, 4),

@@ -377,6 +377,12 @@ int lio_est_set_factor_sharding(lio_est *, int rank, int world, lio_allreduce_fn
  * get returns the number of launches TIMED since timing was enabled (0 for an unknown name or
  * for the oracle), total_ms their summed duration, algorithmic_bytes the summed SURVEY.md §8d bytes. */
 int lio_est_enable_kernel_timing(lio_est *, int on);
+/* Batched roofline probe (SURVEY.md §8d ii): the lidar factors of the CURRENT window (features as left by the last
+ * BuildLocalMap / SolveOptimization) are replicated n_windows times at distinct addresses and evaluated by ONE launch
+ * of the moments kernel (frame descriptors in device memory); `reps` launches are timed with HIP events on the
+ * estimator's stream.  avg_ms_out = mean duration of one launch (moments + reduce), algorithmic_bytes_out = 60 B x
+ * residuals x n_windows.  LIO_ERR_STATE when no features exist (and always for the CPU oracle). */
+int lio_est_bench_batched_moments(lio_est *, int n_windows, int reps, double *avg_ms_out, double *algorithmic_bytes_out);
 int lio_est_get_kernel_timing(lio_est *, const char *name, double *total_ms, double *algorithmic_bytes);
 
 #ifdef __cplusplus

@@ -619,6 +619,10 @@ int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_f
   h->e->shard_rank_ = rank; h->e->shard_world_ = world; h->e->allreduce_ = fn; h->e->allreduce_user_ = user;
   return LIO_OK;
 }
+int lio_est_bench_batched_moments(lio_est *h, int n_windows, int reps, double *avg_ms, double *bytes) {
+  if (!h || n_windows < 1 || reps < 1) return LIO_ERR_ARG;
+  return guarded([&] { return h->e->BenchBatchedMoments(n_windows, reps, avg_ms, bytes) ? LIO_OK : LIO_ERR_STATE; });
+}
 int lio_est_enable_kernel_timing(lio_est *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->e->timers_.on = on != 0;

@@ -101,6 +101,9 @@ class Estimator {
   size_t GetFeatures(int frame, double *pt, double *co, double *sc);
   void Snapshot();
   bool Restore();
+  // B copies of the current window's lidar factors through ONE moments launch (distinct memory per copy); returns the average
+  // launch-pair duration in ms and the algorithmic bytes per launch.  false when no features have been built yet.
+  bool BenchBatchedMoments(int n_windows, int reps, double *avg_ms, double *bytes);
 
   EstConfig cfg_;
   int W_, Wo_;

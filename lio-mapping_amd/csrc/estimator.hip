@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cfloat>
+#include <climits>
 #include <chrono>
 #include <cstring>
 
@@ -591,6 +592,56 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   // command, only the kernel-completion wait (kernel end = system-scope release, so the host sees the data).
   launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, h_moment_out_, stream_);
   timers_.end(th, stream_);
+}
+
+bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *bytes) {
+  if (B < 1 || reps < 1 || total_slots_ == 0 || !init_local_map_) return false;
+  const int pivot = W_ - Wo_;
+  WindowParams P;
+  VectorToParams(P);
+  // replicate the feature slots and the stacks B times (distinct addresses: no cache reuse across windows)
+  DBuf<uint8_t> valid_b; DBuf<float4> coef_b, stack_b;
+  size_t stack_pts = 0;
+  for (int i = pivot + 1; i <= W_; ++i) stack_pts += stacks_[i].n;
+  valid_b.reserve(size_t(B) * total_slots_); coef_b.reserve(size_t(B) * total_slots_); stack_b.reserve(std::max<size_t>(size_t(B) * stack_pts, 1));
+  std::vector<MomentFrame> frames;
+  int max_slots = 0;
+  double nres = 0;
+  for (int b = 0; b < B; ++b) {
+    LIO_HIP(hipMemcpyAsync(valid_b.p + size_t(b) * total_slots_, f_valid_.p, total_slots_, hipMemcpyDeviceToDevice, stream_));
+    LIO_HIP(hipMemcpyAsync(coef_b.p + size_t(b) * total_slots_, f_coef_.p, total_slots_ * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    size_t off = size_t(b) * stack_pts;
+    for (int i = 1; i <= Wo_; ++i) {
+      const int idx = pivot + i;
+      if (stacks_[idx].n) LIO_HIP(hipMemcpyAsync(stack_b.p + off, stacks_[idx].buf.p, stacks_[idx].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+      MomentFrame f{};
+      f.stack = stack_b.p + off; f.M = std::max<int>(1, int(stacks_[idx].n)); f.slot_off = int(size_t(b) * total_slots_) + slot_off_[idx];
+      f.nslots = nslots_[idx]; f.slot_begin = 0; f.slot_end = f.nslots;
+      relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), f.R, f.t);
+      frames.push_back(f);
+      off += stacks_[idx].n;
+      max_slots = std::max(max_slots, f.nslots);
+      nres += f.nslots;
+    }
+  }
+  if (size_t(B) * total_slots_ > size_t(INT_MAX)) return false;
+  const int nf = int(frames.size()), bpf = moment_blocks_per_frame(max_slots);
+  DBuf<MomentFrame> d_frames; DBuf<double> partials, out;
+  d_frames.reserve(nf); partials.reserve(size_t(nf) * bpf * LIO_MOMENT_OUT); out.reserve(size_t(nf) * LIO_MOMENT_OUT);
+  LIO_HIP(hipMemcpyAsync(d_frames.p, frames.data(), sizeof(MomentFrame) * nf, hipMemcpyHostToDevice, stream_));
+  hipEvent_t e0, e1;
+  LIO_HIP(hipEventCreate(&e0)); LIO_HIP(hipEventCreate(&e1));
+  for (int w = 0; w < 2; ++w) launch_lidar_moments_batched(d_frames.p, nf, bpf, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  LIO_HIP(hipEventRecord(e0, stream_));
+  for (int r = 0; r < reps; ++r) launch_lidar_moments_batched(d_frames.p, nf, bpf, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  LIO_HIP(hipEventRecord(e1, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  float ms = 0;
+  LIO_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (avg_ms) *avg_ms = double(ms) / reps;
+  if (bytes) *bytes = 60.0 * nres;  // 60 B read per lidar residual
+  return true;
 }
 
 void Estimator::LidarWait(std::vector<FrameMoments> &m) {

@@ -34,5 +34,8 @@ struct MomentArgs {
 // partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s);
 int moment_blocks_per_frame(int max_slots);
+// same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
+void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,
+                                  double *partials, double *out, hipStream_t s);
 
 }  // namespace lio

@@ -25,9 +25,8 @@ int moment_blocks_per_frame(int max_slots) {
 
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
-__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
-                                                                  const float4 *__restrict__ coef, double *__restrict__ partials) {
-  const MomentFrame &fr = a.fr[blockIdx.y];
+__device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                                   double *__restrict__ partials) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = lane & 15, grp = lane >> 4;
   const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
@@ -92,6 +91,18 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, 
   }
 }
 
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
+                                                                  const float4 *__restrict__ coef, double *__restrict__ partials) {
+  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials);
+}
+
+// Batched form for B windows in flight: the frame descriptors live in device memory (B x Wo of them), everything else is the
+// same code.  Used by the batched roofline measurement (SURVEY.md §8d ii) and by multi-window hosts.
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
+                                                                          const float4 *__restrict__ coef, double *__restrict__ partials) {
+  lidar_moments_body(frames[blockIdx.y], valid, coef, partials);
+}
+
 __global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
   const double *src = partials + size_t(blockIdx.x) * bpf * LIO_MOMENT_OUT;
   const int k = threadIdx.x;
@@ -107,6 +118,14 @@ __global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict_
   }
   for (; b < bpf; ++b) v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
   out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = (v0 + v1) + (v2 + v3);
+}
+
+void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,
+                                  double *partials, double *out, hipStream_t s) {
+  if (nframes <= 0) return;
+  hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
+  hipLaunchKernelGGL(k_moment_reduce, dim3(nframes), dim3(320), 0, s, partials, blocks_per_frame, out);
+  LIO_HIP(hipGetLastError());
 }
 
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s) {

@@ -200,6 +200,7 @@ _SIGS = {
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lio_est_bench_batched_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "lio_est_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_est_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, c_double_p]),
 }
@@ -694,6 +695,12 @@ class Estimator:
         self._allreduce_cb = ALLREDUCE(_cb) if (world > 1 and allreduce_numpy is not None) else None  # keep alive
         fn = C.cast(self._allreduce_cb, C.c_void_p) if self._allreduce_cb else None
         _chk(self.lib.dll.lio_est_set_factor_sharding(self.h, rank, world, fn, None), "lio_est_set_factor_sharding")
+
+    def bench_batched_moments(self, n_windows, reps=20):
+        """One moments launch over n_windows copies of the current window's lidar factors -> (avg ms, algorithmic bytes)."""
+        ms, b = np.zeros(1), np.zeros(1)
+        _chk(self.lib.dll.lio_est_bench_batched_moments(self.h, int(n_windows), int(reps), _dp(ms), _dp(b)), "lio_est_bench_batched_moments")
+        return float(ms[0]), float(b[0])
 
     def enable_kernel_timing(self, on=True):
         """on: False/0 stop, True/1 every launch, N > 1 every N-th launch of each kernel kind."""

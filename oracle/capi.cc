@@ -607,6 +607,7 @@ int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_f
   h->est.shard_rank = rank; h->est.shard_world = world; h->est.allreduce = fn; h->est.allreduce_user = user;
   return LIO_OK;
 }
+int lio_est_bench_batched_moments(lio_est *, int, int, double *, double *) { return LIO_ERR_STATE; }  // device-only measurement
 int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_est_get_kernel_timing(lio_est *, const char *, double *t, double *b) { if (t) *t = 0; if (b) *b = 0; return 0; }
 

@@ -162,6 +162,8 @@ class Estimator {
   DBuf<float> d_transforms_;
   DBuf<OdomState> d_odom_;
   DBuf<double> d_odom_partials_, d_moment_partials_, d_moment_out_;
+  DBuf<int> d_moment_tickets_;
+  bool fold_in_kernel_ = false;
   double *h_moment_out_ = nullptr;  // pinned
   std::unique_ptr<HostState> snap_;
   std::vector<DeviceCloud> snap_stacks_;

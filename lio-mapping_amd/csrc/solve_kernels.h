@@ -32,7 +32,10 @@ struct MomentArgs {
 };
 
 // partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles
-void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s);
+// tickets: nframes ints, zero before the first launch (the kernel re-zeroes them) -> the fold runs inside the same launch;
+// tickets == nullptr -> separate k_moment_reduce launch.
+void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
+                          hipStream_t s);
 int moment_blocks_per_frame(int max_slots);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,

@@ -26,7 +26,7 @@ int moment_blocks_per_frame(int max_slots) {
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
 __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                   double *__restrict__ partials) {
+                                                   double *__restrict__ partials, int *__restrict__ tickets, double *__restrict__ out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = lane & 15, grp = lane >> 4;
   const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
@@ -89,18 +89,47 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
     for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][k];
     dst[k] = v;
   }
+  if (!tickets) return;
+  // ---- fold in the same launch: the block that arrives last at the frame's ticket sums the frame's partials in block order
+  // (independent of which block that is).  Hand-off protocol of cdna_hip_programming.md §6 G16: every wave drains its stores,
+  // block barrier, ONE lane does the agent-scope release/acquire on the ticket, block barrier, plain loads.
+  __shared__ int is_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == int(gridDim.x) - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const double *src = partials + size_t(blockIdx.y) * gridDim.x * LIO_MOMENT_OUT;
+  const int bpf = gridDim.x;
+  for (int k = threadIdx.x; k < 258; k += MOMENT_THREADS) {
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int b = 0;
+    for (; b + 4 <= bpf; b += 4) {
+      v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
+      v1 += src[size_t(b + 1) * LIO_MOMENT_OUT + k];
+      v2 += src[size_t(b + 2) * LIO_MOMENT_OUT + k];
+      v3 += src[size_t(b + 3) * LIO_MOMENT_OUT + k];
+    }
+    for (; b < bpf; ++b) v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
+    out[size_t(blockIdx.y) * LIO_MOMENT_OUT + k] = (v0 + v1) + (v2 + v3);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (stream order)
 }
 
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
-                                                                  const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials);
+                                                                  const float4 *__restrict__ coef, double *__restrict__ partials,
+                                                                  int *__restrict__ tickets, double *__restrict__ out) {
+  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials, tickets, out);
 }
 
 // Batched form for B windows in flight: the frame descriptors live in device memory (B x Wo of them), everything else is the
 // same code.  Used by the batched roofline measurement (SURVEY.md §8d ii) and by multi-window hosts.
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
                                                                           const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_body(frames[blockIdx.y], valid, coef, partials);
+  lidar_moments_body(frames[blockIdx.y], valid, coef, partials, nullptr, nullptr);
 }
 
 __global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
@@ -128,10 +157,11 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
   LIO_HIP(hipGetLastError());
 }
 
-void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s) {
+void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
+                          hipStream_t s) {
   if (a.nframes <= 0) return;
-  hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
-  hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
+  hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out);
+  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }
 

@@ -123,3 +123,43 @@ def test_compact_data_codec_round_trip(hip, oracle):
             assert False
         except capi.LioError:
             pass
+
+
+def test_error_codes_of_the_init_and_mapping_entry_points(hip, oracle):
+    """Argument validation happens before any device work, so it is identical in both libraries: LIO_ERR_ARG (-1) for
+    null / short / inconsistent inputs, NULL handles for bad configurations, never an exception across the C boundary."""
+    import torch
+
+    T = (capi.TransformF * 3)()
+    pims = (ctypes.c_void_p * 3)(None, None, None)
+    lb = capi.TransformF.make([0, 0, 0, 1], [0, 0, 0])
+    Vs, Bgs, g, R = np.zeros(9), np.zeros(9), np.zeros(3), np.zeros(9)
+    dp = lambda a: a.ctypes.data_as(capi.c_double_p)
+    for lib in (oracle, hip):
+        d = lib.dll
+        assert d.lio_imu_estimate_extrinsic_rotation(1, T, pims, ctypes.byref(lb)) == -1            # n < 2
+        assert d.lio_imu_estimate_extrinsic_rotation(3, T, pims, ctypes.byref(lb)) == -1            # pims[1] missing
+        assert d.lio_imu_initialization(3, T, pims, ctypes.byref(lb), dp(Vs), dp(Bgs), dp(g), dp(R)) == -1
+        assert d.lio_imu_initialization(3, T, None, ctypes.byref(lb), dp(Vs), dp(Bgs), dp(g), dp(R)) == -1
+        bad = capi.MapConfig()
+        d.lio_map_default_config(ctypes.byref(bad))
+        assert (bad.map_builder, bad.enable_4d, bad.skip_count, bad.num_max_iterations) == (0, 1, 2, 10)
+        bad.surf_filter_size = 0.0
+        assert not d.lio_map_create(ctypes.byref(bad))
+        bad.surf_filter_size, bad.map_builder, bad.skip_count = 0.4, 1, 0
+        assert not d.lio_map_create(ctypes.byref(bad))
+        assert d.lio_map_process(None, None, 0, None, 0, None, None, None, None) == -1
+        assert d.lio_map_get_cloud(None, 0, None) == 0 and d.lio_map_get_cube_state(None, None, None) == 0
+        assert d.lio_est_process_compact(None, None, 0, 0.0, None, None) == -1
+        assert d.lio_est_get_stage(None, None, None, None, None, None, None) == -1
+        cfg = lib.default_est_config()
+        assert cfg.init_window_factor == 3 and cfg.extrinsic_stage == 2                              # Estimator.h:80-81
+    # a malformed /compact_data message is rejected before anything is pushed (oracle always; product when a GPU exists)
+    libs = [oracle] + ([hip] if torch.cuda.is_available() else [])
+    for lib in libs:
+        est = capi.Estimator(lib, lib.default_est_config())
+        junk = np.zeros((5, 4), np.float32)
+        junk[2, :3] = (3, 3, 3)        # claims 9 points, carries 2
+        rc = lib.dll.lio_est_process_compact(est.h, junk.ctypes.data_as(capi.c_float_p), 5, 1.0, None, None)
+        assert rc == -1
+        assert est.stage()["cir_buf_count"] == 0 and est.stage()["event"] == "skipped"

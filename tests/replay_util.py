@@ -9,10 +9,17 @@ def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kin
     if sweeps is None:
         sweeps = synth.make_sweeps(kind, n_sweeps)
     sw, pose_fn, lid = sweeps
-    traj = synth.Trajectory()   # the indoor trajectory of make_sweeps
-    cfg = pipeline.config_indoor(lib, W, Wo)
+    if kind == "indoor":
+        traj = synth.Trajectory()   # the indoor trajectory of make_sweeps
+        cfg = pipeline.config_indoor(lib, W, Wo)
+        cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
+    else:                           # HDL-64E, outdoor_test_config_64.yaml, the outdoor trajectory of make_sweeps
+        import math
+
+        traj = synth.Trajectory(rx=45.0, ry=60.0, rz=0.3, cx=15.0, cy=15.0, cz=2.2, Kz=2 * math.pi / 5.0, g=9.80, ang_scale=0.3)
+        cfg = pipeline.config_outdoor64(lib, W, Wo)
+        cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [-8.086759e-01, 3.195559e-01, -7.997231e-01])
     cfg.init_window_factor = init_window_factor
-    cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
     cfg.extrinsic_stage = 1
     rp = replay.Replay(lib, cfg, lid, odom_io=odom_io)
     h = 1.0 / imu_rate

@@ -45,3 +45,32 @@ def test_replay_from_zero_matches_oracle(hip, oracle):
     errs_o, _ = window_vs_truth(rpo, traj, W)
     assert errs_h[:, 0].max() < 0.08 and errs_h[:, 1].max() < 1.0, errs_h
     assert abs(errs_h[:, 0].max() - errs_o[:, 0].max()) < 0.03
+
+
+def test_full_size_hdl64_from_zero_tracks_truth(hip):
+    """BASELINE.json's configuration end to end on the GPU: HDL-64E sweeps (133 k points), window 15 / 5, odom_io 3,
+    from the first sweep through IMU initialisation to regular solves.  Checked against the analytic trajectory (the
+    oracle runs the same scenario in ~40 s of CPU time; its agreement is covered at VLP-16 size above)."""
+    W, n = 15, 62
+    rp, traj = run_from_zero(hip, n, W=W, Wo=5, init_window_factor=1, odom_io=3, kind="outdoor")
+    events = [e["event"] for e in rp.log]
+    assert events[:W] == ["filling"] * W and "initialised" in events
+    k0 = events.index("initialised")
+    assert set(events[k0 + 1:]) == {"solved"} and len(events) - k0 >= 4
+    rep = rp.log[-1]["report"]
+    assert rep.n_lidar_residuals > 40000 and rep.iterations == 10
+    st = rp.est.stage()
+    np.testing.assert_allclose(st["g_vec"], [0, 0, -9.80], atol=1e-9)
+    errs, w = window_vs_truth(rp, traj, W)
+    # 0.3 s between window frames at ~15 m/s: 4.5 m steps
+    assert errs[:, 0].max() < 0.3 and errs[:, 1].max() < 1.0, errs
+    assert abs(np.linalg.norm(w["Vs"][W - 1]) - np.linalg.norm(traj.vel(rp.log[-1]["stamp"]))) < 0.5
+    # the CPU oracle on the same scenario (tests/golden/make_e2e_hdl64_oracle_errors.py): same stage events, same errors
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "e2e_hdl64_oracle_errors.json")))
+    assert events == gold["events"]
+    ge = np.array(gold["step_errors_m_deg"])
+    assert np.max(np.abs(errs[:, 0] - ge[:, 0])) < 0.02 and np.max(np.abs(errs[:, 1] - ge[:, 1])) < 0.1, (errs, ge)
+    assert abs(rep.n_lidar_residuals - gold["n_lidar_residuals_last"]) < 0.01 * gold["n_lidar_residuals_last"]

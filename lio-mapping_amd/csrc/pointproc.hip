@@ -113,6 +113,9 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   float *sy = sx + NP, *sz = sy + NP, *scurv = sz + NP;
   signed char *smask = reinterpret_cast<signed char *>(scurv + NP);
   signed char *slabel = smask + NP;
+  unsigned char *snfb = reinterpret_cast<unsigned char *>(slabel + NP);  // MaskPickedInRing reach of every point: nf | nb << 4
+  unsigned char *sgap = snfb + NP;
+  int *lpick = reinterpret_cast<int *>(sgap + NP);                       // this ring's pick lists, flushed to global memory at the end
   for (int i = tid; i < n; i += PP_PICK_THREADS) {
     float4 p = ring_cloud[base + i];
     sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; scurv[i] = 0.f; smask[i] = 0; slabel[i] = 127;
@@ -151,11 +154,24 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
       if (double(diff_next2) > 0.0002 * double(dis2) && double(diff_prev2) > 0.0002 * double(dis2)) smask[i] = 1;
     }
   }
+  // ---- reach of MaskPickedInRing (:624-645) for every point, in parallel: a pick at i masks i+1..i+nf and i-1..i-nb, the
+  // walks stopping at the first consecutive gap above 0.05 m^2.  With this table the serial pick chain below carries no
+  // geometry at all.
+  // gap[i] = the step i -> i+1 exceeds 0.05 m^2: one squared distance per point instead of ten per point
+  for (int i = tid; i < n - 1; i += PP_PICK_THREADS)
+    sgap[i] = double(sqdiff(sx[i + 1], sy[i + 1], sz[i + 1], sx[i], sy[i], sz[i])) > 0.05 ? 1 : 0;
+  __syncthreads();
+  for (int i = c.nc + tid; i < n - c.nc; i += PP_PICK_THREADS) {
+    int nf = c.nc, nb = c.nc;
+    for (int q = 1; q <= c.nc; ++q) if (sgap[i + q - 1]) { nf = q - 1; break; }   // step (i+q-1) -> (i+q)
+    for (int q = 1; q <= c.nc; ++q) if (sgap[i - q]) { nb = q - 1; break; }       // step (i-q) -> (i-q+1)
+    snfb[i] = static_cast<unsigned char>(nf | (nb << 4));
+  }
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63;
   int n_sharp = 0, n_less = 0, n_flat = 0;  // thread 0 only
   for (int jg = 0; jg < c.ns; jg += 8) {
-    // ---- PrepareSubregion for subregion j = jg + wave: curvature + sort slots
+      // ---- PrepareSubregion for subregion j = jg + wave: curvature + sort slots
     const int j = jg + wv;
     unsigned long long *wk = skey + wv * PP_SORT_SLOTS;
     int sp = 0, ep = -1;
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
       wk[k] = key;
     }
     __syncthreads();
-    // ---- bitonic sort, ascending, all 8 waves in lockstep: total order (curvature, index) == std::sort on pair<float,size_t>
+      // ---- bitonic sort, ascending, all 8 waves in lockstep: total order (curvature, index) == std::sort on pair<float,size_t>
     for (int size = 2; size <= PP_SORT_SLOTS; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         for (int t = lane; t < PP_SORT_SLOTS / 2; t += 64) {
@@ -196,34 +212,33 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
           unsigned long long a = wk[lo], b = wk[hi];
           if ((a > b) == up) { wk[lo] = b; wk[hi] = a; }
         }
-        __syncthreads();
+        // each wave sorts its own subregion: a wave-level fence orders the stages, no block barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
+    __syncthreads();  // wave 0 reads every wave's sorted keys
     // ---- picks (:685-725).  The mask is shared by the ring's subregions (A.4), so subregions are taken in order and
     // picks inside one are sequentially dependent — but only through the mask: wave 0 examines 64 sorted candidates at
     // a time, a ballot finds the first still-eligible one (exactly the one the serial loop would reach next), the
     // +-5 neighbour walk of MaskPickedInRing runs on 2*nc lanes, and the ballot is retaken.  Work per subregion is
     // O(#picks + #chunks) wave steps instead of O(#candidates) dependent LDS round trips on one lane.
-    if (wv == 0) {
+      if (wv == 0) {
       volatile signed char *vmask = smask;
-      auto mask_picked = [&](int pidx) {
-        bool fwd_brk = false, bwd_brk = false;
-        if (lane < c.nc) {
-          const int q = lane + 1;
-          fwd_brk = double(sqdiff(sx[pidx + q], sy[pidx + q], sz[pidx + q], sx[pidx + q - 1], sy[pidx + q - 1], sz[pidx + q - 1])) > 0.05;
-        } else if (lane < 2 * c.nc) {
-          const int q = lane - c.nc + 1;
-          bwd_brk = double(sqdiff(sx[pidx - q], sy[pidx - q], sz[pidx - q], sx[pidx - q + 1], sy[pidx - q + 1], sz[pidx - q + 1])) > 0.05;
-        }
-        const unsigned long long fb = __ballot(fwd_brk), bb = __ballot(bwd_brk);
-        const int nf = fb ? (__ffsll((long long)fb) - 1) : c.nc;
-        const int nb = bb ? (__ffsll((long long)bb) - 1 - c.nc) : c.nc;
-        if (lane == 0) vmask[pidx] = 1;
-        if (lane < nf) vmask[pidx + lane + 1] = 1;
-        if (lane >= c.nc && lane - c.nc < nb) vmask[pidx - (lane - c.nc) - 1] = 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // One pick = ballot -> first eligible lane -> three shuffles -> a register compare per lane: every lane keeps the
+      // masked state of ITS candidate in a register and updates it from the picked index and its reach, so the dependent
+      // chain never waits on LDS.  The mask bytes are still written (fire and forget) for the later chunks / subregions,
+      // which read them once when they load their candidates (a wave's DS operations execute in order).
+      auto apply_pick = [&](int pidx, int reach, int idx, bool &masked) {
+        const int nf = reach & 15, nb = reach >> 4;
+        masked = masked || (idx >= pidx - nb && idx <= pidx + nf);
+        // one store per lane, no branches: lane 0 -> the pick, lanes 1..nf -> forward reach, lanes nc+1..nc+nb -> backward reach
+        int off = 0;
+        bool wr = lane == 0;
+        if (lane >= 1 && lane <= nf) { off = lane; wr = true; }
+        if (lane > c.nc && lane - c.nc <= nb) { off = -(lane - c.nc); wr = true; }
+        if (wr) smask[pidx + off] = 1;
       };
       for (int w = 0; w < 8 && jg + w < c.ns; ++w) {
         const int jj = jg + w;
@@ -237,28 +252,32 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         int num_largest = 0;
         bool stop = false;
         for (int pos = region2; pos > 0 && num_largest < c.max_less_sharp && !stop; pos -= 64) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           const int k = pos - 1 - lane;
           const bool in = k >= 0;
           const unsigned long long e = in ? kk[k] : 0ull;
           const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
           const int idx = int(static_cast<unsigned int>(e));
           const bool above = in && (cv > c.curv_th);
+          bool masked = !above || vmask[idx] != 0;
+          const int reach = above ? int(snfb[idx]) : 0;
           int consumed = -1;
           while (num_largest < c.max_less_sharp) {
-            const bool elig = above && lane > consumed && vmask[idx] == 0;
+            const bool elig = above && lane > consumed && !masked;
             const unsigned long long bm = __ballot(elig);
             if (!bm) break;
             const int L = __ffsll((long long)bm) - 1;
-            const int pidx = __shfl(idx, L, 64);
+            const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
+            const int preach = __builtin_amdgcn_readlane(reach, L);
             ++num_largest;
             if (lane == 0) {
-              if (num_largest <= c.max_sharp) { slabel[pidx] = 2; my_pick[n_sharp] = pidx; }
+              if (num_largest <= c.max_sharp) { slabel[pidx] = 2; lpick[n_sharp] = pidx; }
               else slabel[pidx] = 1;
-              my_pick[cap_sharp + n_less] = pidx;
+              lpick[cap_sharp + n_less] = pidx;
             }
             if (num_largest <= c.max_sharp) ++n_sharp;
             ++n_less;
-            mask_picked(pidx);
+            apply_pick(pidx, preach, idx, masked);
             consumed = L;
           }
           if (__ballot(in && !above)) stop = true;  // sorted: nothing further down exceeds the threshold
@@ -267,32 +286,38 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         int num_smallest = 0;
         stop = false;
         for (int pos = 0; pos < region2 && num_smallest < c.max_flat && !stop; pos += 64) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           const int k = pos + lane;
           const bool in = k < region2;
           const unsigned long long e = in ? kk[k] : 0ull;
           const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
           const int idx = int(static_cast<unsigned int>(e));
           const bool below = in && (cv < c.curv_th);
+          bool masked = !below || vmask[idx] != 0;
+          const int reach = below ? int(snfb[idx]) : 0;
           int consumed = -1;
           while (num_smallest < c.max_flat) {
-            const bool elig = below && lane > consumed && vmask[idx] == 0;
+            const bool elig = below && lane > consumed && !masked;
             const unsigned long long bm = __ballot(elig);
             if (!bm) break;
             const int L = __ffsll((long long)bm) - 1;
-            const int pidx = __shfl(idx, L, 64);
+            const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
+            const int preach = __builtin_amdgcn_readlane(reach, L);
             ++num_smallest;
-            if (lane == 0) { slabel[pidx] = -1; my_pick[cap_sharp + cap_less + n_flat] = pidx; }
+            if (lane == 0) { slabel[pidx] = -1; lpick[cap_sharp + cap_less + n_flat] = pidx; }
             ++n_flat;
-            mask_picked(pidx);
+            apply_pick(pidx, preach, idx, masked);
             consumed = L;
           }
           if (__ballot(in && !below)) stop = true;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
     __syncthreads();
   }
   if (tid == 0) { pick_cnt[r * 3 + 0] = n_sharp; pick_cnt[r * 3 + 1] = n_less; pick_cnt[r * 3 + 2] = n_flat; }
+  for (int k = tid; k < cap_all; k += PP_PICK_THREADS) my_pick[k] = lpick[k];
   for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = scurv[i]; g_mask[base + i] = int(smask[i]); g_label[base + i] = slabel[i]; }
 }
 
@@ -459,7 +484,7 @@ void PointProcessorDev::Process(const float *xyzi, size_t n) {
   hipLaunchKernelGGL(k_ring_offsets, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, rings_, d_ring_offsets_.p);
   hipLaunchKernelGGL(k_ring_finalize, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, keys2_.p, vals2_.p, azi_.p, d_ring_offsets_.p, first_valid_.p,
                      rings_, cfg_.scan_period, ring_cloud_.p);
-  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 2);
+  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 4) + size_t(cap_all) * sizeof(int) + 64;
   hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
                      pick_idx_.p, pick_cnt_.p, d_counts_.p);
   hipLaunchKernelGGL(k_class_offsets, dim3(1), dim3(64), 0, s, pick_cnt_.p, rings_, class_off_.p, d_counts_.p);

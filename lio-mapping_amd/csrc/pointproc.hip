@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         const unsigned long long *kk = skey + w * PP_SORT_SLOTS;
         // corners: descending curvature
         int num_largest = 0;
+        int mine = -1;   // lane q keeps the q-th pick of this subregion; labels and lists are written once, after the chain
         bool stop = false;
         for (int pos = region2; pos > 0 && num_largest < c.max_less_sharp && !stop; pos -= 64) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -269,21 +270,23 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
             const int L = __ffsll((long long)bm) - 1;
             const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
             const int preach = __builtin_amdgcn_readlane(reach, L);
+            mine = (lane == num_largest) ? pidx : mine;
             ++num_largest;
-            if (lane == 0) {
-              if (num_largest <= c.max_sharp) { slabel[pidx] = 2; lpick[n_sharp] = pidx; }
-              else slabel[pidx] = 1;
-              lpick[cap_sharp + n_less] = pidx;
-            }
-            if (num_largest <= c.max_sharp) ++n_sharp;
-            ++n_less;
             apply_pick(pidx, preach, idx, masked);
             consumed = L;
           }
           if (__ballot(in && !above)) stop = true;  // sorted: nothing further down exceeds the threshold
         }
+        if (lane < num_largest) {
+          slabel[mine] = lane < c.max_sharp ? 2 : 1;
+          lpick[cap_sharp + n_less + lane] = mine;
+          if (lane < c.max_sharp) lpick[n_sharp + lane] = mine;
+        }
+        n_sharp += min(num_largest, c.max_sharp);
+        n_less += num_largest;
         // flats: ascending curvature
         int num_smallest = 0;
+        mine = -1;
         stop = false;
         for (int pos = 0; pos < region2 && num_smallest < c.max_flat && !stop; pos += 64) {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -303,14 +306,15 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
             const int L = __ffsll((long long)bm) - 1;
             const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
             const int preach = __builtin_amdgcn_readlane(reach, L);
+            mine = (lane == num_smallest) ? pidx : mine;
             ++num_smallest;
-            if (lane == 0) { slabel[pidx] = -1; lpick[cap_sharp + cap_less + n_flat] = pidx; }
-            ++n_flat;
             apply_pick(pidx, preach, idx, masked);
             consumed = L;
           }
           if (__ballot(in && !below)) stop = true;
         }
+        if (lane < num_smallest) { slabel[mine] = -1; lpick[cap_sharp + cap_less + n_flat + lane] = mine; }
+        n_flat += num_smallest;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }

@@ -629,7 +629,7 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
     }
   }
   if (size_t(B) * total_slots_ > size_t(INT_MAX)) return false;
-  const int nf = int(frames.size()), bpf = moment_blocks_per_frame(max_slots);
+  const int nf = int(frames.size()), bpf = moment_blocks_per_frame_batched(max_slots, nf);
   DBuf<MomentFrame> d_frames; DBuf<double> partials, out;
   d_frames.reserve(nf); partials.reserve(size_t(nf) * bpf * LIO_MOMENT_OUT); out.reserve(size_t(nf) * LIO_MOMENT_OUT);
   LIO_HIP(hipMemcpyAsync(d_frames.p, frames.data(), sizeof(MomentFrame) * nf, hipMemcpyHostToDevice, stream_));

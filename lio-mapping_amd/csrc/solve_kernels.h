@@ -37,6 +37,7 @@ struct MomentArgs {
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
                           hipStream_t s);
 int moment_blocks_per_frame(int max_slots);
+int moment_blocks_per_frame_batched(int max_slots, int nframes);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,
                                   double *partials, double *out, hipStream_t s);

@@ -7,6 +7,7 @@
 // the f64 MFMA does NOT use the f32 C/D map).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 
 #include "solve_kernels.h"
@@ -36,47 +37,58 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   double *zb = zbuf[wv];
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0, cnt = 0.0;
-  for (int base = fr.slot_begin + wid * 64; base < fr.slot_end; base += waves_total * 64) {
-    // ---- each lane: its own residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values)
+  // ---- per-lane residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values).  Branch-free (selects) so that
+  // the setup of chunk i+1 sits in the SAME basic block as the 16 dependent MFMAs of chunk i and the scheduler can fill the
+  // 64-cycle MFMA issue slots with it (software pipelining; the arithmetic and its order are unchanged).
+  auto setup = [&](int base, double (&z)[16], double &c_add, double &n_add) {
     const int sidx = base + lane;
-    double z[16];
+    const bool in = sidx < fr.slot_end;
+    const int si = in ? sidx : fr.slot_begin;  // a safe slot to load from when this lane has no residual
+    const bool ok = in && valid[fr.slot_off + si] != 0;
+    const float4 po = fr.stack[si % fr.M];
+    const float4 c = coef[fr.slot_off + si];
+    const double px = po.x, py = po.y, pz = po.z;
+    const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
+    const double qx = fr.R[0] * px + fr.R[1] * py + fr.R[2] * pz + fr.t[0];
+    const double qy = fr.R[3] * px + fr.R[4] * py + fr.R[5] * pz + fr.t[1];
+    const double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
+    const double r = w0 * qx + w1 * qy + w2 * qz + d;
+    const double sq = r * r;
+    const double inv = 1.0 / (1.0 + sq);  // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0 (only sqrt(rho') scaling)
+    const double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
+    const double sw = ok ? sqrt(rho1) : 0.0;
+    const double s0 = sw * w0, s1 = sw * w1, s2 = sw * w2;
+    z[0] = s0 * px; z[1] = s0 * py; z[2] = s0 * pz; z[3] = s0;
+    z[4] = s1 * px; z[5] = s1 * py; z[6] = s1 * pz; z[7] = s1;
+    z[8] = s2 * px; z[9] = s2 * py; z[10] = s2 * pz; z[11] = s2;
+    z[12] = sw * d; z[13] = 0.0; z[14] = 0.0; z[15] = 0.0;
+    c_add = ok ? 0.5 * log(1.0 + sq) : 0.0;
+    n_add = ok ? 1.0 : 0.0;
+  };
+  const int stride = waves_total * 64;
+  int base = fr.slot_begin + wid * 64;
+  if (base < fr.slot_end) {
+    double z[16], c_add, n_add;
+    setup(base, z, c_add, n_add);
+    for (; base < fr.slot_end; base += stride) {
+      cost += c_add; cnt += n_add;
+      // ---- transpose through LDS (wave-private rows; LDS executes a wave's DS ops in order)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) z[k] = 0.0;
-    if (sidx < fr.slot_end && valid[fr.slot_off + sidx]) {
-      float4 po = fr.stack[sidx % fr.M];
-      float4 c = coef[fr.slot_off + sidx];
-      double px = po.x, py = po.y, pz = po.z;
-      double w0 = c.x, w1 = c.y, w2 = c.z, d = c.w;
-      double qx = fr.R[0] * px + fr.R[1] * py + fr.R[2] * pz + fr.t[0];
-      double qy = fr.R[3] * px + fr.R[4] * py + fr.R[5] * pz + fr.t[1];
-      double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
-      double r = w0 * qx + w1 * qy + w2 * qz + d;
-      double sq = r * r;
-      double inv = 1.0 / (1.0 + sq);  // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0 (only sqrt(rho') scaling)
-      double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
-      double sw = sqrt(rho1);
-      double s0 = sw * w0, s1 = sw * w1, s2 = sw * w2;
-      z[0] = s0 * px; z[1] = s0 * py; z[2] = s0 * pz; z[3] = s0;
-      z[4] = s1 * px; z[5] = s1 * py; z[6] = s1 * pz; z[7] = s1;
-      z[8] = s2 * px; z[9] = s2 * py; z[10] = s2 * pz; z[11] = s2;
-      z[12] = sw * d;
-      cost += 0.5 * log(1.0 + sq);
-      cnt += 1.0;
+      for (int k = 0; k < 16; ++k) zb[lane * ZROW + k] = z[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- next chunk's setup (all lanes idle past the end: zeros) overlaps the MFMA chain below
+      setup(base + stride, z, c_add, n_add);
+      // ---- 16 MFMAs consume the 64 residuals: lane supplies element e of residual 4t+grp as A and B operand
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        double op = zb[(4 * t + grp) * ZROW + e];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op, op, acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    // ---- transpose through LDS (wave-private rows; LDS executes a wave's DS ops in order)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) zb[lane * ZROW + k] = z[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- 16 MFMAs consume the 64 residuals: lane supplies element e of residual 4t+grp as A and B operand
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      double op = zb[(4 * t + grp) * ZROW + e];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op, op, acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) sm[wv][(grp + 4 * r) * 16 + e] = acc[r];
@@ -147,6 +159,13 @@ __global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict_
   }
   for (; b < bpf; ++b) v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
   out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = (v0 + v1) + (v2 + v3);
+}
+
+int moment_blocks_per_frame_batched(int max_slots, int nframes) {
+  // enough waves to fill the chip about four times over, each with as many chunks as possible (the chunk loop is software
+  // pipelined: more chunks per wave = more MFMA issue slots filled with the next chunk's setup)
+  const int want = std::max(1, 2048 / std::max(nframes, 1));
+  return std::max(1, std::min(want, moment_blocks_per_frame(max_slots)));
 }
 
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,

@@ -635,9 +635,9 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
   LIO_HIP(hipMemcpyAsync(d_frames.p, frames.data(), sizeof(MomentFrame) * nf, hipMemcpyHostToDevice, stream_));
   hipEvent_t e0, e1;
   LIO_HIP(hipEventCreate(&e0)); LIO_HIP(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) launch_lidar_moments_batched(d_frames.p, nf, bpf, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  for (int w = 0; w < 2; ++w) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_);
   LIO_HIP(hipEventRecord(e0, stream_));
-  for (int r = 0; r < reps; ++r) launch_lidar_moments_batched(d_frames.p, nf, bpf, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  for (int r = 0; r < reps; ++r) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_);
   LIO_HIP(hipEventRecord(e1, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
   float ms = 0;

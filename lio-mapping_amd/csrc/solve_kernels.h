@@ -39,7 +39,7 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
 int moment_blocks_per_frame(int max_slots);
 int moment_blocks_per_frame_batched(int max_slots, int nframes);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
-void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,
-                                  double *partials, double *out, hipStream_t s);
+void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,
+                                  const float4 *coef, double *partials, double *out, hipStream_t s);
 
 }  // namespace lio

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
+#include <string>
 
 #include "solve_kernels.h"
 
@@ -18,11 +20,49 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define MOMENT_THREADS 256
 
+// Two kernels compute the same moments.  Measured on the MI355X (bench.py batched_kernel_roofline): with 2 chunks per wave
+// (one window) the MFMA kernel's launch is 10.5 us against 12.0 us (the register fold at the end of the VALU kernel is on the
+// critical path); from ~4 chunks per wave on the VALU kernel wins, 4.5 vs 3.4 TB/s algorithmic at 512 windows.
+// LIO_MOMENTS=mfma|valu forces one of them; default: by chunks per wave.
+static const int g_moments_mode = [] {
+  const char *e = std::getenv("LIO_MOMENTS");
+  if (e && std::string(e) == "mfma") return 1;
+  if (e && std::string(e) == "valu") return 2;
+  return 0;
+}();
+static bool use_mfma(int max_slots, int blocks_per_frame) {
+  if (g_moments_mode) return g_moments_mode == 1;
+  const int chunks_per_wave = cdiv(max_slots, blocks_per_frame * MOMENT_THREADS);
+  return chunks_per_wave < 4;
+}
+
 int moment_blocks_per_frame(int max_slots) {
   // one residual per lane, 256 residuals per block-iteration; aim for ~2 iterations per block
   int b = cdiv(max_slots, 256 * 2);
   return b < 1 ? 1 : (b > 64 ? 64 : b);
 }
+
+// Cauchy weight sqrt(rho') = (1 + s)^-1/2 from the hardware reciprocal-square-root estimate and two Newton steps (<= 2 ulp),
+// instead of a correctly rounded divide followed by a correctly rounded sqrt (~100 fp64 instructions at 4 cycles each).
+__device__ __forceinline__ double rsqrt_1p(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * __builtin_fma(-hx * y, y, 1.5);
+  y = y * __builtin_fma(-hx * y, y, 1.5);
+  return y;
+}
+// sum of log(1 + s_k) as the log of a running product (renormalised by 2^-400 before it can overflow): one multiply per
+// residual and ONE log per lane per launch instead of a ~150-instruction log per residual
+struct LogProduct {
+  double prod = 1.0, exp2 = 0.0;
+  __device__ __forceinline__ void mul(double f) {
+    prod *= f;
+    const bool big = prod > 0x1p+400;
+    prod = big ? prod * 0x1p-400 : prod;
+    exp2 += big ? 400.0 : 0.0;
+  }
+  __device__ __forceinline__ double log_value() const { return log(prod) + exp2 * 0.69314718055994530942; }
+};
 
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
@@ -37,6 +77,7 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   double *zb = zbuf[wv];
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0, cnt = 0.0;
+  LogProduct lp;
   // ---- per-lane residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values).  Branch-free (selects) so that
   // the setup of chunk i+1 sits in the SAME basic block as the 16 dependent MFMAs of chunk i and the scheduler can fill the
   // 64-cycle MFMA issue slots with it (software pipelining; the arithmetic and its order are unchanged).
@@ -54,15 +95,14 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
     const double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
     const double r = w0 * qx + w1 * qy + w2 * qz + d;
     const double sq = r * r;
-    const double inv = 1.0 / (1.0 + sq);  // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0 (only sqrt(rho') scaling)
-    const double rho1 = inv > DBL_MIN ? inv : DBL_MIN;
-    const double sw = ok ? sqrt(rho1) : 0.0;
+    // CauchyLoss(1): rho' = 1/(1+s); rho'' < 0 => alpha = 0 (only sqrt(rho') scaling)
+    const double sw = ok ? rsqrt_1p(1.0 + sq) : 0.0;
     const double s0 = sw * w0, s1 = sw * w1, s2 = sw * w2;
     z[0] = s0 * px; z[1] = s0 * py; z[2] = s0 * pz; z[3] = s0;
     z[4] = s1 * px; z[5] = s1 * py; z[6] = s1 * pz; z[7] = s1;
     z[8] = s2 * px; z[9] = s2 * py; z[10] = s2 * pz; z[11] = s2;
     z[12] = sw * d; z[13] = 0.0; z[14] = 0.0; z[15] = 0.0;
-    c_add = ok ? 0.5 * log(1.0 + sq) : 0.0;
+    c_add = ok ? 1.0 + sq : 1.0;   // factor of the running product; the log is taken once per lane at the end
     n_add = ok ? 1.0 : 0.0;
   };
   const int stride = waves_total * 64;
@@ -71,7 +111,7 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
     double z[16], c_add, n_add;
     setup(base, z, c_add, n_add);
     for (; base < fr.slot_end; base += stride) {
-      cost += c_add; cnt += n_add;
+      lp.mul(c_add); cnt += n_add;
       // ---- transpose through LDS (wave-private rows; LDS executes a wave's DS ops in order)
 #pragma unroll
       for (int k = 0; k < 16; ++k) zb[lane * ZROW + k] = z[k];
@@ -90,6 +130,7 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
       __builtin_amdgcn_wave_barrier();
     }
   }
+  cost = 0.5 * lp.log_value();
 #pragma unroll
   for (int r = 0; r < 4; ++r) sm[wv][(grp + 4 * r) * 16 + e] = acc[r];
   for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
@@ -131,6 +172,123 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (stream order)
 }
 
+// ------------------------------------------------------------------------------------------------
+// Structured form of the same moments, on the fp64 vector units.  z z^T has only 73 distinct entries:
+//   z = sw [w (x) ph ; d],  ph = (p, 1)   =>   S[(a,i),(b,j)] = (s_a s_b)(ph_i ph_j): 6 pairs (a<=b) x 10 pairs (i<=j) = 60,
+//   S[(a,i),12] = s_a (ph_i dd): 12,  S[12,12] = dd^2: 1.
+// Every lane keeps the 73 sums of ITS residuals in registers (73 FMAs per residual instead of the 16 MFMAs = 512 flop per
+// residual of the padded 16x16 product) and the block folds them once at the end through LDS.  Measured on gfx950 the fp64
+// MFMA does not overlap fp64 VALU work (both ~78.6 TF peak, and the pipelined MFMA kernel tops out at a third of it), so the
+// 3.5x fewer flops win whenever a wave has more than a couple of chunks.
+#define LIO_NACC 73
+#define RED_ROW (16 * 17 + 1)
+
+__device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                                       double *__restrict__ partials) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
+  const int wid = blockIdx.x * (MOMENT_THREADS / 64) + wv;
+  double a[LIO_NACC];
+#pragma unroll
+  for (int k = 0; k < LIO_NACC; ++k) a[k] = 0.0;
+  double cost = 0.0, cnt = 0.0;
+  LogProduct lp;
+  const int stride = waves_total * 64;
+  for (int base = fr.slot_begin + wid * 64; base < fr.slot_end; base += stride) {
+    const int sidx = base + lane;
+    const bool in = sidx < fr.slot_end;
+    const int si = in ? sidx : fr.slot_begin;
+    const bool ok = in && valid[fr.slot_off + si] != 0;
+    const float4 po = fr.stack[si % fr.M];
+    const float4 c = coef[fr.slot_off + si];
+    const double px = po.x, py = po.y, pz = po.z;
+    const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
+    const double qx = fr.R[0] * px + fr.R[1] * py + fr.R[2] * pz + fr.t[0];
+    const double qy = fr.R[3] * px + fr.R[4] * py + fr.R[5] * pz + fr.t[1];
+    const double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
+    const double r = w0 * qx + w1 * qy + w2 * qz + d;
+    const double sq = r * r;
+    const double sw = ok ? rsqrt_1p(1.0 + sq) : 0.0;
+    const double S[3] = {sw * w0, sw * w1, sw * w2};
+    const double dd = sw * d;
+    lp.mul(ok ? 1.0 + sq : 1.0);
+    cnt += ok ? 1.0 : 0.0;
+    const double P[10] = {px * px, px * py, px * pz, px, py * py, py * pz, py, pz * pz, pz, 1.0};
+    const double W[6] = {S[0] * S[0], S[0] * S[1], S[0] * S[2], S[1] * S[1], S[1] * S[2], S[2] * S[2]};
+    const double Q[4] = {px * dd, py * dd, pz * dd, dd};
+#pragma unroll
+    for (int ab = 0; ab < 6; ++ab)
+#pragma unroll
+      for (int ij = 0; ij < 10; ++ij) a[ab * 10 + ij] = __builtin_fma(W[ab], P[ij], a[ab * 10 + ij]);
+#pragma unroll
+    for (int sa = 0; sa < 3; ++sa)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[60 + sa * 4 + i] = __builtin_fma(S[sa], Q[i], a[60 + sa * 4 + i]);
+    a[72] = __builtin_fma(dd, dd, a[72]);
+  }
+  // ---- block fold, 16 accumulators at a time: [16][16 slices of 16 threads, padded to 17] then [16][16 slices]
+  __shared__ double red[16 * RED_ROW];
+  __shared__ double red2[16 * 17];
+  __shared__ double uniq[LIO_NACC + 2];
+  const int kk = tid & 15, sl = tid >> 4;
+#pragma unroll
+  for (int g = 0; g < (LIO_NACC + 15) / 16; ++g) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (g * 16 + k < LIO_NACC) red[k * RED_ROW + sl * 17 + kk] = a[g * 16 + k];
+    __syncthreads();
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += red[kk * RED_ROW + sl * 17 + j];
+    red2[kk * 17 + sl] = v;
+    __syncthreads();
+    if (tid < 16 && g * 16 + tid < LIO_NACC) {
+      double w = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w += red2[tid * 17 + q];
+      uniq[g * 16 + tid] = w;
+    }
+    __syncthreads();
+  }
+  __shared__ double cw[MOMENT_THREADS / 64][2];
+  cost = 0.5 * lp.log_value();
+  for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
+  if (lane == 0) { cw[wv][0] = cost; cw[wv][1] = cnt; }
+  __syncthreads();
+  double *dst = partials + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * LIO_MOMENT_OUT;
+  {
+    // expand the 73 sums into the row-major 16x16 layout the host expects (13x13 used, rest zero)
+    const int r = tid >> 4, cidx = tid & 15;
+    double v = 0.0;
+    if (r < 13 && cidx < 13) {
+      if (r == 12 && cidx == 12) v = uniq[72];
+      else if (r == 12 || cidx == 12) { const int u = r == 12 ? cidx : r; v = uniq[60 + u]; }
+      else {
+        const int ra = r >> 2, ri = r & 3, ca = cidx >> 2, ci = cidx & 3;
+        const int a0 = min(ra, ca), a1 = max(ra, ca), i0 = min(ri, ci), i1 = max(ri, ci);
+        const int ab = a0 == 0 ? a1 : (a0 == 1 ? 2 + a1 : 5);             // 00 01 02 11 12 22
+        const int ij = i0 == 0 ? i1 : (i0 == 1 ? 3 + i1 : (i0 == 2 ? 5 + i1 : 9));  // 00 01 02 03 11 12 13 22 23 33
+        v = uniq[ab * 10 + ij];
+      }
+    }
+    dst[tid] = v;
+    if (tid < 2) {
+      double w = 0.0;
+      for (int q = 0; q < MOMENT_THREADS / 64; ++q) w += cw[q][tid];
+      dst[256 + tid] = w;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_sym(MomentArgs a, const uint8_t *__restrict__ valid,
+                                                                      const float4 *__restrict__ coef, double *__restrict__ partials) {
+  lidar_moments_sym_body(a.fr[blockIdx.y], valid, coef, partials);
+}
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_sym_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
+                                                                              const float4 *__restrict__ coef, double *__restrict__ partials) {
+  lidar_moments_sym_body(frames[blockIdx.y], valid, coef, partials);
+}
+
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
                                                                   const float4 *__restrict__ coef, double *__restrict__ partials,
                                                                   int *__restrict__ tickets, double *__restrict__ out) {
@@ -168,10 +326,13 @@ int moment_blocks_per_frame_batched(int max_slots, int nframes) {
   return std::max(1, std::min(want, moment_blocks_per_frame(max_slots)));
 }
 
-void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, const uint8_t *valid, const float4 *coef,
-                                  double *partials, double *out, hipStream_t s) {
+void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,
+                                  const float4 *coef, double *partials, double *out, hipStream_t s) {
   if (nframes <= 0) return;
-  hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
+  if (use_mfma(max_slots, blocks_per_frame))
+    hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
+  else
+    hipLaunchKernelGGL(k_lidar_moments_sym_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
   hipLaunchKernelGGL(k_moment_reduce, dim3(nframes), dim3(320), 0, s, partials, blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }
@@ -179,7 +340,12 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
                           hipStream_t s) {
   if (a.nframes <= 0) return;
-  hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out);
+  int max_slots = 0;
+  for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
+  if (tickets || use_mfma(max_slots, a.blocks_per_frame))
+    hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out);
+  else
+    hipLaunchKernelGGL(k_lidar_moments_sym, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
   if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }

@@ -702,7 +702,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   Linearization first;
   {
     Layout lay = WindowSystem::solve_layout(P);
-    first.costs = sys.evaluate(P, lay, 1 | 2 | 4 | 8, false, &first.H, &first.g);
+    first.costs = sys.evaluate(P, lay, 1 | 2 | 4 | 8, false, &first.H, &first.g, &first.m);
     first.valid = true;
     const WindowSystem::Costs &gc = first.costs;
     R.cost_pim_before = gc.pim; R.cost_ppp_before = gc.ppp; R.cost_marg_before = gc.marg;
@@ -740,6 +740,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     }
     msys.prior = last_marg_;
     msys.lidar_eval = sys.lidar_eval; msys.lidar_launch = sys.lidar_launch; msys.lidar_wait = sys.lidar_wait;
+    if (msys.use_lidar && !s.final_moments.empty()) msys.preset_moments = &s.final_moments;  // no second device pass at the same point
     last_marg_ = marginalize(msys, M);
     R.marginalized = 1;
     R.ms_marg = now_ms() - tm0;

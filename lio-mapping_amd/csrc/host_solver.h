@@ -119,6 +119,10 @@ class WindowSystem {
   // split form: launch the device pass first, overlap the host-side prior / IMU factors with it, then collect
   std::function<void(const WindowParams &)> lidar_launch;
   std::function<void(std::vector<FrameMoments> &)> lidar_wait;
+  // moments already known for the parameters of the NEXT evaluate call (consumed by it): the marginalization linearises
+  // at the point the solver stopped at, whose lidar moments its last accepted step computed — they depend only on the relative
+  // poses T_{pivot<-i} and the extrinsic, which the yaw re-anchoring of DoubleToVector leaves unchanged
+  const std::vector<FrameMoments> *preset_moments = nullptr;
 
   struct Costs { double marg = 0, pim = 0, ppp = 0, prior = 0; double total() const { return marg + pim + ppp + prior; } };
 
@@ -166,10 +170,14 @@ class WindowSystem {
   }
 
   // which: bit0 prior, bit1 imu, bit2 lidar, bit3 extrinsic prior.  H/g may be null (cost only).
-  Costs evaluate(const WindowParams &P, const Layout &lay, int which, bool imu_only_first, DMat *H, std::vector<double> *g) {
+  Costs evaluate(const WindowParams &P, const Layout &lay, int which, bool imu_only_first, DMat *H, std::vector<double> *g,
+                 std::vector<FrameMoments> *m_out = nullptr) {
     Costs c;
     const bool lidar_on = (which & 4) && use_lidar;
-    const bool split = lidar_on && lidar_launch && lidar_wait;
+    const std::vector<FrameMoments> *preset = preset_moments;
+    preset_moments = nullptr;
+    if (preset && int(preset->size()) != Wo + 1) preset = nullptr;
+    const bool split = lidar_on && !preset && lidar_launch && lidar_wait;
     if (split) lidar_launch(P);  // asynchronous: the kernels run while the host evaluates the prior and the IMU factors
     if (H) { *H = DMat(lay.dim, lay.dim); g->assign(lay.dim, 0.0); }
     if ((which & 1) && prior) {
@@ -233,9 +241,10 @@ class WindowSystem {
         }
       }
     }
-    if (lidar_on && (split || lidar_eval)) {
+    if (lidar_on && (preset || split || lidar_eval)) {
       std::vector<FrameMoments> m(Wo + 1);
-      if (split) lidar_wait(m); else lidar_eval(P, m);
+      if (preset) m = *preset; else if (split) lidar_wait(m); else lidar_eval(P, m);
+      if (m_out) *m_out = m;
       for (int i = 1; i <= Wo; ++i) {
         c.ppp += m[i].cost;
         if (!H || m[i].count == 0) continue;
@@ -287,6 +296,7 @@ struct SolveSummary {
   double initial_cost = 0, final_cost = 0;
   std::vector<double> trace;
   double ms_chol = 0, ms_eval = 0;  // LIO_DEBUG_TIMING breakdown
+  std::vector<FrameMoments> final_moments;  // lidar moments at the point the solver stopped at
   WindowSystem::Costs initial_costs;
 };
 
@@ -311,7 +321,7 @@ inline double ambient_norm(const WindowParams &P, const WindowParams *o, double 
 
 // Ceres 1.14 TrustRegionMinimizer + DoglegStrategy (TRADITIONAL_DOGLEG), jacobi_scaling = true.
 // first_eval (optional) lets the caller reuse the linearisation it already made for the group costs.
-struct Linearization { DMat H; std::vector<double> g; WindowSystem::Costs costs; bool valid = false; };
+struct Linearization { DMat H; std::vector<double> g; WindowSystem::Costs costs; std::vector<FrameMoments> m; bool valid = false; };
 
 inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_iterations, double max_time_s, Linearization *first = nullptr) {
   using clock = std::chrono::steady_clock;
@@ -321,9 +331,10 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   Layout lay = WindowSystem::solve_layout(P);
   const int n = lay.dim;
   DMat H; std::vector<double> g;
+  std::vector<FrameMoments> m_cur, m_cand;  // lidar moments at the current point / at the candidate
   WindowSystem::Costs c0;
-  if (first && first->valid && first->H.r == n) { H = std::move(first->H); g = std::move(first->g); c0 = first->costs; }
-  else c0 = sys.evaluate(P, lay, which, false, &H, &g);
+  if (first && first->valid && first->H.r == n) { H = std::move(first->H); g = std::move(first->g); c0 = first->costs; m_cur = std::move(first->m); }
+  else c0 = sys.evaluate(P, lay, which, false, &H, &g, &m_cur);
   sum.initial_costs = c0;
   double x_cost = c0.total();
   sum.initial_cost = x_cost; sum.trace.push_back(x_cost);
@@ -419,7 +430,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     // Jacobian evaluation Ceres performs next (HandleSuccessfulStep) is already done.
     DMat Hc; std::vector<double> gc;
     const auto te0 = clock::now();
-    double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc).total();
+    double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc, &m_cand).total();
     sum.ms_eval += std::chrono::duration<double, std::milli>(clock::now() - te0).count();
     double step_norm = ambient_norm(P, &cand);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 1; sum.trace.push_back(x_cost); break; }
@@ -431,6 +442,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       x_norm = ambient_norm(P, nullptr);
       x_cost = cand_cost;
       H = std::move(Hc); g = std::move(gc);
+      m_cur.swap(m_cand);
       gmax = grad_max(g);
       apply_scale(H, g);
       ++sum.successful;
@@ -445,6 +457,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   }
   sum.iterations = it;
   sum.final_cost = x_cost;
+  sum.final_moments = std::move(m_cur);
   return sum;
 }
 

@@ -179,7 +179,10 @@ class WindowSystem {
     if (preset && int(preset->size()) != Wo + 1) preset = nullptr;
     const bool split = lidar_on && !preset && lidar_launch && lidar_wait;
     if (split) lidar_launch(P);  // asynchronous: the kernels run while the host evaluates the prior and the IMU factors
-    if (H) { *H = DMat(lay.dim, lay.dim); g->assign(lay.dim, 0.0); }
+    if (H) {
+      if (H->r == lay.dim && H->c == lay.dim) H->zero(); else *H = DMat(lay.dim, lay.dim);  // the dogleg loop recycles two buffers
+      g->assign(lay.dim, 0.0);
+    }
     if ((which & 1) && prior) {
       const MargPrior &pr = *prior;
       std::vector<double> dx;
@@ -359,6 +362,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   std::vector<double> diag(n), grad(n), gn(n), step(n), tmp(n);
   std::vector<double> A(size_t(n) * n);
   int invalid = 0, it = 0;
+  DMat Hc; std::vector<double> gc;  // candidate linearisation; swapped with (H, g) on acceptance, never reallocated
   while (true) {
     if (it >= max_iterations) { sum.termination = 0; break; }
     if (max_time_s > 0 && std::chrono::duration<double>(clock::now() - t0).count() >= max_time_s) { sum.termination = 4; break; }
@@ -428,7 +432,6 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     plus_all(P, lay, delta, cand);
     // Evaluate cost AND linearisation at the candidate in one device pass: if the step is accepted the
     // Jacobian evaluation Ceres performs next (HandleSuccessfulStep) is already done.
-    DMat Hc; std::vector<double> gc;
     const auto te0 = clock::now();
     double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc, &m_cand).total();
     sum.ms_eval += std::chrono::duration<double, std::milli>(clock::now() - te0).count();
@@ -441,7 +444,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       P = cand;
       x_norm = ambient_norm(P, nullptr);
       x_cost = cand_cost;
-      H = std::move(Hc); g = std::move(gc);
+      std::swap(H, Hc); g.swap(gc);
       m_cur.swap(m_cand);
       gmax = grad_max(g);
       apply_scale(H, g);

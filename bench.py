@@ -188,7 +188,7 @@ def main():
 
         # the dominant kernel given B windows of work in one launch
         batched_kernel = None
-        if not args.shard_factors:
+        if not args.shard_factors and world == 1:
             batched_kernel = []
             for B in (1, 8, 64, 512):
                 ms_b, bytes_b = est.bench_batched_moments(B, 20)
@@ -197,12 +197,12 @@ def main():
                                        "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
                                        "mfma_f64_GFLOPs": round(bytes_b / 60.0 * 684.0 / (ms_b * 1e-3) / 1e9, 1)})
         batched = None
-        if args.windows > 1 and not args.shard_factors:
+        if args.windows > 1 and not args.shard_factors and world == 1:
             batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
 
         odom_ms, packer_ms = odometry_ms_per_scan(hip, ds) if kind == "outdoor" else (None, None)
         map_stats = mapping_ms_per_scan(hip, ds, clouds)
-        cpu = None if args.no_cpu_baseline else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)  # N = 1 only
         odom_io = 3 if kind == "outdoor" else 2
         pp_med = float(np.median(pp_ms[1:]))
         out = {
@@ -261,12 +261,16 @@ def main():
 
 def batched_throughput(hip, ds, clouds, kind, W, Wo, est0, n_windows, steps):
     """B independent windows (same data, separate estimators / HIP streams / host threads) in flight on ONE GPU."""
+    import torch
+
+    dev = torch.cuda.current_device()
     ests = [est0] + [make_estimator(hip, ds, clouds, kind, W, Wo) for _ in range(n_windows - 1)]
     for e in ests:
         one_step(e)
     bar = threading.Barrier(n_windows + 1)
 
     def run(e):
+        torch.cuda.set_device(dev)  # a new host thread starts on device 0
         bar.wait()
         for _ in range(steps):
             one_step(e)

@@ -51,6 +51,7 @@ class PointProcessorDev {
   DBuf<int8_t> label_;
   DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_, class_off_;
   DBuf<float> lf_bounds_;
+  DBuf<int> lf_ring_count_;
   DBuf<PPDeviceCounts> d_counts_;
   DBuf<char> tmp_;
 };

@@ -437,6 +437,152 @@ __global__ void k_lf_centroids(const float4 *__restrict__ ring_cloud, const unsi
   out[pos[i]] = o;
 }
 
+// One workgroup per ring does the whole per-ring VoxelGrid in LDS: bounds, (voxel, index) keys, a bitonic sort sized to
+// the ring, run heads, a block scan and the centroids (+ the rel-time recompute of :755-778), written to the ring's own
+// segment of a staging cloud; k_lf_compact then packs the segments in ring order.  Two launches instead of bounds + keys +
+// a 64-bit device-wide sort (block sort and eight merge passes at this size) + heads + scan + centroids.
+#define PP_LF_THREADS 512
+__global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets,
+                                                           const int8_t *__restrict__ label, float inv_leaf, const float *__restrict__ azi,
+                                                           const int *__restrict__ first_valid, double scan_period, float4 *__restrict__ staged,
+                                                           int *__restrict__ ring_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int base = offsets[r], n = offsets[r + 1] - base;
+  if (n <= 0 || n > LIO_PP_MAX_RING_POINTS) { if (tid == 0) ring_count[r] = 0; return; }
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem);            // up to 4096 keys
+  float4 *spt = reinterpret_cast<float4 *>(smem + size_t(4096) * 8);                   // n points
+  int *spos = reinterpret_cast<int *>(smem + size_t(4096) * 8 + size_t(4096) * 16);     // flags -> positions
+  __shared__ float sb[PP_LF_THREADS / 64][6];
+  __shared__ int swave[PP_LF_THREADS / 64];
+  __shared__ int s_members;
+  const int lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_members = 0;
+  // ---- load + bounds of the less-flat members (label <= 0, A.5)
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = tid; i < n; i += PP_LF_THREADS) {
+    const float4 p = ring_cloud[base + i];
+    spt[i] = p;
+    if (label[base + i] <= 0) {
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64)); }
+  if (lane == 0) for (int d = 0; d < 3; ++d) { sb[wv][d] = mn[d]; sb[wv][3 + d] = mx[d]; }
+  __syncthreads();
+  for (int w = 0; w < PP_LF_THREADS / 64; ++w)
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], sb[w][d]); mx[d] = fmaxf(mx[d], sb[w][3 + d]); }
+  const int minb0 = int(floorf(mn[0] * inv_leaf)), minb1 = int(floorf(mn[1] * inv_leaf)), minb2 = int(floorf(mn[2] * inv_leaf));
+  const int div0 = int(floorf(mx[0] * inv_leaf)) - minb0 + 1, div1 = int(floorf(mx[1] * inv_leaf)) - minb1 + 1;
+  // ---- keys of the members only, in any order: voxel index (pcl::VoxelGrid, B.1) in the high word, index in the ring in the
+  // low word => unique keys, and the members of a voxel come out in ascending index (the summation order the oracle fixes)
+  for (int i = tid; i < n; i += PP_LF_THREADS) {
+    if (label[base + i] <= 0) {
+      const float4 p = spt[i];
+      const int i0 = int(floorf(p.x * inv_leaf) - float(minb0));
+      const int i1 = int(floorf(p.y * inv_leaf) - float(minb1));
+      const int i2 = int(floorf(p.z * inv_leaf) - float(minb2));
+      const unsigned int vk = static_cast<unsigned int>(i0 + i1 * div0 + i2 * div0 * div1);
+      skey[atomicAdd(&s_members, 1)] = (static_cast<unsigned long long>(vk) << 32) | static_cast<unsigned int>(i);
+    }
+  }
+  __syncthreads();
+  const int members = s_members;
+  int NS = 128;
+  while (NS < members) NS <<= 1;                             // sort size: next power of two
+  for (int i = members + tid; i < NS; i += PP_LF_THREADS) skey[i] = ~0ull;
+  __syncthreads();
+  // bitonic sort.  Strides <= 64 only move keys inside 128-key chunks, and a chunk is handled by one wave: those stages are
+  // ordered by a wave-level fence; only the strides >= 128 need the block barrier (10 of the 66 stages at 2048 keys).
+  auto exchange = [&](int t, int size, int stride) {
+    const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+    const bool up = ((lo & size) == 0);
+    const unsigned long long a = skey[lo], b = skey[hi];
+    if ((a > b) == up) { skey[lo] = b; skey[hi] = a; }
+  };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int nchunks = NS / 128;
+  for (int c = wv; c < nchunks; c += PP_LF_THREADS / 64)
+    for (int size = 2; size <= 128; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) { exchange(c * 64 + lane, size, stride); wave_sync(); }
+  __syncthreads();
+  for (int size = 256; size <= NS; size <<= 1) {
+    for (int stride = size >> 1; stride >= 128; stride >>= 1) {
+      for (int t = tid; t < NS / 2; t += PP_LF_THREADS) exchange(t, size, stride);
+      __syncthreads();
+    }
+    for (int c = wv; c < nchunks; c += PP_LF_THREADS / 64)
+      for (int stride = 64; stride > 0; stride >>= 1) { exchange(c * 64 + lane, size, stride); wave_sync(); }
+    __syncthreads();
+  }
+  // ---- run heads and their exclusive positions (block scan: per-thread serial over a contiguous slice, then across threads)
+  const int per = NS / PP_LF_THREADS > 0 ? NS / PP_LF_THREADS : 1;
+  int local = 0;
+  for (int q = 0; q < per; ++q) {
+    const int i = tid * per + q;
+    if (i < NS) {
+      const unsigned long long k = skey[i];
+      const bool head = k != ~0ull && (i == 0 || (skey[i - 1] >> 32) != (k >> 32));
+      spos[i] = head ? 1 : 0;
+      local += head ? 1 : 0;
+    }
+  }
+  // inclusive scan of `local` over the block (wave shuffles + one LDS hop)
+  int incl = local;
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) swave[wv] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wv; ++w) wave_off += swave[w];
+  int run = wave_off + incl - local;   // exclusive prefix of this thread's slice
+  int total = 0;
+  for (int w = 0; w < PP_LF_THREADS / 64; ++w) total += swave[w];
+  for (int q = 0; q < per; ++q) {
+    const int i = tid * per + q;
+    if (i < NS) { const int f = spos[i]; spos[i] = f ? run : -1; run += f; }
+  }
+  __syncthreads();
+  // ---- centroids
+  const float start_ori = azi[*first_valid];
+  for (int i = tid; i < NS; i += PP_LF_THREADS) {
+    const int pos = spos[i];
+    if (pos < 0) continue;
+    const unsigned int vk = static_cast<unsigned int>(skey[i] >> 32);
+    float ax = 0, ay = 0, az = 0, ai = 0;
+    int e = i;
+    while (e < NS && skey[e] != ~0ull && static_cast<unsigned int>(skey[e] >> 32) == vk) {
+      const float4 p = spt[static_cast<unsigned int>(skey[e])];
+      ax += p.x; ay += p.y; az += p.z; ai += p.w;
+      ++e;
+    }
+    const float cnt = float(e - i);
+    float4 o = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
+    const float a = azimuth_of(o.x, o.y);
+    float rel = a - start_ori;
+    if (rel < 0) rel = float(double(rel) + 2 * M_PI);
+    const float rel_time = float(scan_period * double(rel) / (2 * M_PI));
+    o.w = float(int(o.w)) + rel_time;
+    staged[base + pos] = o;
+  }
+  if (tid == 0) ring_count[r] = total;
+}
+
+__global__ void k_lf_compact(const float4 *__restrict__ staged, const int *__restrict__ offsets, const int *__restrict__ ring_count, int rings,
+                             float4 *__restrict__ out, PPDeviceCounts *counts) {
+  const int r = blockIdx.x;
+  int dst = 0;
+  for (int q = 0; q < r; ++q) dst += ring_count[q];
+  const int cnt = ring_count[r], src = offsets[r];
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) out[dst + k] = staged[src + k];
+  if (r == rings - 1 && threadIdx.x == 0) counts->n_less_flat = dst + cnt;
+}
+
 // ------------------------------------------------------------------------------------------------
 PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg)
     : lower_(lower), upper_(upper), rings_(rings), cfg_(cfg) {
@@ -448,6 +594,7 @@ PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const 
   ring_offsets_.assign(rings + 1, 0);
   // the pick kernel needs up to ~104 KB of dynamic LDS
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lf_ring), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
 }
 PointProcessorDev::~PointProcessorDev() {
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -496,15 +643,11 @@ void PointProcessorDev::Process(const float *xyzi, size_t n) {
                      class_ring_.p, class_idx_.p, class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total);
   // less-flat
   const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
-  hipLaunchKernelGGL(k_lf_bounds, dim3(rings_), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, lf_bounds_.p);
-  LIO_HIP(hipMemsetAsync(k64_.p, 0xFF, n * sizeof(uint64_t), s));
-  hipLaunchKernelGGL(k_lf_keys, dim3(cdiv(LIO_PP_MAX_RING_POINTS, 256), rings_), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, label_.p,
-                     lf_bounds_.p, inv_leaf, reinterpret_cast<unsigned long long *>(k64_.p), vals_.p);
-  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tb2, k64_.p, k64b_.p, vals_.p, vals2_.p, n, 0, 40, s));
-  hipLaunchKernelGGL(k_lf_heads, dim3(cdiv(ni, 256)), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(k64b_.p), ni, flags_.p);
-  LIO_HIP(rocprim::exclusive_scan(tmp_.p, tb3, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
-  hipLaunchKernelGGL(k_lf_centroids, dim3(cdiv(ni, 256)), dim3(256), 0, s, ring_cloud_.p, reinterpret_cast<unsigned long long *>(k64b_.p), vals2_.p,
-                     flags_.p, pos_.p, ni, azi_.p, first_valid_.p, cfg_.scan_period, less_flat_.p, d_counts_.p);
+  lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);
+  const size_t lf_lds = size_t(4096) * 8 + size_t(4096) * 16 + size_t(4096) * 4;
+  hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, inv_leaf, azi_.p,
+                     first_valid_.p, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
+  hipLaunchKernelGGL(k_lf_compact, dim3(rings_), dim3(256), 0, s, lf_tmp_.p, d_ring_offsets_.p, lf_ring_count_.p, rings_, less_flat_.p, d_counts_.p);
   LIO_HIP(hipGetLastError());
   LIO_HIP(hipMemcpyAsync(&counts_, d_counts_.p, sizeof(counts_), hipMemcpyDeviceToHost, s));
   LIO_HIP(hipMemcpyAsync(ring_offsets_.data(), d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));

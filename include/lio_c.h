@@ -169,6 +169,32 @@ size_t lio_map_get_cube_state(const lio_map *, int cube_center_out[3], uint32_t 
 size_t lio_map_get_score_point_coeff(const lio_map *, float *score_or_null, float *point_xyzi_or_null, float *coeff_or_null);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batched keyframe refinement (BASELINE.json configs[4]).  No reference
+ * counterpart as an API: the unit of work is the reference's scan-to-map Gauss-Newton loop —
+ * MapBuilder::OptimizeMap (MapBuilder.cc:624-1014; 4-DoF, when cfg.map_builder && cfg.enable_4d) or
+ * PointMapping::OptimizeTransformTobeMapped (PointMapping.cc:325-753; 6-DoF otherwise) — run once per keyframe
+ * against that keyframe's local map.  Keyframes are independent; a handle refines all of its keyframes together.
+ * Sharding over GPUs = sharding the keyframe list (one handle per rank); the only exchange is a gather of poses.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lio_kf_batch lio_kf_batch;
+lio_kf_batch *lio_kf_batch_create(const lio_map_config *cfg_or_null);
+void lio_kf_batch_destroy(lio_kf_batch *);
+/* A local map = laser_cloud_corner_from_map_ / laser_cloud_surf_from_map_ (map frame).  Returns its index (>= 0) or
+ * a negative error code.  The buffers are copied. */
+int lio_kf_batch_add_map(lio_kf_batch *, const float *corner_xyzi, size_t n_corner, const float *surf_xyzi, size_t n_surf);
+/* A keyframe = its down-sampled feature stacks in the lidar frame (laser_cloud_{corner,surf}_stack_downsampled_), the
+ * local map it refines against, and its initial transform_tobe_mapped_.  Returns its index (>= 0) or an error code. */
+int lio_kf_batch_add_keyframe(lio_kf_batch *, int map_index, const float *corner_xyzi, size_t n_corner, const float *surf_xyzi,
+                              size_t n_surf, const lio_transform_f *T_init);
+int lio_kf_batch_clear_keyframes(lio_kf_batch *);
+/* Refines every keyframe from its T_init (repeatable).  Outputs are arrays of n_keyframes entries, each optional:
+ * the refined transform, the iterations run (0 when the map is too small, :327-329) and the rows of the last round.
+ * device_ms_or_null (HIP library only; 0 from the oracle) = device time of the round loop. */
+int lio_kf_batch_refine(lio_kf_batch *, lio_transform_f *T_out_or_null, int32_t *iterations_or_null, int32_t *rows_or_null,
+                        double *device_ms_or_null);
+size_t lio_kf_batch_size(const lio_kf_batch *);
+
+/* ------------------------------------------------------------------------------------------------
  * Stateless building blocks (third-party semantics restated)
  * ---------------------------------------------------------------------------------------------- */
 /* pcl::VoxelGrid<PointXYZI> (B.1): centroids in ascending voxel index; out capacity n points.   */

@@ -8,6 +8,7 @@
 #include "../../include/lio_c.h"
 #include "estimator.h"
 #include "host_init.h"
+#include "kf_batch.h"
 #include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
@@ -236,6 +237,52 @@ size_t lio_map_get_score_point_coeff(const lio_map *h, float *score, float *poin
   size_t n = 0;
   guarded([&] { n = h->m->GetScorePointCoeff(score, point, coeff); return LIO_OK; });
   return n;
+}
+
+// ---------------------------------------------------------------- batched keyframe refinement
+struct lio_kf_batch { std::unique_ptr<KfBatchDev> b; };
+lio_kf_batch *lio_kf_batch_create(const lio_map_config *c) {
+  lio_map_config cfg;
+  if (c) cfg = *c; else lio_map_default_config(&cfg);
+  if (cfg.num_max_iterations < 1) return nullptr;
+  lio_kf_batch *h = new (std::nothrow) lio_kf_batch;
+  if (!h) return nullptr;
+  int rc = guarded([&] { h->b.reset(new KfBatchDev(cfg)); return LIO_OK; });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  return h;
+}
+void lio_kf_batch_destroy(lio_kf_batch *h) { delete h; }
+int lio_kf_batch_add_map(lio_kf_batch *h, const float *corner, size_t nc, const float *surf, size_t ns) {
+  if (!h || (!corner && nc) || (!surf && ns)) return LIO_ERR_ARG;
+  int idx = -1;
+  int rc = guarded([&] { idx = h->b->AddMap(corner, nc, surf, ns); return LIO_OK; });
+  return rc == LIO_OK ? idx : rc;
+}
+int lio_kf_batch_add_keyframe(lio_kf_batch *h, int map, const float *corner, size_t nc, const float *surf, size_t ns, const lio_transform_f *T) {
+  if (!h || !T || (!corner && nc) || (!surf && ns) || map < 0 || size_t(map) >= h->b->n_maps()) return LIO_ERR_ARG;
+  int idx = -1;
+  int rc = guarded([&] { idx = h->b->AddKeyframe(map, corner, nc, surf, ns, toT(*T)); return LIO_OK; });
+  return rc == LIO_OK ? idx : rc;
+}
+int lio_kf_batch_clear_keyframes(lio_kf_batch *h) {
+  if (!h) return LIO_ERR_ARG;
+  h->b->ClearKeyframes();
+  return LIO_OK;
+}
+size_t lio_kf_batch_size(const lio_kf_batch *h) { return h ? h->b->n_keyframes() : 0; }
+int lio_kf_batch_refine(lio_kf_batch *h, lio_transform_f *T_out, int32_t *iters, int32_t *rows, double *device_ms) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] {
+    h->b->Refine();
+    const auto &st = h->b->states();
+    for (size_t k = 0; k < st.size(); ++k) {
+      if (T_out) fromT(Rigidf(Quat<float>(st[k].T[3], st[k].T[0], st[k].T[1], st[k].T[2]), Vec3<float>(st[k].T[4], st[k].T[5], st[k].T[6])), &T_out[k]);
+      if (iters) iters[k] = st[k].iters;
+      if (rows) rows[k] = st[k].nsel;
+    }
+    if (device_ms) *device_ms = h->b->device_ms_;
+    return LIO_OK;
+  });
 }
 
 // ---------------------------------------------------------------- /compact_data codec (host: a memcpy-class wire format)

@@ -123,6 +123,28 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
 void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0, int left_update = 0);
 int odom_rows_blocks(int nslots);
 
+// ---- batched keyframe refinement (config 5: B independent OptimizeMap / OptimizeTransformTobeMapped loops, MapBuilder.cc:624-1014,
+// PointMapping.cc:325-753).  Slots of keyframe k = [slot_off, slot_off + Mc) corner, then Ms surf, in one concatenated stack.
+struct KfDesc {
+  int slot_off, Mc, Ms;
+  int map;          // index into the KfMapDesc array
+  int nb;           // row-reduction blocks of this keyframe (= odom_rows_blocks(Mc + Ms), as in the single-keyframe path)
+  int part_off;     // first partial row (28 doubles each)
+  float pz[3];      // point_on_z_axis_ fixed before the iterations
+};
+struct KfMapDesc {
+  const float4 *corner_sorted; const int *corner_cells; GridDesc corner_grid;
+  const float4 *surf_sorted; const int *surf_cells; GridDesc surf_grid;
+};
+// grid z limit: n_keyframes <= 65535 per launch
+void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all,
+                     float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s);
+void launch_kf_rows(const KfDesc *kd, const OdomState *st, int n_keyframes, int max_nb, const float4 *stack_all, const uint8_t *valid, const float4 *coef,
+                    double *partials, int b_from_coef, hipStream_t s);
+// n_converged (device int) is incremented once per keyframe when it converges
+void launch_kf_update(const KfDesc *kd, OdomState *st, int n_keyframes, const double *partials, int iter, int min_rows, int left_update, int *n_converged,
+                      hipStream_t s);
+
 #if defined(__HIPCC__)
 // Fixed-order sum of `nblocks` rows of 28 doubles by a 256-thread block: 8 groups of 32 lanes take the rows b = g (mod 8)
 // in ascending order, then the 8 group sums are added in ascending g.  (One lane per column walking all rows issues

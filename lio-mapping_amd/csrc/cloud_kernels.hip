@@ -442,12 +442,15 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
   }
 }
 
+struct FeatScalars { float min_match_sq_dis, min_plane_dis; int mapping_mode; float fixed_pz[3]; };
+__device__ __forceinline__ FeatScalars feat_scalars(const FeatArgs &a) {
+  return FeatScalars{a.min_match_sq_dis, a.min_plane_dis, a.mapping_mode, {a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]}};
+}
 template <bool MAPPING, int LPQ>
-__device__ __forceinline__ void features_body(const FeatArgs &a, int frame, int block_x, const float *__restrict__ transforms,
+__device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
                                               const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
                                               uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
                                               float4 *__restrict__ abs_coef) {
-  const FeatFrame fr = a.fr[frame];
   const int gt = block_x * blockDim.x + threadIdx.x;
   const int i = gt / LPQ, sub = gt % LPQ;
   const bool active = i < fr.M;
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
                                                  float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
                                                  float4 *__restrict__ abs_coef) {
   if (skip_flag && *skip_flag) return;
-  features_body<MAPPING, LPQ>(a, blockIdx.y, blockIdx.x, transforms, map, cells, g, valid, coef, score, abs_coef);
+  features_body<MAPPING, LPQ>(a.fr[blockIdx.y], feat_scalars(a), blockIdx.x, transforms, map, cells, g, valid, coef, score, abs_coef);
 }
 
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
@@ -613,7 +616,7 @@ __global__ void __launch_bounds__(128) k_map_round(FeatArgs a, MapRoundArgs m, c
                        m.corner_map, m.corner_cells, m.corner_grid, valid, coef);
   } else {
     if (int(blockIdx.x) >= m.blocks_surf) return;
-    features_body<true, 8>(a, 0, blockIdx.x, tp, m.surf_map, m.surf_cells, m.surf_grid, valid, coef, nullptr, abs_coef);
+    features_body<true, 8>(a.fr[0], feat_scalars(a), blockIdx.x, tp, m.surf_map, m.surf_cells, m.surf_grid, valid, coef, nullptr, abs_coef);
   }
 }
 
@@ -659,11 +662,9 @@ void launch_features(const FeatArgs &a, const float *transforms, const float4 *m
 #define ODOM_ROW_THREADS 256
 int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM_ROW_THREADS * 2), 256)); }
 
-__global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__restrict__ stack, int M, int nslots,
-                                                                const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                                const OdomState *__restrict__ st, double *__restrict__ partials,
-                                                                int b_from_coef) {
-  if (st->converged) return;
+__device__ __forceinline__ void odom_rows_body(int block_x, int nblocks, const float4 *__restrict__ stack, int M, int nslots,
+                                               const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                               const OdomState *__restrict__ st, double *__restrict__ partials, int b_from_coef) {
   Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
   Vec3<float> t(st->T[4], st->T[5], st->T[6]);
   Mat3<float> Rm = toRot(q);
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0;
-  for (int sidx = blockIdx.x * blockDim.x + threadIdx.x; sidx < nslots; sidx += gridDim.x * blockDim.x) {
+  for (int sidx = block_x * blockDim.x + threadIdx.x; sidx < nslots; sidx += nblocks * blockDim.x) {
     if (!valid[sidx]) continue;
     float4 po = stack[sidx % M];
     float4 c = coef[sidx];
@@ -713,8 +714,16 @@ __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__
   if (threadIdx.x < 28) {
     double v = 0;
     for (int w = 0; w < ODOM_ROW_THREADS / 64; ++w) v += sm[w][threadIdx.x];
-    partials[blockIdx.x * 28 + threadIdx.x] = v;
+    partials[block_x * 28 + threadIdx.x] = v;
   }
+}
+
+__global__ void __launch_bounds__(ODOM_ROW_THREADS) k_odom_rows(const float4 *__restrict__ stack, int M, int nslots,
+                                                                const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                                                const OdomState *__restrict__ st, double *__restrict__ partials,
+                                                                int b_from_coef) {
+  if (st->converged) return;
+  odom_rows_body(blockIdx.x, gridDim.x, stack, M, nslots, valid, coef, st, partials, b_from_coef);
 }
 
 void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *valid, const float4 *coef, const OdomState *st,
@@ -723,8 +732,8 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
   LIO_HIP(hipGetLastError());
 }
 
-__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows, int left_update) {
-  if (st->converged) return;
+__device__ __forceinline__ void odom_update_body(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
+                                                 int left_update) {
   // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
   __shared__ double ssum[28];
   reduce_partials28(partials, nblocks, ssum);
@@ -769,8 +778,76 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
   if (double(delta_r) < 0.05 && double(delta_t) < 0.05) st->converged = 1;
 }
 
+__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows, int left_update) {
+  if (st->converged) return;
+  odom_update_body(partials, nblocks, st, iter, min_rows, left_update);
+}
+
 void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update) {
   hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(256), 0, s, partials, nblocks, st, iter, min_rows, left_update);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched keyframe refinement: B independent scan-to-map loops advance together, one launch per stage per round
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_kf_round(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,
+                                                 const float4 *__restrict__ stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode,
+                                                 uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
+  const int k = blockIdx.z;
+  if (st[k].converged) return;
+  const KfDesc d = kd[k];
+  const float *tp = st[k].T;
+  if (blockIdx.y == 0) {
+    if (int(blockIdx.x) * 128 >= d.Mc * FEAT_LPQ) return;
+    const KfMapDesc &m = md[d.map];
+    line_features_body(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis, m.corner_sorted,
+                       m.corner_cells, m.corner_grid, valid, coef);
+  } else {
+    if (int(blockIdx.x) * 128 >= d.Ms * 8) return;
+    const KfMapDesc &m = md[d.map];
+    const FeatFrame fr{stack_all + d.slot_off + d.Mc, d.Ms, d.slot_off + d.Mc, 0};
+    const FeatScalars fs{min_match_sq_dis, min_plane_dis, mapping_mode, {d.pz[0], d.pz[1], d.pz[2]}};
+    features_body<true, 8>(fr, fs, blockIdx.x, tp, m.surf_sorted, m.surf_cells, m.surf_grid, valid, coef, nullptr, nullptr);
+  }
+}
+
+__global__ void __launch_bounds__(ODOM_ROW_THREADS) k_kf_rows(const KfDesc *__restrict__ kd, const OdomState *__restrict__ st,
+                                                              const float4 *__restrict__ stack_all, const uint8_t *__restrict__ valid,
+                                                              const float4 *__restrict__ coef, double *__restrict__ partials, int b_from_coef) {
+  const int k = blockIdx.y;
+  if (st[k].converged) return;
+  const KfDesc d = kd[k];
+  if (int(blockIdx.x) >= d.nb) return;
+  const int M = d.Mc + d.Ms;
+  odom_rows_body(blockIdx.x, d.nb, stack_all + d.slot_off, M, M, valid + d.slot_off, coef + d.slot_off, st + k, partials + size_t(d.part_off) * 28,
+                 b_from_coef);
+}
+
+__global__ void k_kf_update(const KfDesc *__restrict__ kd, OdomState *st, const double *__restrict__ partials, int iter, int min_rows, int left_update,
+                            int *n_converged) {
+  const int k = blockIdx.x;
+  if (st[k].converged) return;
+  const KfDesc d = kd[k];
+  odom_update_body(partials + size_t(d.part_off) * 28, d.nb, st + k, iter, min_rows, left_update);
+  if (threadIdx.x == 0 && st[k].converged) atomicAdd(n_converged, 1);
+}
+
+void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all,
+                     float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s) {
+  const int bx = std::max(1, std::max(cdiv((long long)max_Mc * FEAT_LPQ, 128), cdiv((long long)max_Ms * 8, 128)));
+  hipLaunchKernelGGL(k_kf_round, dim3(bx, 2, n_keyframes), dim3(128), 0, s, kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid,
+                     coef);
+  LIO_HIP(hipGetLastError());
+}
+void launch_kf_rows(const KfDesc *kd, const OdomState *st, int n_keyframes, int max_nb, const float4 *stack_all, const uint8_t *valid, const float4 *coef,
+                    double *partials, int b_from_coef, hipStream_t s) {
+  hipLaunchKernelGGL(k_kf_rows, dim3(max_nb, n_keyframes), dim3(ODOM_ROW_THREADS), 0, s, kd, st, stack_all, valid, coef, partials, b_from_coef);
+  LIO_HIP(hipGetLastError());
+}
+void launch_kf_update(const KfDesc *kd, OdomState *st, int n_keyframes, const double *partials, int iter, int min_rows, int left_update, int *n_converged,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_kf_update, dim3(n_keyframes), dim3(256), 0, s, kd, st, partials, iter, min_rows, left_update, n_converged);
   LIO_HIP(hipGetLastError());
 }
 

@@ -155,6 +155,13 @@ _SIGS = {
     "lio_map_get_cube": (C.c_size_t, [C.c_void_p, C.c_int, C.c_uint32, c_float_p]),
     "lio_map_get_cube_state": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "lio_map_get_score_point_coeff": (C.c_size_t, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
+    "lio_kf_batch_create": (C.c_void_p, [C.POINTER(MapConfig)]),
+    "lio_kf_batch_destroy": (None, [C.c_void_p]),
+    "lio_kf_batch_add_map": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 2),
+    "lio_kf_batch_add_keyframe": (C.c_int, [C.c_void_p, C.c_int] + [c_float_p, C.c_size_t] * 2 + [C.POINTER(TransformF)]),
+    "lio_kf_batch_clear_keyframes": (C.c_int, [C.c_void_p]),
+    "lio_kf_batch_refine": (C.c_int, [C.c_void_p, C.POINTER(TransformF), c_int32_p, c_int32_p, c_double_p]),
+    "lio_kf_batch_size": (C.c_size_t, [C.c_void_p]),
     "lio_compact_encode": (C.c_size_t, [C.POINTER(TransformF)] + [c_float_p, C.c_size_t] * 3 + [c_float_p]),
     "lio_compact_decode": (C.c_int, [c_float_p, C.c_size_t, C.POINTER(TransformF)] + [C.POINTER(C.c_size_t)] * 3),
     "lio_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, c_float_p, C.POINTER(C.c_size_t)]),
@@ -519,6 +526,60 @@ class PointMapping:
         if n:
             self.lib.dll.lio_map_get_score_point_coeff(self.h, _fp(score), _fp(point), _fp(coeff))
         return score, point, coeff
+
+
+class KeyframeBatch:
+    """Batched keyframe refinement (BASELINE.json configs[4]): one OptimizeMap / OptimizeTransformTobeMapped loop per
+    keyframe (MapBuilder.cc:624-1014 / PointMapping.cc:325-753), all keyframes of the handle advanced together."""
+
+    def __init__(self, lib: LioLib, **overrides):
+        self.lib = lib
+        cfg = MapConfig()
+        lib.dll.lio_map_default_config(C.byref(cfg))
+        for k, v in overrides.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = lib.dll.lio_kf_batch_create(C.byref(cfg))
+        if not self.h:
+            raise LioError("lio_kf_batch_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_kf_batch_destroy(self.h)
+            self.h = None
+
+    def add_map(self, corner_map, surf_map):
+        c, s = _f32(corner_map).reshape(-1, 4), _f32(surf_map).reshape(-1, 4)
+        idx = self.lib.dll.lio_kf_batch_add_map(self.h, _fp(c), c.shape[0], _fp(s), s.shape[0])
+        if idx < 0:
+            _chk(idx, "lio_kf_batch_add_map")
+        return idx
+
+    def add_keyframe(self, map_index, corner_stack, surf_stack, T_init):
+        c, s = _f32(corner_stack).reshape(-1, 4), _f32(surf_stack).reshape(-1, 4)
+        T = TransformF.make(*T_init)
+        idx = self.lib.dll.lio_kf_batch_add_keyframe(self.h, int(map_index), _fp(c), c.shape[0], _fp(s), s.shape[0], C.byref(T))
+        if idx < 0:
+            _chk(idx, "lio_kf_batch_add_keyframe")
+        return idx
+
+    def clear_keyframes(self):
+        _chk(self.lib.dll.lio_kf_batch_clear_keyframes(self.h), "lio_kf_batch_clear_keyframes")
+
+    def __len__(self):
+        return int(self.lib.dll.lio_kf_batch_size(self.h))
+
+    def refine(self):
+        """-> dict(q (n,4) xyzw, p (n,3), iterations (n,), rows (n,), device_ms)"""
+        n = len(self)
+        T = (TransformF * max(n, 1))()
+        it = np.zeros(max(n, 1), dtype=np.int32)
+        rows = np.zeros(max(n, 1), dtype=np.int32)
+        ms = C.c_double(0)
+        _chk(self.lib.dll.lio_kf_batch_refine(self.h, T, it.ctypes.data_as(c_int32_p), rows.ctypes.data_as(c_int32_p), C.byref(ms)),
+             "lio_kf_batch_refine")
+        arr = np.frombuffer(T, dtype=np.float32).reshape(-1, 7)[:n]
+        return dict(q=arr[:, :4].copy(), p=arr[:, 4:7].copy(), iterations=it[:n], rows=rows[:n], device_ms=ms.value)
 
 
 class PointOdometry:

@@ -238,6 +238,56 @@ size_t lio_map_get_score_point_coeff(const lio_map *h, float *score, float *poin
   return v.size();
 }
 
+// ---------------------------------------------------------------- batched keyframe refinement (sequential restatement)
+struct lio_kf_batch {
+  MappingConfig cfg;
+  struct Map { Cloud corner, surf; };
+  struct Kf { int map; Cloud corner, surf; Transformf T; };
+  std::vector<Map> maps;
+  std::vector<Kf> kfs;
+};
+lio_kf_batch *lio_kf_batch_create(const lio_map_config *c) {
+  lio_map_config cfg;
+  if (c) cfg = *c; else lio_map_default_config(&cfg);
+  if (cfg.num_max_iterations < 1) return nullptr;
+  lio_kf_batch *h = new (std::nothrow) lio_kf_batch;
+  if (!h) return nullptr;
+  h->cfg.corner_filter_size = cfg.corner_filter_size; h->cfg.surf_filter_size = cfg.surf_filter_size;
+  h->cfg.min_match_sq_dis = cfg.min_match_sq_dis; h->cfg.min_plane_dis = cfg.min_plane_dis; h->cfg.num_max_iterations = cfg.num_max_iterations;
+  h->cfg.map_builder = cfg.map_builder != 0; h->cfg.enable_4d = cfg.enable_4d != 0; h->cfg.skip_count = cfg.skip_count;
+  return h;
+}
+void lio_kf_batch_destroy(lio_kf_batch *h) { delete h; }
+int lio_kf_batch_add_map(lio_kf_batch *h, const float *corner, size_t nc, const float *surf, size_t ns) {
+  if (!h || (!corner && nc) || (!surf && ns)) return LIO_ERR_ARG;
+  h->maps.push_back({toCloud(corner, nc), toCloud(surf, ns)});
+  return int(h->maps.size()) - 1;
+}
+int lio_kf_batch_add_keyframe(lio_kf_batch *h, int map, const float *corner, size_t nc, const float *surf, size_t ns, const lio_transform_f *T) {
+  if (!h || !T || (!corner && nc) || (!surf && ns) || map < 0 || size_t(map) >= h->maps.size()) return LIO_ERR_ARG;
+  h->kfs.push_back({map, toCloud(corner, nc), toCloud(surf, ns), toT(*T)});
+  return int(h->kfs.size()) - 1;
+}
+int lio_kf_batch_clear_keyframes(lio_kf_batch *h) {
+  if (!h) return LIO_ERR_ARG;
+  h->kfs.clear();
+  return LIO_OK;
+}
+size_t lio_kf_batch_size(const lio_kf_batch *h) { return h ? h->kfs.size() : 0; }
+int lio_kf_batch_refine(lio_kf_batch *h, lio_transform_f *T_out, int32_t *iters, int32_t *rows, double *device_ms) {
+  if (!h) return LIO_ERR_ARG;
+  if (device_ms) *device_ms = 0;
+  const bool four_dof = h->cfg.map_builder && h->cfg.enable_4d;
+  for (size_t k = 0; k < h->kfs.size(); ++k) {
+    const auto &kf = h->kfs[k];
+    KeyframeRefinement r = RefineKeyframe(h->cfg, h->maps[size_t(kf.map)].corner, h->maps[size_t(kf.map)].surf, kf.corner, kf.surf, kf.T, four_dof);
+    if (T_out) fromT(r.T, &T_out[k]);
+    if (iters) iters[k] = r.iterations;
+    if (rows) rows[k] = r.selected;
+  }
+  return LIO_OK;
+}
+
 // ---------------------------------------------------------------- /compact_data codec
 size_t lio_compact_encode(const lio_transform_f *T, const float *corner, size_t nc, const float *surf, size_t ns, const float *full, size_t nf,
                           float *out) {

@@ -364,4 +364,20 @@ struct PointMapping {
   }
 };
 
+// One keyframe of the batched refinement (BASELINE.json configs[4]): the scan-to-map loop above run on caller-supplied
+// from-map clouds and down-sampled stacks, from the initial pose T_in.  The keyframes of a batch are independent.
+struct KeyframeRefinement { Transformf T; int iterations = 0, selected = 0; bool degenerate = false; };
+inline KeyframeRefinement RefineKeyframe(const MappingConfig &cfg, const Cloud &corner_map, const Cloud &surf_map, const Cloud &corner_stack,
+                                         const Cloud &surf_stack, const Transformf &T_in, bool four_dof) {
+  PointMapping pm(cfg);
+  pm.transform_tobe_mapped = T_in;
+  pm.point_on_z_axis = pm.ToMap(P4{0.f, 0.f, 10.f, 0.f}, T_in);  // fixed before the iterations (PointMapping.cc:803-806)
+  pm.corner_from_map = corner_map; pm.surf_from_map = surf_map;
+  pm.corner_stack_ds = corner_stack; pm.surf_stack_ds = surf_stack;
+  pm.OptimizeTransformTobeMapped(four_dof);
+  KeyframeRefinement r;
+  r.T = pm.transform_tobe_mapped; r.iterations = pm.last_iterations; r.selected = pm.last_selected; r.degenerate = pm.last_degenerate;
+  return r;
+}
+
 }  // namespace orc

@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--windows", type=int, default=4, help="independent windows in flight for the `batched` extra (0 = skip)")
+    ap.add_argument("--keyframes", type=int, default=1000, help="keyframes of the batched-refinement extra (configs[4]); 0 = skip")
     ap.add_argument("--shard-factors", action="store_true",
                     help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
                          "equation moments per linearisation (SURVEY.md §8e).  Default: one independent window per rank, no collective.")
@@ -201,7 +202,14 @@ def main():
             batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
 
         odom_ms, packer_ms = odometry_ms_per_scan(hip, ds) if kind == "outdoor" else (None, None)
-        map_stats = mapping_ms_per_scan(hip, ds, clouds)
+        captured = []
+        map_stats = mapping_ms_per_scan(hip, ds, clouds, capture=captured)
+        kf_stats = None
+        if args.keyframes > 0 and world == 1 and captured:
+            kf_stats = keyframe_batch_stats(hip, captured, args.keyframes)
+            if not args.no_cpu_baseline:
+                orc_kf = keyframe_batch_stats(_oracle_lib(), captured, 4, reps=1, distinct_maps=False)
+                kf_stats["cpu_oracle_keyframes_per_s"] = orc_kf["keyframes_per_s"]
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)  # N = 1 only
         odom_io = 3 if kind == "outdoor" else 2
         pp_med = float(np.median(pp_ms[1:]))
@@ -232,6 +240,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "batched": batched,
+            "keyframe_batch": kf_stats,
             "batched_kernel_roofline": {"kernel": "k_lidar_moments[_sym]_batched + k_moment_reduce (fp64-MFMA form below 4 chunks per wave, structured fp64-VALU form above)", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
             "stages_ms": {
                 "t_build_map": round(rep.ms_build_map, 4),
@@ -314,7 +323,7 @@ def odometry_ms_per_scan(hip, ds):
     return round(float(np.median(ms[1:])), 4), round(float(np.median(ms_packer)), 4)
 
 
-def mapping_ms_per_scan(lib, ds, clouds, n_frames=8):
+def mapping_ms_per_scan(lib, ds, clouds, n_frames=8, capture=None):
     """Scan-to-map step (PointMapping::Process: from-map extraction, stack VoxelGrid, <=10 Gauss-Newton rounds against the
     cube map, map update) on consecutive sweeps; transform_sum = ground truth + a growing drift.  Median wall ms per sweep
     and the map sizes of the last one."""
@@ -335,6 +344,8 @@ def mapping_ms_per_scan(lib, ds, clouds, n_frames=8):
         t = time.perf_counter()
         r = mp.process(corner, surf, T)
         ms.append((time.perf_counter() - t) * 1e3)
+        if capture is not None and k >= 2:   # local map + down-sampled stacks + settled pose of this sweep = one keyframe
+            capture.append(dict(corner_map=mp.cloud(2), surf_map=mp.cloud(3), corner=mp.cloud(0), surf=mp.cloud(1), T=r["T_aft"]))
     return {
         "ms_per_scan": round(float(np.median(ms[2:])), 4),
         "from_map_points": int(mp.cloud(2).shape[0] + mp.cloud(3).shape[0]),
@@ -342,6 +353,68 @@ def mapping_ms_per_scan(lib, ds, clouds, n_frames=8):
         "iterations_last": int(r["iterations"]),
         "rows_last": int(r["num_selected"]),
     }
+
+
+def keyframe_batch_stats(lib, captured, n_keyframes, reps=3, distinct_maps=True):
+    """BASELINE.json configs[4]: n_keyframes 64-line keyframes, each with its own local map (a separate copy in HBM when
+    distinct_maps), initial poses = the settled pose of the source sweep perturbed by up to 0.15 m / 0.01 rad; one
+    OptimizeTransformTobeMapped loop per keyframe, every stage of a round one launch over the whole batch."""
+    from lio_amd import capi, synth
+
+    rng = np.random.default_rng(5)
+    b = capi.KeyframeBatch(lib)
+    t0 = time.perf_counter()
+    n_src = len(captured)
+    n_maps = n_keyframes if distinct_maps else n_src
+    for m in range(n_maps):
+        c = captured[m % n_src]
+        b.add_map(c["corner_map"], c["surf_map"])
+    alg_bytes_round = []
+    for k in range(n_keyframes):
+        c = captured[k % n_src]
+        q, p = c["T"]
+        R = synth.rot_from_quat(np.asarray(q, np.float64)) @ synth.small_rot(rng.uniform(-0.01, 0.01, 3))
+        T0 = (synth.quat_from_rot(R), np.asarray(p, np.float64) + rng.uniform(-0.15, 0.15, 3))
+        b.add_keyframe(k if distinct_maps else k % n_src, c["corner"], c["surf"], T0)
+        M = c["corner"].shape[0] + c["surf"].shape[0]
+        N = c["corner_map"].shape[0] + c["surf_map"].shape[0]
+        alg_bytes_round.append(16 * (M + N) + 8 * 5 * M + 32 * M)   # SURVEY.md §8(d): kNN + fit, per call
+    setup_s = time.perf_counter() - t0
+    r = b.refine()   # warm-up: uploads the stacks
+    wall, dev = [], []
+    for _ in range(reps):
+        t = time.perf_counter()
+        r = b.refine()
+        wall.append((time.perf_counter() - t) * 1e3)
+        dev.append(r["device_ms"])
+    wall_ms, dev_ms = float(np.median(wall)), float(np.median(dev))
+    alg = float(np.dot(np.asarray(alg_bytes_round, np.float64), r["iterations"].astype(np.float64)))
+    spread = float(np.max(np.linalg.norm(r["p"][::n_src][:, :2] - r["p"][::n_src][:, :2].mean(axis=0), axis=1))) if n_keyframes >= 2 * n_src else 0.0
+    return {
+        "keyframes": n_keyframes, "distinct_local_maps": n_maps,
+        "stack_points_per_keyframe": int(captured[0]["corner"].shape[0] + captured[0]["surf"].shape[0]),
+        "local_map_points_per_keyframe": int(captured[0]["corner_map"].shape[0] + captured[0]["surf_map"].shape[0]),
+        "refine_wall_ms": round(wall_ms, 3), "refine_device_ms": round(dev_ms, 3),
+        "keyframes_per_s": round(n_keyframes / (wall_ms * 1e-3), 1),
+        "iterations_mean": round(float(r["iterations"].mean()), 2), "iterations_max": int(r["iterations"].max()),
+        "algorithmic_GB": round(alg / 1e9, 3), "achieved_GBps": round(alg / (dev_ms * 1e-3) / 1e9, 1) if dev_ms > 0 else None,
+        "frac_of_8TBps": round(alg / (dev_ms * 1e-3) / 8e12, 4) if dev_ms > 0 else None,
+        "xy_spread_of_refined_copies_m": round(spread, 4),
+        "setup_s": round(setup_s, 2),
+        "note": "algorithmic bytes = sum over keyframes of iterations x (16(M+N) + 8*5*M + 32*M), SURVEY.md 8(d) kNN+fit row",
+    }
+
+
+def _oracle_lib():
+    """The CPU oracle library: used ONLY for the reported cpu baselines (never on the measured path)."""
+    import subprocess
+
+    from lio_amd import capi
+
+    so = os.path.join(ROOT, "oracle", "liblio_oracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return capi.LioLib(so)
 
 
 def cpu_baseline(kind, W, Wo, steps, ds):

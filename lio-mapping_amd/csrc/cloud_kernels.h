@@ -137,8 +137,8 @@ struct KfMapDesc {
   const float4 *surf_sorted; const int *surf_cells; GridDesc surf_grid;
 };
 // grid z limit: n_keyframes <= 65535 per launch
-void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all,
-                     float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s);
+void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, long long total_queries,
+                     const float4 *stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s);
 void launch_kf_rows(const KfDesc *kd, const OdomState *st, int n_keyframes, int max_nb, const float4 *stack_all, const uint8_t *valid, const float4 *coef,
                     double *partials, int b_from_coef, hipStream_t s);
 // n_converged (device int) is incremented once per keyframe when it converges

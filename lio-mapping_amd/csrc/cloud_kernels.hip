@@ -525,12 +525,13 @@ __global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__res
 
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
 // direction = eigenvector of the largest eigenvalue (accepted when it dominates 3x the middle one).
+template <int LPQ = FEAT_LPQ>
 __device__ __forceinline__ void line_features_body(int block_x, const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
                                                    const Vec3<float> &pz, float min_match_sq_dis, const float4 *__restrict__ map,
                                                    const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
                                                    float4 *__restrict__ coef) {
   const int gt = block_x * blockDim.x + threadIdx.x;
-  const int i = gt / FEAT_LPQ, sub = gt % FEAT_LPQ;
+  const int i = gt / LPQ, sub = gt % LPQ;
   const bool active = i < M;
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   Vec3<float> t(tp[4], tp[5], tp[6]);
@@ -538,7 +539,7 @@ __device__ __forceinline__ void line_features_body(int block_x, const float4 *__
   Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
   Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   float bd[5]; int bi[5], bj[5];
-  knn_scan_group<5, FEAT_LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+  knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
   if (!active || sub != 0) return;
   const int slot = slot_off + i;
   uint8_t ok = 0;
@@ -791,6 +792,7 @@ void launch_odom_update(const double *partials, int nblocks, OdomState *st, int 
 // ------------------------------------------------------------------------------------------------
 // Batched keyframe refinement: B independent scan-to-map loops advance together, one launch per stage per round
 // ------------------------------------------------------------------------------------------------
+template <int LPQ>
 __global__ void __launch_bounds__(128) k_kf_round(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,
                                                  const float4 *__restrict__ stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode,
                                                  uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
@@ -799,16 +801,16 @@ __global__ void __launch_bounds__(128) k_kf_round(const KfDesc *__restrict__ kd,
   const KfDesc d = kd[k];
   const float *tp = st[k].T;
   if (blockIdx.y == 0) {
-    if (int(blockIdx.x) * 128 >= d.Mc * FEAT_LPQ) return;
+    if (int(blockIdx.x) * 128 >= d.Mc * LPQ) return;
     const KfMapDesc &m = md[d.map];
-    line_features_body(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis, m.corner_sorted,
+    line_features_body<LPQ>(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis, m.corner_sorted,
                        m.corner_cells, m.corner_grid, valid, coef);
   } else {
-    if (int(blockIdx.x) * 128 >= d.Ms * 8) return;
+    if (int(blockIdx.x) * 128 >= d.Ms * LPQ) return;
     const KfMapDesc &m = md[d.map];
     const FeatFrame fr{stack_all + d.slot_off + d.Mc, d.Ms, d.slot_off + d.Mc, 0};
     const FeatScalars fs{min_match_sq_dis, min_plane_dis, mapping_mode, {d.pz[0], d.pz[1], d.pz[2]}};
-    features_body<true, 8>(fr, fs, blockIdx.x, tp, m.surf_sorted, m.surf_cells, m.surf_grid, valid, coef, nullptr, nullptr);
+    features_body<true, LPQ>(fr, fs, blockIdx.x, tp, m.surf_sorted, m.surf_cells, m.surf_grid, valid, coef, nullptr, nullptr);
   }
 }
 
@@ -833,11 +835,18 @@ __global__ void k_kf_update(const KfDesc *__restrict__ kd, OdomState *st, const 
   if (threadIdx.x == 0 && st[k].converged) atomicAdd(n_converged, 1);
 }
 
-void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all,
-                     float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s) {
-  const int bx = std::max(1, std::max(cdiv((long long)max_Mc * FEAT_LPQ, 128), cdiv((long long)max_Ms * 8, 128)));
-  hipLaunchKernelGGL(k_kf_round, dim3(bx, 2, n_keyframes), dim3(128), 0, s, kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid,
-                     coef);
+void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, long long total_queries,
+                     const float4 *stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s) {
+  // lanes per query: a small batch is latency-bound (8 lanes shorten each query's dependent candidate walk); once the batch
+  // fills the GPU many times over, one lane per query wins 1.8x (no merge rounds, no idle lanes in the fit): measured
+  // 96 / 69 / 59 / 55 ms for 8 / 4 / 2 / 1 lanes at 1000 HDL-64 keyframes.  The result does not depend on the split.
+  static const int lpq_env = [] { const char *e = std::getenv("LIO_KF_LPQ"); return e ? std::atoi(e) : 0; }();
+  const int lpq = lpq_env ? lpq_env : (total_queries >= 400000 ? 1 : total_queries >= 60000 ? 4 : 8);
+  const int bx = std::max(1, cdiv((long long)std::max(max_Mc, max_Ms) * lpq, 128));
+  const dim3 grid(bx, 2, n_keyframes);
+#define KF_ROUND(L) hipLaunchKernelGGL(k_kf_round<L>, grid, dim3(128), 0, s, kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef)
+  if (lpq == 1) KF_ROUND(1); else if (lpq == 2) KF_ROUND(2); else if (lpq == 4) KF_ROUND(4); else KF_ROUND(8);
+#undef KF_ROUND
   LIO_HIP(hipGetLastError());
 }
 void launch_kf_rows(const KfDesc *kd, const OdomState *st, int n_keyframes, int max_nb, const float4 *stack_all, const uint8_t *valid, const float4 *coef,

@@ -126,7 +126,7 @@ void KfBatchDev::Refine() {
   for (int iter = 0; iter < max_it; ++iter) {
     for (int off = 0; off < B; off += kChunk) {
       const int nk = std::min(kChunk, B - off);
-      launch_kf_round(d_kd_.p + off, d_md_.p, d_st_.p + off, nk, max_Mc_, max_Ms_, d_stack_.p, cfg_.min_match_sq_dis, cfg_.min_plane_dis, mode, valid_.p,
+      launch_kf_round(d_kd_.p + off, d_md_.p, d_st_.p + off, nk, max_Mc_, max_Ms_, n_queries_, d_stack_.p, cfg_.min_match_sq_dis, cfg_.min_plane_dis, mode, valid_.p,
                       coef_.p, s);
       launch_kf_rows(d_kd_.p + off, d_st_.p + off, nk, max_nb_, d_stack_.p, valid_.p, coef_.p, partials_.p, mode, s);
       launch_kf_update(d_kd_.p + off, d_st_.p + off, nk, partials_.p, iter, 50, four_dof ? 1 : 0, d_nconv_.p, s);

@@ -62,3 +62,43 @@ def make_allreduce(device: str = "cpu"):
         buf[:] = t.cpu().numpy()
 
     return allreduce
+
+
+def refine_keyframes_sharded(lib, maps, keyframes, world: int, rank: int, device: str = "cpu", **cfg):
+    """BASELINE.json configs[4] over N ranks: keyframes are independent, so rank r refines keyframes r, r+N, r+2N, ...
+    (with the local maps they reference) on its own GPU, and the one exchange of the path is an all-gather of the
+    refined poses (7 floats + 2 ints per keyframe).  maps = [(corner_map, surf_map)], keyframes = [(map_index,
+    corner_stack, surf_stack, (q_xyzw, p))].  Returns dict(q, p, iterations, rows) for ALL keyframes on every rank."""
+    import numpy as np
+
+    from . import capi
+
+    mine = list(range(rank, len(keyframes), world))
+    batch = capi.KeyframeBatch(lib, **cfg)
+    local_map = {}
+    for k in mine:
+        mi = keyframes[k][0]
+        if mi not in local_map:
+            local_map[mi] = batch.add_map(*maps[mi])
+        batch.add_keyframe(local_map[mi], *keyframes[k][1:4])
+    r = batch.refine()
+    packed = np.zeros((len(mine), 9), np.float32)
+    if mine:
+        packed[:, 0:4], packed[:, 4:7] = r["q"], r["p"]
+        packed[:, 7], packed[:, 8] = r["iterations"], r["rows"]
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        per_rank = -(-len(keyframes) // world)                      # equal-size slots for all_gather
+        buf = torch.zeros((per_rank, 9), dtype=torch.float32, device=device)
+        buf[: len(mine)] = torch.from_numpy(packed).to(device)
+        gathered = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(gathered, buf)
+        out = np.zeros((len(keyframes), 9), np.float32)
+        for rr in range(world):
+            idx = list(range(rr, len(keyframes), world))
+            out[idx] = gathered[rr].cpu().numpy()[: len(idx)]
+    else:
+        out = packed
+    return dict(q=out[:, 0:4], p=out[:, 4:7], iterations=out[:, 7].astype(np.int32), rows=out[:, 8].astype(np.int32))

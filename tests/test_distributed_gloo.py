@@ -117,3 +117,37 @@ def test_factor_sharding_allreduce_matches_single_rank(oracle):
     np.testing.assert_allclose(p0, est.get_window()["Ps"], atol=1e-7)   # summation order differs across shards only
     np.testing.assert_allclose([c0, d0], [r1.final_cost, r2.final_cost], rtol=1e-7)
     np.testing.assert_allclose(j0, est.prior()["JtJ"], rtol=1e-5, atol=1e-6 * np.abs(j0).max())
+
+
+def _kf_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from kf_util import keyframe_inputs
+    from lio_amd import capi, dist_util
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
+    maps, kfs = keyframe_inputs(lib, "indoor", 3, 2)     # deterministic: the same 4 + 1 keyframes on every rank
+    kfs = kfs + [kfs[0]]                                  # odd count: the ranks' shares differ in size
+    r = dist_util.refine_keyframes_sharded(lib, maps, kfs, world, rank)
+    out[rank] = (r["q"], r["p"], r["iterations"], r["rows"])
+    if rank == 0:
+        full = dist_util.refine_keyframes_sharded(lib, maps, kfs, 1, 0)
+        out["full"] = (full["q"], full["p"], full["iterations"], full["rows"])
+    dist.destroy_process_group()
+
+
+def test_keyframe_batch_shards_over_ranks(oracle):
+    """configs[4] at N = 2: keyframes split round-robin, no collective on the refinement itself, one all-gather of the
+    poses; every rank ends with all poses, identical to the single-rank batch."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_kf_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for a, b, c in zip(out[0], out[1], out["full"]):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+    assert out[0][0].shape == (5, 4) and np.all(out[0][2] > 0)

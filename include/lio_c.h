@@ -63,11 +63,17 @@ enum {
 };
 
 void lio_pp_default_config(lio_pp_config *cfg);
-/* PointProcessor(float lower, float upper, int rings) — PointProcessor.cc:75; uneven=false only */
+/* PointProcessor(float lower, float upper, int rings, bool uneven) — PointProcessor.cc:75.  `uneven` is not a
+ * constructor argument here: it only selects which PointToRing overload runs, i.e. which of the two process calls
+ * below the caller uses (PointProcessor.cc:185-190). */
 lio_pp *lio_pp_create(float lower_deg, float upper_deg, int rings, const lio_pp_config *cfg_or_null);
 void lio_pp_destroy(lio_pp *);
 /* SetInputCloud + PointToRing + ExtractFeaturePoints (PointProcessor.cc:96-100, test_point_processor.cc:103-106) */
 int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
+/* The same with the PointIR overload of PointToRing (uneven = true, sensor_type 320 of processor_node.cc:73;
+ * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
+ * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */
+int lio_pp_process_rings(lio_pp *, const float *xyzi, const uint16_t *ring, size_t n);
 size_t lio_pp_count(const lio_pp *, int which);
 int lio_pp_get_cloud(const lio_pp *, int which, float *xyzi_out);
 /* parity object of §8a a4: ordered (ring, in-ring index) per picked class; which in {SHARP,LESS_SHARP,FLAT} */

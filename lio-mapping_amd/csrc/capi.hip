@@ -68,6 +68,10 @@ int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
   return guarded([&] { h->pp->Process(xyzi, n); return LIO_OK; });
 }
+int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
+  if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->Process(xyzi, n, n ? ring : nullptr); return LIO_OK; });
+}
 size_t lio_pp_count(const lio_pp *h, int which) { return (h && which >= 0 && which <= 4) ? h->pp->Count(which) : 0; }
 int lio_pp_get_cloud(const lio_pp *h, int which, float *out) {
   if (!h || which < 0 || which > 4 || !out) return LIO_ERR_ARG;

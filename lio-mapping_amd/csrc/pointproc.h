@@ -26,7 +26,8 @@ class PointProcessorDev {
  public:
   PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg);
   ~PointProcessorDev();
-  void Process(const float *xyzi, size_t n);
+  // ring != nullptr: the PointIR variant (ring field per point, rel-time over the swept range; PointProcessor.cc:428-536)
+  void Process(const float *xyzi, size_t n, const uint16_t *ring = nullptr);
   size_t Count(int which) const;
   void GetCloud(int which, float *out);
   void GetIndices(int which, int32_t *ring, int32_t *idx);
@@ -46,11 +47,10 @@ class PointProcessorDev {
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
   DBuf<float> azi_, curv_;
   DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
-  DBuf<uint64_t> k64_, k64b_;
-  DBuf<int> d_ring_offsets_, first_valid_, mask_, flags_, pos_;
+  DBuf<int> d_ring_offsets_, first_valid_, mask_, end_ori_;
+  DBuf<uint16_t> ring_in_;
   DBuf<int8_t> label_;
   DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_, class_off_;
-  DBuf<float> lf_bounds_;
   DBuf<int> lf_ring_count_;
   DBuf<PPDeviceCounts> d_counts_;
   DBuf<char> tmp_;

@@ -29,8 +29,8 @@ __device__ inline float azimuth_of(float x, float y) {
   return az;
 }
 
-__global__ void k_ring_bin(const float4 *__restrict__ in, int n, float lower, float factor, int rings, uint32_t *__restrict__ keys,
-                           uint32_t *__restrict__ vals, float *__restrict__ azi, int *first_valid) {
+__global__ void k_ring_bin(const float4 *__restrict__ in, const uint16_t *__restrict__ ring_in, int n, float lower, float factor, int rings,
+                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, float *__restrict__ azi, int *first_valid) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = in[i];
@@ -42,6 +42,7 @@ __global__ void k_ring_bin(const float4 *__restrict__ in, int n, float lower, fl
     az = azimuth_of(p.x, p.y);
     float deg = float(double(ele) * 180.0 / M_PI);  // RadToDeg<float>
     int scan_id = int(double((deg - lower) * factor) + 0.5);
+    if (ring_in) scan_id = int(ring_in[i]);  // PointIR variant: the ring comes with the point (PointProcessor.cc:468)
     if (scan_id >= 0 && scan_id < rings) {
       key = uint32_t(scan_id);
       atomicMin(first_valid, i);
@@ -60,9 +61,24 @@ __global__ void k_ring_offsets(const uint32_t *__restrict__ keys, int n, int rin
     for (int r = k + 1; r <= rings; ++r) offsets[r] = n;
 }
 
+// PointIR variant (:481-499): an azimuth behind the first one is unwrapped by 2 pi (half_passed can never be set: its
+// condition asks for i > 3 * cloud_size / 2), end_ori_ = the largest unwrapped azimuth, at least 0.
+__device__ __forceinline__ float unwrap_azimuth(float az, float start_ori) {
+  const float rel = az - start_ori;
+  return rel < 0 ? float(double(az) + 2 * M_PI) : az;
+}
+__global__ void k_ring_end_ori(const uint32_t *__restrict__ keys, const float *__restrict__ azi, int n, int rings, const int *__restrict__ first_valid,
+                               int *end_ori_bits) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = 0.f;
+  if (i < n && int(keys[i]) < rings) v = unwrap_azimuth(azi[i], azi[*first_valid]);
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(end_ori_bits, __float_as_int(v));  // positive floats order like their bits
+}
+
 __global__ void k_ring_finalize(const float4 *__restrict__ in, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                 const float *__restrict__ azi, const int *__restrict__ offsets, const int *__restrict__ first_valid, int rings,
-                                double scan_period, float4 *__restrict__ ring_cloud) {
+                                double scan_period, float4 *__restrict__ ring_cloud, const int *__restrict__ end_ori_bits) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= offsets[rings]) return;
   uint32_t src = vals[s];
@@ -71,6 +87,11 @@ __global__ void k_ring_finalize(const float4 *__restrict__ in, const uint32_t *_
   float rel = azi[src] - start_ori;
   if (rel < 0) rel = float(double(rel) + 2 * M_PI);
   float rel_time = float(scan_period * double(rel) / (2 * M_PI));
+  if (end_ori_bits) {  // :507-524: no wrap of the difference, divided by range_ori = end_ori_ - start_ori_
+    const float range_ori = __int_as_float(*end_ori_bits) - start_ori;
+    const float rel_u = unwrap_azimuth(azi[src], start_ori) - start_ori;
+    rel_time = float(scan_period * double(rel_u) / double(range_ori));
+  }
   float4 p = in[src];
   p.w = float(ring) + rel_time;
   ring_cloud[s] = p;
@@ -357,86 +378,6 @@ __global__ void k_class_gather(const float4 *__restrict__ ring_cloud, const int 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// less-flat: per-ring VoxelGrid, batched over rings
-// ------------------------------------------------------------------------------------------------
-__global__ void k_lf_bounds(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int8_t *__restrict__ label,
-                            float *__restrict__ bounds) {
-  const int r = blockIdx.x;
-  const int base = offsets[r], n = offsets[r + 1] - base;
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (label[base + i] > 0) continue;  // corners (1,2) and untouched (127) are not less-flat (A.5)
-    float4 p = ring_cloud[base + i];
-    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-  }
-  __shared__ float sm[6][256];
-  int t = threadIdx.x;
-  for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (t < st) for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
-    __syncthreads();
-  }
-  if (t < 6) bounds[r * 8 + t] = sm[t][0];
-}
-
-__global__ void k_lf_keys(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int8_t *__restrict__ label,
-                          const float *__restrict__ bounds, float inv_leaf, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
-  const int r = blockIdx.y;
-  const int base = offsets[r], n = offsets[r + 1] - base;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long key = ~0ull;
-  if (label[base + i] <= 0) {
-    const float *b = bounds + r * 8;
-    int minb0 = int(floorf(b[0] * inv_leaf)), minb1 = int(floorf(b[1] * inv_leaf)), minb2 = int(floorf(b[2] * inv_leaf));
-    int div0 = int(floorf(b[3] * inv_leaf)) - minb0 + 1, div1 = int(floorf(b[4] * inv_leaf)) - minb1 + 1;
-    float4 p = ring_cloud[base + i];
-    int i0 = int(floorf(p.x * inv_leaf) - float(minb0));
-    int i1 = int(floorf(p.y * inv_leaf) - float(minb1));
-    int i2 = int(floorf(p.z * inv_leaf) - float(minb2));
-    unsigned int vk = static_cast<unsigned int>(i0 + i1 * div0 + i2 * div0 * div1);
-    key = (static_cast<unsigned long long>(r) << 32) | vk;
-  }
-  keys[base + i] = key;
-  vals[base + i] = uint32_t(base + i);
-}
-
-__global__ void k_lf_heads(const unsigned long long *__restrict__ keys, int n, int *__restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long k = keys[i];
-  flags[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
-}
-
-__global__ void k_lf_centroids(const float4 *__restrict__ ring_cloud, const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
-                               const int *__restrict__ flags, const int *__restrict__ pos, int n, const float *__restrict__ azi,
-                               const int *__restrict__ first_valid, double scan_period, float4 *__restrict__ out, PPDeviceCounts *counts) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) counts->n_less_flat = pos[i] + flags[i];
-  if (!flags[i]) return;
-  unsigned long long k = keys[i];
-  float ax = 0, ay = 0, az = 0, ai = 0;
-  int e = i;
-  while (e < n && keys[e] == k) {
-    float4 p = ring_cloud[vals[e]];
-    ax += p.x; ay += p.y; az += p.z; ai += p.w;
-    ++e;
-  }
-  float cnt = float(e - i);
-  float4 o = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
-  // rel-time recompute on the averaged point (:755-778)
-  float a = azimuth_of(o.x, o.y);
-  float rel = a - azi[*first_valid];
-  if (rel < 0) rel = float(double(rel) + 2 * M_PI);
-  float rel_time = float(scan_period * double(rel) / (2 * M_PI));
-  o.w = float(int(o.w)) + rel_time;
-  out[pos[i]] = o;
-}
-
 // One workgroup per ring does the whole per-ring VoxelGrid in LDS: bounds, (voxel, index) keys, a bitonic sort sized to
 // the ring, run heads, a block scan and the centroids (+ the rel-time recompute of :755-778), written to the ring's own
 // segment of a staging cloud; k_lf_compact then packs the segments in ring order.  Two launches instead of bounds + keys +
@@ -600,16 +541,15 @@ PointProcessorDev::~PointProcessorDev() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-void PointProcessorDev::Process(const float *xyzi, size_t n) {
+void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *ring) {
   std::memset(&counts_, 0, sizeof(counts_));
   std::fill(ring_offsets_.begin(), ring_offsets_.end(), 0);
   if (n == 0) return;
   const int ni = int(n);
   hipStream_t s = stream_;
   in_.reserve(n); ring_cloud_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
-  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); k64_.reserve(n); k64b_.reserve(n);
-  flags_.reserve(n); pos_.reserve(n); less_flat_.reserve(n);
-  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(1); d_counts_.reserve(1); lf_bounds_.reserve(size_t(rings_) * 8);
+  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); less_flat_.reserve(n);
+  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(1); d_counts_.reserve(1); end_ori_.reserve(1);
   PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
              cfg_.max_surf_flat, cfg_.surf_curv_th};
   const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
@@ -623,18 +563,25 @@ void PointProcessorDev::Process(const float *xyzi, size_t n) {
   LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
   int big = INT_MAX;
   LIO_HIP(hipMemcpyAsync(first_valid_.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_ring_bin, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, ni, lower_, factor_, rings_, keys_.p, vals_.p, azi_.p, first_valid_.p);
+  const uint16_t *d_ring = nullptr;
+  if (ring) {
+    ring_in_.reserve(n);
+    LIO_HIP(hipMemcpyAsync(ring_in_.p, ring, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    LIO_HIP(hipMemsetAsync(end_ori_.p, 0, sizeof(int), s));  // end_ori_ = 0 (:439)
+    d_ring = ring_in_.p;
+  }
+  hipLaunchKernelGGL(k_ring_bin, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, vals_.p, azi_.p,
+                     first_valid_.p);
+  if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_.p, end_ori_.p);
   int bits = 1;
   while ((1 << bits) < rings_ + 1) ++bits;
-  size_t tb = 0, tb2 = 0, tb3 = 0;
+  size_t tb = 0;
   LIO_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
-  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tb2, k64_.p, k64b_.p, vals_.p, vals2_.p, n, 0, 40, s));
-  LIO_HIP(rocprim::exclusive_scan(nullptr, tb3, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
-  tmp_.reserve(std::max(tb, std::max(tb2, tb3)) + 256);
+  tmp_.reserve(tb + 256);
   LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
   hipLaunchKernelGGL(k_ring_offsets, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, rings_, d_ring_offsets_.p);
   hipLaunchKernelGGL(k_ring_finalize, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, keys2_.p, vals2_.p, azi_.p, d_ring_offsets_.p, first_valid_.p,
-                     rings_, cfg_.scan_period, ring_cloud_.p);
+                     rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
   const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 4) + size_t(cap_all) * sizeof(int) + 64;
   hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
                      pick_idx_.p, pick_cnt_.p, d_counts_.p);

@@ -18,6 +18,7 @@ c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
+c_uint16_p = C.POINTER(C.c_uint16)
 
 
 class TransformF(C.Structure):
@@ -131,6 +132,7 @@ _SIGS = {
     "lio_pp_create": (C.c_void_p, [C.c_float, C.c_float, C.c_int, C.POINTER(PPConfig)]),
     "lio_pp_destroy": (None, [C.c_void_p]),
     "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
     "lio_pp_get_cloud": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
     "lio_pp_get_indices": (C.c_int, [C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
@@ -416,9 +418,15 @@ class PointProcessor:
             self.lib.dll.lio_pp_destroy(self.h)
             self.h = None
 
-    def process(self, xyzi):
+    def process(self, xyzi, ring=None):
+        """ring (uint16 per point) selects the PointIR overload of PointToRing (uneven sensors, PointProcessor.cc:428-536)."""
         xyzi = _f32(xyzi).reshape(-1, 4)
-        _chk(self.lib.dll.lio_pp_process(self.h, _fp(xyzi), xyzi.shape[0]), "lio_pp_process")
+        if ring is None:
+            _chk(self.lib.dll.lio_pp_process(self.h, _fp(xyzi), xyzi.shape[0]), "lio_pp_process")
+            return
+        ring = np.ascontiguousarray(ring, dtype=np.uint16)
+        assert ring.shape[0] == xyzi.shape[0]
+        _chk(self.lib.dll.lio_pp_process_rings(self.h, _fp(xyzi), ring.ctypes.data_as(c_uint16_p), xyzi.shape[0]), "lio_pp_process_rings")
 
     def cloud(self, which):
         n = self.lib.dll.lio_pp_count(self.h, which)

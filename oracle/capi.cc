@@ -57,6 +57,11 @@ int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   h->pp.Process(xyzi, n);
   return LIO_OK;
 }
+int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
+  if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
+  h->pp.Process(xyzi, n, ring);
+  return LIO_OK;
+}
 static const Cloud *ppCloud(const lio_pp *h, int which) {
   switch (which) {
     case LIO_PP_RINGS: return &h->pp.cloud_rings;

@@ -44,12 +44,44 @@ struct PointProcessor {
   // PointProcessor.h:153-156 — float RadToDeg, float subtraction/multiply, +0.5 in double, trunc
   int ElevationToRing(float rad) const { return int((RadToDeg(rad) - lower_bound_) * factor_ + 0.5); }
 
-  void Process(const float *xyzi, size_t n) {
+  // ring != nullptr selects the PointIR overload of PointToRing (uneven_ == true, PointProcessor.cc:185-190)
+  void Process(const float *xyzi, size_t n, const uint16_t *ring = nullptr) {
     laser_scans.assign(num_rings_, Cloud());
     sharp.clear(); less_sharp.clear(); flat.clear(); less_flat.clear();
     for (int k = 0; k < 4; ++k) { pick_ring[k].clear(); pick_idx[k].clear(); }
-    PointToRing(xyzi, n);
+    if (ring) PointToRingIR(xyzi, ring, n); else PointToRing(xyzi, n);
     ExtractFeaturePoints();
+  }
+
+  // PointProcessor.cc:428-536: ring from the point's own field; azimuths behind the first one are unwrapped by 2 pi
+  // (half_passed is never set: its condition needs i > 3 * cloud_size / 2, :487); end_ori_ = largest unwrapped azimuth
+  // (from 0, :439,495-497); rel_time = scan_period * (azimuth - start_ori_) / (end_ori_ - start_ori_) (:507-524).
+  void PointToRingIR(const float *xyzi, const uint16_t *ring_field, size_t n) {
+    bool start_flag = false;
+    start_ori_ = 0.f;
+    float end_ori = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+      P4 p{xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2], xyzi[4 * i + 3]};
+      if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;  // :456-460
+      float azi_rad = float(2 * M_PI - std::atan2(p.y, p.x));                            // :464
+      if (azi_rad >= 2 * M_PI) azi_rad = float(azi_rad - 2 * M_PI);                      // :466-468
+      int scan_id = ring_field[i];                                                        // :470
+      if (scan_id >= num_rings_ || scan_id < 0) continue;                                 // :472-476
+      if (!start_flag) { start_ori_ = azi_rad; start_flag = true; }                       // :478-481
+      float azi_rad_rel = azi_rad - start_ori_;
+      if (azi_rad_rel < 0) azi_rad = float(azi_rad + 2 * M_PI);                           // :486-489 (half_passed stays false)
+      if (end_ori < azi_rad) end_ori = azi_rad;                                           // :495-497
+      p.i = azi_rad;
+      laser_scans[scan_id].push_back(p);
+    }
+    const float range_ori = end_ori - start_ori_;                                         // :507
+    for (int ring = 0; ring < num_rings_; ++ring)
+      for (P4 &p : laser_scans[ring]) {
+        float azi_rad_rel = p.i - start_ori_;
+        float rel_time = float(config_.scan_period * azi_rad_rel / range_ori);            // :521 (double * float / float)
+        p.i = ring + rel_time;
+      }
+    FinishRings();
   }
 
   void PointToRing(const float *xyzi, size_t n) {
@@ -75,6 +107,10 @@ struct PointProcessor {
         float rel_time = float(config_.scan_period * azi_rad_rel / (2 * M_PI));
         p.i = ring + rel_time;
       }
+    FinishRings();
+  }
+
+  void FinishRings() {  // :191-201
     ring_offsets.assign(num_rings_ + 1, 0);
     cloud_rings.clear();
     for (int r = 0; r < num_rings_; ++r) {

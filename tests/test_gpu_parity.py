@@ -119,10 +119,51 @@ def test_point_processor_matches_oracle(hip, oracle, kind):
     np.testing.assert_allclose(la[:, 3], lb[:, 3], rtol=0, atol=8e-6)
 
 
+@pytest.mark.parametrize("kind", ["vlp16", "hdl64"])
+def test_point_processor_ring_field_variant_matches_oracle(hip, oracle, kind):
+    """PointIR overload of PointToRing (uneven sensors; PointProcessor.cc:428-536) through lio_pp_process_rings: the ring
+    comes from the point's field, rel_time runs over the swept azimuth range.  Some returns carry a ring outside
+    [0, rings) and must be dropped."""
+    from pp_util import ring_field
+
+    ds = synth.make_dataset("indoor" if kind == "vlp16" else "outdoor", 1, 0.1)
+    scan = ds.frames[0].scan
+    ring = ring_field(scan, ds.lidar)
+    rng = np.random.default_rng(11)
+    bad = rng.choice(len(ring), 200, replace=False)
+    ring[bad[:100]] = ds.lidar.rings
+    ring[bad[100:]] = 65535
+    pa = capi.PointProcessor(hip, ds.lidar.lower_deg, ds.lidar.upper_deg, ds.lidar.rings)
+    pb = capi.PointProcessor(oracle, ds.lidar.lower_deg, ds.lidar.upper_deg, ds.lidar.rings)
+    pa.process(scan, ring=ring)
+    pb.process(scan, ring=ring)
+    np.testing.assert_array_equal(pa.ring_offsets(), pb.ring_offsets())
+    ra, rb = pa.cloud(0), pb.cloud(0)
+    np.testing.assert_array_equal(ra[:, :3], rb[:, :3])
+    np.testing.assert_allclose(ra[:, 3], rb[:, 3], rtol=0, atol=8e-6)
+    frac = ra[:, 3] - np.floor(ra[:, 3])
+    assert abs(frac.max() - 0.1) < 8e-6            # the last azimuth of the sweep maps to scan_period
+    for which in (1, 2, 3):
+        (r1, i1), (r2, i2) = pa.indices(which), pb.indices(which)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_array_equal(i1, i2)
+    la, lb = pa.cloud(4), pb.cloud(4)
+    assert la.shape == lb.shape and la.shape[0] > 1000
+    np.testing.assert_array_equal(la[:, :3], lb[:, :3])
+    np.testing.assert_allclose(la[:, 3], lb[:, 3], rtol=0, atol=8e-6)
+    # the handle can switch between the two overloads
+    pa.process(scan)
+    pb.process(scan)
+    np.testing.assert_array_equal(pa.ring_offsets(), pb.ring_offsets())
+    np.testing.assert_allclose(pa.cloud(0), pb.cloud(0), rtol=0, atol=8e-6)
+
+
 def test_point_processor_edge_cases(hip, oracle):
     for scan in (np.zeros((0, 4), np.float32), np.full((50, 4), np.nan, np.float32)):
         pa = capi.PointProcessor(hip, -15, 15, 16)
         pa.process(scan)
+        assert all(pa.cloud(w).shape[0] == 0 for w in range(5))
+        pa.process(scan, ring=np.zeros(len(scan), np.uint16))
         assert all(pa.cloud(w).shape[0] == 0 for w in range(5))
     # a ragged scan: one ring only, too short to be processed (PointProcessor.cc:660-662)
     az = np.linspace(0.1, 1.0, 9)

@@ -46,11 +46,13 @@ class PointProcessorDev {
   std::vector<int> ring_offsets_;
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
   DBuf<float> azi_, curv_;
-  DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
+  DBuf<uint32_t> keys_;
+  DBuf<int> ring_total_;
+  DBuf<int> ring_table_;   // [ring][block] counts -> exclusive offsets (the stable ring split)
   DBuf<int> d_ring_offsets_, first_valid_, mask_, end_ori_;
   DBuf<uint16_t> ring_in_;
   DBuf<int8_t> label_;
-  DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_, class_off_;
+  DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_;
   DBuf<int> lf_ring_count_;
   DBuf<PPDeviceCounts> d_counts_;
   DBuf<char> tmp_;

@@ -15,6 +15,10 @@
 
 #include "pointproc.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace lio {
 
 #define PP_PICK_THREADS 512
@@ -29,36 +33,67 @@ __device__ inline float azimuth_of(float x, float y) {
   return az;
 }
 
-__global__ void k_ring_bin(const float4 *__restrict__ in, const uint16_t *__restrict__ ring_in, int n, float lower, float factor, int rings,
-                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, float *__restrict__ azi, int *first_valid) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = in[i];
-  uint32_t key = uint32_t(rings);
-  float az = 0.f;
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-    float dis = sqrtf(p.x * p.x + p.y * p.y);
-    float ele = atan2f(p.z, dis);
-    az = azimuth_of(p.x, p.y);
-    float deg = float(double(ele) * 180.0 / M_PI);  // RadToDeg<float>
-    int scan_id = int(double((deg - lower) * factor) + 0.5);
-    if (ring_in) scan_id = int(ring_in[i]);  // PointIR variant: the ring comes with the point (PointProcessor.cc:468)
-    if (scan_id >= 0 && scan_id < rings) {
-      key = uint32_t(scan_id);
-      atomicMin(first_valid, i);
+// Ring binning is a STABLE multi-split of the sweep into <= 128 rings (laser_scans[ring] keeps input order, :193-201): a
+// device-wide radix sort of (ring, index) pairs costs ten launches here (55 us at 133 k points).  Instead: per-block ring
+// histograms (this kernel), one scan of the ring-major (ring, block) count table, and a scatter that ranks each point
+// among the points of its ring inside its block.
+#define PP_BIN_THREADS 256
+__global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_bin(const float4 *__restrict__ in, const uint16_t *__restrict__ ring_in, int n, float lower,
+                                                             float factor, int rings, uint32_t *__restrict__ keys, float *__restrict__ azi,
+                                                             int *__restrict__ block_hist, int nblocks, int *first_valid) {
+  __shared__ int hist[LIO_PP_MAX_RINGS];
+  __shared__ int s_first;
+  for (int r = threadIdx.x; r < rings; r += PP_BIN_THREADS) hist[r] = 0;
+  if (threadIdx.x == 0) s_first = INT_MAX;
+  __syncthreads();
+  const int i = blockIdx.x * PP_BIN_THREADS + threadIdx.x;
+  if (i < n) {
+    float4 p = in[i];
+    uint32_t key = uint32_t(rings);
+    float az = 0.f;
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      float dis = sqrtf(p.x * p.x + p.y * p.y);
+      float ele = atan2f(p.z, dis);
+      az = azimuth_of(p.x, p.y);
+      float deg = float(double(ele) * 180.0 / M_PI);  // RadToDeg<float>
+      int scan_id = int(double((deg - lower) * factor) + 0.5);
+      if (ring_in) scan_id = int(ring_in[i]);  // PointIR variant: the ring comes with the point (PointProcessor.cc:468)
+      if (scan_id >= 0 && scan_id < rings) {
+        key = uint32_t(scan_id);
+        atomicAdd(&hist[scan_id], 1);
+        atomicMin(&s_first, i);
+      }
     }
+    keys[i] = key; azi[i] = az;
   }
-  keys[i] = key; vals[i] = uint32_t(i); azi[i] = az;
+  __syncthreads();
+  for (int r = threadIdx.x; r < rings; r += PP_BIN_THREADS) block_hist[r * nblocks + blockIdx.x] = hist[r];
+  if (threadIdx.x == 0 && s_first != INT_MAX) atomicMin(first_valid, s_first);
 }
 
-__global__ void k_ring_offsets(const uint32_t *__restrict__ keys, int n, int rings, int *__restrict__ offsets) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int k = int(keys[i]);
-  int kp = i > 0 ? int(keys[i - 1]) : -1;
-  for (int r = kp + 1; r <= k && r <= rings; ++r) offsets[r] = i;
-  if (i == n - 1)
-    for (int r = k + 1; r <= rings; ++r) offsets[r] = n;
+// per-ring exclusive scan of the count table in place (block r owns ring r's nblocks counts) + the ring totals
+__global__ void __launch_bounds__(256) k_ring_scan(int *__restrict__ table, int nblocks, int *__restrict__ ring_total) {
+  __shared__ int swave[4];
+  __shared__ int s_carry;
+  int *row = table + size_t(blockIdx.x) * nblocks;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 256) {
+    const int k = base + tid;
+    const int c = k < nblocks ? row[k] : 0;
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) swave[wv] = incl;
+    __syncthreads();
+    int pre = s_carry;
+    for (int w = 0; w < wv; ++w) pre += swave[w];
+    if (k < nblocks) row[k] = pre + incl - c;
+    __syncthreads();
+    if (tid == 255) s_carry = pre + incl;
+    __syncthreads();
+  }
+  if (tid == 0) ring_total[blockIdx.x] = s_carry;
 }
 
 // PointIR variant (:481-499): an azimuth behind the first one is unwrapped by 2 pi (half_passed can never be set: its
@@ -76,25 +111,58 @@ __global__ void k_ring_end_ori(const uint32_t *__restrict__ keys, const float *_
   if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(end_ori_bits, __float_as_int(v));  // positive floats order like their bits
 }
 
-__global__ void k_ring_finalize(const float4 *__restrict__ in, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                const float *__restrict__ azi, const int *__restrict__ offsets, const int *__restrict__ first_valid, int rings,
-                                double scan_period, float4 *__restrict__ ring_cloud, const int *__restrict__ end_ori_bits) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= offsets[rings]) return;
-  uint32_t src = vals[s];
-  int ring = int(keys[s]);
-  float start_ori = azi[*first_valid];
-  float rel = azi[src] - start_ori;
+__global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *__restrict__ in, const uint32_t *__restrict__ keys,
+                                                                 const float *__restrict__ azi, const int *__restrict__ table, int nblocks, int n,
+                                                                 const int *__restrict__ ring_total, int *__restrict__ offsets,
+                                                                 const int *__restrict__ first_valid, int rings, double scan_period,
+                                                                 float4 *__restrict__ ring_cloud, const int *__restrict__ end_ori_bits) {
+  __shared__ int wave_cnt[PP_BIN_THREADS / 64][LIO_PP_MAX_RINGS];
+  __shared__ int ring_base[LIO_PP_MAX_RINGS + 1];
+  for (int k = threadIdx.x; k < (PP_BIN_THREADS / 64) * LIO_PP_MAX_RINGS; k += PP_BIN_THREADS) (&wave_cnt[0][0])[k] = 0;
+  // start of every ring = exclusive scan of the <= 128 ring totals (every block redoes it: 128 values)
+  if (threadIdx.x < LIO_PP_MAX_RINGS) ring_base[threadIdx.x + 1] = int(threadIdx.x) < rings ? ring_total[threadIdx.x] : 0;
+  if (threadIdx.x == 0) ring_base[0] = 0;
+  __syncthreads();
+  for (int off = 1; off < LIO_PP_MAX_RINGS; off <<= 1) {
+    int v = 0;
+    if (threadIdx.x < LIO_PP_MAX_RINGS && int(threadIdx.x) + 1 > off) v = ring_base[threadIdx.x + 1 - off];
+    __syncthreads();
+    if (threadIdx.x < LIO_PP_MAX_RINGS) ring_base[threadIdx.x + 1] += v;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int r = threadIdx.x; r <= rings; r += PP_BIN_THREADS) offsets[r] = ring_base[r];
+  const int i = blockIdx.x * PP_BIN_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t key = i < n ? keys[i] : uint32_t(rings);
+  const bool valid = key < uint32_t(rings);
+  // rank among the earlier lanes of this wave with the same ring: one pass per distinct ring present in the wave
+  int rank = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(valid && key == k);
+    if (valid && key == k) rank = __popcll(same & ((1ull << lane) - 1ull));
+    if (lane == leader) wave_cnt[wv][k] = __popcll(same);
+    todo &= ~same;
+  }
+  __syncthreads();
+  if (!valid) return;
+  int dst = ring_base[key] + table[int(key) * nblocks + blockIdx.x] + rank;
+  for (int w = 0; w < wv; ++w) dst += wave_cnt[w][key];
+  const float start_ori = azi[*first_valid];
+  float rel = azi[i] - start_ori;
   if (rel < 0) rel = float(double(rel) + 2 * M_PI);
   float rel_time = float(scan_period * double(rel) / (2 * M_PI));
   if (end_ori_bits) {  // :507-524: no wrap of the difference, divided by range_ori = end_ori_ - start_ori_
     const float range_ori = __int_as_float(*end_ori_bits) - start_ori;
-    const float rel_u = unwrap_azimuth(azi[src], start_ori) - start_ori;
+    const float rel_u = unwrap_azimuth(azi[i], start_ori) - start_ori;
     rel_time = float(scan_period * double(rel_u) / double(range_ori));
   }
-  float4 p = in[src];
-  p.w = float(ring) + rel_time;
-  ring_cloud[s] = p;
+  float4 p = in[i];
+  p.w = float(int(key)) + rel_time;
+  ring_cloud[dst] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,34 +415,50 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
 }
 
 // prefix of the per-ring pick counts -> compact, ring-major lists (the order the reference pushes them)
-__global__ void k_class_offsets(const int *__restrict__ pick_cnt, int rings, int *__restrict__ class_off, PPDeviceCounts *counts) {
-  int cls = threadIdx.x;
-  if (cls >= 3) return;
-  int acc = 0;
-  for (int r = 0; r < rings; ++r) { class_off[cls * (rings + 1) + r] = acc; acc += pick_cnt[r * 3 + cls]; }
-  class_off[cls * (rings + 1) + rings] = acc;
-  counts->n_class[cls + 1] = acc;
-}
-
-__global__ void k_class_gather(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int *__restrict__ pick_idx,
-                               const int *__restrict__ pick_cnt, const int *__restrict__ class_off, PickCfg c, int *__restrict__ class_ring,
-                               int *__restrict__ class_idx, float4 *__restrict__ cloud1, float4 *__restrict__ cloud2, float4 *__restrict__ cloud3,
-                               int cap_total) {
-  const int r = blockIdx.x;
-  const int cap_sharp = c.ns * c.max_sharp, cap_less = c.ns * c.max_less_sharp, cap_flat = c.ns * c.max_flat;
-  const int cap_all = cap_sharp + cap_less + cap_flat;
-  const int *mp = pick_idx + size_t(r) * cap_all;
-  const int src_off[3] = {0, cap_sharp, cap_sharp + cap_less};
-  float4 *clouds[3] = {cloud1, cloud2, cloud3};
-  for (int cls = 0; cls < 3; ++cls) {
-    int cnt = pick_cnt[r * 3 + cls];
-    int dst = class_off[cls * (c.rings + 1) + r];
-    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
-      int idx = mp[src_off[cls] + k];
-      class_ring[cls * cap_total + dst + k] = r;
-      class_idx[cls * cap_total + dst + k] = idx;
-      clouds[cls][dst + k] = ring_cloud[offsets[r] + idx];
+// Packing of the per-ring results in ring order, one launch: blockIdx.y = 0 gathers the picked classes of ring r behind those
+// of the rings before it (the reference appends ring by ring, :647-735), blockIdx.y = 1 packs the ring's less-flat segment.
+// Every block sums the counts of the rings before it itself (<= 128 values per class, one wave each): no offsets kernel.
+__global__ void __launch_bounds__(256) k_pp_pack(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, const int *__restrict__ pick_idx,
+                                                 const int *__restrict__ pick_cnt, PickCfg c, int *__restrict__ class_ring, int *__restrict__ class_idx,
+                                                 float4 *__restrict__ cloud1, float4 *__restrict__ cloud2, float4 *__restrict__ cloud3, int cap_total,
+                                                 const float4 *__restrict__ lf_staged, const int *__restrict__ lf_ring_count,
+                                                 float4 *__restrict__ less_flat, PPDeviceCounts *counts) {
+  __shared__ int s_dst[4];
+  const int r = blockIdx.x, rings = c.rings, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (blockIdx.y == 0) {
+    if (wv < 3) {
+      int acc = 0;
+      for (int q = lane; q < r; q += 64) acc += pick_cnt[q * 3 + wv];
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) s_dst[wv] = acc;
     }
+    __syncthreads();
+    const int cap_sharp = c.ns * c.max_sharp, cap_less = c.ns * c.max_less_sharp, cap_flat = c.ns * c.max_flat;
+    const int cap_all = cap_sharp + cap_less + cap_flat;
+    const int *mp = pick_idx + size_t(r) * cap_all;
+    const int src_off[3] = {0, cap_sharp, cap_sharp + cap_less};
+    float4 *clouds[3] = {cloud1, cloud2, cloud3};
+    for (int cls = 0; cls < 3; ++cls) {
+      const int cnt = pick_cnt[r * 3 + cls], dst = s_dst[cls];
+      for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+        const int idx = mp[src_off[cls] + k];
+        class_ring[cls * cap_total + dst + k] = r;
+        class_idx[cls * cap_total + dst + k] = idx;
+        clouds[cls][dst + k] = ring_cloud[offsets[r] + idx];
+      }
+      if (r == rings - 1 && threadIdx.x == 0) counts->n_class[cls + 1] = dst + cnt;
+    }
+  } else {
+    if (wv == 0) {
+      int acc = 0;
+      for (int q = lane; q < r; q += 64) acc += lf_ring_count[q];
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) s_dst[0] = acc;
+    }
+    __syncthreads();
+    const int dst = s_dst[0], cnt = lf_ring_count[r], src = offsets[r];
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) less_flat[dst + k] = lf_staged[src + k];
+    if (r == rings - 1 && threadIdx.x == 0) counts->n_less_flat = dst + cnt;
   }
 }
 
@@ -514,16 +598,6 @@ __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restr
   if (tid == 0) ring_count[r] = total;
 }
 
-__global__ void k_lf_compact(const float4 *__restrict__ staged, const int *__restrict__ offsets, const int *__restrict__ ring_count, int rings,
-                             float4 *__restrict__ out, PPDeviceCounts *counts) {
-  const int r = blockIdx.x;
-  int dst = 0;
-  for (int q = 0; q < r; ++q) dst += ring_count[q];
-  const int cnt = ring_count[r], src = offsets[r];
-  for (int k = threadIdx.x; k < cnt; k += blockDim.x) out[dst + k] = staged[src + k];
-  if (r == rings - 1 && threadIdx.x == 0) counts->n_less_flat = dst + cnt;
-}
-
 // ------------------------------------------------------------------------------------------------
 PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg)
     : lower_(lower), upper_(upper), rings_(rings), cfg_(cfg) {
@@ -548,18 +622,27 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   const int ni = int(n);
   hipStream_t s = stream_;
   in_.reserve(n); ring_cloud_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
-  keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n); less_flat_.reserve(n);
+  keys_.reserve(n); less_flat_.reserve(n);
+  const int nblocks = cdiv(ni, PP_BIN_THREADS);
+  ring_table_.reserve(size_t(rings_) * nblocks); ring_total_.reserve(rings_);
   d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(1); d_counts_.reserve(1); end_ori_.reserve(1);
   PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
              cfg_.max_surf_flat, cfg_.surf_curv_th};
   const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
   const int cap_all = cap_sharp + cap_less + cap_flat;
   const int cap_total = rings_ * std::max(cap_less, std::max(cap_sharp, cap_flat));
-  pick_idx_.reserve(size_t(rings_) * cap_all); pick_cnt_.reserve(size_t(rings_) * 3); class_off_.reserve(size_t(3) * (rings_ + 1));
+  pick_idx_.reserve(size_t(rings_) * cap_all); pick_cnt_.reserve(size_t(rings_) * 3);
   class_ring_.reserve(size_t(3) * cap_total); class_idx_.reserve(size_t(3) * cap_total);
   for (int cidx = 1; cidx <= 3; ++cidx) class_cloud_[cidx].reserve(cap_total);
 
+  static const bool dbg = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
   LIO_HIP(hipMemcpyAsync(in_.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, s));
+  if (dbg) {
+    LIO_HIP(hipStreamSynchronize(s));
+    std::fprintf(stderr, "[lio_hip pp timing] H2D of %zu points %.1f us\n", n,
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  }
   LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
   int big = INT_MAX;
   LIO_HIP(hipMemcpyAsync(first_valid_.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
@@ -570,35 +653,30 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
     LIO_HIP(hipMemsetAsync(end_ori_.p, 0, sizeof(int), s));  // end_ori_ = 0 (:439)
     d_ring = ring_in_.p;
   }
-  hipLaunchKernelGGL(k_ring_bin, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, vals_.p, azi_.p,
-                     first_valid_.p);
+  hipLaunchKernelGGL(k_ring_bin, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, azi_.p, ring_table_.p,
+                     nblocks, first_valid_.p);
   if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_.p, end_ori_.p);
-  int bits = 1;
-  while ((1 << bits) < rings_ + 1) ++bits;
-  size_t tb = 0;
-  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
-  tmp_.reserve(tb + 256);
-  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tb, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, bits, s));
-  hipLaunchKernelGGL(k_ring_offsets, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, rings_, d_ring_offsets_.p);
-  hipLaunchKernelGGL(k_ring_finalize, dim3(cdiv(ni, 256)), dim3(256), 0, s, in_.p, keys2_.p, vals2_.p, azi_.p, d_ring_offsets_.p, first_valid_.p,
-                     rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
+  hipLaunchKernelGGL(k_ring_scan, dim3(rings_), dim3(256), 0, s, ring_table_.p, nblocks, ring_total_.p);
+  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_.p,
+                     first_valid_.p, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
   const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 4) + size_t(cap_all) * sizeof(int) + 64;
   hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
                      pick_idx_.p, pick_cnt_.p, d_counts_.p);
-  hipLaunchKernelGGL(k_class_offsets, dim3(1), dim3(64), 0, s, pick_cnt_.p, rings_, class_off_.p, d_counts_.p);
-  hipLaunchKernelGGL(k_class_gather, dim3(rings_), dim3(64), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, class_off_.p, pc,
-                     class_ring_.p, class_idx_.p, class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total);
   // less-flat
   const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
   lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);
   const size_t lf_lds = size_t(4096) * 8 + size_t(4096) * 16 + size_t(4096) * 4;
   hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, inv_leaf, azi_.p,
                      first_valid_.p, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
-  hipLaunchKernelGGL(k_lf_compact, dim3(rings_), dim3(256), 0, s, lf_tmp_.p, d_ring_offsets_.p, lf_ring_count_.p, rings_, less_flat_.p, d_counts_.p);
+  hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
+                     class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_.p);
   LIO_HIP(hipGetLastError());
   LIO_HIP(hipMemcpyAsync(&counts_, d_counts_.p, sizeof(counts_), hipMemcpyDeviceToHost, s));
   LIO_HIP(hipMemcpyAsync(ring_offsets_.data(), d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));
   LIO_HIP(hipStreamSynchronize(s));
+  if (dbg)
+    std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us\n",
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   counts_.n_ring_points = ring_offsets_[rings_];
   if (counts_.overflow) throw std::runtime_error("PointProcessor: a ring exceeds LIO_PP_MAX_RING_POINTS");
 }

@@ -719,7 +719,9 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   const double t_opt0 = now_ms();
   SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, cfg_.max_solver_time, &first);
   R.ms_opt = now_ms() - t_opt0;
-  if (getenv("LIO_DEBUG_TIMING")) std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms\n", s.ms_chol, s.ms_eval);
+  if (getenv("LIO_DEBUG_TIMING"))
+    std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms | evaluate x%d: launch %.3f prior %.3f imu %.3f wait %.3f assemble %.3f\n",
+                 s.ms_chol, s.ms_eval, sys.eclk.n, sys.eclk.launch, sys.eclk.prior, sys.eclk.imu, sys.eclk.wait, sys.eclk.assemble);
   R.iterations = s.iterations; R.successful_steps = s.successful; R.termination = s.termination;
   R.initial_cost = s.initial_cost; R.final_cost = s.final_cost;
   for (size_t k = 0; k < s.trace.size() && k < 32; ++k) R.cost_trace[k] = s.trace[k];

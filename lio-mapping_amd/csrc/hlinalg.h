@@ -171,7 +171,7 @@ inline bool chol_upper(double *A, int n, int lda) {
   return has512 ? chol_upper_avx512(A, n, lda) : chol_upper_portable(A, n, lda);
 }
 // solve U^T U x = b in place
-inline void chol_upper_solve(const double *U, int n, int lda, double *b) {
+inline void chol_upper_solve_portable(const double *U, int n, int lda, double *b) {
   for (int i = 0; i < n; ++i) {  // forward: U^T y = b, column-oriented (axpy)
     const double y = b[i] / U[size_t(i) * lda + i];
     b[i] = y;
@@ -184,6 +184,38 @@ inline void chol_upper_solve(const double *U, int n, int lda, double *b) {
     for (int k = i + 1; k < n; ++k) s -= ri[k] * b[k];
     b[i] = s / ri[i];
   }
+}
+
+// The backward sweep is a chain of dot products: one scalar accumulator makes it latency-bound (n^2/2 dependent
+// multiply-adds, 6 us at n = 96).  Eight-lane partial sums cut the chain eight-fold.
+__attribute__((target("avx512f,fma"))) inline void chol_upper_solve_avx512(const double *U, int n, int lda, double *b) {
+  for (int i = 0; i < n; ++i) {  // forward: U^T y = b, column-oriented (axpy)
+    const double y = b[i] / U[size_t(i) * lda + i];
+    b[i] = y;
+    const double *ri = U + size_t(i) * lda;
+    const __m512d Y = _mm512_set1_pd(y);
+    int k = i + 1;
+    for (; k + 8 <= n; k += 8) _mm512_storeu_pd(b + k, _mm512_fnmadd_pd(_mm512_loadu_pd(ri + k), Y, _mm512_loadu_pd(b + k)));
+    if (k < n) {
+      const __mmask8 m = __mmask8((1u << (n - k)) - 1u);
+      _mm512_mask_storeu_pd(b + k, m, _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(m, ri + k), Y, _mm512_maskz_loadu_pd(m, b + k)));
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {  // backward: U x = y
+    const double *ri = U + size_t(i) * lda;
+    __m512d acc = _mm512_setzero_pd();
+    int k = i + 1;
+    for (; k + 8 <= n; k += 8) acc = _mm512_fmadd_pd(_mm512_loadu_pd(ri + k), _mm512_loadu_pd(b + k), acc);
+    if (k < n) {
+      const __mmask8 m = __mmask8((1u << (n - k)) - 1u);
+      acc = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, ri + k), _mm512_maskz_loadu_pd(m, b + k), acc);
+    }
+    b[i] = (b[i] - _mm512_reduce_add_pd(acc)) / ri[i];
+  }
+}
+inline void chol_upper_solve(const double *U, int n, int lda, double *b) {
+  static const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
+  if (has512) chol_upper_solve_avx512(U, n, lda, b); else chol_upper_solve_portable(U, n, lda, b);
 }
 
 // Gauss-Jordan inverse with partial pivoting, n x n.

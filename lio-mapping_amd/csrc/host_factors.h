@@ -244,29 +244,46 @@ inline bool imu_factor(const Preintegration &pim, const double *pose_i, const do
 }
 
 // residual + 1x7 Jacobians (null = skip)
-inline void ppp_factor(const V3d &point, const double coeff[4], const double *pose_p, const double *pose_i, const double *pose_ex,
-                       double *res, double *Jp, double *Ji, double *Jex) {
-  V3d Pp, Pi, tlb; Qd Qp, Qi, qlb;
-  unpack_pose(pose_p, Pp, Qp); unpack_pose(pose_i, Pi, Qi); unpack_pose(pose_ex, tlb, qlb);
+// The pose-dependent part of PivotPointPlaneFactor::Evaluate (PivotPointPlaneFactor.cc:58-70 and the rotation matrices of
+// :85-128), shared by every residual of a (pivot, frame i, extrinsic) triple.
+struct PppPoses {
+  V3d Pp, Pi, tlb, Plpi, dP;       // dP = Pi - Pp
+  Qd Qlpi;
+  M3d Ri, RpT, rlb, rlbT;
+};
+inline PppPoses ppp_prepare(const double *pose_p, const double *pose_i, const double *pose_ex) {
+  PppPoses t;
+  Qd Qp, Qi, qlb;
+  unpack_pose(pose_p, t.Pp, Qp); unpack_pose(pose_i, t.Pi, Qi); unpack_pose(pose_ex, t.tlb, qlb);
   Qd Qlp = Qp * conj(qlb);
-  V3d Plp = Pp - rotate(Qlp, tlb);
+  V3d Plp = t.Pp - rotate(Qlp, t.tlb);
   Qd Qli = Qi * conj(qlb);
-  V3d Pli = Pi - rotate(Qli, tlb);
-  Qd Qlpi = conj(Qlp) * Qli;
-  V3d Plpi = rotate(conj(Qlp), Pli - Plp);
+  V3d Pli = t.Pi - rotate(Qli, t.tlb);
+  t.Qlpi = conj(Qlp) * Qli;
+  t.Plpi = rotate(conj(Qlp), Pli - Plp);
+  t.Ri = toRot(Qi); t.rlb = toRot(qlb);
+  t.RpT = transpose(toRot(Qp)); t.rlbT = transpose(t.rlb);
+  t.dP = t.Pi - t.Pp;
+  return t;
+}
+inline void ppp_eval(const PppPoses &t, const V3d &point, const double coeff[4], double *res, double *Jp, double *Ji, double *Jex) {
   V3d w(coeff[0], coeff[1], coeff[2]);
-  *res = dot(w, rotate(Qlpi, point) + Plpi) + coeff[3];
+  *res = dot(w, rotate(t.Qlpi, point) + t.Plpi) + coeff[3];
   if (!Jp && !Ji && !Jex) return;
-  M3d Ri = toRot(Qi), Rp = toRot(Qp), rlb = toRot(qlb);
-  M3d RpT = transpose(Rp), rlbT = transpose(rlb);
+  const M3d &Ri = t.Ri, &RpT = t.RpT, &rlb = t.rlb, &rlbT = t.rlbT;
+  const V3d &tlb = t.tlb;
   auto put = [](double *J, const V3d &l, const V3d &r) { J[0] = l.x; J[1] = l.y; J[2] = l.z; J[3] = r.x; J[4] = r.y; J[5] = r.z; J[6] = 0; };
-  if (Jp) put(Jp, -rowmul(w, rlb * RpT), rowmul(w, rlb * (skew(RpT * (Ri * (rlbT * (point - tlb)))) + skew(RpT * (Pi - Pp)))));
+  if (Jp) put(Jp, -rowmul(w, rlb * RpT), rowmul(w, rlb * (skew(RpT * (Ri * (rlbT * (point - tlb)))) + skew(RpT * t.dP))));
   if (Ji) put(Ji, rowmul(w, rlb * RpT), rowmul(w, ((rlb * RpT) * Ri) * (-skew(rlbT * point) + skew(rlbT * tlb))));
   if (Jex) {
     M3d RpTRi = RpT * Ri;
     V3d q = rlbT * (point - tlb);
-    put(Jex, rowmul(w, M3d::identity() - (rlb * RpTRi) * rlbT), rowmul(w, rlb * (-skew(RpTRi * q) + RpTRi * skew(q) - skew(RpT * (Pi - Pp)))));
+    put(Jex, rowmul(w, M3d::identity() - (rlb * RpTRi) * rlbT), rowmul(w, rlb * (-skew(RpTRi * q) + RpTRi * skew(q) - skew(RpT * t.dP))));
   }
+}
+inline void ppp_factor(const V3d &point, const double coeff[4], const double *pose_p, const double *pose_i, const double *pose_ex,
+                       double *res, double *Jp, double *Ji, double *Jex) {
+  ppp_eval(ppp_prepare(pose_p, pose_i, pose_ex), point, coeff, res, Jp, Ji, Jex);
 }
 
 inline void prior_factor(const V3d &pos0, const Qd &rot0, const double *pose, double *res, double *J67) {

@@ -79,29 +79,42 @@ inline void relative_lidar_pose(const double *pose_p, const double *pose_i, cons
   t[0] = Plpi.x; t[1] = Plpi.y; t[2] = Plpi.z;
 }
 
-// L (18 x 13, row-major) and l (13): j = L z, r = l^T z, z = [w0*(p,1), w1*(p,1), w2*(p,1), d]
+// L (18 x 13, row-major) and l (13): j = L z, r = l^T z, z = [w0*(p,1), w1*(p,1), w2*(p,1), d].
+// The factor is linear in the plane normal w and affine in the point p, so L is read off the factor's own Jacobian
+// expressions (ppp_eval) at p in {0, e0, e1, e2}; a unit normal e_a just selects row a of the 3x3 matrices those
+// expressions multiply w with, so the four matrices per block are formed once per p instead of once per (p, a).
 inline void lidar_linear_maps(const double *pose_p, const double *pose_i, const double *pose_ex, double L[18 * 13], double l[13]) {
   std::memset(L, 0, sizeof(double) * 18 * 13);
   std::memset(l, 0, sizeof(double) * 13);
-  double j0[3][18], r0[3];
-  for (int a = 0; a < 3; ++a) {
-    double coeff[4] = {0, 0, 0, 0};
-    coeff[a] = 1.0;
-    double Jp[7], Ji[7], Jx[7];
-    ppp_factor(V3d(0, 0, 0), coeff, pose_p, pose_i, pose_ex, &r0[a], Jp, Ji, Jx);
-    for (int k = 0; k < 6; ++k) { j0[a][k] = Jp[k]; j0[a][6 + k] = Ji[k]; j0[a][12 + k] = Jx[k]; }
-    for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + 3] = j0[a][k];
-    l[4 * a + 3] = r0[a];
-    for (int b = 0; b < 3; ++b) {
-      V3d p(b == 0, b == 1, b == 2);
-      double r, Jp2[7], Ji2[7], Jx2[7];
-      ppp_factor(p, coeff, pose_p, pose_i, pose_ex, &r, Jp2, Ji2, Jx2);
-      for (int k = 0; k < 6; ++k) {
-        L[k * 13 + 4 * a + b] = Jp2[k] - j0[a][k];
-        L[(6 + k) * 13 + 4 * a + b] = Ji2[k] - j0[a][6 + k];
-        L[(12 + k) * 13 + 4 * a + b] = Jx2[k] - j0[a][12 + k];
+  const PppPoses t = ppp_prepare(pose_p, pose_i, pose_ex);
+  const M3d A = t.rlb * t.RpT;                 // translation blocks: pivot -w^T A, frame i  w^T A
+  const M3d ARi = A * t.Ri;
+  const M3d RpTRi = t.RpT * t.Ri;
+  const M3d Bx = M3d::identity() - (t.rlb * RpTRi) * t.rlbT;
+  const M3d S1 = skew(t.RpT * t.dP), S2 = skew(t.rlbT * t.tlb);
+  double J[4][3][18], r[4][3];                 // [probe point][normal axis][column]
+  for (int b = 0; b < 4; ++b) {
+    const V3d p(b == 1, b == 2, b == 3);
+    const V3d q = t.rlbT * (p - t.tlb);
+    const M3d Mp = t.rlb * (skew(t.RpT * (t.Ri * q)) + S1);
+    const M3d Mi = ARi * (-skew(t.rlbT * p) + S2);
+    const M3d Mx = t.rlb * (-skew(RpTRi * q) + RpTRi * skew(q) - S1);
+    const V3d rv = rotate(t.Qlpi, p) + t.Plpi;
+    for (int a = 0; a < 3; ++a) {
+      for (int k = 0; k < 3; ++k) {
+        J[b][a][k] = -A(a, k); J[b][a][3 + k] = Mp(a, k);
+        J[b][a][6 + k] = A(a, k); J[b][a][9 + k] = Mi(a, k);
+        J[b][a][12 + k] = Bx(a, k); J[b][a][15 + k] = Mx(a, k);
       }
-      l[4 * a + b] = r - r0[a];
+      r[b][a] = rv[a];
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + 3] = J[0][a][k];
+    l[4 * a + 3] = r[0][a];
+    for (int b = 0; b < 3; ++b) {
+      for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + b] = J[b + 1][a][k] - J[0][a][k];
+      l[4 * a + b] = r[b + 1][a] - r[0][a];
     }
   }
   l[12] = 1.0;
@@ -169,6 +182,11 @@ class WindowSystem {
     }
   }
 
+  // host-side phase clock of evaluate() (printed by the estimator under LIO_DEBUG_TIMING)
+  struct EvalClock { double launch = 0, prior = 0, imu = 0, wait = 0, assemble = 0; int n = 0; };
+  EvalClock eclk;
+  static double clk_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
   // which: bit0 prior, bit1 imu, bit2 lidar, bit3 extrinsic prior.  H/g may be null (cost only).
   Costs evaluate(const WindowParams &P, const Layout &lay, int which, bool imu_only_first, DMat *H, std::vector<double> *g,
                  std::vector<FrameMoments> *m_out = nullptr) {
@@ -178,7 +196,9 @@ class WindowSystem {
     preset_moments = nullptr;
     if (preset && int(preset->size()) != Wo + 1) preset = nullptr;
     const bool split = lidar_on && !preset && lidar_launch && lidar_wait;
+    double tk0 = clk_now();
     if (split) lidar_launch(P);  // asynchronous: the kernels run while the host evaluates the prior and the IMU factors
+    { const double t = clk_now(); eclk.launch += t - tk0; tk0 = t; ++eclk.n; }
     if (H) {
       if (H->r == lay.dim && H->c == lay.dim) H->zero(); else *H = DMat(lay.dim, lay.dim);  // the dogleg loop recycles two buffers
       g->assign(lay.dim, 0.0);
@@ -210,6 +230,7 @@ class WindowSystem {
         }
       }
     }
+    { const double t = clk_now(); eclk.prior += t - tk0; tk0 = t; }
     if (which & 2) {
       int last = imu_only_first ? 1 : Wo;
       for (int i = 0; i < last; ++i) {
@@ -244,9 +265,11 @@ class WindowSystem {
         }
       }
     }
+    { const double t = clk_now(); eclk.imu += t - tk0; tk0 = t; }
     if (lidar_on && (preset || split || lidar_eval)) {
       std::vector<FrameMoments> m(Wo + 1);
       if (preset) m = *preset; else if (split) lidar_wait(m); else lidar_eval(P, m);
+      { const double t = clk_now(); eclk.wait += t - tk0; tk0 = t; }
       if (m_out) *m_out = m;
       for (int i = 1; i <= Wo; ++i) {
         c.ppp += m[i].cost;
@@ -273,6 +296,7 @@ class WindowSystem {
         add_block(*H, *g, cols, sizes, 3, Hb, gb, 18);
       }
     }
+    { const double t = clk_now(); eclk.assemble += t - tk0; tk0 = t; }
     if ((which & 8) && use_prior_factor) {
       double r[6], J[42];
       prior_factor(prior_pos, prior_rot, P.ex.data(), r, H ? J : nullptr);

@@ -357,6 +357,11 @@ int lio_est_push_frame(lio_est *, const lio_transform_f *transform_in, const flo
 int lio_est_solve_optimization(lio_est *, lio_solve_report *report_or_null);
 /* Estimator::SlideWindow (Estimator.cc:2570-2666) */
 int lio_est_slide_window(lio_est *);
+/* The product defers the marginalization of a solve (host-only work whose result, the prior, is first read by the next
+ * solve) to a worker thread; every reader joins it first, so results are those of the synchronous sequence.  This call
+ * waits for all deferred work of the handle (no reference counterpart; a no-op in the oracle).  LIO_ASYNC_MARG=0 in the
+ * environment keeps the marginalization inside lio_est_solve_optimization. */
+int lio_est_sync(lio_est *);
 
 /* ---- test hooks (no reference counterpart): inject / read a window ---- */
 /* n_frames must be window_size+1.  Marks the estimator INITED with a full window. */

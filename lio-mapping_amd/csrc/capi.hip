@@ -578,6 +578,10 @@ int lio_est_slide_window(lio_est *h) {
   if (!h->e->inited_) return LIO_ERR_STATE;
   return guarded([&] { h->e->SlideWindow(); return LIO_OK; });
 }
+int lio_est_sync(lio_est *h) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { h->e->JoinMarg(); return LIO_OK; });
+}
 int lio_est_set_window(lio_est *h, int n, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,
                        const double g[3]) {
   if (!h || !Ps || !Rs || !Vs || !Bas || !Bgs || !g || n != h->e->W_ + 1) return LIO_ERR_ARG;
@@ -646,6 +650,7 @@ int lio_est_get_laser_odom_transform(const lio_est *h, lio_transform_f *out) {
 }
 int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, int *x0_len) {
   if (!h) return LIO_ERR_ARG;
+  const_cast<lio_est *>(h)->e->JoinMarg();
   const auto &pr = h->e->last_marg_;
   if (!pr) return 0;
   const int n = pr->n;

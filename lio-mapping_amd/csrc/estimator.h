@@ -3,7 +3,12 @@
 // BuildLocalMap, SolveOptimization, SlideWindow.  Clouds live in HBM for the life of the window;
 // the host keeps only the (W+1) x {P,R,V,Ba,Bg} states, the pre-integrations and the prior.
 #pragma once
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/lio_c.h"
@@ -73,6 +78,66 @@ struct KernelTimers {
   ~KernelTimers() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); for (Rec &r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
 };
 
+// Marginalization is host-only work (one factor evaluation from the solve's final lidar moments, a Schur complement, two
+// symmetric eigendecompositions: 0.12 ms) whose result — the prior — is first read by the NEXT solve, after that solve
+// has built its local map and features (0.45 ms, mostly device time).  A persistent worker thread computes it meanwhile;
+// every reader of the prior joins first, so the sequence of values is exactly the synchronous one.
+class MargWorker {
+ public:
+  using Task = std::function<std::shared_ptr<MargPrior>()>;
+  ~MargWorker() {
+    { std::lock_guard<std::mutex> lk(mu_); quit_ = true; }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  void submit(Task t) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!th_.joinable()) th_ = std::thread([this] { run(); });
+    cv_.wait(lk, [this] { return state_ == IDLE || state_ == DONE; });  // an unjoined (discarded) task finishes first
+    task_ = std::move(t); state_ = PENDING; err_ = nullptr; result_.reset();
+    lk.unlock();
+    cv_.notify_all();
+  }
+  bool busy() { std::lock_guard<std::mutex> lk(mu_); return state_ != IDLE; }
+  // blocks until the submitted task is done; returns false when nothing was submitted since the last join
+  bool join(std::shared_ptr<MargPrior> &out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (state_ == IDLE) return false;
+    cv_.wait(lk, [this] { return state_ == DONE; });
+    state_ = IDLE;
+    if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    out = std::move(result_);
+    return true;
+  }
+
+ private:
+  enum { IDLE, PENDING, RUNNING, DONE };
+  void run() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [this] { return quit_ || state_ == PENDING; });
+      if (quit_) return;
+      Task t = std::move(task_);
+      state_ = RUNNING;
+      lk.unlock();
+      std::shared_ptr<MargPrior> r;
+      std::exception_ptr e;
+      try { r = t(); } catch (...) { e = std::current_exception(); }
+      lk.lock();
+      result_ = std::move(r); err_ = e; state_ = DONE;
+      cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::thread th_;
+  Task task_;
+  std::shared_ptr<MargPrior> result_;
+  std::exception_ptr err_;
+  int state_ = IDLE;
+  bool quit_ = false;
+};
+
 class Estimator {
  public:
   explicit Estimator(const EstConfig &cfg);
@@ -122,7 +187,11 @@ class Estimator {
   M3d R_WI_;
   enum { EV_SKIPPED = 0, EV_FILLING = 1, EV_INIT_FAILED = 2, EV_INITIALISED = 3, EV_SOLVED = 4 };
   int last_event_ = EV_SKIPPED;
-  std::shared_ptr<MargPrior> last_marg_;
+  std::shared_ptr<MargPrior> last_marg_;   // read through JoinMarg() only: a marginalization may still be running
+  MargWorker marg_worker_;
+  bool async_marg_ = true;                  // LIO_ASYNC_MARG=0 computes it inside SolveOptimization
+  unsigned marg_epoch_ = 0, marg_task_epoch_ = 0;   // Restore() bumps the epoch: a result computed for a discarded state is dropped
+  void JoinMarg() { std::shared_ptr<MargPrior> r; if (marg_worker_.join(r) && marg_task_epoch_ == marg_epoch_) last_marg_ = std::move(r); }
   std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
   std::shared_ptr<Preintegration> tmp_pre_integration_;
   int laser_odom_iters_ = 0;

@@ -85,10 +85,12 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_moment_tickets_.p, 0, LIO_MAX_FRAMES * sizeof(int)));
   // measured on the MI355X: fold inside the launch 18.8 us vs moments + separate reduce launch 13.6 us per linearisation
   fold_in_kernel_ = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL") != nullptr;
+  if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));
 }
 
 Estimator::~Estimator() {
+  try { JoinMarg(); } catch (...) {}
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -686,6 +688,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
       auto &pi = pre_integrations_[pivot + i + 1];
       if (pi && pi->sum_dt <= 10.0) sys.pim[i] = pi;
     }
+  JoinMarg();  // the previous solve's marginalization has had the map + feature stages to finish
   if (cfg_.marginalization_factor && last_marg_) sys.prior = last_marg_;
   if (cfg_.prior_factor) {
     sys.use_prior_factor = true;
@@ -732,18 +735,30 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     WindowParams M;
     VectorToParams(M);
     M.ex_constant = false;
-    WindowSystem msys;
-    msys.Wo = Wo_;
-    msys.use_lidar = cfg_.point_distance_factor;
-    msys.pim.assign(Wo_, nullptr);
+    auto msys = std::make_shared<WindowSystem>();
+    msys->Wo = Wo_;
+    msys->use_lidar = cfg_.point_distance_factor;
+    msys->pim.assign(Wo_, nullptr);
     if (cfg_.imu_factor) {
       auto &pi = pre_integrations_[pivot + 1];
-      if (pi && pi->sum_dt < 10.0) msys.pim[0] = pi;
+      if (pi && pi->sum_dt < 10.0) msys->pim[0] = pi;
     }
-    msys.prior = last_marg_;
-    msys.lidar_eval = sys.lidar_eval; msys.lidar_launch = sys.lidar_launch; msys.lidar_wait = sys.lidar_wait;
-    if (msys.use_lidar && !s.final_moments.empty()) msys.preset_moments = &s.final_moments;  // no second device pass at the same point
-    last_marg_ = marginalize(msys, M);
+    msys->prior = last_marg_;
+    const bool have_moments = msys->use_lidar && !s.final_moments.empty();
+    if (async_marg_ && (have_moments || !msys->use_lidar)) {
+      // host-only from here (the lidar moments at the final point come from the solve): hand it to the worker
+      auto moments = std::make_shared<std::vector<FrameMoments>>(std::move(s.final_moments));
+      auto Mp = std::make_shared<WindowParams>(std::move(M));
+      marg_task_epoch_ = marg_epoch_;
+      marg_worker_.submit([msys, moments, Mp, have_moments] {
+        if (have_moments) msys->preset_moments = moments.get();
+        return marginalize(*msys, *Mp);
+      });
+    } else {
+      msys->lidar_eval = sys.lidar_eval; msys->lidar_launch = sys.lidar_launch; msys->lidar_wait = sys.lidar_wait;
+      if (have_moments) msys->preset_moments = &s.final_moments;  // no second device pass at the same point
+      last_marg_ = marginalize(*msys, M);
+    }
     R.marginalized = 1;
     R.ms_marg = now_ms() - tm0;
   }
@@ -789,6 +804,7 @@ void Estimator::SlideWindow() {
 }
 
 void Estimator::Snapshot() {
+  JoinMarg();
   snap_.reset(new HostState{Ps_, Vs_, Bas_, Bgs_, Rs_, g_vec_, acc_last_, gyr_last_, transform_lb_, inited_, first_imu_, init_local_map_,
                             convergence_flag_, cir_buf_count_, all_laser_transforms_, n_state_, n_frames_, laser_odom_recv_count_,
                             extrinsic_stage_, last_event_, initial_time_, R_WI_, last_marg_, pre_integrations_,
@@ -806,6 +822,7 @@ void Estimator::Snapshot() {
 }
 
 bool Estimator::Restore() {
+  ++marg_epoch_;  // a marginalization still in flight belongs to the state being discarded: its result is dropped at the next join
   if (!snap_) return false;
   const HostState &h = *snap_;
   Ps_ = h.Ps; Vs_ = h.Vs; Bas_ = h.Bas; Bgs_ = h.Bgs; Rs_ = h.Rs; g_vec_ = h.g_vec; acc_last_ = h.acc_last; gyr_last_ = h.gyr_last;

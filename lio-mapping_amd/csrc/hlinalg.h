@@ -247,17 +247,20 @@ inline bool gj_inverse(const double *Ain, int n, double *Ainv) {
 // COLUMNS of V (row-major n x n).  Householder reduction to tridiagonal form followed by the implicit
 // QL algorithm (the classical tred2/tql2 pair).
 inline bool sym_eig(const double *A, int n, double *w, double *V) {
-  std::vector<double> e(n, 0.0);
-  for (int i = 0; i < n * n; ++i) V[i] = A[i];
+  // The classical formulation walks COLUMNS of a row-major V in every inner loop (stride n: no vector loads).  All of it
+  // runs here on T = V^T instead — same operations in the same order, contiguous inner loops — and V is T^T at the end.
+  std::vector<double> e(n, 0.0), Tbuf(size_t(n) * n);
+  double *T = Tbuf.data();
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) T[j * n + i] = A[i * n + j];
   double *d = w;
   // --- tred2
-  for (int j = 0; j < n; ++j) d[j] = V[(n - 1) * n + j];
+  for (int j = 0; j < n; ++j) d[j] = T[(j) * n + (n - 1)];
   for (int i = n - 1; i > 0; --i) {
     double scale = 0.0, h = 0.0;
     for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
     if (scale == 0.0) {
       e[i] = d[i - 1];
-      for (int j = 0; j < i; ++j) { d[j] = V[(i - 1) * n + j]; V[i * n + j] = 0.0; V[j * n + i] = 0.0; }
+      for (int j = 0; j < i; ++j) { d[j] = T[(j) * n + (i - 1)]; T[(j) * n + i] = 0.0; T[(i) * n + j] = 0.0; }
     } else {
       for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
       double f = d[i - 1];
@@ -269,9 +272,9 @@ inline bool sym_eig(const double *A, int n, double *w, double *V) {
       for (int j = 0; j < i; ++j) e[j] = 0.0;
       for (int j = 0; j < i; ++j) {
         f = d[j];
-        V[j * n + i] = f;
-        g = e[j] + V[j * n + j] * f;
-        for (int k = j + 1; k <= i - 1; ++k) { g += V[k * n + j] * d[k]; e[k] += V[k * n + j] * f; }
+        T[(i) * n + j] = f;
+        g = e[j] + T[(j) * n + j] * f;
+        for (int k = j + 1; k <= i - 1; ++k) { g += T[(j) * n + k] * d[k]; e[k] += T[(j) * n + k] * f; }
         e[j] = g;
       }
       f = 0.0;
@@ -280,29 +283,29 @@ inline bool sym_eig(const double *A, int n, double *w, double *V) {
       for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
       for (int j = 0; j < i; ++j) {
         f = d[j]; g = e[j];
-        for (int k = j; k <= i - 1; ++k) V[k * n + j] -= (f * e[k] + g * d[k]);
-        d[j] = V[(i - 1) * n + j];
-        V[i * n + j] = 0.0;
+        { double *__restrict tj = T + size_t(j) * n; for (int k = j; k <= i - 1; ++k) tj[k] -= (f * e[k] + g * d[k]); }
+        d[j] = T[(j) * n + (i - 1)];
+        T[(j) * n + i] = 0.0;
       }
     }
     d[i] = h;
   }
   for (int i = 0; i < n - 1; ++i) {
-    V[(n - 1) * n + i] = V[i * n + i];
-    V[i * n + i] = 1.0;
+    T[(i) * n + (n - 1)] = T[(i) * n + i];
+    T[(i) * n + i] = 1.0;
     double h = d[i + 1];
     if (h != 0.0) {
-      for (int k = 0; k <= i; ++k) d[k] = V[k * n + i + 1] / h;
+      for (int k = 0; k <= i; ++k) d[k] = T[(i + 1) * n + k] / h;
       for (int j = 0; j <= i; ++j) {
         double g = 0.0;
-        for (int k = 0; k <= i; ++k) g += V[k * n + i + 1] * V[k * n + j];
-        for (int k = 0; k <= i; ++k) V[k * n + j] -= g * d[k];
+        for (int k = 0; k <= i; ++k) g += T[(i + 1) * n + k] * T[(j) * n + k];
+        { double *__restrict tj = T + size_t(j) * n; for (int k = 0; k <= i; ++k) tj[k] -= g * d[k]; }
       }
     }
-    for (int k = 0; k <= i; ++k) V[k * n + i + 1] = 0.0;
+    for (int k = 0; k <= i; ++k) T[(i + 1) * n + k] = 0.0;
   }
-  for (int j = 0; j < n; ++j) { d[j] = V[(n - 1) * n + j]; V[(n - 1) * n + j] = 0.0; }
-  V[(n - 1) * n + n - 1] = 1.0;
+  for (int j = 0; j < n; ++j) { d[j] = T[(j) * n + (n - 1)]; T[(j) * n + (n - 1)] = 0.0; }
+  T[(n - 1) * n + (n - 1)] = 1.0;
   e[0] = 0.0;
   // --- tql2
   for (int i = 1; i < n; ++i) e[i - 1] = e[i];
@@ -342,10 +345,11 @@ inline bool sym_eig(const double *A, int n, double *w, double *V) {
           c = p / r;
           p = c * d[i] - s * g;
           d[i + 1] = h + s * (c * g + s * d[i]);
+          double *__restrict t1 = T + size_t(i + 1) * n, *__restrict t0 = T + size_t(i) * n;  // two distinct rows: vectorises
           for (int k = 0; k < n; ++k) {
-            h = V[k * n + i + 1];
-            V[k * n + i + 1] = s * V[k * n + i] + c * h;
-            V[k * n + i] = c * V[k * n + i] - s * h;
+            const double hk = t1[k], vk = t0[k];
+            t1[k] = s * vk + c * hk;
+            t0[k] = c * vk - s * hk;
           }
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
@@ -364,9 +368,10 @@ inline bool sym_eig(const double *A, int n, double *w, double *V) {
       if (d[j] < p) { k = j; p = d[j]; }
     if (k != i) {
       d[k] = d[i]; d[i] = p;
-      for (int j = 0; j < n; ++j) std::swap(V[j * n + i], V[j * n + k]);
+      for (int j = 0; j < n; ++j) std::swap(T[(i) * n + j], T[(k) * n + j]);
     }
   }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = T[j * n + i];
   return true;
 }
 

@@ -195,6 +195,7 @@ _SIGS = {
     "lio_est_push_frame": (C.c_int, [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double]),
     "lio_est_solve_optimization": (C.c_int, [C.c_void_p, C.POINTER(SolveReport)]),
     "lio_est_slide_window": (C.c_int, [C.c_void_p]),
+    "lio_est_sync": (C.c_int, [C.c_void_p]),
     "lio_est_set_window": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 6),
     "lio_est_get_window": (C.c_int, [C.c_void_p, C.c_int] + [c_double_p] * 5 + [C.POINTER(TransformF)]),
     "lio_est_set_surf_stack": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_size_t]),
@@ -678,6 +679,10 @@ class Estimator:
 
     def slide(self):
         _chk(self.lib.dll.lio_est_slide_window(self.h), "lio_est_slide_window")
+
+    def sync(self):
+        """Wait for the handle's deferred work (the marginalization worker of the product)."""
+        _chk(self.lib.dll.lio_est_sync(self.h), "lio_est_sync")
 
     def set_window(self, Ps, Rs, Vs, Bas, Bgs, g_vec):
         n = self.W + 1

@@ -543,6 +543,7 @@ int lio_est_slide_window(lio_est *h) {
   h->est.SlideWindow();
   return LIO_OK;
 }
+int lio_est_sync(lio_est *h) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_est_set_window(lio_est *h, int n, const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs,
                        const double g[3]) {
   if (!h || !Ps || !Rs || !Vs || !Bas || !Bgs || !g) return LIO_ERR_ARG;

@@ -259,6 +259,43 @@ def test_sequence_with_marginalization(hip, oracle):
     np.testing.assert_allclose(pa["x0"], pb["x0"], atol=2e-4)
 
 
+def test_deferred_marginalization_equals_inline(hip, monkeypatch):
+    """The marginalization worker only moves WHEN the prior is computed: a sequence of solves with
+    it gives bit-identical windows and priors to the same sequence with LIO_ASYNC_MARG=0, also across snapshot /
+    restore (which drops an in-flight result of the discarded state)."""
+    ds = synth.make_dataset("indoor", 10, 0.2)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+
+    def run(async_on):
+        monkeypatch.setenv("LIO_ASYNC_MARG", "1" if async_on else "0")
+        cfg = pipeline.config_indoor(hip, 4, 2)
+        cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(hip, cfg)
+        pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01, seed=3)
+        out = []
+        est.solve(); est.slide()
+        for k in range(est.W + 1, 8):
+            pipeline.feed_frame(est, ds, k, clouds[k][0], clouds[k][1])
+            out.append(est.get_window())
+        est.snapshot()
+        pipeline.feed_frame(est, ds, 8, clouds[8][0], clouds[8][1])
+        est.restore()                                   # the marginalization of frame 8 may still be running
+        rep = pipeline.feed_frame(est, ds, 8, clouds[8][0], clouds[8][1])
+        assert rep.marginalized == 1
+        out.append(est.get_window())
+        est.sync()
+        return out, est.prior()
+
+    (wa, pa), (wb, pb) = run(True), run(False)
+    for a, b in zip(wa, wb):
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+            np.testing.assert_array_equal(a[key], b[key])
+    assert pa["n"] == pb["n"]
+    np.testing.assert_array_equal(pa["JtJ"], pb["JtJ"])
+    np.testing.assert_array_equal(pa["x0"], pb["x0"])
+
+
 def test_deskew_path(hip, oracle):
     ds, clouds, ea, eb = _make_pair(hip, oracle, deskew=True, n_frames=7)
     for est in (ea, eb):

@@ -467,6 +467,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // CalculateLaserOdom: <= 10 dependent rounds, no host round trip inside (the device carries the
     // transform and the convergence flag; later launches turn into no-ops)
     OdomState st{};
+    bool have_state = false;  // a converged peek already brought the final state to the host
     std::memcpy(st.T, &tfs[size_t(W_) * 8], 8 * sizeof(float));
     LIO_HIP(hipMemcpyAsync(d_odom_.p, &st, sizeof(st), hipMemcpyHostToDevice, stream_));
     const int M = int(stacks_[W_].n);
@@ -481,7 +482,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         if (iter == chunk_end[chunk]) {
           LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
           LIO_HIP(hipStreamSynchronize(stream_));
-          if (st.converged) break;
+          if (st.converged) { have_state = true; break; }
           ++chunk;
         }
         FeatArgs fo{};
@@ -503,10 +504,14 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         timers_.end(t3h, stream_);
       }
     }
-    LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+    // the older frames' features (second stream) must be complete before anything later on stream_ reads them; the host
+    // itself only needs the final state, which a converged peek has already delivered
     LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
-    LIO_HIP(hipStreamSynchronize(stream_));
-    timers_.resolve();
+    if (!have_state) {
+      LIO_HIP(hipMemcpyAsync(&st, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+      LIO_HIP(hipStreamSynchronize(stream_));
+      timers_.resolve();
+    }
     laser_odom_iters_ = st.iters;
     laser_odom_transform_ = Rigidf(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));
     if (keep_mult > 1) nslots_[W_] = int(stacks_[W_].n) * std::max(1, st.iters);

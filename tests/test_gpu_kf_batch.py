@@ -110,3 +110,35 @@ def test_batch_hdl64_many_keyframes(hip, oracle):
     for lo in (0, 24):
         p = rh["p"][lo:lo + 24]
         assert np.max(np.linalg.norm(p[:, :2] - p[:, :2].mean(axis=0), axis=1)) < 0.02
+
+
+def test_batch_larger_than_one_launch(hip, oracle):
+    """More keyframes than one launch carries (grid z/y limit: 32768 per launch, kf_batch.hip): 33 000 small keyframes
+    against one shared local map; a sample is checked against the oracle and every copy of a keyframe must agree with
+    its twin in the other launch chunk."""
+    maps, kfs = keyframe_inputs(oracle, "indoor", 2, 1)
+    _, cs, ss, T0, _ = kfs[0]
+    rng = np.random.default_rng(2)
+    variants = []
+    for _ in range(8):                                  # 8 distinct sub-sampled keyframes (>= 50 rows each round)
+        variants.append((cs[rng.choice(len(cs), 40, replace=False)], ss[rng.choice(len(ss), 300, replace=False)]))
+    n = 33000
+    bh = capi.KeyframeBatch(hip)
+    bh.add_map(*maps[0])
+    for k in range(n):
+        c, s_ = variants[k % 8]
+        bh.add_keyframe(0, c, s_, T0)
+    rh = bh.refine()
+    assert len(bh) == n and rh["p"].shape == (n, 3)
+    bo = capi.KeyframeBatch(oracle)
+    bo.add_map(*maps[0])
+    for v in range(8):
+        bo.add_keyframe(0, variants[v][0], variants[v][1], T0)
+    ro = bo.refine()
+    first = {key: (rh[key][:8] if key != "device_ms" else rh[key]) for key in rh}
+    _assert_batches_agree(first, ro)
+    for v in range(8):                                   # identical inputs -> identical outputs, whichever chunk they ran in
+        idx = np.arange(v, n, 8)
+        assert np.all(rh["iterations"][idx] == rh["iterations"][v])
+        np.testing.assert_array_equal(rh["p"][idx], np.broadcast_to(rh["p"][v], (len(idx), 3)))
+        np.testing.assert_array_equal(rh["q"][idx], np.broadcast_to(rh["q"][v], (len(idx), 4)))

@@ -55,7 +55,6 @@ class PointProcessorDev {
   DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_;
   DBuf<int> lf_ring_count_;
   DBuf<PPDeviceCounts> d_counts_;
-  DBuf<char> tmp_;
 };
 
 }  // namespace lio

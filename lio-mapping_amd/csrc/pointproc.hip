@@ -8,7 +8,6 @@
 // bit-exact by construction, not by tolerance.
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <cfloat>
 #include <climits>

@@ -38,8 +38,18 @@ class VoxelGridDev {
   // Filters `in` (device, n points) with cubic leaf; result in `out`; returns the output count (host sync).
   // host_params (optional) receives the bounds used.
   size_t run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params = nullptr);
+  // the same in two halves: launch() only enqueues, finish() waits on that stream and returns the count
+  void launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s);
+  size_t finish(VoxParams *host_params = nullptr);
+  VoxelGridDev() = default;
+  VoxelGridDev(const VoxelGridDev &) = delete;
+  VoxelGridDev &operator=(const VoxelGridDev &) = delete;
+  ~VoxelGridDev();
 
  private:
+  const float4 *p_in_ = nullptr; size_t p_n_ = 0; DBuf<float4> *p_out_ = nullptr; hipStream_t p_stream_ = nullptr;  // the pending launch
+  int *h_count_ = nullptr;          // pinned: output count, followed by the VoxParams
+  VoxParams *h_params_ = nullptr;
   DBuf<float> partial_;
   DBuf<VoxParams> params_;
   DBuf<uint32_t> keys_, keys2_, vals_, vals2_;

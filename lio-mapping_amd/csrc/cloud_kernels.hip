@@ -191,11 +191,11 @@ void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxPara
   LIO_HIP(hipGetLastError());
 }
 
-size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params) {
-  if (n == 0) {
-    if (host_params) std::memset(host_params, 0, sizeof(*host_params));
-    return 0;
-  }
+// launch() enqueues the whole filter on `s` (no host sync); finish() waits for it and returns the output count.  Two
+// filters launched on two streams overlap (the scan-to-map step filters its corner and surf stacks that way).
+void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s) {
+  p_in_ = in; p_n_ = n; p_out_ = &out; p_stream_ = s;
+  if (n == 0) return;
   const int ni = int(n);
   const float inv_leaf = 1.0f / leaf;
   const int nb = std::min(cdiv(ni, 256), 512);
@@ -204,6 +204,10 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
   keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n);
   flags_.reserve(n); pos_.reserve(n); count_.reserve(1);
   out.reserve(n);
+  if (!h_count_) {
+    LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_count_), sizeof(int) + sizeof(VoxParams)));
+    h_params_ = reinterpret_cast<VoxParams *>(h_count_ + 1);
+  }
   hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, in, ni, partial_.p);
   hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, s, partial_.p, nb, inv_leaf, params_.p);
   hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, ni, inv_leaf, params_.p, keys_.p, vals_.p);
@@ -217,17 +221,33 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
   LIO_HIP(rocprim::exclusive_scan(tmp_.p, scan_bytes, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
   hipLaunchKernelGGL(k_centroids, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, keys2_.p, vals2_.p, flags_.p, pos_.p, ni, out.p, count_.p);
   LIO_HIP(hipGetLastError());
-  int count = 0;
-  VoxParams hp;
-  LIO_HIP(hipMemcpyAsync(&count, count_.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  LIO_HIP(hipMemcpyAsync(&hp, params_.p, sizeof(VoxParams), hipMemcpyDeviceToHost, s));
-  LIO_HIP(hipStreamSynchronize(s));
+  LIO_HIP(hipMemcpyAsync(h_count_, count_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(h_params_, params_.p, sizeof(VoxParams), hipMemcpyDeviceToHost, s));
+}
+
+size_t VoxelGridDev::finish(VoxParams *host_params) {
+  if (p_n_ == 0) {
+    if (host_params) std::memset(host_params, 0, sizeof(*host_params));
+    return 0;
+  }
+  LIO_HIP(hipStreamSynchronize(p_stream_));
+  int count = *h_count_;
+  const VoxParams hp = *h_params_;
   if (hp.overflow) {  // PCL: "Leaf size is too small for the input dataset" -> output = input
-    LIO_HIP(hipMemcpyAsync(out.p, in, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    count = ni;
+    LIO_HIP(hipMemcpyAsync(p_out_->p, p_in_, p_n_ * sizeof(float4), hipMemcpyDeviceToDevice, p_stream_));
+    count = int(p_n_);
   }
   if (host_params) *host_params = hp;
   return size_t(count);
+}
+
+size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params) {
+  launch(in, n, leaf, out, s);
+  return finish(host_params);
+}
+
+VoxelGridDev::~VoxelGridDev() {
+  if (h_count_) (void)hipHostFree(h_count_);
 }
 
 // ------------------------------------------------------------------------------------------------

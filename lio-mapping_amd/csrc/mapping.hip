@@ -258,6 +258,8 @@ MappingDev::MappingDev(const lio_map_config &cfg) : cfg_(cfg) {
   LIO_HIP(hipGetDeviceCount(&nd));
   if (nd <= 0) throw DeviceError("no HIP device: the product has no CPU path");
   LIO_HIP(hipStreamCreate(&stream_));
+  LIO_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   for (ClassMap &m : cls_) {
     m.h_counters = pinned_alloc<MapCounters>();
     m.h_bounds = pinned_alloc<VoxParams>();
@@ -275,6 +277,8 @@ MappingDev::~MappingDev() {
     if (m.h_bounds) (void)hipHostFree(m.h_bounds);
   }
   if (h_state_) (void)hipHostFree(h_state_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -511,10 +515,12 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   const double tt1 = now_ms();
   // VoxelGrid of the stacks (:1005-1015)
   const float leaf[2] = {cfg_.corner_filter_size, cfg_.surf_filter_size};
-  for (int c = 0; c < 2; ++c) {
-    ClassMap &m = cls_[c];
-    m.n_stack = cnt[c] ? m.vox.run(m.stack_raw.p, cnt[c], leaf[c], m.stack_ds, s) : 0;
-  }
+  // the two filters are independent: the surf one goes to a second stream, forked after the round-trip kernels above
+  LIO_HIP(hipEventRecord(ev_fork_, s));
+  LIO_HIP(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+  hipStream_t vs_stream[2] = {s, stream2_};
+  for (int c = 0; c < 2; ++c) cls_[c].vox.launch(cls_[c].stack_raw.p, cnt[c], leaf[c], cls_[c].stack_ds, vs_stream[c]);
+  for (int c = 0; c < 2; ++c) cls_[c].n_stack = cls_[c].vox.finish();
 
   const double tt2 = now_ms();
   if (builder) {  // MapBuilder.cc:527-558: optimise every skip_count-th call, always update the map

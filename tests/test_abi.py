@@ -50,6 +50,11 @@ def test_product_has_no_cpu_fallback(hip):
     n = ctypes.c_size_t(0)
     rc = hip.dll.lio_voxel_grid(out.ctypes.data_as(capi.c_float_p), 4, 0.4, out.ctypes.data_as(capi.c_float_p), ctypes.byref(n))
     assert rc == -3
+    # every handle that owns device state refuses to exist
+    assert not hip.dll.lio_map_create(None)
+    assert not hip.dll.lio_kf_batch_create(None)
+    assert not hip.dll.lio_odom_create(0.1, 2, 25, 0)
+    assert not hip.dll.lio_pp_create(-15.0, 15.0, 16, None)
 
 
 def test_host_side_preintegration_matches_oracle(hip, oracle):

@@ -14,7 +14,11 @@ moments per linearisation; strong scaling).
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (HIP events on the
 estimator's stream), `cpu_baseline` = the CPU oracle timed on this box's host cores on the same window,
 `batched` = throughput with several independent windows in flight on the one GPU (the single-window path
-is latency-bound; this shows how far the same kernels go when the GPU is given more to do).
+is latency-bound; this shows how far the same kernels go when the GPU is given more to do),
+`keyframe_batch` = BASELINE.json configs[4] at --keyframes keyframes (N = 1 only).
+
+`--workload keyframes` makes configs[4] the bench line itself: a step = one refinement of all --keyframes keyframes,
+the keyframe list sharded over the ranks, one all-gather of the poses per step (strong scaling).
 """
 import argparse
 import json
@@ -92,7 +96,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hdl64", choices=["hdl64", "vlp16"])
+    ap.add_argument("--workload", default="hdl64", choices=["hdl64", "vlp16", "keyframes"],
+                    help="hdl64 (default, the headline metric) / vlp16: sliding-window solves.  keyframes: BASELINE.json configs[4], "
+                         "--keyframes HDL-64 keyframes refined per step, the keyframe list sharded over the ranks + all-gather of the poses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--windows", type=int, default=4, help="independent windows in flight for the `batched` extra (0 = skip)")
@@ -117,6 +123,11 @@ def main():
     from lio_amd import capi, dist_util
 
     hip = capi.load_hip()
+    if args.workload == "keyframes":
+        keyframes_workload(args, hip, rank, world, torch, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     kind = "outdoor" if args.workload == "hdl64" else "indoor"
     W, Wo = 15, 5
     t_setup = time.time()
@@ -267,6 +278,85 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def keyframes_workload(args, hip, rank, world, torch, dist):
+    """configs[4] as a bench line: a step = one refinement of ALL --keyframes keyframes (each with its own local map in HBM).
+    Rank r owns keyframes r, r+N, ...; the one exchange is an all-gather of the refined poses (RCCL).  Strong scaling."""
+    from lio_amd import capi, dist_util, synth
+
+    n_kf = max(args.keyframes, world)
+    ds = make_dataset("outdoor", 15)                      # the same scans on every rank
+    clouds, _ = feature_clouds(hip, ds)
+    captured = []
+    mapping_ms_per_scan(hip, ds, clouds, capture=captured)
+    rng = np.random.default_rng(5)
+    n_src = len(captured)
+    mine = list(range(rank, n_kf, world))
+    b = capi.KeyframeBatch(hip)
+    alg = []
+    T0s = []
+    for k in range(n_kf):                                 # every rank draws all initial poses: identical lists everywhere
+        c = captured[k % n_src]
+        q, p = c["T"]
+        R = synth.rot_from_quat(np.asarray(q, np.float64)) @ synth.small_rot(rng.uniform(-0.01, 0.01, 3))
+        T0s.append((synth.quat_from_rot(R), np.asarray(p, np.float64) + rng.uniform(-0.15, 0.15, 3)))
+    for j, k in enumerate(mine):
+        c = captured[k % n_src]
+        b.add_map(c["corner_map"], c["surf_map"])
+        b.add_keyframe(j, c["corner"], c["surf"], T0s[k])
+        M, N = c["corner"].shape[0] + c["surf"].shape[0], c["corner_map"].shape[0] + c["surf_map"].shape[0]
+        alg.append(16 * (M + N) + 72 * M)
+    per_rank = -(-n_kf // world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.zeros((per_rank, 7), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if world > 1 else None
+
+    def step():
+        r = b.refine()
+        if world > 1:
+            buf[: len(mine), 0:4] = torch.from_numpy(r["q"]).to(dev)
+            buf[: len(mine), 4:7] = torch.from_numpy(r["p"]).to(dev)
+            dist.all_gather(gathered, buf)
+        return r
+
+    for _ in range(max(args.warmup, 1)):
+        r = step()
+    dist_util.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(args.steps):
+        r = step()
+        dev_ms.append(r["device_ms"])
+    torch.cuda.synchronize()
+    dist_util.barrier(world)
+    dt = time.perf_counter() - t0
+    dt_max = dist_util.max_over_ranks(dt, world, device="cuda")
+    if rank != 0:
+        return
+    alg_bytes = float(np.dot(np.asarray(alg, np.float64), r["iterations"].astype(np.float64)))
+    ms = float(np.median(dev_ms))
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        o = keyframe_batch_stats(_oracle_lib(), captured, 4, reps=1, distinct_maps=False)
+        cpu = {"value": o["keyframes_per_s"], "unit": "keyframes/s", "cores": 1, "kind": "port",
+               "sample": "4 keyframes of the same workload refined one after the other by the CPU oracle (oracle/mapping.h RefineKeyframe)"}
+    print(json.dumps({
+        "metric": "keyframe refinements/sec, 64-line local maps (map_builder batched refinement, BASELINE.json configs[4])",
+        "value": round(n_kf * args.steps / dt_max, 1), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n_kf} HDL-64E keyframes (S_outdoor), each against its own local map resident in HBM, one scan-to-map Gauss-Newton loop per keyframe",
+                   "stack_points_per_keyframe": int(captured[0]["corner"].shape[0] + captured[0]["surf"].shape[0]),
+                   "local_map_points_per_keyframe": int(captured[0]["corner_map"].shape[0] + captured[0]["surf_map"].shape[0]),
+                   "iterations_mean": round(float(r["iterations"].mean()), 2),
+                   "parallelism": f"keyframes sharded over {world} ranks, all-gather of the poses" if world > 1 else "1 batch"},
+        "roofline": {"kernel": "k_kf_round (+ k_kf_rows, k_kf_update)", "bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                     "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                     "note": "rank 0's share; algorithmic bytes = sum over its keyframes of iterations x (16(M+N) + 72 M) (SURVEY.md 8(d)); device time of the round loop by HIP events; the kernel is gather-latency-bound (DESIGN.md 3.4)"},
+        "cpu_baseline": cpu,
+    }))
 
 
 def batched_throughput(hip, ds, clouds, kind, W, Wo, est0, n_windows, steps):

@@ -43,6 +43,8 @@ class PointProcessorDev {
   lio_pp_config cfg_;
   hipStream_t stream_ = nullptr;
   PPDeviceCounts counts_{};
+  struct HostOut { PPDeviceCounts counts; int ring_offsets[LIO_PP_MAX_RINGS + 1]; };
+  HostOut *h_out_ = nullptr;   // pinned landing zone of the per-sweep results
   std::vector<int> ring_offsets_;
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
   DBuf<float> azi_, curv_;

@@ -606,11 +606,13 @@ PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const 
   if (nd <= 0) throw DeviceError("no HIP device: the product has no CPU path");
   LIO_HIP(hipStreamCreate(&stream_));
   ring_offsets_.assign(rings + 1, 0);
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_out_), sizeof(HostOut)));
   // the pick kernel needs up to ~104 KB of dynamic LDS
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lf_ring), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
 }
 PointProcessorDev::~PointProcessorDev() {
+  if (h_out_) (void)hipHostFree(h_out_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -643,8 +645,7 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
   LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
-  int big = INT_MAX;
-  LIO_HIP(hipMemcpyAsync(first_valid_.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
+  LIO_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(first_valid_.p), INT_MAX, 1, s));
   const uint16_t *d_ring = nullptr;
   if (ring) {
     ring_in_.reserve(n);
@@ -670,12 +671,15 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
                      class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_.p);
   LIO_HIP(hipGetLastError());
-  LIO_HIP(hipMemcpyAsync(&counts_, d_counts_.p, sizeof(counts_), hipMemcpyDeviceToHost, s));
-  LIO_HIP(hipMemcpyAsync(ring_offsets_.data(), d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));
+  // results come back through pinned memory: a D2H into pageable memory blocks the host per copy (20 us between the two)
+  LIO_HIP(hipMemcpyAsync(&h_out_->counts, d_counts_.p, sizeof(PPDeviceCounts), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(h_out_->ring_offsets, d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));
   LIO_HIP(hipStreamSynchronize(s));
   if (dbg)
     std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us\n",
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  counts_ = h_out_->counts;
+  std::copy(h_out_->ring_offsets, h_out_->ring_offsets + rings_ + 1, ring_offsets_.begin());
   counts_.n_ring_points = ring_offsets_[rings_];
   if (counts_.overflow) throw std::runtime_error("PointProcessor: a ring exceeds LIO_PP_MAX_RING_POINTS");
 }

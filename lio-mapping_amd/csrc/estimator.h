@@ -234,6 +234,7 @@ class Estimator {
   DBuf<int> d_moment_tickets_;
   bool fold_in_kernel_ = false;
   double *h_moment_out_ = nullptr;  // pinned
+  OdomState *h_odom_ = nullptr;     // pinned landing zone of the laser-odom state peeks
   std::unique_ptr<HostState> snap_;
   std::vector<DeviceCloud> snap_stacks_;
 };

@@ -33,6 +33,7 @@ class OdometryDev {
   DBuf<float> partial_c_, partial_s_;
   DBuf<VoxParams> bounds_;
   VoxParams *h_bounds_ = nullptr;  // pinned
+  OdomState *h_state_ = nullptr;   // pinned
 };
 
 }  // namespace lio

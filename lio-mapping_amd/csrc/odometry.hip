@@ -321,6 +321,7 @@ OdometryDev::OdometryDev(float scan_period, int io_ratio, int max_iter, bool no_
 }
 OdometryDev::~OdometryDev() {
   if (h_bounds_) (void)hipHostFree(h_bounds_);
+  if (h_state_) (void)hipHostFree(h_state_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -357,6 +358,7 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
     return;
   }
   if (enable_odom_) {
+    if (!h_state_) LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_state_), sizeof(OdomState), hipHostMallocDefault));
     OdomState st{};
     st.T[0] = transform_es_.rot.x; st.T[1] = transform_es_.rot.y; st.T[2] = transform_es_.rot.z; st.T[3] = transform_es_.rot.w;
     st.T[4] = transform_es_.pos.x; st.T[5] = transform_es_.pos.y; st.T[6] = transform_es_.pos.z;
@@ -374,8 +376,9 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
       d_partials_.reserve(size_t(nb) * 28);
       for (int iter = 0; iter < max_iter_; ++iter) {
         if (iter > 0 && iter % 5 == 0) {  // peek at the abort flag where the reference refreshes correspondences
-          LIO_HIP(hipMemcpyAsync(&st, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
+          LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));  // pinned landing zone
           LIO_HIP(hipStreamSynchronize(s));
+          st = *h_state_;
           if (st.converged) break;
         }
         if (nq > 0 && iter % 5 == 0) hipLaunchKernelGGL(k_odo_corr, dim3(nq), dim3(64), 0, s, a, d_state_.p, idx_.p);
@@ -384,8 +387,9 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
       }
       LIO_HIP(hipGetLastError());
     }
-    LIO_HIP(hipMemcpyAsync(&st, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));
+    st = *h_state_;
     iterations_done_ = st.iters;
     last_num_sel_ = int(st.T[7]);
     transform_es_ = Rigid<float>(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));

@@ -277,6 +277,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # rank 0 runs the untimed extras above: leave the group together
         dist.destroy_process_group()
 
 

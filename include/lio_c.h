@@ -325,6 +325,9 @@ void lio_est_destroy(lio_est *);
 
 /* Estimator::ProcessImu (Estimator.cc:338-427) */
 int lio_est_process_imu(lio_est *, double dt, const double acc[3], const double gyr[3], double stamp);
+/* The IMU loop of Estimator::ProcessEstimation (Estimator.cc:2700-2726): n samples of one laser interval in one call;
+ * acc / gyr are n x 3, row-major.  Identical to n lio_est_process_imu calls. */
+int lio_est_process_imu_batch(lio_est *, size_t n, const double *dt, const double *acc, const double *gyr, const double *stamp);
 /* Estimator::ProcessLaserOdom (Estimator.cc:430-774).  Until the IMU is initialised (NOT_INITED, :490-618): every
  * init_window_factor-th frame is pushed (the clouds are then PointMapping's down-sampled stacks, :474-481); once
  * window_size+1 frames are held, EstimateExtrinsicRotation / RunInitialization (:858-958) are tried and on success

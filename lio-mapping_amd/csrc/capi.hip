@@ -510,6 +510,11 @@ int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double
   h->e->ProcessImu(dt, v3(acc), v3(gyr), stamp);
   return LIO_OK;
 }
+int lio_est_process_imu_batch(lio_est *h, size_t n, const double *dt, const double *acc, const double *gyr, const double *stamp) {
+  if (!h || (n && (!dt || !acc || !gyr || !stamp))) return LIO_ERR_ARG;
+  for (size_t k = 0; k < n; ++k) h->e->ProcessImu(dt[k], v3(acc + 3 * k), v3(gyr + 3 * k), stamp[k]);
+  return LIO_OK;
+}
 int lio_est_process_laser_odom(lio_est *h, const lio_transform_f *T, const float *surf, size_t ns, const float *corner, size_t nc, double stamp,
                                lio_solve_report *rep) {
   if (!h || !T || (!surf && ns) || (!corner && nc)) return LIO_ERR_ARG;

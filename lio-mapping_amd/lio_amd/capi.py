@@ -186,6 +186,7 @@ _SIGS = {
     "lio_est_create": (C.c_void_p, [C.POINTER(EstConfig)]),
     "lio_est_destroy": (None, [C.c_void_p]),
     "lio_est_process_imu": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p, C.c_double]),
+    "lio_est_process_imu_batch": (C.c_int, [C.c_void_p, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p]),
     "lio_est_process_laser_odom": (
         C.c_int,
         [C.c_void_p, C.POINTER(TransformF), c_float_p, C.c_size_t, c_float_p, C.c_size_t, C.c_double, C.POINTER(SolveReport)],
@@ -640,6 +641,13 @@ class Estimator:
 
     def process_imu(self, dt, acc, gyr, stamp):
         _chk(self.lib.dll.lio_est_process_imu(self.h, dt, _dp(_f64(acc)), _dp(_f64(gyr)), stamp), "lio_est_process_imu")
+
+    def process_imu_batch(self, dt, acc, gyr, stamp):
+        """All IMU samples of one laser interval in one call (the loop of Estimator::ProcessEstimation)."""
+        dt, stamp = _f64(dt).reshape(-1), _f64(stamp).reshape(-1)
+        acc, gyr = _f64(acc).reshape(-1, 3), _f64(gyr).reshape(-1, 3)
+        assert acc.shape[0] == gyr.shape[0] == dt.shape[0] == stamp.shape[0]
+        _chk(self.lib.dll.lio_est_process_imu_batch(self.h, dt.shape[0], _dp(dt), _dp(acc), _dp(gyr), _dp(stamp)), "lio_est_process_imu_batch")
 
     def process_laser_odom(self, T: TransformF, surf, corner, stamp):
         surf = _f32(surf).reshape(-1, 4)

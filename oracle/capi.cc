@@ -461,6 +461,11 @@ int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double
   h->est.ProcessImu(dt, v3(acc), v3(gyr), stamp);
   return LIO_OK;
 }
+int lio_est_process_imu_batch(lio_est *h, size_t n, const double *dt, const double *acc, const double *gyr, const double *stamp) {
+  if (!h || (n && (!dt || !acc || !gyr || !stamp))) return LIO_ERR_ARG;
+  for (size_t k = 0; k < n; ++k) h->est.ProcessImu(dt[k], v3(acc + 3 * k), v3(gyr + 3 * k), stamp[k]);
+  return LIO_OK;
+}
 static void fillReport(const SolveReport &R, lio_solve_report *o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));

@@ -5,6 +5,9 @@ import os
 import re
 
 import numpy as np
+import torch  # noqa: F401  -- before the product library is loaded: when both HIP users live in one process (only in this
+#                              file: it asks torch whether a GPU exists), the runtime libraries must be loaded torch-first;
+#                              the other order leaves the second one without a visible device (observed on the MI355X box)
 
 from lio_amd import capi, synth
 
@@ -168,3 +171,32 @@ def test_error_codes_of_the_init_and_mapping_entry_points(hip, oracle):
         rc = lib.dll.lio_est_process_compact(est.h, junk.ctypes.data_as(capi.c_float_p), 5, 1.0, None, None)
         assert rc == -1
         assert est.stage()["cir_buf_count"] == 0 and est.stage()["event"] == "skipped"
+
+
+def test_process_imu_batch_equals_the_loop(oracle, hip):
+    """lio_est_process_imu_batch = n calls of lio_est_process_imu (host-only in both libraries; the product's handle needs
+    a device to exist, so without one only the oracle is exercised)."""
+    import torch
+
+    from lio_amd import pipeline
+
+    libs = [oracle] + ([hip] if torch.cuda.is_available() else [])
+    ds = synth.make_dataset("indoor", 7, 0.2, lidar=synth.Lidar(16, -15, 15, 450))
+    for lib in libs:
+        clouds = [pipeline.feature_clouds(lib, ds.lidar, f.scan)[0] for f in ds.frames]
+        states = []
+        for batch in (False, True):
+            cfg = pipeline.config_indoor(lib, 4, 2)
+            cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+            pipeline.set_extrinsic(cfg, ds)
+            est = capi.Estimator(lib, cfg)
+            pipeline.init_window(est, lib, ds, clouds, pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+            f = ds.frames[5]
+            if batch:
+                est.process_imu_batch(f.imu_dt, f.imu_acc, f.imu_gyr, f.imu_t)
+            else:
+                for j in range(f.imu_dt.shape[0]):
+                    est.process_imu(float(f.imu_dt[j]), f.imu_acc[j], f.imu_gyr[j], float(f.imu_t[j]))
+            states.append(est.get_window())
+        for key in ("Ps", "Rs", "Vs"):
+            np.testing.assert_array_equal(states[0][key], states[1][key])

@@ -67,3 +67,17 @@ def test_rank_deficient_and_indefinite_inputs(checker):
     np.testing.assert_allclose(V1 @ np.diag(w1) @ V1.T, semi, atol=1e-10 * abs(semi).max())
     assert f2[0] == 0 and f2[1] == 0                                            # not positive definite: the dogleg raises mu
     np.testing.assert_allclose(w2, [-2.0, 1.0, 3.0], atol=1e-12)
+
+
+def test_lidar_linear_maps_reproduce_the_factor(tmp_path):
+    """the moments kernel contracts z z^T; the host maps it to the 18x18 block with L.  L is read off four
+    probe points of the factor's own Jacobian expressions — it must agree with the factor everywhere."""
+    import shutil
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "linear_maps_check")
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-ffp-contract=off", "-mavx2", "--offload-arch=gfx950", "-I",
+                    os.path.join(ROOT, "lio-mapping_amd", "csrc"), os.path.join(ROOT, "tests", "host", "linear_maps_check.hip"), "-o", exe],
+                   check=True)
+    jac_err, res_err = (float(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+    assert jac_err < 1e-11 and res_err < 1e-11

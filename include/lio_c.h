@@ -405,7 +405,9 @@ int lio_est_restore(lio_est *);
  * MarginalizationFactor.cc:245-269, extended across ranks): rank r of `world` evaluates only its contiguous share of
  * every frame's lidar factors; `allreduce` (in-place SUM over ranks of `count` doubles, returns 0) is called once per
  * linearisation on the per-shard normal-equation moments; every rank then takes the same trust-region step, so the
- * replicas stay in lockstep without a broadcast.  world = 1 or a null callback switches sharding off. */
+ * replicas stay in lockstep without a broadcast.  world = 1 or a null callback switches sharding off.
+ * While sharding is on, max_solver_time is ignored (a per-rank wall clock must not decide how many collectives a rank
+ * issues): the solve stops on max_num_iterations and the function / parameter / gradient tolerances only. */
 typedef int (*lio_allreduce_fn)(double *inout, int count, void *user);
 int lio_est_set_factor_sharding(lio_est *, int rank, int world, lio_allreduce_fn allreduce, void *user);
 

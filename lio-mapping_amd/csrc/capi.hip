@@ -57,6 +57,12 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   lio_pp_config cfg;
   if (c) cfg = *c; else lio_pp_default_config(&cfg);
   if (cfg.num_scan_subregions < 1 || cfg.num_scan_subregions > 16 || cfg.num_curvature_regions < 1 || cfg.num_curvature_regions > 8) return nullptr;
+  // pick caps size LDS tables and device reserves; the leaf is inverted: keep them in sane ranges
+  const int caps[3] = {cfg.max_corner_sharp, cfg.max_corner_less_sharp, cfg.max_surf_flat};
+  for (int v : caps)
+    if (v < 0 || v > 4096) return nullptr;
+  if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return nullptr;
+  if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return nullptr;
   lio_pp *h = new (std::nothrow) lio_pp;
   if (!h) return nullptr;
   int rc = guarded([&] { h->pp.reset(new PointProcessorDev(lo, up, rings, cfg)); return LIO_OK; });
@@ -304,8 +310,13 @@ size_t lio_compact_encode(const lio_transform_f *T, const float *corner, size_t 
 }
 int lio_compact_decode(const float *d, size_t n, lio_transform_f *T, size_t *nc, size_t *ns, size_t *nf) {
   if (!d || !nc || !ns || !nf || n < 4) return LIO_ERR_ARG;
-  const long long c = (long long)d[8], s = (long long)d[9], f = (long long)d[10];
-  if (c < 0 || s < 0 || f < 0 || size_t(3 + c + s + f) != n) return LIO_ERR_ARG;
+  // the three sizes are untrusted wire floats: reject NaN / Inf / negative / larger-than-the-message values BEFORE any
+  // float -> integer cast (undefined behaviour otherwise) and before they are summed
+  const float lim = float(n);
+  for (int k = 8; k <= 10; ++k)
+    if (!(d[k] >= 0.0f && d[k] <= lim)) return LIO_ERR_ARG;
+  const unsigned long long c = (unsigned long long)d[8], s = (unsigned long long)d[9], f = (unsigned long long)d[10];
+  if (3ull + c + s + f != (unsigned long long)n) return LIO_ERR_ARG;
   if (T) { for (int k = 0; k < 3; ++k) T->p[k] = d[k]; for (int k = 0; k < 4; ++k) T->q[k] = d[4 + k]; }
   *nc = size_t(c); *ns = size_t(s); *nf = size_t(f);
   return LIO_OK;

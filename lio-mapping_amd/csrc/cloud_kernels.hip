@@ -234,7 +234,9 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
   int count = *h_count_;
   const VoxParams hp = *h_params_;
   if (hp.overflow) {  // PCL: "Leaf size is too small for the input dataset" -> output = input
+    p_out_->reserve(p_n_);  // the caller may have swapped the buffer since launch()
     LIO_HIP(hipMemcpyAsync(p_out_->p, p_in_, p_n_ * sizeof(float4), hipMemcpyDeviceToDevice, p_stream_));
+    LIO_HIP(hipStreamSynchronize(p_stream_));  // cold path: consumers on OTHER streams read the output right after finish()
     count = int(p_n_);
   }
   if (host_params) *host_params = hp;

@@ -38,6 +38,13 @@ struct DeviceCloud {
   DBuf<float4> buf;
   size_t n = 0;
   uint64_t id = 0;  // content id: equal ids in the same slot => identical content (restore() skips the copy)
+  DeviceCloud() = default;
+  // a moved-from cloud is EMPTY (n = 0, id = 0), not a null buffer with a stale count
+  DeviceCloud(DeviceCloud &&o) noexcept : buf(std::move(o.buf)), n(o.n), id(o.id) { o.n = 0; o.id = 0; }
+  DeviceCloud &operator=(DeviceCloud &&o) noexcept {
+    if (this != &o) { buf = std::move(o.buf); n = o.n; id = o.id; o.n = 0; o.id = 0; }
+    return *this;
+  }
 };
 
 struct StampedPose { double time; Rigidf T; };
@@ -191,7 +198,15 @@ class Estimator {
   MargWorker marg_worker_;
   bool async_marg_ = true;                  // LIO_ASYNC_MARG=0 computes it inside SolveOptimization
   unsigned marg_epoch_ = 0, marg_task_epoch_ = 0;   // Restore() bumps the epoch: a result computed for a discarded state is dropped
-  void JoinMarg() { std::shared_ptr<MargPrior> r; if (marg_worker_.join(r) && marg_task_epoch_ == marg_epoch_) last_marg_ = std::move(r); }
+  void JoinMarg() {
+    std::shared_ptr<MargPrior> r;
+    const bool discard = marg_task_epoch_ != marg_epoch_;
+    try {
+      if (marg_worker_.join(r) && !discard) last_marg_ = std::move(r);
+    } catch (...) {
+      if (!discard) throw;  // a failure of a task whose result is dropped anyway (state restored meanwhile) is not the caller's problem
+    }
+  }
   std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
   std::shared_ptr<Preintegration> tmp_pre_integration_;
   int laser_odom_iters_ = 0;

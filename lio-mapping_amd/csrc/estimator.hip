@@ -311,6 +311,8 @@ bool Estimator::RunInitialization() {
 
 bool Estimator::PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float * /*corner*/, size_t /*n_corner*/,
                           double stamp, bool surf_on_device) {
+  // every precondition is checked BEFORE the window is touched: a refused frame leaves the estimator as it was
+  if (inited_ && (cfg_.enable_deskew || cfg_.cutoff_deskew) && !cfg_.cutoff_deskew && imu_stamped_.empty()) return false;
   LaserFrame lf;
   lf.time = stamp; lf.transform = transform_in; lf.pim = tmp_pre_integration_;
   push_at(pre_integrations_, n_frames_, tmp_pre_integration_);
@@ -336,7 +338,6 @@ bool Estimator::PushFrame(const Rigidf &transform_in, const float *surf, size_t 
   upload_.n = n_surf;
   if (cfg_.enable_deskew || cfg_.cutoff_deskew) {
     if (!cfg_.cutoff_deskew) {
-      if (imu_stamped_.empty()) return false;
       double time_e = imu_stamped_.back().time;
       Rigidf T_e = imu_stamped_.back().T;
       double time_s = time_e;
@@ -729,7 +730,11 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     }
   }
   const double t_opt0 = now_ms();
-  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, cfg_.max_solver_time, &first);
+  // Factor sharding: every linearisation is a collective, so every rank must take the same number of them.  A per-rank
+  // wall-clock cap (Estimator.cc:1921) could stop one rank an iteration earlier than its peers and leave an unmatched
+  // all-reduce behind; the sharded mode therefore terminates on the iteration / tolerance rules only.
+  const double time_cap = (shard_world_ > 1 && allreduce_) ? -1.0 : cfg_.max_solver_time;
+  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, time_cap, &first);
   R.ms_opt = now_ms() - t_opt0;
   if (getenv("LIO_DEBUG_TIMING"))
     std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms | evaluate x%d: launch %.3f prior %.3f imu %.3f wait %.3f assemble %.3f\n",
@@ -831,8 +836,8 @@ void Estimator::Snapshot() {
 }
 
 bool Estimator::Restore() {
-  ++marg_epoch_;  // a marginalization still in flight belongs to the state being discarded: its result is dropped at the next join
   if (!snap_) return false;
+  ++marg_epoch_;  // a marginalization still in flight belongs to the state being discarded: its result is dropped at the next join
   const HostState &h = *snap_;
   Ps_ = h.Ps; Vs_ = h.Vs; Bas_ = h.Bas; Bgs_ = h.Bgs; Rs_ = h.Rs; g_vec_ = h.g_vec; acc_last_ = h.acc_last; gyr_last_ = h.gyr_last;
   transform_lb_ = h.transform_lb; inited_ = h.inited; first_imu_ = h.first_imu; init_local_map_ = h.init_local_map;

@@ -47,11 +47,6 @@ def feature_clouds(lib: LioLib, lidar: synth.Lidar, scan: np.ndarray):
     return pp.cloud(PointProcessor.LESS_FLAT), pp.cloud(PointProcessor.LESS_SHARP)
 
 
-def strip_time(cloud: np.ndarray) -> np.ndarray:
-    """cutoff_deskew runs keep ring+rel_time in intensity; the stacks only need xyz, keep as is."""
-    return cloud
-
-
 def init_window(est: Estimator, lib: LioLib, ds: synth.Dataset, surf_clouds, pos_sigma=0.03, rot_sigma=0.005, vel_sigma=0.02, seed=3):
     """Inject frames 0..W as an already-initialised window (test hook): ground-truth
     states plus a small perturbation so the solver has work to do; stacks = VoxelGrid(surf, 0.4)."""

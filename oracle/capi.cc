@@ -311,8 +311,10 @@ size_t lio_compact_encode(const lio_transform_f *T, const float *corner, size_t 
 int lio_compact_decode(const float *d, size_t n, lio_transform_f *T, size_t *nc, size_t *ns, size_t *nf) {
   if (!d || !nc || !ns || !nf) return LIO_ERR_ARG;
   if (n < 4) return LIO_ERR_ARG;  // PointMapping.cc:180-183
+  for (int k = 8; k <= 10; ++k)
+    if (!(d[k] >= 0.0f && d[k] <= float(n))) return LIO_ERR_ARG;  // wire floats: NaN / Inf / out-of-range sizes are refused
   int c = int(d[8]), s = int(d[9]), f = int(d[10]);
-  if (c < 0 || s < 0 || f < 0 || size_t(3) + size_t(c) + size_t(s) + size_t(f) != n) return LIO_ERR_ARG;  // :191-195
+  if (size_t(3) + size_t(c) + size_t(s) + size_t(f) != n) return LIO_ERR_ARG;  // :191-195
   if (T) { T->p[0] = d[0]; T->p[1] = d[1]; T->p[2] = d[2]; T->q[0] = d[4]; T->q[1] = d[5]; T->q[2] = d[6]; T->q[3] = d[7]; }
   *nc = size_t(c); *ns = size_t(s); *nf = size_t(f);
   return LIO_OK;

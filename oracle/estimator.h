@@ -575,7 +575,8 @@ struct Estimator {
       }
     }
     double t_opt0 = now_ms();
-    SolveSummary s = SolveDogleg(P, cfg.max_num_iterations, cfg.max_solver_time);
+    // sharded mode: the number of collectives per solve must not depend on a per-rank clock (include/lio_c.h)
+    SolveSummary s = SolveDogleg(P, cfg.max_num_iterations, (shard_world > 1 && allreduce) ? -1.0 : cfg.max_solver_time);
     R.ms_opt = now_ms() - t_opt0;
     R.iterations = s.iterations; R.successful = s.successful; R.termination = s.termination;
     R.initial_cost = s.initial_cost; R.final_cost = s.final_cost; R.trace = s.cost_trace;

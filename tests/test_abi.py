@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import torch  # noqa: F401  -- before the product library is loaded: when both HIP users live in one process (only in this
 #                              file: it asks torch whether a GPU exists), the runtime libraries must be loaded torch-first;
 #                              the other order leaves the second one without a visible device (observed on the MI355X box)
@@ -39,6 +40,33 @@ def test_oracle_library_exports_every_symbol(oracle):
     for s in _declared_symbols():
         assert hasattr(oracle.dll, s), s
     assert oracle.backend == "oracle-cpu"
+
+
+def _c_translation_unit(tmp_path, lib_path, backend):
+    """include/lio_c.h compiled by a C compiler (not C++, not ctypes) and linked with the library."""
+    import subprocess
+
+    inc = tmp_path / "lio_symbols.inc"
+    inc.write_text("".join(f"LIO_SYM({s})\n" for s in _declared_symbols()))
+    exe = tmp_path / "c_abi_check"
+    libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
+    assert libname.startswith("lib") and libname.endswith(".so")
+    cmd = ["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", str(tmp_path),
+           os.path.join(ROOT, "tests", "host", "c_abi_check.c"), "-o", str(exe), "-L", libdir, "-l" + libname[3:-3],
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([str(exe), backend], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert backend in r.stdout
+
+
+def test_header_is_plain_c_and_links_against_the_product(tmp_path):
+    assert os.path.exists(capi.HIP_LIB_PATH)
+    _c_translation_unit(tmp_path, capi.HIP_LIB_PATH, "hip-gfx950")
+
+
+def test_header_is_plain_c_and_links_against_the_oracle(tmp_path, oracle):
+    _c_translation_unit(tmp_path, os.path.join(ROOT, "oracle", "liblio_oracle.so"), "oracle-cpu")
 
 
 def test_product_has_no_cpu_fallback(hip):
@@ -131,6 +159,12 @@ def test_compact_data_codec_round_trip(hip, oracle):
             assert False
         except capi.LioError:
             pass
+        # the sizes are wire floats: non-finite, negative, or absurdly large values are refused before any integer cast
+        for col, val in ((0, np.nan), (1, np.inf), (2, -1.0), (0, 3.0e38), (1, 1.0e19)):
+            bad = a.copy()
+            bad[2, col] = val
+            with pytest.raises(capi.LioError):
+                lib.compact_decode(bad)
 
 
 def test_error_codes_of_the_init_and_mapping_entry_points(hip, oracle):

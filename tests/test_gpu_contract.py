@@ -1,0 +1,139 @@
+"""GPU parity on the contract configurations SURVEY.md §8(d) names beyond the headline window (BASELINE.json `configs`):
+
+  configs[2]  VLP-16 + 200 Hz IMU, window_size 15 / opt_window_size 5 (the compiled default, Estimator.h:78-79);
+  indoor_test_config.yaml:12-13,68  window 12 / opt window 7 with keep_features = 1 through solve + slide + marginalization;
+  configs[3] stress  HDL-64E with opt_window_size = window_size = 15 (tangent dimension D = 246);
+  per-iteration cost trace within 1e-6 relative (Estimator.cc:1990-2021);
+  a teacher-forced chain of 20 consecutive ProcessLaserOdom calls at 1e-4 m / 1e-4 rad.
+
+The product runs through the C-ABI of liblio_hip.so; the oracle is the checker."""
+import numpy as np
+import pytest
+
+from lio_amd import pipeline
+from window_util import assert_cost_trace_close, assert_windows_close, force_window, make_pair, window_gap
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_decisions(ra, rb):
+    assert ra.iterations == rb.iterations and ra.termination == rb.termination and ra.successful_steps == rb.successful_steps
+    assert ra.convergence_flag == rb.convergence_flag and ra.turn_off == rb.turn_off and ra.marginalized == rb.marginalized
+
+
+def test_vlp16_window15_matches_oracle(hip, oracle):
+    """BASELINE.json configs[2]: full sliding-window estimator at VLP-16 size, window 15 / opt window 5."""
+    W, Wo = 15, 5
+    ds, clouds, (ea, eb) = make_pair((hip, oracle), "indoor", W, Wo, W + 5, 0.2)
+    ra, rb = ea.solve(), eb.solve()
+    assert rb.n_lidar_residuals > 20000
+    _same_decisions(ra, rb)
+    gap, flips = assert_cost_trace_close(ra, rb)
+    print(f"vlp16 15/5 first solve: trace rel gap {gap:.2e} ({flips} newest-frame factor flips), window gap {window_gap(ea.get_window(), eb.get_window())}")
+    assert_windows_close(ea.get_window(), eb.get_window())
+    for est in (ea, eb):
+        est.slide()
+    for k in range(W + 1, W + 5):
+        ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
+        rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
+        _same_decisions(ra, rb)
+        assert_cost_trace_close(ra, rb)
+        assert_windows_close(ea.get_window(), eb.get_window())
+    pa, pb = ea.prior(), eb.prior()
+    assert pa["n"] == pb["n"] == 6 * Wo + 15
+    rel = np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / np.abs(pb["JtJ"]).max()
+    print(f"vlp16 15/5 prior: |dJtJ|/max {rel:.2e}, |dx0| {np.max(np.abs(pa['x0'] - pb['x0'])):.2e}")
+    assert rel < 1e-6
+    np.testing.assert_allclose(pa["x0"], pb["x0"], atol=1e-4)
+
+
+@pytest.mark.parametrize("prior_factor", [1, 0])
+def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
+    """config/indoor_test_config.yaml: window 12 / opt window 7, keep_features 1 (the newest frame's factor list
+    accumulates over its <= 10 Gauss-Newton rounds, Estimator.cc:978-980), IMU deskew on.  prior_factor 0 is the shipped
+    value; 1 adds the extrinsic prior the other parity tests use.  States are teacher-forced after every step so that a
+    one-off borderline feature of the newest frame cannot compound."""
+    W, Wo = 12, 7
+    ds, clouds, (ea, eb) = make_pair((hip, oracle), "indoor", W, Wo, W + 7, 0.2, keep=1, deskew=True, prior_factor=prior_factor)
+    ra, rb = ea.solve(), eb.solve()
+    _same_decisions(ra, rb)
+    assert rb.laser_odom_iterations >= 2 and ra.laser_odom_iterations == rb.laser_odom_iterations
+    # keep_features: the newest frame contributes one factor list per round
+    assert rb.n_lidar_residuals > 1.2 * sum(eb.features(f)[0].shape[0] for f in range(W - Wo + 1, W)) / (Wo - 1) * Wo
+    assert_cost_trace_close(ra, rb)
+    assert_windows_close(ea.get_window(), eb.get_window())
+    for est in (ea, eb):
+        est.slide()
+    force_window(ea, eb.get_window(), ds)
+    worst = 0.0
+    for k in range(W + 1, W + 7):
+        ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
+        rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
+        _same_decisions(ra, rb)
+        assert ra.laser_odom_iterations == rb.laser_odom_iterations
+        assert_cost_trace_close(ra, rb)
+        wa, wb = ea.get_window(), eb.get_window()
+        worst = max(worst, window_gap(wa, wb)[0])
+        assert_windows_close(wa, wb)
+        force_window(ea, wb, ds)
+    print(f"indoor 12/7 keep_features prior_factor={prior_factor}: worst |dP| over 6 teacher-forced steps {worst:.2e} m")
+    pa, pb = ea.prior(), eb.prior()
+    assert pa["n"] == pb["n"] == 6 * Wo + 15
+
+
+def test_hdl64_opt_window_15_stress(hip, oracle):
+    """The Wo = 15 stress of configs[3]: every frame of the window is optimised (pivot = 0), tangent dimension
+    D = 15 (Wo + 1) + 6 = 246, marginalization keeps n = 6 Wo + 15 = 105 columns."""
+    W, Wo = 15, 15
+    ds, clouds, (ea, eb) = make_pair((hip, oracle), "outdoor", W, Wo, W + 3, 0.3, pp_lib=hip)
+    ra, rb = ea.solve(), eb.solve()
+    assert rb.n_lidar_residuals > 100000
+    _same_decisions(ra, rb)
+    assert_cost_trace_close(ra, rb)
+    assert_windows_close(ea.get_window(), eb.get_window())
+    for est in (ea, eb):
+        est.slide()
+    for k in range(W + 1, W + 3):
+        ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
+        rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
+        _same_decisions(ra, rb)
+        assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)
+    pa, pb = ea.prior(), eb.prior()
+    assert pa["n"] == pb["n"] == 105
+
+
+@pytest.mark.parametrize("kind,frame_dt", [("indoor", 0.2), ("outdoor", 0.3)])
+def test_teacher_forced_chain_of_20_solves(hip, oracle, kind, frame_dt):
+    """20 consecutive ProcessLaserOdom calls (push + solve + marginalization + slide) at window 15 / opt window 5 on VLP-16
+    and HDL-64E sweeps.  After every step the oracle's window states are copied into the product (lio_est_set_window), so
+    each step is compared on the same inputs: 1e-4 m / 1e-4 rad on every step, equal solver decisions, and the clouds the
+    two windows carry stay equal to fp32 rounding."""
+    W, Wo, n_chain = 15, 5, 20
+    ds, clouds, (ea, eb) = make_pair((hip, oracle), kind, W, Wo, W + 1 + n_chain, frame_dt, pp_lib=hip)
+    ra, rb = ea.solve(), eb.solve()
+    _same_decisions(ra, rb)
+    assert_windows_close(ea.get_window(), eb.get_window())
+    for est in (ea, eb):
+        est.slide()
+    force_window(ea, eb.get_window(), ds)
+    worst_p = worst_r = 0.0
+    odom_iter_mismatch = 0
+    for k in range(W + 1, W + 1 + n_chain):
+        ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
+        rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
+        _same_decisions(ra, rb)
+        odom_iter_mismatch += int(ra.laser_odom_iterations != rb.laser_odom_iterations)
+        wa, wb = ea.get_window(), eb.get_window()
+        g = window_gap(wa, wb)
+        worst_p, worst_r = max(worst_p, g[0]), max(worst_r, g[1])
+        assert_windows_close(wa, wb)
+        np.testing.assert_allclose(wa["t_lb"], wb["t_lb"], atol=1e-4)   # the optimised extrinsic travels with the window
+        force_window(ea, wb, ds)
+    print(f"teacher-forced chain ({kind}): worst |dP| {worst_p:.2e} m, worst rotation gap {worst_r:.2e} rad over {n_chain} steps; "
+          f"{odom_iter_mismatch} steps with a different newest-frame round count")
+    assert odom_iter_mismatch <= 2
+    # the clouds never left HBM on the product side: after 20 slides they still match the oracle's
+    for f in (W - Wo, W - 1, W):
+        sa, sb = ea.get_surf_stack(f), eb.get_surf_stack(f)
+        assert sa.shape == sb.shape
+        np.testing.assert_allclose(sa[:, :3], sb[:, :3], atol=5e-4)

@@ -254,8 +254,15 @@ def test_sequence_with_marginalization(hip, oracle):
     pa, pb = ea.prior(), eb.prior()
     assert pa is not None and pb is not None and pa["n"] == pb["n"]
     # marginalization parity on the order-equivariant invariants
+    # The two chains are NOT teacher-forced here: the linearisation points differ by the windows' ~1e-9 m gap and by the odd
+    # borderline newest-frame feature, which is what bounds |dJtJ| (measured value printed; the 1e-8 eigenvalue cut of
+    # MarginalizationFactor.cc:275-302 is not crossed differently: pa and pb have the same rank, checked below).
     scale = np.abs(pb["JtJ"]).max()
-    assert np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / scale < 1e-3
+    rel = np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / scale
+    print(f"prior after 5 chained steps: |dJtJ|/max {rel:.2e}, |dx0| {np.max(np.abs(pa['x0'] - pb['x0'])):.2e}")
+    assert rel < 1e-5
+    ea_, eb_ = np.linalg.eigvalsh(pa["JtJ"]), np.linalg.eigvalsh(pb["JtJ"])
+    assert (ea_ > 1e-8 * ea_.max()).sum() == (eb_ > 1e-8 * eb_.max()).sum()
     np.testing.assert_allclose(pa["x0"], pb["x0"], atol=2e-4)
 
 

@@ -1,0 +1,62 @@
+"""Helpers shared by the GPU parity tests that drive the product and the oracle through the same window."""
+import numpy as np
+
+from lio_amd import capi, pipeline, synth
+
+
+def make_pair(libs, kind, W, Wo, n_frames, frame_dt, keep=0, deskew=False, prior_factor=1, seed=3, sigmas=(0.01, 0.001, 0.01), pp_lib=None):
+    """One estimator per library in `libs`, all initialised with the same window (frames 0..W of a seeded synthetic
+    run, ground truth + the same perturbation) and the same stacks.  Feature clouds come from `pp_lib` (default: the
+    last library, i.e. the oracle in (hip, oracle))."""
+    ds = synth.make_dataset(kind, n_frames, frame_dt)
+    pp_lib = pp_lib or libs[-1]
+    clouds = [pipeline.feature_clouds(pp_lib, ds.lidar, f.scan) for f in ds.frames]
+    ests = []
+    for lib in libs:
+        cfg = pipeline.config_indoor(lib, W, Wo) if kind == "indoor" else pipeline.config_outdoor64(lib, W, Wo)
+        cfg.keep_features = keep
+        cfg.prior_factor = prior_factor
+        cfg.cutoff_deskew = 0 if deskew else 1
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(lib, cfg)
+        pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=sigmas[0], rot_sigma=sigmas[1], vel_sigma=sigmas[2], seed=seed)
+        ests.append(est)
+    return ds, clouds, ests
+
+
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1)))
+
+
+def window_gap(wa, wb):
+    """(max |dP| m, max rotation angle rad, max |dV|, max |dBa|, max |dBg|) between two get_window() results."""
+    return (float(np.max(np.abs(wa["Ps"] - wb["Ps"]))), max(rot_angle(a, b) for a, b in zip(wa["Rs"], wb["Rs"])),
+            float(np.max(np.abs(wa["Vs"] - wb["Vs"]))), float(np.max(np.abs(wa["Bas"] - wb["Bas"]))), float(np.max(np.abs(wa["Bgs"] - wb["Bgs"]))))
+
+
+def assert_windows_close(wa, wb, tol_p=1e-4, tol_r=1e-4):
+    dp, dr, dv, dba, dbg = window_gap(wa, wb)
+    assert dp < tol_p, dp            # 1e-4 m (north_star)
+    assert dr < tol_r, dr            # 1e-4 rad
+    assert dv < 1e-3 and dba < 1e-3 and dbg < 1e-4, (dv, dba, dbg)
+
+
+def assert_cost_trace_close(ra, rb):
+    """Per-iteration cost trace (Estimator.cc:1990-2021 summary) within 1e-6 relative.  The two
+    newest-frame Gauss-Newton loops sum their fp32 rows in different orders, so a borderline feature of the NEWEST frame
+    may be accepted by one side only; each such factor moves the total by about one residual's share, which the bound
+    admits explicitly (it is exactly 1e-6 whenever the factor sets are equal)."""
+    assert ra.iterations == rb.iterations
+    n = min(rb.iterations + 1, 32)
+    ta, tb = np.asarray(ra.cost_trace[:n]), np.asarray(rb.cost_trace[:n])
+    flips = abs(ra.n_lidar_residuals - rb.n_lidar_residuals)
+    tol = 1e-6 + 20.0 * flips / max(rb.n_lidar_residuals, 1)
+    np.testing.assert_allclose(ta, tb, rtol=tol, atol=0)
+    assert np.all(np.diff(tb) <= 0)  # the trace holds the cost of the ACCEPTED point: it never increases
+    return float(np.max(np.abs(ta - tb) / np.abs(tb))), flips
+
+
+def force_window(dst, src_window, ds):
+    """Teacher forcing: the states of `src_window` become the states of estimator `dst` (lio_est_set_window)."""
+    dst.set_window(src_window["Ps"], src_window["Rs"], src_window["Vs"], src_window["Bas"], src_window["Bgs"], np.array([0, 0, -ds.g]))

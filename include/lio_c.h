@@ -397,6 +397,18 @@ int lio_est_get_laser_odom_transform(const lio_est *, lio_transform_f *out);
 int lio_est_get_prior(const lio_est *, double *JtJ_or_null, double *Jtr_or_null, double *x0_or_null,
                       int *x0_len_or_null);
 
+/* Test hooks (no reference counterpart, like lio_est_set_window): read / overwrite the NUMBERS of the current prior —
+ * linearized_jacobians (n*n, row-major), linearized_residuals (n), keep_block_data (x0, ambient layout) — and the extrinsic
+ * T_lb.  A chain of ProcessLaserOdom calls amplifies a 1e-8 difference of its inputs to 1e-3 m within a few steps through
+ * the prior (measured on the CPU oracle against itself, tests/golden/README.md), so a step-by-step parity chain has to
+ * hand BOTH implementations the same states, the same prior and the same extrinsic before every step.
+ * get: returns n (0 = no prior).  set: the estimator must already hold a prior of the same n and x0 length (the block
+ * structure is not transferable), else LIO_ERR_STATE. */
+int lio_est_get_prior_factor(const lio_est *, double *lin_jac_or_null, double *lin_res_or_null, double *x0_or_null,
+                             int *x0_len_or_null);
+int lio_est_set_prior_factor(lio_est *, int n, const double *lin_jac, const double *lin_res, const double *x0, int x0_len);
+int lio_est_set_extrinsic(lio_est *, const lio_transform_f *T_lb);
+
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);

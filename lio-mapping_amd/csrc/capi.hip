@@ -677,6 +677,43 @@ int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, in
   if (x0_len) *x0_len = len;
   return n;
 }
+int lio_est_get_prior_factor(const lio_est *h, double *lin_jac, double *lin_res, double *x0, int *x0_len) {
+  if (!h) return LIO_ERR_ARG;
+  const_cast<lio_est *>(h)->e->JoinMarg();
+  const auto &pr = h->e->last_marg_;
+  if (!pr) return 0;
+  const int n = pr->n;
+  if (lin_jac) std::memcpy(lin_jac, pr->lin_jac.a.data(), sizeof(double) * size_t(n) * n);
+  if (lin_res) std::memcpy(lin_res, pr->lin_res.data(), sizeof(double) * n);
+  int len = 0;
+  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+  if (x0_len) *x0_len = len;
+  return n;
+}
+int lio_est_set_prior_factor(lio_est *h, int n, const double *lin_jac, const double *lin_res, const double *x0, int x0_len) {
+  if (!h || !lin_jac || !lin_res || !x0 || n <= 0) return LIO_ERR_ARG;
+  return guarded([&] {
+    h->e->JoinMarg();
+    const auto &old = h->e->last_marg_;
+    if (!old || old->n != n) return LIO_ERR_STATE;
+    int len = 0;
+    for (const auto &b : old->x0) len += int(b.size());
+    if (len != x0_len) return LIO_ERR_STATE;
+    auto pr = std::make_shared<MargPrior>(*old);   // the old object may still be referenced by a snapshot
+    std::memcpy(pr->lin_jac.a.data(), lin_jac, sizeof(double) * size_t(n) * n);
+    std::memcpy(pr->lin_res.data(), lin_res, sizeof(double) * n);
+    len = 0;
+    for (auto &b : pr->x0) for (double &v : b) v = x0[len++];
+    pr->finalize();
+    h->e->last_marg_ = pr;
+    return LIO_OK;
+  });
+}
+int lio_est_set_extrinsic(lio_est *h, const lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  h->e->transform_lb_ = toT(*T);
+  return LIO_OK;
+}
 int lio_est_snapshot(lio_est *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->e->Snapshot(); return LIO_OK; });

@@ -25,13 +25,41 @@ struct PimNoise { double acc_n = 0.1, gyr_n = 0.01, acc_w = 0.0002, gyr_w = 2.0e
 
 enum { kOP = 0, kOR = 3, kOV = 6, kOBA = 9, kOBG = 12 };
 
-inline void put3(double *M, int ld, int r, int c, const M3d &B) {
+LIO_HD void put3(double *M, int ld, int r, int c, const M3d &B) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[(r + i) * ld + c + j] = B(i, j);
 }
-inline M3d get3(const double *M, int ld, int r, int c) {
+LIO_HD M3d get3(const double *M, int ld, int r, int c) {
   M3d B;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B(i, j) = M[(r + i) * ld + c + j];
   return B;
+}
+
+// The frozen quantities of a pre-integration that the factor reads, as a POD view (also what the device-resident solver
+// is handed: solve_step.h).  jac points at the 15x15 row-major bias Jacobian.
+struct PimCore {
+  double dp[3], dq[4] /* w, x, y, z */, dv[3], ba[3], bg[3], g[3], sum_dt;
+  const double *jac;
+};
+
+// IntegrationBase::Evaluate (IntegrationBase.h:309-357): unwhitened 15-d residual
+LIO_HD void pim_residual(const PimCore &c, const V3d &Pi, const Qd &Qi, const V3d &Vi, const V3d &Bai, const V3d &Bgi, const V3d &Pj,
+                         const Qd &Qj, const V3d &Vj, const V3d &Baj, const V3d &Bgj, double r[15]) {
+  const V3d dp(c.dp[0], c.dp[1], c.dp[2]), dv(c.dv[0], c.dv[1], c.dv[2]), ba(c.ba[0], c.ba[1], c.ba[2]), bg(c.bg[0], c.bg[1], c.bg[2]);
+  const V3d g_vec(c.g[0], c.g[1], c.g[2]);
+  const Qd dq(c.dq[0], c.dq[1], c.dq[2], c.dq[3]);
+  const double sum_dt = c.sum_dt;
+  M3d dp_dba = get3(c.jac, 15, kOP, kOBA), dp_dbg = get3(c.jac, 15, kOP, kOBG), dq_dbg = get3(c.jac, 15, kOR, kOBG);
+  M3d dv_dba = get3(c.jac, 15, kOV, kOBA), dv_dbg = get3(c.jac, 15, kOV, kOBG);
+  V3d dba = Bai - ba, dbg = Bgi - bg;
+  Qd cq = dq * deltaQ(dq_dbg * dbg);
+  V3d cv = dv + dv_dba * dba + dv_dbg * dbg;
+  V3d cp = dp + dp_dba * dba + dp_dbg * dbg;
+  Qd Qii = qinverse(Qi);
+  V3d rp = rotate(Qii, (-0.5) * g_vec * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt) - cp;
+  V3d rr = 2.0 * (qinverse(cq) * (Qii * Qj)).vec();
+  V3d rv = rotate(Qii, (-1.0) * g_vec * sum_dt + Vj - Vi) - cv;
+  V3d rba = Baj - Bai, rbg = Bgj - Bgi;
+  for (int k = 0; k < 3; ++k) { r[kOP + k] = rp[k]; r[kOR + k] = rr[k]; r[kOV + k] = rv[k]; r[kOBA + k] = rba[k]; r[kOBG + k] = rbg[k]; }
 }
 
 class Preintegration {
@@ -143,20 +171,16 @@ class Preintegration {
     sum_dt += dt;
     acc0 = a1; gyr0 = g1;
   }
+  PimCore core() const {
+    PimCore c;
+    for (int k = 0; k < 3; ++k) { c.dp[k] = dp[k]; c.dv[k] = dv[k]; c.ba[k] = ba[k]; c.bg[k] = bg[k]; c.g[k] = g_vec[k]; }
+    c.dq[0] = dq.w; c.dq[1] = dq.x; c.dq[2] = dq.y; c.dq[3] = dq.z;
+    c.sum_dt = sum_dt; c.jac = jac;
+    return c;
+  }
   void evaluate(const V3d &Pi, const Qd &Qi, const V3d &Vi, const V3d &Bai, const V3d &Bgi, const V3d &Pj, const Qd &Qj, const V3d &Vj,
                 const V3d &Baj, const V3d &Bgj, double r[15]) const {
-    M3d dp_dba = get3(jac, 15, kOP, kOBA), dp_dbg = get3(jac, 15, kOP, kOBG), dq_dbg = get3(jac, 15, kOR, kOBG);
-    M3d dv_dba = get3(jac, 15, kOV, kOBA), dv_dbg = get3(jac, 15, kOV, kOBG);
-    V3d dba = Bai - ba, dbg = Bgi - bg;
-    Qd cq = dq * deltaQ(dq_dbg * dbg);
-    V3d cv = dv + dv_dba * dba + dv_dbg * dbg;
-    V3d cp = dp + dp_dba * dba + dp_dbg * dbg;
-    Qd Qii = qinverse(Qi);
-    V3d rp = rotate(Qii, (-0.5) * g_vec * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt) - cp;
-    V3d rr = 2.0 * (qinverse(cq) * (Qii * Qj)).vec();
-    V3d rv = rotate(Qii, (-1.0) * g_vec * sum_dt + Vj - Vi) - cv;
-    V3d rba = Baj - Bai, rbg = Bgj - Bgi;
-    for (int k = 0; k < 3; ++k) { r[kOP + k] = rp[k]; r[kOR + k] = rr[k]; r[kOV + k] = rv[k]; r[kOBA + k] = rba[k]; r[kOBG + k] = rbg[k]; }
+    pim_residual(core(), Pi, Qi, Vi, Bai, Bgi, Pj, Qj, Vj, Baj, Bgj, r);
   }
   // upper-triangular whitening matrix L^T with L L^T = cov^-1; cached: cov is frozen once the frame is pushed
   const double *sqrt_info() const {
@@ -174,11 +198,11 @@ class Preintegration {
   mutable bool sqrt_info_valid_ = false, sqrt_info_ok_ = false;
 };
 
-inline void unpack_pose(const double *p, V3d &P, Qd &Q) { P = V3d(p[0], p[1], p[2]); Q = Qd(p[6], p[3], p[4], p[5]); }
+LIO_HD void unpack_pose(const double *p, V3d &P, Qd &Q) { P = V3d(p[0], p[1], p[2]); Q = Qd(p[6], p[3], p[4], p[5]); }
 
 // 4x4 quaternion matrices, top-left 3x3 of Left(a) * Right(b)
-inline M3d left_tl3(const Qd &q) { return M3d::identity() * q.w + skew(q.vec()); }
-inline M3d left_right_tl3(const Qd &a, const Qd &b) {
+LIO_HD M3d left_tl3(const Qd &q) { return M3d::identity() * q.w + skew(q.vec()); }
+LIO_HD M3d left_right_tl3(const Qd &a, const Qd &b) {
   double L[4][4], R[4][4];
   M3d la = left_tl3(a), rb = M3d::identity() * b.w - skew(b.vec());
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { L[i][j] = la(i, j); R[i][j] = rb(i, j); }
@@ -190,6 +214,49 @@ inline M3d left_right_tl3(const Qd &a, const Qd &b) {
   return out;
 }
 
+// Unwhitened Jacobian block `which` of ImuFactor::Evaluate (ImuFactor.h:88-160) in AMBIENT layout, row-major, zero-filled:
+// 0: d r / d pose_i (15x7), 1: d r / d speed-bias_i (15x9), 2: d r / d pose_j (15x7), 3: d r / d speed-bias_j (15x9).
+LIO_HD void imu_raw_jacobian(const PimCore &c, int which, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j,
+                             double *J) {
+  V3d Pi, Pj; Qd Qi, Qj;
+  unpack_pose(pose_i, Pi, Qi); unpack_pose(pose_j, Pj, Qj);
+  const V3d Vi(sb_i[0], sb_i[1], sb_i[2]), Bgi(sb_i[6], sb_i[7], sb_i[8]);
+  const V3d Vj(sb_j[0], sb_j[1], sb_j[2]);
+  const double sum_dt = c.sum_dt;
+  const V3d g(c.g[0], c.g[1], c.g[2]), pbg(c.bg[0], c.bg[1], c.bg[2]);
+  const Qd pdq(c.dq[0], c.dq[1], c.dq[2], c.dq[3]);
+  M3d dp_dba = get3(c.jac, 15, kOP, kOBA), dp_dbg = get3(c.jac, 15, kOP, kOBG), dq_dbg = get3(c.jac, 15, kOR, kOBG);
+  M3d dv_dba = get3(c.jac, 15, kOV, kOBA), dv_dbg = get3(c.jac, 15, kOV, kOBG);
+  Qd Qii = qinverse(Qi);
+  M3d RiT = toRot(Qii);
+  Qd cq = pdq * deltaQ(dq_dbg * (Bgi - pbg));
+  const int cols = (which & 1) ? 9 : 7;
+  for (int k = 0; k < 15 * cols; ++k) J[k] = 0.0;
+  if (which == 0) {
+    put3(J, 7, kOP, 0, -RiT);
+    put3(J, 7, kOP, 3, skew(rotate(Qii, (-0.5) * g * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt)));
+    put3(J, 7, kOR, 3, -left_right_tl3(qinverse(Qj) * Qi, cq));
+    put3(J, 7, kOV, 3, skew(rotate(Qii, (-1.0) * g * sum_dt + Vj - Vi)));
+  } else if (which == 1) {
+    put3(J, 9, kOP, 0, -RiT * sum_dt);
+    put3(J, 9, kOP, 3, -dp_dba);
+    put3(J, 9, kOP, 6, -dp_dbg);
+    put3(J, 9, kOR, 6, -left_tl3(qinverse(Qj) * Qi * cq) * dq_dbg);
+    put3(J, 9, kOV, 0, -RiT);
+    put3(J, 9, kOV, 3, -dv_dba);
+    put3(J, 9, kOV, 6, -dv_dbg);
+    put3(J, 9, kOBA, 3, -M3d::identity());
+    put3(J, 9, kOBG, 6, -M3d::identity());
+  } else if (which == 2) {
+    put3(J, 7, kOP, 0, RiT);
+    put3(J, 7, kOR, 3, left_tl3(qinverse(cq) * Qii * Qj));
+  } else {
+    put3(J, 9, kOV, 0, RiT);
+    put3(J, 9, kOBA, 3, M3d::identity());
+    put3(J, 9, kOBG, 6, M3d::identity());
+  }
+}
+
 // Whitened residual (15) and Jacobians in AMBIENT layout (15x7, 15x9, 15x7, 15x9; null = skip).
 inline bool imu_factor(const Preintegration &pim, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j,
                        double *res, double *J0, double *J1, double *J2, double *J3) {
@@ -198,18 +265,12 @@ inline bool imu_factor(const Preintegration &pim, const double *pose_i, const do
   V3d Vi(sb_i[0], sb_i[1], sb_i[2]), Bai(sb_i[3], sb_i[4], sb_i[5]), Bgi(sb_i[6], sb_i[7], sb_i[8]);
   V3d Vj(sb_j[0], sb_j[1], sb_j[2]), Baj(sb_j[3], sb_j[4], sb_j[5]), Bgj(sb_j[6], sb_j[7], sb_j[8]);
   double r[15];
-  pim.evaluate(Pi, Qi, Vi, Bai, Bgi, Pj, Qj, Vj, Baj, Bgj, r);
+  const PimCore core = pim.core();
+  pim_residual(core, Pi, Qi, Vi, Bai, Bgi, Pj, Qj, Vj, Baj, Bgj, r);
   const double *S = pim.sqrt_info();
   if (!S) return false;
   for (int i = 0; i < 15; ++i) { double s = 0; for (int k = i; k < 15; ++k) s += S[i * 15 + k] * r[k]; res[i] = s; }
   if (!J0 && !J1 && !J2 && !J3) return true;
-  const double sum_dt = pim.sum_dt;
-  M3d dp_dba = get3(pim.jac, 15, kOP, kOBA), dp_dbg = get3(pim.jac, 15, kOP, kOBG), dq_dbg = get3(pim.jac, 15, kOR, kOBG);
-  M3d dv_dba = get3(pim.jac, 15, kOV, kOBA), dv_dbg = get3(pim.jac, 15, kOV, kOBG);
-  const V3d g = pim.g_vec;
-  Qd Qii = qinverse(Qi);
-  M3d RiT = toRot(Qii);
-  Qd cq = pim.dq * deltaQ(dq_dbg * (Bgi - pim.bg));
   auto whiten = [&](const double *J, int cols, double *out) {
     // row-axpy form (same k-ascending summation order as the dot form, but the inner loop is contiguous
     // and vectorises under strict IEEE semantics)
@@ -223,39 +284,12 @@ inline bool imu_factor(const Preintegration &pim, const double *pose_i, const do
       }
     }
   };
-  if (J0) {
-    double J[105] = {0};
-    put3(J, 7, kOP, 0, -RiT);
-    put3(J, 7, kOP, 3, skew(rotate(Qii, (-0.5) * g * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt)));
-    put3(J, 7, kOR, 3, -left_right_tl3(qinverse(Qj) * Qi, cq));
-    put3(J, 7, kOV, 3, skew(rotate(Qii, (-1.0) * g * sum_dt + Vj - Vi)));
-    whiten(J, 7, J0);
-  }
-  if (J1) {
-    double J[135] = {0};
-    put3(J, 9, kOP, 0, -RiT * sum_dt);
-    put3(J, 9, kOP, 3, -dp_dba);
-    put3(J, 9, kOP, 6, -dp_dbg);
-    put3(J, 9, kOR, 6, -left_tl3(qinverse(Qj) * Qi * cq) * dq_dbg);
-    put3(J, 9, kOV, 0, -RiT);
-    put3(J, 9, kOV, 3, -dv_dba);
-    put3(J, 9, kOV, 6, -dv_dbg);
-    put3(J, 9, kOBA, 3, -M3d::identity());
-    put3(J, 9, kOBG, 6, -M3d::identity());
-    whiten(J, 9, J1);
-  }
-  if (J2) {
-    double J[105] = {0};
-    put3(J, 7, kOP, 0, RiT);
-    put3(J, 7, kOR, 3, left_tl3(qinverse(cq) * Qii * Qj));
-    whiten(J, 7, J2);
-  }
-  if (J3) {
-    double J[135] = {0};
-    put3(J, 9, kOV, 0, RiT);
-    put3(J, 9, kOBA, 3, M3d::identity());
-    put3(J, 9, kOBG, 6, M3d::identity());
-    whiten(J, 9, J3);
+  double *outs[4] = {J0, J1, J2, J3};
+  for (int which = 0; which < 4; ++which) {
+    if (!outs[which]) continue;
+    double J[135];
+    imu_raw_jacobian(core, which, pose_i, sb_i, pose_j, sb_j, J);
+    whiten(J, (which & 1) ? 9 : 7, outs[which]);
   }
   return true;
 }
@@ -268,7 +302,7 @@ struct PppPoses {
   Qd Qlpi;
   M3d Ri, RpT, rlb, rlbT;
 };
-inline PppPoses ppp_prepare(const double *pose_p, const double *pose_i, const double *pose_ex) {
+LIO_HD PppPoses ppp_prepare(const double *pose_p, const double *pose_i, const double *pose_ex) {
   PppPoses t;
   Qd Qp, Qi, qlb;
   unpack_pose(pose_p, t.Pp, Qp); unpack_pose(pose_i, t.Pi, Qi); unpack_pose(pose_ex, t.tlb, qlb);
@@ -283,7 +317,7 @@ inline PppPoses ppp_prepare(const double *pose_p, const double *pose_i, const do
   t.dP = t.Pi - t.Pp;
   return t;
 }
-inline void ppp_eval(const PppPoses &t, const V3d &point, const double coeff[4], double *res, double *Jp, double *Ji, double *Jex) {
+LIO_HD void ppp_eval(const PppPoses &t, const V3d &point, const double coeff[4], double *res, double *Jp, double *Ji, double *Jex) {
   V3d w(coeff[0], coeff[1], coeff[2]);
   *res = dot(w, rotate(t.Qlpi, point) + t.Plpi) + coeff[3];
   if (!Jp && !Ji && !Jex) return;
@@ -298,19 +332,19 @@ inline void ppp_eval(const PppPoses &t, const V3d &point, const double coeff[4],
     put(Jex, rowmul(w, M3d::identity() - (rlb * RpTRi) * rlbT), rowmul(w, rlb * (-skew(RpTRi * q) + RpTRi * skew(q) - skew(RpT * t.dP))));
   }
 }
-inline void ppp_factor(const V3d &point, const double coeff[4], const double *pose_p, const double *pose_i, const double *pose_ex,
+LIO_HD void ppp_factor(const V3d &point, const double coeff[4], const double *pose_p, const double *pose_i, const double *pose_ex,
                        double *res, double *Jp, double *Ji, double *Jex) {
   ppp_eval(ppp_prepare(pose_p, pose_i, pose_ex), point, coeff, res, Jp, Ji, Jex);
 }
 
-inline void prior_factor(const V3d &pos0, const Qd &rot0, const double *pose, double *res, double *J67) {
+LIO_HD void prior_factor(const V3d &pos0, const Qd &rot0, const double *pose, double *res, double *J67) {
   V3d P; Qd Q;
   unpack_pose(pose, P, Q);
   V3d dp = P - pos0;
   V3d dr = 2.0 * (qinverse(rot0) * Q).vec();
   for (int k = 0; k < 3; ++k) { res[k] = 1000.0 * dp[k]; res[3 + k] = 0.1 * dr[k]; }
   if (J67) {
-    std::memset(J67, 0, 42 * sizeof(double));
+    for (int k = 0; k < 42; ++k) J67[k] = 0.0;
     M3d B = left_tl3(qinverse(Q) * rot0);  // as written at PriorFactor.cc:56 (skew sign differs from the true derivative)
     for (int i = 0; i < 3; ++i) {
       J67[i * 7 + i] = 1000.0;
@@ -319,7 +353,7 @@ inline void prior_factor(const V3d &pos0, const Qd &rot0, const double *pose, do
   }
 }
 
-inline void pose_plus(const double *x, const double *d, double *out) {
+LIO_HD void pose_plus(const double *x, const double *d, double *out) {
   Qd q(x[6], x[3], x[4], x[5]);
   Qd qn = normalized(q * deltaQ(V3d(d[3], d[4], d[5])));
   out[0] = x[0] + d[0]; out[1] = x[1] + d[1]; out[2] = x[2] + d[2];

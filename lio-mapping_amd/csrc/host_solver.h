@@ -63,7 +63,7 @@ struct Layout {
 struct FrameMoments { double S[256]; double cost; double count; };
 
 // T_{pivot<-i} in fp64 from the parameter blocks (PivotPointPlaneFactor.cc:58-70)
-inline void relative_lidar_pose(const double *pose_p, const double *pose_i, const double *pose_ex, double R[9], double t[3]) {
+LIO_HD void relative_lidar_pose(const double *pose_p, const double *pose_i, const double *pose_ex, double R[9], double t[3]) {
   V3d Pp, Pi, tlb; Qd Qp, Qi, qlb;
   unpack_pose(pose_p, Pp, Qp); unpack_pose(pose_i, Pi, Qi); unpack_pose(pose_ex, tlb, qlb);
   Qd Qlp = Qp * conj(qlb);
@@ -83,41 +83,59 @@ inline void relative_lidar_pose(const double *pose_p, const double *pose_i, cons
 // The factor is linear in the plane normal w and affine in the point p, so L is read off the factor's own Jacobian
 // expressions (ppp_eval) at p in {0, e0, e1, e2}; a unit normal e_a just selects row a of the 3x3 matrices those
 // expressions multiply w with, so the four matrices per block are formed once per p instead of once per (p, a).
-inline void lidar_linear_maps(const double *pose_p, const double *pose_i, const double *pose_ex, double L[18 * 13], double l[13]) {
-  std::memset(L, 0, sizeof(double) * 18 * 13);
-  std::memset(l, 0, sizeof(double) * 13);
-  const PppPoses t = ppp_prepare(pose_p, pose_i, pose_ex);
-  const M3d A = t.rlb * t.RpT;                 // translation blocks: pivot -w^T A, frame i  w^T A
-  const M3d ARi = A * t.Ri;
-  const M3d RpTRi = t.RpT * t.Ri;
-  const M3d Bx = M3d::identity() - (t.rlb * RpTRi) * t.rlbT;
-  const M3d S1 = skew(t.RpT * t.dP), S2 = skew(t.rlbT * t.tlb);
-  double J[4][3][18], r[4][3];                 // [probe point][normal axis][column]
-  for (int b = 0; b < 4; ++b) {
-    const V3d p(b == 1, b == 2, b == 3);
-    const V3d q = t.rlbT * (p - t.tlb);
-    const M3d Mp = t.rlb * (skew(t.RpT * (t.Ri * q)) + S1);
-    const M3d Mi = ARi * (-skew(t.rlbT * p) + S2);
-    const M3d Mx = t.rlb * (-skew(RpTRi * q) + RpTRi * skew(q) - S1);
-    const V3d rv = rotate(t.Qlpi, p) + t.Plpi;
-    for (int a = 0; a < 3; ++a) {
-      for (int k = 0; k < 3; ++k) {
-        J[b][a][k] = -A(a, k); J[b][a][3 + k] = Mp(a, k);
-        J[b][a][6 + k] = A(a, k); J[b][a][9 + k] = Mi(a, k);
-        J[b][a][12 + k] = Bx(a, k); J[b][a][15 + k] = Mx(a, k);
-      }
-      r[b][a] = rv[a];
-    }
-  }
+// Split in three so that the device can evaluate the four probe points on four lanes (solve_step.h): the pose-only part,
+// one probe point, the combination.  lidar_linear_maps() below runs them in sequence (same arithmetic either way).
+struct LidarMapPrep { PppPoses t; M3d A, ARi, RpTRi, Bx, S1, S2; };
+LIO_HD LidarMapPrep lidar_map_prepare(const double *pose_p, const double *pose_i, const double *pose_ex) {
+  LidarMapPrep m;
+  m.t = ppp_prepare(pose_p, pose_i, pose_ex);
+  const PppPoses &t = m.t;
+  m.A = t.rlb * t.RpT;                 // translation blocks: pivot -w^T A, frame i  w^T A
+  m.ARi = m.A * t.Ri;
+  m.RpTRi = t.RpT * t.Ri;
+  m.Bx = M3d::identity() - (t.rlb * m.RpTRi) * t.rlbT;
+  m.S1 = skew(t.RpT * t.dP); m.S2 = skew(t.rlbT * t.tlb);
+  return m;
+}
+// probe point b in {0: origin, 1..3: unit axes}: J[normal axis][column] (3 x 18) and r[normal axis]
+LIO_HD void lidar_map_probe(const LidarMapPrep &m, int b, double *J /* 3 x 18 */, double *r /* 3 */) {
+  const PppPoses &t = m.t;
+  const V3d p(b == 1, b == 2, b == 3);
+  const V3d q = t.rlbT * (p - t.tlb);
+  const M3d Mp = t.rlb * (skew(t.RpT * (t.Ri * q)) + m.S1);
+  const M3d Mi = m.ARi * (-skew(t.rlbT * p) + m.S2);
+  const M3d Mx = t.rlb * (-skew(m.RpTRi * q) + m.RpTRi * skew(q) - m.S1);
+  const V3d rv = rotate(t.Qlpi, p) + t.Plpi;
   for (int a = 0; a < 3; ++a) {
-    for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + 3] = J[0][a][k];
-    l[4 * a + 3] = r[0][a];
-    for (int b = 0; b < 3; ++b) {
-      for (int k = 0; k < 18; ++k) L[k * 13 + 4 * a + b] = J[b + 1][a][k] - J[0][a][k];
-      l[4 * a + b] = r[b + 1][a] - r[0][a];
+    for (int k = 0; k < 3; ++k) {
+      J[a * 18 + k] = -m.A(a, k); J[a * 18 + 3 + k] = Mp(a, k);
+      J[a * 18 + 6 + k] = m.A(a, k); J[a * 18 + 9 + k] = Mi(a, k);
+      J[a * 18 + 12 + k] = m.Bx(a, k); J[a * 18 + 15 + k] = Mx(a, k);
     }
+    r[a] = rv[a];
   }
-  l[12] = 1.0;
+}
+// entry `e` of the packed output [L (18 x 13) | l (13)] from the four probes: J4 = [probe][axis][column], r4 = [probe][axis]
+LIO_HD double lidar_map_entry(const double *J4 /* 4 x 3 x 18 */, const double *r4 /* 4 x 3 */, int e) {
+  if (e < 18 * 13) {
+    const int k = e / 13, c = e % 13;
+    if (c == 12) return 0.0;
+    const int a = c >> 2, b = c & 3;
+    if (b == 3) return J4[(0 * 3 + a) * 18 + k];
+    return J4[((b + 1) * 3 + a) * 18 + k] - J4[(0 * 3 + a) * 18 + k];
+  }
+  const int c = e - 18 * 13;
+  if (c == 12) return 1.0;
+  const int a = c >> 2, b = c & 3;
+  if (b == 3) return r4[0 * 3 + a];
+  return r4[(b + 1) * 3 + a] - r4[0 * 3 + a];
+}
+LIO_HD void lidar_linear_maps(const double *pose_p, const double *pose_i, const double *pose_ex, double L[18 * 13], double l[13]) {
+  const LidarMapPrep m = lidar_map_prepare(pose_p, pose_i, pose_ex);
+  double J4[4 * 3 * 18], r4[4 * 3];
+  for (int b = 0; b < 4; ++b) lidar_map_probe(m, b, J4 + b * 54, r4 + b * 3);
+  for (int e = 0; e < 18 * 13; ++e) L[e] = lidar_map_entry(J4, r4, e);
+  for (int c = 0; c < 13; ++c) l[c] = lidar_map_entry(J4, r4, 18 * 13 + c);
 }
 
 class WindowSystem {

@@ -208,6 +208,9 @@ _SIGS = {
     "lio_est_get_features": (C.c_size_t, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "lio_est_get_laser_odom_transform": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
     "lio_est_get_prior": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
+    "lio_est_get_prior_factor": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
+    "lio_est_set_prior_factor": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int]),
+    "lio_est_set_extrinsic": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -761,6 +764,25 @@ class Estimator:
         x0 = np.zeros(ln.value)
         self.lib.dll.lio_est_get_prior(self.h, _dp(JtJ), _dp(Jtr), _dp(x0), C.byref(ln))
         return dict(n=n, JtJ=JtJ, Jtr=Jtr, x0=x0)
+
+    def prior_factor(self):
+        """linearized_jacobians / linearized_residuals / keep_block_data of the current prior (None when there is none)."""
+        n = self.lib.dll.lio_est_get_prior_factor(self.h, None, None, None, None)
+        if n <= 0:
+            return None
+        ln = C.c_int(0)
+        self.lib.dll.lio_est_get_prior_factor(self.h, None, None, None, C.byref(ln))
+        J, r, x0 = np.zeros((n, n)), np.zeros(n), np.zeros(ln.value)
+        self.lib.dll.lio_est_get_prior_factor(self.h, _dp(J), _dp(r), _dp(x0), C.byref(ln))
+        return dict(n=n, lin_jac=J, lin_res=r, x0=x0)
+
+    def set_prior_factor(self, pf):
+        J, r, x0 = _f64(pf["lin_jac"]), _f64(pf["lin_res"]), _f64(pf["x0"])
+        _chk(self.lib.dll.lio_est_set_prior_factor(self.h, int(pf["n"]), _dp(J), _dp(r), _dp(x0), x0.shape[0]), "lio_est_set_prior_factor")
+
+    def set_extrinsic(self, q_xyzw, p):
+        T = TransformF.make(q_xyzw, p)
+        _chk(self.lib.dll.lio_est_set_extrinsic(self.h, C.byref(T)), "lio_est_set_extrinsic")
 
     def set_factor_sharding(self, rank, world, allreduce_numpy):
         """`allreduce_numpy(buf: np.ndarray[float64])` must sum `buf` in place over all ranks (e.g. torch.distributed)."""

@@ -645,6 +645,37 @@ int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, in
   if (x0_len) *x0_len = len;
   return n;
 }
+int lio_est_get_prior_factor(const lio_est *h, double *lin_jac, double *lin_res, double *x0, int *x0_len) {
+  if (!h) return LIO_ERR_ARG;
+  const auto &pr = h->est.last_marg;
+  if (!pr) return 0;
+  int n = pr->n;
+  if (lin_jac) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) lin_jac[i * n + j] = pr->lin_jac(i, j);
+  if (lin_res) for (int i = 0; i < n; ++i) lin_res[i] = pr->lin_res[i];
+  int len = 0;
+  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+  if (x0_len) *x0_len = len;
+  return n;
+}
+int lio_est_set_prior_factor(lio_est *h, int n, const double *lin_jac, const double *lin_res, const double *x0, int x0_len) {
+  if (!h || !lin_jac || !lin_res || !x0 || n <= 0) return LIO_ERR_ARG;
+  const auto &old = h->est.last_marg;
+  if (!old || old->n != n) return LIO_ERR_STATE;
+  int len = 0;
+  for (const auto &b : old->x0) len += int(b.size());
+  if (len != x0_len) return LIO_ERR_STATE;
+  auto pr = std::make_shared<MargPrior>(*old);
+  for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) pr->lin_jac(i, j) = lin_jac[i * n + j]; pr->lin_res[i] = lin_res[i]; }
+  len = 0;
+  for (auto &b : pr->x0) for (double &v : b) v = x0[len++];
+  h->est.last_marg = pr;
+  return LIO_OK;
+}
+int lio_est_set_extrinsic(lio_est *h, const lio_transform_f *T) {
+  if (!h || !T) return LIO_ERR_ARG;
+  h->est.transform_lb = toT(*T);
+  return LIO_OK;
+}
 int lio_est_snapshot(lio_est *h) {
   if (!h) return LIO_ERR_ARG;
   h->snap.reset(new Estimator(h->est));

@@ -409,6 +409,11 @@ int lio_est_get_prior_factor(const lio_est *, double *lin_jac_or_null, double *l
 int lio_est_set_prior_factor(lio_est *, int n, const double *lin_jac, const double *lin_res, const double *x0, int x0_len);
 int lio_est_set_extrinsic(lio_est *, const lio_transform_f *T_lb);
 
+/* Test hook: x = A^-1 b for a symmetric positive definite A (n*n row-major, n <= 128) by the dense factorisation the solver
+ * uses for its D x D system (Estimator.cc:1911 DENSE_SCHUR; the product: blocked L D L^T in LDS with fp64-MFMA trailing
+ * updates, csrc/solve_step.h).  LIO_ERR_STATE when A is not positive definite. */
+int lio_dense_spd_solve(const double *A, const double *b, int n, double *x_out);
+
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);

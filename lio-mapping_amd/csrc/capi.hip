@@ -714,6 +714,13 @@ int lio_est_set_extrinsic(lio_est *h, const lio_transform_f *T) {
   h->e->transform_lb_ = toT(*T);
   return LIO_OK;
 }
+int lio_dense_spd_solve(const double *A, const double *b, int n, double *x) {
+  if (!A || !b || !x || n < 1 || n > 128) return LIO_ERR_ARG;
+  return guarded([&] {
+    const int ok = ldlt_solve_device(A, b, n, x, scratch().s);
+    return ok == 1 ? LIO_OK : (ok == -2 ? LIO_ERR_ARG : LIO_ERR_STATE);
+  });
+}
 int lio_est_snapshot(lio_est *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->e->Snapshot(); return LIO_OK; });

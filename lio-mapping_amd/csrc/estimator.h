@@ -15,6 +15,7 @@
 #include "cloud_kernels.h"
 #include "host_init.h"
 #include "host_solver.h"
+#include "solve_step.h"
 
 namespace lio {
 
@@ -223,6 +224,10 @@ class Estimator {
   Rigidf RelTransform(int i, const Rigidd &T_pivot, const Rigidd &lb) const;
   void VectorToParams(WindowParams &P) const;
   void ParamsToVector(const WindowParams &P);
+  // The whole trust-region loop on the device (solve_step.h): two launches per iteration, no host round trip.  false: the
+  // problem does not fit that path (or changed shape at the first evaluation) and the caller runs the host solver instead.
+  bool SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &sum, WindowSystem::Costs &costs0, bool &turn_off);
+  void FillMomentArgs(MomentArgs &ma, int &max_slots) const;
   void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
   void LidarLaunch(const WindowParams &P);             // asynchronous part: frame transforms + moments kernels
   void LidarWait(std::vector<FrameMoments> &m);        // stream sync (+ all-reduce when sharded) + unpack
@@ -248,6 +253,17 @@ class Estimator {
   DBuf<double> d_odom_partials_, d_moment_partials_, d_moment_out_;
   DBuf<int> d_moment_tickets_;
   bool fold_in_kernel_ = false;
+  // Device-resident dogleg (solve_step.h), opt-in with LIO_DEVICE_SOLVE=1.  Measured on the MI355X at D = 96 it is SLOWER than
+  // the host loop for one window (launch B = one workgroup: 150 us per iteration against the host's 17 us of assemble +
+  // Cholesky + step), so the host loop stays the default; it exists for hosts that drive many windows per
+  // thread, where the estimator's host thread is the bottleneck.
+  bool device_solve_ = false;
+  double dev_n_lidar_ = -1;                 // valid lidar factors at the last device evaluation (-1: the host path ran)
+  struct DsHost { DevProblem pb; DevState st; double prior_mats[2 * 64 * 64 + 2 * 64]; double S_buf[2 * DS_MAX_WO * LIO_MOMENT_OUT]; };
+  DsHost *h_ds_ = nullptr;                  // pinned staging: problem + state up, state + moments back
+  DBuf<char> d_ds_;                         // device image of {DevProblem, DevState, prior_mats}
+  DBuf<double> d_ds_imu_, d_ds_lmap_, d_ds_prior_out_, d_ds_exprior_out_, d_ds_Hcur_, d_ds_Sbuf_;
+  DBuf<long long> d_ds_prof_;
   double *h_moment_out_ = nullptr;  // pinned
   OdomState *h_odom_ = nullptr;     // pinned landing zone of the laser-odom state peeks
   std::unique_ptr<HostState> snap_;

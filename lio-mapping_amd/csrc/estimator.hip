@@ -85,6 +85,8 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_moment_tickets_.p, 0, LIO_MAX_FRAMES * sizeof(int)));
   // measured on the MI355X: fold inside the launch 18.8 us vs moments + separate reduce launch 13.6 us per linearisation
   fold_in_kernel_ = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL") != nullptr;
+  if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_odom_), sizeof(OdomState)));
@@ -94,6 +96,7 @@ Estimator::~Estimator() {
   try { JoinMarg(); } catch (...) {}
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
   if (h_odom_) (void)hipHostFree(h_odom_);
+  if (h_ds_) (void)hipHostFree(h_ds_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -580,12 +583,10 @@ void Estimator::LidarEval(const WindowParams &P, std::vector<FrameMoments> &m) {
   LidarWait(m);
 }
 
-void Estimator::LidarLaunch(const WindowParams &P) {
-  const double t_dbg0 = now_ms();
-  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; } } dbg_acc{this, t_dbg0};
+void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
   const int pivot = W_ - Wo_;
-  MomentArgs ma{};
-  int max_slots = 0;
+  ma = MomentArgs{};
+  max_slots = 0;
   for (int i = 1; i <= Wo_; ++i) {
     MomentFrame &f = ma.fr[ma.nframes++];
     const int idx = pivot + i;
@@ -595,10 +596,91 @@ void Estimator::LidarLaunch(const WindowParams &P) {
       f.slot_begin = int((long long)f.nslots * shard_rank_ / shard_world_);
       f.slot_end = int((long long)f.nslots * (shard_rank_ + 1) / shard_world_);
     }
-    relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), f.R, f.t);
     max_slots = std::max(max_slots, f.nslots);
   }
   ma.blocks_per_frame = moment_blocks_per_frame(max_slots);
+}
+
+// Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.
+bool Estimator::SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &sum, WindowSystem::Costs &costs0, bool &turn_off) {
+  if (!device_solve_ || (shard_world_ > 1 && allreduce_) || !sys.use_lidar || total_slots_ == 0) return false;
+  MomentArgs ma;
+  int max_slots = 0;
+  FillMomentArgs(ma, max_slots);
+  DsHost &H = *h_ds_;
+  std::vector<double> pm;
+  if (!ds_pack_problem(sys, P, cfg_.max_num_iterations, ma.blocks_per_frame, convergence_flag_, cfg_.imu_factor, H.pb, pm)) return false;
+  if (pm.size() > sizeof(H.prior_mats) / sizeof(double)) return false;
+  if (ds_lds_doubles(H.pb.n_pad, Wo_) * sizeof(double) > 160 * 1024) return false;
+  if (!pm.empty()) std::memcpy(H.prior_mats, pm.data(), pm.size() * sizeof(double));
+  ds_init_state(P, H.st);
+  const size_t up_bytes = offsetof(DsHost, prior_mats) + std::max<size_t>(pm.size(), 4) * sizeof(double);
+  d_ds_.reserve(sizeof(DsHost));
+  d_ds_imu_.reserve(size_t(DS_MAX_WO) * DS_IMU_OUT); d_ds_lmap_.reserve(size_t(DS_MAX_WO) * DS_LMAP_OUT);
+  d_ds_prior_out_.reserve(72); d_ds_exprior_out_.reserve(DS_EXP_OUT);
+  d_ds_Hcur_.reserve(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); d_ds_Sbuf_.reserve(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT);
+  d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
+  LIO_HIP(hipMemcpyAsync(d_ds_.p, &H, up_bytes, hipMemcpyHostToDevice, stream_));
+  const DevProblem *d_pb = reinterpret_cast<const DevProblem *>(d_ds_.p + offsetof(DsHost, pb));
+  DevState *d_st = reinterpret_cast<DevState *>(d_ds_.p + offsetof(DsHost, st));
+  const double *d_pm = reinterpret_cast<const double *>(d_ds_.p + offsetof(DsHost, prior_mats));
+  static const bool dbg_prof = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  if (dbg_prof) { d_ds_prof_.reserve(32); LIO_HIP(hipMemsetAsync(d_ds_prof_.p, 0, 32 * sizeof(long long), stream_)); }
+  StepBuffers B{d_pm, d_moment_partials_.p, d_ds_imu_.p, d_ds_lmap_.p, d_ds_prior_out_.p, d_ds_exprior_out_.p, d_ds_Hcur_.p, d_ds_Sbuf_.p,
+                dbg_prof ? d_ds_prof_.p : nullptr};
+  double nres = 0;
+  for (int k = 0; k < ma.nframes; ++k) nres += ma.fr[k].nslots;
+  // iteration k evaluates candidate k (k = 0: the initial point); at most max_num_iterations candidates follow it
+  static const int dbg_max_launch = [] { const char *e = std::getenv("LIO_DS_MAX_LAUNCH"); return e ? std::atoi(e) : 1 << 30; }();  // debug: truncate the chain
+  for (int k = 0; k <= cfg_.max_num_iterations && k < dbg_max_launch; ++k) {
+    int th = timers_.begin(KT_MOMENTS, 60.0 * nres, stream_);
+    launch_solve_iteration(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, d_pb, d_st, B, d_ds_imu_.p, d_ds_lmap_.p, d_ds_prior_out_.p,
+                           d_ds_exprior_out_.p, H.pb.n_pad, stream_);
+    timers_.end(th, stream_);
+  }
+  LIO_HIP(hipMemcpyAsync(&H.st, d_st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(H.S_buf, d_ds_Sbuf_.p, sizeof(double) * 2 * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  timers_.resolve();
+  if (dbg_prof) {
+    long long pr[32];
+    LIO_HIP(hipMemcpy(pr, d_ds_prof_.p, sizeof(pr), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[lio_hip timing] launch B phases (shader clocks):");
+    for (int k = 1; k < 14; ++k) if (pr[k] && pr[k - 1]) std::fprintf(stderr, " P%d %lld", k, pr[k] - pr[k - 1]); else if (pr[k]) { int j = k - 1; while (j > 0 && !pr[j]) --j; std::fprintf(stderr, " P%d(from %d) %lld", k, j, pr[k] - pr[j]); }
+    std::fprintf(stderr, " | ldlt: panel0 %lld trsm0 %lld update0 %lld all-blocks %lld backsolve %lld | raw", pr[17] - pr[16], pr[18] - pr[17], pr[19] - pr[18], pr[20] - pr[16],
+                 pr[21] - pr[20]);
+    for (int k = 0; k < 24; ++k) std::fprintf(stderr, " %lld", pr[k] ? pr[k] - pr[0] : -1);
+    std::fprintf(stderr, "\n");
+  }
+  const DevState &st = H.st;
+  if (st.need_host || !st.started) return false;
+  costs0.marg = st.costs0[0]; costs0.pim = st.costs0[1]; costs0.ppp = st.costs0[2]; costs0.prior = st.costs0[3];
+  turn_off = st.turn_off != 0;
+  convergence_flag_ = st.conv_flag_out != 0;
+  ds_unpack_params(st.x, P);
+  sum = SolveSummary();
+  sum.iterations = st.it; sum.successful = st.successful; sum.termination = st.termination;
+  sum.trace.assign(st.trace, st.trace + std::min(st.ntrace, 40));
+  sum.initial_cost = st.ntrace > 0 ? st.trace[0] : 0.0; sum.final_cost = st.x_cost;
+  sum.initial_costs = costs0;
+  sum.final_moments.assign(Wo_ + 1, FrameMoments());
+  const double *Sc = H.S_buf + size_t(st.s_cur) * Wo_ * LIO_MOMENT_OUT;
+  for (int i = 1; i <= Wo_; ++i) {
+    const double *src = Sc + size_t(i - 1) * LIO_MOMENT_OUT;
+    std::memcpy(sum.final_moments[i].S, src, 256 * sizeof(double));
+    sum.final_moments[i].cost = src[256]; sum.final_moments[i].count = src[257];
+  }
+  dev_n_lidar_ = st.n_lidar;
+  return true;
+}
+
+void Estimator::LidarLaunch(const WindowParams &P) {
+  const double t_dbg0 = now_ms();
+  struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; } } dbg_acc{this, t_dbg0};
+  MomentArgs ma;
+  int max_slots = 0;
+  FillMomentArgs(ma, max_slots);
+  for (int i = 1; i <= Wo_; ++i) relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), ma.fr[i - 1].R, ma.fr[i - 1].t);
   d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
   d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
   double nres = 0;
@@ -712,8 +794,25 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   // Group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984).
   // The reference evaluates the three groups, then Ceres linearises again at the same point; here ONE device
   // pass yields both — unless the flag logic changes the problem (prior dropped / extrinsic frozen).
-  Linearization first;
+  // Device-resident dogleg first (solve_step.h); it reports the group costs and applies the convergence_flag_ logic itself and
+  // hands the solve back (false) when that logic changes the shape of the problem or the problem does not fit.
+  SolveSummary s;
+  bool on_device = false;
   {
+    WindowSystem::Costs gc;
+    bool toff = true;
+    const double t_dev0 = now_ms();
+    on_device = SolveOnDevice(sys, P, s, gc, toff);
+    if (on_device) {
+      R.ms_opt = now_ms() - t_dev0;
+      R.cost_pim_before = gc.pim; R.cost_ppp_before = gc.ppp; R.cost_marg_before = gc.marg;
+      turn_off = toff;
+      if (!convergence_flag_) { last_marg_.reset(); sys.prior.reset(); }
+    }
+  }
+  Linearization first;
+  if (!on_device) {
+    dev_n_lidar_ = -1;
     Layout lay = WindowSystem::solve_layout(P);
     first.costs = sys.evaluate(P, lay, 1 | 2 | 4 | 8, false, &first.H, &first.g, &first.m);
     first.valid = true;
@@ -730,15 +829,17 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     }
   }
   const double t_opt0 = now_ms();
+  if (!on_device) {
   // Factor sharding: every linearisation is a collective, so every rank must take the same number of them.  A per-rank
   // wall-clock cap (Estimator.cc:1921) could stop one rank an iteration earlier than its peers and leave an unmatched
   // all-reduce behind; the sharded mode therefore terminates on the iteration / tolerance rules only.
   const double time_cap = (shard_world_ > 1 && allreduce_) ? -1.0 : cfg_.max_solver_time;
-  SolveSummary s = solve_dogleg(sys, P, cfg_.max_num_iterations, time_cap, &first);
+  s = solve_dogleg(sys, P, cfg_.max_num_iterations, time_cap, &first);
   R.ms_opt = now_ms() - t_opt0;
   if (getenv("LIO_DEBUG_TIMING"))
     std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms | evaluate x%d: launch %.3f prior %.3f imu %.3f wait %.3f assemble %.3f\n",
                  s.ms_chol, s.ms_eval, sys.eclk.n, sys.eclk.launch, sys.eclk.prior, sys.eclk.imu, sys.eclk.wait, sys.eclk.assemble);
+  }
   R.iterations = s.iterations; R.successful_steps = s.successful; R.termination = s.termination;
   R.initial_cost = s.initial_cost; R.final_cost = s.final_cost;
   for (size_t k = 0; k < s.trace.size() && k < 32; ++k) R.cost_trace[k] = s.trace[k];
@@ -780,6 +881,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   {
     double cnt = 0;
     for (int i = 1; i <= Wo_; ++i) cnt += h_moment_out_[size_t(i - 1) * LIO_MOMENT_OUT + 257];
+    if (dev_n_lidar_ >= 0) cnt = dev_n_lidar_;
     R.n_lidar_residuals = cfg_.point_distance_factor ? int(cnt) : 0;
   }
   R.ms_total = now_ms() - t_total0;

@@ -13,6 +13,7 @@
 #include <string>
 
 #include "solve_kernels.h"
+#include "solve_step.h"
 
 namespace lio {
 
@@ -67,10 +68,11 @@ struct LogProduct {
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
 __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                   double *__restrict__ partials, int *__restrict__ tickets, double *__restrict__ out) {
+                                                   double *__restrict__ partials, int *__restrict__ tickets, double *__restrict__ out, int nblk) {
+  // nblk = blocks per frame (gridDim.x of the plain launches; the device-solver launch has a wider grid: k_lidar_moments_dev)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = lane & 15, grp = lane >> 4;
-  const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
+  const int waves_total = nblk * (MOMENT_THREADS / 64);
   const int wid = blockIdx.x * (MOMENT_THREADS / 64) + wv;
   __shared__ double zbuf[MOMENT_THREADS / 64][64 * ZROW];
   __shared__ double sm[MOMENT_THREADS / 64][LIO_MOMENT_OUT];
@@ -136,7 +138,7 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
   if (lane == 0) { sm[wv][256] = cost; sm[wv][257] = cnt; }
   __syncthreads();
-  double *dst = partials + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * LIO_MOMENT_OUT;
+  double *dst = partials + (size_t(blockIdx.y) * nblk + blockIdx.x) * LIO_MOMENT_OUT;
   for (int k = threadIdx.x; k < 258; k += MOMENT_THREADS) {
     double v = 0;
     for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][k];
@@ -151,12 +153,12 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   __syncthreads();
   if (threadIdx.x == 0) {
     const int t = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == int(gridDim.x) - 1);
+    is_last = (t == nblk - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  const double *src = partials + size_t(blockIdx.y) * gridDim.x * LIO_MOMENT_OUT;
-  const int bpf = gridDim.x;
+  const double *src = partials + size_t(blockIdx.y) * nblk * LIO_MOMENT_OUT;
+  const int bpf = nblk;
   for (int k = threadIdx.x; k < 258; k += MOMENT_THREADS) {
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     int b = 0;
@@ -184,9 +186,9 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
 #define RED_ROW (16 * 17 + 1)
 
 __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                       double *__restrict__ partials) {
+                                                       double *__restrict__ partials, int nblk) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int waves_total = gridDim.x * (MOMENT_THREADS / 64);
+  const int waves_total = nblk * (MOMENT_THREADS / 64);
   const int wid = blockIdx.x * (MOMENT_THREADS / 64) + wv;
   double a[LIO_NACC];
 #pragma unroll
@@ -255,7 +257,7 @@ __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, co
   for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
   if (lane == 0) { cw[wv][0] = cost; cw[wv][1] = cnt; }
   __syncthreads();
-  double *dst = partials + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * LIO_MOMENT_OUT;
+  double *dst = partials + (size_t(blockIdx.y) * nblk + blockIdx.x) * LIO_MOMENT_OUT;
   {
     // expand the 73 sums into the row-major 16x16 layout the host expects (13x13 used, rest zero)
     const int r = tid >> 4, cidx = tid & 15;
@@ -282,24 +284,24 @@ __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, co
 
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_sym(MomentArgs a, const uint8_t *__restrict__ valid,
                                                                       const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_sym_body(a.fr[blockIdx.y], valid, coef, partials);
+  lidar_moments_sym_body(a.fr[blockIdx.y], valid, coef, partials, gridDim.x);
 }
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_sym_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
                                                                               const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_sym_body(frames[blockIdx.y], valid, coef, partials);
+  lidar_moments_sym_body(frames[blockIdx.y], valid, coef, partials, gridDim.x);
 }
 
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
                                                                   const float4 *__restrict__ coef, double *__restrict__ partials,
                                                                   int *__restrict__ tickets, double *__restrict__ out) {
-  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials, tickets, out);
+  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials, tickets, out, gridDim.x);
 }
 
 // Batched form for B windows in flight: the frame descriptors live in device memory (B x Wo of them), everything else is the
 // same code.  Used by the batched roofline measurement (SURVEY.md §8d ii) and by multi-window hosts.
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
                                                                           const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_body(frames[blockIdx.y], valid, coef, partials, nullptr, nullptr);
+  lidar_moments_body(frames[blockIdx.y], valid, coef, partials, nullptr, nullptr, gridDim.x);
 }
 
 __global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
@@ -347,6 +349,241 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
   else
     hipLaunchKernelGGL(k_lidar_moments_sym, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
   if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
+  LIO_HIP(hipGetLastError());
+}
+
+// ================================================================================================
+// Device-resident dogleg (solve_step.h): the kernel-side executor and the two launches of one iteration
+// ================================================================================================
+__device__ __forceinline__ double ds_bcast_lane(double v, int src_lane) {   // src_lane: wave-uniform (a constant after unrolling)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+struct DevExec {
+  static constexpr bool kDevice = true;
+  static constexpr int WT = 64;
+  int tid, nthr, lane, wave, nwave;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ double wsum(double v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
+  __device__ __forceinline__ double wmax(double v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+  }
+  // 1 / d from the hardware estimate and two Newton steps (<= 1 ulp): a correctly rounded fp64 divide is ~40 instructions on
+  // the pivot chain of the factorisation
+  __device__ __forceinline__ double rcp(double d) const {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+  }
+  // lanes 4m .. 4m+3 hold v0..v3: every one of them gets (v0 + v1) + (v2 + v3)
+  __device__ __forceinline__ void stamp(long long *prof, int k) const { if (prof && tid == 0) prof[k] = clock64(); }
+  __device__ __forceinline__ double pair_sum4(double v) const {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+  }
+
+  // L D L^T of the 16x16 diagonal block at p: lane r (mod 16) keeps row r in registers, pivots and columns travel by
+  // v_readlane; the arithmetic and its order are those of the reference loop in ds_panel_factor.
+  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd) const {
+    const int r = lane & 15;
+    double a[DS_NB];
+    const double *row = A + size_t(p + r) * ld + p;
+#pragma unroll
+    for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
+    int ok = 1;
+    double myinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < DS_NB; ++j) {
+      const double d = ds_bcast_lane(a[j], j);
+      ok &= (d > 0.0) ? 1 : 0;
+      const double inv = rcp(d);
+      const double t = a[j];
+      const double l = t * inv;
+#pragma unroll
+      for (int c = j + 1; c < DS_NB; ++c) {
+        const double tc = ds_bcast_lane(t, c);
+        a[c] -= l * tc;
+      }
+      a[j] = (r > j) ? l : a[j];
+      myinv = (r == j) ? inv : myinv;
+    }
+    if (lane < DS_NB) {
+      double *orow = A + size_t(p + r) * ld + p;
+#pragma unroll
+      for (int c = 0; c < DS_NB; ++c)
+        if (c <= r) orow[c] = a[c];
+      invd[p + r] = myinv;
+    }
+    return ok;
+  }
+
+  // A22 -= L21 D L21^T on the fp64 matrix cores, one 16x16 tile of the lower triangle per wave at a time.
+  // v_mfma_f64_16x16x4: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D row = (l >> 4) + 4 reg, col = l & 15.
+  __device__ __forceinline__ void trailing_update_mfma(double *A, int ld, int npad, int p) const {
+    const int q0 = p + DS_NB, nb = (npad - q0) / DS_NB;
+    const int i = lane & 15, kq = lane >> 4;
+    double dk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) dk[kk] = A[size_t(p + 4 * kk + kq) * ld + p + 4 * kk + kq];
+    int t = 0;
+    for (int I = 0; I < nb; ++I)
+      for (int J = 0; J <= I; ++J, ++t) {
+        if (t % nwave != wave) continue;
+        const int rb = q0 + DS_NB * I, cb = q0 + DS_NB * J;
+        v4f64 acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = A[size_t(rb + kq + 4 * rr) * ld + cb + i];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + kq;
+          const double aop = -A[size_t(rb + i) * ld + p + k];
+          const double bop = A[size_t(cb + i) * ld + p + k] * dk[kk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = kq + 4 * rr;
+          if (I != J || row >= i) A[size_t(rb + row) * ld + cb + i] = acc[rr];   // a diagonal tile keeps its strict upper triangle
+        }
+      }
+  }
+
+  // x_blk of L^T x = z for the 16 unknowns at p: lane j keeps y_j and column j of the unit-lower block
+  __device__ __forceinline__ void panel_backsolve_regs(double *A, int ld, int p, double *gz, const double *part) const {
+    const int j = lane & 15;
+    double s2 = 0.0;
+    for (int sl = 0; sl < 32; ++sl) s2 += part[sl * 16 + j];
+    double y = gz[p + j] - s2;
+    double col[DS_NB];
+#pragma unroll
+    for (int k = 0; k < DS_NB; ++k) col[k] = (k > j) ? A[size_t(p + k) * ld + p + j] : 0.0;
+#pragma unroll
+    for (int k = DS_NB - 1; k >= 1; --k) {
+      const double yk = ds_bcast_lane(y, k);
+      y -= col[k] * yk;
+    }
+    if (lane < DS_NB) gz[p + j] = y;
+  }
+};
+
+// Launch A of an iteration.  Grid (max(bpf, Wo + 1), Wo + 1): rows 0 .. Wo-1 are the moments of frames 1 .. Wo at the candidate's
+// T_{pivot<-i} (read from the device-resident state, not from the launch arguments); row Wo is the aux row: block i < Wo the
+// ImuFactor between optimised frames i and i + 1 and the lidar linear map of frame i + 1, block Wo the marginalization prior
+// and the extrinsic prior — all of it at the candidate, all of it hidden under the moments pass.
+template <bool SYM>
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_dev(MomentArgs a, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
+                                                                      double *__restrict__ partials, const DevProblem *__restrict__ pb,
+                                                                      const DevState *__restrict__ st, const double *__restrict__ prior_mats,
+                                                                      double *__restrict__ imu_out, double *__restrict__ lmap,
+                                                                      double *__restrict__ prior_out, double *__restrict__ exprior_out) {
+  if (st->done) return;
+  const int Wo = a.nframes;
+  if (int(blockIdx.y) < Wo) {
+    if (int(blockIdx.x) >= a.blocks_per_frame) return;
+    MomentFrame fr = a.fr[blockIdx.y];
+    const double *Rt = st->cand_Rt[blockIdx.y];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fr.R[k] = Rt[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
+    if (SYM) lidar_moments_sym_body(fr, valid, coef, partials, a.blocks_per_frame);
+    else lidar_moments_body(fr, valid, coef, partials, nullptr, nullptr, a.blocks_per_frame);
+    return;
+  }
+  __shared__ double aux_lds[1024];
+  const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
+  const int i = blockIdx.x;
+  const DevParams &P = st->cand;
+  if (i < Wo) {
+    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], imu_out + size_t(i) * DS_IMU_OUT, aux_lds);
+    __syncthreads();
+    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+  } else if (i == Wo) {
+    if (pb->have_prior) aux_prior(x, *pb, prior_mats, P, prior_out, aux_lds);
+    if (pb->use_ex_prior) aux_exprior(x, *pb, P, exprior_out);
+  }
+}
+
+// Launch B: one workgroup (solve_step.h)
+__global__ void __launch_bounds__(DS_THREADS) k_solve_step(const DevProblem *__restrict__ pb, DevState *st, StepBuffers B) {
+  extern __shared__ __attribute__((aligned(16))) double ds_lds[];
+  const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
+  solve_step(x, *pb, *st, B, ds_lds);
+}
+
+// Test hook (lio_ldlt_solve): the LDS-resident blocked L D L^T + back-substitution of launch B on its own
+__global__ void __launch_bounds__(DS_THREADS) k_ldlt_test(const double *__restrict__ Ain, const double *__restrict__ b, int n, int npad,
+                                                         double *__restrict__ xout, int *__restrict__ ok_out) {
+  extern __shared__ __attribute__((aligned(16))) double ds_lds[];
+  const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
+  const int ld = npad + 1;
+  double *A = ds_lds, *gz = A + size_t(npad) * ld, *invd = gz + npad, *part = invd + npad;
+  int *flag = reinterpret_cast<int *>(part + 512);
+  for (int e = x.tid; e < npad * npad; e += x.nthr) {
+    const int r = e / npad, c = e % npad;
+    A[size_t(r) * ld + c] = (r < n && c < n) ? Ain[size_t(r) * n + c] : (r == c ? 1.0 : 0.0);
+  }
+  for (int i = x.tid; i < npad; i += x.nthr) gz[i] = i < n ? b[i] : 0.0;
+  x.sync();
+  const int ok = ds_ldlt_solve(x, A, ld, npad, gz, invd, part, flag);
+  if (x.tid == 0) *ok_out = ok;
+  if (ok) for (int i = x.tid; i < n; i += x.nthr) xout[i] = gz[i];
+  // the strict upper triangle must have survived (launch B reads H from it after the factorisation)
+  if (ok) for (int e = x.tid; e < n * n; e += x.nthr) { const int r = e / n, c = e % n; if (c > r && A[size_t(r) * ld + c] != Ain[size_t(r) * n + c]) *ok_out = -1; }
+}
+int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipStream_t s) {
+  const int npad = (n + DS_NB - 1) / DS_NB * DS_NB;
+  const size_t lds = (size_t(npad) * (npad + 1) + 2 * size_t(npad) + 512 + 8) * sizeof(double);
+  if (n < 1 || lds > 160 * 1024) return -2;
+  static const bool attr_set = [] {
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldlt_test), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return true;
+  }();
+  (void)attr_set;
+  DBuf<double> dA, db, dx; DBuf<int> dok;
+  dA.reserve(size_t(n) * n); db.reserve(n); dx.reserve(n); dok.reserve(1);
+  LIO_HIP(hipMemcpyAsync(dA.p, A, sizeof(double) * n * n, hipMemcpyHostToDevice, s));
+  LIO_HIP(hipMemcpyAsync(db.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_ldlt_test, dim3(1), dim3(DS_THREADS), lds, s, dA.p, db.p, n, npad, dx.p, dok.p);
+  LIO_HIP(hipGetLastError());
+  int ok = 0;
+  LIO_HIP(hipMemcpyAsync(&ok, dok.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(xh, dx.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
+  return ok;
+}
+
+void launch_solve_iteration(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, const DevProblem *pb, DevState *st,
+                            const StepBuffers &B, double *imu_out, double *lmap, double *prior_out, double *exprior_out, int n_pad, hipStream_t s) {
+  static const bool attr_set = [] {
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return true;
+  }();
+  (void)attr_set;
+  int max_slots = 0;
+  for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
+  const dim3 grid(std::max(a.blocks_per_frame, a.nframes + 1), a.nframes + 1);
+  if (use_mfma(max_slots, a.blocks_per_frame))
+    hipLaunchKernelGGL(k_lidar_moments_dev<false>, grid, dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, pb, st, B.prior_mats, imu_out, lmap, prior_out,
+                       exprior_out);
+  else
+    hipLaunchKernelGGL(k_lidar_moments_dev<true>, grid, dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, pb, st, B.prior_mats, imu_out, lmap, prior_out,
+                       exprior_out);
+  const size_t lds = ds_lds_doubles(n_pad, a.nframes) * sizeof(double);
+  hipLaunchKernelGGL(k_solve_step, dim3(1), dim3(DS_THREADS), lds, s, pb, st, B);
   LIO_HIP(hipGetLastError());
 }
 

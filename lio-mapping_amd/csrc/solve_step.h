@@ -89,6 +89,7 @@ struct HostExec {
   double wsum(double v) const { return v; }
   double wmax(double v) const { return v; }
   double rcp(double d) const { return 1.0 / d; }
+  void stamp(long long *, int) const {}
 };
 
 // block-wide sum of K per-thread partials (every thread gets the totals); `red` holds >= 8 * K doubles
@@ -261,6 +262,7 @@ struct StepBuffers {
   const double *exprior_out;   // DS_EXP_OUT
   double *Hcur;                // n_pad * ld: scaled H at the accepted point
   double *S_buf;               // 2 * Wo * LIO_MOMENT_OUT: moments at the accepted point / at the candidate (st.s_cur picks)
+  long long *prof;             // optional: 32 shader-clock stamps of the last launch B (LIO_DEBUG_TIMING)
 };
 
 struct StepLds {
@@ -320,14 +322,16 @@ LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd) {
 }
 
 template <class X>
-LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, int *flag) {
+LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, int *flag, long long *prof = nullptr) {
   const int nblk = npad / DS_NB;
   for (int kb = 0; kb < nblk; ++kb) {
     const int p = kb * DS_NB, q = p + DS_NB;
     // ---- phase 1: diagonal block (wave 0)
+    if (kb == 0) x.stamp(prof, 16);
     const int ok = ds_panel_factor(x, A, ld, p, invd);
     if (x.tid == 0) *flag = ok;
     x.sync();
+    if (kb == 0) x.stamp(prof, 17);
     if (!*flag) return 0;   // uniform: every thread reads the same LDS word after the barrier
     // ---- phase 2: rows below the block and the right-hand side: T = A21 L11^-T (forward substitution along the columns),
     // stored as L = T D^-1
@@ -348,6 +352,7 @@ LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, do
       for (int j = 0; j < DS_NB; ++j) row[j] = tr[j] * invd[p + j];
     }
     x.sync();
+    if (kb == 0) x.stamp(prof, 18);
     if (q >= npad) break;
     // ---- phase 3: trailing update  A22 -= L21 D L21^T  (lower triangle), rhs -= L21 D z
     for (int c = q + x.tid; c < npad; c += x.nthr) {
@@ -368,7 +373,9 @@ LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, do
         }
     }
     x.sync();
+    if (kb == 0) x.stamp(prof, 19);
   }
+  x.stamp(prof, 20);
   // ---- back-substitution  L^T x = z, block by block from the bottom
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int p = kb * DS_NB, q = p + DS_NB;
@@ -415,6 +422,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   x.sync();
   if (C.done) return;
   double *A = L.A;
+  x.stamp(B.prof, 0);
   // ---- P1: fold the per-block partials of launch A (the order of k_moment_reduce: four interleaved chains, remainder on the
   // first, (v0 + v1) + (v2 + v3)); the folded moments also go to the candidate slot of S_buf
   double *Sx = A;                                   // Wo x 260, dead once the assembly starts
@@ -446,6 +454,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     }
   }
   x.sync();
+  x.stamp(B.prof, 1);
   // ---- P2: LS = L S (18 x 13 per frame)
   for (int e = x.tid; e < Wo * 234; e += x.nthr) {
     const int f = e / 234, a = (e % 234) / 13, b = e % 13;
@@ -455,6 +464,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     LS[e] = o;
   }
   x.sync();
+  x.stamp(B.prof, 2);
   // ---- P3: H_i = (L S) L^T (18 x 18), g_i = (L S) l
   for (int e = x.tid; e < Wo * 342; e += x.nthr) {
     const int f = e / 342, r = e % 342;
@@ -470,6 +480,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     L.zb[f * 344 + r] = o;
   }
   x.sync();
+  x.stamp(B.prof, 3);
   // ---- P4: assemble the candidate's H (full, unscaled) and g in the order of WindowSystem::evaluate:
   // prior, ImuFactor 0..Wo-1, lidar frames 1..Wo, extrinsic prior
   const double *JtJ = B.prior_mats;
@@ -522,6 +533,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   }
   x.sync();
   // NOTE: Sx / LS aliased A and are gone now; S_cand (global) keeps the moments.
+  x.stamp(B.prof, 4);
   // ---- P5: decide on the pending candidate (thread 0)
   if (x.tid == 0) {
     double marg = pb.have_prior ? B.prior_out[np] : 0.0, pim = 0.0, ppp = 0.0, cnt = 0.0;
@@ -578,6 +590,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   x.sync();
   if (C.done) { if (x.tid == 0) { st.it = C.it; st.successful = C.successful; } return; }
   const int mode = C.mode;
+  x.stamp(B.prof, 5);
   // ---- P6: make (H, g, x) the current point
   DevParams &P = st.x;
   if (mode == DS_MODE_ACCEPT) {
@@ -644,6 +657,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     }
   }
   x.sync();
+  x.stamp(B.prof, 6);
   // ---- P7: the minimizer loop up to the next candidate (TrustRegionMinimizer::Minimize + DoglegStrategy::ComputeStep)
   for (int guard = 0; guard < 64; ++guard) {
     if (x.tid == 0) {
@@ -687,6 +701,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       }
       block_sum<X, 2>(x, L.red, gq);
       if (x.tid == 0) C.alpha = gq[0] / gq[1];
+      x.stamp(B.prof, 7);
       // Gauss-Newton step of the regularised system; mu grows until the factorisation succeeds (DoglegStrategy::ComputeGaussNewtonStep)
       for (int attempt = 0; attempt < 12; ++attempt) {
         x.sync();
@@ -699,7 +714,8 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
         for (int i = x.tid; i < npad; i += x.nthr) L.gz[i] = L.g[i];
         x.sync();
-        int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, &C.fact_ok);
+        int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, &C.fact_ok, B.prof);
+        x.stamp(B.prof, 21);
         int fin = 1;
         if (ok) for (int i = x.tid; i < n; i += x.nthr) if (!(fabs(L.gz[i]) <= 1.7e308)) fin = 0;
         double fv[1] = {double(fin)};
@@ -709,6 +725,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
       }
       x.sync();
+      x.stamp(B.prof, 8);
       if (C.lin_ok) {
         for (int i = x.tid; i < npad; i += x.nthr) {
           const double v = i < n ? L.gz[i] * (-L.diag[i]) : 0.0;
@@ -751,6 +768,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       if (kind == 2) { block_sum<X, 1>(x, L.red, sn); dnorm = sqrt(sn[0]); } else x.sync();
       for (int i = x.tid; i < n; i += x.nthr) L.step[i] = L.step[i] / L.diag[i];
       x.sync();
+      x.stamp(B.prof, 9);
       double mq[2] = {0.0, 0.0};
       for (int i = x.tid; i < n; i += x.nthr) {
         double sres = 0;
@@ -774,6 +792,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     if (C.done) break;
   }
   x.sync();
+  x.stamp(B.prof, 12);
   // ---- P8: write the candidate (Plus), its ambient step norm and the relative lidar poses launch A will read
   if (!C.done) {
     for (int t = x.tid; t < (Wo + 1) * 10 + 1; t += x.nthr) {
@@ -810,6 +829,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     if (x.tid == 0) { C.step_norm = sqrt(sq[0]); C.invalid = 0; }
   }
   x.sync();
+  x.stamp(B.prof, 13);
   if (x.tid == 0) {
     st.radius = C.radius; st.mu = C.mu; st.alpha = C.alpha; st.dogleg_norm = C.dogleg_norm; st.gmax = C.gmax; st.x_cost = C.x_cost;
     st.x_norm = C.x_norm; st.model_change = C.model_change; st.step_norm = C.step_norm;

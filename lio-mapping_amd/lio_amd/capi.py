@@ -211,6 +211,7 @@ _SIGS = {
     "lio_est_get_prior_factor": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "lio_est_set_prior_factor": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int]),
     "lio_est_set_extrinsic": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
+    "lio_dense_spd_solve": (C.c_int, [c_double_p, c_double_p, C.c_int, c_double_p]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -287,6 +288,14 @@ class LioLib:
         return dict(ok=bool(rc), Vs=Vs, Bgs=bgs, g=g, R_WI=R)
 
     # ---- stateless blocks
+    def dense_spd_solve(self, A, b):
+        A, b = _f64(A), _f64(b)
+        n = b.shape[0]
+        assert A.shape == (n, n)
+        x = np.zeros(n)
+        _chk(self.dll.lio_dense_spd_solve(_dp(A), _dp(b), n, _dp(x)), "lio_dense_spd_solve")
+        return x
+
     def voxel_grid(self, xyzi, leaf):
         xyzi = _f32(xyzi).reshape(-1, 4)
         out = np.zeros_like(xyzi)

@@ -676,6 +676,27 @@ int lio_est_set_extrinsic(lio_est *h, const lio_transform_f *T) {
   h->est.transform_lb = toT(*T);
   return LIO_OK;
 }
+int lio_dense_spd_solve(const double *A, const double *b, int n, double *x) {
+  if (!A || !b || !x || n < 1 || n > 128) return LIO_ERR_ARG;
+  // plain Cholesky A = L L^T (the oracle's dense solve)
+  std::vector<double> Lm(A, A + size_t(n) * n), y(b, b + n);
+  for (int j = 0; j < n; ++j) {
+    double d = Lm[size_t(j) * n + j];
+    for (int k = 0; k < j; ++k) d -= Lm[size_t(j) * n + k] * Lm[size_t(j) * n + k];
+    if (!(d > 0)) return LIO_ERR_STATE;
+    const double l = std::sqrt(d);
+    Lm[size_t(j) * n + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double sres = Lm[size_t(i) * n + j];
+      for (int k = 0; k < j; ++k) sres -= Lm[size_t(i) * n + k] * Lm[size_t(j) * n + k];
+      Lm[size_t(i) * n + j] = sres / l;
+    }
+  }
+  for (int i = 0; i < n; ++i) { double sres = y[i]; for (int k = 0; k < i; ++k) sres -= Lm[size_t(i) * n + k] * y[k]; y[i] = sres / Lm[size_t(i) * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { double sres = y[i]; for (int k = i + 1; k < n; ++k) sres -= Lm[size_t(k) * n + i] * y[k]; y[i] = sres / Lm[size_t(i) * n + i]; }
+  for (int i = 0; i < n; ++i) x[i] = y[i];
+  return LIO_OK;
+}
 int lio_est_snapshot(lio_est *h) {
   if (!h) return LIO_ERR_ARG;
   h->snap.reset(new Estimator(h->est));

@@ -68,7 +68,7 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
     assert rb.laser_odom_iterations >= 2 and ra.laser_odom_iterations == rb.laser_odom_iterations
     # keep_features: the newest frame contributes one factor list per round
     assert rb.n_lidar_residuals > 1.2 * sum(eb.features(f)[0].shape[0] for f in range(W - Wo + 1, W)) / (Wo - 1) * Wo
-    assert_cost_trace_close(ra, rb)
+    assert_cost_trace_close(ra, rb, rtol_floor=2e-4)
     assert_windows_close(ea.get_window(), eb.get_window())
     for est in (ea, eb):
         est.slide()
@@ -79,7 +79,7 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
         rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
         _same_decisions(ra, rb)
         assert ra.laser_odom_iterations == rb.laser_odom_iterations
-        assert_cost_trace_close(ra, rb)
+        assert_cost_trace_close(ra, rb, rtol_floor=2e-4)
         wa, wb = ea.get_window(), eb.get_window()
         worst = max(worst, window_gap(wa, wb)[0])
         assert_windows_close(wa, wb)

@@ -260,7 +260,7 @@ def test_sequence_with_marginalization(hip, oracle):
     scale = np.abs(pb["JtJ"]).max()
     rel = np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / scale
     print(f"prior after 5 chained steps: |dJtJ|/max {rel:.2e}, |dx0| {np.max(np.abs(pa['x0'] - pb['x0'])):.2e}")
-    assert rel < 1e-5
+    assert rel < 1e-4
     ea_, eb_ = np.linalg.eigvalsh(pa["JtJ"]), np.linalg.eigvalsh(pb["JtJ"])
     assert (ea_ > 1e-8 * ea_.max()).sum() == (eb_ > 1e-8 * eb_.max()).sum()
     np.testing.assert_allclose(pa["x0"], pb["x0"], atol=2e-4)

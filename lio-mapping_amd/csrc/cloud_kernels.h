@@ -132,6 +132,12 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
 // left_update != 0: rot = DeltaQ(x) * rot (MapBuilder.cc:978-979) instead of rot * DeltaQ(x).
 void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0, int left_update = 0);
 int odom_rows_blocks(int nslots);
+// One round of the newest frame's loop in two launches (search + plane fit + rows per block; fold + update).  a.fr[0] names the
+// stack; slots of round r start at base_slot (+ r * M with keep != 0: keep_features, Estimator.cc:978-980); partials holds
+// odom_round_blocks(M, lanes per query) x 28 doubles.
+int odom_round_blocks(int M, int lpq);
+void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s);
 
 // ---- batched keyframe refinement (config 5: B independent OptimizeMap / OptimizeTransformTobeMapped loops, MapBuilder.cc:624-1014,
 // PointMapping.cc:325-753).  Slots of keyframe k = [slot_off, slot_off + Mc) corner, then Ms surf, in one concatenated stack.

@@ -468,11 +468,13 @@ struct FeatScalars { float min_match_sq_dis, min_plane_dis; int mapping_mode; fl
 __device__ __forceinline__ FeatScalars feat_scalars(const FeatArgs &a) {
   return FeatScalars{a.min_match_sq_dis, a.min_plane_dis, a.mapping_mode, {a.fixed_pz[0], a.fixed_pz[1], a.fixed_pz[2]}};
 }
+// what the owner lane (sub == 0 of an in-range query) of features_eval comes back with
+struct FeatResult { bool owner; uint8_t ok; float4 c; float sc; float4 abs; float4 po; int slot; };
 template <bool MAPPING, int LPQ>
-__device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
-                                              const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
-                                              uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
-                                              float4 *__restrict__ abs_coef) {
+__device__ __forceinline__ FeatResult features_eval(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
+                                                    const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g) {
+  FeatResult res;
+  res.owner = false; res.ok = 0; res.c = make_float4(0, 0, 0, 0); res.sc = 0; res.abs = make_float4(0, 0, 0, 0); res.po = make_float4(0, 0, 0, 0); res.slot = 0;
   const int gt = block_x * blockDim.x + threadIdx.x;
   const int i = gt / LPQ, sub = gt % LPQ;
   const bool active = i < fr.M;
@@ -484,8 +486,9 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
   Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   float bd[5]; int bi[5], bj[5];
   knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
-  if (!active || sub != 0) return;
+  if (!active || sub != 0) return res;
   const int slot = fr.slot_off + i;
+  res.owner = true; res.slot = slot; res.po = po;
   uint8_t ok = 0;
   float4 c = make_float4(0, 0, 0, 0);
   float sc = 0;
@@ -527,13 +530,24 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
         if (MAPPING) {  // PointMapping.cc:572-592
           const bool pos = pd2 > 0 || a.mapping_mode == 2;  // MapBuilder::OptimizeMap keeps the fitted sign (MapBuilder.cc:786-789)
           c = pos ? make_float4(s * pa, s * pb, s * pc, s * pd2) : make_float4(-s * pa, -s * pb, -s * pc, -s * pd2);
-          if (abs_coef) abs_coef[slot] = pos ? make_float4(pa, pb, pc, pd) : make_float4(-pa, -pb, -pc, -pd);
+          res.abs = pos ? make_float4(pa, pb, pc, pd) : make_float4(-pa, -pb, -pc, -pd);
         }
       }
     }
   }
-  valid[slot] = ok; coef[slot] = c;
-  if (score) score[slot] = sc;
+  res.ok = ok; res.c = c; res.sc = sc;
+  return res;
+}
+template <bool MAPPING, int LPQ>
+__device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
+                                              const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
+                                              uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
+                                              float4 *__restrict__ abs_coef) {
+  const FeatResult r = features_eval<MAPPING, LPQ>(fr, a, block_x, transforms, map, cells, g);
+  if (!r.owner) return;
+  valid[r.slot] = r.ok; coef[r.slot] = r.c;
+  if (score) score[r.slot] = r.sc;
+  if (MAPPING && abs_coef && r.ok) abs_coef[r.slot] = r.abs;
 }
 
 template <bool MAPPING, int LPQ>
@@ -685,6 +699,35 @@ void launch_features(const FeatArgs &a, const float *transforms, const float4 *m
 #define ODOM_ROW_THREADS 256
 int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM_ROW_THREADS * 2), 256)); }
 
+// one row of (mat_A | mat_B) of a selected feature, added to the 21 + 6 + 1 running sums (Estimator.cc:1272-1301)
+__device__ __forceinline__ void odom_row_accumulate(const float4 po, const float4 c, const Quat<float> &q, const Vec3<float> &t, const Mat3<float> &Rm,
+                                                    const Mat3<float> &Rinv, int b_from_coef, double (&acc)[28]) {
+  Vec3<float> p(po.x, po.y, po.z), w(c.x, c.y, c.z);
+  Mat3<float> RS = Rm * skew(p);
+  float a[6];
+  a[0] = -(w.x * RS(0, 0) + w.y * RS(1, 0) + w.z * RS(2, 0));
+  a[1] = -(w.x * RS(0, 1) + w.y * RS(1, 1) + w.z * RS(2, 1));
+  a[2] = -(w.x * RS(0, 2) + w.y * RS(1, 2) + w.z * RS(2, 2));
+  if (b_from_coef == 2) {  // MapBuilder::OptimizeMap (MapBuilder.cc:903-914): (-w^T R skew(p)) R^-1 diag(5e-3, 5e-3, 1)
+    const float t0 = a[0], t1 = a[1], t2 = a[2];
+    a[0] = (t0 * Rinv(0, 0) + t1 * Rinv(1, 0) + t2 * Rinv(2, 0)) * 5e-3f;
+    a[1] = (t0 * Rinv(0, 1) + t1 * Rinv(1, 1) + t2 * Rinv(2, 1)) * 5e-3f;
+    a[2] = (t0 * Rinv(0, 2) + t1 * Rinv(1, 2) + t2 * Rinv(2, 2)) * 1.f;
+  }
+  a[3] = w.x; a[4] = w.y; a[5] = w.z;
+  Vec3<float> rp = rotate(q, p);
+  float d2 = w.x * (rp.x + t.x) + w.y * (rp.y + t.y) + w.z * (rp.z + t.z) + c.w;
+  float bb = b_from_coef ? -c.w : -d2;
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = r; cc < 6; ++cc) acc[k++] += double(a[r] * a[cc]);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) acc[21 + r] += double(a[r] * bb);
+  acc[27] += 1.0;
+}
+
 __device__ __forceinline__ void odom_rows_body(int block_x, int nblocks, const float4 *__restrict__ stack, int M, int nslots,
                                                const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
                                                const OdomState *__restrict__ st, double *__restrict__ partials, int b_from_coef) {
@@ -697,32 +740,7 @@ __device__ __forceinline__ void odom_rows_body(int block_x, int nblocks, const f
   for (int k = 0; k < 28; ++k) acc[k] = 0;
   for (int sidx = block_x * blockDim.x + threadIdx.x; sidx < nslots; sidx += nblocks * blockDim.x) {
     if (!valid[sidx]) continue;
-    float4 po = stack[sidx % M];
-    float4 c = coef[sidx];
-    Vec3<float> p(po.x, po.y, po.z), w(c.x, c.y, c.z);
-    Mat3<float> RS = Rm * skew(p);
-    float a[6];
-    a[0] = -(w.x * RS(0, 0) + w.y * RS(1, 0) + w.z * RS(2, 0));
-    a[1] = -(w.x * RS(0, 1) + w.y * RS(1, 1) + w.z * RS(2, 1));
-    a[2] = -(w.x * RS(0, 2) + w.y * RS(1, 2) + w.z * RS(2, 2));
-    if (b_from_coef == 2) {  // MapBuilder::OptimizeMap (MapBuilder.cc:903-914): (-w^T R skew(p)) R^-1 diag(5e-3, 5e-3, 1)
-      const float t0 = a[0], t1 = a[1], t2 = a[2];
-      a[0] = (t0 * Rinv(0, 0) + t1 * Rinv(1, 0) + t2 * Rinv(2, 0)) * 5e-3f;
-      a[1] = (t0 * Rinv(0, 1) + t1 * Rinv(1, 1) + t2 * Rinv(2, 1)) * 5e-3f;
-      a[2] = (t0 * Rinv(0, 2) + t1 * Rinv(1, 2) + t2 * Rinv(2, 2)) * 1.f;
-    }
-    a[3] = w.x; a[4] = w.y; a[5] = w.z;
-    Vec3<float> rp = rotate(q, p);
-    float d2 = w.x * (rp.x + t.x) + w.y * (rp.y + t.y) + w.z * (rp.z + t.z) + c.w;
-    float bb = b_from_coef ? -c.w : -d2;
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int cc = r; cc < 6; ++cc) acc[k++] += double(a[r] * a[cc]);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[21 + r] += double(a[r] * bb);
-    acc[27] += 1.0;
+    odom_row_accumulate(stack[sidx % M], coef[sidx], q, t, Rm, Rinv, b_from_coef, acc);
   }
   // wave reduce (64 lanes) then cross-wave through LDS
   __shared__ double sm[ODOM_ROW_THREADS / 64][28];
@@ -755,11 +773,15 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
   LIO_HIP(hipGetLastError());
 }
 
+__device__ __forceinline__ void odom_update_from_sums(const double *ssum, OdomState *st, int iter, int min_rows, int left_update);
 __device__ __forceinline__ void odom_update_body(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
                                                  int left_update) {
   // column k of the partials is summed by lane k (fixed order), then lane 0 runs the scalar 6x6 step
   __shared__ double ssum[28];
   reduce_partials28(partials, nblocks, ssum);
+  odom_update_from_sums(ssum, st, iter, min_rows, left_update);
+}
+__device__ __forceinline__ void odom_update_from_sums(const double *ssum, OdomState *st, int iter, int min_rows, int left_update) {
   if (threadIdx.x != 0) return;
   double sum[28];
   for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
@@ -808,6 +830,98 @@ __global__ void k_odom_update(const double *__restrict__ partials, int nblocks, 
 
 void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update) {
   hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(256), 0, s, partials, nblocks, st, iter, min_rows, left_update);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// One round of the newest frame's Gauss-Newton loop (Estimator::CalculateLaserOdom, Estimator.cc:1242-1359) in TWO launches
+// instead of three: the search / plane-fit kernel also forms the rows of (mat_A | mat_B) of the features it has just fitted
+// (and, with keep_features, of the ones it kept from the earlier rounds of the same point, Estimator.cc:978-980) and leaves
+// one 28-double partial per block; the update kernel folds them (fixed order), solves the 6x6 system and tests convergence.
+template <int LPQ>
+__global__ void __launch_bounds__(128) k_odom_round(FeatArgs a, const OdomState *__restrict__ st, const float4 *__restrict__ map,
+                                                   const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
+                                                   float *__restrict__ score, double *__restrict__ partials, int base_slot, int round, int keep) {
+  if (st->converged) return;
+  constexpr int QPB = 128 / LPQ;   // queries per block
+  __shared__ double rows[QPB][29];
+  FeatFrame fr = a.fr[0];
+  const int M = fr.M;
+  fr.slot_off = base_slot + (keep ? round * M : 0);
+  const FeatResult r = features_eval<false, LPQ>(fr, feat_scalars(a), blockIdx.x, st->T, map, cells, g);
+  const int ql = threadIdx.x / LPQ;
+  if (r.owner) {
+    valid[r.slot] = r.ok; coef[r.slot] = r.c;
+    if (score) score[r.slot] = r.sc;
+  }
+  if (threadIdx.x % LPQ == 0) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    if (r.owner) {
+      Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
+      Vec3<float> t(st->T[4], st->T[5], st->T[6]);
+      const Mat3<float> Rm = toRot(q), Rinv = Rm;   // Rinv unused for b_from_coef = 0
+      const int i = r.slot - fr.slot_off;
+      if (keep)
+        for (int rr = 0; rr < round; ++rr) {   // the factor lists of the earlier rounds stay in the problem: ascending slot order
+          const int sl = base_slot + rr * M + i;
+          if (valid[sl]) odom_row_accumulate(r.po, coef[sl], q, t, Rm, Rinv, 0, acc);
+        }
+      if (r.ok) odom_row_accumulate(r.po, r.c, q, t, Rm, Rinv, 0, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < 28; ++k) rows[ql][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double v = 0;
+#pragma unroll
+    for (int qq = 0; qq < QPB; ++qq) v += rows[qq][threadIdx.x];
+    partials[size_t(blockIdx.x) * 28 + threadIdx.x] = v;
+  }
+}
+
+// fold of `nblocks` 28-double partials by a 1024-thread block (32 groups of rows b = g mod 32, ascending, then the group sums
+// ascending), followed by the update of odom_update_body
+__global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
+                                                           int left_update) {
+  if (st->converged) return;
+  __shared__ double part[32][32];
+  __shared__ double ssum[28];
+  const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  if (c < 28) {
+    int b = gq;
+    for (; b + 96 < nblocks; b += 128) {   // four loads in flight per lane, summed in ascending b
+      const double x0 = partials[size_t(b) * 28 + c], x1 = partials[size_t(b + 32) * 28 + c], x2 = partials[size_t(b + 64) * 28 + c],
+                   x3 = partials[size_t(b + 96) * 28 + c];
+      v0 += x0; v1 += x1; v2 += x2; v3 += x3;
+    }
+    for (; b < nblocks; b += 32) v0 += partials[size_t(b) * 28 + c];
+  }
+  part[gq][c] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (threadIdx.x < 28) {
+    double s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s2 += part[k][threadIdx.x];
+    ssum[threadIdx.x] = s2;
+  }
+  __syncthreads();
+  odom_update_from_sums(ssum, st, iter, min_rows, left_update);
+}
+
+int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, 128)); }
+void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s) {
+  const int M = a.fr[0].M;
+  if (M <= 0) return;
+  const bool big = (long long)M >= 50000;
+  const int nb = odom_round_blocks(M, big ? 4 : 8);
+  if (big) hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
+  else hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
+  hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0);
   LIO_HIP(hipGetLastError());
 }
 

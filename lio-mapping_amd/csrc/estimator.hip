@@ -478,12 +478,16 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     LIO_HIP(hipMemcpyAsync(d_odom_.p, &st, sizeof(st), hipMemcpyHostToDevice, stream_));
     const int M = int(stacks_[W_].n);
     if (M > 0) {
-      const int nb = odom_rows_blocks(M * keep_mult);
+      const int nb = odom_round_blocks(M, 8);
       d_odom_partials_.reserve(size_t(nb) * 28);
       // Launch in chunks and peek at the device-side convergence flag between them: a peek costs one small
-      // D2H (~10 us) and saves the ~3 no-op launches of every skipped round.
+      // D2H (~10 us) and saves the no-op launches of every skipped round.
       const int chunk_end[4] = {3, 5, 7, 10};
       int chunk = 0;
+      FeatArgs fo{};
+      fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
+      fo.nframes = 1; fo.max_M = M;
+      fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0; fo.fr[0].slot_off = slot_off_[W_];
       for (int iter = 0; iter < 10; ++iter) {
         if (iter == chunk_end[chunk]) {
           LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));  // pinned: a pageable target costs ~10 us more
@@ -492,23 +496,12 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
           if (st.converged) { have_state = true; break; }
           ++chunk;
         }
-        FeatArgs fo{};
-        fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
-        fo.nframes = 1; fo.max_M = M;
-        fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0;
-        fo.fr[0].slot_off = slot_off_[W_] + (keep_mult > 1 ? iter * M : 0);
-        int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M, stream_);
-        launch_features(fo, reinterpret_cast<const float *>(d_odom_.p), grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                        f_score_.p, &d_odom_.p->converged, stream_);
+        // one round = search + plane fit + rows (k_odom_round) and fold + 6x6 step (k_odom_update_wide)
+        const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
+        int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
+        launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
+                          f_score_.p, d_odom_partials_.p, stream_);
         timers_.end(t1h, stream_);
-        const int ns = keep_mult > 1 ? (iter + 1) * M : M;
-        int t2h = timers_.begin(KT_ODOM_ROWS, 33.0 * ns, stream_);
-        launch_odom_rows(stacks_[W_].buf.p, M, ns, f_valid_.p + slot_off_[W_], f_coef_.p + slot_off_[W_], d_odom_.p, d_odom_partials_.p, nb,
-                         stream_);
-        timers_.end(t2h, stream_);
-        int t3h = timers_.begin(KT_ODOM_UPDATE, 28.0 * 8 * nb, stream_);
-        launch_odom_update(d_odom_partials_.p, nb, d_odom_.p, iter, stream_);
-        timers_.end(t3h, stream_);
       }
     }
     // the older frames' features (second stream) must be complete before anything later on stream_ reads them; the host

@@ -304,21 +304,28 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const 
   lidar_moments_body(frames[blockIdx.y], valid, coef, partials, nullptr, nullptr, gridDim.x);
 }
 
-__global__ void __launch_bounds__(320) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
-  const double *src = partials + size_t(blockIdx.x) * bpf * LIO_MOMENT_OUT;
-  const int k = threadIdx.x;
-  if (k >= 258) return;
-  // fixed order (deterministic); 4 independent chains keep several loads in flight
-  double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-  int b = 0;
-  for (; b + 4 <= bpf; b += 4) {
-    v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
-    v1 += src[size_t(b + 1) * LIO_MOMENT_OUT + k];
-    v2 += src[size_t(b + 2) * LIO_MOMENT_OUT + k];
-    v3 += src[size_t(b + 3) * LIO_MOMENT_OUT + k];
+// Fold of the per-block partials: out[f][k] = sum_b partials[f][b][k].  Four lanes per value, lane q walks the blocks b = q, q + 4, ...
+// with all of its loads in flight (the remainder beyond the last multiple of four goes to lane 0), then (v0 + v1) + (v2 + v3)
+// by two xor-shuffles: the same additions in the same order as one lane with four interleaved chains, at a quarter of the
+// dependent-load depth (4.9 -> 2.x us at 39 blocks per frame).  Grid (frames, 3), 384 threads: 96 values per block.
+#define REDUCE_THREADS 384
+__global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
+  const int k = blockIdx.y * (REDUCE_THREADS / 4) + (threadIdx.x >> 2), q = threadIdx.x & 3;
+  const bool in = k < 258;
+  const double *src = partials + size_t(blockIdx.x) * bpf * LIO_MOMENT_OUT + (in ? k : 0);
+  const int b4 = bpf & ~3;
+  double v = 0;
+  int b = q;
+  for (; b + 12 < b4; b += 16) {   // four loads in flight per lane
+    const double x0 = src[size_t(b) * LIO_MOMENT_OUT], x1 = src[size_t(b + 4) * LIO_MOMENT_OUT], x2 = src[size_t(b + 8) * LIO_MOMENT_OUT],
+                 x3 = src[size_t(b + 12) * LIO_MOMENT_OUT];
+    v += x0; v += x1; v += x2; v += x3;
   }
-  for (; b < bpf; ++b) v0 += src[size_t(b) * LIO_MOMENT_OUT + k];
-  out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = (v0 + v1) + (v2 + v3);
+  for (; b < b4; b += 4) v += src[size_t(b) * LIO_MOMENT_OUT];
+  if (q == 0) for (int r = b4; r < bpf; ++r) v += src[size_t(r) * LIO_MOMENT_OUT];
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  if (in && q == 0) out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = v;
 }
 
 int moment_blocks_per_frame_batched(int max_slots, int nframes) {
@@ -335,7 +342,7 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
     hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
-  hipLaunchKernelGGL(k_moment_reduce, dim3(nframes), dim3(320), 0, s, partials, blocks_per_frame, out);
+  hipLaunchKernelGGL(k_moment_reduce, dim3(nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }
 
@@ -348,7 +355,7 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
     hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
-  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes), dim3(320), 0, s, partials, a.blocks_per_frame, out);
+  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, a.blocks_per_frame, out);
   LIO_HIP(hipGetLastError());
 }
 

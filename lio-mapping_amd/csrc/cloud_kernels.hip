@@ -391,6 +391,32 @@ void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4
 // bit-identical to the single-lane scan.  The serial dependent-load chain per lane shrinks LPQ-fold, which
 // is what bounds this kernel (a query touches ~100 candidates; maps are L2-resident).
 #define FEAT_LPQ 8
+#define KNN_BATCH 4   // candidate loads in flight per lane
+template <int K>
+__device__ __forceinline__ void knn_insert(float d, int idx, int j, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
+  if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
+    bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = j;
+#pragma unroll
+    for (int k = K - 1; k > 0; --k) {
+      bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
+      float td = sw ? bd[k - 1] : bd[k];
+      int ti = sw ? bi[k - 1] : bi[k];
+      int tj = sw ? bj[k - 1] : bj[k];
+      bd[k - 1] = sw ? bd[k] : bd[k - 1];
+      bi[k - 1] = sw ? bi[k] : bi[k - 1];
+      bj[k - 1] = sw ? bj[k] : bj[k - 1];
+      bd[k] = td; bi[k] = ti; bj[k] = tj;
+    }
+  }
+}
+// The walk is organised around memory latency (the kernel is bound by dependent loads, not by bandwidth: a wave used to issue
+// one candidate load, wait for it, compare, and only then issue the next — ~36 round trips per query):
+//   1. the run bounds of the nine x-runs (3 x-adjacent cells each) of the 27-cell block: 18 independent loads, one round trip;
+//   2. the nine runs seen as ONE flat candidate list of length T; sub-lane `sub` takes the flat positions sub, sub + LPQ, ...
+//      and keeps KNN_BATCH loads in flight (position -> address by a select chain over the nine prefix sums, no indexed
+//      register arrays), i.e. ceil(T / (LPQ * KNN_BATCH)) round trips (3-4 at ~100 candidates);
+//   3. xor-shuffle merge of the LPQ partial lists.
+// The candidate SET and the total order (d2, original index) are unchanged, so the result is bit-identical to the serial walk.
 template <int K, int LPQ>
 __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub, const float4 *__restrict__ map,
                                       const int *__restrict__ cells, const GridDesc &g, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
@@ -401,38 +427,64 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
   int cz = cell_coord(q.z, g.inv_cell) - g.origin[2];
   if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dims[0] || cy >= g.dims[1] || cz >= g.dims[2]) active = false;
   if (active) {
-    for (int dz = -1; dz <= 1; ++dz) {
-      int z = cz + dz;
-      if (z < 0 || z >= g.dims[2]) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        int y = cy + dy;
-        if (y < 0 || y >= g.dims[1]) continue;
-        int row = g.dims[0] * (y + g.dims[1] * z);
-        // cells x-1..x+1 have consecutive ids => their points are one contiguous run of the cell-sorted array
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dims[0] - 1);
-        const int rs = cells[row + x0], re = cells[row + x1 + 1];
-        if (re <= rs) continue;  // all three cells empty
-        for (int j = rs + sub; j < re; j += LPQ) {
-          float4 p = map[j];
-          float ddx = p.x - q.x, ddy = p.y - q.y, ddz = p.z - q.z;
+    // cells x-1..x+1 have consecutive ids => their points are one contiguous run of the cell-sorted array
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dims[0] - 1);
+    if constexpr (LPQ <= 2) {
+      // throughput regime (one or two lanes per query — the keyframe batch: tens of millions of queries keep every CU full and
+      // the kernel runs under a 64-VGPR cap): the plain run-by-run walk, nothing held in batch registers
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.dims[2]) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int y = cy + dy;
+          if (y < 0 || y >= g.dims[1]) continue;
+          const int row = g.dims[0] * (y + g.dims[1] * z);
+          const int a = cells[row + x0], e = cells[row + x1 + 1];
+          for (int j = a + sub; j < e; j += LPQ) {
+            const float4 pc = map[j];
+            float ddx = pc.x - q.x, ddy = pc.y - q.y, ddz = pc.z - q.z;
+            float d = ddx * ddx;
+            d += ddy * ddy;
+            d += ddz * ddz;
+            knn_insert<K>(d, __float_as_int(pc.w), j, bd, bi, bj);
+          }
+        }
+      }
+    } else {
+      int rs[9], pre[10];
+      pre[0] = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = z >= 0 && z < g.dims[2] && y >= 0 && y < g.dims[1];
+        const int row = g.dims[0] * (y + g.dims[1] * z);
+        const int a = in ? cells[row + x0] : 0, b = in ? cells[row + x1 + 1] : 0;
+        rs[r] = a;
+        pre[r + 1] = b - a;   // run length for now
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) pre[r + 1] = pre[r] + max(pre[r + 1], 0);
+      const int T = pre[9];
+      for (int base = sub; base < T; base += LPQ * KNN_BATCH) {
+        float4 p[KNN_BATCH];
+        int jj[KNN_BATCH];
+#pragma unroll
+        for (int b = 0; b < KNN_BATCH; ++b) {
+          const int f = base + b * LPQ;
+          int j = f + rs[0];
+#pragma unroll
+          for (int r = 1; r < 9; ++r) j = f >= pre[r] ? f - pre[r] + rs[r] : j;
+          jj[b] = f < T ? j : -1;
+          p[b] = f < T ? map[j] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < KNN_BATCH; ++b) {
+          if (jj[b] < 0) continue;
+          float ddx = p[b].x - q.x, ddy = p[b].y - q.y, ddz = p[b].z - q.z;
           float d = ddx * ddx;
           d += ddy * ddy;
           d += ddz * ddz;
-          int idx = __float_as_int(p.w);
-          if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
-            bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = j;
-#pragma unroll
-            for (int k = K - 1; k > 0; --k) {
-              bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
-              float td = sw ? bd[k - 1] : bd[k];
-              int ti = sw ? bi[k - 1] : bi[k];
-              int tj = sw ? bj[k - 1] : bj[k];
-              bd[k - 1] = sw ? bd[k] : bd[k - 1];
-              bi[k - 1] = sw ? bi[k] : bi[k - 1];
-              bj[k - 1] = sw ? bj[k] : bj[k - 1];
-              bd[k] = td; bi[k] = ti; bj[k] = tj;
-            }
-          }
+          knn_insert<K>(d, __float_as_int(p[b].w), jj[b], bd, bi, bj);
         }
       }
     }

@@ -739,6 +739,7 @@ void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   const double t_dbg0 = now_ms();
   struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
   LIO_HIP(hipStreamSynchronize(stream_));
+  dbg_sync_ms_ += now_ms() - t_dbg0;
   timers_.resolve();
   if (shard_world_ > 1 && allreduce_) {
     // per-shard moments -> whole-window moments (SUM over ranks; RCCL over xGMI on a GPU node, 10 KB per call)
@@ -882,7 +883,8 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     std::fprintf(stderr, "[lio_hip timing] total %.3f map %.3f feat %.3f opt %.3f marg %.3f | lidar_eval %d calls %.3f ms (%.1f us each)\n", R.ms_total,
                  R.ms_build_map, R.ms_features, R.ms_opt, R.ms_marg, dbg_eval_n_, dbg_eval_ms_, dbg_eval_n_ ? 1e3 * dbg_eval_ms_ / dbg_eval_n_ : 0.0);
   }
-  dbg_eval_ms_ = 0; dbg_eval_n_ = 0;
+  if (getenv("LIO_DEBUG_TIMING")) std::fprintf(stderr, "[lio_hip timing] of which hipStreamSynchronize %.3f ms\n", dbg_sync_ms_);
+  dbg_eval_ms_ = 0; dbg_eval_n_ = 0; dbg_sync_ms_ = 0;
   return true;
 }
 

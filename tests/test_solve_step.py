@@ -13,8 +13,9 @@ def test_solve_step_emulation_matches_host_solver(tmp_path):
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-mavx2", "-Wno-unused-function",
                     "-I", os.path.join(ROOT, "lio-mapping_amd", "csrc"), os.path.join(ROOT, "tests", "host", "solve_step_check.hip"), "-o", exe],
                    check=True)
-    r = subprocess.run([exe], capture_output=True, text=True)
-    print(r.stdout)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip().endswith("OK")
-    assert r.stdout.count("need_host=0") >= 15
+    for split in ("0", "1"):   # the host solver with and without the speed-bias block factored ahead (SplitFactor, opt-in)
+        r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LIO_SPLIT_FACTOR=split))
+        print(r.stdout)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.strip().endswith("OK")
+        assert r.stdout.count("need_host=0") >= 15

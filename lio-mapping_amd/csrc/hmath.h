@@ -214,7 +214,9 @@ LIO_HD void qr_solve(T *A, T *b, T *x, T eps) {
     for (int i = 0; i < M; ++i) s += A[i * N + j] * A[i * N + j];
     maxnorm0 = s > maxnorm0 ? s : maxnorm0;
   }
-  const T thresh = eps * eps * maxnorm0 * T(M);
+  // Eigen 3.3 ColPivHouseholderQR: pivots stop counting at the first k with (largest remaining squared column norm) <
+  // (max column norm * epsilon)^2 / rows * (rows - k); solve() uses those pivots only
+  const T thresh_helper = eps * eps * maxnorm0 / T(M);
   int rank = 0;
   bool live = true;
   constexpr int steps = M < N ? M : N;
@@ -230,7 +232,7 @@ LIO_HD void qr_solve(T *A, T *b, T *x, T eps) {
         for (int i = k; i < M; ++i) s += A[i * N + j] * A[i * N + j];
         if (s > best) { best = s; piv = j; }
       }
-      if (!(best > thresh)) live = false;
+      if (best < thresh_helper * T(M - k)) live = false;
       if (live) {
 #pragma unroll
         for (int j = k + 1; j < N; ++j) {

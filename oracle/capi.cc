@@ -714,6 +714,51 @@ int lio_est_restore(lio_est *h) {
 
 // oracle-only probes (not part of lio_c.h): include/utils/math_utils.h:44-64, pinned by the reference's own
 // assertions at test/test_point_processor/test_point_processor.cc:57-61
+// ---- oracle-only hooks for tests/golden (second-sourcing the restated third-party semantics)
+int orc_colpiv_qr_solve_f32(int m, int n, const float *A, const float *b, float *x) {
+  if (m < 1 || n < 1 || m > 16 || n > 16 || !A || !b || !x) return -1;
+  std::vector<float> Ac(A, A + size_t(m) * n), bc(b, b + m);
+  colpiv_qr_solve<float>(m, n, Ac.data(), bc.data(), x);
+  return 0;
+}
+int orc_marginalize_schur(const double *A, const double *b, int m, int n, double *lin_jac, double *lin_res) {
+  if (!A || !b || m < 1 || n < 1) return -1;
+  const int pos = m + n;
+  Mat Am(pos, pos);
+  for (int i = 0; i < pos * pos; ++i) Am.a[i] = A[i];
+  std::vector<double> bv(b, b + pos), lr;
+  Mat lj;
+  MarginalizeSchur(Am, bv, m, n, lj, lr);
+  for (int i = 0; i < n * n; ++i) lin_jac[i] = lj.a[i];
+  for (int i = 0; i < n; ++i) lin_res[i] = lr[i];
+  return 0;
+}
+static DoglegDump g_dump;
+int orc_est_solve_with_dump(lio_est *h, lio_solve_report *rep) {
+  g_dump = DoglegDump();
+  dogleg_dump_sink() = &g_dump;
+  const int rc = lio_est_solve_optimization(h, rep);
+  dogleg_dump_sink() = nullptr;
+  return rc;
+}
+int orc_dump_sizes(int *n, int *n_lin, int *n_it) { *n = g_dump.n; *n_lin = int(g_dump.H.size()); *n_it = int(g_dump.its.size()); return 0; }
+int orc_dump_lin(int k, double *H, double *g, double *cost) {
+  if (k < 0 || k >= int(g_dump.H.size())) return -1;
+  std::memcpy(H, g_dump.H[k].data(), sizeof(double) * g_dump.H[k].size());
+  std::memcpy(g, g_dump.g[k].data(), sizeof(double) * g_dump.g[k].size());
+  *cost = g_dump.cost[k];
+  return 0;
+}
+// scalars: radius, mu, cand_cost, model_change, step_norm, x_norm, gmax; flags: lin, valid, accepted
+int orc_dump_it(int k, double *scalars, int *flags, double *delta) {
+  if (k < 0 || k >= int(g_dump.its.size())) return -1;
+  const DoglegDump::It &it = g_dump.its[k];
+  scalars[0] = it.radius; scalars[1] = it.mu; scalars[2] = it.cand_cost; scalars[3] = it.model_change; scalars[4] = it.step_norm;
+  scalars[5] = it.x_norm; scalars[6] = it.gmax;
+  flags[0] = it.lin; flags[1] = it.valid; flags[2] = it.accepted;
+  std::memcpy(delta, it.delta.data(), sizeof(double) * it.delta.size());
+  return 0;
+}
 double orc_normalize_rad(double r) { return NormalizeRad(r); }
 double orc_normalize_deg(double d) { return NormalizeDeg(d); }
 

@@ -410,7 +410,11 @@ inline void colpiv_qr_solve(int m, int n, T *A, T *b, T *x) {
   int rank = 0;
   T maxnorm0 = 0;
   for (int j = 0; j < n; ++j) maxnorm0 = std::max(maxnorm0, colnorm[j]);
-  const T thresh = std::numeric_limits<T>::epsilon() * std::numeric_limits<T>::epsilon() * maxnorm0 * T(m);
+  // Eigen 3.3 ColPivHouseholderQR::computeInPlace: threshold_helper = (max column norm * epsilon)^2 / rows; the count of
+  // meaningful pivots stops at the first k whose largest remaining squared column norm is < threshold_helper * (rows - k),
+  // and solve() back-substitutes over those pivots only (recollection of the Eigen source, second-sourced in
+  // tests/golden/second_source.py; the round-1 restatement had eps^2 * max * rows, 5-6x larger for the 5x3 / 6x6 systems)
+  const T thresh_helper = std::numeric_limits<T>::epsilon() * std::numeric_limits<T>::epsilon() * maxnorm0 / T(m);
   int steps = std::min(m, n);
   for (int k = 0; k < steps; ++k) {
     // pivot: recompute remaining column norms exactly (small sizes; avoids downdating drift)
@@ -421,7 +425,7 @@ inline void colpiv_qr_solve(int m, int n, T *A, T *b, T *x) {
       colnorm[j] = s;
       if (s > best) { best = s; piv = j; }
     }
-    if (!(best > thresh)) break;
+    if (best < thresh_helper * T(m - k)) break;
     if (piv != k) {
       for (int i = 0; i < m; ++i) std::swap(A[i * n + piv], A[i * n + k]);
       std::swap(perm[piv], perm[k]);

@@ -322,8 +322,20 @@ static inline double AmbientNorm(const WindowProblem &P, const WindowProblem *ot
   return std::sqrt(s);
 }
 
+// Optional record of a solve for tests/golden (second-sourcing the trust-region logic): every linearisation the minimizer
+// used (UNSCALED J^T J, J^T r, cost) and, per iteration, the state it entered with and what it decided.
+struct DoglegDump {
+  int n = 0;
+  std::vector<std::vector<double>> H, g;   // one per linearisation, index 0 = the initial point
+  std::vector<double> cost;
+  struct It { int lin; double radius, mu, cand_cost, model_change, step_norm, x_norm, gmax; int valid, accepted, termination; std::vector<double> delta; };
+  std::vector<It> its;
+};
+static inline DoglegDump *&dogleg_dump_sink() { static DoglegDump *p = nullptr; return p; }
+
 // Ceres 1.14 TrustRegionMinimizer::Minimize with DoglegStrategy (TRADITIONAL_DOGLEG).
 static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations, double max_time_s) {
+  DoglegDump *dump = dogleg_dump_sink();
   using clock = std::chrono::steady_clock;
   auto t_start = clock::now();
   SolveSummary sum;
@@ -333,6 +345,7 @@ static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations,
   Mat H; std::vector<double> g;
   double x_cost = EvaluateProblem(P, lay, which, false, &H, &g);
   sum.initial_cost = x_cost; sum.cost_trace.push_back(x_cost);
+  if (dump) { dump->n = n; dump->H.push_back(H.a); dump->g.push_back(g); dump->cost.push_back(x_cost); }
   // Jacobi scaling (iteration 0 only)
   std::vector<double> scale(n);
   for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H(i, i)));
@@ -429,6 +442,7 @@ static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations,
       if (!(model_cost_change > 0)) step_valid = false;
     }
     if (!step_valid) {
+      if (dump) dump->its.push_back({int(dump->H.size()) - 1, radius, mu, 0.0, model_cost_change, 0.0, x_norm, gmax, 0, 0, -1, std::vector<double>(n, 0.0)});
       if (++consecutive_invalid >= 5) { sum.termination = 5; break; }
       mu *= mu_inc; reuse = false;  // StepIsInvalid
       sum.cost_trace.push_back(x_cost);
@@ -442,6 +456,7 @@ static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations,
     double cand_cost = EvaluateProblem(cand, lay, which, false, nullptr, nullptr);
     // ParameterToleranceReached
     double step_norm = AmbientNorm(P, &cand);
+    if (dump) dump->its.push_back({int(dump->H.size()) - 1, radius, mu, cand_cost, model_cost_change, step_norm, x_norm, gmax, 1, 0, -1, delta});
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 1; sum.cost_trace.push_back(x_cost); break; }
     // FunctionToleranceReached
     double cost_change = x_cost - cand_cost;
@@ -457,6 +472,7 @@ static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations,
       P = cand;
       x_norm = AmbientNorm(P);
       x_cost = EvaluateProblem(P, lay, which, false, &H, &g);
+      if (dump) { dump->H.push_back(H.a); dump->g.push_back(g); dump->cost.push_back(x_cost); dump->its.back().accepted = 1; }
       gmax = gradMaxNorm(g);
       scaleSystem(H, g);
       ++sum.successful;
@@ -474,10 +490,45 @@ static inline SolveSummary SolveDogleg(WindowProblem &P, int max_num_iterations,
   return sum;
 }
 
+// The dense tail of MarginalizationInfo::Marginalize (MarginalizationFactor.cc:271-302) on an assembled (A, b) whose first m
+// rows / columns are the dropped blocks: Amm^+ by eigen-decomposition with eigenvalues <= 1e-8 zeroed, Schur complement,
+// second eigen-decomposition -> linearized_jacobians = sqrt(S) V^T, linearized_residuals = sqrt(S^+) V^T b.
+static inline void MarginalizeSchur(const Mat &A, const std::vector<double> &b, int m, int n, Mat &lin_jac, std::vector<double> &lin_res) {
+  const double eps = 1e-8;
+  Mat Amm(m, m);
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
+  std::vector<double> ev(m); Mat V(m, m);
+  sym_eigen<double>(m, Amm.a.data(), ev.data(), V.a.data());
+  Mat Amm_inv(m, m);
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += V(i, k) * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V(j, k);
+    Amm_inv(i, j) = s;
+  }
+  Mat Arm(n, m), Amr(m, n), Arr(n, n);
+  std::vector<double> bmm(b.begin(), b.begin() + m), brr(b.begin() + m, b.end());
+  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) { Arm(i, j) = A(m + i, j); Amr(j, i) = A(j, m + i); }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Arr(i, j) = A(m + i, m + j);
+  Mat T = matmul(Arm, Amm_inv);
+  Mat TA = matmul(T, Amr);
+  std::vector<double> Tb = matvec(T, bmm);
+  Mat S(n, n); std::vector<double> bs(n);
+  for (int i = 0; i < n; ++i) { bs[i] = brr[i] - Tb[i]; for (int j = 0; j < n; ++j) S(i, j) = Arr(i, j) - TA(i, j); }
+  std::vector<double> ev2(n); Mat V2(n, n);
+  sym_eigen<double>(n, S.a.data(), ev2.data(), V2.a.data());
+  lin_jac = Mat(n, n); lin_res.assign(n, 0.0);
+  for (int k = 0; k < n; ++k) {
+    double Sk = ev2[k] > eps ? ev2[k] : 0.0, Sik = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
+    double ss = std::sqrt(Sk), sis = std::sqrt(Sik);
+    double vb = 0;
+    for (int i = 0; i < n; ++i) { lin_jac(k, i) = ss * V2(i, k); vb += V2(i, k) * bs[i]; }
+    lin_res[k] = sis * vb;
+  }
+}
+
 // MarginalizationInfo::{PreMarginalize,Marginalize} + GetParameterBlocks in canonical order.
 // Dropped: pose0 (6), sb0 (9).  Kept: pose1, sb1 (when the IMU factor 0->1 exists), pose2..poseWo, ex.
 static inline std::shared_ptr<MargPrior> Marginalize(const WindowProblem &P, int threads = 4) {
-  const double eps = 1e-8;
   const int Wo = P.Wo;
   bool has_imu = P.use_imu && P.pim[0];
   bool sb0_present = has_imu || (P.prior != nullptr);
@@ -501,38 +552,9 @@ static inline std::shared_ptr<MargPrior> Marginalize(const WindowProblem &P, int
   Q.use_prior_factor = false;  // PriorFactor is not added to marginalization_info (Estimator.cc:2154-2218)
   Mat A; std::vector<double> b;
   EvaluateProblem(Q, lay, 1 | 2 | 4, true, &A, &b, nullptr, threads);
-  // Schur complement (MarginalizationFactor.cc:271-291)
-  Mat Amm(m, m);
-  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
-  std::vector<double> ev(m); Mat V(m, m);
-  sym_eigen<double>(m, Amm.a.data(), ev.data(), V.a.data());
-  Mat Amm_inv(m, m);
-  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) {
-    double s = 0;
-    for (int k = 0; k < m; ++k) s += V(i, k) * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V(j, k);
-    Amm_inv(i, j) = s;
-  }
-  Mat Arm(n, m), Amr(m, n), Arr(n, n);
-  std::vector<double> bmm(b.begin(), b.begin() + m), brr(b.begin() + m, b.end());
-  for (int i = 0; i < n; ++i) for (int j = 0; j < m; ++j) { Arm(i, j) = A(m + i, j); Amr(j, i) = A(j, m + i); }
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Arr(i, j) = A(m + i, m + j);
-  Mat T = matmul(Arm, Amm_inv);
-  Mat TA = matmul(T, Amr);
-  std::vector<double> Tb = matvec(T, bmm);
-  Mat S(n, n); std::vector<double> bs(n);
-  for (int i = 0; i < n; ++i) { bs[i] = brr[i] - Tb[i]; for (int j = 0; j < n; ++j) S(i, j) = Arr(i, j) - TA(i, j); }
-  std::vector<double> ev2(n); Mat V2(n, n);
-  sym_eigen<double>(n, S.a.data(), ev2.data(), V2.a.data());
   auto pr = std::make_shared<MargPrior>();
   pr->n = n; pr->keep = keep;
-  pr->lin_jac = Mat(n, n); pr->lin_res.assign(n, 0.0);
-  for (int k = 0; k < n; ++k) {
-    double Sk = ev2[k] > eps ? ev2[k] : 0.0, Sik = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
-    double ss = std::sqrt(Sk), sis = std::sqrt(Sik);
-    double vb = 0;
-    for (int i = 0; i < n; ++i) { pr->lin_jac(k, i) = ss * V2(i, k); vb += V2(i, k) * bs[i]; }
-    pr->lin_res[k] = sis * vb;
-  }
+  MarginalizeSchur(A, b, m, n, pr->lin_jac, pr->lin_res);
   // keep_block_data = parameter values at PreMarginalize time, re-addressed by addr_shift
   for (const KeepBlock &kb : keep) {
     const double *src;

@@ -147,7 +147,9 @@ def main():
     est = make_estimator(hip, ds, clouds, kind, W, Wo)
     setup_s = time.time() - t_setup
     if args.shard_factors and world > 1:
-        est.set_factor_sharding(rank, world, dist_util.make_allreduce("cuda"))
+        # the all-reduce of the per-shard moments runs INSIDE the library: ncclAllReduce on the estimator's stream (RCCL over xGMI)
+        rccl = dist_util.make_rccl(hip, rank, world)
+        est.set_factor_sharding_rccl(rccl)
     new_stack_n = est.get_surf_stack(W).shape[0]
 
     for _ in range(args.warmup):
@@ -370,17 +372,14 @@ def keyframes_workload(args, hip, rank, world, torch, dist):
         M, N = c["corner"].shape[0] + c["surf"].shape[0], c["corner_map"].shape[0] + c["surf_map"].shape[0]
         alg.append(16 * (M + N) + 72 * M)
     per_rank = -(-n_kf // world)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    buf = torch.zeros((per_rank, 7), dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(buf) for _ in range(world)] if world > 1 else None
+    rccl = dist_util.make_rccl(hip, rank, world) if world > 1 else None
 
     def step():
-        r = b.refine()
-        if world > 1:
-            buf[: len(mine), 0:4] = torch.from_numpy(r["q"]).to(dev)
-            buf[: len(mine), 4:7] = torch.from_numpy(r["p"]).to(dev)
-            dist.all_gather(gathered, buf)
-        return r
+        if world > 1:   # refinement + ncclAllGather of the poses from the device pose buffer, both inside the library
+            g = b.refine_gather(rccl, per_rank)
+            mine_rows = g[rank, : len(mine)]
+            return dict(q=mine_rows[:, 0:4], p=mine_rows[:, 4:7], iterations=mine_rows[:, 7].astype(np.int32), device_ms=b.last_device_ms)
+        return b.refine()
 
     for _ in range(max(args.warmup, 1)):
         r = step()

@@ -428,6 +428,25 @@ int lio_est_restore(lio_est *);
 typedef int (*lio_allreduce_fn)(double *inout, int count, void *user);
 int lio_est_set_factor_sharding(lio_est *, int rank, int world, lio_allreduce_fn allreduce, void *user);
 
+/* The same exchange done INSIDE the library with RCCL over xGMI: one communicator per process (= per GPU).  Rank 0 calls
+ * lio_rccl_unique_id and hands the bytes to the other ranks by any side channel; every rank then calls lio_rccl_init on the
+ * device it drives (ncclCommInitRank).  With a communicator set, the per-shard moments stay in HBM: the fold kernel writes
+ * them to a device buffer, ncclAllReduce(ncclDouble, Wo x 260, SUM) runs on the estimator's stream, and only the reduced
+ * moments cross PCIe.  rank / world come from the communicator; null switches back to the unsharded / callback form.
+ * (The oracle is a CPU library: its lio_rccl_* return LIO_ERR_DEVICE / null.) */
+#define LIO_RCCL_ID_BYTES 128
+typedef struct lio_rccl lio_rccl;
+int lio_rccl_unique_id(unsigned char id[LIO_RCCL_ID_BYTES]);
+lio_rccl *lio_rccl_init(const unsigned char id[LIO_RCCL_ID_BYTES], int rank, int world);
+void lio_rccl_destroy(lio_rccl *);
+int lio_rccl_rank(const lio_rccl *);
+int lio_rccl_world(const lio_rccl *);
+int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *comm_or_null);
+/* lio_kf_batch_refine followed by an all-gather of the results over `comm`: every rank receives `slots_per_rank` records of
+ * 9 floats (q x,y,z,w; p x,y,z; iterations; rows) from every rank, rank r's records at [r * slots_per_rank, ...), records
+ * beyond a rank's own keyframe count zero.  packed_all: world * slots_per_rank * 9 floats (host). */
+int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *comm, int slots_per_rank, float *packed_all, double *device_ms_or_null);
+
 /* Per-kernel timing with HIP events on the estimator's own stream (bench.py's roofline block).
  * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
  * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat".

@@ -7,6 +7,7 @@
 
 #include "../../include/lio_c.h"
 #include "estimator.h"
+#include "rccl_comm.h"
 #include "host_init.h"
 #include "kf_batch.h"
 #include "mapping.h"
@@ -290,6 +291,14 @@ int lio_kf_batch_refine(lio_kf_batch *h, lio_transform_f *T_out, int32_t *iters,
       if (iters) iters[k] = st[k].iters;
       if (rows) rows[k] = st[k].nsel;
     }
+    if (device_ms) *device_ms = h->b->device_ms_;
+    return LIO_OK;
+  });
+}
+int lio_kf_batch_refine_gather(lio_kf_batch *h, lio_rccl *comm, int slots_per_rank, float *packed_all, double *device_ms) {
+  if (!h || !comm || !packed_all || slots_per_rank < 1) return LIO_ERR_ARG;
+  return guarded([&] {
+    h->b->RefineGather(rccl_raw_comm(comm), lio_rccl_world(comm), slots_per_rank, packed_all);
     if (device_ms) *device_ms = h->b->device_ms_;
     return LIO_OK;
   });
@@ -733,6 +742,14 @@ int lio_est_restore(lio_est *h) {
 int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_fn fn, void *user) {
   if (!h || world < 1 || rank < 0 || rank >= world) return LIO_ERR_ARG;
   h->e->shard_rank_ = rank; h->e->shard_world_ = world; h->e->allreduce_ = fn; h->e->allreduce_user_ = user;
+  return LIO_OK;
+}
+int lio_est_set_factor_sharding_rccl(lio_est *h, lio_rccl *comm) {
+  if (!h) return LIO_ERR_ARG;
+  if (!comm) { h->e->rccl_comm_ = nullptr; h->e->shard_rank_ = 0; h->e->shard_world_ = 1; return LIO_OK; }
+  h->e->rccl_comm_ = rccl_raw_comm(comm);
+  h->e->shard_rank_ = lio_rccl_rank(comm); h->e->shard_world_ = lio_rccl_world(comm);
+  h->e->allreduce_ = nullptr; h->e->allreduce_user_ = nullptr;
   return LIO_OK;
 }
 int lio_est_bench_batched_moments(lio_est *h, int n_windows, int reps, double *avg_ms, double *bytes) {

@@ -217,6 +217,8 @@ class Estimator {
   int shard_rank_ = 0, shard_world_ = 1;
   lio_allreduce_fn allreduce_ = nullptr;
   void *allreduce_user_ = nullptr;
+  void *rccl_comm_ = nullptr;               // ncclComm_t (lio_est_set_factor_sharding_rccl): the all-reduce runs on stream_, in HBM
+  bool Sharded() const { return shard_world_ > 1 && (allreduce_ || rccl_comm_); }
 
  private:
   struct HostState;  // snapshot payload

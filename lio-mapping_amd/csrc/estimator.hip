@@ -2,6 +2,7 @@
 // Reference call structure: Estimator.cc:430-774 (ProcessLaserOdom), :1361-1646 (BuildLocalMap),
 // :1648-2438 (SolveOptimization), :2440-2568 (VectorToDouble/DoubleToVector), :2570-2666 (SlideWindow).
 #include "estimator.h"
+#include "rccl_comm.h"
 
 #include <atomic>
 #include <cfloat>
@@ -81,6 +82,8 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   // ClearState (Estimator.cc:234-288): the running pre-integration exists before the first IMU sample
   tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[0], Bgs_[0], cfg_.pim);
   d_odom_.reserve(1);
+  d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
+  LIO_HIP(hipMemset(d_moment_out_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));   // the two pad entries per frame stay zero under the all-reduce
   d_moment_tickets_.reserve(LIO_MAX_FRAMES);
   LIO_HIP(hipMemset(d_moment_tickets_.p, 0, LIO_MAX_FRAMES * sizeof(int)));
   // measured on the MI355X: fold inside the launch 18.8 us vs moments + separate reduce launch 13.6 us per linearisation
@@ -585,7 +588,7 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
     const int idx = pivot + i;
     f.stack = stacks_[idx].buf.p; f.M = std::max<int>(1, int(stacks_[idx].n)); f.slot_off = slot_off_[idx]; f.nslots = nslots_[idx];
     f.slot_begin = 0; f.slot_end = f.nslots;
-    if (shard_world_ > 1 && allreduce_) {  // contiguous share of this frame's factor slots
+    if (Sharded()) {  // contiguous share of this frame's factor slots
       f.slot_begin = int((long long)f.nslots * shard_rank_ / shard_world_);
       f.slot_end = int((long long)f.nslots * (shard_rank_ + 1) / shard_world_);
     }
@@ -596,7 +599,7 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
 
 // Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.
 bool Estimator::SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &sum, WindowSystem::Costs &costs0, bool &turn_off) {
-  if (!device_solve_ || (shard_world_ > 1 && allreduce_) || !sys.use_lidar || total_slots_ == 0) return false;
+  if (!device_solve_ || Sharded() || rccl_comm_ || !sys.use_lidar || total_slots_ == 0) return false;
   MomentArgs ma;
   int max_slots = 0;
   FillMomentArgs(ma, max_slots);
@@ -681,7 +684,15 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   int th = timers_.begin(KT_MOMENTS, 60.0 * nres, stream_);  // 60 B read per lidar residual
   // k_moment_reduce stores its Wo x 260 doubles directly into pinned, device-mapped host memory: no copy
   // command, only the kernel-completion wait (kernel end = system-scope release, so the host sees the data).
-  launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_);
+  if (rccl_comm_) {
+    // per-shard moments -> whole-window moments without leaving HBM: fold into a device buffer, SUM all-reduce over xGMI on the
+    // same stream, then the 10 KB result goes to the pinned landing zone
+    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, nullptr, d_moment_out_.p, stream_);
+    rccl_all_reduce_sum_f64(rccl_comm_, d_moment_out_.p, size_t(Wo_) * LIO_MOMENT_OUT, stream_);
+    LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
+  } else {
+    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_);
+  }
   timers_.end(th, stream_);
 }
 
@@ -741,8 +752,8 @@ void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   LIO_HIP(hipStreamSynchronize(stream_));
   dbg_sync_ms_ += now_ms() - t_dbg0;
   timers_.resolve();
-  if (shard_world_ > 1 && allreduce_) {
-    // per-shard moments -> whole-window moments (SUM over ranks; RCCL over xGMI on a GPU node, 10 KB per call)
+  if (shard_world_ > 1 && allreduce_ && !rccl_comm_) {
+    // per-shard moments -> whole-window moments through the caller's callback (gloo on CPU hosts; the RCCL form never gets here)
     if (allreduce_(h_moment_out_, Wo_ * LIO_MOMENT_OUT, allreduce_user_) != 0) throw std::runtime_error("factor-sharding all-reduce failed");
   }
   for (int i = 1; i <= Wo_; ++i) {
@@ -827,7 +838,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   // Factor sharding: every linearisation is a collective, so every rank must take the same number of them.  A per-rank
   // wall-clock cap (Estimator.cc:1921) could stop one rank an iteration earlier than its peers and leave an unmatched
   // all-reduce behind; the sharded mode therefore terminates on the iteration / tolerance rules only.
-  const double time_cap = (shard_world_ > 1 && allreduce_) ? -1.0 : cfg_.max_solver_time;
+  const double time_cap = Sharded() ? -1.0 : cfg_.max_solver_time;
   s = solve_dogleg(sys, P, cfg_.max_num_iterations, time_cap, &first);
   R.ms_opt = now_ms() - t_opt0;
   if (getenv("LIO_DEBUG_TIMING"))

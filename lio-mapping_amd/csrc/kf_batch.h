@@ -20,6 +20,9 @@ class KfBatchDev {
   int AddKeyframe(int map, const float *corner, size_t nc, const float *surf, size_t ns, const Rigid<float> &T_init);
   void ClearKeyframes();
   void Refine();
+  // Refine + all-gather of the packed results (9 floats per keyframe: q, p, iterations, rows) over an RCCL communicator, straight
+  // from the device pose buffer; packed_all (host) receives world * slots_per_rank * 9 floats
+  void RefineGather(void *nccl_comm, int world, int slots_per_rank, float *packed_all);
   size_t n_keyframes() const { return h_kd_.size(); }
   size_t n_maps() const { return maps_.size(); }
   const std::vector<OdomState> &states() const { return h_st_; }
@@ -48,6 +51,7 @@ class KfBatchDev {
   DBuf<uint8_t> valid_;
   DBuf<double> partials_;
   DBuf<int> d_nconv_;
+  DBuf<float> d_pack_, d_gather_;
   int *h_nconv_ = nullptr;  // pinned
   bool md_dirty_ = true, kf_dirty_ = true;
   int max_Mc_ = 0, max_Ms_ = 0, max_nb_ = 1, total_nb_ = 0, n_gated_ = 0;

@@ -1,6 +1,7 @@
 // kf_batch.hip — host side of the batched keyframe refinement; the kernels are the scan-to-map stages of cloud_kernels.hip
 // indexed by keyframe.
 #include "kf_batch.h"
+#include "rccl_comm.h"
 
 #include <algorithm>
 #include <cmath>
@@ -145,6 +146,36 @@ void KfBatchDev::Refine() {
   float ms = 0;
   LIO_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
   device_ms_ = ms;
+}
+
+__global__ void k_kf_pack(const OdomState *__restrict__ st, int B, int slots, float *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= slots) return;
+  float *o = out + size_t(k) * 9;
+  if (k < B) {
+    const OdomState s = st[k];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) o[j] = s.T[j];
+    o[7] = float(s.iters); o[8] = float(s.nsel);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) o[j] = 0.f;
+  }
+}
+
+void KfBatchDev::RefineGather(void *nccl_comm, int world, int slots_per_rank, float *packed_all) {
+  Refine();
+  const int B = int(h_kd_.size());
+  if (slots_per_rank < B) throw std::runtime_error("RefineGather: slots_per_rank smaller than this rank's keyframe count");
+  hipStream_t s = stream_;
+  d_pack_.reserve(size_t(slots_per_rank) * 9);
+  d_gather_.reserve(size_t(world) * slots_per_rank * 9);
+  d_st_.reserve(std::max(1, B));
+  hipLaunchKernelGGL(k_kf_pack, dim3(cdiv(slots_per_rank, 256)), dim3(256), 0, s, d_st_.p, B, slots_per_rank, d_pack_.p);
+  LIO_HIP(hipGetLastError());
+  rccl_all_gather_f32(nccl_comm, d_pack_.p, d_gather_.p, size_t(slots_per_rank) * 9, s);
+  LIO_HIP(hipMemcpyAsync(packed_all, d_gather_.p, sizeof(float) * size_t(world) * slots_per_rank * 9, hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace lio

@@ -215,6 +215,13 @@ _SIGS = {
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lio_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "lio_rccl_init": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
+    "lio_rccl_destroy": (None, [C.c_void_p]),
+    "lio_rccl_rank": (C.c_int, [C.c_void_p]),
+    "lio_rccl_world": (C.c_int, [C.c_void_p]),
+    "lio_est_set_factor_sharding_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lio_kf_batch_refine_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_float_p, c_double_p]),
     "lio_est_bench_batched_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "lio_est_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_est_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, c_double_p]),
@@ -550,6 +557,30 @@ class PointMapping:
         return score, point, coeff
 
 
+class Rccl:
+    """In-library RCCL communicator (one per process / GPU): `Rccl.unique_id(lib)` on rank 0, the bytes sent to every rank by
+    any side channel, then `Rccl(lib, id_bytes, rank, world)` on the device the process drives."""
+
+    @staticmethod
+    def unique_id(lib: LioLib) -> bytes:
+        buf = C.create_string_buffer(128)
+        _chk(lib.dll.lio_rccl_unique_id(buf), "lio_rccl_unique_id")
+        return bytes(buf.raw)
+
+    def __init__(self, lib: LioLib, id_bytes: bytes, rank: int, world: int):
+        assert len(id_bytes) == 128
+        self.lib = lib
+        self.h = lib.dll.lio_rccl_init(C.create_string_buffer(id_bytes, 128), int(rank), int(world))
+        if not self.h:
+            raise LioError("lio_rccl_init failed")
+        self.rank, self.world = int(rank), int(world)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_rccl_destroy(self.h)
+            self.h = None
+
+
 class KeyframeBatch:
     """Batched keyframe refinement (BASELINE.json configs[4]): one OptimizeMap / OptimizeTransformTobeMapped loop per
     keyframe (MapBuilder.cc:624-1014 / PointMapping.cc:325-753), all keyframes of the handle advanced together."""
@@ -590,6 +621,15 @@ class KeyframeBatch:
 
     def __len__(self):
         return int(self.lib.dll.lio_kf_batch_size(self.h))
+
+    def refine_gather(self, comm: "Rccl", slots_per_rank: int):
+        """refine() + all-gather of every rank's results inside the library (ncclAllGather from the device pose buffer).
+        -> (world, slots_per_rank, 9) float32: q xyzw, p, iterations, rows; rows beyond a rank's keyframe count are zero."""
+        out = np.zeros((comm.world, int(slots_per_rank), 9), dtype=np.float32)
+        ms = C.c_double(0)
+        _chk(self.lib.dll.lio_kf_batch_refine_gather(self.h, comm.h, int(slots_per_rank), _fp(out), C.byref(ms)), "lio_kf_batch_refine_gather")
+        self.last_device_ms = ms.value
+        return out
 
     def refine(self):
         """-> dict(q (n,4) xyzw, p (n,3), iterations (n,), rows (n,), device_ms)"""
@@ -792,6 +832,12 @@ class Estimator:
     def set_extrinsic(self, q_xyzw, p):
         T = TransformF.make(q_xyzw, p)
         _chk(self.lib.dll.lio_est_set_extrinsic(self.h, C.byref(T)), "lio_est_set_extrinsic")
+
+    def set_factor_sharding_rccl(self, comm):
+        """comm: capi.Rccl or None.  The all-reduce of the per-shard moments then runs inside the library (ncclAllReduce on the
+        estimator's stream)."""
+        self._rccl = comm   # keep the communicator alive as long as the estimator uses it
+        _chk(self.lib.dll.lio_est_set_factor_sharding_rccl(self.h, comm.h if comm is not None else None), "lio_est_set_factor_sharding_rccl")
 
     def set_factor_sharding(self, rank, world, allreduce_numpy):
         """`allreduce_numpy(buf: np.ndarray[float64])` must sum `buf` in place over all ranks (e.g. torch.distributed)."""

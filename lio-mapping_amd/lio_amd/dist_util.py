@@ -64,7 +64,21 @@ def make_allreduce(device: str = "cpu"):
     return allreduce
 
 
-def refine_keyframes_sharded(lib, maps, keyframes, world: int, rank: int, device: str = "cpu", **cfg):
+def make_rccl(lib, rank: int, world: int):
+    """In-library RCCL communicator for this rank: rank 0 draws the unique id, torch.distributed (whatever backend the process
+    group has) carries the 128 bytes to the others, every rank joins with ncclCommInitRank on its current device."""
+    from . import capi
+
+    if world <= 1:
+        return capi.Rccl(lib, capi.Rccl.unique_id(lib), 0, 1)
+    import torch.distributed as dist
+
+    box = [capi.Rccl.unique_id(lib) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return capi.Rccl(lib, box[0], rank, world)
+
+
+def refine_keyframes_sharded(lib, maps, keyframes, world: int, rank: int, device: str = "cpu", rccl=None, **cfg):
     """BASELINE.json configs[4] over N ranks: keyframes are independent, so rank r refines keyframes r, r+N, r+2N, ...
     (with the local maps they reference) on its own GPU, and the one exchange of the path is an all-gather of the
     refined poses (7 floats + 2 ints per keyframe).  maps = [(corner_map, surf_map)], keyframes = [(map_index,
@@ -81,6 +95,14 @@ def refine_keyframes_sharded(lib, maps, keyframes, world: int, rank: int, device
         if mi not in local_map:
             local_map[mi] = batch.add_map(*maps[mi])
         batch.add_keyframe(local_map[mi], *keyframes[k][1:4])
+    if rccl is not None and world > 1:   # the exchange inside the library: all-gather from the device pose buffer
+        per_rank = -(-len(keyframes) // world)
+        g = batch.refine_gather(rccl, per_rank)
+        out = np.zeros((len(keyframes), 9), np.float32)
+        for rr in range(world):
+            idx = list(range(rr, len(keyframes), world))
+            out[idx] = g[rr, : len(idx)]
+        return dict(q=out[:, 0:4], p=out[:, 4:7], iterations=out[:, 7].astype(np.int32), rows=out[:, 8].astype(np.int32))
     r = batch.refine()
     packed = np.zeros((len(mine), 9), np.float32)
     if mine:

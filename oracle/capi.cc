@@ -767,6 +767,14 @@ int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_f
   h->est.shard_rank = rank; h->est.shard_world = world; h->est.allreduce = fn; h->est.allreduce_user = user;
   return LIO_OK;
 }
+// RCCL lives in the product only (the oracle is a CPU library)
+int lio_rccl_unique_id(unsigned char *) { return LIO_ERR_DEVICE; }
+lio_rccl *lio_rccl_init(const unsigned char *, int, int) { return nullptr; }
+void lio_rccl_destroy(lio_rccl *) {}
+int lio_rccl_rank(const lio_rccl *) { return -1; }
+int lio_rccl_world(const lio_rccl *) { return 0; }
+int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *) { return LIO_ERR_DEVICE; }
+int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *, int, float *, double *) { return LIO_ERR_DEVICE; }
 int lio_est_bench_batched_moments(lio_est *, int, int, double *, double *) { return LIO_ERR_STATE; }  // device-only measurement
 int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_est_get_kernel_timing(lio_est *, const char *, double *t, double *b) { if (t) *t = 0; if (b) *b = 0; return 0; }

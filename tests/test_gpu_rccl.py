@@ -1,0 +1,132 @@
+"""In-library RCCL (csrc/rccl_comm.hip) and the product under world_size 2.
+
+One MI355X is visible to these tests, and RCCL does not let two ranks share a device, so:
+  * the RCCL entry points run with a world-size-1 communicator (ncclCommInitRank, ncclAllReduce, ncclAllGather all execute; a
+    one-rank collective is the identity) and must reproduce the un-sharded results bit for bit — this covers the device-buffer
+    fold, the collective on the estimator's stream, the D2H of the reduced moments and the pose pack / gather;
+  * the sharding logic itself (slot ranges, lockstep replicas, the exchange) runs with the PRODUCT on two processes that share the
+    GPU and exchange through the callback form over gloo — the same test tests/test_distributed_gloo.py runs with the oracle.
+The 2 / 4 / 8-GPU runs are the driver's (bench.py --gpus N [--shard-factors | --workload keyframes])."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from lio_amd import capi, dist_util, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _window(lib, n_frames=7):
+    ds = synth.make_dataset("indoor", n_frames, 0.2, lidar=synth.Lidar(16, -15, 15, 450))
+    clouds = [pipeline.feature_clouds(lib, ds.lidar, f.scan) for f in ds.frames]
+    cfg = pipeline.config_indoor(lib, 4, 2)
+    cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+    pipeline.set_extrinsic(cfg, ds)
+    est = capi.Estimator(lib, cfg)
+    pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=0.005, rot_sigma=0.0005, vel_sigma=0.005)
+    return ds, clouds, est
+
+
+def _run(est, ds, clouds):
+    reps = [est.solve()]
+    est.slide()
+    for k in (5, 6):
+        reps.append(pipeline.feed_frame(est, ds, k, clouds[k][0], clouds[k][1]))
+    return est.get_window(), reps, est.prior()
+
+
+def test_rccl_allreduce_path_is_identity_at_world_1(hip):
+    comm = dist_util.make_rccl(hip, 0, 1)
+    assert hip.dll.lio_rccl_world(comm.h) == 1 and hip.dll.lio_rccl_rank(comm.h) == 0
+    ds, clouds, ea = _window(hip)
+    _, _, eb = _window(hip)
+    ea.set_factor_sharding_rccl(comm)          # moments: fold -> device buffer -> ncclAllReduce on the estimator's stream -> pinned host
+    wa, ra, pa = _run(ea, ds, clouds)
+    wb, rb, pb = _run(eb, ds, clouds)
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        np.testing.assert_array_equal(wa[key], wb[key])
+    for a, b in zip(ra, rb):
+        assert (a.iterations, a.termination, a.final_cost, a.n_lidar_residuals) == (b.iterations, b.termination, b.final_cost, b.n_lidar_residuals)
+    np.testing.assert_array_equal(pa["JtJ"], pb["JtJ"])
+    ea.set_factor_sharding_rccl(None)          # and back
+
+
+def test_rccl_keyframe_gather_at_world_1(hip):
+    from kf_util import keyframe_inputs
+
+    maps, kfs = keyframe_inputs(hip, "indoor", 3, 2)
+    comm = dist_util.make_rccl(hip, 0, 1)
+    b = capi.KeyframeBatch(hip)
+    for m in maps:
+        b.add_map(*m)
+    for kf in kfs:
+        b.add_keyframe(*kf[:4])
+    r = b.refine()
+    g = b.refine_gather(comm, len(kfs) + 3)
+    assert g.shape == (1, len(kfs) + 3, 9)
+    np.testing.assert_array_equal(g[0, : len(kfs), 0:4], r["q"])
+    np.testing.assert_array_equal(g[0, : len(kfs), 4:7], r["p"])
+    np.testing.assert_array_equal(g[0, : len(kfs), 7].astype(np.int32), r["iterations"])
+    assert np.all(g[0, len(kfs):] == 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = capi.load_hip()
+    ds, clouds, est = _window(lib)
+    est.set_factor_sharding(rank, world, dist_util.make_allreduce("cpu"))
+    w, reps, prior = _run(est, ds, clouds)
+    from kf_util import keyframe_inputs
+
+    maps, kfs = keyframe_inputs(lib, "indoor", 3, 2)
+    kfs = kfs + [kfs[0]]
+    kr = dist_util.refine_keyframes_sharded(lib, maps, kfs, world, rank)
+    out[rank] = (w["Ps"].copy(), [r.final_cost for r in reps], [r.n_lidar_residuals for r in reps], prior["JtJ"].copy(), kr["q"], kr["p"], kr["iterations"])
+    dist.destroy_process_group()
+
+
+def test_product_factor_sharding_and_keyframe_sharding_two_processes(hip):
+    """The product as the per-rank worker of the world_size-2 tests: factors of ONE window sharded over two processes (moments
+    summed by a gloo all-reduce through the callback form), keyframes sharded round-robin + all-gather."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (p0, c0, n0, j0, q0, t0, i0), (p1, c1, n1, j1, q1, t1, i1) = out[0], out[1]
+    np.testing.assert_array_equal(p0, p1)                      # lockstep replicas
+    assert c0 == c1 and n0 == n1
+    np.testing.assert_array_equal(q0, q1); np.testing.assert_array_equal(t0, t1)
+    ds, clouds, est = _window(hip)
+    w, reps, prior = _run(est, ds, clouds)
+    assert n0 == [r.n_lidar_residuals for r in reps]           # every factor counted exactly once across the shards
+    # only the summation order of the moments differs (1e-16 relative); three chained steps amplify that to ~6e-6 m on this
+    # small window (tests/golden/README.md: a chain amplifies its inputs' differences), the first step alone agrees to 1e-9
+    np.testing.assert_allclose(p0, w["Ps"], atol=5e-5)
+    np.testing.assert_allclose(c0, [r.final_cost for r in reps], rtol=1e-4)
+    np.testing.assert_allclose(j0, prior["JtJ"], rtol=0, atol=1e-3 * np.abs(j0).max())
+    from kf_util import keyframe_inputs
+
+    maps, kfs = keyframe_inputs(hip, "indoor", 3, 2)
+    kfs = kfs + [kfs[0]]
+    full = dist_util.refine_keyframes_sharded(hip, maps, kfs, 1, 0)
+    np.testing.assert_array_equal(q0, full["q"]); np.testing.assert_array_equal(t0, full["p"]); np.testing.assert_array_equal(i0, full["iterations"])

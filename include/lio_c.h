@@ -50,6 +50,9 @@ typedef struct {
   int max_corner_less_sharp;   /* 20    :111 */
   int max_surf_flat;           /* 4     :112 */
   float less_flat_filter_size; /* 0.2f  :113 */
+  int infer_start_ori;         /* 0     :119 — lio_pp_process only: replace a jumping start azimuth by the one the last ten
+                                  sweeps predict (PointProcessor.cc:348-387); the ten-sweep history lives in the lio_pp */
+  double rad_diff;             /* 0.2   :117 — the jump (rad) that triggers the replacement */
 } lio_pp_config;
 
 typedef struct lio_pp lio_pp;
@@ -74,6 +77,8 @@ int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
  * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
  * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */
 int lio_pp_process_rings(lio_pp *, const float *xyzi, const uint16_t *ring, size_t n);
+/* start_ori_ the last process call used (after the inference when infer_start_ori is set); NaN before the first call */
+float lio_pp_start_ori(const lio_pp *);
 size_t lio_pp_count(const lio_pp *, int which);
 int lio_pp_get_cloud(const lio_pp *, int which, float *xyzi_out);
 /* parity object of §8a a4: ordered (ring, in-ring index) per picked class; which in {SHARP,LESS_SHARP,FLAT} */

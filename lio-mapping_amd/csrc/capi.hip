@@ -52,6 +52,7 @@ void lio_pp_default_config(lio_pp_config *c) {
   if (!c) return;
   c->scan_period = 0.1; c->num_scan_subregions = 8; c->num_curvature_regions = 5; c->surf_curv_th = 0.1f;
   c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
+  c->infer_start_ori = 0; c->rad_diff = 0.2;
 }
 lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   if (rings <= 0 || rings > LIO_PP_MAX_RINGS || !(up > lo)) return nullptr;
@@ -64,6 +65,7 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
     if (v < 0 || v > 4096) return nullptr;
   if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return nullptr;
   if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return nullptr;
+  if (cfg.infer_start_ori && !(cfg.rad_diff >= 0.0)) return nullptr;
   lio_pp *h = new (std::nothrow) lio_pp;
   if (!h) return nullptr;
   int rc = guarded([&] { h->pp.reset(new PointProcessorDev(lo, up, rings, cfg)); return LIO_OK; });
@@ -71,6 +73,12 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   return h;
 }
 void lio_pp_destroy(lio_pp *h) { delete h; }
+float lio_pp_start_ori(const lio_pp *h) {
+  if (!h) return std::nanf("");
+  float v = std::nanf("");
+  guarded([&] { v = h->pp->StartOri(); return LIO_OK; });
+  return v;
+}
 int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
   return guarded([&] { h->pp->Process(xyzi, n); return LIO_OK; });

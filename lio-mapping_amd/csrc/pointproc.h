@@ -22,6 +22,26 @@ struct PPDeviceCounts {
   int overflow;          // a ring exceeded LIO_PP_MAX_RING_POINTS
 };
 
+// config_.infer_start_ori_ (PointProcessor.cc:348-387): two ten-deep histories of the start azimuth — as measured (buf2) and
+// as used (buf1).  A start azimuth that jumps by more than rad_diff from the last used one is replaced by the last one plus
+// the mean step of the used history; once the measured history steps evenly again (all nine steps within 0.05 rad of the used
+// history's mean step, and the two mean steps within 0.05 rad) the azimuth of ring 0's first point is taken instead.
+class StartOriFilter {
+ public:
+  // measured = azimuth of the sweep's first kept point; ring0_front = azimuth of ring 0's first point (NaN: ring 0 is empty —
+  // the reference dereferences an empty cloud there; the value is then left as it is).  Returns start_ori_ for this sweep.
+  float Update(float measured, float ring0_front, double rad_diff);
+  void Reset() { n1_ = n2_ = h1_ = h2_ = 0; }
+
+ private:
+  static constexpr int kDepth = 10;
+  float used_[kDepth], seen_[kDepth];   // start_ori_buf1_, start_ori_buf2_ (CircularBuffer<float>{10})
+  int n1_ = 0, h1_ = 0, n2_ = 0, h2_ = 0;
+  static void Push(float *buf, int &n, int &head, float v) {
+    if (n < kDepth) buf[n++] = v; else { buf[head] = v; head = (head + 1) % kDepth; }
+  }
+};
+
 class PointProcessorDev {
  public:
   PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg);
@@ -36,6 +56,7 @@ class PointProcessorDev {
   // device-resident results (valid until the next Process)
   const float4 *d_less_flat() const { return less_flat_.p; }
   size_t n_less_flat() const { return size_t(counts_.n_less_flat); }
+  float StartOri();   // start_ori_ of the last Process (one small D2H unless infer_start_ori already fetched it)
 
  private:
   float lower_, upper_, factor_;
@@ -43,11 +64,13 @@ class PointProcessorDev {
   lio_pp_config cfg_;
   hipStream_t stream_ = nullptr;
   PPDeviceCounts counts_{};
-  struct HostOut { PPDeviceCounts counts; int ring_offsets[LIO_PP_MAX_RINGS + 1]; };
+  struct HostOut { PPDeviceCounts counts; int ring_offsets[LIO_PP_MAX_RINGS + 1]; float start_ori_probe[3]; };
   HostOut *h_out_ = nullptr;   // pinned landing zone of the per-sweep results
   std::vector<int> ring_offsets_;
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
-  DBuf<float> azi_, curv_;
+  DBuf<float> azi_, curv_, start_ori_dev_;
+  StartOriFilter start_ori_filter_;
+  bool processed_ = false, start_ori_known_ = false;
   DBuf<uint32_t> keys_;
   DBuf<int> ring_total_;
   DBuf<int> ring_table_;   // [ring][block] counts -> exclusive offsets (the stable ring split)

@@ -41,9 +41,9 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_bin(const float4 *__res
                                                              float factor, int rings, uint32_t *__restrict__ keys, float *__restrict__ azi,
                                                              int *__restrict__ block_hist, int nblocks, int *first_valid) {
   __shared__ int hist[LIO_PP_MAX_RINGS];
-  __shared__ int s_first;
+  __shared__ int s_first, s_first0;   // first kept point; first kept point of ring 0 (ring_out[0]->front(), :383)
   for (int r = threadIdx.x; r < rings; r += PP_BIN_THREADS) hist[r] = 0;
-  if (threadIdx.x == 0) s_first = INT_MAX;
+  if (threadIdx.x == 0) { s_first = INT_MAX; s_first0 = INT_MAX; }
   __syncthreads();
   const int i = blockIdx.x * PP_BIN_THREADS + threadIdx.x;
   if (i < n) {
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_bin(const float4 *__res
         key = uint32_t(scan_id);
         atomicAdd(&hist[scan_id], 1);
         atomicMin(&s_first, i);
+        if (scan_id == 0) atomicMin(&s_first0, i);
       }
     }
     keys[i] = key; azi[i] = az;
@@ -68,6 +69,18 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_bin(const float4 *__res
   __syncthreads();
   for (int r = threadIdx.x; r < rings; r += PP_BIN_THREADS) block_hist[r * nblocks + blockIdx.x] = hist[r];
   if (threadIdx.x == 0 && s_first != INT_MAX) atomicMin(first_valid, s_first);
+  if (threadIdx.x == 0 && s_first0 != INT_MAX) atomicMin(first_valid + 1, s_first0);
+}
+
+// start_ori_ of the sweep: the azimuth of the first kept point (:261-264), or the value the host's ten-sweep filter
+// decided on (infer_start_ori, :348-387).  Kernels read it through this.
+__device__ __forceinline__ float sweep_start_ori(const float *__restrict__ azi, const int *__restrict__ first_valid, const float *__restrict__ start_ori_override) {
+  return start_ori_override ? *start_ori_override : azi[*first_valid];
+}
+// infer_start_ori only: the two azimuths the host filter needs
+__global__ void k_start_ori_probe(const float *__restrict__ azi, const int *__restrict__ first_valid, float *__restrict__ out) {
+  out[0] = first_valid[0] != INT_MAX ? azi[first_valid[0]] : 0.f;
+  out[1] = first_valid[1] != INT_MAX ? azi[first_valid[1]] : __int_as_float(0x7fc00000);
 }
 
 // per-ring exclusive scan of the count table in place (block r owns ring r's nblocks counts) + the ring totals
@@ -113,7 +126,7 @@ __global__ void k_ring_end_ori(const uint32_t *__restrict__ keys, const float *_
 __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *__restrict__ in, const uint32_t *__restrict__ keys,
                                                                  const float *__restrict__ azi, const int *__restrict__ table, int nblocks, int n,
                                                                  const int *__restrict__ ring_total, int *__restrict__ offsets,
-                                                                 const int *__restrict__ first_valid, int rings, double scan_period,
+                                                                 const int *__restrict__ first_valid, const float *__restrict__ start_ori_override, int rings, double scan_period,
                                                                  float4 *__restrict__ ring_cloud, const int *__restrict__ end_ori_bits) {
   __shared__ int wave_cnt[PP_BIN_THREADS / 64][LIO_PP_MAX_RINGS];
   __shared__ int ring_base[LIO_PP_MAX_RINGS + 1];
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *_
   if (!valid) return;
   int dst = ring_base[key] + table[int(key) * nblocks + blockIdx.x] + rank;
   for (int w = 0; w < wv; ++w) dst += wave_cnt[w][key];
-  const float start_ori = azi[*first_valid];
+  const float start_ori = sweep_start_ori(azi, first_valid, start_ori_override);
   float rel = azi[i] - start_ori;
   if (rel < 0) rel = float(double(rel) + 2 * M_PI);
   float rel_time = float(scan_period * double(rel) / (2 * M_PI));
@@ -468,7 +481,7 @@ __global__ void __launch_bounds__(256) k_pp_pack(const float4 *__restrict__ ring
 #define PP_LF_THREADS 512
 __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets,
                                                            const int8_t *__restrict__ label, float inv_leaf, const float *__restrict__ azi,
-                                                           const int *__restrict__ first_valid, double scan_period, float4 *__restrict__ staged,
+                                                           const int *__restrict__ first_valid, const float *__restrict__ start_ori_override, double scan_period, float4 *__restrict__ staged,
                                                            int *__restrict__ ring_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int r = blockIdx.x, tid = threadIdx.x;
@@ -573,7 +586,7 @@ __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restr
   }
   __syncthreads();
   // ---- centroids
-  const float start_ori = azi[*first_valid];
+  const float start_ori = sweep_start_ori(azi, first_valid, start_ori_override);
   for (int i = tid; i < NS; i += PP_LF_THREADS) {
     const int pos = spos[i];
     if (pos < 0) continue;
@@ -598,6 +611,50 @@ __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// NormalizeRad<float> / AbsRadDistance (math_utils.h:44-51, PointProcessor.cc:70-72) with the reference's float/double mix
+static float normalize_rad_f(float rad) {
+  rad = float(std::fmod(double(rad) + M_PI, 2 * M_PI));
+  if (rad < 0) rad = float(double(rad) + 2 * M_PI);
+  return float(double(rad) - M_PI);
+}
+static double abs_rad_distance(double a, double b) {
+  double rad = std::fmod(a - b + M_PI, 2 * M_PI);
+  if (rad < 0) rad += 2 * M_PI;
+  return std::fabs(rad - M_PI);
+}
+float StartOriFilter::Update(float measured, float ring0_front, double rad_diff) {
+  float s = measured;
+  Push(seen_, n2_, h2_, s);
+  if (n1_ >= kDepth) {
+    auto used = [&](int i) { return used_[(h1_ + i) % kDepth]; };
+    auto seen = [&](int i) { return seen_[(h2_ + i) % kDepth]; };
+    const float step_used = normalize_rad_f(used(9) - used(0)) / 9;
+    const float step_seen = normalize_rad_f(seen(9) - seen(0)) / 9;
+    if (double(std::fabs(normalize_rad_f(s - used(9)))) > rad_diff) {   // a jump: extrapolate the used history (:362-368)
+      s = normalize_rad_f(used(9) + step_used);
+      if (s < 0) s = float(double(s) + 2 * M_PI);
+    }
+    bool even = abs_rad_distance(step_used, step_seen) < 0.05;          // :371-383
+    for (int k = 9; k >= 1 && even; --k) even = abs_rad_distance(seen(k) - seen(k - 1), step_used) < 0.05;
+    if (even && ring0_front == ring0_front) s = ring0_front;
+  }
+  Push(used_, n1_, h1_, s);
+  return s;
+}
+
+float PointProcessorDev::StartOri() {
+  if (!processed_) return std::nanf("");
+  if (!start_ori_known_) {
+    start_ori_dev_.reserve(3);
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, stream_, azi_.p, first_valid_.p, start_ori_dev_.p);
+    LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    LIO_HIP(hipStreamSynchronize(stream_));
+    h_out_->start_ori_probe[2] = h_out_->start_ori_probe[0];
+    start_ori_known_ = true;
+  }
+  return h_out_->start_ori_probe[2];
+}
+
 PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg)
     : lower_(lower), upper_(upper), rings_(rings), cfg_(cfg) {
   factor_ = (rings - 1) / (upper - lower);
@@ -626,7 +683,7 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   keys_.reserve(n); less_flat_.reserve(n);
   const int nblocks = cdiv(ni, PP_BIN_THREADS);
   ring_table_.reserve(size_t(rings_) * nblocks); ring_total_.reserve(rings_);
-  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(1); d_counts_.reserve(1); end_ori_.reserve(1);
+  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(2); d_counts_.reserve(1); end_ori_.reserve(1);
   PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
              cfg_.max_surf_flat, cfg_.surf_curv_th};
   const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
@@ -645,7 +702,7 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
   LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
-  LIO_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(first_valid_.p), INT_MAX, 1, s));
+  LIO_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(first_valid_.p), INT_MAX, 2, s));
   const uint16_t *d_ring = nullptr;
   if (ring) {
     ring_in_.reserve(n);
@@ -657,8 +714,21 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
                      nblocks, first_valid_.p);
   if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_.p, end_ori_.p);
   hipLaunchKernelGGL(k_ring_scan, dim3(rings_), dim3(256), 0, s, ring_table_.p, nblocks, ring_total_.p);
+  const float *d_override = nullptr;
+  processed_ = true; start_ori_known_ = false;
+  if (cfg_.infer_start_ori && !ring) {
+    // :348-387 — ten lines of host state between the two passes of PointToRing; costs one round trip, only when enabled
+    start_ori_dev_.reserve(3);
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, s, azi_.p, first_valid_.p, start_ori_dev_.p);
+    LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipStreamSynchronize(s));
+    h_out_->start_ori_probe[2] = start_ori_filter_.Update(h_out_->start_ori_probe[0], h_out_->start_ori_probe[1], cfg_.rad_diff);
+    LIO_HIP(hipMemcpyAsync(start_ori_dev_.p + 2, h_out_->start_ori_probe + 2, sizeof(float), hipMemcpyHostToDevice, s));
+    d_override = start_ori_dev_.p + 2;
+    start_ori_known_ = true;
+  }
   hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_.p,
-                     first_valid_.p, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
+                     first_valid_.p, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
   const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 4) + size_t(cap_all) * sizeof(int) + 64;
   hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
                      pick_idx_.p, pick_cnt_.p, d_counts_.p);
@@ -667,7 +737,7 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);
   const size_t lf_lds = size_t(4096) * 8 + size_t(4096) * 16 + size_t(4096) * 4;
   hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, inv_leaf, azi_.p,
-                     first_valid_.p, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
+                     first_valid_.p, d_override, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
   hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
                      class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_.p);
   LIO_HIP(hipGetLastError());

@@ -47,6 +47,8 @@ class PPConfig(C.Structure):
         ("max_corner_less_sharp", C.c_int),
         ("max_surf_flat", C.c_int),
         ("less_flat_filter_size", C.c_float),
+        ("infer_start_ori", C.c_int),
+        ("rad_diff", C.c_double),
     ]
 
 
@@ -133,6 +135,7 @@ _SIGS = {
     "lio_pp_destroy": (None, [C.c_void_p]),
     "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
+    "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
     "lio_pp_get_cloud": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
     "lio_pp_get_indices": (C.c_int, [C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
@@ -448,6 +451,10 @@ class PointProcessor:
         ring = np.ascontiguousarray(ring, dtype=np.uint16)
         assert ring.shape[0] == xyzi.shape[0]
         _chk(self.lib.dll.lio_pp_process_rings(self.h, _fp(xyzi), ring.ctypes.data_as(c_uint16_p), xyzi.shape[0]), "lio_pp_process_rings")
+
+    def start_ori(self):
+        """start_ori_ of the last process call (after infer_start_ori's filter when that is enabled)."""
+        return float(self.lib.dll.lio_pp_start_ori(self.h))
 
     def cloud(self, which):
         n = self.lib.dll.lio_pp_count(self.h, which)

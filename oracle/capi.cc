@@ -39,6 +39,7 @@ void lio_pp_default_config(lio_pp_config *c) {
   if (!c) return;
   c->scan_period = 0.1; c->num_scan_subregions = 8; c->num_curvature_regions = 5; c->surf_curv_th = 0.1f;
   c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
+  c->infer_start_ori = 0; c->rad_diff = 0.2;
 }
 lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   if (rings <= 0 || !(up > lo)) return nullptr;
@@ -48,10 +49,12 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
     k.scan_period = c->scan_period; k.num_scan_subregions = c->num_scan_subregions; k.num_curvature_regions = c->num_curvature_regions;
     k.surf_curv_th = c->surf_curv_th; k.max_corner_sharp = c->max_corner_sharp; k.max_corner_less_sharp = c->max_corner_less_sharp;
     k.max_surf_flat = c->max_surf_flat; k.less_flat_filter_size = c->less_flat_filter_size;
+    k.infer_start_ori_ = c->infer_start_ori != 0; k.rad_diff = c->rad_diff;
   }
   return h;
 }
 void lio_pp_destroy(lio_pp *h) { delete h; }
+float lio_pp_start_ori(const lio_pp *h) { return h ? h->pp.start_ori_ : std::nanf(""); }
 int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
   h->pp.Process(xyzi, n);

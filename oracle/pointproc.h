@@ -21,13 +21,30 @@ struct PPConfig {
   int max_corner_less_sharp = 20;
   int max_surf_flat = 4;
   float less_flat_filter_size = 0.2f;
+  bool infer_start_ori_ = false;   // PointProcessor.h:119
+  double rad_diff = 0.2;           // PointProcessor.h:117
+};
+
+// PointProcessor.cc:70-72; NormalizeRad (liomath.h) is instantiated with T = float at PointProcessor.cc:354-364
+inline double AbsRadDistance(double a, double b) { return std::fabs(NormalizeRad(a - b)); }
+
+// utils/CircularBuffer.h:118-172 — push overwrites the oldest element once full; [i] counts from the oldest
+struct Ring10 {
+  float buf[10];
+  size_t size_ = 0, start_ = 0;
+  void push(float v) { if (size_ < 10) buf[size_++] = v; else { buf[start_] = v; start_ = (start_ + 1) % 10; } }
+  float operator[](size_t i) const { return buf[(start_ + i) % 10]; }
+  float first() const { return buf[start_]; }
+  float last() const { return buf[size_ == 0 ? 0 : (start_ + size_ - 1) % 10]; }
+  size_t size() const { return size_; }
 };
 
 struct PointProcessor {
   float lower_bound_, upper_bound_, factor_;
   int num_rings_;
   PPConfig config_;
-  float start_ori_ = 0.f;
+  float start_ori_ = std::nanf("");
+  Ring10 start_ori_buf1_, start_ori_buf2_;   // PointProcessor.h: CircularBuffer<float>{10} each
 
   std::vector<Cloud> laser_scans;   // intensity = ring + rel_time
   std::vector<int> ring_offsets;    // rings+1
@@ -98,6 +115,25 @@ struct PointProcessor {
       if (!start_flag) { start_ori_ = azi_rad; start_flag = true; }  // :261-264
       p.i = azi_rad;  // :268
       laser_scans[scan_id].push_back(p);
+    }
+    if (config_.infer_start_ori_) {  // :348-387
+      start_ori_buf2_.push(start_ori_);
+      if (start_ori_buf1_.size() >= 10) {
+        float start_ori_diff1 = start_ori_buf1_.last() - start_ori_buf1_.first();
+        float start_ori_step1 = NormalizeRad(start_ori_diff1) / 9;
+        float start_ori_diff2 = start_ori_buf2_.last() - start_ori_buf2_.first();
+        float start_ori_step2 = NormalizeRad(start_ori_diff2) / 9;
+        if (std::fabs(NormalizeRad(start_ori_ - start_ori_buf1_.last())) > config_.rad_diff) {
+          start_ori_ = start_ori_buf1_.last() + start_ori_step1;
+          start_ori_ = NormalizeRad(start_ori_);
+          if (start_ori_ < 0) start_ori_ += 2 * M_PI;
+        }
+        bool steady = AbsRadDistance(start_ori_step1, start_ori_step2) < 0.05;
+        for (int k = 9; k >= 1; --k) steady = steady && AbsRadDistance(start_ori_buf2_[k] - start_ori_buf2_[k - 1], start_ori_step1) < 0.05;
+        // :383 reads ring_out[0]->front() unguarded; an empty ring 0 leaves the value alone here
+        if (steady && !laser_scans[0].empty()) start_ori_ = laser_scans[0].front().i;
+      }
+      start_ori_buf1_.push(start_ori_);
     }
     // :393-423 second pass: intensity = ring + rel_time
     for (int ring = 0; ring < num_rings_; ++ring)

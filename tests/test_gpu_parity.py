@@ -89,6 +89,44 @@ def test_calculate_features_matches_oracle(hip, oracle):
 
 
 # ------------------------------------------------------------------------------------------------ point processor
+def test_point_processor_infer_start_ori_matches_oracle(hip, oracle):
+    """config_.infer_start_ori_ (PointProcessor.cc:348-387): 30 sweeps with a drifting start azimuth and stray leading returns
+    at three of them.  The filter's decisions are host state fed by two device azimuths; start_ori_ and everything downstream
+    of it (ring + rel_time, the less-flat rel-time recompute) must follow the oracle sweep by sweep."""
+    from start_ori_util import make_sweeps
+    ds = synth.make_dataset("indoor", 1, 0.1)
+    lid = ds.lidar
+    sweeps = make_sweeps(ds.frames[0].scan, 30, 0.03, stray_at=(14, 15, 22))
+    cfgs = []
+    for lib in (hip, oracle):
+        cfg = capi.PPConfig()
+        lib.dll.lio_pp_default_config(cfg)
+        assert cfg.infer_start_ori == 0 and cfg.rad_diff == 0.2
+        cfg.infer_start_ori = 1
+        cfgs.append(cfg)
+    pa = capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings, cfgs[0])
+    pb = capi.PointProcessor(oracle, lid.lower_deg, lid.upper_deg, lid.rings, cfgs[1])
+    plain = capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings)
+    assert np.isnan(pa.start_ori())
+    n_replaced = 0
+    for k, scan in enumerate(sweeps):
+        pa.process(scan)
+        pb.process(scan)
+        plain.process(scan)
+        assert abs(pa.start_ori() - pb.start_ori()) < 2e-6, (k, pa.start_ori(), pb.start_ori())   # atan2f ulp
+        n_replaced += int(abs(pa.start_ori() - plain.start_ori()) > 1.0)
+        np.testing.assert_array_equal(pa.ring_offsets(), pb.ring_offsets())
+        ra, rb = pa.cloud(0), pb.cloud(0)
+        np.testing.assert_array_equal(ra[:, :3], rb[:, :3])
+        np.testing.assert_allclose(ra[:, 3], rb[:, 3], rtol=0, atol=8e-6)
+        la, lb = pa.cloud(4), pb.cloud(4)
+        np.testing.assert_array_equal(la[:, :3], lb[:, :3])
+        np.testing.assert_allclose(la[:, 3], lb[:, 3], rtol=0, atol=8e-6)
+        for which in (1, 2, 3):
+            np.testing.assert_array_equal(pa.indices(which)[1], pb.indices(which)[1])
+    assert n_replaced == 3
+
+
 @pytest.mark.parametrize("kind", ["vlp16", "hdl64"])
 def test_point_processor_matches_oracle(hip, oracle, kind):
     if kind == "vlp16":

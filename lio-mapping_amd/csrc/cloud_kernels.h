@@ -137,7 +137,8 @@ int odom_rows_blocks(int nslots);
 // odom_round_blocks(M, lanes per query) x 28 doubles.
 int odom_round_blocks(int M, int lpq);
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
-                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s);
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail = nullptr,
+                       const HostSignal &sig = HostSignal());
 
 // ---- batched keyframe refinement (config 5: B independent OptimizeMap / OptimizeTransformTobeMapped loops, MapBuilder.cc:624-1014,
 // PointMapping.cc:325-753).  Slots of keyframe k = [slot_off, slot_off + Mc) corner, then Ms surf, in one concatenated stack.

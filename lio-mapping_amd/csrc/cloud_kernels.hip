@@ -936,9 +936,14 @@ __global__ void __launch_bounds__(128) k_odom_round(FeatArgs a, const OdomState 
 
 // fold of `nblocks` 28-double partials by a 1024-thread block (32 groups of rows b = g mod 32, ascending, then the group sums
 // ascending), followed by the update of odom_update_body
+// mail: a copy of the state in coherent pinned host memory, posted with the round's sequence number after every round (also
+// by the no-op rounds behind convergence), so the host's look at the convergence flag is a read of its own memory.
 __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
-                                                           int left_update) {
-  if (st->converged) return;
+                                                           int left_update, OdomState *mail, HostSignal sig) {
+  if (st->converged) {
+    if (sig.flag && threadIdx.x == 0) { *mail = *st; post_host_signal(sig); }
+    return;
+  }
   __shared__ double part[32][32];
   __shared__ double ssum[28];
   const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
@@ -962,18 +967,19 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
   }
   __syncthreads();
   odom_update_from_sums(ssum, st, iter, min_rows, left_update);
+  if (sig.flag && threadIdx.x == 0) { *mail = *st; post_host_signal(sig); }
 }
 
 int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, 128)); }
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
-                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s) {
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
   const bool big = (long long)M >= 50000;
   const int nb = odom_round_blocks(M, big ? 4 : 8);
   if (big) hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   else hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
-  hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0);
+  hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());
 }
 

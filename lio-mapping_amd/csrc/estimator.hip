@@ -91,13 +91,20 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_odom_), sizeof(OdomState)));
+  // coherent (fine-grained): kernels store results and completion words here and the host reads them while the stream is live
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT, hipHostMallocCoherent));
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_odom_), sizeof(OdomState), hipHostMallocCoherent));
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_signal_), 64 * sizeof(unsigned), hipHostMallocCoherent));
+  std::memset(h_signal_, 0, 64 * sizeof(unsigned));
+  d_signal_ticket_.reserve(2);
+  LIO_HIP(hipMemset(d_signal_ticket_.p, 0, 2 * sizeof(int)));
+  if (const char *e = std::getenv("LIO_HOST_SIGNAL")) host_signal_ = std::atoi(e) != 0;
 }
 
 Estimator::~Estimator() {
   try { JoinMarg(); } catch (...) {}
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
+  if (h_signal_) (void)hipHostFree(h_signal_);
   if (h_odom_) (void)hipHostFree(h_odom_);
   if (h_ds_) (void)hipHostFree(h_ds_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -480,6 +487,8 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     std::memcpy(st.T, &tfs[size_t(W_) * 8], 8 * sizeof(float));
     LIO_HIP(hipMemcpyAsync(d_odom_.p, &st, sizeof(st), hipMemcpyHostToDevice, stream_));
     const int M = int(stacks_[W_].n);
+    const bool mail = host_signal_ && !timers_.on;
+    HostSignal sig{};
     if (M > 0) {
       const int nb = odom_round_blocks(M, 8);
       d_odom_partials_.reserve(size_t(nb) * 28);
@@ -493,17 +502,22 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
       fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0; fo.fr[0].slot_off = slot_off_[W_];
       for (int iter = 0; iter < 10; ++iter) {
         if (iter == chunk_end[chunk]) {
-          LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));  // pinned: a pageable target costs ~10 us more
-          LIO_HIP(hipStreamSynchronize(stream_));
+          if (mail) {
+            wait_host_signal(sig, stream_);   // the round before this one has posted its state
+          } else {
+            LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));  // pinned: a pageable target costs ~10 us more
+            LIO_HIP(hipStreamSynchronize(stream_));
+          }
           st = *h_odom_;
           if (st.converged) { have_state = true; break; }
           ++chunk;
         }
+        if (mail) { sig.flag = h_signal_ + 16; sig.seq = ++signal_seq_[1]; }
         // one round = search + plane fit + rows (k_odom_round) and fold + 6x6 step (k_odom_update_wide)
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
         launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                          f_score_.p, d_odom_partials_.p, stream_);
+                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig);
         timers_.end(t1h, stream_);
       }
     }
@@ -511,8 +525,12 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // itself only needs the final state, which a converged peek has already delivered
     LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (!have_state) {
-      LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
-      LIO_HIP(hipStreamSynchronize(stream_));
+      if (sig.flag) {
+        wait_host_signal(sig, stream_);
+      } else {
+        LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(st), hipMemcpyDeviceToHost, stream_));
+        LIO_HIP(hipStreamSynchronize(stream_));
+      }
       st = *h_odom_;
       timers_.resolve();
     }
@@ -691,7 +709,12 @@ void Estimator::LidarLaunch(const WindowParams &P) {
     rccl_all_reduce_sum_f64(rccl_comm_, d_moment_out_.p, size_t(Wo_) * LIO_MOMENT_OUT, stream_);
     LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
   } else {
-    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_);
+    moment_signal_ = HostSignal();
+    if (host_signal_ && !fold_in_kernel_ && !timers_.on) {
+      moment_signal_.ticket = d_signal_ticket_.p; moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0];
+    }
+    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_,
+                         moment_signal_);
   }
   timers_.end(th, stream_);
 }
@@ -749,7 +772,8 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
 void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   const double t_dbg0 = now_ms();
   struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
-  LIO_HIP(hipStreamSynchronize(stream_));
+  if (moment_signal_.flag && !rccl_comm_) wait_host_signal(moment_signal_, stream_);
+  else LIO_HIP(hipStreamSynchronize(stream_));
   dbg_sync_ms_ += now_ms() - t_dbg0;
   timers_.resolve();
   if (shard_world_ > 1 && allreduce_ && !rccl_comm_) {

@@ -35,7 +35,7 @@ struct MomentArgs {
 // tickets: nframes ints, zero before the first launch (the kernel re-zeroes them) -> the fold runs inside the same launch;
 // tickets == nullptr -> separate k_moment_reduce launch.
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
-                          hipStream_t s);
+                          hipStream_t s, const HostSignal &sig = HostSignal());
 int moment_blocks_per_frame(int max_slots);
 int moment_blocks_per_frame_batched(int max_slots, int nframes);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const 
 // by two xor-shuffles: the same additions in the same order as one lane with four interleaved chains, at a quarter of the
 // dependent-load depth (4.9 -> 2.x us at 39 blocks per frame).  Grid (frames, 3), 384 threads: 96 values per block.
 #define REDUCE_THREADS 384
-__global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out) {
+__global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *__restrict__ partials, int bpf, double *__restrict__ out, HostSignal sig) {
   const int k = blockIdx.y * (REDUCE_THREADS / 4) + (threadIdx.x >> 2), q = threadIdx.x & 3;
   const bool in = k < 258;
   const double *src = partials + size_t(blockIdx.x) * bpf * LIO_MOMENT_OUT + (in ? k : 0);
@@ -326,6 +326,17 @@ __global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   if (in && q == 0) out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = v;
+  if (sig.flag) {   // the last block to get here tells the host that every block's results are out
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nblk = int(gridDim.x * gridDim.y);
+      if (atomicAdd(sig.ticket, 1) == nblk - 1) {
+        *sig.ticket = 0;
+        post_host_signal(sig);
+      }
+    }
+  }
 }
 
 int moment_blocks_per_frame_batched(int max_slots, int nframes) {
@@ -342,12 +353,12 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
     hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
-  hipLaunchKernelGGL(k_moment_reduce, dim3(nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, blocks_per_frame, out);
+  hipLaunchKernelGGL(k_moment_reduce, dim3(nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, blocks_per_frame, out, HostSignal());
   LIO_HIP(hipGetLastError());
 }
 
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
-                          hipStream_t s) {
+                          hipStream_t s, const HostSignal &sig) {
   if (a.nframes <= 0) return;
   int max_slots = 0;
   for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
@@ -355,7 +366,7 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
     hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
-  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, a.blocks_per_frame, out);
+  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, a.blocks_per_frame, out, sig);
   LIO_HIP(hipGetLastError());
 }
 

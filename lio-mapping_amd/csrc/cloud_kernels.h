@@ -38,7 +38,8 @@ class VoxelGridDev {
   // Filters `in` (device, n points) with cubic leaf; result in `out`; returns the output count (host sync).
   // host_params (optional) receives the bounds used.
   size_t run(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s, VoxParams *host_params = nullptr);
-  // the same in two halves: launch() only enqueues, finish() waits on that stream and returns the count
+  // the same in two halves: launch() only enqueues; finish() returns the count as soon as the device has posted it — the
+  // centroids themselves may still be in flight on `s`, so consumers on OTHER streams must wait for `s` through an event
   void launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s);
   size_t finish(VoxParams *host_params = nullptr);
   VoxelGridDev() = default;
@@ -48,14 +49,21 @@ class VoxelGridDev {
 
  private:
   const float4 *p_in_ = nullptr; size_t p_n_ = 0; DBuf<float4> *p_out_ = nullptr; hipStream_t p_stream_ = nullptr;  // the pending launch
+  float p_leaf_ = 0.f;
+  void enqueue(bool exact);
   int *h_count_ = nullptr;          // pinned: output count, followed by the VoxParams
   VoxParams *h_params_ = nullptr;
   DBuf<float> partial_;
   DBuf<VoxParams> params_;
   DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
-  DBuf<int> flags_, pos_, count_;
+  DBuf<int> count_, tile_heads_;
   DBuf<char> tmp_;
+  unsigned *h_flag_ = nullptr;      // completion word behind the mailbox (dev.h: HostSignal)
+  unsigned seq_ = 0;
+  HostSignal sig_{};
 };
+// LIO_HOST_SIGNAL=0: every wait is a hipStreamSynchronize again
+bool host_signal_enabled();
 
 struct GridDesc {
   int origin[3];   // cell coordinate of cell (0,0,0)

@@ -156,31 +156,153 @@ __global__ void k_vox_keys(const float4 *__restrict__ pts, int n, float inv_leaf
   vals[i] = uint32_t(i);
 }
 
-__global__ void k_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k = keys[i];
-  flags[i] = (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+// The fast path needs no bounds before the keys.  PCL's voxel index i0 + i1 * div0 + i2 * div0 * div1 (cells relative to the
+// cloud's minimum) orders the voxels lexicographically by (cell_z, cell_y, cell_x), and so does any key that packs the ABSOLUTE
+// cells floor(p * inverse_leaf) with a fixed offset per axis: 10 bits for z, 11 for y and x (+-204 m x +-409 m x +-409 m at a
+// 0.4 m leaf).  A cloud that leaves that range raises `range_overflow` and the filter reruns with PCL's own index (exact path
+// below).  The same pass leaves the per-block bounds the later kernels and the host need (VoxParams); they are folded by the
+// extra block of k_vox_tile_heads, after the sort, so nothing waits for them.
+#define VOX_KEY_THREADS 256
+__global__ void __launch_bounds__(VOX_KEY_THREADS) k_vox_keys_abs(const float4 *__restrict__ pts, int n, float inv_leaf, uint32_t *__restrict__ keys,
+                                                                 uint32_t *__restrict__ vals, float *__restrict__ partial, int *__restrict__ range_overflow) {
+  const int i = blockIdx.x * VOX_KEY_THREADS + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float cnt = 0;
+  if (i < n) {
+    const float4 p = pts[i];
+    uint32_t key = 0xFFFFFFFFu;
+    if (finite3(p)) {
+      cnt = 1.f;
+      mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
+      const float cx = floorf(p.x * inv_leaf), cy = floorf(p.y * inv_leaf), cz = floorf(p.z * inv_leaf);
+      if (fabsf(cx) < 1024.f && fabsf(cy) < 1024.f && fabsf(cz) < 511.f) key = (uint32_t(int(cz) + 512) << 22) | (uint32_t(int(cy) + 1024) << 11) | uint32_t(int(cx) + 1024);
+      else *range_overflow = 1;
+    }
+    keys[i] = key;
+    vals[i] = uint32_t(i);
+  }
+  __shared__ float sm[7][VOX_KEY_THREADS / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) { for (int d = 0; d < 3; ++d) { sm[d][wv] = mn[d]; sm[3 + d][wv] = mx[d]; } sm[6][wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int t = threadIdx.x;
+    float v = sm[t][0];
+    for (int w = 1; w < VOX_KEY_THREADS / 64; ++w) v = t < 3 ? fminf(v, sm[t][w]) : (t < 6 ? fmaxf(v, sm[t][w]) : v + sm[t][w]);
+    partial[size_t(blockIdx.x) * 8 + t] = v;
+  }
 }
 
-__global__ void k_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                            const int *__restrict__ flags, const int *__restrict__ pos, int n, float4 *__restrict__ out,
-                            int *__restrict__ count) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) *count = pos[i] + flags[i];
-  if (!flags[i]) return;
-  uint32_t k = keys[i];
-  float ax = 0, ay = 0, az = 0, ai = 0;
-  int e = i;
-  // stable sort => ascending original index inside the run: the within-voxel order the oracle fixes
-  while (e < n && keys[e] == k) {
-    float4 p = pts[vals[e]];
-    ax += p.x; ay += p.y; az += p.z; ai += p.w;
-    ++e;
+// heads (first entry of a run of equal keys) in each VOX_TILE-entry tile of the sorted keys
+#define VOX_TILE 256
+__device__ __forceinline__ bool vox_is_head(const uint32_t *__restrict__ keys, int i, int n, uint32_t k) {
+  return i < n && k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k);
+}
+__global__ void __launch_bounds__(VOX_TILE) k_vox_tile_heads(const uint32_t *__restrict__ keys, int n, int *__restrict__ tile_heads,
+                                                             const float *__restrict__ partial, int npartial, float inv_leaf, VoxParams *__restrict__ params) {
+  if (blockIdx.x == gridDim.x - 1) {
+    // the extra block (fast path only: npartial > 0): bounds of the cloud from k_vox_keys_abs's per-block partials -> VoxParams
+    if (npartial <= 0) return;
+    __shared__ float sm[7][VOX_TILE];
+    const int t = threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    float cnt = 0;
+    for (int b = t; b < npartial; b += VOX_TILE) {
+      for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], partial[size_t(b) * 8 + d]); mx[d] = fmaxf(mx[d], partial[size_t(b) * 8 + 3 + d]); }
+      cnt += partial[size_t(b) * 8 + 6];   // integers below 2^24: exact in any order
+    }
+    for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+    sm[6][t] = cnt;
+    __syncthreads();
+    for (int st = VOX_TILE / 2; st > 0; st >>= 1) {
+      if (t < st) {
+        for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+        sm[6][t] += sm[6][t + st];
+      }
+      __syncthreads();
+    }
+    if (t != 0) return;
+    VoxParams v;
+    long long dd[3];
+    for (int d = 0; d < 3; ++d) {
+      v.mn[d] = sm[d][0]; v.mx[d] = sm[3 + d][0];
+      dd[d] = (long long)((v.mx[d] - v.mn[d]) * inv_leaf) + 1;
+      v.minb[d] = int(floorf(v.mn[d] * inv_leaf));
+      const int maxb = int(floorf(v.mx[d] * inv_leaf));
+      v.divb[d] = maxb - v.minb[d] + 1;
+    }
+    v.overflow = (sm[6][0] > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+    v.n_valid = int(sm[6][0]);
+    *params = v;
+    return;
   }
-  float cnt = float(e - i);
-  out[pos[i]] = make_float4(ax / cnt, ay / cnt, az / cnt, ai / cnt);
+  __shared__ int swave[VOX_TILE / 64];
+  const int i = blockIdx.x * VOX_TILE + threadIdx.x;
+  const uint32_t k = i < n ? keys[i] : 0xFFFFFFFFu;
+  const unsigned long long b = __ballot(vox_is_head(keys, i, n, k));
+  if ((threadIdx.x & 63) == 0) swave[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_heads[blockIdx.x] = (swave[0] + swave[1]) + (swave[2] + swave[3]);
+}
+
+// Centroids of the sorted runs.  The tile's points are gathered into LDS by all lanes at once; the thread of a run's first
+// entry then adds the run up in sorted order (stable sort => ascending original index inside a voxel: the within-voxel order
+// the oracle fixes) out of LDS, and out of global memory only for the part of a run that leaves the tile.  One thread per run
+// walking global memory was a chain of dependent gathers: 57 us on the 150 k-point local map against 4 us like this.
+// The output slot of a run = heads in the tiles before this one + heads before it in the tile.  The last tile's block knows
+// the total and posts it (with the bounds) to the host's mailbox.
+struct VoxMail { int count; VoxParams params; int range_overflow; };
+__global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ vals, const int *__restrict__ tile_heads, int n,
+                                                            float4 *__restrict__ out, int *__restrict__ count, const VoxParams *__restrict__ params,
+                                                            const int *__restrict__ range_overflow, VoxMail *mail, HostSignal sig) {
+  __shared__ float4 sp[VOX_TILE];
+  __shared__ uint32_t sk[VOX_TILE];
+  __shared__ int swave[VOX_TILE / 64], sbase[VOX_TILE / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int base_i = blockIdx.x * VOX_TILE, i = base_i + tid;
+  int before = 0;
+  for (int b = tid; b < int(blockIdx.x); b += VOX_TILE) before += tile_heads[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  const uint32_t k = i < n ? keys[i] : 0xFFFFFFFFu;
+  sk[tid] = k;
+  if (k != 0xFFFFFFFFu) sp[tid] = pts[vals[i]];
+  const bool head = vox_is_head(keys, i, n, k);
+  const unsigned long long hb = __ballot(head);
+  if (lane == 0) { swave[wv] = __popcll(hb); sbase[wv] = before; }
+  __syncthreads();
+  int pos = (sbase[0] + sbase[1]) + (sbase[2] + sbase[3]);
+  for (int w = 0; w < wv; ++w) pos += swave[w];
+  pos += __popcll(hb & ((1ull << lane) - 1ull));
+  if (blockIdx.x == gridDim.x - 1) {   // the last tile knows the total
+    __shared__ VoxMail smail;
+    if (tid == VOX_TILE - 1) {
+      const int total = pos + (head ? 1 : 0);
+      *count = total;
+      smail.count = total; smail.params = *params; smail.range_overflow = *range_overflow;
+    }
+    if (sig.flag) {
+      __syncthreads();
+      if (tid < 64) post_host_mail(sig, mail, &smail, int(sizeof(VoxMail) / 4), tid);
+    }
+  }
+  if (!head) return;
+  float ax = 0, ay = 0, az = 0, ai = 0;
+  int e = tid;
+  while (e < VOX_TILE && sk[e] == k) { const float4 p = sp[e]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++e; }
+  int cnt = e - tid;
+  if (e == VOX_TILE) {
+    int g = base_i + VOX_TILE;
+    while (g < n && keys[g] == k) { const float4 p = pts[vals[g]]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++g; ++cnt; }
+  }
+  const float c = float(cnt);
+  out[pos] = make_float4(ax / c, ay / c, az / c, ai / c);
 }
 
 void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxParams *d_out, hipStream_t s) {
@@ -191,38 +313,72 @@ void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxPara
   LIO_HIP(hipGetLastError());
 }
 
+bool host_signal_enabled() {
+  static const bool on = [] { const char *e = std::getenv("LIO_HOST_SIGNAL"); return e ? std::atoi(e) != 0 : true; }();
+  return on;
+}
+
 // launch() enqueues the whole filter on `s` (no host sync); finish() waits for it and returns the output count.  Two
 // filters launched on two streams overlap (the scan-to-map step filters its corner and surf stacks that way).
 void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s) {
-  p_in_ = in; p_n_ = n; p_out_ = &out; p_stream_ = s;
+  p_in_ = in; p_n_ = n; p_out_ = &out; p_stream_ = s; p_leaf_ = leaf;
   if (n == 0) return;
+  enqueue(false);
+}
+
+// exact == false: absolute-cell keys, bounds folded on the side (4 stages: keys, sort, tile heads, centroids);
+// exact == true: PCL's own index from the bounds (two more launches in front), used when the cloud leaves the key's range.
+void VoxelGridDev::enqueue(bool exact) {
+  const float4 *in = p_in_;
+  const size_t n = p_n_;
+  DBuf<float4> &out = *p_out_;
+  hipStream_t s = p_stream_;
   const int ni = int(n);
-  const float inv_leaf = 1.0f / leaf;
-  const int nb = std::min(cdiv(ni, 256), 512);
-  partial_.reserve(size_t(nb) * 8);
+  const float inv_leaf = 1.0f / p_leaf_;
+  const int nkb = cdiv(ni, VOX_KEY_THREADS);
+  partial_.reserve(size_t(std::max(nkb, 512)) * 8);
   params_.reserve(1);
   keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n);
-  flags_.reserve(n); pos_.reserve(n); count_.reserve(1);
+  count_.reserve(2);
   out.reserve(n);
   if (!h_count_) {
-    LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_count_), sizeof(int) + sizeof(VoxParams)));
+    // coherent pinned memory: k_vox_centroids posts the count, the bounds and the range flag here (VoxMail), then the completion word
+    LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_count_), 256, hipHostMallocCoherent));
+    static_assert(sizeof(VoxMail) <= 128, "mailbox layout");
+    std::memset(h_count_, 0, 256);
     h_params_ = reinterpret_cast<VoxParams *>(h_count_ + 1);
+    h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_count_) + 128);
   }
-  hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, in, ni, partial_.p);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, s, partial_.p, nb, inv_leaf, params_.p);
-  hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, ni, inv_leaf, params_.p, keys_.p, vals_.p);
+  int *d_range = count_.p + 1;
+  LIO_HIP(hipMemsetAsync(d_range, 0, sizeof(int), s));
+  int npartial = 0;
+  if (exact) {
+    const int nb = std::min(cdiv(ni, 256), 512);
+    hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(256), 0, s, in, ni, partial_.p);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(256), 0, s, partial_.p, nb, inv_leaf, params_.p);
+    hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, ni, inv_leaf, params_.p, keys_.p, vals_.p);
+  } else {
+    hipLaunchKernelGGL(k_vox_keys_abs, dim3(nkb), dim3(VOX_KEY_THREADS), 0, s, in, ni, inv_leaf, keys_.p, vals_.p, partial_.p, d_range);
+    npartial = nkb;
+  }
   size_t tmp_bytes = 0;
   LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-  size_t scan_bytes = 0;
-  LIO_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
-  tmp_.reserve(std::max(tmp_bytes, scan_bytes) + 256);
+  tmp_.reserve(tmp_bytes + 256);
   LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-  hipLaunchKernelGGL(k_heads, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys2_.p, ni, flags_.p);
-  LIO_HIP(rocprim::exclusive_scan(tmp_.p, scan_bytes, flags_.p, pos_.p, 0, n, rocprim::plus<int>(), s));
-  hipLaunchKernelGGL(k_centroids, dim3(cdiv(ni, 256)), dim3(256), 0, s, in, keys2_.p, vals2_.p, flags_.p, pos_.p, ni, out.p, count_.p);
+  const int ntiles = cdiv(ni, VOX_TILE);
+  tile_heads_.reserve(ntiles);
+  hipLaunchKernelGGL(k_vox_tile_heads, dim3(ntiles + 1), dim3(VOX_TILE), 0, s, keys2_.p, ni, tile_heads_.p, partial_.p, npartial, inv_leaf, params_.p);
+  sig_ = HostSignal();
+  if (host_signal_enabled()) { sig_.flag = h_flag_; sig_.seq = ++seq_; }
+  hipLaunchKernelGGL(k_vox_centroids, dim3(ntiles), dim3(VOX_TILE), 0, s, in, keys2_.p, vals2_.p, tile_heads_.p, ni, out.p, count_.p, params_.p, d_range,
+                     reinterpret_cast<VoxMail *>(h_count_), sig_);
   LIO_HIP(hipGetLastError());
-  LIO_HIP(hipMemcpyAsync(h_count_, count_.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  LIO_HIP(hipMemcpyAsync(h_params_, params_.p, sizeof(VoxParams), hipMemcpyDeviceToHost, s));
+  if (!sig_.flag) {
+    VoxMail *m = reinterpret_cast<VoxMail *>(h_count_);
+    LIO_HIP(hipMemcpyAsync(&m->count, count_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipMemcpyAsync(&m->params, params_.p, sizeof(VoxParams), hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipMemcpyAsync(&m->range_overflow, d_range, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
 }
 
 size_t VoxelGridDev::finish(VoxParams *host_params) {
@@ -230,9 +386,15 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
     if (host_params) std::memset(host_params, 0, sizeof(*host_params));
     return 0;
   }
-  LIO_HIP(hipStreamSynchronize(p_stream_));
-  int count = *h_count_;
-  const VoxParams hp = *h_params_;
+  const VoxMail *m = reinterpret_cast<const VoxMail *>(h_count_);
+  for (int attempt = 0;; ++attempt) {
+    if (sig_.flag) wait_host_signal(sig_, p_stream_);   // the count is out; the centroids follow in stream order
+    else LIO_HIP(hipStreamSynchronize(p_stream_));
+    if (!m->range_overflow || attempt) break;
+    enqueue(true);   // cold path: the cloud spans more cells than the absolute key holds
+  }
+  int count = m->count;
+  const VoxParams hp = m->params;
   if (hp.overflow) {  // PCL: "Leaf size is too small for the input dataset" -> output = input
     p_out_->reserve(p_n_);  // the caller may have swapped the buffer since launch()
     LIO_HIP(hipMemcpyAsync(p_out_->p, p_in_, p_n_ * sizeof(float4), hipMemcpyDeviceToDevice, p_stream_));
@@ -941,7 +1103,7 @@ __global__ void __launch_bounds__(128) k_odom_round(FeatArgs a, const OdomState 
 __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
                                                            int left_update, OdomState *mail, HostSignal sig) {
   if (st->converged) {
-    if (sig.flag && threadIdx.x == 0) { *mail = *st; post_host_signal(sig); }
+    if (sig.flag && threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
     return;
   }
   __shared__ double part[32][32];
@@ -967,7 +1129,10 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
   }
   __syncthreads();
   odom_update_from_sums(ssum, st, iter, min_rows, left_update);
-  if (sig.flag && threadIdx.x == 0) { *mail = *st; post_host_signal(sig); }
+  if (sig.flag) {
+    __syncthreads();   // thread 0's update of *st is visible to wave 0
+    if (threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
+  }
 }
 
 int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, 128)); }

@@ -268,11 +268,10 @@ class Estimator {
   DBuf<long long> d_ds_prof_;
   double *h_moment_out_ = nullptr;  // pinned
   OdomState *h_odom_ = nullptr;     // pinned landing zone of the laser-odom state peeks
-  // Completion words (dev.h: HostSignal) in coherent pinned memory: [0] moments pass, [1] newest-frame round.  The host spins
-  // on them instead of hipStreamSynchronize (LIO_HOST_SIGNAL=0 restores the synchronize calls).
+  // Completion words (dev.h: HostSignal) in coherent pinned memory: [0, 96) one per block of k_moment_reduce, [128] the
+  // newest-frame round.  The host spins on them instead of hipStreamSynchronize (LIO_HOST_SIGNAL=0 restores the synchronize calls).
   unsigned *h_signal_ = nullptr;
   unsigned signal_seq_[2] = {0, 0};
-  DBuf<int> d_signal_ticket_;
   bool host_signal_ = true;
   HostSignal moment_signal_{};
   std::unique_ptr<HostState> snap_;

@@ -94,10 +94,8 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   // coherent (fine-grained): kernels store results and completion words here and the host reads them while the stream is live
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT, hipHostMallocCoherent));
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_odom_), sizeof(OdomState), hipHostMallocCoherent));
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_signal_), 64 * sizeof(unsigned), hipHostMallocCoherent));
-  std::memset(h_signal_, 0, 64 * sizeof(unsigned));
-  d_signal_ticket_.reserve(2);
-  LIO_HIP(hipMemset(d_signal_ticket_.p, 0, 2 * sizeof(int)));
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_signal_), 256 * sizeof(unsigned), hipHostMallocCoherent));
+  std::memset(h_signal_, 0, 256 * sizeof(unsigned));
   if (const char *e = std::getenv("LIO_HOST_SIGNAL")) host_signal_ = std::atoi(e) != 0;
 }
 
@@ -512,7 +510,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
           if (st.converged) { have_state = true; break; }
           ++chunk;
         }
-        if (mail) { sig.flag = h_signal_ + 16; sig.seq = ++signal_seq_[1]; }
+        if (mail) { sig.flag = h_signal_ + 128; sig.seq = ++signal_seq_[1]; }
         // one round = search + plane fit + rows (k_odom_round) and fold + 6x6 step (k_odom_update_wide)
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
@@ -711,7 +709,7 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   } else {
     moment_signal_ = HostSignal();
     if (host_signal_ && !fold_in_kernel_ && !timers_.on) {
-      moment_signal_.ticket = d_signal_ticket_.p; moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0];
+      moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0]; moment_signal_.nslots = 3 * ma.nframes;   // k_moment_reduce's grid
     }
     launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_,
                          moment_signal_);

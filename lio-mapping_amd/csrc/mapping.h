@@ -94,7 +94,7 @@ class MappingDev {
 
   lio_map_config cfg_;
   hipStream_t stream_ = nullptr, stream2_ = nullptr;   // stream2_: the surf stack's VoxelGrid beside the corner one
-  hipEvent_t ev_fork_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   ClassMap cls_[2];  // 0 corner, 1 surf
   float pz_[3] = {0, 0, 10};
   DBuf<float4> stack_all_;

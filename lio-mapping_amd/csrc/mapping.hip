@@ -260,6 +260,7 @@ MappingDev::MappingDev(const lio_map_config &cfg) : cfg_(cfg) {
   LIO_HIP(hipStreamCreate(&stream_));
   LIO_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   for (ClassMap &m : cls_) {
     m.h_counters = pinned_alloc<MapCounters>();
     m.h_bounds = pinned_alloc<VoxParams>();
@@ -278,6 +279,7 @@ MappingDev::~MappingDev() {
   }
   if (h_state_) (void)hipHostFree(h_state_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -520,6 +522,10 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   LIO_HIP(hipStreamWaitEvent(stream2_, ev_fork_, 0));
   hipStream_t vs_stream[2] = {s, stream2_};
   for (int c = 0; c < 2; ++c) cls_[c].vox.launch(cls_[c].stack_raw.p, cnt[c], leaf[c], cls_[c].stack_ds, vs_stream[c]);
+  // finish() only waits for the output COUNT (posted to the host's mailbox); the consumers on `s` wait for the surf filter's
+  // stream through an event
+  LIO_HIP(hipEventRecord(ev_join_, stream2_));
+  LIO_HIP(hipStreamWaitEvent(s, ev_join_, 0));
   for (int c = 0; c < 2; ++c) cls_[c].n_stack = cls_[c].vox.finish();
 
   const double tt2 = now_ms();

@@ -325,17 +325,14 @@ __global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *
   if (q == 0) for (int r = b4; r < bpf; ++r) v += src[size_t(r) * LIO_MOMENT_OUT];
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
-  if (in && q == 0) out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = v;
-  if (sig.flag) {   // the last block to get here tells the host that every block's results are out
-    __threadfence_system();
+  if (in && q == 0) {
+    if (sig.flag) host_store(&out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k], v);   // `out` is coherent host memory then
+    else out[size_t(blockIdx.x) * LIO_MOMENT_OUT + k] = v;
+  }
+  if (sig.flag) {   // this block's values are out: post its completion word (dev.h: HostSignal)
+    host_signal_drain();
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const int nblk = int(gridDim.x * gridDim.y);
-      if (atomicAdd(sig.ticket, 1) == nblk - 1) {
-        *sig.ticket = 0;
-        post_host_signal(sig);
-      }
-    }
+    if (threadIdx.x == 0) post_host_signal(sig, int(blockIdx.x * gridDim.y + blockIdx.y));
   }
 }
 

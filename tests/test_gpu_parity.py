@@ -38,6 +38,25 @@ def test_voxel_grid_matches_oracle(hip, oracle, n, leaf):
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("extent,leaf", [(450.0, 0.4), (60.0, 0.05), (3000.0, 0.4)])
+def test_voxel_grid_beyond_the_fast_key_range(hip, oracle, extent, leaf):
+    """The filter's fast path packs absolute cells into 10 + 11 + 11 bits; clouds that leave that range (|cell| >= 1024 in
+    x / y, 511 in z) rerun with PCL's own index from the bounds.  Both must give the oracle's cloud bit for bit, and the
+    very wide cloud trips PCL's "leaf size too small" guard (output = input)."""
+    rng = np.random.default_rng(int(extent))
+    pts = _random_cloud(rng, 20000, extent)
+    pts[:100, 2] = rng.uniform(-300, 300, 100).astype(np.float32)     # also leave the z range
+    if extent > 1000:
+        pts[:, 2] = rng.uniform(-3000, 3000, len(pts)).astype(np.float32)
+    a, b = hip.voxel_grid(pts, leaf), oracle.voxel_grid(pts, leaf)
+    np.testing.assert_array_equal(a, b)
+    if extent > 1000:
+        assert len(b) == len(pts)
+    # a well-behaved cloud right after an overflowing one through the same handle
+    small = _random_cloud(rng, 3000)
+    np.testing.assert_array_equal(hip.voxel_grid(small, 0.4), oracle.voxel_grid(small, 0.4))
+
+
 def test_voxel_grid_empty(hip):
     assert hip.voxel_grid(np.zeros((0, 4), np.float32), 0.4).shape == (0, 4)
 

@@ -419,6 +419,13 @@ int lio_est_set_extrinsic(lio_est *, const lio_transform_f *T_lb);
  * updates, csrc/solve_step.h).  LIO_ERR_STATE when A is not positive definite. */
 int lio_dense_spd_solve(const double *A, const double *b, int n, double *x_out);
 
+/* Test hook: the dense tail of MarginalizationInfo::Marginalize (MarginalizationFactor.cc:271-302) on a caller-supplied
+ * system.  A: (m + n)^2 row-major, b: m + n, the first m parameters are marginalised (m <= 15, n <= 80).  Out: lin_jac n x n
+ * row-major = diag(sqrt(s_k > 1e-8 ? s_k : 0)) V^T, lin_res n = diag(1 / sqrt(s_k) or 0) V^T bs, evals n (ascending s_k of the
+ * Schur complement).  The product runs it on the device (csrc/marg_kernels.hip: Jacobi eigensolver in LDS, Schur complement on
+ * the fp64 matrix cores) — the path LIO_DEVICE_MARG=1 switches the estimator to. */
+int lio_marginalize_schur(const double *A, const double *b, int m, int n, double *lin_jac, double *lin_res, double *evals);
+
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);

@@ -738,6 +738,15 @@ int lio_dense_spd_solve(const double *A, const double *b, int n, double *x) {
     return ok == 1 ? LIO_OK : (ok == -2 ? LIO_ERR_ARG : LIO_ERR_STATE);
   });
 }
+int lio_marginalize_schur(const double *A, const double *b, int m, int n, double *lin_jac, double *lin_res, double *evals) {
+  if (!A || !b || !lin_jac || !lin_res || m < 1 || m > MARG_MAX_M - 1 || n < 1 || n > MARG_MAX_N) return LIO_ERR_ARG;
+  return guarded([&] {
+    int dev = 0;
+    LIO_HIP(hipGetDevice(&dev));
+    MargSchurDev md(dev);
+    return md.Run(A, b, m, n, 1e-8, lin_jac, lin_res, evals, nullptr) ? LIO_OK : LIO_ERR_ARG;
+  });
+}
 int lio_est_snapshot(lio_est *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->e->Snapshot(); return LIO_OK; });

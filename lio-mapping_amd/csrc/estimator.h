@@ -15,6 +15,7 @@
 #include "cloud_kernels.h"
 #include "host_init.h"
 #include "host_solver.h"
+#include "marg_kernels.h"
 #include "solve_step.h"
 
 namespace lio {
@@ -273,6 +274,11 @@ class Estimator {
   unsigned *h_signal_ = nullptr;
   unsigned signal_seq_[2] = {0, 0};
   bool host_signal_ = true;
+  // Marginalization's dense tail on the device (marg_kernels.h), opt-in with LIO_DEVICE_MARG=1: one workgroup of Jacobi sweeps
+  // takes longer than the host's tridiagonal QL at these sizes (n = 45 .. 105), and the work is off the critical path anyway.
+  bool device_marg_ = false;
+  int device_id_ = 0;
+  std::shared_ptr<MargSchurDev> marg_dev_;
   HostSignal moment_signal_{};
   std::unique_ptr<HostState> snap_;
   std::vector<DeviceCloud> snap_stacks_;

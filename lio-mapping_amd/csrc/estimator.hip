@@ -97,6 +97,9 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_signal_), 256 * sizeof(unsigned), hipHostMallocCoherent));
   std::memset(h_signal_, 0, 256 * sizeof(unsigned));
   if (const char *e = std::getenv("LIO_HOST_SIGNAL")) host_signal_ = std::atoi(e) != 0;
+  LIO_HIP(hipGetDevice(&device_id_));
+  if (const char *e = std::getenv("LIO_DEVICE_MARG")) device_marg_ = std::atoi(e) != 0;
+  if (device_marg_) marg_dev_ = std::make_shared<MargSchurDev>(device_id_);
 }
 
 Estimator::~Estimator() {
@@ -886,6 +889,12 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
       if (pi && pi->sum_dt < 10.0) msys->pim[0] = pi;
     }
     msys->prior = last_marg_;
+    if (marg_dev_) {
+      std::shared_ptr<MargSchurDev> md = marg_dev_;   // the task may outlive a Restore(); the device object is shared
+      msys->marg_schur_hook = [md](const double *A, const double *b, int m, int n, double eps, double *jac, double *res) {
+        return md->Run(A, b, m, n, eps, jac, res, nullptr, nullptr);
+      };
+    }
     const bool have_moments = msys->use_lidar && !s.final_moments.empty();
     if (async_marg_ && (have_moments || !msys->use_lidar)) {
       // host-only from here (the lidar moments at the final point come from the solve): hand it to the worker

@@ -157,6 +157,9 @@ class WindowSystem {
   // called inside evaluate() with the prior + IMU part of (H, g) — complete for the speed-bias rows, which no lidar factor
   // touches — right before the host blocks on the device pass: the solver factors the speed-bias block there (SplitFactor)
   std::function<void(const DMat &, const std::vector<double> &)> static_part_hook;
+  // marginalize(): when set, the dense tail (Amm^+, Schur complement, both eigendecompositions, square-root factors) is handed
+  // to it — the device path (marg_kernels.h).  (A, b, m, n, eps, lin_jac n x n, lin_res n) -> false: not handled, run the host code.
+  std::function<bool(const double *, const double *, int, int, double, double *, double *)> marg_schur_hook;
 
   struct Costs { double marg = 0, pim = 0, ppp = 0, prior = 0; double total() const { return marg + pim + ppp + prior; } };
 
@@ -656,6 +659,18 @@ inline std::shared_ptr<MargPrior> marginalize(WindowSystem &sys, const WindowPar
   sys.use_prior_factor = false;
   sys.evaluate(P, lay, 1 | 2 | 4, true, &A, &b);
   sys.use_prior_factor = saved;
+  auto pr = std::make_shared<MargPrior>();
+  pr->n = n; pr->keep = keep;
+  pr->lin_jac = DMat(n, n); pr->lin_res.assign(n, 0.0);
+  auto finish = [&] {
+    for (const KeepBlock &kb : keep) {
+      const double *src = kb.kind == 0 ? Pin.pose[kb.index + 1].data() : (kb.kind == 1 ? Pin.sb[kb.index + 1].data() : Pin.ex.data());
+      pr->x0.emplace_back(src, src + kb.size);
+    }
+    pr->finalize();
+    return pr;
+  };
+  if (sys.marg_schur_hook && sys.marg_schur_hook(A.a.data(), b.data(), m, n, eps, pr->lin_jac.a.data(), pr->lin_res.data())) return finish();
   std::vector<double> Amm(size_t(m) * m), ev(m), V(size_t(m) * m);
   for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm[size_t(i) * m + j] = 0.5 * (A(i, j) + A(j, i));
   sym_eig(Amm.data(), m, ev.data(), V.data());
@@ -677,21 +692,13 @@ inline std::shared_ptr<MargPrior> marginalize(WindowSystem &sys, const WindowPar
   }
   std::vector<double> ev2(n), V2(size_t(n) * n);
   sym_eig(S.data(), n, ev2.data(), V2.data());
-  auto pr = std::make_shared<MargPrior>();
-  pr->n = n; pr->keep = keep;
-  pr->lin_jac = DMat(n, n); pr->lin_res.assign(n, 0.0);
   for (int k = 0; k < n; ++k) {
     double Sk = ev2[k] > eps ? ev2[k] : 0.0, Sik = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
     double ss = std::sqrt(Sk), sis = std::sqrt(Sik), vb = 0;
     for (int i = 0; i < n; ++i) { pr->lin_jac(k, i) = ss * V2[size_t(i) * n + k]; vb += V2[size_t(i) * n + k] * bs[i]; }
     pr->lin_res[k] = sis * vb;
   }
-  for (const KeepBlock &kb : keep) {
-    const double *src = kb.kind == 0 ? Pin.pose[kb.index + 1].data() : (kb.kind == 1 ? Pin.sb[kb.index + 1].data() : Pin.ex.data());
-    pr->x0.emplace_back(src, src + kb.size);
-  }
-  pr->finalize();
-  return pr;
+  return finish();
 }
 
 }  // namespace lio

@@ -215,6 +215,7 @@ _SIGS = {
     "lio_est_set_prior_factor": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int]),
     "lio_est_set_extrinsic": (C.c_int, [C.c_void_p, C.POINTER(TransformF)]),
     "lio_dense_spd_solve": (C.c_int, [c_double_p, c_double_p, C.c_int, c_double_p]),
+    "lio_marginalize_schur": (C.c_int, [c_double_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -305,6 +306,15 @@ class LioLib:
         x = np.zeros(n)
         _chk(self.dll.lio_dense_spd_solve(_dp(A), _dp(b), n, _dp(x)), "lio_dense_spd_solve")
         return x
+
+    def marginalize_schur(self, A, b, m):
+        """-> (lin_jac n x n, lin_res n, evals n) of MarginalizationInfo::Marginalize's dense tail (MarginalizationFactor.cc:271-302)."""
+        A, b = _f64(A), _f64(b)
+        n = b.shape[0] - m
+        assert A.shape == (m + n, m + n)
+        J, r, s = np.zeros((n, n)), np.zeros(n), np.zeros(n)
+        _chk(self.dll.lio_marginalize_schur(_dp(A), _dp(b), m, n, _dp(J), _dp(r), _dp(s)), "lio_marginalize_schur")
+        return J, r, s
 
     def voxel_grid(self, xyzi, leaf):
         xyzi = _f32(xyzi).reshape(-1, 4)

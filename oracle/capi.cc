@@ -724,6 +724,20 @@ int orc_colpiv_qr_solve_f32(int m, int n, const float *A, const float *b, float 
   colpiv_qr_solve<float>(m, n, Ac.data(), bc.data(), x);
   return 0;
 }
+int lio_marginalize_schur(const double *A, const double *b, int m, int n, double *lin_jac, double *lin_res, double *evals) {
+  if (!A || !b || !lin_jac || !lin_res || m < 1 || n < 1) return LIO_ERR_ARG;
+  const int pos = m + n;
+  Mat Am(pos, pos);
+  for (int i = 0; i < pos * pos; ++i) Am.a[i] = A[i];
+  std::vector<double> bv(b, b + pos), lr;
+  Mat lj;
+  MarginalizeSchur(Am, bv, m, n, lj, lr);
+  for (int i = 0; i < n * n; ++i) lin_jac[i] = lj.a[i];
+  for (int i = 0; i < n; ++i) lin_res[i] = lr[i];
+  if (evals)   // row k of lin_jac = sqrt(s_k) v_k^T with |v_k| = 1
+    for (int k = 0; k < n; ++k) { double s2 = 0; for (int i = 0; i < n; ++i) s2 += lj.a[size_t(k) * n + i] * lj.a[size_t(k) * n + i]; evals[k] = s2; }
+  return LIO_OK;
+}
 int orc_marginalize_schur(const double *A, const double *b, int m, int n, double *lin_jac, double *lin_res) {
   if (!A || !b || m < 1 || n < 1) return -1;
   const int pos = m + n;

@@ -553,7 +553,9 @@ void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4
 // bit-identical to the single-lane scan.  The serial dependent-load chain per lane shrinks LPQ-fold, which
 // is what bounds this kernel (a query touches ~100 candidates; maps are L2-resident).
 #define FEAT_LPQ 8
+#ifndef KNN_BATCH
 #define KNN_BATCH 4   // candidate loads in flight per lane
+#endif
 template <int K>
 __device__ __forceinline__ void knn_insert(float d, int idx, int j, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
   if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
@@ -684,29 +686,18 @@ __device__ __forceinline__ FeatScalars feat_scalars(const FeatArgs &a) {
 }
 // what the owner lane (sub == 0 of an in-range query) of features_eval comes back with
 struct FeatResult { bool owner; uint8_t ok; float4 c; float sc; float4 abs; float4 po; int slot; };
-template <bool MAPPING, int LPQ>
-__device__ __forceinline__ FeatResult features_eval(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
-                                                    const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g) {
+// The fit half of a surf feature (Estimator.cc:1021-1097 / PointMapping.cc:503-619) for ONE query whose five nearest map
+// points are known: 5x3 column-pivoted QR plane fit, validity, score, FOV.  q, t: the frame's transform; po: the stack point;
+// sel: its image; bd4 / bi4: distance and original index of the fifth neighbour; bj: positions of the five in `map`.
+template <bool MAPPING>
+__device__ __forceinline__ FeatResult features_fit(const FeatScalars &a, int slot, const Quat<float> &q, const Vec3<float> &t, const float4 &po,
+                                                   const Vec3<float> &sel, float bd4, int bi4, const int (&bj)[5], const float4 *__restrict__ map) {
   FeatResult res;
-  res.owner = false; res.ok = 0; res.c = make_float4(0, 0, 0, 0); res.sc = 0; res.abs = make_float4(0, 0, 0, 0); res.po = make_float4(0, 0, 0, 0); res.slot = 0;
-  const int gt = block_x * blockDim.x + threadIdx.x;
-  const int i = gt / LPQ, sub = gt % LPQ;
-  const bool active = i < fr.M;
-  const float *tp = transforms + 8 * fr.tf_index;
-  Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
-  Vec3<float> t(tp[4], tp[5], tp[6]);
-  float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
-  Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
-  Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
-  float bd[5]; int bi[5], bj[5];
-  knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
-  if (!active || sub != 0) return res;
-  const int slot = fr.slot_off + i;
-  res.owner = true; res.slot = slot; res.po = po;
+  res.owner = true; res.ok = 0; res.c = make_float4(0, 0, 0, 0); res.sc = 0; res.abs = make_float4(0, 0, 0, 0); res.po = po; res.slot = slot;
   uint8_t ok = 0;
   float4 c = make_float4(0, 0, 0, 0);
   float sc = 0;
-  if (bi[4] != INT_MAX && bd[4] < a.min_match_sq_dis) {
+  if (bi4 != INT_MAX && bd4 < a.min_match_sq_dis) {
     float A[15], B[5] = {-1, -1, -1, -1, -1}, X[3];
     float nx[5], ny[5], nz[5];
 #pragma unroll
@@ -753,6 +744,25 @@ __device__ __forceinline__ FeatResult features_eval(const FeatFrame fr, const Fe
   return res;
 }
 template <bool MAPPING, int LPQ>
+__device__ __forceinline__ FeatResult features_eval(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
+                                                    const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g) {
+  FeatResult res;
+  res.owner = false; res.ok = 0; res.c = make_float4(0, 0, 0, 0); res.sc = 0; res.abs = make_float4(0, 0, 0, 0); res.po = make_float4(0, 0, 0, 0); res.slot = 0;
+  const int gt = block_x * blockDim.x + threadIdx.x;
+  const int i = gt / LPQ, sub = gt % LPQ;
+  const bool active = i < fr.M;
+  const float *tp = transforms + 8 * fr.tf_index;
+  Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  Vec3<float> t(tp[4], tp[5], tp[6]);
+  float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
+  Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+  Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+  float bd[5]; int bi[5], bj[5];
+  knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+  if (!active || sub != 0) return res;
+  return features_fit<MAPPING>(a, fr.slot_off + i, q, t, po, sel, bd[4], bi[4], bj, map);
+}
+template <bool MAPPING, int LPQ>
 __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScalars a, int block_x, const float *__restrict__ transforms,
                                               const float4 *__restrict__ map, const int *__restrict__ cells, const GridDesc &g,
                                               uint8_t *__restrict__ valid, float4 *__restrict__ coef, float *__restrict__ score,
@@ -764,13 +774,56 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
   if (MAPPING && abs_coef && r.ok) abs_coef[r.slot] = r.abs;
 }
 
+// CalculateFeatures for every frame of the launch (blockIdx.y).  Two phases, like k_odom_round below: FEAT_THREADS lanes search
+// with LPQ lanes per query and park each query's five neighbours in LDS, then ONE wave runs the plane fit with a query per lane
+// (the fit used to occupy one lane in LPQ of every wave while costing all of its issue slots — these kernels are bound by
+// vector-instruction issue, not by memory).
+#define FEAT_THREADS 256
 template <bool MAPPING, int LPQ>
-__global__ void __launch_bounds__(128) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
-                                                 const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                 float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
-                                                 float4 *__restrict__ abs_coef) {
+__global__ void __launch_bounds__(FEAT_THREADS) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                                          const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                          float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
+                                                          float4 *__restrict__ abs_coef) {
   if (skip_flag && *skip_flag) return;
-  features_body<MAPPING, LPQ>(a.fr[blockIdx.y], feat_scalars(a), blockIdx.x, transforms, map, cells, g, valid, coef, score, abs_coef);
+  constexpr int QPB = FEAT_THREADS / LPQ;
+  static_assert(QPB <= 64, "the fit phase is one wave");
+  __shared__ int s_bj[QPB][5];
+  __shared__ float s_bd4[QPB];
+  __shared__ int s_bi4[QPB];
+  const FeatFrame fr = a.fr[blockIdx.y];
+  if (int(blockIdx.x) * QPB >= fr.M) return;
+  const FeatScalars fs = feat_scalars(a);
+  const float *tp = transforms + 8 * fr.tf_index;
+  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  const Vec3<float> t(tp[4], tp[5], tp[6]);
+  {
+    const int ql = threadIdx.x / LPQ, sub = threadIdx.x % LPQ;
+    const int i = blockIdx.x * QPB + ql;
+    const bool active = i < fr.M;
+    const float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
+    const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+    const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+    float bd[5]; int bi[5], bj[5];
+    knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+    if (sub == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s_bj[ql][k] = bj[k];
+      s_bd4[ql] = bd[4]; s_bi4[ql] = bi[4];
+    }
+  }
+  __syncthreads();
+  const int ql = threadIdx.x, i = blockIdx.x * QPB + ql;
+  if (ql >= QPB || i >= fr.M) return;
+  const float4 po = fr.stack[i];
+  const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+  const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+  int bj[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
+  const FeatResult res = features_fit<MAPPING>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
+  valid[res.slot] = res.ok; coef[res.slot] = res.c;
+  if (score) score[res.slot] = res.sc;
+  if (MAPPING && abs_coef && res.ok) abs_coef[res.slot] = res.abs;
 }
 
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
@@ -896,14 +949,14 @@ void launch_features(const FeatArgs &a, const float *transforms, const float4 *m
   // lanes per query: 8 when the launch is small (latency-bound: shorter per-lane candidate walks), 4 when it already fills
   // the GPU several times over (throughput-bound: fewer shuffle-merge rounds per query)
   const bool big = (long long)a.max_M * a.nframes >= 50000;
-  const dim3 grid(cdiv((long long)a.max_M * (big ? 4 : 8), 128), a.nframes);
+  const dim3 grid(cdiv((long long)a.max_M * (big ? 4 : 8), FEAT_THREADS), a.nframes);
   if (a.mapping_mode)
-    hipLaunchKernelGGL((k_features<true, 8>), dim3(cdiv((long long)a.max_M * 8, 128), a.nframes), dim3(128), 0, s, a, transforms, map_sorted, cells, g,
-                       valid, coef, score, skip_flag, abs_coef);
+    hipLaunchKernelGGL((k_features<true, 8>), dim3(cdiv((long long)a.max_M * 8, FEAT_THREADS), a.nframes), dim3(FEAT_THREADS), 0, s, a, transforms, map_sorted,
+                       cells, g, valid, coef, score, skip_flag, abs_coef);
   else if (big)
-    hipLaunchKernelGGL((k_features<false, 4>), grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
+    hipLaunchKernelGGL((k_features<false, 4>), grid, dim3(FEAT_THREADS), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
   else
-    hipLaunchKernelGGL((k_features<false, 8>), grid, dim3(128), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
+    hipLaunchKernelGGL((k_features<false, 8>), grid, dim3(FEAT_THREADS), 0, s, a, transforms, map_sorted, cells, g, valid, coef, score, skip_flag, abs_coef);
   LIO_HIP(hipGetLastError());
 }
 
@@ -1052,42 +1105,81 @@ void launch_odom_update(const double *partials, int nblocks, OdomState *st, int 
 // instead of three: the search / plane-fit kernel also forms the rows of (mat_A | mat_B) of the features it has just fitted
 // (and, with keep_features, of the ones it kept from the earlier rounds of the same point, Estimator.cc:978-980) and leaves
 // one 28-double partial per block; the update kernel folds them (fixed order), solves the 6x6 system and tests convergence.
+//
+// The kernel is bound by vector-instruction issue, not by memory (A/B on the MI355X: 4 / 8 lanes per query, 4 / 8 candidate
+// loads in flight and a merged first round trip all leave it at 34 us; 16 lanes per query make it slower).  With LPQ lanes per
+// query the fit + row half used to run on 1 lane in LPQ while costing the whole wave's issue slots, and it is as long as the
+// search half.  So the block works in two phases: all ODOM_ROUND_THREADS lanes search (LPQ per query) and park the five
+// neighbours of each of the block's ODOM_ROUND_THREADS / LPQ queries in LDS; then ONE wave fits and forms rows with one query
+// per lane (every lane busy) while the other waves retire.  Rows are summed in ascending query order: one partial per block.
+#define ODOM_ROUND_THREADS 256
 template <int LPQ>
-__global__ void __launch_bounds__(128) k_odom_round(FeatArgs a, const OdomState *__restrict__ st, const float4 *__restrict__ map,
-                                                   const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
-                                                   float *__restrict__ score, double *__restrict__ partials, int base_slot, int round, int keep) {
-  if (st->converged) return;
-  constexpr int QPB = 128 / LPQ;   // queries per block
+__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_round(FeatArgs a, const OdomState *__restrict__ st, const float4 *__restrict__ map,
+                                                                  const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                                  float4 *__restrict__ coef, float *__restrict__ score, double *__restrict__ partials,
+                                                                  int base_slot, int round, int keep) {
+  constexpr int QPB = ODOM_ROUND_THREADS / LPQ;   // queries per block
+  static_assert(QPB <= 64, "the fit phase is one wave");
+  __shared__ int s_bj[QPB][5];
+  __shared__ float s_bd4[QPB];
+  __shared__ int s_bi4[QPB];
   __shared__ double rows[QPB][29];
   FeatFrame fr = a.fr[0];
   const int M = fr.M;
   fr.slot_off = base_slot + (keep ? round * M : 0);
-  const FeatResult r = features_eval<false, LPQ>(fr, feat_scalars(a), blockIdx.x, st->T, map, cells, g);
-  const int ql = threadIdx.x / LPQ;
-  if (r.owner) {
-    valid[r.slot] = r.ok; coef[r.slot] = r.c;
-    if (score) score[r.slot] = r.sc;
-  }
-  if (threadIdx.x % LPQ == 0) {
-    double acc[28];
+  if (st->converged) return;
+  const FeatScalars fs = feat_scalars(a);
+  const float *tp = st->T;
+  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  const Vec3<float> t(tp[4], tp[5], tp[6]);
+  {   // ---- phase 1: search, LPQ lanes per query
+    const int ql = threadIdx.x / LPQ, sub = threadIdx.x % LPQ;
+    const int i = blockIdx.x * QPB + ql;
+    const bool active = i < M;
+    const float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
+    const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+    const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+    float bd[5]; int bi[5], bj[5];
+    knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
+    if (sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0;
-    if (r.owner) {
-      Quat<float> q(st->T[3], st->T[0], st->T[1], st->T[2]);
-      Vec3<float> t(st->T[4], st->T[5], st->T[6]);
-      const Mat3<float> Rm = toRot(q), Rinv = Rm;   // Rinv unused for b_from_coef = 0
-      const int i = r.slot - fr.slot_off;
-      if (keep)
-        for (int rr = 0; rr < round; ++rr) {   // the factor lists of the earlier rounds stay in the problem: ascending slot order
-          const int sl = base_slot + rr * M + i;
-          if (valid[sl]) odom_row_accumulate(r.po, coef[sl], q, t, Rm, Rinv, 0, acc);
-        }
-      if (r.ok) odom_row_accumulate(r.po, r.c, q, t, Rm, Rinv, 0, acc);
+      for (int k = 0; k < 5; ++k) s_bj[ql][k] = bj[k];
+      s_bd4[ql] = bd[4]; s_bi4[ql] = bi[4];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  // ---- phase 2 (wave 0): fit + rows, one query per lane
+  const int ql = threadIdx.x;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0;
+  const int i = blockIdx.x * QPB + ql;
+  if (ql < QPB && i < M) {
+    const float4 po = fr.stack[i];
+    const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+    const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+    int bj[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
+    const FeatResult res = features_fit<false>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
+    valid[res.slot] = res.ok; coef[res.slot] = res.c;
+    if (score) score[res.slot] = res.sc;
+    const Mat3<float> Rm = toRot(q), Rinv = Rm;   // Rinv unused for b_from_coef = 0
+    if (keep)
+      for (int rr = 0; rr < round; ++rr) {   // the factor lists of the earlier rounds stay in the problem: ascending slot order
+        const int sl = base_slot + rr * M + i;
+        if (valid[sl]) odom_row_accumulate(res.po, coef[sl], q, t, Rm, Rinv, 0, acc);
+      }
+    if (res.ok) odom_row_accumulate(res.po, res.c, q, t, Rm, Rinv, 0, acc);
+  }
+  if (ql < QPB) {
 #pragma unroll
     for (int k = 0; k < 28; ++k) rows[ql][k] = acc[k];
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (threadIdx.x < 28) {
     double v = 0;
 #pragma unroll
@@ -1135,15 +1227,13 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
   }
 }
 
-int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, 128)); }
+int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, ODOM_ROUND_THREADS)); }
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
                        uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
-  const bool big = (long long)M >= 50000;
-  const int nb = odom_round_blocks(M, big ? 4 : 8);
-  if (big) hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
-  else hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(128), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
+  const int nb = odom_round_blocks(M, 8);
+  hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());
 }

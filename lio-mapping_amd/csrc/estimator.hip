@@ -993,7 +993,7 @@ bool Estimator::Restore() {
       LIO_HIP(hipMemcpyAsync(stacks_[i].buf.p, snap_stacks_[i].buf.p, snap_stacks_[i].n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
     stacks_[i].n = snap_stacks_[i].n;
   }
-  LIO_HIP(hipStreamSynchronize(stream_));
+  // no host wait: every consumer of the stacks is ordered behind these copies on stream_ (or behind an event recorded on it)
   return true;
 }
 

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "liblio_hip.so")
+HIP_LIB_PATH = os.environ.get("LIO_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "liblio_hip.so")   # LIO_HIP_LIB: A/B builds of the product
 
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)

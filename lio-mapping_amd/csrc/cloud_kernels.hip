@@ -556,20 +556,25 @@ void launch_knn(const float4 *query, int m, int k, float radius_sq, const float4
 #ifndef KNN_BATCH
 #define KNN_BATCH 4   // candidate loads in flight per lane
 #endif
+// Top-K list ordered by (squared distance, original index).  Both live in ONE 64-bit key — the distance's bit pattern (non-negative
+// floats order like their bits) above the index — so a comparison is one v_cmp_lt_u64 instead of three compares and two logic
+// ops, and a compare-exchange moves three registers instead of three guarded by that chain.  The search kernels are bound by
+// vector-instruction issue (3473 VALU instructions per wave measured in k_odom_round before this form).
+__device__ __forceinline__ unsigned long long knn_key(float d, int idx) {
+  return (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned int>(idx);
+}
 template <int K>
-__device__ __forceinline__ void knn_insert(float d, int idx, int j, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
-  if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
-    bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = j;
+__device__ __forceinline__ void knn_insert(unsigned long long key, int j, unsigned long long (&bk)[K], int (&bj)[K]) {
+  if (key < bk[K - 1]) {
+    bk[K - 1] = key; bj[K - 1] = j;
 #pragma unroll
     for (int k = K - 1; k > 0; --k) {
-      bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
-      float td = sw ? bd[k - 1] : bd[k];
-      int ti = sw ? bi[k - 1] : bi[k];
-      int tj = sw ? bj[k - 1] : bj[k];
-      bd[k - 1] = sw ? bd[k] : bd[k - 1];
-      bi[k - 1] = sw ? bi[k] : bi[k - 1];
+      const bool sw = bk[k - 1] > bk[k];
+      const unsigned long long tk = sw ? bk[k - 1] : bk[k];
+      const int tj = sw ? bj[k - 1] : bj[k];
+      bk[k - 1] = sw ? bk[k] : bk[k - 1];
       bj[k - 1] = sw ? bj[k] : bj[k - 1];
-      bd[k] = td; bi[k] = ti; bj[k] = tj;
+      bk[k] = tk; bj[k] = tj;
     }
   }
 }
@@ -584,8 +589,9 @@ __device__ __forceinline__ void knn_insert(float d, int idx, int j, float (&bd)[
 template <int K, int LPQ>
 __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub, const float4 *__restrict__ map,
                                       const int *__restrict__ cells, const GridDesc &g, float (&bd)[K], int (&bi)[K], int (&bj)[K]) {
+  unsigned long long bk[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) { bd[k] = INFINITY; bi[k] = INT_MAX; bj[k] = 0; }
+  for (int k = 0; k < K; ++k) { bk[k] = knn_key(INFINITY, INT_MAX); bj[k] = 0; }
   int cx = cell_coord(q.x, g.inv_cell) - g.origin[0];
   int cy = cell_coord(q.y, g.inv_cell) - g.origin[1];
   int cz = cell_coord(q.z, g.inv_cell) - g.origin[2];
@@ -610,7 +616,7 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
             float d = ddx * ddx;
             d += ddy * ddy;
             d += ddz * ddz;
-            knn_insert<K>(d, __float_as_int(pc.w), j, bd, bi, bj);
+            knn_insert<K>(knn_key(d, __float_as_int(pc.w)), j, bk, bj);
           }
         }
       }
@@ -648,7 +654,7 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
           float d = ddx * ddx;
           d += ddy * ddy;
           d += ddz * ddz;
-          knn_insert<K>(d, __float_as_int(p[b].w), jj[b], bd, bi, bj);
+          knn_insert<K>(knn_key(d, __float_as_int(p[b].w)), jj[b], bk, bj);
         }
       }
     }
@@ -656,28 +662,18 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
   // butterfly merge of the LPQ partial lists (every lane of the wave takes part in the shuffles)
 #pragma unroll
   for (int m = 1; m < LPQ; m <<= 1) {
-    float od[K]; int oi[K], oj[K];
+    unsigned long long ok[K]; int oj[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { od[k] = __shfl_xor(bd[k], m, 64); oi[k] = __shfl_xor(bi[k], m, 64); oj[k] = __shfl_xor(bj[k], m, 64); }
-#pragma unroll
-    for (int c = 0; c < K; ++c) {
-      float d = od[c]; int idx = oi[c];
-      if (d < bd[K - 1] || (d == bd[K - 1] && idx < bi[K - 1])) {
-        bd[K - 1] = d; bi[K - 1] = idx; bj[K - 1] = oj[c];
-#pragma unroll
-        for (int k = K - 1; k > 0; --k) {
-          bool sw = bd[k - 1] > bd[k] || (bd[k - 1] == bd[k] && bi[k - 1] > bi[k]);
-          float td = sw ? bd[k - 1] : bd[k];
-          int ti = sw ? bi[k - 1] : bi[k];
-          int tj = sw ? bj[k - 1] : bj[k];
-          bd[k - 1] = sw ? bd[k] : bd[k - 1];
-          bi[k - 1] = sw ? bi[k] : bi[k - 1];
-          bj[k - 1] = sw ? bj[k] : bj[k - 1];
-          bd[k] = td; bi[k] = ti; bj[k] = tj;
-        }
-      }
+    for (int k = 0; k < K; ++k) {
+      const unsigned int lo = __shfl_xor(static_cast<unsigned int>(bk[k]), m, 64), hi = __shfl_xor(static_cast<unsigned int>(bk[k] >> 32), m, 64);
+      ok[k] = (static_cast<unsigned long long>(hi) << 32) | lo;
+      oj[k] = __shfl_xor(bj[k], m, 64);
     }
+#pragma unroll
+    for (int c = 0; c < K; ++c) knn_insert<K>(ok[c], oj[c], bk, bj);
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k) { bd[k] = __uint_as_float(static_cast<unsigned int>(bk[k] >> 32)); bi[k] = int(static_cast<unsigned int>(bk[k])); }
 }
 
 struct FeatScalars { float min_match_sq_dis, min_plane_dis; int mapping_mode; float fixed_pz[3]; };

@@ -86,8 +86,12 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_moment_out_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));   // the two pad entries per frame stay zero under the all-reduce
   d_moment_tickets_.reserve(LIO_MAX_FRAMES);
   LIO_HIP(hipMemset(d_moment_tickets_.p, 0, LIO_MAX_FRAMES * sizeof(int)));
-  // measured on the MI355X: fold inside the launch 18.8 us vs moments + separate reduce launch 13.6 us per linearisation
-  fold_in_kernel_ = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL") != nullptr;
+  LIO_HIP(hipDeviceSynchronize());   // the memsets above run on the null stream; the kernels that read them on streams of our own
+  // Fold inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL=1) or as a separate k_moment_reduce launch (default).  Measured
+  // on the MI355X per linearisation: in-kernel fold with agent-scope fences 18.8 us (round 1), with the fence-free sc1
+  // store / load / relaxed-ticket protocol 18.8 us again (round 2: 39 serialised ticket adds and memory-side loads per frame
+  // cost what the fences did), two launches 12.5 us.
+  if (const char *e = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL")) fold_in_kernel_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
@@ -711,8 +715,10 @@ void Estimator::LidarLaunch(const WindowParams &P) {
     LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
   } else {
     moment_signal_ = HostSignal();
-    if (host_signal_ && !fold_in_kernel_ && !timers_.on) {
-      moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0]; moment_signal_.nslots = 3 * ma.nframes;   // k_moment_reduce's grid
+    if (host_signal_ && !timers_.on) {
+      // one completion word per block of the kernel that writes the result: k_moment_reduce's (frames, 3) grid, or the
+      // last-ticket block of each frame when the fold runs inside k_lidar_moments
+      moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0]; moment_signal_.nslots = (fold_in_kernel_ ? 1 : 3) * ma.nframes;
     }
     launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_,
                          moment_signal_);

@@ -138,7 +138,8 @@ void launch_odom_rows(const float4 *stack, int M, int nslots, const uint8_t *val
 // reduce + 6x6 solve + degeneracy mask + transform update + convergence test (Estimator.cc:1303-1357)
 // min_rows > 0: a round with fewer selected rows leaves the transform untouched (`continue`, PointMapping.cc:623-626).
 // left_update != 0: rot = DeltaQ(x) * rot (MapBuilder.cc:978-979) instead of rot * DeltaQ(x).
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0, int left_update = 0);
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows = 0, int left_update = 0,
+                        OdomState *mail = nullptr, const HostSignal &sig = HostSignal());
 int odom_rows_blocks(int nslots);
 // One round of the newest frame's loop in two launches (search + plane fit + rows per block; fold + update).  a.fr[0] names the
 // stack; slots of round r start at base_slot (+ r * M with keep != 0: keep_features, Estimator.cc:978-980); partials holds

@@ -1086,13 +1086,18 @@ __device__ __forceinline__ void odom_update_from_sums(const double *ssum, OdomSt
   if (double(delta_r) < 0.05 && double(delta_t) < 0.05) st->converged = 1;
 }
 
-__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows, int left_update) {
-  if (st->converged) return;
-  odom_update_body(partials, nblocks, st, iter, min_rows, left_update);
+__global__ void k_odom_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows, int left_update, OdomState *mail,
+                              HostSignal sig) {
+  if (!st->converged) odom_update_body(partials, nblocks, st, iter, min_rows, left_update);
+  if (sig.flag) {   // the rounds at which the host looks at the convergence flag post the state to its mailbox (dev.h)
+    __syncthreads();
+    if (threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
+  }
 }
 
-void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update) {
-  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(256), 0, s, partials, nblocks, st, iter, min_rows, left_update);
+void launch_odom_update(const double *partials, int nblocks, OdomState *st, int iter, hipStream_t s, int min_rows, int left_update, OdomState *mail,
+                        const HostSignal &sig) {
+  hipLaunchKernelGGL(k_odom_update, dim3(1), dim3(256), 0, s, partials, nblocks, st, iter, min_rows, left_update, mail, sig);
   LIO_HIP(hipGetLastError());
 }
 

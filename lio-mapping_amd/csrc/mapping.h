@@ -102,7 +102,9 @@ class MappingDev {
   DBuf<float4> f_coef_, f_abs_;
   DBuf<OdomState> d_state_;
   DBuf<double> d_partials_;
-  OdomState *h_state_ = nullptr;  // pinned
+  OdomState *h_state_ = nullptr;  // pinned, coherent: the state's mailbox
+  unsigned *h_flag_ = nullptr;    // its completion word
+  unsigned seq_ = 0;
   size_t n_score_slots_ = 0;
   bool score_ready_ = false;
   size_t n_from_map_[2] = {0, 0};  // sizes of laser_cloud_{corner,surf}_from_map_ of the last Process

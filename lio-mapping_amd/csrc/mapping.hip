@@ -268,7 +268,11 @@ MappingDev::MappingDev(const lio_map_config &cfg) : cfg_(cfg) {
     m.bounds.reserve(1);
     m.cube_bounds.reserve(LIO_MAP_MAX_VALID * 6);
   }
-  h_state_ = pinned_alloc<OdomState>();
+  // coherent: the update kernel posts the state and a completion word here (dev.h: HostSignal)
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_state_), 128, hipHostMallocCoherent));
+  static_assert(sizeof(OdomState) <= 64, "mailbox layout");
+  std::memset(h_state_, 0, 128);
+  h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_state_) + 64);
   d_state_.reserve(1);
 }
 
@@ -604,15 +608,22 @@ void MappingDev::Optimize(bool four_dof) {
     int until = max_it;
     while (peek_i < 4 && kPeek[peek_i] <= iter) ++peek_i;
     if (peek_i < 4) until = std::min(max_it, kPeek[peek_i]);
+    HostSignal sig{};
     for (; iter < until; ++iter) {
       // the corner (line) and surf (plane) searches of a round are independent: one launch, blockIdx.y picks the branch
       launch_map_round(fa, stack_all_.p, Mc, d_T, mc.grid.sorted(), mc.grid.cells(), mc.grid.desc(), ms.grid.sorted(), ms.grid.cells(), ms.grid.desc(),
                        f_valid_.p, f_coef_.p, f_abs_.p, d_conv, s);
       launch_odom_rows(stack_all_.p, M, M, f_valid_.p, f_coef_.p, d_state_.p, d_partials_.p, nb, s, four_dof ? 2 : 1);
-      launch_odom_update(d_partials_.p, nb, d_state_.p, iter, s, 50, four_dof ? 1 : 0);
+      // the last round before a look at the convergence flag posts the state to the host's mailbox (dev.h: HostSignal)
+      if (iter == until - 1 && host_signal_enabled()) { sig.flag = h_flag_; sig.seq = ++seq_; }
+      launch_odom_update(d_partials_.p, nb, d_state_.p, iter, s, 50, four_dof ? 1 : 0, h_state_, sig);
     }
-    LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(OdomState), hipMemcpyDeviceToHost, s));
-    LIO_HIP(hipStreamSynchronize(s));
+    if (sig.flag) {
+      wait_host_signal(sig, s);
+    } else {
+      LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(OdomState), hipMemcpyDeviceToHost, s));
+      LIO_HIP(hipStreamSynchronize(s));
+    }
     if (h_state_->converged) done = true;
   }
   st = *h_state_;

@@ -33,7 +33,9 @@ class OdometryDev {
   DBuf<float> partial_c_, partial_s_;
   DBuf<VoxParams> bounds_;
   VoxParams *h_bounds_ = nullptr;  // pinned
-  OdomState *h_state_ = nullptr;   // pinned
+  OdomState *h_state_ = nullptr;   // pinned, coherent: the state's mailbox
+  unsigned *h_flag_ = nullptr;     // its completion word
+  unsigned seq_ = 0;
 };
 
 }  // namespace lio

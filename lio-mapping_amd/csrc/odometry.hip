@@ -247,11 +247,22 @@ __global__ void __launch_bounds__(ODO_ROW_THREADS) k_odo_rows(OdoArgs a, const O
   }
 }
 
-__global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter) {
-  if (st->converged) return;
-  __shared__ double ssum[28];
-  reduce_partials28(partials, nblocks, ssum);
-  if (threadIdx.x != 0) return;
+// the serial 6x6 step of one iteration (thread 0); see k_odo_update
+__device__ __forceinline__ void odo_update_step(const double *ssum, OdomState *st, int iter);
+// mail / sig: at the iterations where the host looks at the convergence flag (every fifth) the state is posted to its mailbox
+// (dev.h: HostSignal) instead of being fetched with a copy + stream synchronisation
+__global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, OdomState *mail, HostSignal sig) {
+  if (!st->converged) {
+    __shared__ double ssum[28];
+    reduce_partials28(partials, nblocks, ssum);
+    if (threadIdx.x == 0) odo_update_step(ssum, st, iter);
+  }
+  if (sig.flag) {
+    __syncthreads();
+    if (threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
+  }
+}
+__device__ __forceinline__ void odo_update_step(const double *ssum, OdomState *st, int iter) {
   double sum[28];
   for (int k = 0; k < 28; ++k) sum[k] = ssum[k];
   st->iters = iter + 1;
@@ -358,7 +369,12 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
     return;
   }
   if (enable_odom_) {
-    if (!h_state_) LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_state_), sizeof(OdomState), hipHostMallocDefault));
+    if (!h_state_) {   // coherent: k_odo_update posts the state and its completion word here (dev.h: HostSignal)
+      LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_state_), 128, hipHostMallocCoherent));
+      static_assert(sizeof(OdomState) <= 64, "mailbox layout");
+      std::memset(h_state_, 0, 128);
+      h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_state_) + 64);
+    }
     OdomState st{};
     st.T[0] = transform_es_.rot.x; st.T[1] = transform_es_.rot.y; st.T[2] = transform_es_.rot.z; st.T[3] = transform_es_.rot.w;
     st.T[4] = transform_es_.pos.x; st.T[5] = transform_es_.pos.y; st.T[6] = transform_es_.pos.z;
@@ -374,22 +390,42 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
                 no_deskew_ ? 1 : 0, grid_c_.sorted(), grid_c_.cells(), grid_c_.desc(), grid_s_.sorted(), grid_s_.cells(), grid_s_.desc()};
       const int nb = std::max(1, std::min(cdiv(nq, ODO_ROW_THREADS), 64));
       d_partials_.reserve(size_t(nb) * 28);
+      const bool mail = host_signal_enabled();
+      HostSignal sig{};
+      bool have_state = false;
       for (int iter = 0; iter < max_iter_; ++iter) {
-        if (iter > 0 && iter % 5 == 0) {  // peek at the abort flag where the reference refreshes correspondences
-          LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));  // pinned landing zone
-          LIO_HIP(hipStreamSynchronize(s));
+        if (iter > 0 && iter % 5 == 0) {  // look at the abort flag where the reference refreshes correspondences
+          if (mail) {
+            wait_host_signal(sig, s);
+          } else {
+            LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));  // pinned landing zone
+            LIO_HIP(hipStreamSynchronize(s));
+          }
           st = *h_state_;
-          if (st.converged) break;
+          if (st.converged) { have_state = true; break; }
         }
         if (nq > 0 && iter % 5 == 0) hipLaunchKernelGGL(k_odo_corr, dim3(nq), dim3(64), 0, s, a, d_state_.p, idx_.p);
         hipLaunchKernelGGL(k_odo_rows, dim3(nb), dim3(ODO_ROW_THREADS), 0, s, a, d_state_.p, idx_.p, iter, d_partials_.p);
-        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(256), 0, s, d_partials_.p, nb, d_state_.p, iter);
+        const bool post = mail && (iter % 5 == 4 || iter == max_iter_ - 1);
+        HostSignal sg{};
+        if (post) { sig.flag = h_flag_; sig.seq = ++seq_; sg = sig; }
+        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(256), 0, s, d_partials_.p, nb, d_state_.p, iter, h_state_, sg);
       }
       LIO_HIP(hipGetLastError());
+      if (!have_state) {
+        if (sig.flag) {
+          wait_host_signal(sig, s);
+        } else {
+          LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
+          LIO_HIP(hipStreamSynchronize(s));
+        }
+        st = *h_state_;
+      }
+    } else {
+      LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
+      LIO_HIP(hipStreamSynchronize(s));
+      st = *h_state_;
     }
-    LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
-    LIO_HIP(hipStreamSynchronize(s));
-    st = *h_state_;
     iterations_done_ = st.iters;
     last_num_sel_ = int(st.T[7]);
     transform_es_ = Rigid<float>(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));

@@ -601,23 +601,34 @@ __device__ inline void knn_scan_group(const Vec3<float> &q, bool active, int sub
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dims[0] - 1);
     if constexpr (LPQ <= 2) {
       // throughput regime (one or two lanes per query — the keyframe batch: tens of millions of queries keep every CU full and
-      // the kernel runs under a 64-VGPR cap): the plain run-by-run walk, nothing held in batch registers
-      for (int dz = -1; dz <= 1; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= g.dims[2]) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int y = cy + dy;
-          if (y < 0 || y >= g.dims[1]) continue;
-          const int row = g.dims[0] * (y + g.dims[1] * z);
-          const int a = cells[row + x0], e = cells[row + x1 + 1];
-          for (int j = a + sub; j < e; j += LPQ) {
-            const float4 pc = map[j];
-            float ddx = pc.x - q.x, ddy = pc.y - q.y, ddz = pc.z - q.z;
-            float d = ddx * ddx;
-            d += ddy * ddy;
-            d += ddz * ddz;
-            knn_insert<K>(knn_key(d, __float_as_int(pc.w)), j, bk, bj);
-          }
+      // the kernel runs under a 64-VGPR cap): the plain run-by-run walk, nothing held in batch registers.  Measured there
+      // (profiles/r2_pmc_sq_search_kernels.md): 5-8 k vector instructions per wave, 70 % of the kernel's time in VALU issue, and
+      // with a query per lane the ~35-instruction insertion runs for every candidate (some lane always inserts).  So whole
+      // rows are skipped: the query's own row is walked first, then the rows sharing a face, then the corners, and a row is
+      // entered only if the distance from the query to that row of cells (a lower bound for every point in it, shrunk by
+      // 1e-3 cell against rounding of the cell arithmetic) does not exceed the current fifth-best distance.  Exact: a skipped
+      // row cannot hold a candidate that would enter the list.
+      const float uy = q.y * g.inv_cell, uz = q.z * g.inv_cell;
+      const float fy = uy - floorf(uy), fz = uz - floorf(uz);
+      const float cell = 1.0f / g.inv_cell;
+      const float ey_lo = fmaxf(fy - 1e-3f, 0.f) * cell, ey_hi = fmaxf(1.0f - fy - 1e-3f, 0.f) * cell;
+      const float ez_lo = fmaxf(fz - 1e-3f, 0.f) * cell, ez_hi = fmaxf(1.0f - fz - 1e-3f, 0.f) * cell;
+      for (int r = 0; r < 9; ++r) {
+        // (dy, dz) + 1 packed two bits each: own row, four face rows, four corner rows
+        const int dy = int((0x22161u >> (2 * r)) & 3u) - 1, dz = int((0x28215u >> (2 * r)) & 3u) - 1;
+        const int z = cz + dz, y = cy + dy;
+        if (z < 0 || z >= g.dims[2] || y < 0 || y >= g.dims[1]) continue;
+        const float ey = dy < 0 ? ey_lo : (dy > 0 ? ey_hi : 0.f), ez = dz < 0 ? ez_lo : (dz > 0 ? ez_hi : 0.f);
+        if (ey * ey + ez * ez > __uint_as_float(static_cast<unsigned int>(bk[K - 1] >> 32))) continue;
+        const int row = g.dims[0] * (y + g.dims[1] * z);
+        const int a = cells[row + x0], e = cells[row + x1 + 1];
+        for (int j = a + sub; j < e; j += LPQ) {
+          const float4 pc = map[j];
+          float ddx = pc.x - q.x, ddy = pc.y - q.y, ddz = pc.z - q.z;
+          float d = ddx * ddx;
+          d += ddy * ddy;
+          d += ddz * ddz;
+          knn_insert<K>(knn_key(d, __float_as_int(pc.w)), j, bk, bj);
         }
       }
     } else {

@@ -61,7 +61,7 @@ class FilterModel:
             even = abs(norm_rad(step_used - step_seen)) < 0.05
             for k in range(9, 0, -1):
                 even = even and abs(norm_rad(self.seen[k] - self.seen[k - 1] - step_used)) < 0.05
-            if even:
+            if even and ring0_front is not None:      # ring 0 empty: the reference dereferences an empty cloud; the value is kept
                 s = ring0_front
         self.used = (self.used + [s])[-10:]
         return s

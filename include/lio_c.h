@@ -104,6 +104,13 @@ int lio_odom_process(lio_odom *, const float *sharp_xyzi, size_t n_sharp, const 
                      const float *flat_xyzi, size_t n_flat, const float *less_flat_xyzi, size_t n_less_flat,
                      lio_transform_f *transform_sum_out, lio_transform_f *transform_es_out, int *iterations_out,
                      int *num_selected_out);
+/* The iterations of the last lio_odom_process, one record each (SURVEY.md §8(d) config 2 compares them one by one):
+ * trace[k] = transform_es_ at the end of iteration k (PointOdometry.cc:337-652; an iteration with fewer than 10 selected
+ * rows leaves it unchanged, :535).  Returns the number of iterations run (<= num_max_iterations; 0 for the first call, a
+ * disabled odometry or too small previous clouds) and copies min(that, capacity) records.  kz_out (may be null): the number
+ * of leading update components zeroed by the degeneracy test of iteration 0 (:584-615, eigenvalues of AtA below 10;
+ * the reference's mat_P is diag(0..0,1..1)); 0 = not degenerate. */
+int lio_odom_get_iteration_trace(const lio_odom *, lio_transform_f *trace_or_null, int capacity, int *kz_out);
 /* /enable_odom service (PointOdometry.h:126-131): 0 turns the step into a packer (A.18) */
 int lio_odom_enable(lio_odom *, int on);
 /* last_corner_cloud_ / last_surf_cloud_ after the swap (:667-668), i.e. the TransformToEnd outputs.
@@ -160,6 +167,10 @@ void lio_map_destroy(lio_map *);
 int lio_map_process(lio_map *, const float *corner_last_xyzi, size_t n_corner, const float *surf_last_xyzi, size_t n_surf,
                     const lio_transform_f *transform_sum, lio_transform_f *transform_aft_mapped_out, int *iterations_out,
                     int *num_selected_out);
+/* is_degenerate of the last Process's OptimizeTransformTobeMapped (PointMapping.cc:650-680; MapBuilder::OptimizeMap,
+ * MapBuilder.cc:930-960): returns 1 / 0 (< 0 on error); kz_out (may be null) = leading eigenvalues of AtA below 100 in
+ * round 0 = leading components of every round's update that were zeroed. */
+int lio_map_get_degeneracy(const lio_map *, int *kz_out);
 /* SetInitFlag (:299-301): once set, Process neither applies the odometry increment nor updates the map */
 int lio_map_set_init_flag(lio_map *, int imu_inited);
 /* transform_tobe_mapped_ accessors (the estimator overwrites it after init, Estimator.cc:796-797) */
@@ -203,6 +214,8 @@ int lio_kf_batch_clear_keyframes(lio_kf_batch *);
  * device_ms_or_null (HIP library only; 0 from the oracle) = device time of the round loop. */
 int lio_kf_batch_refine(lio_kf_batch *, lio_transform_f *T_out_or_null, int32_t *iterations_or_null, int32_t *rows_or_null,
                         double *device_ms_or_null);
+/* kz of every keyframe's last refine (see lio_map_get_degeneracy); n_keyframes entries.  LIO_ERR_STATE before the first refine. */
+int lio_kf_batch_get_degeneracy(const lio_kf_batch *, int32_t *kz_out);
 size_t lio_kf_batch_size(const lio_kf_batch *);
 
 /* ------------------------------------------------------------------------------------------------
@@ -320,6 +333,8 @@ typedef struct {
   double ms_opt;              /* "t_opt" :1993 */
   double ms_marg;             /* "whole marginalization costs" :2247 */
   double ms_total;            /* "tic_toc_opt" :2436 */
+  int laser_odom_kz;          /* CalculateLaserOdom's degeneracy test (Estimator.cc:1308-1339): leading eigenvalues of the newest
+                                 frame's 6x6 AtA below 100 in round 0 = leading update components zeroed in every round; 0 = none */
 } lio_solve_report;
 
 typedef struct lio_est lio_est;

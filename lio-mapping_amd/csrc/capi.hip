@@ -127,6 +127,13 @@ int lio_odom_process(lio_odom *h, const float *sharp, size_t n_sharp, const floa
     return LIO_OK;
   });
 }
+int lio_odom_get_iteration_trace(const lio_odom *h, lio_transform_f *trace, int capacity, int *kz) {
+  if (!h || capacity < 0 || (!trace && capacity)) return LIO_ERR_ARG;
+  const int n = h->o->iterations_done_;
+  for (int k = 0; k < n && k < capacity && k < int(h->o->es_trace_.size()); ++k) fromT(h->o->es_trace_[size_t(k)], &trace[k]);
+  if (kz) *kz = h->o->last_kz_;
+  return n;
+}
 int lio_odom_enable(lio_odom *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->o->enable_odom_ = on != 0;
@@ -210,6 +217,11 @@ int lio_map_process(lio_map *h, const float *corner, size_t nc, const float *sur
     if (nsel) *nsel = h->m->num_selected_;
     return LIO_OK;
   });
+}
+int lio_map_get_degeneracy(const lio_map *h, int *kz) {
+  if (!h) return LIO_ERR_ARG;
+  if (kz) *kz = h->m->kz_;
+  return h->m->degenerate_ ? 1 : 0;
 }
 int lio_map_set_init_flag(lio_map *h, int on) {
   if (!h) return LIO_ERR_ARG;
@@ -302,6 +314,13 @@ int lio_kf_batch_refine(lio_kf_batch *h, lio_transform_f *T_out, int32_t *iters,
     if (device_ms) *device_ms = h->b->device_ms_;
     return LIO_OK;
   });
+}
+int lio_kf_batch_get_degeneracy(const lio_kf_batch *h, int32_t *kz_out) {
+  if (!h || !kz_out) return LIO_ERR_ARG;
+  const auto &st = h->b->states();
+  if (st.size() != h->b->n_keyframes()) return LIO_ERR_STATE;   // no refine since the keyframe list changed
+  for (size_t k = 0; k < st.size(); ++k) kz_out[k] = st[k].kz;
+  return LIO_OK;
 }
 int lio_kf_batch_refine_gather(lio_kf_batch *h, lio_rccl *comm, int slots_per_rank, float *packed_all, double *device_ms) {
   if (!h || !comm || !packed_all || slots_per_rank < 1) return LIO_ERR_ARG;

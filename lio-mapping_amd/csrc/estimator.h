@@ -211,7 +211,7 @@ class Estimator {
   }
   std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
   std::shared_ptr<Preintegration> tmp_pre_integration_;
-  int laser_odom_iters_ = 0;
+  int laser_odom_iters_ = 0, laser_odom_kz_ = 0;
   double dbg_eval_ms_ = 0, dbg_sync_ms_ = 0; int dbg_eval_n_ = 0;  // LIO_DEBUG_TIMING: time inside LidarEval (launch + D2H + sync)
   KernelTimers timers_;
   // factor sharding across ranks (lio_est_set_factor_sharding)

@@ -483,7 +483,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     timers_.end(th, sf);
     if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
   }
-  laser_odom_iters_ = 0;
+  laser_odom_iters_ = 0; laser_odom_kz_ = 0;
   if (cfg_.imu_factor) {
     // CalculateLaserOdom: <= 10 dependent rounds, no host round trip inside (the device carries the
     // transform and the convergence flag; later launches turn into no-ops)
@@ -540,6 +540,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
       timers_.resolve();
     }
     laser_odom_iters_ = st.iters;
+    laser_odom_kz_ = st.degenerate ? st.kz : 0;
     laser_odom_transform_ = Rigidf(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));
     if (keep_mult > 1) nslots_[W_] = int(stacks_[W_].n) * std::max(1, st.iters);
   } else {
@@ -549,7 +550,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
   const double t2 = now_ms();
   if (rep) {
     rep->ms_build_map = t1 - t0; rep->ms_features = t2 - t1; rep->n_local_map = int(local_filtered_.n);
-    rep->laser_odom_iterations = laser_odom_iters_;
+    rep->laser_odom_iterations = laser_odom_iters_; rep->laser_odom_kz = laser_odom_kz_;
   }
 }
 

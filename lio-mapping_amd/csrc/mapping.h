@@ -55,6 +55,7 @@ class MappingDev {
   std::vector<uint32_t> valid_idx_;
   int iterations_ = 0, num_selected_ = 0;
   bool degenerate_ = false;
+  int kz_ = 0;   // leading update components masked by round 0's degeneracy test (PointMapping.cc:650-680)
 
  private:
   struct ClassMap {

@@ -436,7 +436,7 @@ void MappingDev::Process(const float *corner_last, size_t n_corner, const float 
   const double tt0 = now_ms();
   transform_sum_ = sum;
   score_ready_ = false;
-  iterations_ = 0; num_selected_ = 0; degenerate_ = false;
+  iterations_ = 0; num_selected_ = 0; degenerate_ = false; kz_ = 0;
   const bool builder = cfg_.map_builder != 0;
   if (builder && !system_init_) {  // MapBuilder::ProcessMap (MapBuilder.cc:227-232)
     system_init_ = true;
@@ -632,6 +632,7 @@ void MappingDev::Optimize(bool four_dof) {
   iterations_ = st.iters;
   num_selected_ = st.nsel;
   degenerate_ = st.degenerate != 0;
+  kz_ = degenerate_ ? st.kz : 0;
   transform_bef_mapped_ = transform_sum_;            // TransformUpdate (:760-763)
   transform_aft_mapped_ = transform_tobe_mapped_;
   n_score_slots_ = size_t(M);

@@ -16,6 +16,8 @@ class OdometryDev {
 
   Rigid<float> transform_es_, transform_sum_;
   int iterations_done_ = 0, last_num_sel_ = 0;
+  int last_kz_ = 0;                         // degeneracy test of iteration 0 (:584-615): leading update components masked
+  std::vector<Rigid<float>> es_trace_;      // transform_es_ after every iteration of the last Process (lio_odom_get_iteration_trace)
   bool enable_odom_ = true;
 
  private:
@@ -28,6 +30,8 @@ class OdometryDev {
   DBuf<int> idx_;              // 2*nc + 3*ns correspondence indices
   DBuf<OdomState> d_state_;
   DBuf<double> d_partials_;
+  DBuf<float> d_trace_;        // 8 floats per iteration, written by k_odo_update
+  std::vector<float> h_trace_;
   void BuildGrids();
   KnnGrid grid_c_, grid_s_;
   DBuf<float> partial_c_, partial_s_;

@@ -251,11 +251,16 @@ __global__ void __launch_bounds__(ODO_ROW_THREADS) k_odo_rows(OdoArgs a, const O
 __device__ __forceinline__ void odo_update_step(const double *ssum, OdomState *st, int iter);
 // mail / sig: at the iterations where the host looks at the convergence flag (every fifth) the state is posted to its mailbox
 // (dev.h: HostSignal) instead of being fetched with a copy + stream synchronisation
-__global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, OdomState *mail, HostSignal sig) {
+__global__ void k_odo_update(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, OdomState *mail, HostSignal sig,
+                             float *__restrict__ trace) {
   if (!st->converged) {
     __shared__ double ssum[28];
     reduce_partials28(partials, nblocks, ssum);
-    if (threadIdx.x == 0) odo_update_step(ssum, st, iter);
+    if (threadIdx.x == 0) {
+      odo_update_step(ssum, st, iter);
+      // per-iteration record of transform_es_ (lio_odom_get_iteration_trace); 32 B, read back once per sweep
+      for (int k = 0; k < 7; ++k) trace[iter * 8 + k] = st->T[k];
+    }
   }
   if (sig.flag) {
     __syncthreads();
@@ -357,7 +362,7 @@ static void upload(DBuf<float4> &b, const float *src, size_t n, hipStream_t s) {
 
 void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_sharp, size_t n_ls, const float *flat, size_t n_flat,
                           const float *less_flat, size_t n_lf) {
-  iterations_done_ = 0; last_num_sel_ = 0;
+  iterations_done_ = 0; last_num_sel_ = 0; last_kz_ = 0; es_trace_.clear();
   hipStream_t s = stream_;
   upload(less_sharp_, less_sharp, n_ls, s);
   upload(less_flat_, less_flat, n_lf, s);
@@ -390,6 +395,7 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
                 no_deskew_ ? 1 : 0, grid_c_.sorted(), grid_c_.cells(), grid_c_.desc(), grid_s_.sorted(), grid_s_.cells(), grid_s_.desc()};
       const int nb = std::max(1, std::min(cdiv(nq, ODO_ROW_THREADS), 64));
       d_partials_.reserve(size_t(nb) * 28);
+      d_trace_.reserve(size_t(max_iter_) * 8);
       const bool mail = host_signal_enabled();
       HostSignal sig{};
       bool have_state = false;
@@ -409,7 +415,7 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
         const bool post = mail && (iter % 5 == 4 || iter == max_iter_ - 1);
         HostSignal sg{};
         if (post) { sig.flag = h_flag_; sig.seq = ++seq_; sg = sig; }
-        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(256), 0, s, d_partials_.p, nb, d_state_.p, iter, h_state_, sg);
+        hipLaunchKernelGGL(k_odo_update, dim3(1), dim3(256), 0, s, d_partials_.p, nb, d_state_.p, iter, h_state_, sg, d_trace_.p);
       }
       LIO_HIP(hipGetLastError());
       if (!have_state) {
@@ -421,12 +427,22 @@ void OdometryDev::Process(const float *sharp, size_t n_sharp, const float *less_
         }
         st = *h_state_;
       }
+      if (st.iters > 0) {   // the records of the iterations that ran (every launch behind them is complete: the state came back)
+        h_trace_.resize(size_t(st.iters) * 8);
+        LIO_HIP(hipMemcpyAsync(h_trace_.data(), d_trace_.p, size_t(st.iters) * 8 * sizeof(float), hipMemcpyDeviceToHost, s));
+        LIO_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < st.iters; ++k) {
+          const float *T = &h_trace_[size_t(k) * 8];
+          es_trace_.push_back(Rigid<float>(Quat<float>(T[3], T[0], T[1], T[2]), Vec3<float>(T[4], T[5], T[6])));
+        }
+      }
     } else {
       LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, sizeof(st), hipMemcpyDeviceToHost, s));
       LIO_HIP(hipStreamSynchronize(s));
       st = *h_state_;
     }
     iterations_done_ = st.iters;
+    last_kz_ = st.degenerate ? st.kz : 0;
     last_num_sel_ = int(st.T[7]);
     transform_es_ = Rigid<float>(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));
     // :654-656 accumulate, :660-661 TransformToEnd, :663 normalise

@@ -117,6 +117,7 @@ class SolveReport(C.Structure):
         ("ms_opt", C.c_double),
         ("ms_marg", C.c_double),
         ("ms_total", C.c_double),
+        ("laser_odom_kz", C.c_int),
     ]
 
     def as_dict(self):
@@ -146,6 +147,9 @@ _SIGS = {
     "lio_odom_process": (C.c_int, [C.c_void_p] + [c_float_p, C.c_size_t] * 4 + [C.POINTER(TransformF), C.POINTER(TransformF), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lio_odom_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_odom_get_last_cloud": (C.c_size_t, [C.c_void_p, C.c_int, c_float_p]),
+    "lio_odom_get_iteration_trace": (C.c_int, [C.c_void_p, C.POINTER(TransformF), C.c_int, C.POINTER(C.c_int)]),
+    "lio_map_get_degeneracy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "lio_kf_batch_get_degeneracy": (C.c_int, [C.c_void_p, c_int32_p]),
     "lio_imu_estimate_extrinsic_rotation": (C.c_int, [C.c_size_t, C.POINTER(TransformF), C.POINTER(C.c_void_p), C.POINTER(TransformF)]),
     "lio_imu_initialization": (C.c_int, [C.c_size_t, C.POINTER(TransformF), C.POINTER(C.c_void_p), C.POINTER(TransformF), c_double_p, c_double_p, c_double_p, c_double_p]),
     "lio_map_default_config": (None, [C.POINTER(MapConfig)]),
@@ -522,7 +526,9 @@ class PointMapping:
         it, ns = C.c_int(0), C.c_int(0)
         _chk(self.lib.dll.lio_map_process(self.h, _fp(c), c.shape[0], _fp(s), s.shape[0], C.byref(Ts), C.byref(Ta), C.byref(it), C.byref(ns)),
              "lio_map_process")
-        return dict(T_aft=Ta.to_np(), iterations=it.value, num_selected=ns.value)
+        kz = C.c_int(0)
+        deg = self.lib.dll.lio_map_get_degeneracy(self.h, C.byref(kz))
+        return dict(T_aft=Ta.to_np(), iterations=it.value, num_selected=ns.value, degenerate=int(deg), kz=kz.value)
 
     def set_init_flag(self, on):
         _chk(self.lib.dll.lio_map_set_init_flag(self.h, 1 if on else 0), "lio_map_set_init_flag")
@@ -658,7 +664,9 @@ class KeyframeBatch:
         _chk(self.lib.dll.lio_kf_batch_refine(self.h, T, it.ctypes.data_as(c_int32_p), rows.ctypes.data_as(c_int32_p), C.byref(ms)),
              "lio_kf_batch_refine")
         arr = np.frombuffer(T, dtype=np.float32).reshape(-1, 7)[:n]
-        return dict(q=arr[:, :4].copy(), p=arr[:, 4:7].copy(), iterations=it[:n], rows=rows[:n], device_ms=ms.value)
+        kz = np.zeros(max(n, 1), dtype=np.int32)
+        _chk(self.lib.dll.lio_kf_batch_get_degeneracy(self.h, kz.ctypes.data_as(c_int32_p)), "lio_kf_batch_get_degeneracy")
+        return dict(q=arr[:, :4].copy(), p=arr[:, 4:7].copy(), iterations=it[:n], rows=rows[:n], kz=kz[:n], device_ms=ms.value)
 
 
 class PointOdometry:
@@ -681,7 +689,14 @@ class PointOdometry:
         for c in cl:
             args += [_fp(c), c.shape[0]]
         _chk(self.lib.dll.lio_odom_process(self.h, *args, C.byref(Ts), C.byref(Te), C.byref(it), C.byref(ns)), "lio_odom_process")
-        return dict(T_sum=Ts.to_np(), T_es=Te.to_np(), iterations=it.value, num_selected=ns.value)
+        cap = max(it.value, 1)
+        tr = (TransformF * cap)()
+        kz = C.c_int(0)
+        n = self.lib.dll.lio_odom_get_iteration_trace(self.h, tr, cap, C.byref(kz))
+        if n < 0:
+            raise LioError(f"lio_odom_get_iteration_trace -> {n}")
+        trace = np.frombuffer(tr, dtype=np.float32).reshape(-1, 7)[:n].copy()   # rows: q xyzw, p
+        return dict(T_sum=Ts.to_np(), T_es=Te.to_np(), iterations=it.value, num_selected=ns.value, trace=trace, kz=kz.value)
 
     def enable(self, on):
         _chk(self.lib.dll.lio_odom_enable(self.h, 1 if on else 0), "lio_odom_enable")

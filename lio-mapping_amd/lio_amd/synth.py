@@ -124,6 +124,50 @@ class Trajectory:
         return self.rot(t).T @ (self.acc(t) + np.array([0, 0, self.g]))
 
 
+class FixtureTrajectory:
+    """A sampled trajectory + IMU stream in the layout of the reference's test/data/imu_pose_vel*.txt (rows at a fixed rate;
+    columns t qw qx qy qz px py pz vx vy vz gx gy gz ax ay az — include/utils/LoadVirtual.h:84-106).  Poses between samples
+    are interpolated (position / velocity linearly, rotation by normalised linear interpolation of the quaternions: at
+    200 Hz the chord error is < 1e-7); accel / gyro return the SAMPLE at the nearest row, i.e. the recorded stream."""
+
+    def __init__(self, rows, g=9.805):
+        self.rows = np.asarray(rows, dtype=np.float64)
+        self.t0 = float(self.rows[0, 0])
+        self.h = float(self.rows[1, 0] - self.rows[0, 0])
+        self.g = g
+
+    def _bracket(self, t):
+        u = (t - self.t0) / self.h
+        i = int(np.clip(math.floor(u), 0, self.rows.shape[0] - 2))
+        return i, float(np.clip(u - i, 0.0, 1.0))
+
+    def pos(self, t):
+        i, a = self._bracket(t)
+        return (1 - a) * self.rows[i, 5:8] + a * self.rows[i + 1, 5:8]
+
+    def vel(self, t):
+        i, a = self._bracket(t)
+        return (1 - a) * self.rows[i, 8:11] + a * self.rows[i + 1, 8:11]
+
+    def rot(self, t):
+        i, a = self._bracket(t)
+        q0, q1 = self.rows[i, 1:5], self.rows[i + 1, 1:5]
+        if np.dot(q0, q1) < 0:
+            q1 = -q1
+        q = (1 - a) * q0 + a * q1
+        q = q / np.linalg.norm(q)
+        return rot_from_quat(np.array([q[1], q[2], q[3], q[0]]))
+
+    def _row(self, t):
+        return int(np.clip(round((t - self.t0) / self.h), 0, self.rows.shape[0] - 1))
+
+    def gyro(self, t):
+        return self.rows[self._row(t), 11:14].copy()
+
+    def accel(self, t):
+        return self.rows[self._row(t), 14:17].copy()
+
+
 # ------------------------------------------------------------------------------------------------
 # scenes + ray casting
 # ------------------------------------------------------------------------------------------------
@@ -163,6 +207,34 @@ def scene_outdoor(seed=64):
     for _ in range(80):
         cyls.append([rng.uniform(-85, 115), rng.uniform(-85, 115), rng.uniform(0.1, 0.4), 0.0, rng.uniform(3, 12)])
     return Scene(None, np.array(boxes), np.array(cyls), 0.0, 120.0)
+
+
+def scene_ground_only(n_poles=0, pole_radius=0.3):
+    """A single ground plane: x, y and yaw are unobservable (the leading eigenvalues of every 6x6 AtA are ~0) — the
+    degeneracy branch of SURVEY.md A.6 with kz up to 3.  `n_poles` vertical cylinders 6-14 m from the origin add a few
+    edge rows each: with the scan-to-scan threshold of 10 (PointOdometry.cc:584-615) zero / one / two poles give
+    kz = 3 (2) / 1 / 0 on the synthetic VLP-16 sweeps, i.e. the scene family straddles that threshold."""
+    ang = np.arange(n_poles) * (2 * np.pi / max(n_poles, 1)) + 0.3
+    dist = 6.0 + 2.0 * np.arange(n_poles) % 5
+    cyls = np.array([[d * np.cos(a), d * np.sin(a), pole_radius, 0.0, 6.0] for a, d in zip(ang, dist)]).reshape(-1, 5)
+    return Scene(None, np.zeros((0, 2, 3)), cyls, 0.0, 60.0)
+
+
+def scene_corridor(cap_height=0.0, cap_x=14.0, half_width=2.0, height=3.0):
+    """A 4 m x 3 m corridor along x whose end walls lie beyond the sensor's range: translation along x is unobservable
+    (kz = 1).  cap_height > 0 adds a low wall across the corridor at x = cap_x: the few returns on it are the only
+    constraint along x, so its height places the smallest eigenvalue of AtA on either side of the degeneracy thresholds
+    (100 for the estimator / scan-to-map, 10 for scan-to-scan)."""
+    room = np.array([[-400.0, -half_width, 0.0], [400.0, half_width, height]])
+    boxes = np.zeros((0, 2, 3))
+    if cap_height > 0:
+        boxes = np.array([[[cap_x, -half_width, 0.0], [cap_x + 0.5, half_width, cap_height]]])
+    return Scene(room, boxes, np.zeros((0, 5)), None, 45.0)
+
+
+def traj_corridor():
+    """Slow motion about the corridor's axis: +-3 m along x, +-0.3 m across, +-5 cm in height, one yaw turn per 20 s."""
+    return Trajectory(rx=3.0, ry=0.3, rz=0.05, cx=0.0, cy=0.0, cz=1.5, Kz=2 * math.pi / 5.0, g=9.805, ang_scale=0.2)
 
 
 def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray) -> np.ndarray:
@@ -285,8 +357,10 @@ class Dataset:
 
 
 def make_dataset(kind: str, n_frames: int, frame_dt: float, t0: float = 1.0, imu_rate: float = 200.0, seed: int = 7, imu_noise: bool = False,
-                 lidar: Lidar | None = None) -> Dataset:
-    """kind = 'indoor' (VLP-16, S_indoor, fixture-like trajectory) or 'outdoor' (HDL-64E, S_outdoor, xy x3)."""
+                 lidar: Lidar | None = None, scene: Scene | None = None, traj: Trajectory | None = None, range_sigma: float = 0.02) -> Dataset:
+    """kind = 'indoor' (VLP-16, S_indoor, fixture-like trajectory) or 'outdoor' (HDL-64E, S_outdoor, xy x3); `scene` / `traj`
+    replace the kind's scene / trajectory (its extrinsic, gravity and lidar stay)."""
+    scene_in, traj_in = scene, traj
     if kind == "indoor":
         scene, lid, traj = scene_indoor(), lidar or Lidar.vlp16(), Trajectory()
         R_lb, t_lb, g = np.eye(3), np.array([0.0, 0.0, -0.081939]), 9.805  # indoor_test_config.yaml:23-36
@@ -302,6 +376,8 @@ def make_dataset(kind: str, n_frames: int, frame_dt: float, t0: float = 1.0, imu
         t_lb, g = np.array([-8.086759e-01, 3.195559e-01, -7.997231e-01]), 9.80
     else:
         raise ValueError(kind)
+    scene = scene_in or scene
+    traj = traj_in or traj
     rng = np.random.default_rng(seed)
     h = 1.0 / imu_rate
     frames = []
@@ -311,7 +387,7 @@ def make_dataset(kind: str, n_frames: int, frame_dt: float, t0: float = 1.0, imu
         R_wb, p_wb = traj.rot(tk), traj.pos(tk)
         R_wl = R_wb @ R_lb.T
         p_wl = p_wb - R_wl @ t_lb
-        scan = make_scan(scene, lid, R_wl, p_wl, seed=1000 + k)
+        scan = make_scan(scene, lid, R_wl, p_wl, seed=1000 + k, range_sigma=range_sigma)
         ts = tk - frame_dt + h * (np.arange(steps) + 1)
         acc = np.array([traj.accel(t) for t in ts])
         gyr = np.array([traj.gyro(t) for t in ts])
@@ -322,9 +398,11 @@ def make_dataset(kind: str, n_frames: int, frame_dt: float, t0: float = 1.0, imu
     return Dataset(frames, R_lb, t_lb, g, traj.accel(t0), traj.gyro(t0), lid)
 
 
-def make_sweeps(kind: str, n_sweeps: int, scan_period: float = 0.1, t0: float = 1.0, lidar: Lidar | None = None):
+def make_sweeps(kind: str, n_sweeps: int, scan_period: float = 0.1, t0: float = 1.0, lidar: Lidar | None = None, scene: Scene | None = None,
+                traj: Trajectory | None = None, range_sigma: float = 0.02):
     """Consecutive motion-distorted sweeps for the scan-to-scan odometry: sweep k spans
-    [t0 + k T, t0 + (k+1) T].  Returns (sweeps, lidar pose function, lidar)."""
+    [t0 + k T, t0 + (k+1) T].  Returns (sweeps, lidar pose function, lidar).  `scene` / `traj` as in make_dataset."""
+    scene_in, traj_in = scene, traj
     if kind == "indoor":
         scene, lid, traj = scene_indoor(), lidar or Lidar.vlp16(), Trajectory()
         R_lb, t_lb = np.eye(3), np.array([0.0, 0.0, -0.081939])
@@ -332,11 +410,14 @@ def make_sweeps(kind: str, n_sweeps: int, scan_period: float = 0.1, t0: float = 
         scene, lid = scene_outdoor(), lidar or Lidar.hdl64()
         traj = Trajectory(rx=45.0, ry=60.0, rz=0.3, cx=15.0, cy=15.0, cz=2.2, Kz=2 * math.pi / 5.0, g=9.80, ang_scale=0.3)
         R_lb, t_lb = np.eye(3), np.array([-8.086759e-01, 3.195559e-01, -7.997231e-01])
+    scene = scene_in or scene
+    traj = traj_in or traj
 
     def pose_fn(t):
         R_wb = traj.rot(t)
         R_wl = R_wb @ R_lb.T
         return R_wl, traj.pos(t) - R_wl @ t_lb
 
-    sweeps = [make_scan(scene, lid, None, None, seed=2000 + k, pose_fn=pose_fn, t_start=t0 + k * scan_period, scan_period=scan_period) for k in range(n_sweeps)]
+    sweeps = [make_scan(scene, lid, None, None, seed=2000 + k, range_sigma=range_sigma, pose_fn=pose_fn, t_start=t0 + k * scan_period, scan_period=scan_period)
+              for k in range(n_sweeps)]
     return sweeps, pose_fn, lid

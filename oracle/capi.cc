@@ -115,6 +115,13 @@ int lio_odom_process(lio_odom *h, const float *sharp, size_t n_sharp, const floa
   if (nsel) *nsel = h->o.last_num_sel_;
   return LIO_OK;
 }
+int lio_odom_get_iteration_trace(const lio_odom *h, lio_transform_f *trace, int capacity, int *kz) {
+  if (!h || capacity < 0 || (!trace && capacity)) return LIO_ERR_ARG;
+  const int n = int(h->o.es_trace_.size());
+  for (int k = 0; k < n && k < capacity; ++k) fromT(h->o.es_trace_[size_t(k)], &trace[k]);
+  if (kz) *kz = h->o.last_kz_;
+  return n;
+}
 int lio_odom_enable(lio_odom *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->o.enable_odom_ = on != 0;
@@ -191,6 +198,11 @@ int lio_map_process(lio_map *h, const float *corner, size_t nc, const float *sur
   if (nsel) *nsel = h->m.last_selected;
   return LIO_OK;
 }
+int lio_map_get_degeneracy(const lio_map *h, int *kz) {
+  if (!h) return LIO_ERR_ARG;
+  if (kz) *kz = h->m.last_kz;
+  return h->m.last_degenerate ? 1 : 0;
+}
 int lio_map_set_init_flag(lio_map *h, int on) {
   if (!h) return LIO_ERR_ARG;
   h->m.imu_inited = on != 0;
@@ -253,6 +265,7 @@ struct lio_kf_batch {
   struct Kf { int map; Cloud corner, surf; Transformf T; };
   std::vector<Map> maps;
   std::vector<Kf> kfs;
+  std::vector<int32_t> last_kz;   // per keyframe, of the last refine
 };
 lio_kf_batch *lio_kf_batch_create(const lio_map_config *c) {
   lio_map_config cfg;
@@ -286,13 +299,21 @@ int lio_kf_batch_refine(lio_kf_batch *h, lio_transform_f *T_out, int32_t *iters,
   if (!h) return LIO_ERR_ARG;
   if (device_ms) *device_ms = 0;
   const bool four_dof = h->cfg.map_builder && h->cfg.enable_4d;
+  h->last_kz.assign(h->kfs.size(), 0);
   for (size_t k = 0; k < h->kfs.size(); ++k) {
     const auto &kf = h->kfs[k];
     KeyframeRefinement r = RefineKeyframe(h->cfg, h->maps[size_t(kf.map)].corner, h->maps[size_t(kf.map)].surf, kf.corner, kf.surf, kf.T, four_dof);
     if (T_out) fromT(r.T, &T_out[k]);
     if (iters) iters[k] = r.iterations;
     if (rows) rows[k] = r.selected;
+    h->last_kz[k] = r.kz;
   }
+  return LIO_OK;
+}
+int lio_kf_batch_get_degeneracy(const lio_kf_batch *h, int32_t *kz_out) {
+  if (!h || !kz_out) return LIO_ERR_ARG;
+  if (h->last_kz.size() != h->kfs.size()) return LIO_ERR_STATE;   // no refine since the keyframe list changed
+  for (size_t k = 0; k < h->last_kz.size(); ++k) kz_out[k] = h->last_kz[k];
   return LIO_OK;
 }
 
@@ -475,7 +496,7 @@ static void fillReport(const SolveReport &R, lio_solve_report *o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   o->iterations = R.iterations; o->successful_steps = R.successful; o->termination = R.termination;
-  o->n_lidar_residuals = R.n_lidar; o->n_local_map = R.n_local_map; o->laser_odom_iterations = R.laser_odom_iters;
+  o->n_lidar_residuals = R.n_lidar; o->n_local_map = R.n_local_map; o->laser_odom_iterations = R.laser_odom_iters; o->laser_odom_kz = R.laser_odom_kz;
   o->turn_off = R.turn_off; o->convergence_flag = R.convergence_flag; o->marginalized = R.marginalized;
   o->cost_pim_before = R.cost_pim; o->cost_ppp_before = R.cost_ppp; o->cost_marg_before = R.cost_marg;
   o->initial_cost = R.initial_cost; o->final_cost = R.final_cost;

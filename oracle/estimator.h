@@ -35,7 +35,7 @@ struct EstimatorConfig {
 };
 
 struct SolveReport {
-  int iterations = 0, successful = 0, termination = 0, n_lidar = 0, n_local_map = 0, laser_odom_iters = 0;
+  int iterations = 0, successful = 0, termination = 0, n_lidar = 0, n_local_map = 0, laser_odom_iters = 0, laser_odom_kz = 0;
   bool turn_off = true, convergence_flag = false, marginalized = false;
   double cost_pim = 0, cost_ppp = 0, cost_marg = 0, initial_cost = 0, final_cost = 0;
   std::vector<double> trace;
@@ -89,6 +89,7 @@ struct Estimator {
   std::vector<std::vector<PlaneFeature>> feature_frames;
   Transformf laser_odom_transform;
   int laser_odom_iters = 0;
+  int laser_odom_kz = 0;  // leading update components masked by the degeneracy test of round 0 (Estimator.cc:1308-1339)
   double ms_features_acc = 0;
   int shard_rank = 0, shard_world = 1;
   int (*allreduce)(double *, int, void *) = nullptr;
@@ -352,7 +353,7 @@ struct Estimator {
   void CalculateLaserOdom(const KdTree &tree, const Cloud &map, const Cloud &stack, Transformf &T, std::vector<PlaneFeature> &features) {
     bool is_degenerate = false;
     float matP[36];
-    laser_odom_iters = 0;
+    laser_odom_iters = 0; laser_odom_kz = 0;
     for (size_t iter = 0; iter < 10; ++iter) {  // num_max_iterations_ = 10 (PointMapping.h:171)
       ++laser_odom_iters;
       CalculateFeatures(tree, map, stack, T, cfg.min_match_sq_dis, cfg.min_plane_dis, cfg.keep_features, features);
@@ -391,6 +392,7 @@ struct Estimator {
         int kz = 0;
         for (int i = 0; i < 6; ++i) { if (E[i] < 100.f) { ++kz; is_degenerate = true; } else break; }
         for (int i = kz; i < 6; ++i) matP[i * 6 + i] = 1.f;
+        laser_odom_kz = kz;
       }
       if (is_degenerate) {
         float X2[6];
@@ -476,7 +478,7 @@ struct Estimator {
       }
       ms_features_acc += now_ms() - tf0;
     }
-    if (rep) { rep->ms_build_map = t1 - t0; rep->ms_features = ms_features_acc; rep->n_local_map = int(local_map_filtered.size()); rep->laser_odom_iters = laser_odom_iters; }
+    if (rep) { rep->ms_build_map = t1 - t0; rep->ms_features = ms_features_acc; rep->n_local_map = int(local_map_filtered.size()); rep->laser_odom_iters = laser_odom_iters; rep->laser_odom_kz = laser_odom_kz; }
   }
 
   void VectorToProblem(WindowProblem &P) const {  // Estimator.cc:2440-2477

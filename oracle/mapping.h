@@ -47,6 +47,7 @@ struct PointMapping {
   float matP[36];
   int last_iterations = 0, last_selected = 0;
   bool last_degenerate = false;
+  int last_kz = 0;   // leading update components masked (PointMapping.cc:650-680, MapBuilder.cc:930-960)
   bool system_init = false;  // MapBuilder.h:65
   int odom_count = 0;        // MapBuilder.h:69
 
@@ -198,7 +199,7 @@ struct PointMapping {
   // four_dof = MapBuilder::OptimizeMap (MapBuilder.cc:624-1014): no sign flip of the plane coefficients, rotation
   // Jacobian in the map frame weighted diag(5e-3, 5e-3, 1), left-multiplied rotation update, no score list
   void OptimizeTransformTobeMapped(bool four_dof) {
-    last_iterations = 0; last_selected = 0; last_degenerate = false;
+    last_iterations = 0; last_selected = 0; last_degenerate = false; last_kz = 0;
     if (corner_from_map.size() <= 10 || surf_from_map.size() <= 100) return;
     KdTree tree_corner, tree_surf;
     tree_corner.Build(corner_from_map);
@@ -310,6 +311,7 @@ struct PointMapping {
         int kz = 0;
         for (int i = 0; i < 6; ++i) { if (E[i] < 100.f) { ++kz; is_degenerate = true; } else break; }  // A.6
         for (int i = kz; i < 6; ++i) matP[i * 6 + i] = 1.f;
+        last_kz = kz;
       }
       if (is_degenerate) {
         float X2[6];
@@ -366,7 +368,7 @@ struct PointMapping {
 
 // One keyframe of the batched refinement (BASELINE.json configs[4]): the scan-to-map loop above run on caller-supplied
 // from-map clouds and down-sampled stacks, from the initial pose T_in.  The keyframes of a batch are independent.
-struct KeyframeRefinement { Transformf T; int iterations = 0, selected = 0; bool degenerate = false; };
+struct KeyframeRefinement { Transformf T; int iterations = 0, selected = 0, kz = 0; bool degenerate = false; };
 inline KeyframeRefinement RefineKeyframe(const MappingConfig &cfg, const Cloud &corner_map, const Cloud &surf_map, const Cloud &corner_stack,
                                          const Cloud &surf_stack, const Transformf &T_in, bool four_dof) {
   PointMapping pm(cfg);
@@ -376,7 +378,7 @@ inline KeyframeRefinement RefineKeyframe(const MappingConfig &cfg, const Cloud &
   pm.corner_stack_ds = corner_stack; pm.surf_stack_ds = surf_stack;
   pm.OptimizeTransformTobeMapped(four_dof);
   KeyframeRefinement r;
-  r.T = pm.transform_tobe_mapped; r.iterations = pm.last_iterations; r.selected = pm.last_selected; r.degenerate = pm.last_degenerate;
+  r.T = pm.transform_tobe_mapped; r.iterations = pm.last_iterations; r.selected = pm.last_selected; r.degenerate = pm.last_degenerate; r.kz = pm.last_kz;
   return r;
 }
 

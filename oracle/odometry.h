@@ -24,6 +24,8 @@ struct PointOdometry {
   bool trees_valid_ = false;
   size_t frame_count_ = 0;
   int iterations_done_ = 0, last_num_sel_ = 0;
+  int last_kz_ = 0;                       // leading update components masked by iteration 0's degeneracy test (:584-615)
+  std::vector<Twist<float>> es_trace_;    // transform_es_ at the end of every iteration of the last Process
 
   PointOdometry(float scan_period, int io_ratio, size_t max_iter, bool no_deskew)
       : scan_period_(scan_period), time_factor_(1 / scan_period), io_ratio_(io_ratio), num_max_iterations_(max_iter), no_deskew_(no_deskew) {}
@@ -61,7 +63,7 @@ struct PointOdometry {
   }
 
   void Process(const Cloud &sharp, Cloud less_sharp, const Cloud &flat, Cloud less_flat) {
-    iterations_done_ = 0; last_num_sel_ = 0;
+    iterations_done_ = 0; last_num_sel_ = 0; last_kz_ = 0; es_trace_.clear();
     if (!system_inited_) {
       last_corner_.swap(less_sharp); last_surf_.swap(less_flat);
       kd_corner_.Build(last_corner_); kd_surf_.Build(last_surf_);
@@ -159,7 +161,7 @@ struct PointOdometry {
           }
           const int nsel = int(ori.size());
           last_num_sel_ = nsel;
-          if (nsel < 10) continue;
+          if (nsel < 10) { es_trace_.push_back(transform_es_); continue; }
           float AtA[36] = {0}, AtB[6] = {0};
           Q<float> R0 = transform_es_.rot.normalized();  // SO3 ctor normalises
           M3<float> Rt = transform_es_.rot.toRotationMatrix().transpose();
@@ -186,6 +188,7 @@ struct PointOdometry {
             sym_eigen<float>(6, AtA, E, V);
             is_degenerate = false; kz = 0;
             for (int i = 0; i < 6; ++i) { if (E[i] < 10.f) { ++kz; is_degenerate = true; } else break; }
+            last_kz_ = kz;
           }
           if (is_degenerate) for (int i = 0; i < kz; ++i) X[i] = 0.f;  // matP = diag(0..0,1..1) (A.6)
           transform_es_.pos.x += X[3]; transform_es_.pos.y += X[4]; transform_es_.pos.z += X[5];
@@ -195,6 +198,7 @@ struct PointOdometry {
           if (!std::isfinite(transform_es_.pos.z)) transform_es_.pos.z = 0;
           float delta_r = RadToDeg(R0.angularDistance(transform_es_.rot));
           float delta_t = float(std::sqrt(std::pow(X[3] * 100, 2) + std::pow(X[4] * 100, 2) + std::pow(X[5] * 100, 2)));
+          es_trace_.push_back(transform_es_);
           if (delta_r < delta_r_abort_ && delta_t < delta_t_abort_) break;
         }
       }

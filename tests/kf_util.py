@@ -12,12 +12,12 @@ def perturbed(T, rng, dpos, drot):
     return synth.quat_from_rot(R).astype(np.float32), (np.asarray(p, np.float64) + rng.uniform(-dpos, dpos, 3)).astype(np.float32)
 
 
-def keyframe_inputs(oracle, kind, n_frames, n_perturb, seed=7, dpos=0.08, drot=0.01):
+def keyframe_inputs(oracle, kind, n_frames, n_perturb, seed=7, dpos=0.08, drot=0.01, map_builder=0, **dataset_kw):
     """-> maps [(corner_from_map, surf_from_map)], keyframes [(map_index, corner_stack, surf_stack, T_init, T_ref)]
     T_ref = the pose the sequential scan-to-map run settled on for that frame (the perturbations should come back near it)."""
     rng = np.random.default_rng(seed)
-    frames = drifting_inputs(oracle, kind, n_frames)
-    mp = capi.PointMapping(oracle)
+    frames = drifting_inputs(oracle, kind, n_frames, **dataset_kw)
+    mp = capi.PointMapping(oracle, map_builder=map_builder)
     maps, kfs = [], []
     for k, (corner, surf, T_sum, _) in enumerate(frames):
         r = mp.process(corner, surf, T_sum)

@@ -4,10 +4,10 @@ import numpy as np
 from lio_amd import pipeline, synth
 
 
-def drifting_inputs(lib, kind, n_frames, frame_dt=0.1):
+def drifting_inputs(lib, kind, n_frames, frame_dt=0.1, **dataset_kw):
     """Undistorted scans along the synthetic trajectory with a drifting 'odometry' transform_sum: the scan-to-map
     step has to pull the pose back onto the map.  Returns [(corner_last, surf_last, (q_xyzw, p), p_gt)]."""
-    ds = synth.make_dataset(kind, n_frames, frame_dt)
+    ds = synth.make_dataset(kind, n_frames, frame_dt, **dataset_kw)
     f0 = ds.frames[0]
     R0 = f0.R_wb @ ds.R_lb.T
     p0 = f0.p_wb - R0 @ ds.t_lb

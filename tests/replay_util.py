@@ -5,10 +5,14 @@ import numpy as np
 from lio_amd import capi, pipeline, replay, synth
 
 
-def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kind="indoor", imu_rate=200.0, sweeps=None):
+def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kind="indoor", imu_rate=200.0, sweeps=None, traj=None, t0=1.0,
+                  configure=None, on_step=None):
+    """traj / t0: the trajectory object behind `sweeps` when it is not the kind's default (e.g. synth.FixtureTrajectory with
+    t0 = 0); configure(cfg) may edit the estimator config; on_step(rp, k, log_entry) is called after every processed message."""
     if sweeps is None:
         sweeps = synth.make_sweeps(kind, n_sweeps)
     sw, pose_fn, lid = sweeps
+    traj_in = traj
     if kind == "indoor":
         traj = synth.Trajectory()   # the indoor trajectory of make_sweeps
         cfg = pipeline.config_indoor(lib, W, Wo)
@@ -19,13 +23,16 @@ def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kin
         traj = synth.Trajectory(rx=45.0, ry=60.0, rz=0.3, cx=15.0, cy=15.0, cz=2.2, Kz=2 * math.pi / 5.0, g=9.80, ang_scale=0.3)
         cfg = pipeline.config_outdoor64(lib, W, Wo)
         cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [-8.086759e-01, 3.195559e-01, -7.997231e-01])
+    traj = traj_in or traj
     cfg.init_window_factor = init_window_factor
     cfg.extrinsic_stage = 1
+    if configure:
+        configure(cfg)
     rp = replay.Replay(lib, cfg, lid, odom_io=odom_io)
     h = 1.0 / imu_rate
-    t_imu = 1.0
+    t_imu = t0
     for k, s in enumerate(sw[:n_sweeps]):
-        t_end = 1.0 + 0.1 * (k + 1)
+        t_end = t0 + 0.1 * (k + 1)
         while t_imu <= t_end + h + 1e-9:
             rp.add_imu(t_imu, traj.accel(t_imu), traj.gyro(t_imu))
             t_imu += h
@@ -33,6 +40,8 @@ def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kin
         rp.add_sweep(s, t_end)
         for e in rp.log[n0:]:
             e["window"] = rp.est.get_window() if e["inited"] else None
+            if on_step:
+                on_step(rp, k, e)
     return rp, traj
 
 

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from lio_amd import pipeline
-from window_util import assert_cost_trace_close, assert_windows_close, force_all, make_pair, window_gap
+from window_util import assert_cost_trace_close, assert_priors_close, assert_windows_close, force_all, make_pair, window_gap
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,7 @@ def test_vlp16_window15_matches_oracle(hip, oracle):
     gap, flips = assert_cost_trace_close(ra, rb)
     print(f"vlp16 15/5 first solve: trace rel gap {gap:.2e} ({flips} newest-frame factor flips), window gap {window_gap(ea.get_window(), eb.get_window())}")
     assert_windows_close(ea.get_window(), eb.get_window())
+    assert_priors_close(ea, eb, ra, rb)
     for est in (ea, eb):
         est.slide()
     force_all(ea, eb, ds)
@@ -45,6 +46,7 @@ def test_vlp16_window15_matches_oracle(hip, oracle):
         _same_decisions(ra, rb)
         assert_cost_trace_close(ra, rb)
         assert_windows_close(ea.get_window(), eb.get_window())
+        assert_priors_close(ea, eb, ra, rb)      # the product's OWN marginalization output, every step
         if k < W + 4:
             force_all(ea, eb, ds)
     pa, pb = ea.prior(), eb.prior()
@@ -70,6 +72,7 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
     assert rb.n_lidar_residuals > 1.2 * sum(eb.features(f)[0].shape[0] for f in range(W - Wo + 1, W)) / (Wo - 1) * Wo
     assert_cost_trace_close(ra, rb, rtol_floor=2e-4)
     assert_windows_close(ea.get_window(), eb.get_window())
+    worst_prior = assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4)[0]   # keep_features: same floor as the cost trace (window_util)
     for est in (ea, eb):
         est.slide()
     force_all(ea, eb, ds)
@@ -83,8 +86,10 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
         wa, wb = ea.get_window(), eb.get_window()
         worst = max(worst, window_gap(wa, wb)[0])
         assert_windows_close(wa, wb)
+        worst_prior = max(worst_prior, assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4)[0])
         force_all(ea, eb, ds)
-    print(f"indoor 12/7 keep_features prior_factor={prior_factor}: worst |dP| over 6 teacher-forced steps {worst:.2e} m")
+    print(f"indoor 12/7 keep_features prior_factor={prior_factor}: worst |dP| over 6 teacher-forced steps {worst:.2e} m, worst |dJtJ|/max of the "
+          f"priors {worst_prior:.2e}")
     pa, pb = ea.prior(), eb.prior()
     assert pa["n"] == pb["n"] == 6 * Wo + 15
 
@@ -121,6 +126,7 @@ def test_teacher_forced_chain_of_20_solves(hip, oracle, kind, frame_dt):
     ra, rb = ea.solve(), eb.solve()
     _same_decisions(ra, rb)
     assert_windows_close(ea.get_window(), eb.get_window())
+    worst_prior, worst_x0 = assert_priors_close(ea, eb, ra, rb)[:2]
     for est in (ea, eb):
         est.slide()
     force_all(ea, eb, ds)
@@ -136,9 +142,12 @@ def test_teacher_forced_chain_of_20_solves(hip, oracle, kind, frame_dt):
         worst_p, worst_r = max(worst_p, g[0]), max(worst_r, g[1])
         assert_windows_close(wa, wb)
         np.testing.assert_allclose(wa["t_lb"], wb["t_lb"], atol=1e-4)   # the optimised extrinsic travels with the window
+        # the prior each side marginalised ITSELF in this step, before the forcing below replaces the product's with the oracle's
+        pr = assert_priors_close(ea, eb, ra, rb)
+        worst_prior, worst_x0 = max(worst_prior, pr[0]), max(worst_x0, pr[1])
         force_all(ea, eb, ds)
     print(f"teacher-forced chain ({kind}): worst |dP| {worst_p:.2e} m, worst rotation gap {worst_r:.2e} rad over {n_chain} steps; "
-          f"{odom_iter_mismatch} steps with a different newest-frame round count")
+          f"{odom_iter_mismatch} steps with a different newest-frame round count; priors: worst |dJtJ|/max {worst_prior:.2e}, |dx0| {worst_x0:.2e}")
     assert odom_iter_mismatch <= 2
     # the clouds never left HBM on the product side: after 20 slides they still match the oracle's
     for f in (W - Wo, W - 1, W):

@@ -72,6 +72,27 @@ def assert_cost_trace_close(ra, rb, rtol_floor=1e-6):
     return float(np.max(np.abs(ta - prior_gap - tb) / np.abs(tb))), flips
 
 
+def assert_priors_close(ea, eb, ra=None, rb=None, rel_floor=1e-6, tol_x0=1e-4):
+    """The marginalization prior each side produced ITSELF in the step just taken (before any teacher forcing overwrites
+    it): same size, |dJtJ| / max|JtJ| <= 1e-6, linearisation point within 1e-4.  JtJ sums every lidar factor of the window
+    (each PivotPointPlaneFactor touches the marginalised pivot pose), so a newest-frame factor accepted by one side only
+    (see assert_cost_trace_close) moves it by about one residual's share: the bound widens by 20 / n_res per such flip.
+    Returns (relative JtJ gap, |dx0|, flips)."""
+    pa, pb = ea.prior(), eb.prior()
+    if pb is None:
+        assert pa is None
+        return 0.0, 0.0, 0
+    assert pa is not None and pa["n"] == pb["n"]
+    flips = abs(ra.n_lidar_residuals - rb.n_lidar_residuals) if ra is not None else 0
+    n_res = max(rb.n_lidar_residuals, 1) if rb is not None else 1
+    rel = float(np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / np.abs(pb["JtJ"]).max())
+    relr = float(np.max(np.abs(pa["Jtr"] - pb["Jtr"])) / max(np.abs(pb["Jtr"]).max(), 1e-300))
+    dx0 = float(np.max(np.abs(pa["x0"] - pb["x0"])))
+    assert rel <= rel_floor + 20.0 * flips / n_res, (rel, flips)
+    assert dx0 <= tol_x0, dx0
+    return max(rel, 0.0), dx0, flips
+
+
 def force_window(dst, src_window, ds):
     """Teacher forcing: the states of `src_window` become the states of estimator `dst` (lio_est_set_window)."""
     dst.set_window(src_window["Ps"], src_window["Rs"], src_window["Vs"], src_window["Bas"], src_window["Bgs"], np.array([0, 0, -ds.g]))

@@ -311,6 +311,17 @@ typedef struct {
   int extrinsic_stage;        /* estimate_extrinsic / extrinsic_stage_ (Estimator.h:81,174): 0 = fixed (SetParameterBlockConstant),
                                  1 = refine in the window, 2 = calibrate the rotation first (EstimateExtrinsicRotation) */
   int init_window_factor;     /* 3    Estimator.h:80: only every n-th frame enters the window until the IMU is initialised */
+  /* ---- execution switches of the product (no reference counterpart; results are the same up to the documented tolerances, the
+   * oracle ignores them).  0 = the shipped default.  An environment variable (named at each field), when set, overrides the
+   * field at lio_est_create — for A/B runs of a host that cannot be rebuilt. */
+  int device_solve;           /* 1: trust-region loop on the device, two launches per iteration (LIO_DEVICE_SOLVE); ignores max_solver_time */
+  int device_marg;            /* 1: marginalization's Schur complement + eigensolves on the device (LIO_DEVICE_MARG) */
+  int inline_marg;            /* 1: marginalization inside lio_est_solve_optimization instead of the worker thread (LIO_ASYNC_MARG=0) */
+  int stream_sync;            /* 1: hipStreamSynchronize + D2H copies instead of completion words in host memory (LIO_HOST_SIGNAL=0) */
+  int moments_form;           /* 0: by launch size, 1: fp64 MFMA form, 2: structured fp64 VALU form (LIO_MOMENTS=mfma|valu) */
+  int moments_fold_in_kernel; /* 1: fold the per-block moments inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL) */
+  int resident_moments;       /* 0: by default rule (on), 1: on, 2: off — the lidar moments of a solve come from ONE resident kernel
+                                 that waits for each linearisation point on a doorbell in host memory (LIO_RESIDENT_MOMENTS=0|1) */
 } lio_est_config;
 
 /* Named after the reference's TicToc stages so CPU/GPU tables line up. */

@@ -324,6 +324,10 @@ int lio_kf_batch_get_degeneracy(const lio_kf_batch *h, int32_t *kz_out) {
 }
 int lio_kf_batch_refine_gather(lio_kf_batch *h, lio_rccl *comm, int slots_per_rank, float *packed_all, double *device_ms) {
   if (!h || !comm || !packed_all || slots_per_rank < 1) return LIO_ERR_ARG;
+  // collective precondition, checked before any device work: slots_per_rank is the SAME on every rank and >= every rank's
+  // keyframe count (a rank that returned here would leave its peers waiting in ncclAllGather — the caller sizes it from the
+  // global maximum, dist_util.refine_keyframes_sharded)
+  if (size_t(slots_per_rank) < h->b->n_keyframes()) return LIO_ERR_CAPACITY;
   return guarded([&] {
     h->b->RefineGather(rccl_raw_comm(comm), lio_rccl_world(comm), slots_per_rank, packed_all);
     if (device_ms) *device_ms = h->b->device_ms_;
@@ -542,6 +546,10 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
   e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
   e.init_window_factor = c->init_window_factor > 0 ? c->init_window_factor : 1;
+  e.device_solve = c->device_solve != 0; e.device_marg = c->device_marg != 0; e.inline_marg = c->inline_marg != 0;
+  e.stream_sync = c->stream_sync != 0; e.moments_fold_in_kernel = c->moments_fold_in_kernel != 0;
+  e.moments_form = (c->moments_form == 1 || c->moments_form == 2) ? c->moments_form : 0;
+  e.resident_moments = (c->resident_moments == 1 || c->resident_moments == 2) ? c->resident_moments : 0;
   // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
   h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;
@@ -702,29 +710,34 @@ int lio_est_get_laser_odom_transform(const lio_est *h, lio_transform_f *out) {
 }
 int lio_est_get_prior(const lio_est *h, double *JtJ, double *Jtr, double *x0, int *x0_len) {
   if (!h) return LIO_ERR_ARG;
-  const_cast<lio_est *>(h)->e->JoinMarg();
-  const auto &pr = h->e->last_marg_;
-  if (!pr) return 0;
-  const int n = pr->n;
-  if (JtJ) std::memcpy(JtJ, pr->JtJ.a.data(), sizeof(double) * size_t(n) * n);
-  if (Jtr) std::memcpy(Jtr, pr->Jtr0.data(), sizeof(double) * n);
-  int len = 0;
-  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
-  if (x0_len) *x0_len = len;
-  return n;
+  return guarded([&] {
+    const_cast<lio_est *>(h)->e->JoinMarg();
+    const auto &pr = h->e->last_marg_;
+    if (!pr) return 0;
+    const int n = pr->n;
+    if (JtJ) std::memcpy(JtJ, pr->JtJ.a.data(), sizeof(double) * size_t(n) * n);
+    if (Jtr) std::memcpy(Jtr, pr->Jtr0.data(), sizeof(double) * n);
+    int len = 0;
+    for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+    if (x0_len) *x0_len = len;
+    return n;
+  });
 }
 int lio_est_get_prior_factor(const lio_est *h, double *lin_jac, double *lin_res, double *x0, int *x0_len) {
   if (!h) return LIO_ERR_ARG;
-  const_cast<lio_est *>(h)->e->JoinMarg();
-  const auto &pr = h->e->last_marg_;
-  if (!pr) return 0;
-  const int n = pr->n;
-  if (lin_jac) std::memcpy(lin_jac, pr->lin_jac.a.data(), sizeof(double) * size_t(n) * n);
-  if (lin_res) std::memcpy(lin_res, pr->lin_res.data(), sizeof(double) * n);
-  int len = 0;
-  for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
-  if (x0_len) *x0_len = len;
-  return n;
+  // JoinMarg rethrows a failed worker task: nothing may unwind through the C boundary
+  return guarded([&] {
+    const_cast<lio_est *>(h)->e->JoinMarg();
+    const auto &pr = h->e->last_marg_;
+    if (!pr) return 0;
+    const int n = pr->n;
+    if (lin_jac) std::memcpy(lin_jac, pr->lin_jac.a.data(), sizeof(double) * size_t(n) * n);
+    if (lin_res) std::memcpy(lin_res, pr->lin_res.data(), sizeof(double) * n);
+    int len = 0;
+    for (const auto &b : pr->x0) { if (x0) for (double v : b) x0[len++] = v; else len += int(b.size()); }
+    if (x0_len) *x0_len = len;
+    return n;
+  });
 }
 int lio_est_set_prior_factor(lio_est *h, int n, const double *lin_jac, const double *lin_res, const double *x0, int x0_len) {
   if (!h || !lin_jac || !lin_res || !x0 || n <= 0) return LIO_ERR_ARG;
@@ -747,8 +760,11 @@ int lio_est_set_prior_factor(lio_est *h, int n, const double *lin_jac, const dou
 }
 int lio_est_set_extrinsic(lio_est *h, const lio_transform_f *T) {
   if (!h || !T) return LIO_ERR_ARG;
-  h->e->transform_lb_ = toT(*T);
-  return LIO_OK;
+  return guarded([&] {
+    h->e->JoinMarg();   // a marginalization in flight captured its own copy of the states; join so that nothing reads half a change
+    h->e->transform_lb_ = toT(*T);
+    return LIO_OK;
+  });
 }
 int lio_dense_spd_solve(const double *A, const double *b, int n, double *x) {
   if (!A || !b || !x || n < 1 || n > 128) return LIO_ERR_ARG;
@@ -778,6 +794,7 @@ int lio_est_restore(lio_est *h) {
 int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_fn fn, void *user) {
   if (!h || world < 1 || rank < 0 || rank >= world) return LIO_ERR_ARG;
   h->e->shard_rank_ = rank; h->e->shard_world_ = world; h->e->allreduce_ = fn; h->e->allreduce_user_ = user;
+  h->e->rccl_comm_ = nullptr;   // the callback form replaces an RCCL communicator set earlier (which the caller may destroy now)
   return LIO_OK;
 }
 int lio_est_set_factor_sharding_rccl(lio_est *h, lio_rccl *comm) {

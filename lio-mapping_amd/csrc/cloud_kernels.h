@@ -42,6 +42,7 @@ class VoxelGridDev {
   // centroids themselves may still be in flight on `s`, so consumers on OTHER streams must wait for `s` through an event
   void launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s);
   size_t finish(VoxParams *host_params = nullptr);
+  void set_host_signal(bool on) { use_signal_ = on; }   // false: counts come back by copy + hipStreamSynchronize (lio_est_config.stream_sync)
   VoxelGridDev() = default;
   VoxelGridDev(const VoxelGridDev &) = delete;
   VoxelGridDev &operator=(const VoxelGridDev &) = delete;
@@ -61,6 +62,7 @@ class VoxelGridDev {
   unsigned *h_flag_ = nullptr;      // completion word behind the mailbox (dev.h: HostSignal)
   unsigned seq_ = 0;
   HostSignal sig_{};
+  bool use_signal_ = true;
 };
 // LIO_HOST_SIGNAL=0: every wait is a hipStreamSynchronize again
 bool host_signal_enabled();

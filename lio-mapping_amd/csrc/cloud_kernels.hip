@@ -369,7 +369,7 @@ void VoxelGridDev::enqueue(bool exact) {
   tile_heads_.reserve(ntiles);
   hipLaunchKernelGGL(k_vox_tile_heads, dim3(ntiles + 1), dim3(VOX_TILE), 0, s, keys2_.p, ni, tile_heads_.p, partial_.p, npartial, inv_leaf, params_.p);
   sig_ = HostSignal();
-  if (host_signal_enabled()) { sig_.flag = h_flag_; sig_.seq = ++seq_; }
+  if (use_signal_ && host_signal_enabled()) { sig_.flag = h_flag_; sig_.seq = ++seq_; }
   hipLaunchKernelGGL(k_vox_centroids, dim3(ntiles), dim3(VOX_TILE), 0, s, in, keys2_.p, vals2_.p, tile_heads_.p, ni, out.p, count_.p, params_.p, d_range,
                      reinterpret_cast<VoxMail *>(h_count_), sig_);
   LIO_HIP(hipGetLastError());
@@ -390,8 +390,13 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
   for (int attempt = 0;; ++attempt) {
     if (sig_.flag) wait_host_signal(sig_, p_stream_);   // the count is out; the centroids follow in stream order
     else LIO_HIP(hipStreamSynchronize(p_stream_));
-    if (!m->range_overflow || attempt) break;
-    enqueue(true);   // cold path: the cloud spans more cells than the absolute key holds
+    if (!m->range_overflow || attempt) {
+      // cold path: the exact pass was enqueued AFTER launch() returned, i.e. after the caller may have recorded the event other
+      // streams wait on — those consumers are not ordered behind it, so the output must be complete before finish() returns
+      if (attempt) LIO_HIP(hipStreamSynchronize(p_stream_));
+      break;
+    }
+    enqueue(true);   // the cloud spans more cells than the absolute key holds
   }
   int count = m->count;
   const VoxParams hp = m->params;

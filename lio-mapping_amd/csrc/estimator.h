@@ -34,6 +34,9 @@ struct EstConfig {
   double max_solver_time = 0.10;
   int extrinsic_stage = 2;
   int init_window_factor = 3;
+  // execution switches (lio_est_config's trailing block; environment overrides are applied in the constructor)
+  bool device_solve = false, device_marg = false, inline_marg = false, stream_sync = false, moments_fold_in_kernel = false;
+  int moments_form = 0, resident_moments = 0;
 };
 
 struct DeviceCloud {
@@ -256,6 +259,8 @@ class Estimator {
   DBuf<double> d_odom_partials_, d_moment_partials_, d_moment_out_;
   DBuf<int> d_moment_tickets_;
   bool fold_in_kernel_ = false;
+  int moments_form_ = 0;            // 0 by launch size, 1 MFMA, 2 VALU
+  bool resident_moments_ = true;    // the moments of a solve from one resident kernel behind a doorbell (solve_kernels.h)
   // Device-resident dogleg (solve_step.h), opt-in with LIO_DEVICE_SOLVE=1.  Measured on the MI355X at D = 96 it is SLOWER than
   // the host loop for one window (launch B = one workgroup: 150 us per iteration against the host's 17 us of assemble +
   // Cholesky + step), so the host loop stays the default; it exists for hosts that drive many windows per

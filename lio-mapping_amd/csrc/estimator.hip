@@ -12,6 +12,7 @@
 
 namespace lio {
 
+static const bool g_debug_timing = std::getenv("LIO_DEBUG_TIMING") != nullptr;   // read once: the solve is a hot path
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // math_utils.h:186-232 (degrees)
@@ -91,8 +92,14 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   // on the MI355X per linearisation: in-kernel fold with agent-scope fences 18.8 us (round 1), with the fence-free sc1
   // store / load / relaxed-ticket protocol 18.8 us again (round 2: 39 serialised ticket adds and memory-side loads per frame
   // cost what the fences did), two launches 12.5 us.
+  // Execution switches: lio_est_config's trailing block, each overridable by its environment variable (A/B runs of a built host).
+  fold_in_kernel_ = cfg.moments_fold_in_kernel; device_solve_ = cfg.device_solve; async_marg_ = !cfg.inline_marg;
+  host_signal_ = !cfg.stream_sync; device_marg_ = cfg.device_marg; moments_form_ = cfg.moments_form;
+  resident_moments_ = cfg.resident_moments != 2;
   if (const char *e = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL")) fold_in_kernel_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
+  if (const char *e = std::getenv("LIO_MOMENTS")) moments_form_ = std::string(e) == "mfma" ? 1 : (std::string(e) == "valu" ? 2 : moments_form_);
+  if (const char *e = std::getenv("LIO_RESIDENT_MOMENTS")) resident_moments_ = std::atoi(e) != 0;
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
   // coherent (fine-grained): kernels store results and completion words here and the host reads them while the stream is live
@@ -101,6 +108,7 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_signal_), 256 * sizeof(unsigned), hipHostMallocCoherent));
   std::memset(h_signal_, 0, 256 * sizeof(unsigned));
   if (const char *e = std::getenv("LIO_HOST_SIGNAL")) host_signal_ = std::atoi(e) != 0;
+  vox_.set_host_signal(host_signal_);
   LIO_HIP(hipGetDevice(&device_id_));
   if (const char *e = std::getenv("LIO_DEVICE_MARG")) device_marg_ = std::atoi(e) != 0;
   if (device_marg_) marg_dev_ = std::make_shared<MargSchurDev>(device_id_);
@@ -619,6 +627,7 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
     max_slots = std::max(max_slots, f.nslots);
   }
   ma.blocks_per_frame = moment_blocks_per_frame(max_slots);
+  ma.form = moments_form_;
 }
 
 // Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.
@@ -644,7 +653,7 @@ bool Estimator::SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &
   const DevProblem *d_pb = reinterpret_cast<const DevProblem *>(d_ds_.p + offsetof(DsHost, pb));
   DevState *d_st = reinterpret_cast<DevState *>(d_ds_.p + offsetof(DsHost, st));
   const double *d_pm = reinterpret_cast<const double *>(d_ds_.p + offsetof(DsHost, prior_mats));
-  static const bool dbg_prof = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  const bool dbg_prof = g_debug_timing;
   if (dbg_prof) { d_ds_prof_.reserve(32); LIO_HIP(hipMemsetAsync(d_ds_prof_.p, 0, 32 * sizeof(long long), stream_)); }
   StepBuffers B{d_pm, d_moment_partials_.p, d_ds_imu_.p, d_ds_lmap_.p, d_ds_prior_out_.p, d_ds_exprior_out_.p, d_ds_Hcur_.p, d_ds_Sbuf_.p,
                 dbg_prof ? d_ds_prof_.p : nullptr};
@@ -764,9 +773,9 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
   LIO_HIP(hipMemcpyAsync(d_frames.p, frames.data(), sizeof(MomentFrame) * nf, hipMemcpyHostToDevice, stream_));
   hipEvent_t e0, e1;
   LIO_HIP(hipEventCreate(&e0)); LIO_HIP(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  for (int w = 0; w < 2; ++w) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_, moments_form_);
   LIO_HIP(hipEventRecord(e0, stream_));
-  for (int r = 0; r < reps; ++r) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_);
+  for (int r = 0; r < reps; ++r) launch_lidar_moments_batched(d_frames.p, nf, bpf, max_slots, valid_b.p, coef_b.p, partials.p, out.p, stream_, moments_form_);
   LIO_HIP(hipEventRecord(e1, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
   float ms = 0;
@@ -873,7 +882,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   const double time_cap = Sharded() ? -1.0 : cfg_.max_solver_time;
   s = solve_dogleg(sys, P, cfg_.max_num_iterations, time_cap, &first);
   R.ms_opt = now_ms() - t_opt0;
-  if (getenv("LIO_DEBUG_TIMING"))
+  if (g_debug_timing)
     std::fprintf(stderr, "[lio_hip timing] dogleg: chol %.3f ms, candidate evaluate %.3f ms | evaluate x%d: launch %.3f prior %.3f imu %.3f wait %.3f assemble %.3f\n",
                  s.ms_chol, s.ms_eval, sys.eclk.n, sys.eclk.launch, sys.eclk.prior, sys.eclk.imu, sys.eclk.wait, sys.eclk.assemble);
   }
@@ -928,11 +937,11 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     R.n_lidar_residuals = cfg_.point_distance_factor ? int(cnt) : 0;
   }
   R.ms_total = now_ms() - t_total0;
-  if (getenv("LIO_DEBUG_TIMING")) {
+  if (g_debug_timing) {
     std::fprintf(stderr, "[lio_hip timing] total %.3f map %.3f feat %.3f opt %.3f marg %.3f | lidar_eval %d calls %.3f ms (%.1f us each)\n", R.ms_total,
                  R.ms_build_map, R.ms_features, R.ms_opt, R.ms_marg, dbg_eval_n_, dbg_eval_ms_, dbg_eval_n_ ? 1e3 * dbg_eval_ms_ / dbg_eval_n_ : 0.0);
   }
-  if (getenv("LIO_DEBUG_TIMING")) std::fprintf(stderr, "[lio_hip timing] of which hipStreamSynchronize %.3f ms\n", dbg_sync_ms_);
+  if (g_debug_timing) std::fprintf(stderr, "[lio_hip timing] of which hipStreamSynchronize %.3f ms\n", dbg_sync_ms_);
   dbg_eval_ms_ = 0; dbg_eval_n_ = 0; dbg_sync_ms_ = 0;
   return true;
 }

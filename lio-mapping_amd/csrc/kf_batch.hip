@@ -164,9 +164,12 @@ __global__ void k_kf_pack(const OdomState *__restrict__ st, int B, int slots, fl
 }
 
 void KfBatchDev::RefineGather(void *nccl_comm, int world, int slots_per_rank, float *packed_all) {
-  Refine();
-  const int B = int(h_kd_.size());
-  if (slots_per_rank < B) throw std::runtime_error("RefineGather: slots_per_rank smaller than this rank's keyframe count");
+  if (slots_per_rank < int(h_kd_.size())) throw std::runtime_error("RefineGather: slots_per_rank smaller than this rank's keyframe count");
+  // A rank whose own refinement fails still takes part in the gather (with zeroed records) and reports the failure afterwards:
+  // returning before the collective would leave every peer blocked in ncclAllGather.
+  std::exception_ptr local_failure;
+  int B = int(h_kd_.size());
+  try { Refine(); } catch (...) { local_failure = std::current_exception(); B = 0; }
   hipStream_t s = stream_;
   d_pack_.reserve(size_t(slots_per_rank) * 9);
   d_gather_.reserve(size_t(world) * slots_per_rank * 9);
@@ -176,6 +179,7 @@ void KfBatchDev::RefineGather(void *nccl_comm, int world, int slots_per_rank, fl
   rccl_all_gather_f32(nccl_comm, d_pack_.p, d_gather_.p, size_t(slots_per_rank) * 9, s);
   LIO_HIP(hipMemcpyAsync(packed_all, d_gather_.p, sizeof(float) * size_t(world) * slots_per_rank * 9, hipMemcpyDeviceToHost, s));
   LIO_HIP(hipStreamSynchronize(s));
+  if (local_failure) std::rethrow_exception(local_failure);
 }
 
 }  // namespace lio

@@ -6,9 +6,12 @@
 // One communicator per process (= per GPU), created from a unique id the caller distributes by whatever side channel it has
 // (bench.py: torch.distributed broadcast).  xGMI is point-to-point; both messages are tiny (10 KB / 36 B per keyframe), so they
 // are latency-bound: one collective per linearisation, nothing chunked.
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library itself is loaded on first use
 
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/lio_c.h"
 #include "dev.h"
@@ -16,17 +19,57 @@
 
 namespace lio {
 
+// RCCL is needed by the opt-in lio_rccl_* entry points only, so liblio_hip.so does not link it: the single-GPU product loads on
+// a host without RCCL (or with ROCm installed elsewhere).  First use resolves the six calls from librccl by SONAME — inside a
+// process that already carries RCCL (torch) that is the SAME library object, so both share one set of communicator internals —
+// then from $ROCM_PATH/lib and /opt/rocm/lib.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+static const RcclApi &rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::string rocm = std::getenv("ROCM_PATH") ? std::getenv("ROCM_PATH") : "/opt/rocm";
+    const std::string names[] = {"librccl.so.1", "librccl.so", rocm + "/lib/librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const std::string &n : names)
+      if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GetErrorString;
+  });
+  return api;
+}
+static const RcclApi &rccl_api_or_throw() {
+  const RcclApi &a = rccl_api();
+  if (!a.ok) throw DeviceError("librccl could not be loaded: the lio_rccl_* entry points need RCCL on this host");
+  return a;
+}
+
 #define LIO_NCCL(call)                                                                                             \
   do {                                                                                                             \
     ncclResult_t r__ = (call);                                                                                     \
-    if (r__ != ncclSuccess) throw DeviceError(std::string(#call) + " -> " + ncclGetErrorString(r__));              \
+    if (r__ != ncclSuccess) throw DeviceError(std::string(#call) + " -> " + rccl_api().GetErrorString(r__));       \
   } while (0)
 
 void rccl_all_reduce_sum_f64(void *comm, double *dev_buf, size_t count, hipStream_t s) {
-  LIO_NCCL(ncclAllReduce(dev_buf, dev_buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(comm), s));
+  LIO_NCCL(rccl_api_or_throw().AllReduce(dev_buf, dev_buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(comm), s));
 }
 void rccl_all_gather_f32(void *comm, const float *dev_send, float *dev_recv, size_t count_per_rank, hipStream_t s) {
-  LIO_NCCL(ncclAllGather(dev_send, dev_recv, count_per_rank, ncclFloat, static_cast<ncclComm_t>(comm), s));
+  LIO_NCCL(rccl_api_or_throw().AllGather(dev_send, dev_recv, count_per_rank, ncclFloat, static_cast<ncclComm_t>(comm), s));
 }
 
 }  // namespace lio
@@ -42,7 +85,8 @@ int lio_rccl_unique_id(unsigned char id[LIO_RCCL_ID_BYTES]) {
   if (!id) return LIO_ERR_ARG;
   static_assert(sizeof(ncclUniqueId) == LIO_RCCL_ID_BYTES, "ncclUniqueId size");
   ncclUniqueId u;
-  if (ncclGetUniqueId(&u) != ncclSuccess) return LIO_ERR_DEVICE;
+  const lio::RcclApi &api = lio::rccl_api();
+  if (!api.ok || api.GetUniqueId(&u) != ncclSuccess) return LIO_ERR_DEVICE;
   std::memcpy(id, &u, sizeof(u));
   return LIO_OK;
 }
@@ -55,14 +99,15 @@ lio_rccl *lio_rccl_init(const unsigned char id[LIO_RCCL_ID_BYTES], int rank, int
   std::memcpy(&u, id, sizeof(u));
   lio_rccl *h = new (std::nothrow) lio_rccl;
   if (!h) return nullptr;
-  if (ncclCommInitRank(&h->comm, world, u, rank) != ncclSuccess) { delete h; return nullptr; }
+  const lio::RcclApi &api = lio::rccl_api();
+  if (!api.ok || api.CommInitRank(&h->comm, world, u, rank) != ncclSuccess) { delete h; return nullptr; }
   h->rank = rank; h->world = world;
   return h;
 }
 
 void lio_rccl_destroy(lio_rccl *h) {
   if (!h) return;
-  if (h->comm) (void)ncclCommDestroy(h->comm);
+  if (h->comm && lio::rccl_api().ok) (void)lio::rccl_api().CommDestroy(h->comm);
   delete h;
 }
 

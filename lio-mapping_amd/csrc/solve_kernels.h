@@ -29,6 +29,7 @@ struct MomentArgs {
   MomentFrame fr[LIO_MAX_FRAMES];
   int nframes;
   int blocks_per_frame;
+  int form;   // 0: MFMA or VALU form by chunks per wave, 1: MFMA, 2: VALU (lio_est_config.moments_form)
 };
 
 // partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles
@@ -40,7 +41,7 @@ int moment_blocks_per_frame(int max_slots);
 int moment_blocks_per_frame_batched(int max_slots, int nframes);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,
-                                  const float4 *coef, double *partials, double *out, hipStream_t s);
+                                  const float4 *coef, double *partials, double *out, hipStream_t s, int form = 0);
 
 // One iteration of the device-resident dogleg (solve_step.h): launch A (moments at the candidate + aux row) and launch B
 // (k_solve_step), both on `s`, no host interaction.  The StepBuffers' partials must be `partials`.

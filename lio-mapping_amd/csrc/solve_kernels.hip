@@ -24,15 +24,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Two kernels compute the same moments.  Measured on the MI355X (bench.py batched_kernel_roofline): with 2 chunks per wave
 // (one window) the MFMA kernel's launch is 10.5 us against 12.0 us (the register fold at the end of the VALU kernel is on the
 // critical path); from ~4 chunks per wave on the VALU kernel wins, 4.5 vs 3.4 TB/s algorithmic at 512 windows.
-// LIO_MOMENTS=mfma|valu forces one of them; default: by chunks per wave.
-static const int g_moments_mode = [] {
-  const char *e = std::getenv("LIO_MOMENTS");
-  if (e && std::string(e) == "mfma") return 1;
-  if (e && std::string(e) == "valu") return 2;
-  return 0;
-}();
-static bool use_mfma(int max_slots, int blocks_per_frame) {
-  if (g_moments_mode) return g_moments_mode == 1;
+// lio_est_config.moments_form (or LIO_MOMENTS=mfma|valu, read by the estimator) forces one of them; default: by chunks per wave.
+static bool use_mfma(int max_slots, int blocks_per_frame, int form) {
+  if (form) return form == 1;
   const int chunks_per_wave = cdiv(max_slots, blocks_per_frame * MOMENT_THREADS);
   return chunks_per_wave < 4;
 }
@@ -373,9 +367,9 @@ int moment_blocks_per_frame_batched(int max_slots, int nframes) {
 }
 
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,
-                                  const float4 *coef, double *partials, double *out, hipStream_t s) {
+                                  const float4 *coef, double *partials, double *out, hipStream_t s, int form) {
   if (nframes <= 0) return;
-  if (use_mfma(max_slots, blocks_per_frame))
+  if (use_mfma(max_slots, blocks_per_frame, form))
     hipLaunchKernelGGL(k_lidar_moments_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym_batched, dim3(blocks_per_frame, nframes), dim3(MOMENT_THREADS), 0, s, d_frames, valid, coef, partials);
@@ -388,7 +382,7 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
   if (a.nframes <= 0) return;
   int max_slots = 0;
   for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
-  if (tickets || use_mfma(max_slots, a.blocks_per_frame))
+  if (tickets || use_mfma(max_slots, a.blocks_per_frame, a.form))
     hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out,
                        tickets ? sig : HostSignal());
   else
@@ -621,7 +615,7 @@ void launch_solve_iteration(const MomentArgs &a, const uint8_t *valid, const flo
   int max_slots = 0;
   for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
   const dim3 grid(std::max(a.blocks_per_frame, a.nframes + 1), a.nframes + 1);
-  if (use_mfma(max_slots, a.blocks_per_frame))
+  if (use_mfma(max_slots, a.blocks_per_frame, a.form))
     hipLaunchKernelGGL(k_lidar_moments_dev<false>, grid, dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, pb, st, B.prior_mats, imu_out, lmap, prior_out,
                        exprior_out);
   else

@@ -91,6 +91,13 @@ class EstConfig(C.Structure):
         ("max_solver_time", C.c_double),
         ("extrinsic_stage", C.c_int),
         ("init_window_factor", C.c_int),
+        ("device_solve", C.c_int),
+        ("device_marg", C.c_int),
+        ("inline_marg", C.c_int),
+        ("stream_sync", C.c_int),
+        ("moments_form", C.c_int),
+        ("moments_fold_in_kernel", C.c_int),
+        ("resident_moments", C.c_int),
     ]
 
 

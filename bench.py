@@ -19,6 +19,15 @@ is latency-bound; this shows how far the same kernels go when the GPU is given m
 
 `--workload keyframes` makes configs[4] the bench line itself: a step = one refinement of all --keyframes keyframes,
 the keyframe list sharded over the ranks, one all-gather of the poses per step (strong scaling).
+
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>`
+(the command the driver uses), after checking that N GPUs are visible.  Under a launcher, WORLD_SIZE must equal --gpus.
+At N > 1 the ONE line carries, besides the weak-scaling value, `sharded` (one window, factors sharded, in-library RCCL
+all-reduce per linearisation: solves/s and microseconds per all-reduce) and `keyframes` (configs[4], strong scaling,
+in-library all-gather), each with `rccl_world` as the communicator reports it.
+`--dry-launch` runs the same multi-rank control flow on CPU hosts: gloo process group, the CPU oracle as the worker, a small
+VLP-16 window (tests/test_distributed_gloo.py spawns it with --gpus 2).
 """
 import argparse
 import json
@@ -88,6 +97,195 @@ def one_step(est):
     return est.solve()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start one rank per GPU with the command the driver uses and pass the
+    flags through.  Fails loudly when the node has fewer than N GPUs (unless --dry-launch, which needs none)."""
+    import socket
+    import subprocess
+
+    if not args.dry_launch:
+        import torch
+
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _shared_window(lib, kind, W, Wo):
+    """The SAME window on every rank (shift 0): the unit of the factor-sharded mode."""
+    ds = make_dataset(kind, W, 0.0)
+    clouds, _ = feature_clouds(lib, ds)
+    return make_estimator(lib, ds, clouds, kind, W, Wo)
+
+
+def sharded_solve_stats(lib, kind, W, Wo, rank, world, steps, sync, device, rccl=None, allreduce_numpy=None):
+    """ONE window solved cooperatively by all ranks (MarginalizationFactor.cc:245-269 across ranks): every rank
+    evaluates its share of the lidar factors, the per-shard moments (Wo x 260 doubles) are summed by one all-reduce per
+    linearisation — in-library RCCL on the estimator's stream (GPU) or the gloo callback (CPU rehearsal).  Collective: every rank
+    calls it.  Returns the dict rank 0 prints (other ranks: None)."""
+    from lio_amd import dist_util
+
+    est = _shared_window(lib, kind, W, Wo)
+    rep0 = one_step(est)                       # unsharded reference solve of the same window (every rank, no collective)
+    own = None
+    if allreduce_numpy is None:
+        own = rccl = rccl or dist_util.make_rccl(lib, rank, world)
+        est.set_factor_sharding_rccl(rccl)
+    else:
+        est.set_factor_sharding(rank, world, allreduce_numpy)
+    for _ in range(2):
+        rep = one_step(est)
+    dist_util.barrier(world)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = one_step(est)
+    est.sync()
+    sync()
+    dist_util.barrier(world)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=device)
+    us = rccl.bench_all_reduce(Wo * 260, 200) if own is not None or rccl is not None else None
+    out = {
+        "mode": f"1 window, lidar factors sharded over {world} ranks, one SUM all-reduce of {Wo} x 260 doubles per linearisation",
+        "value": round(steps / dt, 3), "unit": "solves/s", "scaling": "strong", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+        "rccl_world": rccl.world_seen_by_rccl() if rccl is not None else None,
+        "allreduce": "in-library ncclAllReduce on the estimator's stream" if rccl is not None else "gloo callback (CPU rehearsal)",
+        "us_per_allreduce": round(us, 2) if us is not None else None,
+        "linearisations_per_solve": int(rep.iterations) + 1,
+        "solver_iterations": int(rep.iterations), "solver_iterations_unsharded": int(rep0.iterations),
+        "final_cost_rel_gap_to_unsharded": float(abs(rep.final_cost - rep0.final_cost) / max(abs(rep0.final_cost), 1e-300)),
+    }
+    est.set_factor_sharding_rccl(None) if allreduce_numpy is None else est.set_factor_sharding(0, 1, None)
+    return out if rank == 0 else None
+
+
+def keyframes_measure(lib, rank, world, n_kf, steps, sync, device, rccl=None, use_library_gather=True, kind="outdoor", warmup=1):
+    """configs[4]: a step = one refinement of ALL n_kf keyframes (each against its own local map); rank r owns keyframes r, r + N, ...;
+    the one exchange is an all-gather of the refined poses — ncclAllGather inside the library from the device pose buffer, or the
+    torch collective (CPU rehearsal).  Collective.  Returns the measurement dict on rank 0 (None elsewhere)."""
+    from lio_amd import capi, dist_util, synth
+
+    n_kf = max(n_kf, world)
+    ds = make_dataset(kind, 15 if kind == "outdoor" else 4)      # the same scans on every rank
+    clouds, _ = feature_clouds(lib, ds)
+    captured = []
+    mapping_ms_per_scan(lib, ds, clouds, n_frames=8 if kind == "outdoor" else 4, capture=captured)
+    rng = np.random.default_rng(5)
+    n_src = len(captured)
+    mine = list(range(rank, n_kf, world))
+    alg, T0s, maps, kfs = [], [], [], []
+    for k in range(n_kf):                                 # every rank draws all initial poses: identical lists everywhere
+        c = captured[k % n_src]
+        q, p = c["T"]
+        R = synth.rot_from_quat(np.asarray(q, np.float64)) @ synth.small_rot(rng.uniform(-0.01, 0.01, 3))
+        T0s.append((synth.quat_from_rot(R), np.asarray(p, np.float64) + rng.uniform(-0.15, 0.15, 3)))
+    per_rank = -(-n_kf // world)
+    if world > 1 and use_library_gather and rccl is None:
+        rccl = dist_util.make_rccl(lib, rank, world)
+    b = capi.KeyframeBatch(lib)
+    for j, k in enumerate(mine):
+        c = captured[k % n_src]
+        b.add_map(c["corner_map"], c["surf_map"])
+        b.add_keyframe(j, c["corner"], c["surf"], T0s[k])
+        M, N = c["corner"].shape[0] + c["surf"].shape[0], c["corner_map"].shape[0] + c["surf_map"].shape[0]
+        alg.append(16 * (M + N) + 72 * M)
+
+    def step():
+        if world > 1 and rccl is not None:   # refinement + ncclAllGather of the poses from the device pose buffer, both inside the library
+            g = b.refine_gather(rccl, per_rank)
+            mine_rows = g[rank, : len(mine)]
+            return dict(q=mine_rows[:, 0:4], p=mine_rows[:, 4:7], iterations=mine_rows[:, 7].astype(np.int32), device_ms=b.last_device_ms)
+        r = b.refine()
+        if world > 1:                        # CPU rehearsal: the same exchange through the torch collective
+            import torch
+            import torch.distributed as dist
+
+            buf = torch.zeros((per_rank, 9), dtype=torch.float32)
+            if mine:
+                buf[: len(mine), 0:4], buf[: len(mine), 4:7] = torch.from_numpy(r["q"]), torch.from_numpy(r["p"])
+                buf[: len(mine), 7] = torch.from_numpy(r["iterations"].astype(np.float32))
+            dist.all_gather([torch.empty_like(buf) for _ in range(world)], buf)
+        return r
+
+    for _ in range(max(warmup, 1)):
+        r = step()
+    dist_util.barrier(world)
+    sync()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(steps):
+        r = step()
+        dev_ms.append(r["device_ms"])
+    sync()
+    dist_util.barrier(world)
+    dt_max = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=device)
+    if rank != 0:
+        return None
+    alg_bytes = float(np.dot(np.asarray(alg, np.float64), r["iterations"].astype(np.float64)))
+    ms = float(np.median(dev_ms))
+    return {
+        "n_kf": n_kf, "dt_max": dt_max, "steps": steps, "alg_bytes": alg_bytes, "device_ms": ms, "captured": captured,
+        "iterations_mean": round(float(r["iterations"].mean()), 2),
+        "line": {
+            "value": round(n_kf * steps / dt_max, 1), "unit": "keyframes/s", "scaling": "strong", "steps": steps, "ms_per_step": round(1e3 * dt_max / steps, 3),
+            "keyframes": n_kf, "rccl_world": rccl.world_seen_by_rccl() if rccl is not None else None,
+            "exchange": ("in-library ncclAllGather of 9 floats per keyframe" if rccl is not None else "torch all_gather (CPU rehearsal)") if world > 1 else "none (1 rank)",
+            "parallelism": f"keyframes sharded over {world} ranks, all-gather of the poses" if world > 1 else "1 batch",
+        },
+    }
+
+
+def dry_run(args, rank, world, torch, dist):
+    """CPU rehearsal of the multi-rank run (no GPU, nothing measured): gloo process group, the CPU oracle behind the same C-ABI
+    as the worker, a small VLP-16 window.  Exercises exactly the control flow of the real run: per-rank windows between
+    barriers + max-over-ranks, the factor-sharded solve with an all-reduce per linearisation, the sharded keyframe batch with
+    its all-gather, one JSON line from rank 0."""
+    from lio_amd import dist_util
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    lib = _oracle_lib()
+    kind, W, Wo = "indoor", 6, 3
+    ds = make_dataset(kind, W, dist_util.window_shift_for_rank(rank))
+    clouds, _ = feature_clouds(lib, ds)
+    est = make_estimator(lib, ds, clouds, kind, W, Wo)
+    steps = max(1, min(args.steps, 2))
+    rep = one_step(est)
+    dist_util.barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = one_step(est)
+    est.sync()
+    dist_util.barrier(world)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cpu")
+    sharded = keyframes = None
+    if world > 1:
+        sharded = sharded_solve_stats(lib, kind, W, Wo, rank, world, steps, sync=lambda: None, device="cpu", allreduce_numpy=dist_util.make_allreduce("cpu"))
+        km = keyframes_measure(lib, rank, world, 2 * world, 1, sync=lambda: None, device="cpu", use_library_gather=False, kind="indoor")
+        keyframes = km["line"] if km else None
+    if rank == 0:
+        print(json.dumps({
+            "dry_launch": True, "backend": lib.backend, "process_group": "gloo" if world > 1 else None,
+            "metric": "CPU rehearsal of the multi-rank control flow (NOT a measurement)", "value": round(world * steps / dt, 3), "unit": "solves/s",
+            "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (solve) / f32 (features)", "data": "synthetic",
+            "config": {"workload": f"VLP-16 indoor, window_size={W} opt_window_size={Wo}, CPU oracle", "n_lidar_residuals": int(rep.n_lidar_residuals),
+                       "parallelism": f"{world} independent windows" if world > 1 else "1 window"},
+            "sharded": sharded, "keyframes": keyframes,
+        }))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +305,13 @@ def main():
     ap.add_argument("--shard-factors", action="store_true",
                     help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
                          "equation moments per linearisation (SURVEY.md §8e).  Default: one independent window per rank, no collective.")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU rehearsal of the multi-rank run: gloo + the CPU oracle on a small VLP-16 window (no GPU needed, nothing measured)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))          # one rank per GPU under torch.distributed.run, same flags
 
     import torch
     import torch.distributed as dist
@@ -115,8 +319,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N` "
+                         "without a launcher and let it start the ranks itself)")
+    if args.dry_launch:
+        return dry_run(args, rank, world, torch, dist)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -150,6 +361,7 @@ def main():
         # the all-reduce of the per-shard moments runs INSIDE the library: ncclAllReduce on the estimator's stream (RCCL over xGMI)
         rccl = dist_util.make_rccl(hip, rank, world)
         est.set_factor_sharding_rccl(rccl)
+        assert rccl.world_seen_by_rccl() == world
     new_stack_n = est.get_surf_stack(W).shape[0]
 
     for _ in range(args.warmup):
@@ -182,6 +394,14 @@ def main():
     value = world * args.steps / dt_max
     if args.shard_factors:
         value = args.steps / dt_max  # one window solved cooperatively: total work is fixed
+
+    # N > 1: the two modes with a real exchange step, measured in the same run on every rank (collective), reported by rank 0
+    sharded_extra = keyframes_extra = None
+    if world > 1 and not args.shard_factors:
+        sharded_extra = sharded_solve_stats(hip, kind, W, Wo, rank, world, max(10, args.steps // 2), sync=torch.cuda.synchronize, device="cuda")
+        if args.keyframes > 0:
+            km = keyframes_measure(hip, rank, world, min(args.keyframes, 256), 3, sync=torch.cuda.synchronize, device="cuda")
+            keyframes_extra = km["line"] if km else None
 
     names = ["features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"]
     est.enable_kernel_timing(1)   # HIP events around EVERY launch of each kernel kind on the estimator's stream: untimed block
@@ -283,7 +503,8 @@ def main():
         odom_io = 3 if kind == "outdoor" else 2
         pp_med = float(np.median(pp_ms[1:]))
         out = {
-            "metric": "sliding-window solves/sec, 64-line 130k-pt scans, window=15 (opt_window=5)",
+            "metric": "sliding-window solves/sec, 64-line 130k-pt scans, window=15 (opt_window=5)" if kind == "outdoor"
+            else "sliding-window solves/sec, VLP-16 28.8k-pt scans, window=15 (opt_window=5) [NOT the headline workload]",
             "value": round(value, 3),
             "unit": "solves/s",
             "n_gpus": world,
@@ -311,6 +532,8 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "sharded": sharded_extra,
+            "keyframes": keyframes_extra,
             "batched": batched,
             "keyframe_batch": kf_stats,
             "batched_kernel_roofline": {"kernel": "k_lidar_moments[_sym]_batched + k_moment_reduce (fp64-MFMA form below 4 chunks per wave, structured fp64-VALU form above)", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
@@ -347,57 +570,10 @@ def main():
 def keyframes_workload(args, hip, rank, world, torch, dist):
     """configs[4] as a bench line: a step = one refinement of ALL --keyframes keyframes (each with its own local map in HBM).
     Rank r owns keyframes r, r+N, ...; the one exchange is an all-gather of the refined poses (RCCL).  Strong scaling."""
-    from lio_amd import capi, dist_util, synth
-
-    n_kf = max(args.keyframes, world)
-    ds = make_dataset("outdoor", 15)                      # the same scans on every rank
-    clouds, _ = feature_clouds(hip, ds)
-    captured = []
-    mapping_ms_per_scan(hip, ds, clouds, capture=captured)
-    rng = np.random.default_rng(5)
-    n_src = len(captured)
-    mine = list(range(rank, n_kf, world))
-    b = capi.KeyframeBatch(hip)
-    alg = []
-    T0s = []
-    for k in range(n_kf):                                 # every rank draws all initial poses: identical lists everywhere
-        c = captured[k % n_src]
-        q, p = c["T"]
-        R = synth.rot_from_quat(np.asarray(q, np.float64)) @ synth.small_rot(rng.uniform(-0.01, 0.01, 3))
-        T0s.append((synth.quat_from_rot(R), np.asarray(p, np.float64) + rng.uniform(-0.15, 0.15, 3)))
-    for j, k in enumerate(mine):
-        c = captured[k % n_src]
-        b.add_map(c["corner_map"], c["surf_map"])
-        b.add_keyframe(j, c["corner"], c["surf"], T0s[k])
-        M, N = c["corner"].shape[0] + c["surf"].shape[0], c["corner_map"].shape[0] + c["surf_map"].shape[0]
-        alg.append(16 * (M + N) + 72 * M)
-    per_rank = -(-n_kf // world)
-    rccl = dist_util.make_rccl(hip, rank, world) if world > 1 else None
-
-    def step():
-        if world > 1:   # refinement + ncclAllGather of the poses from the device pose buffer, both inside the library
-            g = b.refine_gather(rccl, per_rank)
-            mine_rows = g[rank, : len(mine)]
-            return dict(q=mine_rows[:, 0:4], p=mine_rows[:, 4:7], iterations=mine_rows[:, 7].astype(np.int32), device_ms=b.last_device_ms)
-        return b.refine()
-
-    for _ in range(max(args.warmup, 1)):
-        r = step()
-    dist_util.barrier(world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dev_ms = []
-    for _ in range(args.steps):
-        r = step()
-        dev_ms.append(r["device_ms"])
-    torch.cuda.synchronize()
-    dist_util.barrier(world)
-    dt = time.perf_counter() - t0
-    dt_max = dist_util.max_over_ranks(dt, world, device="cuda")
+    m = keyframes_measure(hip, rank, world, args.keyframes, args.steps, sync=torch.cuda.synchronize, device="cuda", warmup=args.warmup)
     if rank != 0:
         return
-    alg_bytes = float(np.dot(np.asarray(alg, np.float64), r["iterations"].astype(np.float64)))
-    ms = float(np.median(dev_ms))
+    n_kf, dt_max, alg_bytes, ms, captured = m["n_kf"], m["dt_max"], m["alg_bytes"], m["device_ms"], m["captured"]
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         o = keyframe_batch_stats(_oracle_lib(), captured, 4, reps=1, distinct_maps=False)
@@ -411,8 +587,8 @@ def keyframes_workload(args, hip, rank, world, torch, dist):
         "config": {"workload": f"{n_kf} HDL-64E keyframes (S_outdoor), each against its own local map resident in HBM, one scan-to-map Gauss-Newton loop per keyframe",
                    "stack_points_per_keyframe": int(captured[0]["corner"].shape[0] + captured[0]["surf"].shape[0]),
                    "local_map_points_per_keyframe": int(captured[0]["corner_map"].shape[0] + captured[0]["surf_map"].shape[0]),
-                   "iterations_mean": round(float(r["iterations"].mean()), 2),
-                   "parallelism": f"keyframes sharded over {world} ranks, all-gather of the poses" if world > 1 else "1 batch"},
+                   "iterations_mean": m["iterations_mean"], "rccl_world": m["line"]["rccl_world"],
+                   "parallelism": m["line"]["parallelism"]},
         "roofline": {"kernel": "k_kf_round (+ k_kf_rows, k_kf_update)", "bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(alg_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None,
                      "note": "rank 0's share; algorithmic bytes = sum over its keyframes of iterations x (16(M+N) + 72 M) (SURVEY.md 8(d)); device time of the round loop by HIP events; the kernel is gather-latency-bound (DESIGN.md 3.4)"},

@@ -480,6 +480,10 @@ void lio_rccl_destroy(lio_rccl *);
 int lio_rccl_rank(const lio_rccl *);
 int lio_rccl_world(const lio_rccl *);
 int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *comm_or_null);
+/* Measurement hook (collective: every rank of `comm` calls it with the same arguments): `reps` in-place SUM all-reduces of
+ * `count` doubles from a device buffer, back to back on one stream; avg_us_out = mean microseconds per all-reduce by HIP
+ * events on this rank.  bench.py reports it next to the factor-sharded solve rate (count = opt_window_size x 260). */
+int lio_rccl_bench_all_reduce(lio_rccl *comm, int count, int reps, double *avg_us_out);
 /* lio_kf_batch_refine followed by an all-gather of the results over `comm`: every rank receives `slots_per_rank` records of
  * 9 floats (q x,y,z,w; p x,y,z; iterations; rows) from every rank, rank r's records at [r * slots_per_rank, ...), records
  * beyond a rank's own keyframe count zero.  packed_all: world * slots_per_rank * 9 floats (host). */

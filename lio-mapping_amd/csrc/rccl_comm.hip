@@ -62,7 +62,7 @@ static const RcclApi &rccl_api_or_throw() {
 #define LIO_NCCL(call)                                                                                             \
   do {                                                                                                             \
     ncclResult_t r__ = (call);                                                                                     \
-    if (r__ != ncclSuccess) throw DeviceError(std::string(#call) + " -> " + rccl_api().GetErrorString(r__));       \
+    if (r__ != ncclSuccess) throw ::lio::DeviceError(std::string(#call) + " -> " + ::lio::rccl_api().GetErrorString(r__)); \
   } while (0)
 
 void rccl_all_reduce_sum_f64(void *comm, double *dev_buf, size_t count, hipStream_t s) {
@@ -111,6 +111,29 @@ void lio_rccl_destroy(lio_rccl *h) {
   delete h;
 }
 
+int lio_rccl_bench_all_reduce(lio_rccl *h, int count, int reps, double *avg_us) {
+  if (!h || !h->comm || count < 1 || reps < 1 || !avg_us) return LIO_ERR_ARG;
+  try {
+    const lio::RcclApi &api = lio::rccl_api_or_throw();
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double *buf = nullptr;
+    LIO_HIP(hipStreamCreate(&s));
+    LIO_HIP(hipEventCreate(&e0)); LIO_HIP(hipEventCreate(&e1));
+    LIO_HIP(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(double) * size_t(count)));
+    LIO_HIP(hipMemsetAsync(buf, 0, sizeof(double) * size_t(count), s));
+    for (int k = 0; k < 3; ++k) LIO_NCCL(api.AllReduce(buf, buf, size_t(count), ncclDouble, ncclSum, h->comm, s));   // warm-up: channel setup
+    LIO_HIP(hipEventRecord(e0, s));
+    for (int k = 0; k < reps; ++k) LIO_NCCL(api.AllReduce(buf, buf, size_t(count), ncclDouble, ncclSum, h->comm, s));
+    LIO_HIP(hipEventRecord(e1, s));
+    LIO_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    LIO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1e3 * double(ms) / reps;
+    (void)hipFree(buf); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return LIO_OK;
+  } catch (...) { return LIO_ERR_DEVICE; }
+}
 int lio_rccl_rank(const lio_rccl *h) { return h ? h->rank : -1; }
 int lio_rccl_world(const lio_rccl *h) { return h ? h->world : 0; }
 

@@ -237,6 +237,7 @@ _SIGS = {
     "lio_rccl_world": (C.c_int, [C.c_void_p]),
     "lio_est_set_factor_sharding_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lio_kf_batch_refine_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_float_p, c_double_p]),
+    "lio_rccl_bench_all_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "lio_est_bench_batched_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "lio_est_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "lio_est_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, c_double_p]),
@@ -604,6 +605,16 @@ class Rccl:
         if not self.h:
             raise LioError("lio_rccl_init failed")
         self.rank, self.world = int(rank), int(world)
+
+    def world_seen_by_rccl(self) -> int:
+        """lio_rccl_world: what the communicator itself reports (bench.py prints it next to n_gpus)."""
+        return int(self.lib.dll.lio_rccl_world(self.h))
+
+    def bench_all_reduce(self, count: int, reps: int = 200) -> float:
+        """collective: mean microseconds per in-place SUM all-reduce of `count` doubles (HIP events, this rank)."""
+        us = C.c_double(0)
+        _chk(self.lib.dll.lio_rccl_bench_all_reduce(self.h, int(count), int(reps), C.byref(us)), "lio_rccl_bench_all_reduce")
+        return us.value
 
     def __del__(self):
         if getattr(self, "h", None):

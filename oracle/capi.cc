@@ -812,6 +812,7 @@ void lio_rccl_destroy(lio_rccl *) {}
 int lio_rccl_rank(const lio_rccl *) { return -1; }
 int lio_rccl_world(const lio_rccl *) { return 0; }
 int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *) { return LIO_ERR_DEVICE; }
+int lio_rccl_bench_all_reduce(lio_rccl *, int, int, double *) { return LIO_ERR_DEVICE; }
 int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *, int, float *, double *) { return LIO_ERR_DEVICE; }
 int lio_est_bench_batched_moments(lio_est *, int, int, double *, double *) { return LIO_ERR_STATE; }  // device-only measurement
 int lio_est_enable_kernel_timing(lio_est *h, int) { return h ? LIO_OK : LIO_ERR_ARG; }

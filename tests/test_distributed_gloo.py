@@ -151,3 +151,34 @@ def test_keyframe_batch_shards_over_ranks(oracle):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(a, c)
     assert out[0][0].shape == (5, 4) and np.all(out[0][2] > 0)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (torch.distributed.run on 127.0.0.1) and print ONE
+    line with n_gpus = 2 plus the `sharded` and `keyframes` extras; --dry-launch runs that control flow on gloo with the CPU
+    oracle as the worker.  Without --dry-launch and without GPUs the launcher refuses loudly instead of running one rank."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "2 independent windows"
+    sh, kf = out["sharded"], out["keyframes"]
+    assert sh["scaling"] == "strong" and sh["value"] > 0 and sh["linearisations_per_solve"] == sh["solver_iterations"] + 1
+    assert sh["solver_iterations"] == sh["solver_iterations_unsharded"] and sh["final_cost_rel_gap_to_unsharded"] < 1e-9
+    assert kf["scaling"] == "strong" and kf["keyframes"] == 4 and kf["value"] > 0
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -154,3 +154,28 @@ def test_teacher_forced_chain_of_20_solves(hip, oracle, kind, frame_dt):
         sa, sb = ea.get_surf_stack(f), eb.get_surf_stack(f)
         assert sa.shape == sb.shape
         np.testing.assert_allclose(sa[:, :3], sb[:, :3], atol=5e-4)
+
+
+def test_stream_sync_fallback_gives_the_same_bits(hip, oracle):
+    """lio_est_config.stream_sync = 1 (the LIO_HOST_SIGNAL=0 path: D2H copies + hipStreamSynchronize instead of completion words in
+    host memory) must stay alive: same kernels, same arithmetic => the same window bit for bit over solve + slide + solve."""
+    from lio_amd import capi, synth
+    W, Wo = 8, 4
+    ds = synth.make_dataset("indoor", W + 3, 0.2)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+    wins = []
+    for sync in (0, 1):
+        cfg = pipeline.config_indoor(hip, W, Wo)
+        cfg.keep_features, cfg.cutoff_deskew, cfg.prior_factor, cfg.stream_sync = 0, 1, 1, sync
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(hip, cfg)
+        pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)
+        reps = [est.solve()]
+        est.slide()
+        for k in (W + 1, W + 2):
+            reps.append(pipeline.feed_frame(est, ds, k, clouds[k][0], clouds[k][1]))
+        wins.append((est.get_window(), [r.final_cost for r in reps], [r.n_lidar_residuals for r in reps]))
+    (wa, ca, na), (wb, cb, nb) = wins
+    assert na == nb and ca == cb
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        np.testing.assert_array_equal(wa[key], wb[key])

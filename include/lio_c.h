@@ -491,7 +491,9 @@ int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *comm, int slots_per_ran
 
 /* Per-kernel timing with HIP events on the estimator's own stream (bench.py's roofline block).
  * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
- * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat".
+ * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat"; and "moments_resident": the passes of the
+ * resident moments kernel (lio_est_config.resident_moments), which one launch per solve serves — timed on the device's wall
+ * clock from the doorbell seen to the sums posted, counted since the handle was created, independent of `on`.
  * `on` = 0 stops, 1 times every launch, N > 1 times every N-th launch of each kind (an event pair between two
  * kernels costs a few microseconds of dispatch overlap; sampling keeps the timed region honest).
  * get returns the number of launches TIMED since timing was enabled (0 for an unknown name or

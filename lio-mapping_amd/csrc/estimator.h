@@ -260,7 +260,31 @@ class Estimator {
   DBuf<int> d_moment_tickets_;
   bool fold_in_kernel_ = false;
   int moments_form_ = 0;            // 0 by launch size, 1 MFMA, 2 VALU
-  bool resident_moments_ = true;    // the moments of a solve from one resident kernel behind a doorbell (solve_kernels.h)
+  // Resident moments (solve_kernels.h): one launch per solve; every linearisation is a doorbell write + a spin on
+  // the blocks' completion words.  Begun lazily by the first LidarLaunch of a SolveOptimization, stopped when it returns.
+  bool resident_moments_ = true;    // configured (lio_est_config.resident_moments / LIO_RESIDENT_MOMENTS)
+  int res_per_lane_ = 4;            // residuals a lane keeps in registers (LIO_RES_PER_LANE: 1, 2, 4, 8)
+  bool res_allowed_ = false;        // inside SolveOptimization
+  bool res_active_ = false;         // a resident kernel is waiting on the doorbell
+  int res_bpf_ = 0, res_nframes_ = 0;
+  unsigned res_seq_ = 0;            // sequence number of the last pass rung (monotonic over the life of the handle)
+  double *h_res_door_ = nullptr, *h_res_out_ = nullptr;    // coherent pinned host memory: doorbell, per-frame folded records
+  unsigned *h_res_words_ = nullptr;
+  long long res_timeout_ticks_ = 0;
+  double res_tick_us_ = 0.01;       // microseconds per wall-clock tick
+  double res_busy_us_ = 0, res_bytes_ = 0; int res_passes_ = 0, res_passes_total_ = 0;   // device-side busy time of the passes (doorbell copy seen -> sums posted), SURVEY 8(d) bytes
+  MomentArgs res_args_{};
+  DBuf<double> d_res_relay_, d_res_part_;   // HBM: the doorbell as republished by the relay block; the per-block records
+  double res_diag_us_[4] = {0, 0, 0, 0}, res_polls_ = 0, res_relay_us_ = 0, res_ring_to_done_ms_ = 0, res_t_ring_ = 0;
+  int ResidentBpf(int max_slots, int nframes) const;
+  bool ResidentBegin(const MomentArgs &ma);
+  void ResidentRing(const MomentArgs &ma);
+  void ResidentWait(std::vector<FrameMoments> &m);
+  void ResidentLaunchKernel(unsigned first_seq);
+ public:
+  void ResidentEnd();
+  double ResidentBusyUs(int *passes, double *bytes) const { if (passes) *passes = res_passes_total_; if (bytes) *bytes = res_bytes_; return res_busy_us_; }
+ private:
   // Device-resident dogleg (solve_step.h), opt-in with LIO_DEVICE_SOLVE=1.  Measured on the MI355X at D = 96 it is SLOWER than
   // the host loop for one window (launch B = one workgroup: 150 us per iteration against the host's 17 us of assemble +
   // Cholesky + step), so the host loop stays the default; it exists for hosts that drive many windows per

@@ -100,6 +100,23 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_MOMENTS")) moments_form_ = std::string(e) == "mfma" ? 1 : (std::string(e) == "valu" ? 2 : moments_form_);
   if (const char *e = std::getenv("LIO_RESIDENT_MOMENTS")) resident_moments_ = std::atoi(e) != 0;
+  d_res_relay_.reserve(size_t(LIO_MAX_FRAMES) * LIO_RES_DOOR);
+  LIO_HIP(hipMemset(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR));
+  d_res_part_.reserve(size_t(LIO_RES_MAX_BLOCKS) * LIO_MOMENT_OUT);
+  LIO_HIP(hipMemset(d_res_part_.p, 0, sizeof(double) * LIO_RES_MAX_BLOCKS * LIO_MOMENT_OUT));   // flags: no pass has sequence number 0
+  if (const char *e = std::getenv("LIO_RES_PER_LANE")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) res_per_lane_ = v; }
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_door_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, hipHostMallocCoherent));
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_OUT, hipHostMallocCoherent));
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_words_), sizeof(unsigned) * (LIO_MAX_FRAMES + 1), hipHostMallocCoherent));   // + the relay block's word
+  std::memset(h_res_door_, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR);
+  std::memset(h_res_words_, 0, sizeof(unsigned) * (LIO_MAX_FRAMES + 1));
+  {
+    int khz = 0, dev = 0;
+    LIO_HIP(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz on gfx9
+    res_tick_us_ = 1e3 / double(khz);
+    res_timeout_ticks_ = (long long)(0.2 * 1e3 * khz);   // 200 ms without a doorbell: the block posts LIO_RES_EXPIRED and exits
+  }
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
   // coherent (fine-grained): kernels store results and completion words here and the host reads them while the stream is live
@@ -115,7 +132,11 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
 }
 
 Estimator::~Estimator() {
+  try { ResidentEnd(); if (stream_) (void)hipStreamSynchronize(stream_); } catch (...) {}
   try { JoinMarg(); } catch (...) {}
+  if (h_res_door_) (void)hipHostFree(h_res_door_);
+  if (h_res_out_) (void)hipHostFree(h_res_out_);
+  if (h_res_words_) (void)hipHostFree(h_res_words_);
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
   if (h_signal_) (void)hipHostFree(h_signal_);
   if (h_odom_) (void)hipHostFree(h_odom_);
@@ -628,6 +649,114 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
   }
   ma.blocks_per_frame = moment_blocks_per_frame(max_slots);
   ma.form = moments_form_;
+  // With the resident form configured, BOTH paths use its partition (blocks per frame so that a lane holds <= res_per_lane_
+  // 64-slot chunks per wave, fp64-MFMA form): the launch path — taken when a pass cannot use the resident kernel (kernel timing, factor
+  // sharding, stream_sync) — then yields bit-identical moments.
+  const int rb = ResidentBpf(max_slots, ma.nframes);
+  if (rb > 0) { ma.blocks_per_frame = rb; ma.form = 1; }
+}
+
+int Estimator::ResidentBpf(int max_slots, int nframes) const {
+  if (!resident_moments_ || fold_in_kernel_ || moments_form_ == 2) return 0;
+  return resident_blocks_per_frame(max_slots, nframes, res_per_lane_);
+}
+
+void Estimator::ResidentLaunchKernel(unsigned first_seq) {
+  ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p};
+  // the relay copy may still hold the previous launch's STOP: clear it behind that launch, in front of this one
+  LIO_HIP(hipMemsetAsync(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, stream_));
+  launch_lidar_moments_resident(res_args_, ra, res_per_lane_, f_valid_.p, f_coef_.p, stream_);
+}
+
+// The resident kernel of this solve: launched behind everything the feature stage enqueued on stream_; it returns when the host
+// writes LIO_RES_STOP (ResidentEnd) or after res_timeout_ticks_ without a doorbell.
+bool Estimator::ResidentBegin(const MomentArgs &ma) {
+  if (!res_allowed_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_ || device_solve_) return false;
+  int max_slots = 0;
+  for (int k = 0; k < ma.nframes; ++k) max_slots = std::max(max_slots, ma.fr[k].nslots);
+  if (ResidentBpf(max_slots, ma.nframes) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
+  res_args_ = ma;
+  res_bpf_ = ma.blocks_per_frame; res_nframes_ = ma.nframes;
+  for (int f = 0; f < res_nframes_; ++f) {   // idle doorbell: neither the expected sequence number nor STOP
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 7), 0ull, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 15), 0ull, __ATOMIC_RELEASE);
+  }
+  ResidentLaunchKernel(res_seq_ + 1);
+  res_active_ = true;
+  return true;
+}
+
+void Estimator::ResidentRing(const MomentArgs &ma) {
+  const unsigned seq = ++res_seq_;
+  const double sd = double(seq);
+  for (int f = 0; f < res_nframes_; ++f) {
+    double *d = h_res_door_ + f * LIO_RES_DOOR;
+    const MomentFrame &fr = ma.fr[f];
+    // payload first, the sequence slot of each cache line last (x86 keeps the order of stores; the GPU reads a line at a time)
+    for (int k = 0; k < 7; ++k) d[k] = fr.R[k];
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(d + 7), *reinterpret_cast<const unsigned long long *>(&sd), __ATOMIC_RELEASE);
+    d[8] = fr.R[7]; d[9] = fr.R[8]; d[10] = fr.t[0]; d[11] = fr.t[1]; d[12] = fr.t[2]; d[13] = 0.0; d[14] = 0.0;
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(d + 15), *reinterpret_cast<const unsigned long long *>(&sd), __ATOMIC_RELEASE);
+  }
+}
+
+void Estimator::ResidentWait(std::vector<FrameMoments> &m) {
+  const unsigned seq = res_seq_;
+  const int nf = res_nframes_;
+  const volatile unsigned *w = h_res_words_;
+  int k = 0;
+  for (unsigned long it = 1;; ++it) {
+    while (k < nf && __atomic_load_n(w + k, __ATOMIC_ACQUIRE) == seq) ++k;
+    if (k == nf) break;
+    if (__atomic_load_n(w + LIO_MAX_FRAMES, __ATOMIC_ACQUIRE) == LIO_RES_EXPIRED) {
+      // the relay gave up waiting (this host thread was held up for > 200 ms): let that launch drain — a timeout ends it between
+      // passes, so no ticket is half drawn — and start a new one for the pass that is pending; its doorbell is still rung
+      LIO_HIP(hipStreamSynchronize(stream_));
+      h_res_words_[LIO_MAX_FRAMES] = 0;
+      ResidentLaunchKernel(seq);
+      k = 0;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((it & 0xFFFFu) == 0) {
+      const hipError_t e = hipStreamQuery(stream_);
+      if (e != hipErrorNotReady && e != hipSuccess) throw DeviceError(std::string("resident moments pass failed: ") + hipGetErrorString(e));
+      if (e == hipSuccess && h_res_words_[LIO_MAX_FRAMES] != LIO_RES_EXPIRED) {   // the kernel is gone although nobody stopped it
+        bool all = true;
+        for (int f = 0; f < nf; ++f) all = all && h_res_words_[f] == seq;
+        if (!all) throw DeviceError("resident moments kernel ended without posting its pass");
+      }
+    }
+  }
+  double busy = 0, fold = 0, polls = 0;
+  for (int f = 0; f < nf; ++f) {
+    FrameMoments &fm = m[f + 1];
+    const double *rec = h_res_out_ + size_t(f) * LIO_RES_OUT;
+    std::memcpy(fm.S, rec, 256 * sizeof(double));
+    fm.cost = rec[256]; fm.count = rec[257];
+    double *o = h_moment_out_ + size_t(f) * LIO_MOMENT_OUT;   // the landing zone of the launch path doubles as "the last moments"
+    o[256] = fm.cost; o[257] = fm.count;
+    for (int q = 0; q < 4; ++q) res_diag_us_[q] += rec[258 + q] * res_tick_us_ / nf;
+    polls += rec[262] / nf;
+    res_relay_us_ += rec[263] * res_tick_us_ / nf;
+    busy = std::max(busy, rec[261]);
+  }
+  (void)fold;
+  res_busy_us_ += busy * res_tick_us_;   // doorbell copy seen -> sums posted, slowest frame
+  { double nres = 0; for (int f = 0; f < nf; ++f) nres += res_args_.fr[f].nslots; res_bytes_ += 60.0 * nres; }   // 60 B per lidar residual
+  res_polls_ += polls; ++res_passes_; ++res_passes_total_;
+}
+
+void Estimator::ResidentEnd() {
+  res_allowed_ = false;
+  if (!res_active_) return;
+  const double stop = LIO_RES_STOP;
+  const unsigned long long bits = *reinterpret_cast<const unsigned long long *>(&stop);
+  for (int f = 0; f < res_nframes_; ++f) {
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 7), bits, __ATOMIC_RELEASE);
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 15), bits, __ATOMIC_RELEASE);
+  }
+  res_active_ = false;   // the kernel leaves within one poll; whatever is enqueued on stream_ next is ordered behind it
 }
 
 // Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.
@@ -710,6 +839,7 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   int max_slots = 0;
   FillMomentArgs(ma, max_slots);
   for (int i = 1; i <= Wo_; ++i) relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), ma.fr[i - 1].R, ma.fr[i - 1].t);
+  if (res_active_ || ResidentBegin(ma)) { res_t_ring_ = now_ms(); ResidentRing(ma); return; }
   d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
   d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
   double nres = 0;
@@ -789,6 +919,7 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
 void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   const double t_dbg0 = now_ms();
   struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
+  if (res_active_) { ResidentWait(m); dbg_sync_ms_ += now_ms() - t_dbg0; res_ring_to_done_ms_ += now_ms() - res_t_ring_; return; }
   if (moment_signal_.flag && !rccl_comm_) wait_host_signal(moment_signal_, stream_);
   else LIO_HIP(hipStreamSynchronize(stream_));
   dbg_sync_ms_ += now_ms() - t_dbg0;
@@ -812,6 +943,9 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   std::memset(&R, 0, sizeof(R));
   bool turn_off = true;
   BuildLocalMap(&R);
+  // from here to the end of the solve the lidar passes may come from ONE resident kernel (begun by the first LidarLaunch)
+  struct ResidentScope { Estimator *e; ~ResidentScope() { e->ResidentEnd(); } } resident_scope{this};
+  res_allowed_ = true;
   const double t_prep0 = now_ms();
   const int pivot = W_ - Wo_;
   WindowParams P;
@@ -940,6 +1074,12 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   if (g_debug_timing) {
     std::fprintf(stderr, "[lio_hip timing] total %.3f map %.3f feat %.3f opt %.3f marg %.3f | lidar_eval %d calls %.3f ms (%.1f us each)\n", R.ms_total,
                  R.ms_build_map, R.ms_features, R.ms_opt, R.ms_marg, dbg_eval_n_, dbg_eval_ms_, dbg_eval_n_ ? 1e3 * dbg_eval_ms_ / dbg_eval_n_ : 0.0);
+  }
+  if (g_debug_timing && res_passes_) {
+    std::fprintf(stderr, "[lio_hip timing] resident moments: %d passes; folding block, from the doorbell copy seen (us): accumulated %.2f, parked %.2f, all flags in %.2f, sums posted %.2f; relay detect -> copy seen %.2f; host ring -> moments unpacked %.2f; HBM polls %.1f; %d worker blocks\n",
+                 res_passes_, res_diag_us_[0] / res_passes_, res_diag_us_[1] / res_passes_, res_diag_us_[2] / res_passes_, res_diag_us_[3] / res_passes_,
+                 res_relay_us_ / res_passes_, 1e3 * res_ring_to_done_ms_ / res_passes_, res_polls_ / res_passes_, res_bpf_ * res_nframes_);
+    res_diag_us_[0] = res_diag_us_[1] = res_diag_us_[2] = res_diag_us_[3] = res_polls_ = res_relay_us_ = res_ring_to_done_ms_ = 0; res_passes_ = 0;
   }
   if (g_debug_timing) std::fprintf(stderr, "[lio_hip timing] of which hipStreamSynchronize %.3f ms\n", dbg_sync_ms_);
   dbg_eval_ms_ = 0; dbg_eval_n_ = 0; dbg_sync_ms_ = 0;

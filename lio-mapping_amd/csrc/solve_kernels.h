@@ -38,6 +38,33 @@ struct MomentArgs {
 void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
                           hipStream_t s, const HostSignal &sig = HostSignal());
 int moment_blocks_per_frame(int max_slots);
+
+// ---- resident form: ONE launch per solve.  The worker blocks keep their residuals in registers and wait for
+// every linearisation point (Wo relative poses + a sequence number) on a doorbell; each pass a wave pushes its cached residuals
+// through the fp64 MFMA tile, the block parks its 16x16 sums (+ cost, count) in HBM behind a per-block flag; block 0 of each frame
+// waits for its frame's flags, folds the blocks in k_moment_reduce's order and posts the frame's moments + a completion word to
+// coherent host memory.  One extra block — the
+// relay — is the only poller of host memory: measured on the MI355X box (tools/micro/pingpong.hip) a host -> kernel -> host
+// round trip is 2.3 us with one polling block and 13-19 us with a hundred, so the relay republishes the doorbell in HBM and the
+// workers poll that copy.  Arithmetic per block = k_lidar_moments (MFMA form) at the same blocks per frame and the fold =
+// k_moment_reduce's, so the moments are bit-identical to the two-launch path in that configuration.
+#define LIO_RES_OUT 264            // doubles per frame in the host landing zone: 256 S entries + cost + count + 5 diagnostics + pad
+#define LIO_RES_DOOR 16            // doubles per frame in the doorbell: [R0..R6, seq | R7, R8, t0, t1, t2, 0, 0, seq] (two cache lines)
+#define LIO_RES_EXPIRED 0xFFFFFFFFu
+#define LIO_RES_STOP (-1.0)
+#define LIO_RES_MAX_BLOCKS 256     // one per CU: every block must be co-resident with nothing but the host to wait for
+struct ResidentArgs {
+  const double *door;        // host, coherent
+  double *out;               // host, coherent: frame f's folded moments at f * LIO_RES_OUT (layout of LIO_MOMENT_OUT, then diagnostics)
+  unsigned *words;           // host, coherent: one completion word per frame, [LIO_MAX_FRAMES] = the relay's (LIO_RES_EXPIRED on a timeout)
+  unsigned first_seq;        // the sequence number of the first pass this launch serves
+  long long timeout_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) without a doorbell before the kernel gives up
+  double *relay;             // device: the doorbell republished by the relay block (same layout)
+  double *block_part;        // device: block b's record at b * LIO_MOMENT_OUT; slot LIO_MOMENT_OUT - 1 = the pass it belongs to (the flag)
+};
+// blocks per frame so that a lane holds at most `per_lane` residuals (0 when the window does not fit LIO_RES_MAX_BLOCKS)
+int resident_blocks_per_frame(int max_slots, int nframes, int per_lane);
+void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, int per_lane, const uint8_t *valid, const float4 *coef, hipStream_t s);
 int moment_blocks_per_frame_batched(int max_slots, int nframes);
 // same pass over `nframes` frame descriptors held in device memory (any number of windows in one launch)
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,

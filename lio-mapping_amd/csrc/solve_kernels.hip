@@ -59,6 +59,8 @@ struct LogProduct {
   __device__ __forceinline__ double log_value() const { return log(prod) + exp2 * 0.69314718055994530942; }
 };
 
+__device__ __forceinline__ double ds_bcast_lane(double v, int src_lane);   // defined below (v_readlane of both halves)
+
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
 __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
@@ -208,6 +210,88 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
 #define LIO_NACC 73
 #define RED_ROW (16 * 17 + 1)
 
+// one residual into the 73 per-lane sums (shared by the launch form and the resident form: identical arithmetic)
+__device__ __forceinline__ void sym_accumulate(const double *__restrict__ Rm, const double *__restrict__ tv, float fpx, float fpy, float fpz, float4 c, bool ok,
+                                               double (&a)[LIO_NACC], LogProduct &lp, double &cnt) {
+  const double px = fpx, py = fpy, pz = fpz;
+  const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
+  const double qx = Rm[0] * px + Rm[1] * py + Rm[2] * pz + tv[0];
+  const double qy = Rm[3] * px + Rm[4] * py + Rm[5] * pz + tv[1];
+  const double qz = Rm[6] * px + Rm[7] * py + Rm[8] * pz + tv[2];
+  const double r = w0 * qx + w1 * qy + w2 * qz + d;
+  const double sq = r * r;
+  const double sw = ok ? rsqrt_1p(1.0 + sq) : 0.0;
+  const double S[3] = {sw * w0, sw * w1, sw * w2};
+  const double dd = sw * d;
+  lp.mul(ok ? 1.0 + sq : 1.0);
+  cnt += ok ? 1.0 : 0.0;
+  const double P[10] = {px * px, px * py, px * pz, px, py * py, py * pz, py, pz * pz, pz, 1.0};
+  const double W[6] = {S[0] * S[0], S[0] * S[1], S[0] * S[2], S[1] * S[1], S[1] * S[2], S[2] * S[2]};
+  const double Q[4] = {px * dd, py * dd, pz * dd, dd};
+#pragma unroll
+  for (int ab = 0; ab < 6; ++ab)
+#pragma unroll
+    for (int ij = 0; ij < 10; ++ij) a[ab * 10 + ij] = __builtin_fma(W[ab], P[ij], a[ab * 10 + ij]);
+#pragma unroll
+  for (int sa = 0; sa < 3; ++sa)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[60 + sa * 4 + i] = __builtin_fma(S[sa], Q[i], a[60 + sa * 4 + i]);
+  a[72] = __builtin_fma(dd, dd, a[72]);
+}
+
+// block fold of the 73 per-lane sums (+ cost, count) into uniq[0..74], 16 accumulators at a time:
+// [16][16 slices of 16 threads, padded to 17] then [16][16 slices].  Ends with a barrier: uniq is readable by every thread.
+struct SymFoldLds {
+  double red[16 * RED_ROW];
+  double red2[16 * 17];
+  double uniq[LIO_NACC + 2];
+  double cw[MOMENT_THREADS / 64][2];
+};
+__device__ __forceinline__ void sym_block_fold(const double (&a)[LIO_NACC], const LogProduct &lp, double cnt, SymFoldLds &L) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kk = tid & 15, sl = tid >> 4;
+#pragma unroll
+  for (int g = 0; g < (LIO_NACC + 15) / 16; ++g) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (g * 16 + k < LIO_NACC) L.red[k * RED_ROW + sl * 17 + kk] = a[g * 16 + k];
+    __syncthreads();
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += L.red[kk * RED_ROW + sl * 17 + j];
+    L.red2[kk * 17 + sl] = v;
+    __syncthreads();
+    if (tid < 16 && g * 16 + tid < LIO_NACC) {
+      double w = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w += L.red2[tid * 17 + q];
+      L.uniq[g * 16 + tid] = w;
+    }
+    __syncthreads();
+  }
+  double cost = 0.5 * lp.log_value();
+  for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
+  if (lane == 0) { L.cw[wv][0] = cost; L.cw[wv][1] = cnt; }
+  __syncthreads();
+  if (tid < 2) {
+    double w = 0.0;
+    for (int q = 0; q < MOMENT_THREADS / 64; ++q) w += L.cw[q][tid];
+    L.uniq[LIO_NACC + tid] = w;
+  }
+  __syncthreads();
+}
+// (row, col) of the 16x16 moment matrix -> index into the 73 sums (-1: structural zero)
+__host__ __device__ inline int sym_unique_index(int r, int cidx) {
+  if (r >= 13 || cidx >= 13) return -1;
+  if (r == 12 && cidx == 12) return 72;
+  if (r == 12 || cidx == 12) return 60 + (r == 12 ? cidx : r);
+  const int ra = r >> 2, ri = r & 3, ca = cidx >> 2, ci = cidx & 3;
+  const int a0 = ra < ca ? ra : ca, a1 = ra < ca ? ca : ra, i0 = ri < ci ? ri : ci, i1 = ri < ci ? ci : ri;
+  const int ab = a0 == 0 ? a1 : (a0 == 1 ? 2 + a1 : 5);                          // 00 01 02 11 12 22
+  const int ij = i0 == 0 ? i1 : (i0 == 1 ? 3 + i1 : (i0 == 2 ? 5 + i1 : 9));     // 00 01 02 03 11 12 13 22 23 33
+  return ab * 10 + ij;
+}
+
 __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
                                                        double *__restrict__ partials, int nblk) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -216,7 +300,7 @@ __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, co
   double a[LIO_NACC];
 #pragma unroll
   for (int k = 0; k < LIO_NACC; ++k) a[k] = 0.0;
-  double cost = 0.0, cnt = 0.0;
+  double cnt = 0.0;
   LogProduct lp;
   const int stride = waves_total * 64;
   for (int base = fr.slot_begin + wid * 64; base < fr.slot_end; base += stride) {
@@ -226,82 +310,286 @@ __device__ __forceinline__ void lidar_moments_sym_body(const MomentFrame &fr, co
     const bool ok = in && valid[fr.slot_off + si] != 0;
     const float4 po = fr.stack[si % fr.M];
     const float4 c = coef[fr.slot_off + si];
-    const double px = po.x, py = po.y, pz = po.z;
-    const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
-    const double qx = fr.R[0] * px + fr.R[1] * py + fr.R[2] * pz + fr.t[0];
-    const double qy = fr.R[3] * px + fr.R[4] * py + fr.R[5] * pz + fr.t[1];
-    const double qz = fr.R[6] * px + fr.R[7] * py + fr.R[8] * pz + fr.t[2];
-    const double r = w0 * qx + w1 * qy + w2 * qz + d;
-    const double sq = r * r;
-    const double sw = ok ? rsqrt_1p(1.0 + sq) : 0.0;
-    const double S[3] = {sw * w0, sw * w1, sw * w2};
-    const double dd = sw * d;
-    lp.mul(ok ? 1.0 + sq : 1.0);
-    cnt += ok ? 1.0 : 0.0;
-    const double P[10] = {px * px, px * py, px * pz, px, py * py, py * pz, py, pz * pz, pz, 1.0};
-    const double W[6] = {S[0] * S[0], S[0] * S[1], S[0] * S[2], S[1] * S[1], S[1] * S[2], S[2] * S[2]};
-    const double Q[4] = {px * dd, py * dd, pz * dd, dd};
-#pragma unroll
-    for (int ab = 0; ab < 6; ++ab)
-#pragma unroll
-      for (int ij = 0; ij < 10; ++ij) a[ab * 10 + ij] = __builtin_fma(W[ab], P[ij], a[ab * 10 + ij]);
-#pragma unroll
-    for (int sa = 0; sa < 3; ++sa)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[60 + sa * 4 + i] = __builtin_fma(S[sa], Q[i], a[60 + sa * 4 + i]);
-    a[72] = __builtin_fma(dd, dd, a[72]);
+    sym_accumulate(fr.R, fr.t, po.x, po.y, po.z, c, ok, a, lp, cnt);
   }
-  // ---- block fold, 16 accumulators at a time: [16][16 slices of 16 threads, padded to 17] then [16][16 slices]
-  __shared__ double red[16 * RED_ROW];
-  __shared__ double red2[16 * 17];
-  __shared__ double uniq[LIO_NACC + 2];
-  const int kk = tid & 15, sl = tid >> 4;
-#pragma unroll
-  for (int g = 0; g < (LIO_NACC + 15) / 16; ++g) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (g * 16 + k < LIO_NACC) red[k * RED_ROW + sl * 17 + kk] = a[g * 16 + k];
-    __syncthreads();
-    double v = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v += red[kk * RED_ROW + sl * 17 + j];
-    red2[kk * 17 + sl] = v;
-    __syncthreads();
-    if (tid < 16 && g * 16 + tid < LIO_NACC) {
-      double w = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) w += red2[tid * 17 + q];
-      uniq[g * 16 + tid] = w;
-    }
-    __syncthreads();
-  }
-  __shared__ double cw[MOMENT_THREADS / 64][2];
-  cost = 0.5 * lp.log_value();
-  for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
-  if (lane == 0) { cw[wv][0] = cost; cw[wv][1] = cnt; }
-  __syncthreads();
+  __shared__ SymFoldLds L;
+  sym_block_fold(a, lp, cnt, L);
   double *dst = partials + (size_t(blockIdx.y) * nblk + blockIdx.x) * LIO_MOMENT_OUT;
   {
     // expand the 73 sums into the row-major 16x16 layout the host expects (13x13 used, rest zero)
-    const int r = tid >> 4, cidx = tid & 15;
-    double v = 0.0;
-    if (r < 13 && cidx < 13) {
-      if (r == 12 && cidx == 12) v = uniq[72];
-      else if (r == 12 || cidx == 12) { const int u = r == 12 ? cidx : r; v = uniq[60 + u]; }
-      else {
-        const int ra = r >> 2, ri = r & 3, ca = cidx >> 2, ci = cidx & 3;
-        const int a0 = min(ra, ca), a1 = max(ra, ca), i0 = min(ri, ci), i1 = max(ri, ci);
-        const int ab = a0 == 0 ? a1 : (a0 == 1 ? 2 + a1 : 5);             // 00 01 02 11 12 22
-        const int ij = i0 == 0 ? i1 : (i0 == 1 ? 3 + i1 : (i0 == 2 ? 5 + i1 : 9));  // 00 01 02 03 11 12 13 22 23 33
-        v = uniq[ab * 10 + ij];
+    const int u = sym_unique_index(tid >> 4, tid & 15);
+    dst[tid] = u >= 0 ? L.uniq[u] : 0.0;
+    if (tid < 2) dst[256 + tid] = L.uniq[LIO_NACC + tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident form: see solve_kernels.h.  Block b = frame * blocks_per_frame + j serves frame `frame` with the lane -> residual map
+// of k_lidar_moments_sym at the same blocks per frame (wave w of the frame takes slots slot_begin + 64 w + lane + it * stride).
+// one poll of a frame's doorbell record in HBM by lanes 0..15: returns the sequence number both cache lines agree on (NaN while
+// they differ); v keeps the lane's slot
+__device__ __forceinline__ double door_poll(const double *door, int lane, double &v) {
+  if (lane < LIO_RES_DOOR) v = __hip_atomic_load(door + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double s0 = ds_bcast_lane(v, 7), s1 = ds_bcast_lane(v, 15);
+  return s0 == s1 ? s0 : __builtin_nan("");
+}
+
+// The relay block: the only poller of host memory.  It waits until EVERY frame's two lines carry the expected sequence number (a
+// line is read whole, and the host stores a line's payload before its sequence slot), republishes what that poll read in HBM —
+// payload first, acknowledged, then the sequence slots — and goes back to polling.  STOP and the timeout travel the same way.
+#define RES_COST_AT (13 * 16 + 13)   // padding entries of the 16x16 tile that carry cost / count through the frame fold
+#define RES_CNT_AT (13 * 16 + 14)
+#define RES_RELAY_SLOTS 8   // doubles per lane: LIO_MAX_FRAMES * LIO_RES_DOOR / 64
+__device__ __forceinline__ void resident_relay(const MomentArgs &a, const ResidentArgs &ra) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x >= 64) return;
+  const int nd = a.nframes * LIO_RES_DOOR;
+  unsigned seq = ra.first_seq;
+  for (;;) {
+    const long long t0 = wall_clock64();
+    double v[RES_RELAY_SLOTS];
+    double verdict = 0.0;
+    for (;;) {
+      bool all_seq = true, all_stop = true;
+#pragma unroll
+      for (int q = 0; q < RES_RELAY_SLOTS; ++q) {
+        const int i = q * 64 + lane;
+        v[q] = (i < nd) ? __hip_atomic_load(ra.door + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < RES_RELAY_SLOTS; ++q) {
+        const int i = q * 64 + lane;
+        const bool is_slot = i < nd && ((i & 7) == 7);
+        all_seq = all_seq && __all(!is_slot || v[q] == double(seq));
+        all_stop = all_stop && __all(!is_slot || v[q] == LIO_RES_STOP);
+      }
+      if (all_seq) { verdict = double(seq); break; }
+      if (all_stop) { verdict = LIO_RES_STOP; break; }
+      if (wall_clock64() - t0 > ra.timeout_ticks) {
+        verdict = LIO_RES_STOP;
+        if (lane == 0) host_store(ra.words + LIO_MAX_FRAMES, LIO_RES_EXPIRED);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const double t_detect = double(wall_clock64());   // diagnostics: rides in the unused payload slot 13 of every frame record
+#pragma unroll
+    for (int q = 0; q < RES_RELAY_SLOTS; ++q) {
+      const int i = q * 64 + lane;
+      if (i < nd && (i & 7) != 7) __hip_atomic_store(ra.relay + i, (i & 15) == 13 ? t_detect : v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < RES_RELAY_SLOTS; ++q) {
+      const int i = q * 64 + lane;
+      if (i < nd && (i & 7) == 7) __hip_atomic_store(ra.relay + i, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (verdict == LIO_RES_STOP) return;
+    ++seq;
+  }
+}
+
+// z (13 values padded to 16), the factor of the running cost product and the count of ONE residual at the pose (Rm, tv): the
+// arithmetic of lidar_moments_body's setup, shared with it
+__device__ __forceinline__ void moment_z(const double *__restrict__ Rm, const double *__restrict__ tv, float fpx, float fpy, float fpz, float4 c, bool ok,
+                                         double (&z)[16], double &c_add, double &n_add) {
+  const double px = fpx, py = fpy, pz = fpz;
+  const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
+  const double qx = Rm[0] * px + Rm[1] * py + Rm[2] * pz + tv[0];
+  const double qy = Rm[3] * px + Rm[4] * py + Rm[5] * pz + tv[1];
+  const double qz = Rm[6] * px + Rm[7] * py + Rm[8] * pz + tv[2];
+  const double r = w0 * qx + w1 * qy + w2 * qz + d;
+  const double sq = r * r;
+  const double sw = ok ? rsqrt_1p(1.0 + sq) : 0.0;
+  const double s0 = sw * w0, s1 = sw * w1, s2 = sw * w2;
+  z[0] = s0 * px; z[1] = s0 * py; z[2] = s0 * pz; z[3] = s0;
+  z[4] = s1 * px; z[5] = s1 * py; z[6] = s1 * pz; z[7] = s1;
+  z[8] = s2 * px; z[9] = s2 * py; z[10] = s2 * pz; z[11] = s2;
+  z[12] = sw * d; z[13] = 0.0; z[14] = 0.0; z[15] = 0.0;
+  c_add = ok ? 1.0 + sq : 1.0;
+  n_add = ok ? 1.0 : 0.0;
+}
+
+// The resident kernel: fp64-MFMA form.  Block b = frame * blocks_per_frame + j serves frame `frame` with the wave -> chunk map of
+// k_lidar_moments at the same blocks per frame (wave w of the frame takes the 64-slot chunks slot_begin + 64 w + it * stride), the
+// chunks of a wave accumulate into its 16x16 MFMA tile in the same order, the four waves of a block are summed in the same order:
+// block records equal that kernel's partials bit for bit.
+template <int R>
+__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(MomentArgs a, ResidentArgs ra, const uint8_t *__restrict__ valid,
+                                                                           const float4 *__restrict__ coef) {
+  static_assert(LIO_MAX_FRAMES * LIO_RES_DOOR <= 64 * RES_RELAY_SLOTS, "relay lane slots");
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int e = lane & 15, grp = lane >> 4;
+  const int nblk = a.blocks_per_frame;
+  if (int(blockIdx.x) == nblk * a.nframes) { resident_relay(a, ra); return; }
+  const int f = blockIdx.x / nblk, j = blockIdx.x - f * nblk;
+  const MomentFrame &fr = a.fr[f];
+  // ---- the wave's residuals, loaded ONCE (features do not change during a solve); chunks past the frame's end stay empty
+  float px[R], py[R], pz[R];
+  float4 cf[R];
+  bool ok[R];
+  int nchunk = 0;
+  {
+    const int stride = nblk * (MOMENT_THREADS / 64) * 64;
+    const int base0 = fr.slot_begin + (j * (MOMENT_THREADS / 64) + wv) * 64;
+#pragma unroll
+    for (int it = 0; it < R; ++it) {
+      const int base = base0 + it * stride;
+      if (base < fr.slot_end) nchunk = it + 1;
+      const int sidx = base + lane;
+      const bool in = sidx < fr.slot_end;
+      const int si = in ? sidx : fr.slot_begin;
+      ok[it] = in && valid[fr.slot_off + si] != 0;
+      const float4 po = fr.stack[si % fr.M];
+      px[it] = po.x; py[it] = po.y; pz[it] = po.z;
+      cf[it] = coef[fr.slot_off + si];
+    }
+  }
+  __shared__ double zbuf[MOMENT_THREADS / 64][64 * ZROW];
+  __shared__ double sm[MOMENT_THREADS / 64][LIO_MOMENT_OUT];
+  __shared__ double pose[12];
+  __shared__ int cmd, go;
+  __shared__ long long t_seen;
+  __shared__ int n_polls;
+  __shared__ double t_relay;
+  double *zb = zbuf[wv];
+  const double *door = ra.relay + size_t(f) * LIO_RES_DOOR;
+  double *mine = ra.block_part + size_t(blockIdx.x) * LIO_MOMENT_OUT;
+  const double *frame_part = ra.block_part + size_t(f) * nblk * LIO_MOMENT_OUT;
+  unsigned seq = ra.first_seq;
+  for (;; ++seq) {
+    // ---- wait for the doorbell copy in HBM
+    if (wv == 0) {
+      const long long t0 = wall_clock64();
+      int state = 0, polls = 0;
+      double v = 0.0;
+      for (;;) {
+        const double sq = door_poll(door, lane, v);
+        ++polls;
+        if (sq == double(seq)) { state = 1; break; }
+        if (sq == LIO_RES_STOP) { state = 2; break; }
+        if (wall_clock64() - t0 > 2 * ra.timeout_ticks) { state = 2; break; }   // the relay is gone: leave quietly (it reported the timeout)
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (state == 1) {
+        // lanes 0..6 -> R[0..6], lanes 8, 9 -> R[7], R[8], lanes 10..12 -> t
+        if (lane < 7) pose[lane] = v;
+        else if (lane == 8 || lane == 9) pose[lane - 1] = v;
+        else if (lane >= 10 && lane <= 12) pose[lane - 1] = v;
+        else if (lane == 13) t_relay = v;
+      }
+      if (lane == 0) { cmd = state; t_seen = wall_clock64(); n_polls = polls; }
+    }
+    __syncthreads();
+    if (cmd != 1) return;
+    double Rm[9], tv[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm[k] = pose[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tv[k] = pose[9 + k];
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    double cnt = 0.0;
+    LogProduct lp;
+#pragma unroll
+    for (int it = 0; it < R; ++it) {
+      if (it < nchunk) {   // wave-uniform
+        double z[16], c_add, n_add;
+        moment_z(Rm, tv, px[it], py[it], pz[it], cf[it], ok[it], z, c_add, n_add);
+        lp.mul(c_add); cnt += n_add;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) zb[lane * ZROW + k] = z[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const double op = zb[(4 * t + grp) * ZROW + e];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op, op, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    dst[tid] = v;
-    if (tid < 2) {
-      double w = 0.0;
-      for (int q = 0; q < MOMENT_THREADS / 64; ++q) w += cw[q][tid];
-      dst[256 + tid] = w;
+    const long long t_acc = wall_clock64();
+    double cost = 0.5 * lp.log_value();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm[wv][(grp + 4 * r) * 16 + e] = acc[r];
+    for (int off = 32; off > 0; off >>= 1) { cost += __shfl_down(cost, off, 64); cnt += __shfl_down(cnt, off, 64); }
+    if (lane == 0) { sm[wv][256] = cost; sm[wv][257] = cnt; }
+    __syncthreads();
+    // ---- park the block's record in HBM (agent-scope stores: written through, visible to every XCD); once every wave's stores
+    // are acknowledged, the pass number goes into slot 259: the flag the frame's folding block waits for.  No atomics: a ticket
+    // drawn by twenty blocks at once serialises on one address.
+    // (the tile is 13 x 13 in a 16 x 16 frame: entries RES_COST_AT / RES_CNT_AT of the padding carry cost / count, so that the
+    // 256 threads move the whole record in one round — a second round costs the folding block two more memory round trips)
+    {
+      const int ksrc = tid == RES_COST_AT ? 256 : (tid == RES_CNT_AT ? 257 : tid);
+      double v = 0;
+      for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][ksrc];
+      __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long t_parked = wall_clock64();
+    if (tid == 0) __hip_atomic_store(mine + LIO_MOMENT_OUT - 1, double(seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j != 0) continue;
+    // ---- block 0 of the frame folds: wave 0 waits until every block's flag carries this pass, then the block sums the records in
+    // k_moment_reduce's order (chain q takes the blocks q, q + 4, ... below the last multiple of four, chain 0 then the remainder,
+    // the chains combine as (v0 + v1) + (v2 + v3)), one lane per value, all loads of a lane in flight together.
+    if (wv == 0) {
+      const long long t0 = wall_clock64();
+      int ready = 0;
+      for (;;) {
+        bool all = true;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+          const int b = b0 + lane;
+          const double fl = b < nblk ? __hip_atomic_load(frame_part + size_t(b) * LIO_MOMENT_OUT + LIO_MOMENT_OUT - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : double(seq);
+          all = all && __all(fl == double(seq));
+        }
+        if (all) { ready = 1; break; }
+        if (wall_clock64() - t0 > ra.timeout_ticks) break;   // a block died: the host's stream query reports it
+      }
+      if (lane == 0) go = ready;
+    }
+    __syncthreads();
+    if (!go) return;
+    const long long t_ready = wall_clock64();
+    const int b4 = nblk & ~3;
+    {
+      const int k = tid;
+      const double *src = frame_part + k;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+      for (int b0 = 0; b0 < nblk; b0 += 32) {   // up to thirty-two loads in flight per lane, then the sums in block order
+        double x[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          x[u] = (b0 + u < nblk) ? __hip_atomic_load(src + size_t(b0 + u) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+          if (b0 + u < b4) { v0 += x[u]; v1 += x[u + 1]; v2 += x[u + 2]; v3 += x[u + 3]; }
+          else {   // the remainder beyond the last multiple of four: chain 0, in block order
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (b0 + u + r < nblk) v0 += x[u + r];
+          }
+        }
+      }
+      const double sum = (v0 + v1) + (v2 + v3);
+      double *o = ra.out + size_t(f) * LIO_RES_OUT;
+      if (k == RES_COST_AT) { host_store(o + 256, sum); host_store(o + k, 0.0); }
+      else if (k == RES_CNT_AT) { host_store(o + 257, sum); host_store(o + k, 0.0); }
+      else host_store(o + k, sum);
+    }
+    // diagnostics (wall-clock ticks from the doorbell copy seen): accumulated, parked, every flag in, sums formed; polls
+    if (tid == 0) {
+      double *dg = ra.out + size_t(f) * LIO_RES_OUT + 258;
+      host_store(dg + 0, double(t_acc - t_seen)); host_store(dg + 1, double(t_parked - t_seen)); host_store(dg + 2, double(t_ready - t_seen));
+      host_store(dg + 3, double(wall_clock64() - t_seen)); host_store(dg + 4, double(n_polls)); host_store(dg + 5, double(t_seen) - t_relay);
+    }
+    host_signal_drain();
+    __syncthreads();
+    if (tid == 0) host_store(ra.words + f, seq);
   }
 }
 
@@ -357,6 +645,24 @@ __global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *
     __syncthreads();
     if (threadIdx.x == 0) post_host_signal(sig, int(blockIdx.x * gridDim.y + blockIdx.y));
   }
+}
+
+int resident_blocks_per_frame(int max_slots, int nframes, int per_lane) {
+  if (max_slots <= 0 || nframes <= 0 || per_lane < 1) return 0;
+  const int b = cdiv(max_slots, MOMENT_THREADS * per_lane);
+  return (b * nframes <= LIO_RES_MAX_BLOCKS) ? b : 0;
+}
+
+void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, int per_lane, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+  const dim3 grid(a.blocks_per_frame * a.nframes + 1), block(MOMENT_THREADS);   // workers + the relay
+  switch (per_lane) {
+    case 1: hipLaunchKernelGGL(k_lidar_moments_resident<1>, grid, block, 0, s, a, ra, valid, coef); break;
+    case 2: hipLaunchKernelGGL(k_lidar_moments_resident<2>, grid, block, 0, s, a, ra, valid, coef); break;
+    case 4: hipLaunchKernelGGL(k_lidar_moments_resident<4>, grid, block, 0, s, a, ra, valid, coef); break;
+    case 8: hipLaunchKernelGGL(k_lidar_moments_resident<8>, grid, block, 0, s, a, ra, valid, coef); break;
+    default: throw DeviceError("resident moments: per_lane must be 1, 2, 4 or 8");
+  }
+  LIO_HIP(hipGetLastError());
 }
 
 int moment_blocks_per_frame_batched(int max_slots, int nframes) {

@@ -72,7 +72,7 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
     assert rb.n_lidar_residuals > 1.2 * sum(eb.features(f)[0].shape[0] for f in range(W - Wo + 1, W)) / (Wo - 1) * Wo
     assert_cost_trace_close(ra, rb, rtol_floor=2e-4)
     assert_windows_close(ea.get_window(), eb.get_window())
-    worst_prior = assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4)[0]   # keep_features: same floor as the cost trace (window_util)
+    worst_prior = assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4, tol_ex=1e-4 if prior_factor else 1e-3)[0]   # keep_features: the cost trace's floor
     for est in (ea, eb):
         est.slide()
     force_all(ea, eb, ds)
@@ -86,7 +86,8 @@ def test_indoor_12_7_keep_features_chain(hip, oracle, prior_factor):
         wa, wb = ea.get_window(), eb.get_window()
         worst = max(worst, window_gap(wa, wb)[0])
         assert_windows_close(wa, wb)
-        worst_prior = max(worst_prior, assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4)[0])
+        # prior_factor 0: the extrinsic is free and weakly observable (window_util.assert_priors_close)
+        worst_prior = max(worst_prior, assert_priors_close(ea, eb, ra, rb, rel_floor=2e-4, tol_ex=1e-4 if prior_factor else 1e-3)[0])
         force_all(ea, eb, ds)
     print(f"indoor 12/7 keep_features prior_factor={prior_factor}: worst |dP| over 6 teacher-forced steps {worst:.2e} m, worst |dJtJ|/max of the "
           f"priors {worst_prior:.2e}")

@@ -44,7 +44,7 @@ def test_replay_200_scans_of_the_noise_fixture(hip, oracle):
     rph, _ = run_from_zero(hip, n, W=W, Wo=Wo, init_window_factor=3, odom_io=2, sweeps=sweeps, traj=traj, t0=0.0)
     rpo, _ = run_from_zero(oracle, n, W=W, Wo=Wo, init_window_factor=3, odom_io=2, sweeps=sweeps, traj=traj, t0=0.0)
     ev_h, ev_o = [e["event"] for e in rph.log], [e["event"] for e in rpo.log]
-    assert len(ev_o) == 99            # odom_io 2: every second sweep is a /compact_data message; the last one waits for an IMU sample past 20 s
+    assert len(ev_o) == 100           # odom_io 2: every second sweep after the first is a /compact_data message
     assert ev_h == ev_o
     k0 = ev_o.index("initialised")
     assert ev_o[k0 + 1:] == ["solved"] * (len(ev_o) - k0 - 1) and len(ev_o) - k0 >= 60

@@ -476,14 +476,14 @@ def test_point_odometry_matches_oracle(hip, oracle, kind, n_sweeps):
         if k > 0:
             assert rb["num_selected"] > 100
             assert abs(ra["num_selected"] - rb["num_selected"]) <= 2
-            np.testing.assert_allclose(ra["T_es"][1], rb["T_es"][1], atol=2e-5)   # translation, m
-            np.testing.assert_allclose(ra["T_es"][0], rb["T_es"][0], atol=2e-5)   # quaternion
+            np.testing.assert_allclose(ra["T_es"][1], rb["T_es"][1], atol=1e-5)   # translation, m (1e-5)
+            np.testing.assert_allclose(ra["T_es"][0], rb["T_es"][0], atol=1e-5)   # quaternion
             # transform_es_ after EACH of the <= 25 iterations (lio_odom_get_iteration_trace)
             assert ra["trace"].shape == rb["trace"].shape == (rb["iterations"], 7) and ra["kz"] == rb["kz"] == 0
             gap = np.abs(ra["trace"] - rb["trace"]).max(axis=1)
             print(f"{kind} sweep {k}: per-iteration |dT_es| max {gap.max():.2e} (iteration {int(gap.argmax())}), final {gap[-1]:.2e}, "
                   f"{int((gap <= 1e-5).sum())}/{len(gap)} iterations within 1e-5")
-            np.testing.assert_allclose(ra["trace"], rb["trace"], atol=2e-5)
+            np.testing.assert_allclose(ra["trace"], rb["trace"], atol=1e-5)   # measured on the MI355X: <= 3.5e-7 on every iteration
             np.testing.assert_allclose(ra["T_sum"][1], rb["T_sum"][1], atol=1e-4)
             # sanity against ground truth: the sweep-to-sweep motion is recovered to a few cm
             R0, p0 = pose_fn(1.0 + 0.1 * k)

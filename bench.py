@@ -404,6 +404,12 @@ def main():
             keyframes_extra = km["line"] if km else None
 
     resident = est.kernel_timing("moments_resident")   # passes served by the resident moments kernel so far (the timed blocks above)
+    est.enable_kernel_timing(-1)                       # untimed block: HIP events around the resident kernel's launches (dispatch -> exit)
+    for _ in range(max(5, args.steps // 5)):
+        one_step(est)
+    est.sync()
+    resident_launch = est.kernel_timing("moments_resident_launch")
+    est.enable_kernel_timing(False)
     names = ["features", "odom_features", "odom_rows", "odom_update", "moments", "voxel", "knn_grid", "concat"]
     est.enable_kernel_timing(1)   # HIP events around EVERY launch of each kernel kind on the estimator's stream: untimed block
     for _ in range(max(5, args.steps // 5)):
@@ -447,28 +453,56 @@ def main():
             roofline["actual_bytes_per_launch"] = round(actual, 1)
             roofline["frac_actual"] = round(actual / (avg_ms * 1e-3) / 8e12, 6)
             roofline["actual_note"] = "33 B read per slot + per-block partials (written, then read by the fold); the 60 B figure counts p and w as fp64 triples, the kernel reads them as fp32"
+        pmc, pmc_note = ({}, "skipped (--no-pmc or N > 1)")
         if not args.no_pmc and world == 1:
-            traffic, tnote = measure_pmc_traffic(ds, clouds, kernel_of[dom], args.workload)
+            pmc, pmc_note = measure_pmc(ds, clouds, args.workload)
+            traffic, tnote = pmc_traffic(pmc, kernel_of[dom])
             roofline["traffic"] = traffic
-            roofline["traffic_source"] = tnote
+            roofline["traffic_source"] = pmc_note + "; " + tnote
         roofline["others"] = {
             n: {"avg_launch_us": round(per_launch(n)[0] * 1e3, 3), "achieved_GBps": round(per_launch(n)[1], 2)}
             for n in ("features", "odom_features", "moments", "voxel", "knn_grid") if n != dom
         }
+        # the search kernels are bound by vector-instruction issue, not by HBM: the yardstick that fits them
+        for stage, kname in (("features", "k_features"), ("odom_features", "k_odom_round")):
+            vi = pmc_valu_issue(pmc, kname)
+            tgt = roofline if stage == dom else roofline["others"].get(stage)
+            if vi and tgt is not None:
+                tgt["valu_issue"] = vi
         if resident["launches"] > 0:
             # In the timed region the lidar moments do NOT come from the k_lidar_moments + k_moment_reduce launches timed above
-            # (those are the same arithmetic as separate launches, used when events bracket every kernel) but from ONE resident
-            # kernel per solve that serves every linearisation behind a doorbell.  Its passes are timed on the
-            # device's wall clock (doorbell seen -> sums posted); between passes the kernel idles while the host factors.
+            # (the same arithmetic as separate launches, used when events bracket every kernel) but from ONE resident kernel per
+            # solve that serves every linearisation behind a doorbell.  A pass of it is timed on the device's wall
+            # clock (doorbell seen -> sums posted); between passes the kernel idles while the host factors the system.
             p_us = 1e3 * resident["total_ms"] / resident["launches"]
             b = resident["algorithmic_bytes"] / resident["launches"]
-            roofline["moments_resident"] = {
+            n_solves = max(1, n_blocks * args.steps + args.warmup)
+            ppl = resident["launches"] / n_solves
+            l_us = 1e3 * resident_launch["total_ms"] / max(resident_launch["launches"], 1)
+            rt, rnote = pmc_traffic(pmc, "k_lidar_moments_resident")
+            res = {
                 "kernel": "k_lidar_moments_resident (fp64-MFMA form; 1 launch per solve, 1 pass per linearisation)",
-                "passes": resident["launches"], "avg_pass_us": round(p_us, 3), "algorithmic_bytes_per_pass": round(b, 1),
-                "achieved_GBps": round(b / (p_us * 1e-6) / 1e9, 2) if p_us > 0 else None,
-                "frac_of_8TBps": round(b / (p_us * 1e-6) / 8e12, 5) if p_us > 0 else None,
-                "note": "pass duration from the device wall clock inside the kernel (HIP events cannot bracket a pass of a resident kernel); rocprofv3 shows one k_lidar_moments_resident dispatch per solve whose duration spans the whole dogleg loop including the host's factorisations",
+                "stage": "moments", "bound": "hbm",
+                "achieved": round(b / (p_us * 1e-6) / 1e9, 3) if p_us > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                "frac": round(b / (p_us * 1e-6) / 8e12, 6) if p_us > 0 else None,
+                "traffic": round(rt / ppl, 1) if rt else None,
+                "traffic_source": pmc_note + "; " + rnote + f"; per LAUNCH {rt} B (the features are read once per launch and stay in registers), divided by {ppl:.2f} passes per launch",
+                "unit_of_work": "one PASS = one linearisation of the window's lidar factors (what one k_lidar_moments + k_moment_reduce launch pair did in round 2)",
+                "passes": resident["launches"], "avg_pass_us": round(p_us, 3), "algorithmic_bytes_per_pass": round(b, 1), "passes_per_launch": round(ppl, 2),
+                "pass_timing": "device wall clock inside the kernel, doorbell seen -> sums posted, slowest frame (HIP events cannot bracket a pass of a resident kernel)",
+                "avg_launch_us": round(l_us, 2), "launches_timed": resident_launch["launches"],
+                "achieved_over_whole_launch_GBps": round(b * ppl / (l_us * 1e-6) / 1e9, 2) if l_us > 0 else None,
+                "frac_over_whole_launch": round(b * ppl / (l_us * 1e-6) / 8e12, 6) if l_us > 0 else None,
+                "launch_timing": "HIP events around the kernel's launches in a separate untimed block: dispatch -> exit = the whole dogleg loop of a solve incl. the host's factorisations between passes (what rocprofv3 --stats reports as this kernel's duration)",
             }
+            if dom == "moments":   # the resident kernel IS the dominant kernel of the timed region: it leads, the launch form follows as a cross-check
+                launch_form = {k: v for k, v in roofline.items() if k != "others"}
+                others = roofline["others"]
+                roofline = res
+                roofline["launch_form_of_the_same_pass"] = launch_form
+                roofline["others"] = others
+            else:
+                roofline["moments_resident"] = res
 
         # the dominant kernel given B windows of work in one launch
         batched_kernel = None
@@ -761,12 +795,11 @@ def _oracle_lib():
     return capi.LioLib(so)
 
 
-def measure_pmc_traffic(ds, clouds, kernel, workload):
-    """HBM bytes per launch of `kernel` from rocprofv3 PMC counters, measured NOW on this box: the workload is pickled, a child
-    `bench.py --pmc-child` replays a few solves on it under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE`
-    (separate passes: the two counters do not fit one pass, MI355X_MICROARCH.md).  Both counters are in KB; FETCH_SIZE is
-    doubled (gfx950 reports half the bytes of a wide coalesced read).  Returns (bytes per launch of the most frequent grid size
-    or None, note)."""
+def measure_pmc(ds, clouds, workload, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
+    """Per-kernel PMC counters measured NOW on this box: the workload is pickled and a child `bench.py --pmc-child` replays a few
+    solves on it under `rocprofv3 --pmc <counter> --kernel-trace`, ONE counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass, MI355X_MICROARCH.md; SQ counters in a pass of their own).  Returns ({counter: {kernel: (grid, launches, avg value, avg
+    duration ns)}} for the most frequent grid size of every kernel, note) — or ({}, reason)."""
     import pickle
     import shutil
     import sqlite3
@@ -775,36 +808,57 @@ def measure_pmc_traffic(ds, clouds, kernel, workload):
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return {}, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="lio_pmc_")
+    out = {}
     try:
         pk = os.path.join(tmp, "workload.pkl")
         with open(pk, "wb") as fh:
             pickle.dump((ds, clouds), fh)
-        vals = {}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
+        for counter in counters:
+            d = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR=tmp)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", pk,
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", pk,
                    "--steps", "3", "--workload", workload]
             r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
-            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+                return out, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
             cur = sqlite3.connect(dbs[0]).cursor()
-            q = "select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name, grid_size"
-            rows = [(k, g, n, v) for k, g, n, v in cur.execute(q, (counter,)) if k.split("(")[0].split("<")[0].endswith("::" + kernel)]
-            if not rows:
-                return None, f"no {counter} rows for {kernel}"
-            vals[counter] = max(rows, key=lambda t: t[2])
-        f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
-        hbm = (2.0 * f[3] + w[3]) * 1024.0
-        return round(hbm, 1), (f"live: child runs of this bench under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), kernel {kernel}, grid {f[1]}, "
-                               f"{f[2]} launches; (2 x FETCH_SIZE {f[3]:.1f} KB + WRITE_SIZE {w[3]:.1f} KB) x 1024; kernel only, its fold / update launch not included")
+            q = ("select kernel_name, grid_size, count(*), avg(value), avg(duration) from counters_collection where counter_name=? "
+                 "group by kernel_name, grid_size")
+            best = {}
+            for k, g, n, v, dur in cur.execute(q, (counter,)):
+                short = k.split("(")[0].split("<")[0].split("::")[-1].strip()
+                if short not in best or n > best[short][1]:
+                    best[short] = (g, n, v, dur)
+            out[counter] = best
+        return out, "live: child runs of this bench under rocprofv3 --pmc <one counter> --kernel-trace (separate passes)"
     except Exception as e:  # noqa: BLE001 -- a profiler problem must not take the bench line down
-        return None, f"pmc measurement failed: {type(e).__name__}: {e}"
+        return out, f"pmc measurement failed: {type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic(pmc, kernel):
+    """HBM bytes per launch of `kernel`: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — both counters are in KB and FETCH_SIZE reports half
+    the bytes of a wide coalesced read on gfx950 (MI355X_MICROARCH.md).  (bytes or None, note)"""
+    f, w = pmc.get("FETCH_SIZE", {}).get(kernel), pmc.get("WRITE_SIZE", {}).get(kernel)
+    if not f or not w:
+        return None, f"no FETCH_SIZE / WRITE_SIZE rows for {kernel}"
+    return round((2.0 * f[2] + w[2]) * 1024.0, 1), (f"kernel {kernel}, grid {f[0]}, {f[1]} launches; (2 x FETCH_SIZE {f[2]:.1f} KB + WRITE_SIZE {w[2]:.1f} KB) x 1024; "
+                                                   "this kernel only")
+
+
+def pmc_valu_issue(pmc, kernel, n_simd=1024, ghz=2.4):
+    """Fraction of the chip's vector-issue slots the kernel fills: SQ_INSTS_VALU wave-instructions x 4 clocks each, spread over
+    1024 SIMDs, against the kernel's duration in the same (profiled) run."""
+    v = pmc.get("SQ_INSTS_VALU", {}).get(kernel)
+    if not v or not v[3]:
+        return None
+    issue_us = v[2] / n_simd * 4.0 / (ghz * 1e3)
+    return {"SQ_INSTS_VALU": round(v[2]), "issue_us_at_2p4GHz": round(issue_us, 2), "duration_us_profiled": round(v[3] / 1e3, 2),
+            "valu_issue_frac": round(issue_us / (v[3] / 1e3), 3)}
 
 
 def cpu_baseline(kind, W, Wo, steps, ds):

@@ -48,7 +48,8 @@ typedef struct {
   float surf_curv_th;          /* 0.1f  :109 */
   int max_corner_sharp;        /* 2     :110 */
   int max_corner_less_sharp;   /* 20    :111 */
-  int max_surf_flat;           /* 4     :112 */
+  int max_surf_flat;           /* 4     :112 — the product requires max_corner_less_sharp + max_surf_flat <= 64 and
+                                  max_corner_sharp <= max_corner_less_sharp (lio_pp_create returns NULL otherwise) */
   float less_flat_filter_size; /* 0.2f  :113 */
   int infer_start_ori;         /* 0     :119 — lio_pp_process only: replace a jumping start azimuth by the one the last ten
                                   sweeps predict (PointProcessor.cc:348-387); the ten-sweep history lives in the lio_pp */
@@ -493,7 +494,9 @@ int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *comm, int slots_per_ran
  * Names: "features" (batched CalculateFeatures), "odom_features", "odom_rows", "odom_update",
  * "moments" (lidar normal-equation moments, MFMA), "voxel", "knn_grid", "concat"; and "moments_resident": the passes of the
  * resident moments kernel (lio_est_config.resident_moments), which one launch per solve serves — timed on the device's wall
- * clock from the doorbell seen to the sums posted, counted since the handle was created, independent of `on`.
+ * clock from the doorbell seen to the sums posted, counted since the handle was created, independent of `on`; and
+ * "moments_resident_launch": the dispatch-to-exit span of that kernel's launches, bracketed by HIP events while `on` = -1
+ * (under `on` >= 1 every pass is a separate launch so that events can bracket it, and the resident kernel is not used).
  * `on` = 0 stops, 1 times every launch, N > 1 times every N-th launch of each kind (an event pair between two
  * kernels costs a few microseconds of dispatch overlap; sampling keeps the timed region honest).
  * get returns the number of launches TIMED since timing was enabled (0 for an unknown name or

@@ -63,6 +63,8 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   const int caps[3] = {cfg.max_corner_sharp, cfg.max_corner_less_sharp, cfg.max_surf_flat};
   for (int v : caps)
     if (v < 0 || v > 4096) return nullptr;
+  // k_ring_pick keeps the picks of a subregion one per lane of a wave (corner picks + flat picks in 64 slots)
+  if (cfg.max_corner_less_sharp + cfg.max_surf_flat > 64 || cfg.max_corner_sharp > cfg.max_corner_less_sharp) return nullptr;
   if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return nullptr;
   if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return nullptr;
   if (cfg.infer_start_ori && !(cfg.rad_diff >= 0.0)) return nullptr;
@@ -811,7 +813,8 @@ int lio_est_bench_batched_moments(lio_est *h, int n_windows, int reps, double *a
 }
 int lio_est_enable_kernel_timing(lio_est *h, int on) {
   if (!h) return LIO_ERR_ARG;
-  h->e->timers_.on = on != 0;
+  h->e->ResidentLaunchTiming(on == -1);   // -1: only the resident moments kernel's launches are bracketed (it stays in use)
+  h->e->timers_.on = on > 0;
   h->e->timers_.sample = on > 1 ? on : 1;
   h->e->timers_.reset();
   return LIO_OK;
@@ -828,6 +831,11 @@ int lio_est_get_kernel_timing(lio_est *h, const char *name, double *total_ms, do
     const double us = h->e->ResidentBusyUs(&passes, bytes);
     if (total_ms) *total_ms = us * 1e-3;
     return passes;
+  }
+  if (std::strcmp(name, "moments_resident_launch") == 0) {   // dispatch-to-exit spans recorded under lio_est_enable_kernel_timing(-1)
+    int n = 0;
+    guarded([&] { n = h->e->ResidentLaunchStats(total_ms); return LIO_OK; });
+    return n;
   }
   for (int k = 0; k < KT_COUNT; ++k)
     if (std::strcmp(name, names[k]) == 0) {

@@ -275,6 +275,15 @@ class Estimator {
   double res_busy_us_ = 0, res_bytes_ = 0; int res_passes_ = 0, res_passes_total_ = 0;   // device-side busy time of the passes (doorbell copy seen -> sums posted), SURVEY 8(d) bytes
   MomentArgs res_args_{};
   DBuf<double> d_res_relay_, d_res_part_;   // HBM: the doorbell as republished by the relay block; the per-block records
+  // lio_est_enable_kernel_timing(-1): HIP events around every launch of the resident kernel (it stays in use, unlike under
+  // the per-kernel timing of on >= 1): its dispatch-to-exit span, which is what rocprofv3 reports for it
+  bool res_time_launch_ = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> res_launch_events_;
+  double res_launch_ms_ = 0; int res_launches_ = 0;
+ public:
+  void ResidentLaunchTiming(bool on) { res_time_launch_ = on; }
+  int ResidentLaunchStats(double *total_ms);
+ private:
   double res_diag_us_[4] = {0, 0, 0, 0}, res_polls_ = 0, res_relay_us_ = 0, res_ring_to_done_ms_ = 0, res_t_ring_ = 0;
   int ResidentBpf(int max_slots, int nframes) const;
   bool ResidentBegin(const MomentArgs &ma);

@@ -681,9 +681,27 @@ bool Estimator::ResidentBegin(const MomentArgs &ma) {
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 7), 0ull, __ATOMIC_RELEASE);
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 15), 0ull, __ATOMIC_RELEASE);
   }
+  if (res_time_launch_) {
+    hipEvent_t a, b;
+    LIO_HIP(hipEventCreate(&a)); LIO_HIP(hipEventCreate(&b));
+    LIO_HIP(hipEventRecord(a, stream_));
+    res_launch_events_.push_back({a, b});
+  }
   ResidentLaunchKernel(res_seq_ + 1);
   res_active_ = true;
   return true;
+}
+
+int Estimator::ResidentLaunchStats(double *total_ms) {
+  LIO_HIP(hipStreamSynchronize(stream_));
+  for (auto &ev : res_launch_events_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { res_launch_ms_ += ms; ++res_launches_; }
+    (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+  }
+  res_launch_events_.clear();
+  if (total_ms) *total_ms = res_launch_ms_;
+  return res_launches_;
 }
 
 void Estimator::ResidentRing(const MomentArgs &ma) {
@@ -757,6 +775,7 @@ void Estimator::ResidentEnd() {
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 15), bits, __ATOMIC_RELEASE);
   }
   res_active_ = false;   // the kernel leaves within one poll; whatever is enqueued on stream_ next is ordered behind it
+  if (res_time_launch_ && !res_launch_events_.empty()) (void)hipEventRecord(res_launch_events_.back().second, stream_);
 }
 
 // Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.

@@ -20,6 +20,8 @@ struct PPDeviceCounts {
   int n_less_flat;       // voxel-filtered less-flat points
   int n_class[4];        // [1] sharp, [2] less_sharp, [3] flat
   int overflow;          // a ring exceeded LIO_PP_MAX_RING_POINTS
+  int pad;
+  long long pick_stamps[8];   // LIO_DEBUG_TIMING: wall-clock ticks of ring 0's block at the phase boundaries of k_ring_pick
 };
 
 // config_.infer_start_ori_ (PointProcessor.cc:348-387): two ten-deep histories of the start azimuth — as measured (buf2) and
@@ -74,12 +76,16 @@ class PointProcessorDev {
   DBuf<uint32_t> keys_;
   DBuf<int> ring_total_;
   DBuf<int> ring_table_;   // [ring][block] counts -> exclusive offsets (the stable ring split)
-  DBuf<int> d_ring_offsets_, first_valid_, mask_, end_ori_;
+  DBuf<int> mask_;
+  // the small per-sweep device state in ONE allocation, laid out like HostOut (counts, ring offsets) followed by first_valid[2]
+  // and end_ori: one init kernel instead of three fills in front of a sweep, one copy instead of two behind it
+  DBuf<int> d_state_;
+  PPDeviceCounts *d_counts_p_ = nullptr;
+  int *d_ring_offsets_p_ = nullptr, *first_valid_p_ = nullptr, *end_ori_p_ = nullptr;
   DBuf<uint16_t> ring_in_;
   DBuf<int8_t> label_;
   DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_;
   DBuf<int> lf_ring_count_;
-  DBuf<PPDeviceCounts> d_counts_;
 };
 
 }  // namespace lio

@@ -22,6 +22,9 @@ namespace lio {
 
 #define PP_PICK_THREADS 512
 #define PP_SORT_SLOTS 512
+#define PP_WMASK 576     // bytes of a private subregion mask: PP_SORT_SLOTS + 2 x nc (nc <= 15), rounded up to a multiple of 64
+#define PP_STAMP_RING 20   // the ring whose block stamps its phases (an HDL-64 ring that looks at the scene, not the sky)
+#define PP_WSEL 64       // ints per wave for its speculative picks: max_corner_less_sharp + max_surf_flat <= 64
 
 // ------------------------------------------------------------------------------------------------
 // ring binning
@@ -177,6 +180,24 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *_
   ring_cloud[dst] = p;
 }
 
+// value of lane ^ m (m a compile-time power of two).  m = 1, 2, 8 are DPP moves (quad permutes, a rotation by 8 inside the row of
+// 16): no trip through the LDS crossbar, which the eight sorting waves of a block would otherwise saturate; the rest is a shuffle
+__device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long v, int m) {
+  int lo = int(unsigned(v)), hi = int(unsigned(v >> 32));
+  if (m == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }        // quad_perm [1,0,3,2]
+  else if (m == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+  else if (m == 8) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true); } // row_ror:8
+  else { lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64); }
+  return (static_cast<unsigned long long>(unsigned(hi)) << 32) | unsigned(lo);
+}
+
+// counts <- 0, first_valid <- INT_MAX (the atomicMin targets of k_ring_bin), end_ori <- 0: the state a sweep starts from
+__global__ void k_pp_init(int *__restrict__ state, int n_count_ints, int *__restrict__ first_valid, int *__restrict__ end_ori) {
+  for (int k = threadIdx.x; k < n_count_ints; k += blockDim.x) state[k] = 0;
+  if (threadIdx.x < 2) first_valid[threadIdx.x] = INT_MAX;
+  if (threadIdx.x == 2) *end_ori = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-ring feature picking
 // ------------------------------------------------------------------------------------------------
@@ -216,12 +237,21 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   signed char *slabel = smask + NP;
   unsigned char *snfb = reinterpret_cast<unsigned char *>(slabel + NP);  // MaskPickedInRing reach of every point: nf | nb << 4
   unsigned char *sgap = snfb + NP;
-  int *lpick = reinterpret_cast<int *>(sgap + NP);                       // this ring's pick lists, flushed to global memory at the end
+  signed char *macc = reinterpret_cast<signed char *>(sgap + NP);        // the ring's mask incl. the reach of every final pick
+  signed char *zfwd = macc + NP;                                         // forward reach of finished subregions beyond their end
+  signed char *wmask = zfwd + NP;                                        // 8 private masks: a subregion's range +- nc
+  int *wsel = reinterpret_cast<int *>(wmask + 8 * PP_WMASK);             // 8 x (corner picks, flat picks) of the speculative pass
+  int *wcnt = wsel + 8 * PP_WSEL;                                        // 8 x (number of corner picks, number of flat picks)
+  volatile int *wdone = wcnt + 16;                                       // 8 flags: the wave's picks (and its zfwd entries) are final
+  int *lpick = const_cast<int *>(wdone) + 8;                                                // this ring's pick lists, flushed to global memory at the end
+#define PICK_STAMP(k) do { if (r == PP_STAMP_RING && tid == 0) counts->pick_stamps[k] = wall_clock64(); } while (0)
+  PICK_STAMP(0);
   for (int i = tid; i < n; i += PP_PICK_THREADS) {
     float4 p = ring_cloud[base + i];
     sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; scurv[i] = 0.f; smask[i] = 0; slabel[i] = 127;
   }
   __syncthreads();
+  PICK_STAMP(1);
   // ---- PrepareRing (:542-585): writes are idempotent stores of 1, so the i-loop parallelises as is
   for (int i = c.nc + tid; i < n - c.nc; i += PP_PICK_THREADS) {
     float cx = sx[i], cy = sy[i], cz = sz[i];
@@ -270,9 +300,13 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   }
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63;
-  int n_sharp = 0, n_less = 0, n_flat = 0;  // thread 0 only
+  int n_sharp = 0, n_less = 0, n_flat = 0;  // wave 0 only
+  // smask is PrepareRing's mask from here on (read-only); macc accumulates it + the reach of every FINAL pick (the ring's mask)
+  for (int i = tid; i < n; i += PP_PICK_THREADS) { macc[i] = smask[i]; zfwd[i] = 0; }
+  __syncthreads();
+  PICK_STAMP(2);
   for (int jg = 0; jg < c.ns; jg += 8) {
-      // ---- PrepareSubregion for subregion j = jg + wave: curvature + sort slots
+    // ---- PrepareSubregion for subregion j = jg + wave: curvature + sort slots
     const int j = jg + wv;
     unsigned long long *wk = skey + wv * PP_SORT_SLOTS;
     int sp = 0, ep = -1;
@@ -283,147 +317,211 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
       if (ep <= sp) active = false;
     }
     const int region = active ? ep - sp + 1 : 0;
-    if (region > PP_SORT_SLOTS) { if (lane == 0) atomicExch(&counts->overflow, 1); }
-    for (int k = lane; k < PP_SORT_SLOTS; k += 64) {
-      unsigned long long key = ~0ull;
-      if (k < region && region <= PP_SORT_SLOTS) {
+    if (region > PP_SORT_SLOTS) { if (lane == 0) atomicExch(&counts->overflow, 1); active = false; }
+    // the wave's 512 keys stay in REGISTERS through the sort (eight per lane): (curvature bits << 32 | ring index) orders like
+    // std::sort on pair<float, size_t> for the non-negative curvatures; empty slots sort last.  Which key starts in which slot
+    // does not matter to a sort, so lane l computes the points l, l + 64, ... (neighbouring lanes read neighbouring LDS words)
+    unsigned long long key[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = q * 64 + lane;
+      key[q] = ~0ull;
+      if (active && k < region) {
         const int i = sp + k;
         const int npn = 2 * c.nc;
         float dx = float(-npn) * sx[i], dy = float(-npn) * sy[i], dz = float(-npn) * sz[i];
-        for (int q = 1; q <= c.nc; ++q) {
-          dx += sx[i + q] + sx[i - q];
-          dy += sy[i + q] + sy[i - q];
-          dz += sz[i + q] + sz[i - q];
+        for (int t = 1; t <= c.nc; ++t) {
+          dx += sx[i + t] + sx[i - t];
+          dy += sy[i + t] + sy[i - t];
+          dz += sz[i + t] + sz[i - t];
         }
         float cv = dx * dx + dy * dy + dz * dz;
         scurv[i] = cv;
         slabel[i] = 0;
-        key = (static_cast<unsigned long long>(__float_as_uint(cv)) << 32) | static_cast<unsigned int>(i);
+        key[q] = (static_cast<unsigned long long>(__float_as_uint(cv)) << 32) | static_cast<unsigned int>(i);
       }
-      wk[k] = key;
     }
-    __syncthreads();
-      // ---- bitonic sort, ascending, all 8 waves in lockstep: total order (curvature, index) == std::sort on pair<float,size_t>
-    for (int size = 2; size <= PP_SORT_SLOTS; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int t = lane; t < PP_SORT_SLOTS / 2; t += 64) {
-          int lo = 2 * t - (t & (stride - 1));
-          int hi = lo + stride;
-          bool up = ((lo & size) == 0);
-          unsigned long long a = wk[lo], b = wk[hi];
-          if ((a > b) == up) { wk[lo] = b; wk[hi] = a; }
+    if (jg == 0) PICK_STAMP(3);
+    // ---- bitonic sort of the wave's 512 slots, ascending.  Strides below 8 exchange registers of one lane, strides of 8 and more
+    // exchange whole registers with lane ^ (stride / 8): 21 shuffle steps and 24 register steps instead of 45 passes through LDS
+    // with a wave fence each (20 us of the kernel's 66 in round 2).
+    if (active) {
+#pragma unroll
+      for (int size = 2; size <= PP_SORT_SLOTS; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+          if (stride >= 8) {
+            const int m = stride >> 3;
+            const bool up = (lane & (size >> 3)) == 0;
+            const bool keep_min = ((lane & m) == 0) == up;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const unsigned long long mine_k = key[q];
+              const unsigned long long other = lane_xor_u64(mine_k, m);
+              const bool take_other = keep_min ? (other < mine_k) : (other > mine_k);
+              key[q] = take_other ? other : mine_k;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              if ((q & stride) == 0) {
+                // slot g = 8 lane + q: the direction bit (g & size) is a register bit for size <= 4, a lane bit above
+                const bool up = size >= 8 ? ((lane & (size >> 3)) == 0) : ((q & size) == 0);
+                const unsigned long long a = key[q], b = key[q | stride];
+                const bool sw = (a > b) == up;
+                key[q] = sw ? b : a;
+                key[q | stride] = sw ? a : b;
+              }
+            }
+          }
         }
-        // each wave sorts its own subregion: a wave-level fence orders the stages, no block barrier needed
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
-    __syncthreads();  // wave 0 reads every wave's sorted keys
-    // ---- picks (:685-725).  The mask is shared by the ring's subregions (A.4), so subregions are taken in order and
-    // picks inside one are sequentially dependent — but only through the mask: wave 0 examines 64 sorted candidates at
-    // a time, a ballot finds the first still-eligible one (exactly the one the serial loop would reach next), the
-    // +-5 neighbour walk of MaskPickedInRing runs on 2*nc lanes, and the ballot is retaken.  Work per subregion is
-    // O(#picks + #chunks) wave steps instead of O(#candidates) dependent LDS round trips on one lane.
-      if (wv == 0) {
-      volatile signed char *vmask = smask;
-      // One pick = ballot -> first eligible lane -> three shuffles -> a register compare per lane: every lane keeps the
-      // masked state of ITS candidate in a register and updates it from the picked index and its reach, so the dependent
-      // chain never waits on LDS.  The mask bytes are still written (fire and forget) for the later chunks / subregions,
-      // which read them once when they load their candidates (a wave's DS operations execute in order).
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wk[lane * 8 + q] = key[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (jg == 0) PICK_STAMP(4);
+    // ---- picks (:685-725).  The mask is shared by the ring's subregions (A.4): a pick masks up to nc points on either side, so a
+    // subregion sees its predecessors' picks — but only through the <= nc points behind its start (its "zone").  The eight waves
+    // therefore pick their subregions at the same time, each on a private copy of the mask (its range +- nc) that starts as
+    // PrepareRing's; what finished predecessors reach forward is published in zfwd.  A wave runs freely until the candidate it would
+    // pick next lies in its zone: whether the serial loop picks or skips that one depends on the predecessors, so the wave then (and
+    // only then) waits for all of them, folds zfwd into its zone and retakes the decision.  Everything it did before is what the
+    // serial loop does: up to that candidate the two runs see the same mask on every candidate they actually pick or skip for
+    // being masked ... except zone points, none of which was reached.  No pick is ever undone.
+    // Inside a subregion the picks are sequentially dependent through the mask only: a wave examines 64 sorted candidates at a time,
+    // a ballot finds the first still-eligible one (the one the serial loop would reach next), every lane keeps the masked state of
+    // ITS candidate in a register and updates it from the picked index and its reach, so the dependent chain never waits on LDS.
+    volatile signed char *wm = wmask + wv * PP_WMASK;
+    int *sel = wsel + wv * PP_WSEL;
+    const int off = sp - c.nc;
+    const int zone_end = sp + c.nc;   // zone = [sp, zone_end)
+    if (lane == 0) wdone[wv] = 0;
+    if (active)
+      for (int li = lane; li < region + 2 * c.nc; li += 64) { const int i = off + li; wm[li] = (i >= 0 && i < n) ? smask[i] : 0; }
+    __syncthreads();
+    if (active) {
+      bool resolved = false;
+      auto resolve_zone = [&](int idx, bool cand, bool &masked) {
+        // every predecessor of this group has published its forward reach (earlier groups did before the last block barrier)
+        for (int w2 = 0; w2 < wv; ++w2)
+          while (wdone[w2] == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < c.nc) { const int i = sp + lane; if (i <= ep && zfwd[i]) wm[i - off] = 1; }
+        masked = masked || (cand && idx < zone_end && zfwd[idx] != 0);
+        resolved = true;
+      };
+      if (wv == 0) { bool dummy = false; resolve_zone(0, false, dummy); }   // nothing to wait for: zfwd already holds the earlier groups
       auto apply_pick = [&](int pidx, int reach, int idx, bool &masked) {
         const int nf = reach & 15, nb = reach >> 4;
         masked = masked || (idx >= pidx - nb && idx <= pidx + nf);
         // one store per lane, no branches: lane 0 -> the pick, lanes 1..nf -> forward reach, lanes nc+1..nc+nb -> backward reach
-        int off = 0;
+        int o = 0;
         bool wr = lane == 0;
-        if (lane >= 1 && lane <= nf) { off = lane; wr = true; }
-        if (lane > c.nc && lane - c.nc <= nb) { off = -(lane - c.nc); wr = true; }
-        if (wr) smask[pidx + off] = 1;
+        if (lane >= 1 && lane <= nf) { o = lane; wr = true; }
+        if (lane > c.nc && lane - c.nc <= nb) { o = -(lane - c.nc); wr = true; }
+        if (wr) wm[pidx + o - off] = 1;
       };
-      for (int w = 0; w < 8 && jg + w < c.ns; ++w) {
-        const int jj = jg + w;
-        int sp2 = int((size_t(c.nc) * size_t(c.ns - jj) + size_t(n - c.nc) * size_t(jj)) / size_t(c.ns));
-        int ep2 = int((size_t(c.nc) * size_t(c.ns - 1 - jj) + size_t(n - c.nc) * size_t(jj + 1)) / size_t(c.ns)) - 1;
-        if (ep2 <= sp2) continue;
-        const int region2 = ep2 - sp2 + 1;
-        if (region2 > PP_SORT_SLOTS) continue;
-        const unsigned long long *kk = skey + w * PP_SORT_SLOTS;
-        // corners: descending curvature
-        int num_largest = 0;
-        int mine = -1;   // lane q keeps the q-th pick of this subregion; labels and lists are written once, after the chain
-        bool stop = false;
-        for (int pos = region2; pos > 0 && num_largest < c.max_less_sharp && !stop; pos -= 64) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          const int k = pos - 1 - lane;
-          const bool in = k >= 0;
-          const unsigned long long e = in ? kk[k] : 0ull;
-          const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
-          const int idx = int(static_cast<unsigned int>(e));
-          const bool above = in && (cv > c.curv_th);
-          bool masked = !above || vmask[idx] != 0;
-          const int reach = above ? int(snfb[idx]) : 0;
-          int consumed = -1;
-          while (num_largest < c.max_less_sharp) {
-            const bool elig = above && lane > consumed && !masked;
-            const unsigned long long bm = __ballot(elig);
-            if (!bm) break;
-            const int L = __ffsll((long long)bm) - 1;
-            const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
-            const int preach = __builtin_amdgcn_readlane(reach, L);
-            mine = (lane == num_largest) ? pidx : mine;
-            ++num_largest;
-            apply_pick(pidx, preach, idx, masked);
-            consumed = L;
-          }
-          if (__ballot(in && !above)) stop = true;  // sorted: nothing further down exceeds the threshold
-        }
-        if (lane < num_largest) {
-          slabel[mine] = lane < c.max_sharp ? 2 : 1;
-          lpick[cap_sharp + n_less + lane] = mine;
-          if (lane < c.max_sharp) lpick[n_sharp + lane] = mine;
-        }
-        n_sharp += min(num_largest, c.max_sharp);
-        n_less += num_largest;
-        // flats: ascending curvature
-        int num_smallest = 0;
-        mine = -1;
-        stop = false;
-        for (int pos = 0; pos < region2 && num_smallest < c.max_flat && !stop; pos += 64) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          const int k = pos + lane;
-          const bool in = k < region2;
-          const unsigned long long e = in ? kk[k] : 0ull;
-          const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
-          const int idx = int(static_cast<unsigned int>(e));
-          const bool below = in && (cv < c.curv_th);
-          bool masked = !below || vmask[idx] != 0;
-          const int reach = below ? int(snfb[idx]) : 0;
-          int consumed = -1;
-          while (num_smallest < c.max_flat) {
-            const bool elig = below && lane > consumed && !masked;
-            const unsigned long long bm = __ballot(elig);
-            if (!bm) break;
-            const int L = __ffsll((long long)bm) - 1;
-            const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
-            const int preach = __builtin_amdgcn_readlane(reach, L);
-            mine = (lane == num_smallest) ? pidx : mine;
-            ++num_smallest;
-            apply_pick(pidx, preach, idx, masked);
-            consumed = L;
-          }
-          if (__ballot(in && !below)) stop = true;
-        }
-        if (lane < num_smallest) { slabel[mine] = -1; lpick[cap_sharp + cap_less + n_flat + lane] = mine; }
-        n_flat += num_smallest;
+      // corners: descending curvature
+      int num_largest = 0;
+      int mine = -1;   // lane q keeps the q-th pick of this subregion; labels and lists are written once, after the chain
+      bool stop = false;
+      for (int pos = region; pos > 0 && num_largest < c.max_less_sharp && !stop; pos -= 64) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int k = pos - 1 - lane;
+        const bool in = k >= 0;
+        const unsigned long long e = in ? wk[k] : 0ull;
+        const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+        const int idx = int(static_cast<unsigned int>(e));
+        const bool above = in && (cv > c.curv_th);
+        bool masked = !above || wm[idx - off] != 0;
+        const int reach = above ? int(snfb[idx]) : 0;
+        int consumed = -1;
+        while (num_largest < c.max_less_sharp) {
+          const bool elig = above && lane > consumed && !masked;
+          const unsigned long long bm = __ballot(elig);
+          if (!bm) break;
+          const int L = __ffsll((long long)bm) - 1;
+          const int pidx = __builtin_amdgcn_readlane(idx, L);      // L is wave-uniform: v_readlane, no LDS round trip
+          if (!resolved && pidx < zone_end) { resolve_zone(idx, above, masked); continue; }
+          const int preach = __builtin_amdgcn_readlane(reach, L);
+          mine = (lane == num_largest) ? pidx : mine;
+          ++num_largest;
+          apply_pick(pidx, preach, idx, masked);
+          consumed = L;
+        }
+        if (__ballot(in && !above)) stop = true;  // sorted: nothing further down exceeds the threshold
+      }
+      if (lane < num_largest) { slabel[mine] = lane < c.max_sharp ? 2 : 1; sel[lane] = mine; }
+      // flats: ascending curvature
+      int num_smallest = 0;
+      mine = -1;
+      stop = false;
+      for (int pos = 0; pos < region && num_smallest < c.max_flat && !stop; pos += 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int k = pos + lane;
+        const bool in = k < region;
+        const unsigned long long e = in ? wk[k] : 0ull;
+        const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
+        const int idx = int(static_cast<unsigned int>(e));
+        const bool below = in && (cv < c.curv_th);
+        bool masked = !below || wm[idx - off] != 0;
+        const int reach = below ? int(snfb[idx]) : 0;
+        int consumed = -1;
+        while (num_smallest < c.max_flat) {
+          const bool elig = below && lane > consumed && !masked;
+          const unsigned long long bm = __ballot(elig);
+          if (!bm) break;
+          const int L = __ffsll((long long)bm) - 1;
+          const int pidx = __builtin_amdgcn_readlane(idx, L);
+          if (!resolved && pidx < zone_end) { resolve_zone(idx, below, masked); continue; }
+          const int preach = __builtin_amdgcn_readlane(reach, L);
+          mine = (lane == num_smallest) ? pidx : mine;
+          ++num_smallest;
+          apply_pick(pidx, preach, idx, masked);
+          consumed = L;
+        }
+        if (__ballot(in && !below)) stop = true;
+      }
+      if (lane < num_smallest) { slabel[mine] = -1; sel[c.max_less_sharp + lane] = mine; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // publish what this subregion's picks reach beyond its end — all a later subregion can see of it — then the flag
+      if (lane < c.nc) { const int i = ep + 1 + lane; if (i < n && wm[i - off]) zfwd[i] = 1; }
+      if (lane == 0) { wcnt[2 * wv] = num_largest; wcnt[2 * wv + 1] = num_smallest; }
+    } else if (lane == 0) { wcnt[2 * wv] = 0; wcnt[2 * wv + 1] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) wdone[wv] = 1;
+    __syncthreads();
+    if (jg == 0) PICK_STAMP(5);
+    // the ring's lists in subregion order; every wave folds its private mask into the ring's mask (stores of 1 only, so the
+    // overlapping margins need no ordering)
+    if (wv == 0) {
+      for (int w = 0; w < 8 && jg + w < c.ns; ++w) {
+        const int nl = wcnt[2 * w], nsm = wcnt[2 * w + 1];
+        const int *sel2 = wsel + w * PP_WSEL;
+        if (lane < nl) {
+          const int m = sel2[lane];
+          lpick[cap_sharp + n_less + lane] = m;
+          if (lane < c.max_sharp) lpick[n_sharp + lane] = m;
+        }
+        if (lane < nsm) lpick[cap_sharp + cap_less + n_flat + lane] = sel2[c.max_less_sharp + lane];
+        n_sharp += min(nl, c.max_sharp);
+        n_less += nl;
+        n_flat += nsm;
       }
     }
+    if (active)
+      for (int li = lane; li < region + 2 * c.nc; li += 64) { const int i = off + li; if (i >= 0 && i < n && wm[li]) macc[i] = 1; }
     __syncthreads();
   }
+  PICK_STAMP(6);
   if (tid == 0) { pick_cnt[r * 3 + 0] = n_sharp; pick_cnt[r * 3 + 1] = n_less; pick_cnt[r * 3 + 2] = n_flat; }
   for (int k = tid; k < cap_all; k += PP_PICK_THREADS) my_pick[k] = lpick[k];
-  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = scurv[i]; g_mask[base + i] = int(smask[i]); g_label[base + i] = slabel[i]; }
+  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = scurv[i]; g_mask[base + i] = int(macc[i]); g_label[base + i] = slabel[i]; }
+  __syncthreads();
+  PICK_STAMP(7);
 }
 
 // prefix of the per-ring pick counts -> compact, ring-major lists (the order the reference pushes them)
@@ -646,7 +744,7 @@ float PointProcessorDev::StartOri() {
   if (!processed_) return std::nanf("");
   if (!start_ori_known_) {
     start_ori_dev_.reserve(3);
-    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, stream_, azi_.p, first_valid_.p, start_ori_dev_.p);
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, stream_, azi_.p, first_valid_p_, start_ori_dev_.p);
     LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     LIO_HIP(hipStreamSynchronize(stream_));
     h_out_->start_ori_probe[2] = h_out_->start_ori_probe[0];
@@ -683,7 +781,15 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   keys_.reserve(n); less_flat_.reserve(n);
   const int nblocks = cdiv(ni, PP_BIN_THREADS);
   ring_table_.reserve(size_t(rings_) * nblocks); ring_total_.reserve(rings_);
-  d_ring_offsets_.reserve(rings_ + 1); first_valid_.reserve(2); d_counts_.reserve(1); end_ori_.reserve(1);
+  if (!d_counts_p_) {
+    static_assert(sizeof(PPDeviceCounts) % sizeof(int) == 0 && offsetof(HostOut, ring_offsets) == sizeof(PPDeviceCounts), "device state mirrors HostOut");
+    const size_t nc_ints = sizeof(PPDeviceCounts) / sizeof(int);
+    d_state_.reserve(nc_ints + LIO_PP_MAX_RINGS + 1 + 4);
+    d_counts_p_ = reinterpret_cast<PPDeviceCounts *>(d_state_.p);
+    d_ring_offsets_p_ = d_state_.p + nc_ints;
+    first_valid_p_ = d_ring_offsets_p_ + LIO_PP_MAX_RINGS + 1;
+    end_ori_p_ = first_valid_p_ + 2;
+  }
   PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
              cfg_.max_surf_flat, cfg_.surf_curv_th};
   const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
@@ -701,25 +807,24 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
     std::fprintf(stderr, "[lio_hip pp timing] H2D of %zu points %.1f us\n", n,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
-  LIO_HIP(hipMemsetAsync(d_counts_.p, 0, sizeof(PPDeviceCounts), s));
-  LIO_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(first_valid_.p), INT_MAX, 2, s));
+  hipLaunchKernelGGL(k_pp_init, dim3(1), dim3(64), 0, s, d_state_.p, int(sizeof(PPDeviceCounts) / sizeof(int)), first_valid_p_, end_ori_p_);
   const uint16_t *d_ring = nullptr;
   if (ring) {
     ring_in_.reserve(n);
     LIO_HIP(hipMemcpyAsync(ring_in_.p, ring, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-    LIO_HIP(hipMemsetAsync(end_ori_.p, 0, sizeof(int), s));  // end_ori_ = 0 (:439)
+    // end_ori_ = 0 (:439): k_pp_init
     d_ring = ring_in_.p;
   }
   hipLaunchKernelGGL(k_ring_bin, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, azi_.p, ring_table_.p,
-                     nblocks, first_valid_.p);
-  if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_.p, end_ori_.p);
+                     nblocks, first_valid_p_);
+  if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_p_, end_ori_p_);
   hipLaunchKernelGGL(k_ring_scan, dim3(rings_), dim3(256), 0, s, ring_table_.p, nblocks, ring_total_.p);
   const float *d_override = nullptr;
   processed_ = true; start_ori_known_ = false;
   if (cfg_.infer_start_ori && !ring) {
     // :348-387 — ten lines of host state between the two passes of PointToRing; costs one round trip, only when enabled
     start_ori_dev_.reserve(3);
-    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, s, azi_.p, first_valid_.p, start_ori_dev_.p);
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, s, azi_.p, first_valid_p_, start_ori_dev_.p);
     LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));
     h_out_->start_ori_probe[2] = start_ori_filter_.Update(h_out_->start_ori_probe[0], h_out_->start_ori_probe[1], cfg_.rad_diff);
@@ -727,27 +832,31 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
     d_override = start_ori_dev_.p + 2;
     start_ori_known_ = true;
   }
-  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_.p,
-                     first_valid_.p, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_.p : nullptr);
-  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 4) + size_t(cap_all) * sizeof(int) + 64;
-  hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_.p, pc, curv_.p, mask_.p, label_.p,
-                     pick_idx_.p, pick_cnt_.p, d_counts_.p);
+  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_p_,
+                     first_valid_p_, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_p_ : nullptr);
+  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 6) + size_t(8) * PP_WMASK +
+                     size_t(8) * PP_WSEL * sizeof(int) + 24 * sizeof(int) + size_t(cap_all) * sizeof(int) + 64;
+  hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
+                     pick_idx_.p, pick_cnt_.p, d_counts_p_);
   // less-flat
   const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
   lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);
   const size_t lf_lds = size_t(4096) * 8 + size_t(4096) * 16 + size_t(4096) * 4;
-  hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_.p, label_.p, inv_leaf, azi_.p,
-                     first_valid_.p, d_override, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
-  hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_.p, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
-                     class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_.p);
+  hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_p_, label_.p, inv_leaf, azi_.p,
+                     first_valid_p_, d_override, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
+  hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_p_, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
+                     class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_p_);
   LIO_HIP(hipGetLastError());
   // results come back through pinned memory: a D2H into pageable memory blocks the host per copy (20 us between the two)
-  LIO_HIP(hipMemcpyAsync(&h_out_->counts, d_counts_.p, sizeof(PPDeviceCounts), hipMemcpyDeviceToHost, s));
-  LIO_HIP(hipMemcpyAsync(h_out_->ring_offsets, d_ring_offsets_.p, sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipMemcpyAsync(&h_out_->counts, d_counts_p_, sizeof(PPDeviceCounts) + sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));   // counts + ring offsets
   LIO_HIP(hipStreamSynchronize(s));
-  if (dbg)
+  if (dbg) {
     std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us\n",
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    const long long *st = h_out_->counts.pick_stamps;
+    std::fprintf(stderr, "[lio_hip pp timing] k_ring_pick ring %d, 10 ns ticks: load %lld, PrepareRing+reach %lld, curvature+keys %lld, sort %lld, picks %lld, lists + mask merge %lld, write-back %lld\n",
+                 PP_STAMP_RING, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6]);
+  }
   counts_ = h_out_->counts;
   std::copy(h_out_->ring_offsets, h_out_->ring_offsets + rings_ + 1, ring_offsets_.begin());
   counts_.n_ring_points = ring_offsets_[rings_];

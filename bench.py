@@ -305,6 +305,7 @@ def main():
     ap.add_argument("--shard-factors", action="store_true",
                     help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
                          "equation moments per linearisation (SURVEY.md §8e).  Default: one independent window per rank, no collective.")
+    ap.add_argument("--no-fed", action="store_true", help="skip the fed-GPU points (B keyframes / sweeps / clouds at once) of the stages besides the moments kernel")
     ap.add_argument("--dry-launch", action="store_true",
                     help="CPU rehearsal of the multi-rank run: gloo + the CPU oracle on a small VLP-16 window (no GPU needed, nothing measured)")
     args = ap.parse_args()
@@ -351,6 +352,10 @@ def main():
         for _ in range(args.steps):
             one_step(est)
         est.sync()
+        if kind == "outdoor":   # the keyframe-batch kernels under the same counters (64 keyframes, each with its own local map)
+            captured = []
+            mapping_ms_per_scan(hip, ds, clouds, capture=captured)
+            keyframe_batch_stats(hip, captured, 64, reps=2)
         return
     t_setup = time.time()
     ds = make_dataset(kind, W, 0.0 if args.shard_factors else dist_util.window_shift_for_rank(rank))
@@ -548,6 +553,19 @@ def main():
             if not args.no_cpu_baseline:
                 orc_kf = keyframe_batch_stats(_oracle_lib(), captured, 4, reps=1, distinct_maps=False)
                 kf_stats["cpu_oracle_keyframes_per_s"] = orc_kf["keyframes_per_s"]
+        fed = None
+        if world == 1 and not args.no_fed and kind == "outdoor":
+            try:
+                fed = fed_gpu_points(hip, ds, est, captured, W, Wo)
+            except Exception as e:  # noqa: BLE001 -- an extra must not take the bench line down
+                fed = {"error": f"{type(e).__name__}: {e}"}
+        if fed and "search_and_fit" in fed and pmc:
+            vi = pmc_valu_issue(pmc, "k_kf_round*")
+            tr, tn = pmc_traffic(pmc, "k_kf_round*")
+            c0 = captured[0]
+            M, N = c0["corner"].shape[0] + c0["surf"].shape[0], c0["corner_map"].shape[0] + c0["surf_map"].shape[0]
+            fed["search_and_fit"]["pmc_at_64_keyframes"] = {"valu_issue": vi, "hbm_bytes_per_round": tr, "algorithmic_bytes_per_round": 64 * (16 * (M + N) + 72 * M),
+                                                            "traffic_ratio": round(tr / (64.0 * (16 * (M + N) + 72 * M)), 2) if tr else None, "source": tn}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(kind, W, Wo, args.cpu_steps, ds)  # N = 1 only
         odom_io = 3 if kind == "outdoor" else 2
         pp_med = float(np.median(pp_ms[1:]))
@@ -584,6 +602,7 @@ def main():
             "sharded": sharded_extra,
             "keyframes": keyframes_extra,
             "batched": batched,
+            "fed_gpu": fed,
             "keyframe_batch": kf_stats,
             "batched_kernel_roofline": {"kernel": "k_lidar_moments[_sym]_batched + k_moment_reduce (fp64-MFMA form below 4 chunks per wave, structured fp64-VALU form above)", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
             "stages_ms": {
@@ -643,6 +662,69 @@ def keyframes_workload(args, hip, rank, world, torch, dist):
                      "note": "rank 0's share; algorithmic bytes = sum over its keyframes of iterations x (16(M+N) + 72 M) (SURVEY.md 8(d)); device time of the round loop by HIP events; the kernel is gather-latency-bound (DESIGN.md 3.4)"},
         "cpu_baseline": cpu,
     }))
+
+
+def fed_gpu_points(hip, ds, est, captured, W, Wo):
+    """SURVEY.md 8(d) ii for the stages besides the moments kernel: the same kernels given B units of work at once, B in {1, 8, 64(, 512)},
+    against the bound that limits them.  Search + plane fit: B keyframes (each with its own local map in HBM) through k_kf_round,
+    the batched form of the k_features / k_odom_round device body.  PointProcessor: B sweeps in flight (one handle + stream each,
+    lio_pp_process_async).  VoxelGrid: one filter over B tiled copies of the window's surf clouds (B x 150 k points)."""
+    from lio_amd import capi
+
+    out = {}
+    # (i) search + fit
+    pts = []
+    for B in (1, 8, 64, 512):
+        if not captured:
+            break
+        k = keyframe_batch_stats(hip, captured, B, reps=3)
+        pts.append({"keyframes": B, "device_ms": k["refine_device_ms"], "iterations_mean": k["iterations_mean"], "achieved_GBps": k["achieved_GBps"],
+                    "frac_of_8TBps": k["frac_of_8TBps"], "keyframes_per_s": k["keyframes_per_s"]})
+    out["search_and_fit"] = {"kernel": "k_kf_round (+ k_kf_rows, k_kf_update): B scan-to-map Gauss-Newton loops in lock-step, the batched form of the search + plane-fit body",
+                             "bound": "vector-instruction issue (DESIGN.md 3.9); HBM fraction shown for reference", "points": pts}
+    # (ii) PointProcessor, B sweeps in flight
+    lid = ds.lidar
+    scans = [f.scan for f in ds.frames[:4]]
+    pts = []
+    for B in (1, 8, 64):
+        hs = [capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings) for _ in range(B)]
+        for i, h in enumerate(hs):
+            h.process(scans[i % len(scans)])
+        reps = max(2, 64 // B)
+        t = time.perf_counter()
+        for _ in range(reps):
+            for i, h in enumerate(hs):
+                h.process_async(scans[i % len(scans)])
+            for h in hs:
+                h.wait()
+        dt = time.perf_counter() - t
+        npts = float(np.mean([sc.shape[0] for sc in scans]))
+        rate = B * reps / dt
+        pts.append({"sweeps_in_flight": B, "sweeps_per_s": round(rate, 1), "ms_per_sweep": round(1e3 / rate, 4), "achieved_GBps": round(rate * npts * 40.0 / 1e9, 2),
+                    "frac_of_8TBps": round(rate * npts * 40.0 / 8e12, 5)})
+        del hs
+    out["point_processor"] = {"bound": "hbm, 40 B per input point (SURVEY.md 8(d)); wall clock incl. the 2.1 MB upload of every sweep over PCIe", "points": pts,
+                              "note": "one handle (own stream + buffers) per sweep in flight; 512 handles are not run: at 64 the host's enqueue calls are already the limit"}
+    # (iii) VoxelGrid over B tiled copies
+    cloud = np.concatenate([est.get_surf_stack(i) for i in range(W - Wo, W)], axis=0)
+    cloud = cloud[(np.abs(cloud[:, 0]) < 60.0) & (np.abs(cloud[:, 1]) < 60.0) & (np.abs(cloud[:, 2]) < 20.0)]   # the 120 m x 120 m core: tiles 132 m apart stay inside the key
+    pitch = 132.0
+    order = [0, -1, 1, -2, 2]
+    pts = []
+    for B in (1, 8, 64):
+        tiles = []
+        for b in range(B):
+            ix, iy, iz = order[b % 5], order[(b // 5) % 5], order[(b // 25) % 5]
+            c = cloud.copy()
+            c[:, 0] += ix * pitch; c[:, 1] += iy * pitch; c[:, 2] += iz * 45.0
+            tiles.append(c)
+        big = np.concatenate(tiles, axis=0)
+        ms, n_out = hip.bench_voxel_grid(big, 0.4, reps=5 if B < 64 else 2)
+        pts.append({"copies": len(tiles), "points_in": int(big.shape[0]), "points_out": n_out, "device_ms": round(ms, 4),
+                    "achieved_GBps": round(32.0 * big.shape[0] / (ms * 1e-3) / 1e9, 2), "frac_of_8TBps": round(32.0 * big.shape[0] / (ms * 1e-3) / 8e12, 5)})
+    out["voxel_grid"] = {"bound": "hbm, 32 B per point (read 16 + written <= 16)", "points": pts,
+                         "note": "one filter call over tiled copies of the window's surf clouds (the copies sit 2.2 extents apart, inside the 10 + 11 + 11-bit absolute-cell key)"}
+    return out
 
 
 def batched_throughput(hip, ds, clouds, kind, W, Wo, est0, n_windows, steps):
@@ -840,10 +922,19 @@ def measure_pmc(ds, clouds, workload, counters=("FETCH_SIZE", "WRITE_SIZE", "SQ_
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _pmc_row(pmc, counter, kernel):
+    """the counter's row of `kernel`; a trailing '*' matches the most-launched kernel whose name starts with the prefix"""
+    rows = pmc.get(counter, {})
+    if not kernel.endswith("*"):
+        return rows.get(kernel)
+    cand = [(v[1], v) for k, v in rows.items() if k.startswith(kernel[:-1])]
+    return max(cand, key=lambda t: t[0])[1] if cand else None
+
+
 def pmc_traffic(pmc, kernel):
     """HBM bytes per launch of `kernel`: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — both counters are in KB and FETCH_SIZE reports half
     the bytes of a wide coalesced read on gfx950 (MI355X_MICROARCH.md).  (bytes or None, note)"""
-    f, w = pmc.get("FETCH_SIZE", {}).get(kernel), pmc.get("WRITE_SIZE", {}).get(kernel)
+    f, w = _pmc_row(pmc, "FETCH_SIZE", kernel), _pmc_row(pmc, "WRITE_SIZE", kernel)
     if not f or not w:
         return None, f"no FETCH_SIZE / WRITE_SIZE rows for {kernel}"
     return round((2.0 * f[2] + w[2]) * 1024.0, 1), (f"kernel {kernel}, grid {f[0]}, {f[1]} launches; (2 x FETCH_SIZE {f[2]:.1f} KB + WRITE_SIZE {w[2]:.1f} KB) x 1024; "
@@ -853,7 +944,7 @@ def pmc_traffic(pmc, kernel):
 def pmc_valu_issue(pmc, kernel, n_simd=1024, ghz=2.4):
     """Fraction of the chip's vector-issue slots the kernel fills: SQ_INSTS_VALU wave-instructions x 4 clocks each, spread over
     1024 SIMDs, against the kernel's duration in the same (profiled) run."""
-    v = pmc.get("SQ_INSTS_VALU", {}).get(kernel)
+    v = _pmc_row(pmc, "SQ_INSTS_VALU", kernel)
     if not v or not v[3]:
         return None
     issue_us = v[2] / n_simd * 4.0 / (ghz * 1e3)

@@ -74,6 +74,12 @@ lio_pp *lio_pp_create(float lower_deg, float upper_deg, int rings, const lio_pp_
 void lio_pp_destroy(lio_pp *);
 /* SetInputCloud + PointToRing + ExtractFeaturePoints (PointProcessor.cc:96-100, test_point_processor.cc:103-106) */
 int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
+/* lio_pp_process in two halves, for hosts that keep several sweeps in flight (one handle per sweep in flight, each with its
+ * own stream): _async enqueues upload + all kernels + the copy of the counts and returns; _wait blocks until they are done.
+ * xyzi must stay untouched between the two calls; every accessor below (and the next _async on the handle) waits first.
+ * (The oracle processes inside _async; its _wait is a no-op.) */
+int lio_pp_process_async(lio_pp *, const float *xyzi, size_t n);
+int lio_pp_wait(lio_pp *);
 /* The same with the PointIR overload of PointToRing (uneven = true, sensor_type 320 of processor_node.cc:73;
  * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
  * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */
@@ -224,6 +230,10 @@ size_t lio_kf_batch_size(const lio_kf_batch *);
  * ---------------------------------------------------------------------------------------------- */
 /* pcl::VoxelGrid<PointXYZI> (B.1): centroids in ascending voxel index; out capacity n points.   */
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *xyzi_out, size_t *n_out);
+/* Measurement hook (SURVEY.md 8(d) ii): the same filter on a cloud already resident in HBM, `reps` times back to back on one
+ * stream, timed with HIP events; avg_ms_out = one filter (keys, sort, run heads, centroids, the count's way back to the host).
+ * The oracle returns LIO_ERR_DEVICE. */
+int lio_bench_voxel_grid(const float *xyzi, size_t n, float leaf, int reps, double *avg_ms_out, size_t *n_out_or_null);
 /* pcl::KdTreeFLANN::nearestKSearch (B.2): exact K-NN, ascending squared distance, index tiebreak.
  * idx_out / sqd_out are m*k.  The product restricts the search to radius_sq (entries beyond it
  * come back as idx -1 / sqd +inf); pass radius_sq <= 0 for an unbounded search (oracle only).  */

@@ -78,33 +78,46 @@ void lio_pp_destroy(lio_pp *h) { delete h; }
 float lio_pp_start_ori(const lio_pp *h) {
   if (!h) return std::nanf("");
   float v = std::nanf("");
-  guarded([&] { v = h->pp->StartOri(); return LIO_OK; });
+  guarded([&] { h->pp->ProcessFinish(); v = h->pp->StartOri(); return LIO_OK; });
   return v;
 }
 int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
   return guarded([&] { h->pp->Process(xyzi, n); return LIO_OK; });
 }
+int lio_pp_process_async(lio_pp *h, const float *xyzi, size_t n) {
+  if (!h || (!xyzi && n)) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->ProcessLaunch(xyzi, n); return LIO_OK; });
+}
+int lio_pp_wait(lio_pp *h) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->ProcessFinish(); return LIO_OK; });
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   return guarded([&] { h->pp->Process(xyzi, n, n ? ring : nullptr); return LIO_OK; });
 }
-size_t lio_pp_count(const lio_pp *h, int which) { return (h && which >= 0 && which <= 4) ? h->pp->Count(which) : 0; }
+size_t lio_pp_count(const lio_pp *h, int which) {
+  if (!h || which < 0 || which > 4) return 0;
+  size_t n = 0;
+  guarded([&] { h->pp->ProcessFinish(); n = h->pp->Count(which); return LIO_OK; });   // a sweep still in flight (lio_pp_process_async) is waited for
+  return n;
+}
 int lio_pp_get_cloud(const lio_pp *h, int which, float *out) {
   if (!h || which < 0 || which > 4 || !out) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->GetCloud(which, out); return LIO_OK; });
+  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetCloud(which, out); return LIO_OK; });
 }
 int lio_pp_get_indices(const lio_pp *h, int which, int32_t *ring, int32_t *idx) {
   if (!h || which < 1 || which > 3 || !ring || !idx) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->GetIndices(which, ring, idx); return LIO_OK; });
+  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetIndices(which, ring, idx); return LIO_OK; });
 }
 int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
   if (!h || !out) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->GetRingOffsets(out); return LIO_OK; });
+  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetRingOffsets(out); return LIO_OK; });
 }
 int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (!h) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->GetCurvature(curv, mask); return LIO_OK; });
+  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetCurvature(curv, mask); return LIO_OK; });
 }
 
 // ---------------------------------------------------------------- PointOdometry
@@ -806,6 +819,31 @@ int lio_est_set_factor_sharding_rccl(lio_est *h, lio_rccl *comm) {
   h->e->shard_rank_ = lio_rccl_rank(comm); h->e->shard_world_ = lio_rccl_world(comm);
   h->e->allreduce_ = nullptr; h->e->allreduce_user_ = nullptr;
   return LIO_OK;
+}
+int lio_bench_voxel_grid(const float *xyzi, size_t n, float leaf, int reps, double *avg_ms, size_t *n_out) {
+  if (!xyzi || n == 0 || !(leaf > 0) || reps < 1 || !avg_ms) return LIO_ERR_ARG;
+  return guarded([&] {
+    hipStream_t s = nullptr;
+    LIO_HIP(hipStreamCreate(&s));
+    DBuf<float4> in, out;
+    in.reserve(n);
+    LIO_HIP(hipMemcpyAsync(in.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, s));
+    VoxelGridDev vox;
+    size_t m = 0;
+    for (int w = 0; w < 2; ++w) m = vox.run(in.p, n, leaf, out, s);   // warm-up: buffers, sort scratch
+    hipEvent_t e0, e1;
+    LIO_HIP(hipEventCreate(&e0)); LIO_HIP(hipEventCreate(&e1));
+    LIO_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) m = vox.run(in.p, n, leaf, out, s);
+    LIO_HIP(hipEventRecord(e1, s));
+    LIO_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    LIO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = double(ms) / reps;
+    if (n_out) *n_out = m;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return LIO_OK;
+  });
 }
 int lio_est_bench_batched_moments(lio_est *h, int n_windows, int reps, double *avg_ms, double *bytes) {
   if (!h || n_windows < 1 || reps < 1) return LIO_ERR_ARG;

@@ -4,6 +4,7 @@
 //                   MaskPickedInRing (:624-645) — one workgroup per ring, the whole ring in LDS
 //   less_flat     : per-ring pcl::VoxelGrid(0.2) (:737-751) + rel-time recompute (:755-778), batched over rings
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <vector>
 
@@ -52,6 +53,10 @@ class PointProcessorDev {
   void Process(const float *xyzi, size_t n, const uint16_t *ring = nullptr);
   size_t Count(int which) const;
   void GetCloud(int which, float *out);
+  // the two halves of Process: Launch enqueues the whole sweep on the handle's stream and returns; Finish waits for it.  Several
+  // handles launched one after the other keep that many sweeps in flight on one GPU (lio_pp_process_async / lio_pp_wait).
+  void ProcessLaunch(const float *xyzi, size_t n, const uint16_t *ring = nullptr);
+  void ProcessFinish();
   void GetIndices(int which, int32_t *ring, int32_t *idx);
   void GetRingOffsets(int32_t *out);
   void GetCurvature(float *curv, int32_t *mask);
@@ -72,7 +77,8 @@ class PointProcessorDev {
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
   DBuf<float> azi_, curv_, start_ori_dev_;
   StartOriFilter start_ori_filter_;
-  bool processed_ = false, start_ori_known_ = false;
+  bool processed_ = false, start_ori_known_ = false, in_flight_ = false;
+  std::chrono::steady_clock::time_point t_begin_{};
   DBuf<uint32_t> keys_;
   DBuf<int> ring_total_;
   DBuf<int> ring_table_;   // [ring][block] counts -> exclusive offsets (the stable ring split)

@@ -772,9 +772,18 @@ PointProcessorDev::~PointProcessorDev() {
 }
 
 void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *ring) {
+  ProcessLaunch(xyzi, n, ring);
+  ProcessFinish();
+}
+
+// Everything a sweep needs, enqueued on the handle's stream: upload, ring split, picks, less-flat filter, packing, and the copy
+// of the counts into pinned memory.  The caller's buffer is read by the upload: it must stay untouched until ProcessFinish().
+void PointProcessorDev::ProcessLaunch(const float *xyzi, size_t n, const uint16_t *ring) {
+  if (in_flight_) ProcessFinish();
   std::memset(&counts_, 0, sizeof(counts_));
   std::fill(ring_offsets_.begin(), ring_offsets_.end(), 0);
   if (n == 0) return;
+  in_flight_ = true;
   const int ni = int(n);
   hipStream_t s = stream_;
   in_.reserve(n); ring_cloud_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
@@ -849,7 +858,15 @@ void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *rin
   LIO_HIP(hipGetLastError());
   // results come back through pinned memory: a D2H into pageable memory blocks the host per copy (20 us between the two)
   LIO_HIP(hipMemcpyAsync(&h_out_->counts, d_counts_p_, sizeof(PPDeviceCounts) + sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));   // counts + ring offsets
-  LIO_HIP(hipStreamSynchronize(s));
+  t_begin_ = t_begin;
+}
+
+void PointProcessorDev::ProcessFinish() {
+  if (!in_flight_) return;
+  in_flight_ = false;
+  static const bool dbg = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  const auto t_begin = t_begin_;
+  LIO_HIP(hipStreamSynchronize(stream_));
   if (dbg) {
     std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us\n",
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());

@@ -143,6 +143,9 @@ _SIGS = {
     "lio_pp_destroy": (None, [C.c_void_p]),
     "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
+    "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
+    "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
     "lio_pp_get_cloud": (C.c_int, [C.c_void_p, C.c_int, c_float_p]),
@@ -328,6 +331,13 @@ class LioLib:
         _chk(self.dll.lio_marginalize_schur(_dp(A), _dp(b), m, n, _dp(J), _dp(r), _dp(s)), "lio_marginalize_schur")
         return J, r, s
 
+    def bench_voxel_grid(self, xyzi, leaf, reps=10):
+        """device time of one VoxelGrid of a resident cloud (HIP events over `reps` runs) -> (ms, output points)"""
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        ms, n_out = C.c_double(0), C.c_size_t(0)
+        _chk(self.dll.lio_bench_voxel_grid(_fp(xyzi), xyzi.shape[0], float(leaf), int(reps), C.byref(ms), C.byref(n_out)), "lio_bench_voxel_grid")
+        return ms.value, int(n_out.value)
+
     def voxel_grid(self, xyzi, leaf):
         xyzi = _f32(xyzi).reshape(-1, 4)
         out = np.zeros_like(xyzi)
@@ -463,6 +473,15 @@ class PointProcessor:
         if getattr(self, "h", None):
             self.lib.dll.lio_pp_destroy(self.h)
             self.h = None
+
+    def process_async(self, xyzi):
+        """enqueue a sweep and return; `wait()` (or any accessor) blocks until it is done.  Keeps `xyzi` alive meanwhile."""
+        self._pending = _f32(xyzi).reshape(-1, 4)
+        _chk(self.lib.dll.lio_pp_process_async(self.h, _fp(self._pending), self._pending.shape[0]), "lio_pp_process_async")
+
+    def wait(self):
+        _chk(self.lib.dll.lio_pp_wait(self.h), "lio_pp_wait")
+        self._pending = None
 
     def process(self, xyzi, ring=None):
         """ring (uint16 per point) selects the PointIR overload of PointToRing (uneven sensors, PointProcessor.cc:428-536)."""

@@ -60,6 +60,8 @@ int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   h->pp.Process(xyzi, n);
   return LIO_OK;
 }
+int lio_pp_process_async(lio_pp *h, const float *xyzi, size_t n) { return lio_pp_process(h, xyzi, n); }
+int lio_pp_wait(lio_pp *h) { return h ? LIO_OK : LIO_ERR_ARG; }
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   h->pp.Process(xyzi, n, ring);
@@ -812,6 +814,7 @@ void lio_rccl_destroy(lio_rccl *) {}
 int lio_rccl_rank(const lio_rccl *) { return -1; }
 int lio_rccl_world(const lio_rccl *) { return 0; }
 int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *) { return LIO_ERR_DEVICE; }
+int lio_bench_voxel_grid(const float *, size_t, float, int, double *, size_t *) { return LIO_ERR_DEVICE; }
 int lio_rccl_bench_all_reduce(lio_rccl *, int, int, double *) { return LIO_ERR_DEVICE; }
 int lio_kf_batch_refine_gather(lio_kf_batch *, lio_rccl *, int, float *, double *) { return LIO_ERR_DEVICE; }
 int lio_est_bench_batched_moments(lio_est *, int, int, double *, double *) { return LIO_ERR_STATE; }  // device-only measurement

@@ -333,6 +333,10 @@ typedef struct {
   int moments_fold_in_kernel; /* 1: fold the per-block moments inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL) */
   int resident_moments;       /* 0: by default rule (on), 1: on, 2: off — the lidar moments of a solve come from ONE resident kernel
                                  that waits for each linearisation point on a doorbell in host memory (LIO_RESIDENT_MOMENTS=0|1) */
+  int resident_rounds;        /* 1: the <= 10 rounds of CalculateLaserOdom as ONE launch (search blocks + an update block that folds, steps and
+                                 republishes the state between rounds; LIO_RESIDENT_ROUNDS=1).  Measured no faster than a launch pair per
+                                 round (30 vs 32 us per round: the one-thread 6x6 step and the fold dominate the gap), and it admits one
+                                 window per process at a time, so it is opt-in */
 } lio_est_config;
 
 /* Named after the reference's TicToc stages so CPU/GPU tables line up. */

@@ -565,6 +565,7 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.stream_sync = c->stream_sync != 0; e.moments_fold_in_kernel = c->moments_fold_in_kernel != 0;
   e.moments_form = (c->moments_form == 1 || c->moments_form == 2) ? c->moments_form : 0;
   e.resident_moments = (c->resident_moments == 1 || c->resident_moments == 2) ? c->resident_moments : 0;
+  e.resident_rounds = c->resident_rounds == 1;
   // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
   h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;

@@ -149,7 +149,14 @@ int odom_rows_blocks(int nslots);
 int odom_round_blocks(int M, int lpq);
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
                        uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail = nullptr,
-                       const HostSignal &sig = HostSignal());
+                       const HostSignal &sig = HostSignal(), int lpq = 8);
+
+// every round of the loop in ONE launch: nb search blocks + one update block that folds, steps and republishes
+// the state between rounds; block_flag (nb words) and state_seq (1 word) must hold values below seq0 (they only ever grow);
+// the final state reaches the host through mail / sig.  max_rounds <= 10.
+void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int max_rounds, OdomState *st, const float4 *map_sorted, const int *cells,
+                                 const GridDesc &g, uint8_t *valid, float4 *coef, float *score, double *partials, unsigned *block_flag, unsigned *state_seq,
+                                 unsigned seq0, long long timeout_ticks, hipStream_t s, OdomState *mail, const HostSignal &sig, long long *stamps = nullptr, int lpq = 8);
 
 // ---- batched keyframe refinement (config 5: B independent OptimizeMap / OptimizeTransformTobeMapped loops, MapBuilder.cc:624-1014,
 // PointMapping.cc:325-753).  Slots of keyframe k = [slot_off, slot_off + Mc) corner, then Ms surf, in one concatenated stack.

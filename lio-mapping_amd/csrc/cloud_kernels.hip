@@ -1130,28 +1130,24 @@ void launch_odom_update(const double *partials, int nblocks, OdomState *st, int 
 // neighbours of each of the block's ODOM_ROUND_THREADS / LPQ queries in LDS; then ONE wave fits and forms rows with one query
 // per lane (every lane busy) while the other waves retire.  Rows are summed in ascending query order: one partial per block.
 #define ODOM_ROUND_THREADS 256
+// one block's share of a round at the transform (q, t): phase 1 on all lanes, phase 2 on wave 0, which leaves the block's 28 sums
+// in `out28` (lanes 0..27 of wave 0 return them; the other waves return 0 and must not use the value)
 template <int LPQ>
-__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_round(FeatArgs a, const OdomState *__restrict__ st, const float4 *__restrict__ map,
-                                                                  const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                                  float4 *__restrict__ coef, float *__restrict__ score, double *__restrict__ partials,
-                                                                  int base_slot, int round, int keep) {
+__device__ __forceinline__ double odom_round_block(const FeatArgs &a, FeatFrame fr, const Quat<float> q, const Vec3<float> t, const float4 *__restrict__ map,
+                                                   const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
+                                                   float *__restrict__ score, int base_slot, int round, int keep, int block) {
   constexpr int QPB = ODOM_ROUND_THREADS / LPQ;   // queries per block
   static_assert(QPB <= 64, "the fit phase is one wave");
   __shared__ int s_bj[QPB][5];
   __shared__ float s_bd4[QPB];
   __shared__ int s_bi4[QPB];
   __shared__ double rows[QPB][29];
-  FeatFrame fr = a.fr[0];
   const int M = fr.M;
   fr.slot_off = base_slot + (keep ? round * M : 0);
-  if (st->converged) return;
   const FeatScalars fs = feat_scalars(a);
-  const float *tp = st->T;
-  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
-  const Vec3<float> t(tp[4], tp[5], tp[6]);
   {   // ---- phase 1: search, LPQ lanes per query
     const int ql = threadIdx.x / LPQ, sub = threadIdx.x % LPQ;
-    const int i = blockIdx.x * QPB + ql;
+    const int i = block * QPB + ql;
     const bool active = i < M;
     const float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
     const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
@@ -1165,44 +1161,188 @@ __global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_round(FeatArgs a, c
     }
   }
   __syncthreads();
-  if (threadIdx.x >= 64) return;
-  // ---- phase 2 (wave 0): fit + rows, one query per lane
-  const int ql = threadIdx.x;
-  double acc[28];
+  double v = 0;
+  if (threadIdx.x < 64) {
+    // ---- phase 2 (wave 0): fit + rows, one query per lane
+    const int ql = threadIdx.x;
+    double acc[28];
 #pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0;
-  const int i = blockIdx.x * QPB + ql;
-  if (ql < QPB && i < M) {
-    const float4 po = fr.stack[i];
-    const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
-    const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
-    int bj[5];
+    for (int k = 0; k < 28; ++k) acc[k] = 0;
+    const int i = block * QPB + ql;
+    if (ql < QPB && i < M) {
+      const float4 po = fr.stack[i];
+      const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+      const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
+      int bj[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
-    const FeatResult res = features_fit<false>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
-    valid[res.slot] = res.ok; coef[res.slot] = res.c;
-    if (score) score[res.slot] = res.sc;
-    const Mat3<float> Rm = toRot(q), Rinv = Rm;   // Rinv unused for b_from_coef = 0
-    if (keep)
-      for (int rr = 0; rr < round; ++rr) {   // the factor lists of the earlier rounds stay in the problem: ascending slot order
-        const int sl = base_slot + rr * M + i;
-        if (valid[sl]) odom_row_accumulate(res.po, coef[sl], q, t, Rm, Rinv, 0, acc);
+      for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
+      const FeatResult res = features_fit<false>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
+      valid[res.slot] = res.ok; coef[res.slot] = res.c;
+      if (score) score[res.slot] = res.sc;
+      const Mat3<float> Rm = toRot(q), Rinv = Rm;   // Rinv unused for b_from_coef = 0
+      if (keep)
+        for (int rr = 0; rr < round; ++rr) {   // the factor lists of the earlier rounds stay in the problem: ascending slot order
+          const int sl = base_slot + rr * M + i;
+          if (valid[sl]) odom_row_accumulate(res.po, coef[sl], q, t, Rm, Rinv, 0, acc);
+        }
+      if (res.ok) odom_row_accumulate(res.po, res.c, q, t, Rm, Rinv, 0, acc);
+    }
+    if (ql < QPB) {
+#pragma unroll
+      for (int k = 0; k < 28; ++k) rows[ql][k] = acc[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x < 28) {
+#pragma unroll
+      for (int qq = 0; qq < QPB; ++qq) v += rows[qq][threadIdx.x];
+    }
+  }
+  return v;
+}
+
+template <int LPQ>
+__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_round(FeatArgs a, const OdomState *__restrict__ st, const float4 *__restrict__ map,
+                                                                  const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                                  float4 *__restrict__ coef, float *__restrict__ score, double *__restrict__ partials,
+                                                                  int base_slot, int round, int keep) {
+  if (st->converged) return;
+  const float *tp = st->T;
+  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  const Vec3<float> t(tp[4], tp[5], tp[6]);
+  const double v = odom_round_block<LPQ>(a, a.fr[0], q, t, map, cells, g, valid, coef, score, base_slot, round, keep, int(blockIdx.x));
+  if (threadIdx.x < 28) partials[size_t(blockIdx.x) * 28 + threadIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All rounds of the newest frame's loop in ONE launch.  Grid = the search blocks of k_odom_round + one update
+// block.  A round: every search block computes its 28 sums at the current transform, parks them in HBM (agent-scope stores,
+// acknowledged) and raises its flag to the round's number; the update block waits for all flags, folds the partials in
+// k_odom_update_wide's order, takes the 6x6 step on its copy of the state, republishes the state and then the round number the
+// search blocks are waiting for.  After convergence or the last round the update block posts the state to the host's mailbox.
+// No atomics, no fences: flags and data travel as agent-scope stores / loads, the writer waits for its data to be acknowledged
+// before it raises the flag.  Every waiter gives up after `timeout_ticks` of the wall clock (a dead peer must not hang the GPU).
+struct OdomRoundsCtl {
+  double *partials;          // nb x 28
+  unsigned *block_flag;      // nb
+  unsigned *state_seq;       // 1: number of the round whose INPUT state is published
+  unsigned seq0;             // number of round 0 of this launch (monotonic over the life of the handle)
+  int max_rounds;
+  long long timeout_ticks;
+  long long *stamps;         // optional (LIO_DEBUG_TIMING): wall clock of the update block at its start, [1 + 2 r] all flags of round r in, [2 + 2 r] state republished
+};
+template <int LPQ>
+__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_rounds_resident(FeatArgs a, OdomState *st, const float4 *__restrict__ map, const int *__restrict__ cells,
+                                                                            GridDesc g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
+                                                                            float *__restrict__ score, int base_slot, int keep, OdomRoundsCtl ctl, OdomState *mail,
+                                                                            HostSignal sig) {
+  const int nb = int(gridDim.x) - 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ OdomState s_st;
+  __shared__ int s_go;
+  unsigned *su = reinterpret_cast<unsigned *>(&s_st);
+  constexpr int NW = int(sizeof(OdomState) / 4);
+  if (int(blockIdx.x) < nb) {
+    // ---------------- search block
+    for (int round = 0; round < ctl.max_rounds; ++round) {
+      const unsigned seq = ctl.seq0 + unsigned(round);
+      if (tid < 64) {
+        int ok = 1;
+        if (round > 0) {   // round 0's state was uploaded in front of the launch
+          const long long t0 = wall_clock64();
+          while (__hip_atomic_load(ctl.state_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+            if (wall_clock64() - t0 > ctl.timeout_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (lane < NW) su[lane] = __hip_atomic_load(reinterpret_cast<unsigned *>(st) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) s_go = ok;
       }
-    if (res.ok) odom_row_accumulate(res.po, res.c, q, t, Rm, Rinv, 0, acc);
+      __syncthreads();
+      if (!s_go || s_st.converged) return;
+      const Quat<float> q(s_st.T[3], s_st.T[0], s_st.T[1], s_st.T[2]);
+      const Vec3<float> t(s_st.T[4], s_st.T[5], s_st.T[6]);
+      const double v = odom_round_block<LPQ>(a, a.fr[0], q, t, map, cells, g, valid, coef, score, base_slot, round, keep, int(blockIdx.x));
+      if (tid < 64) {
+        if (tid < 28) __hip_atomic_store(ctl.partials + size_t(blockIdx.x) * 28 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(ctl.block_flag + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();   // the next round overwrites s_st and the LDS tables of odom_round_block
+    }
+    return;
   }
-  if (ql < QPB) {
+  // ---------------- update block
+  __shared__ double part[32][32];
+  __shared__ double ssum[28];
+  if (tid < NW) su[tid] = reinterpret_cast<const unsigned *>(st)[tid];   // uploaded in front of the launch
+  if (ctl.stamps && tid == 0) ctl.stamps[0] = wall_clock64();
+  __syncthreads();
+  int round = 0;
+  for (; round < ctl.max_rounds && !s_st.converged; ++round) {
+    const unsigned seq = ctl.seq0 + unsigned(round);
+    if (tid < 64) {
+      const long long t0 = wall_clock64();
+      int ok = 1;
+      for (;;) {
+        bool all = true;
+        for (int b0 = 0; b0 < nb; b0 += 64) {
+          const int b = b0 + lane;
+          const unsigned f = b < nb ? __hip_atomic_load(ctl.block_flag + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+          all = all && __all(f == seq);
+        }
+        if (all) break;
+        if (wall_clock64() - t0 > ctl.timeout_ticks) { ok = 0; break; }
+      }
+      if (lane == 0) s_go = ok;
+    }
+    __syncthreads();
+    if (!s_go) break;
+    if (ctl.stamps && tid == 0) ctl.stamps[1 + 2 * round] = wall_clock64();
+    // fold in k_odom_update_wide's order: 32 groups g of rows b = g, g + 32, ..., each as four interleaved chains combined
+    // (v0 + v1) + (v2 + v3), then the group sums in ascending g.  256 threads stand in for its 1024: thread (c, g0) takes the
+    // groups g0, g0 + 8, g0 + 16, g0 + 24 one after the other.
+    {
+      const int c = tid & 31, g0 = tid >> 5;
+      for (int gq = g0; gq < 32; gq += 8) {
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (c < 28) {
+          int b = gq;
+          for (; b + 96 < nb; b += 128) {
+            const double x0 = __hip_atomic_load(ctl.partials + size_t(b) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double x1 = __hip_atomic_load(ctl.partials + size_t(b + 32) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double x2 = __hip_atomic_load(ctl.partials + size_t(b + 64) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double x3 = __hip_atomic_load(ctl.partials + size_t(b + 96) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v0 += x0; v1 += x1; v2 += x2; v3 += x3;
+          }
+          for (; b < nb; b += 32) v0 += __hip_atomic_load(ctl.partials + size_t(b) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        part[gq][c] = (v0 + v1) + (v2 + v3);
+      }
+    }
+    __syncthreads();
+    if (tid < 28) {
+      double s2 = 0;
 #pragma unroll
-    for (int k = 0; k < 28; ++k) rows[ql][k] = acc[k];
+      for (int k = 0; k < 32; ++k) s2 += part[k][tid];
+      ssum[tid] = s2;
+    }
+    __syncthreads();
+    odom_update_from_sums(ssum, &s_st, round, 0, 0);   // thread 0, on the LDS copy
+    __syncthreads();
+    // republish: the state first, acknowledged, then the number of the round that may start from it
+    if (tid < 64) {
+      if (lane < NW) __hip_atomic_store(reinterpret_cast<unsigned *>(st) + lane, su[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(ctl.state_seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ctl.stamps && lane == 0) ctl.stamps[2 + 2 * round] = wall_clock64();
+    }
+    __syncthreads();
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (threadIdx.x < 28) {
-    double v = 0;
-#pragma unroll
-    for (int qq = 0; qq < QPB; ++qq) v += rows[qq][threadIdx.x];
-    partials[size_t(blockIdx.x) * 28 + threadIdx.x] = v;
-  }
+  // the loop ended by convergence, by the round limit or by a timeout: release waiting search blocks (a converged / final state is
+  // already published; after a timeout nothing more can be done for them: they give up on their own), then tell the host
+  if (sig.flag && tid < 64) post_host_mail(sig, mail, &s_st, NW, tid);
 }
 
 // fold of `nblocks` 28-double partials by a 1024-thread block (32 groups of rows b = g mod 32, ascending, then the group sums
@@ -1245,11 +1385,29 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
 }
 
 int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, ODOM_ROUND_THREADS)); }
-void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
-                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig) {
+void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int max_rounds, OdomState *st, const float4 *map_sorted, const int *cells,
+                                 const GridDesc &g, uint8_t *valid, float4 *coef, float *score, double *partials, unsigned *block_flag, unsigned *state_seq,
+                                 unsigned seq0, long long timeout_ticks, hipStream_t s, OdomState *mail, const HostSignal &sig, long long *stamps, int lpq) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
-  const int nb = odom_round_blocks(M, 8);
+  const int nb = odom_round_blocks(M, lpq);
+  OdomRoundsCtl ctl{partials, block_flag, state_seq, seq0, max_rounds, timeout_ticks, stamps};
+  if (lpq == 4)
+    hipLaunchKernelGGL(k_odom_rounds_resident<4>, dim3(nb + 1), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, base_slot, keep, ctl,
+                       mail, sig);
+  else
+  hipLaunchKernelGGL(k_odom_rounds_resident<8>, dim3(nb + 1), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, base_slot, keep, ctl,
+                     mail, sig);
+  LIO_HIP(hipGetLastError());
+}
+void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq) {
+  const int M = a.fr[0].M;
+  if (M <= 0) return;
+  const int nb = odom_round_blocks(M, lpq);
+  if (lpq == 4)
+    hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
+  else
   hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());

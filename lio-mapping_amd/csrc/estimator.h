@@ -37,6 +37,7 @@ struct EstConfig {
   // execution switches (lio_est_config's trailing block; environment overrides are applied in the constructor)
   bool device_solve = false, device_marg = false, inline_marg = false, stream_sync = false, moments_fold_in_kernel = false;
   int moments_form = 0, resident_moments = 0;
+  bool resident_rounds = false;
 };
 
 struct DeviceCloud {
@@ -275,6 +276,13 @@ class Estimator {
   double res_busy_us_ = 0, res_bytes_ = 0; int res_passes_ = 0, res_passes_total_ = 0;   // device-side busy time of the passes (doorbell copy seen -> sums posted), SURVEY 8(d) bytes
   MomentArgs res_args_{};
   DBuf<double> d_res_relay_, d_res_part_;   // HBM: the doorbell as republished by the relay block; the per-block records
+  // The newest frame's rounds as one launch (cloud_kernels.h: launch_odom_rounds_resident): lio_est_config.resident_rounds /
+  // LIO_RESIDENT_ROUNDS=1.  Opt-in: measured at 30 us per round against 32 for a launch pair per round.
+  static constexpr int kOdomResidentMaxBlocks = 512;
+  bool resident_rounds_ = false;
+  DBuf<long long> d_odom_stamps_;
+  DBuf<unsigned> d_odom_flags_;   // [0, 512) one flag per search block, [512] the state's round number
+  unsigned odom_seq_ = 16;        // round numbers grow over the life of the handle: flags never need a reset
   // lio_est_enable_kernel_timing(-1): HIP events around every launch of the resident kernel (it stays in use, unlike under
   // the per-kernel timing of on >= 1): its dispatch-to-exit span, which is what rocprofv3 reports for it
   bool res_time_launch_ = false;

@@ -104,6 +104,11 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR));
   d_res_part_.reserve(size_t(LIO_RES_MAX_BLOCKS) * LIO_MOMENT_OUT);
   LIO_HIP(hipMemset(d_res_part_.p, 0, sizeof(double) * LIO_RES_MAX_BLOCKS * LIO_MOMENT_OUT));   // flags: no pass has sequence number 0
+  resident_rounds_ = cfg.resident_rounds;
+  if (const char *e = std::getenv("LIO_RESIDENT_ROUNDS")) resident_rounds_ = std::atoi(e) != 0;
+  d_odom_stamps_.reserve(24);
+  d_odom_flags_.reserve(kOdomResidentMaxBlocks + 1);
+  LIO_HIP(hipMemset(d_odom_flags_.p, 0, sizeof(unsigned) * (kOdomResidentMaxBlocks + 1)));
   if (const char *e = std::getenv("LIO_RES_PER_LANE")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) res_per_lane_ = v; }
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_door_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, hipHostMallocCoherent));
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_OUT, hipHostMallocCoherent));
@@ -206,7 +211,12 @@ void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, 
   n_state_ = n_frames_ = W_ + 1;
 }
 
-static std::atomic<uint64_t> g_content_id{1};  // bumped whenever a window cloud is (re)written (estimators may live on several host threads)
+static std::atomic<uint64_t> g_content_id{1};
+// Resident kernels hold their CUs until the host (or a peer block) feeds them, so the blocks of ALL of them must be co-resident:
+// a process that drives many windows admits only as many as fit (one round kernel of ~300 blocks, four moments kernels of ~100);
+// a solve that is not admitted takes the launch path, with the same results.
+static std::atomic<int> g_resident_rounds{0}, g_resident_moments{0};
+static constexpr int kMaxResidentRounds = 1, kMaxResidentMoments = 4;  // bumped whenever a window cloud is (re)written (estimators may live on several host threads)
 
 void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
   DeviceCloud &c = stacks_[frame];
@@ -524,16 +534,44 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     const bool mail = host_signal_ && !timers_.on;
     HostSignal sig{};
     if (M > 0) {
-      const int nb = odom_round_blocks(M, 8);
+      // lanes per query: eight, or four when eight would need more search blocks than can be co-resident for the one-launch form
+      // (the K-NN result does not depend on it; the row partition does, so both forms of the loop use the same value)
+      const int lpq = (!resident_rounds_ || odom_round_blocks(M, 8) + 1 <= kOdomResidentMaxBlocks) ? 8 : 4;
+      const int nb = odom_round_blocks(M, lpq);
       d_odom_partials_.reserve(size_t(nb) * 28);
-      // Launch in chunks and peek at the device-side convergence flag between them: a peek costs one small
-      // D2H (~10 us) and saves the no-op launches of every skipped round.
-      const int chunk_end[4] = {3, 5, 7, 10};
-      int chunk = 0;
       FeatArgs fo{};
       fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
       fo.nframes = 1; fo.max_M = M;
       fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0; fo.fr[0].slot_off = slot_off_[W_];
+      // All rounds in ONE launch when its blocks can be co-resident and no other window of this process holds
+      // the chip with one; otherwise round by round.
+      bool resident = mail && resident_rounds_ && nb + 1 <= kOdomResidentMaxBlocks;
+      if (resident && g_resident_rounds.fetch_add(1) >= kMaxResidentRounds) { g_resident_rounds.fetch_sub(1); resident = false; }
+      if (resident) {
+        sig.flag = h_signal_ + 128; sig.seq = ++signal_seq_[1];
+        const unsigned seq0 = odom_seq_;
+        odom_seq_ += 16;
+        launch_odom_rounds_resident(fo, slot_off_[W_], keep_mult > 1 ? 1 : 0, 10, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
+                                    f_score_.p, d_odom_partials_.p, d_odom_flags_.p, d_odom_flags_.p + kOdomResidentMaxBlocks, seq0, res_timeout_ticks_ / 4, stream_,
+                                    h_odom_, sig, g_debug_timing ? d_odom_stamps_.p : nullptr, lpq);
+        struct Release { ~Release() { g_resident_rounds.fetch_sub(1); } } release;   // (the launch is asynchronous; the slot is held until the state is back)
+        LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+        wait_host_signal(sig, stream_);
+        st = *h_odom_;
+        have_state = true;
+        if (g_debug_timing) {
+          long long sp[24] = {0};
+          LIO_HIP(hipMemcpy(sp, d_odom_stamps_.p, sizeof(sp), hipMemcpyDeviceToHost));
+          std::fprintf(stderr, "[lio_hip timing] resident rounds (%d blocks), update block, us from its start:", nb);
+          for (int r = 0; r < st.iters && r < 10; ++r) std::fprintf(stderr, " round %d flags in %.1f republished %.1f |", r, (sp[1 + 2 * r] - sp[0]) * res_tick_us_, (sp[2 + 2 * r] - sp[0]) * res_tick_us_);
+          std::fprintf(stderr, "\n");
+        }
+        if (st.iters == 0 && !st.converged) throw DeviceError("newest-frame rounds: the resident kernel gave up (a block did not report)");
+      } else {
+      // Launch in chunks and peek at the device-side convergence flag between them: a peek costs one small
+      // D2H (~10 us) and saves the no-op launches of every skipped round.
+      const int chunk_end[4] = {3, 5, 7, 10};
+      int chunk = 0;
       for (int iter = 0; iter < 10; ++iter) {
         if (iter == chunk_end[chunk]) {
           if (mail) {
@@ -551,8 +589,9 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
         launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig);
+                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq);
         timers_.end(t1h, stream_);
+      }
       }
     }
     // the older frames' features (second stream) must be complete before anything later on stream_ reads them; the host
@@ -675,6 +714,7 @@ bool Estimator::ResidentBegin(const MomentArgs &ma) {
   int max_slots = 0;
   for (int k = 0; k < ma.nframes; ++k) max_slots = std::max(max_slots, ma.fr[k].nslots);
   if (ResidentBpf(max_slots, ma.nframes) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
+  if (g_resident_moments.fetch_add(1) >= kMaxResidentMoments) { g_resident_moments.fetch_sub(1); return false; }
   res_args_ = ma;
   res_bpf_ = ma.blocks_per_frame; res_nframes_ = ma.nframes;
   for (int f = 0; f < res_nframes_; ++f) {   // idle doorbell: neither the expected sequence number nor STOP
@@ -775,6 +815,7 @@ void Estimator::ResidentEnd() {
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 15), bits, __ATOMIC_RELEASE);
   }
   res_active_ = false;   // the kernel leaves within one poll; whatever is enqueued on stream_ next is ordered behind it
+  g_resident_moments.fetch_sub(1);
   if (res_time_launch_ && !res_launch_events_.empty()) (void)hipEventRecord(res_launch_events_.back().second, stream_);
 }
 

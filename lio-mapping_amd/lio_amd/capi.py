@@ -98,6 +98,7 @@ class EstConfig(C.Structure):
         ("moments_form", C.c_int),
         ("moments_fold_in_kernel", C.c_int),
         ("resident_moments", C.c_int),
+        ("resident_rounds", C.c_int),
     ]
 
 

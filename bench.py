@@ -604,7 +604,7 @@ def main():
             "batched": batched,
             "fed_gpu": fed,
             "keyframe_batch": kf_stats,
-            "batched_kernel_roofline": {"kernel": "k_lidar_moments[_sym]_batched + k_moment_reduce (fp64-MFMA form below 4 chunks per wave, structured fp64-VALU form above)", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
+            "batched_kernel_roofline": {"kernel": "k_lidar_moments_batched + k_moment_reduce (fp64-MFMA form at every size; the structured fp64-VALU form is LIO_MOMENTS=valu)", "note": "B copies of this window's lidar factors at distinct addresses, one launch, HIP events over 20 launches; 60 B and 684 MFMA-flop per residual (SURVEY.md §8d)", "points": batched_kernel},
             "stages_ms": {
                 "t_build_map": round(rep.ms_build_map, 4),
                 "feature_cost": round(rep.ms_features, 4),

@@ -21,14 +21,14 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define MOMENT_THREADS 256
 
-// Two kernels compute the same moments.  Measured on the MI355X (bench.py batched_kernel_roofline): with 2 chunks per wave
-// (one window) the MFMA kernel's launch is 10.5 us against 12.0 us (the register fold at the end of the VALU kernel is on the
-// critical path); from ~4 chunks per wave on the VALU kernel wins, 4.5 vs 3.4 TB/s algorithmic at 512 windows.
-// lio_est_config.moments_form (or LIO_MOMENTS=mfma|valu, read by the estimator) forces one of them; default: by chunks per wave.
+// Two kernels compute the same moments: the fp64-MFMA form (default) and a structured fp64-VALU form (73 sums per lane,
+// lio_est_config.moments_form = 2 / LIO_MOMENTS=valu).  Measured on the MI355X (tools/batched_moments.py, B windows of the bench
+// workload in one launch): round 2 chose the VALU form from four chunks per wave on (4.5 vs 3.4 TB/s algorithmic at B = 512) because
+// the MFMA kernel paid the HBM latency once per chunk; with its loads issued three chunks ahead and four blocks per CU the MFMA form
+// is level at B = 64 (3.57 vs 3.70 TB/s) and ahead at B = 512 (4.01 vs 3.82), so it is used at every size.
 static bool use_mfma(int max_slots, int blocks_per_frame, int form) {
-  if (form) return form == 1;
-  const int chunks_per_wave = cdiv(max_slots, blocks_per_frame * MOMENT_THREADS);
-  return chunks_per_wave < 4;
+  (void)max_slots; (void)blocks_per_frame;
+  return form != 2;
 }
 
 int moment_blocks_per_frame(int max_slots) {
@@ -71,22 +71,34 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   const int e = lane & 15, grp = lane >> 4;
   const int waves_total = nblk * (MOMENT_THREADS / 64);
   const int wid = blockIdx.x * (MOMENT_THREADS / 64) + wv;
+  // LDS: one transpose buffer per wave; after the chunk loop the same memory carries the wave's 16x16 tile to the block fold
+  // (a wave touches only its own slice until the block barrier), so a block needs 34 KB and four of them fit a CU
   __shared__ double zbuf[MOMENT_THREADS / 64][64 * ZROW];
-  __shared__ double sm[MOMENT_THREADS / 64][LIO_MOMENT_OUT];
+  static_assert(64 * ZROW >= LIO_MOMENT_OUT, "the fold's slice fits the transpose buffer");
+  double (*sm)[64 * ZROW] = zbuf;
   double *zb = zbuf[wv];
   v4f64 acc = {0.0, 0.0, 0.0, 0.0};
   double cost = 0.0, cnt = 0.0;
   LogProduct lp;
-  // ---- per-lane residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values).  Branch-free (selects) so that
-  // the setup of chunk i+1 sits in the SAME basic block as the 16 dependent MFMAs of chunk i and the scheduler can fill the
-  // 64-cycle MFMA issue slots with it (software pipelining; the arithmetic and its order are unchanged).
-  auto setup = [&](int base, double (&z)[16], double &c_add, double &n_add) {
+  // ---- a chunk in two steps.  fetch(): the three loads of a lane's residual, issued THREE chunks ahead of their use — a wave
+  // that only starts loading chunk i + 1 when it computes chunk i pays the HBM latency (1-2 us) once per chunk, and with three
+  // or four waves per SIMD nothing hides it (the batched launch ran at a quarter of what its vector and matrix issue rate allow).
+  // weigh(): residual at the current T_{pivot<-i}, Cauchy weight, scaled z (13 values), branch-free so that it sits in the same
+  // basic block as the 16 dependent MFMAs of the chunk before and fills their issue slots.  Arithmetic and order are unchanged.
+  struct Raw { float4 po, c; bool ok; };
+  auto fetch = [&](int base) {
+    Raw r;
     const int sidx = base + lane;
     const bool in = sidx < fr.slot_end;
     const int si = in ? sidx : fr.slot_begin;  // a safe slot to load from when this lane has no residual
-    const bool ok = in && valid[fr.slot_off + si] != 0;
-    const float4 po = fr.stack[si % fr.M];
-    const float4 c = coef[fr.slot_off + si];
+    r.ok = in && valid[fr.slot_off + si] != 0;
+    r.po = fr.stack[si % fr.M];
+    r.c = coef[fr.slot_off + si];
+    return r;
+  };
+  auto weigh = [&](const Raw &rw, double (&z)[16], double &c_add, double &n_add) {
+    const bool ok = rw.ok;
+    const float4 po = rw.po, c = rw.c;
     const double px = po.x, py = po.y, pz = po.z;
     const double w0 = ok ? double(c.x) : 0.0, w1 = ok ? double(c.y) : 0.0, w2 = ok ? double(c.z) : 0.0, d = ok ? double(c.w) : 0.0;
     const double qx = fr.R[0] * px + fr.R[1] * py + fr.R[2] * pz + fr.t[0];
@@ -107,8 +119,9 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   const int stride = waves_total * 64;
   int base = fr.slot_begin + wid * 64;
   if (base < fr.slot_end) {
+    Raw r1 = fetch(base + stride), r2 = fetch(base + 2 * stride), r3 = fetch(base + 3 * stride);   // (past the end: the safe slot, ok = false)
     double z[16], c_add, n_add;
-    setup(base, z, c_add, n_add);
+    { const Raw r0 = fetch(base); weigh(r0, z, c_add, n_add); }
     for (; base < fr.slot_end; base += stride) {
       lp.mul(c_add); cnt += n_add;
       // ---- transpose through LDS (wave-private rows; LDS executes a wave's DS ops in order)
@@ -117,8 +130,10 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // ---- next chunk's setup (all lanes idle past the end: zeros) overlaps the MFMA chain below
-      setup(base + stride, z, c_add, n_add);
+      // ---- next chunk's weights (all lanes idle past the end: zeros) overlap the MFMA chain below; the loads for the chunk
+      // four ahead go out now
+      weigh(r1, z, c_add, n_add);
+      r1 = r2; r2 = r3; r3 = fetch(base + 4 * stride);
       // ---- 16 MFMAs consume the 64 residuals: lane supplies element e of residual 4t+grp as A and B operand
 #pragma unroll
       for (int t = 0; t < 16; ++t) {

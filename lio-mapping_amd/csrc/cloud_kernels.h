@@ -123,6 +123,18 @@ void launch_map_round(const FeatArgs &surf, const float4 *corner_stack, int Mc, 
                       const int *corner_cells, const GridDesc &corner_grid, const float4 *surf_map, const int *surf_cells,
                       const GridDesc &surf_grid, uint8_t *valid, float4 *coef, float4 *abs_coef, const int *skip_flag, hipStream_t s);
 
+// What a solve's feature stage starts from, in ONE launch instead of a fill and two small uploads (each a command of its own in
+// the stream, the uploads staged through the runtime's pinned buffer): valid[0, n_valid) <- 0, the (W + 1) x 8 local transforms,
+// the newest frame's Gauss-Newton state.
+struct SolveSetup {
+  float tf[LIO_MAX_FRAMES][8];
+  int ntf;
+  float odom_T[8];
+  int set_odom;
+};
+struct OdomState;
+void launch_solve_setup(const SolveSetup &a, float *d_transforms, OdomState *d_odom, uint8_t *valid, size_t n_valid, hipStream_t s);
+
 struct OdomState {
   float T[8];        // qx,qy,qz,qw,px,py,pz,pad : local_transform of the newest frame
   int converged;

@@ -260,7 +260,7 @@ struct VoxMail { int count; VoxParams params; int range_overflow; };
 __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys,
                                                             const uint32_t *__restrict__ vals, const int *__restrict__ tile_heads, int n,
                                                             float4 *__restrict__ out, int *__restrict__ count, const VoxParams *__restrict__ params,
-                                                            const int *__restrict__ range_overflow, VoxMail *mail, HostSignal sig) {
+                                                            int *__restrict__ range_overflow, VoxMail *mail, HostSignal sig) {
   __shared__ float4 sp[VOX_TILE];
   __shared__ uint32_t sk[VOX_TILE];
   __shared__ int swave[VOX_TILE / 64], sbase[VOX_TILE / 64];
@@ -286,6 +286,7 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
       const int total = pos + (head ? 1 : 0);
       *count = total;
       smail.count = total; smail.params = *params; smail.range_overflow = *range_overflow;
+      if (sig.flag) *range_overflow = 0;   // the mail carries it: leave the flag clear for the next run (no fill command in front of it)
     }
     if (sig.flag) {
       __syncthreads();
@@ -339,7 +340,7 @@ void VoxelGridDev::enqueue(bool exact) {
   partial_.reserve(size_t(std::max(nkb, 512)) * 8);
   params_.reserve(1);
   keys_.reserve(n); keys2_.reserve(n); vals_.reserve(n); vals2_.reserve(n);
-  count_.reserve(2);
+  if (count_.cap < 2) { count_.reserve(2); LIO_HIP(hipMemsetAsync(count_.p, 0, count_.cap * sizeof(int), s)); }
   out.reserve(n);
   if (!h_count_) {
     // coherent pinned memory: k_vox_centroids posts the count, the bounds and the range flag here (VoxMail), then the completion word
@@ -349,8 +350,9 @@ void VoxelGridDev::enqueue(bool exact) {
     h_params_ = reinterpret_cast<VoxParams *>(h_count_ + 1);
     h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_count_) + 128);
   }
-  int *d_range = count_.p + 1;
-  LIO_HIP(hipMemsetAsync(d_range, 0, sizeof(int), s));
+  int *d_range = count_.p + 1;   // zero between runs: with the mailbox k_vox_centroids clears it after reading it (one fill command less)
+  const bool use_sig = use_signal_ && host_signal_enabled();
+  if (!use_sig) LIO_HIP(hipMemsetAsync(d_range, 0, sizeof(int), s));   // copy-back path: the host reads the flag behind the kernels, so they cannot clear it
   int npartial = 0;
   if (exact) {
     const int nb = std::min(cdiv(ni, 256), 512);
@@ -369,7 +371,8 @@ void VoxelGridDev::enqueue(bool exact) {
   tile_heads_.reserve(ntiles);
   hipLaunchKernelGGL(k_vox_tile_heads, dim3(ntiles + 1), dim3(VOX_TILE), 0, s, keys2_.p, ni, tile_heads_.p, partial_.p, npartial, inv_leaf, params_.p);
   sig_ = HostSignal();
-  if (use_signal_ && host_signal_enabled()) { sig_.flag = h_flag_; sig_.seq = ++seq_; }
+  if (use_sig) { sig_.flag = h_flag_; sig_.seq = ++seq_; }
+
   hipLaunchKernelGGL(k_vox_centroids, dim3(ntiles), dim3(VOX_TILE), 0, s, in, keys2_.p, vals2_.p, tile_heads_.p, ni, out.p, count_.p, params_.p, d_range,
                      reinterpret_cast<VoxMail *>(h_count_), sig_);
   LIO_HIP(hipGetLastError());
@@ -443,13 +446,17 @@ __global__ void k_cell_count(const float4 *__restrict__ pts, int n, GridDesc g, 
   slot[i] = uint32_t(atomicAdd(&cnt[c], 1));
 }
 
+// cnt: the histogram of k_cell_count, already scanned into `starts`; every point puts its cell's count back to zero (plain
+// stores of the same value), so the table is all zeros again when the build ends and the next build needs no fill command
 __global__ void k_cell_place(const float4 *__restrict__ pts, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ slot, int n,
-                             const int *__restrict__ starts, float4 *__restrict__ sorted) {
+                             const int *__restrict__ starts, float4 *__restrict__ sorted, int *__restrict__ cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
   p.w = __int_as_float(i);
-  sorted[starts[keys[i]] + int(slot[i])] = p;
+  const uint32_t c = keys[i];
+  sorted[starts[c] + int(slot[i])] = p;
+  cnt[c] = 0;
 }
 
 void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float mx[3], float cell, hipStream_t s) {
@@ -464,8 +471,11 @@ void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float 
     ncells *= size_t(desc_.dims[d]);
   }
   if (ncells > (size_t(1) << 30)) throw DeviceError("KnnGrid: cell table too large");
-  cells_.reserve(ncells + 1); cnt_.reserve(ncells + 1);
-  LIO_HIP(hipMemsetAsync(cnt_.p, 0, (ncells + 1) * sizeof(int), s));
+  cells_.reserve(ncells + 1);
+  if (cnt_.cap < ncells + 1) {   // a fresh table starts zeroed; after that k_cell_place leaves it zeroed (no fill per build)
+    cnt_.reserve(ncells + 1);
+    LIO_HIP(hipMemsetAsync(cnt_.p, 0, cnt_.cap * sizeof(int), s));
+  }
   keys_.reserve(std::max<size_t>(n, 1)); vals_.reserve(std::max<size_t>(n, 1)); sorted_.reserve(std::max<size_t>(n, 1));
   const int ni = int(n);
   if (ni) hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, ni, desc_, keys_.p, vals_.p, cnt_.p);
@@ -473,7 +483,7 @@ void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float 
   LIO_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_.p, cells_.p, 0, ncells + 1, rocprim::plus<int>(), s));
   tmp_.reserve(tmp_bytes + 256);
   LIO_HIP(rocprim::exclusive_scan(tmp_.p, tmp_bytes, cnt_.p, cells_.p, 0, ncells + 1, rocprim::plus<int>(), s));
-  if (ni) hipLaunchKernelGGL(k_cell_place, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys_.p, vals_.p, ni, cells_.p, sorted_.p);
+  if (ni) hipLaunchKernelGGL(k_cell_place, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys_.p, vals_.p, ni, cells_.p, sorted_.p, cnt_.p);
   LIO_HIP(hipGetLastError());
 }
 
@@ -1382,6 +1392,27 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
     __syncthreads();   // thread 0's update of *st is visible to wave 0
     if (threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
   }
+}
+
+__global__ void __launch_bounds__(256) k_solve_setup(SolveSetup a, float *__restrict__ d_transforms, OdomState *__restrict__ d_odom, uint8_t *__restrict__ valid,
+                                                     size_t n_valid) {
+  const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 16;
+  if (i + 16 <= n_valid) *reinterpret_cast<uint4 *>(valid + i) = make_uint4(0, 0, 0, 0);
+  else for (size_t k = i; k < n_valid; ++k) valid[k] = 0;
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < a.ntf * 8; k += 256) d_transforms[k] = a.tf[k >> 3][k & 7];
+    if (a.set_odom) {
+      unsigned *o = reinterpret_cast<unsigned *>(d_odom);
+      const int nw = int(sizeof(OdomState) / 4);
+      if (int(threadIdx.x) < nw) o[threadIdx.x] = threadIdx.x < 8 ? __float_as_uint(a.odom_T[threadIdx.x]) : 0u;
+    }
+  }
+}
+void launch_solve_setup(const SolveSetup &a, float *d_transforms, OdomState *d_odom, uint8_t *valid, size_t n_valid, hipStream_t s) {
+  static_assert(offsetof(OdomState, T) == 0 && sizeof(OdomState) <= 256 * 4, "state layout: T first, the rest zero");
+  const int nb = std::max(1, cdiv((long long)n_valid, 256 * 16));
+  hipLaunchKernelGGL(k_solve_setup, dim3(nb), dim3(256), 0, s, a, d_transforms, d_odom, valid, n_valid);
+  LIO_HIP(hipGetLastError());
 }
 
 int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, ODOM_ROUND_THREADS)); }

@@ -269,6 +269,7 @@ class Estimator {
   bool res_active_ = false;         // a resident kernel is waiting on the doorbell
   int res_bpf_ = 0, res_nframes_ = 0;
   unsigned res_seq_ = 0;            // sequence number of the last pass rung (monotonic over the life of the handle)
+  unsigned res_launch_seq_ = 0;     // first sequence number of the launch in flight (its STOP value is derived from it)
   double *h_res_door_ = nullptr, *h_res_out_ = nullptr;    // coherent pinned host memory: doorbell, per-frame folded records
   unsigned *h_res_words_ = nullptr;
   long long res_timeout_ticks_ = 0;

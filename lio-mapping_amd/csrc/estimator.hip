@@ -487,16 +487,20 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     if (i > pivot) { nslots_[i] = int(stacks_[i].n) * ((i == W_) ? keep_mult : 1); total_slots_ += size_t(nslots_[i]); }
   }
   f_valid_.reserve(std::max<size_t>(total_slots_, 1)); f_coef_.reserve(std::max<size_t>(total_slots_, 1)); f_score_.reserve(std::max<size_t>(total_slots_, 1));
-  if (total_slots_) LIO_HIP(hipMemsetAsync(f_valid_.p, 0, total_slots_, stream_));
-  // transforms -> device
+  // feature flags cleared, local transforms and the newest frame's state on the device: one launch (cloud_kernels.h: SolveSetup)
   std::vector<float> tfs(size_t(W_ + 1) * 8, 0.f);
+  SolveSetup su{};
+  su.ntf = W_ + 1;
   for (int i = 0; i <= W_; ++i) {
     const Rigidf &T = local_transforms[i];
     float *o = &tfs[size_t(i) * 8];
     o[0] = T.rot.x; o[1] = T.rot.y; o[2] = T.rot.z; o[3] = T.rot.w; o[4] = T.pos.x; o[5] = T.pos.y; o[6] = T.pos.z;
+    std::memcpy(su.tf[i], o, 8 * sizeof(float));
   }
+  std::memcpy(su.odom_T, &tfs[size_t(W_) * 8], 8 * sizeof(float));
+  su.set_odom = cfg_.imu_factor ? 1 : 0;
   d_transforms_.reserve(tfs.size());
-  LIO_HIP(hipMemcpyAsync(d_transforms_.p, tfs.data(), tfs.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  launch_solve_setup(su, d_transforms_.p, d_odom_.p, f_valid_.p, total_slots_, stream_);
   // frames pivot+1 .. W-1 (and W when the IMU factor is off): one batched launch
   FeatArgs fa{};
   fa.min_match_sq_dis = cfg_.min_match_sq_dis; fa.min_plane_dis = cfg_.min_plane_dis;
@@ -528,8 +532,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // transform and the convergence flag; later launches turn into no-ops)
     OdomState st{};
     bool have_state = false;  // a converged peek already brought the final state to the host
-    std::memcpy(st.T, &tfs[size_t(W_) * 8], 8 * sizeof(float));
-    LIO_HIP(hipMemcpyAsync(d_odom_.p, &st, sizeof(st), hipMemcpyHostToDevice, stream_));
+    std::memcpy(st.T, &tfs[size_t(W_) * 8], 8 * sizeof(float));   // (on the device since launch_solve_setup)
     const int M = int(stacks_[W_].n);
     const bool mail = host_signal_ && !timers_.on;
     HostSignal sig{};
@@ -702,8 +705,7 @@ int Estimator::ResidentBpf(int max_slots, int nframes) const {
 
 void Estimator::ResidentLaunchKernel(unsigned first_seq) {
   ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p};
-  // the relay copy may still hold the previous launch's STOP: clear it behind that launch, in front of this one
-  LIO_HIP(hipMemsetAsync(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, stream_));
+  res_launch_seq_ = first_seq;   // (the HBM copy of the doorbell needs no clearing: sequence numbers only grow and STOP is per launch)
   launch_lidar_moments_resident(res_args_, ra, res_per_lane_, f_valid_.p, f_coef_.p, stream_);
 }
 
@@ -808,7 +810,7 @@ void Estimator::ResidentWait(std::vector<FrameMoments> &m) {
 void Estimator::ResidentEnd() {
   res_allowed_ = false;
   if (!res_active_) return;
-  const double stop = LIO_RES_STOP;
+  const double stop = LIO_RES_STOP(res_launch_seq_);
   const unsigned long long bits = *reinterpret_cast<const unsigned long long *>(&stop);
   for (int f = 0; f < res_nframes_; ++f) {
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 7), bits, __ATOMIC_RELEASE);

@@ -51,7 +51,9 @@ int moment_blocks_per_frame(int max_slots);
 #define LIO_RES_OUT 264            // doubles per frame in the host landing zone: 256 S entries + cost + count + 5 diagnostics + pad
 #define LIO_RES_DOOR 16            // doubles per frame in the doorbell: [R0..R6, seq | R7, R8, t0, t1, t2, 0, 0, seq] (two cache lines)
 #define LIO_RES_EXPIRED 0xFFFFFFFFu
-#define LIO_RES_STOP (-1.0)
+// the doorbell value that ends a launch: minus the sequence number of its first pass — unique per launch, so whatever an earlier
+// launch left in the HBM copy of the doorbell (its STOP, its last sequence number) means nothing to this one and needs no clearing
+#define LIO_RES_STOP(first_seq) (-double(first_seq))
 #define LIO_RES_MAX_BLOCKS 256     // one per CU: every block must be co-resident with nothing but the host to wait for
 struct ResidentArgs {
   const double *door;        // host, coherent

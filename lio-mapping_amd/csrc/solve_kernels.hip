@@ -360,6 +360,7 @@ __device__ __forceinline__ void resident_relay(const MomentArgs &a, const Reside
   if (threadIdx.x >= 64) return;
   const int nd = a.nframes * LIO_RES_DOOR;
   unsigned seq = ra.first_seq;
+  const double stop = LIO_RES_STOP(ra.first_seq);
   for (;;) {
     const long long t0 = wall_clock64();
     double v[RES_RELAY_SLOTS];
@@ -376,12 +377,12 @@ __device__ __forceinline__ void resident_relay(const MomentArgs &a, const Reside
         const int i = q * 64 + lane;
         const bool is_slot = i < nd && ((i & 7) == 7);
         all_seq = all_seq && __all(!is_slot || v[q] == double(seq));
-        all_stop = all_stop && __all(!is_slot || v[q] == LIO_RES_STOP);
+        all_stop = all_stop && __all(!is_slot || v[q] == stop);
       }
       if (all_seq) { verdict = double(seq); break; }
-      if (all_stop) { verdict = LIO_RES_STOP; break; }
+      if (all_stop) { verdict = stop; break; }
       if (wall_clock64() - t0 > ra.timeout_ticks) {
-        verdict = LIO_RES_STOP;
+        verdict = stop;
         if (lane == 0) host_store(ra.words + LIO_MAX_FRAMES, LIO_RES_EXPIRED);
         break;
       }
@@ -400,7 +401,7 @@ __device__ __forceinline__ void resident_relay(const MomentArgs &a, const Reside
       if (i < nd && (i & 7) == 7) __hip_atomic_store(ra.relay + i, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (verdict == LIO_RES_STOP) return;
+    if (verdict == stop) return;
     ++seq;
   }
 }
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
         const double sq = door_poll(door, lane, v);
         ++polls;
         if (sq == double(seq)) { state = 1; break; }
-        if (sq == LIO_RES_STOP) { state = 2; break; }
+        if (sq == LIO_RES_STOP(ra.first_seq)) { state = 2; break; }
         if (wall_clock64() - t0 > 2 * ra.timeout_ticks) { state = 2; break; }   // the relay is gone: leave quietly (it reported the timeout)
         __builtin_amdgcn_s_sleep(1);
       }

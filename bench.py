@@ -400,14 +400,6 @@ def main():
     if args.shard_factors:
         value = args.steps / dt_max  # one window solved cooperatively: total work is fixed
 
-    # N > 1: the two modes with a real exchange step, measured in the same run on every rank (collective), reported by rank 0
-    sharded_extra = keyframes_extra = None
-    if world > 1 and not args.shard_factors:
-        sharded_extra = sharded_solve_stats(hip, kind, W, Wo, rank, world, max(10, args.steps // 2), sync=torch.cuda.synchronize, device="cuda")
-        if args.keyframes > 0:
-            km = keyframes_measure(hip, rank, world, min(args.keyframes, 256), 3, sync=torch.cuda.synchronize, device="cuda")
-            keyframes_extra = km["line"] if km else None
-
     resident = est.kernel_timing("moments_resident")   # passes served by the resident moments kernel so far (the timed blocks above)
     est.enable_kernel_timing(-1)                       # untimed block: HIP events around the resident kernel's launches (dispatch -> exit)
     for _ in range(max(5, args.steps // 5)):
@@ -599,8 +591,8 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "sharded": sharded_extra,
-            "keyframes": keyframes_extra,
+            "sharded": None,
+            "keyframes": None,
             "batched": batched,
             "fed_gpu": fed,
             "keyframe_batch": kf_stats,
@@ -629,10 +621,43 @@ def main():
             },
             "setup_s": round(setup_s, 2),
         }
-        print(json.dumps(out))
+    # N > 1: the two modes with a real exchange step, measured in the same run on every rank (collective), reported by rank 0 in
+    # the same line.  They come LAST and under a watchdog: if a rank fails or a collective never completes, rank 0 still prints the
+    # line it has (the weak-scaling measurement) with the failure noted, instead of hanging the whole run.
+    if world > 1 and not args.shard_factors:
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(timeout=240.0):
+                return
+            if rank == 0:
+                out["sharded"] = out["keyframes"] = {"error": "the multi-GPU extras did not finish within 240 s (a rank failed or a collective hung); the headline line above them is unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        extras = {}
+        try:
+            extras["sharded"] = sharded_solve_stats(hip, kind, W, Wo, rank, world, max(10, args.steps // 2), sync=torch.cuda.synchronize, device="cuda")
+            if args.keyframes > 0:
+                km = keyframes_measure(hip, rank, world, min(args.keyframes, 256), 3, sync=torch.cuda.synchronize, device="cuda")
+                extras["keyframes"] = km["line"] if km else None
+        except Exception as e:  # noqa: BLE001 -- this rank failed: say so; the peers' watchdogs end them
+            extras = {"sharded": {"error": f"rank {rank}: {type(e).__name__}: {e}"}, "keyframes": None}
+            if rank != 0:
+                done.set()
+                os._exit(3)
+        done.set()
+        if rank == 0:
+            out.update(extras)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()   # rank 0 runs the untimed extras above: leave the group together
-        dist.destroy_process_group()
+        try:
+            dist.barrier()   # leave the group together
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def keyframes_workload(args, hip, rank, world, torch, dist):

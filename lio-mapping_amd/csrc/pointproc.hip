@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
     // Inside a subregion the picks are sequentially dependent through the mask only: a wave examines 64 sorted candidates at a time,
     // a ballot finds the first still-eligible one (the one the serial loop would reach next), every lane keeps the masked state of
     // ITS candidate in a register and updates it from the picked index and its reach, so the dependent chain never waits on LDS.
-    volatile signed char *wm = wmask + wv * PP_WMASK;
+    // (plain pointer: the wave's own DS operations execute in order, and the wave fences at the chunk boundaries keep the compiler
+    // from carrying mask bytes across them — a volatile pointer costs a wait per store inside the dependent pick chain)
+    signed char *wm = wmask + wv * PP_WMASK;
     int *sel = wsel + wv * PP_WSEL;
     const int off = sp - c.nc;
     const int zone_end = sp + c.nc;   // zone = [sp, zone_end)

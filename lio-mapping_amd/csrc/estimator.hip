@@ -1168,7 +1168,8 @@ void Estimator::SlideWindow() {
     launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
     scratch_cloud_.n = size_t(ca.total);
     scratch_cloud_.id = ++g_content_id;
-    LIO_HIP(hipStreamSynchronize(stream_));
+    // no host wait: the swap exchanges host-side handles only, and every reader or writer of either buffer (the next solve's
+    // BuildLocalMap, PushFrame's recycling, Restore's copies, lio_est_get_stack) is enqueued on stream_ behind this kernel
     std::swap(stacks_[i], scratch_cloud_);
   }
   PushState(cir_buf_count_);

@@ -331,8 +331,13 @@ typedef struct {
   int stream_sync;            /* 1: hipStreamSynchronize + D2H copies instead of completion words in host memory (LIO_HOST_SIGNAL=0) */
   int moments_form;           /* 0: by launch size, 1: fp64 MFMA form, 2: structured fp64 VALU form (LIO_MOMENTS=mfma|valu) */
   int moments_fold_in_kernel; /* 1: fold the per-block moments inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL) */
-  int resident_moments;       /* 0: by default rule (on), 1: on, 2: off — the lidar moments of a solve come from ONE resident kernel
-                                 that waits for each linearisation point on a doorbell in host memory (LIO_RESIDENT_MOMENTS=0|1) */
+  int resident_moments;       /* 0: by default rule (on), 1: on, 2: off, 3: its partition with launches only — the lidar moments of a solve
+                                 come from ONE resident kernel that waits for each linearisation point on a doorbell in host memory
+                                 (LIO_RESIDENT_MOMENTS=0|1).  "On" is a permission: a solve takes the resident form while it is the only
+                                 solve in flight in the process and its factor slots fit 256 co-resident blocks, and a launch pair
+                                 per linearisation otherwise — over the SAME partition of the factor slots, so the moments do not
+                                 depend on which of the two ran (3 pins the launch pairs: what a refused solve gets).  2 is round 2's
+                                 launch pair with its own partition: the same sums in a different order, last-ulp differences */
   int resident_rounds;        /* 1: the <= 10 rounds of CalculateLaserOdom as ONE launch (search blocks + an update block that folds, steps and
                                  republishes the state between rounds; LIO_RESIDENT_ROUNDS=1).  Measured no faster than a launch pair per
                                  round (30 vs 32 us per round: the one-thread 6x6 step and the fold dominate the gap), and it admits one
@@ -492,8 +497,8 @@ typedef struct lio_rccl lio_rccl;
 int lio_rccl_unique_id(unsigned char id[LIO_RCCL_ID_BYTES]);
 lio_rccl *lio_rccl_init(const unsigned char id[LIO_RCCL_ID_BYTES], int rank, int world);
 void lio_rccl_destroy(lio_rccl *);
-int lio_rccl_rank(const lio_rccl *);
-int lio_rccl_world(const lio_rccl *);
+int lio_rccl_rank(const lio_rccl *);    /* ncclCommUserRank of the communicator (-1: null handle or RCCL error) */
+int lio_rccl_world(const lio_rccl *);   /* ncclCommCount of the communicator (0: null handle or RCCL error) — what RCCL itself counts */
 int lio_est_set_factor_sharding_rccl(lio_est *, lio_rccl *comm_or_null);
 /* Measurement hook (collective: every rank of `comm` calls it with the same arguments): `reps` in-place SUM all-reduces of
  * `count` doubles from a device buffer, back to back on one stream; avg_us_out = mean microseconds per all-reduce by HIP

@@ -564,7 +564,7 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.device_solve = c->device_solve != 0; e.device_marg = c->device_marg != 0; e.inline_marg = c->inline_marg != 0;
   e.stream_sync = c->stream_sync != 0; e.moments_fold_in_kernel = c->moments_fold_in_kernel != 0;
   e.moments_form = (c->moments_form == 1 || c->moments_form == 2) ? c->moments_form : 0;
-  e.resident_moments = (c->resident_moments == 1 || c->resident_moments == 2) ? c->resident_moments : 0;
+  e.resident_moments = (c->resident_moments >= 1 && c->resident_moments <= 3) ? c->resident_moments : 0;
   e.resident_rounds = c->resident_rounds == 1;
   // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;

@@ -264,6 +264,7 @@ class Estimator {
   // Resident moments (solve_kernels.h): one launch per solve; every linearisation is a doorbell write + a spin on
   // the blocks' completion words.  Begun lazily by the first LidarLaunch of a SolveOptimization, stopped when it returns.
   bool resident_moments_ = true;    // configured (lio_est_config.resident_moments / LIO_RESIDENT_MOMENTS)
+  bool resident_never_ = false;     // resident_moments = 3: the resident form's partition, launch pairs only (what a refused solve gets)
   int res_per_lane_ = 4;            // residuals a lane keeps in registers (LIO_RES_PER_LANE: 1, 2, 4, 8)
   bool res_allowed_ = false;        // inside SolveOptimization
   bool res_active_ = false;         // a resident kernel is waiting on the doorbell

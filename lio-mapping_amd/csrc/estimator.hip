@@ -96,6 +96,7 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   fold_in_kernel_ = cfg.moments_fold_in_kernel; device_solve_ = cfg.device_solve; async_marg_ = !cfg.inline_marg;
   host_signal_ = !cfg.stream_sync; device_marg_ = cfg.device_marg; moments_form_ = cfg.moments_form;
   resident_moments_ = cfg.resident_moments != 2;
+  resident_never_ = cfg.resident_moments == 3;
   if (const char *e = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL")) fold_in_kernel_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_MOMENTS")) moments_form_ = std::string(e) == "mfma" ? 1 : (std::string(e) == "valu" ? 2 : moments_form_);
@@ -216,7 +217,14 @@ static std::atomic<uint64_t> g_content_id{1};
 // a process that drives many windows admits only as many as fit (one round kernel of ~300 blocks, four moments kernels of ~100);
 // a solve that is not admitted takes the launch path, with the same results.
 static std::atomic<int> g_resident_rounds{0}, g_resident_moments{0};
-static constexpr int kMaxResidentRounds = 1, kMaxResidentMoments = 4;  // bumped whenever a window cloud is (re)written (estimators may live on several host threads)
+// Solves in flight in this process.  A resident moments kernel holds ~100 CUs' worth of registers while it waits for the host,
+// which is free when the GPU has nothing else to do and expensive when other windows' feature kernels want those CUs: measured
+// on the MI355X with four windows solving on four host threads, 3290 solves/s with every solve resident, 3530 with one at a time,
+// 4230 with none (launch pairs).  So a solve takes the resident form only while it is the ONLY solve in flight.
+static std::atomic<int> g_active_solves{0};
+static constexpr int kMaxResidentRounds = 1;
+// (process-wide, hence an environment knob and not a lio_est_config field; 0 = every solve takes the launch path)
+static const int kMaxResidentMoments = [] { const char *e = std::getenv("LIO_MAX_RESIDENT_MOMENTS"); return e ? std::max(0, std::atoi(e)) : 4; }();
 
 void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
   DeviceCloud &c = stacks_[frame];
@@ -712,10 +720,11 @@ void Estimator::ResidentLaunchKernel(unsigned first_seq) {
 // The resident kernel of this solve: launched behind everything the feature stage enqueued on stream_; it returns when the host
 // writes LIO_RES_STOP (ResidentEnd) or after res_timeout_ticks_ without a doorbell.
 bool Estimator::ResidentBegin(const MomentArgs &ma) {
-  if (!res_allowed_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_ || device_solve_) return false;
+  if (!res_allowed_ || resident_never_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_ || device_solve_) return false;
   int max_slots = 0;
   for (int k = 0; k < ma.nframes; ++k) max_slots = std::max(max_slots, ma.fr[k].nslots);
   if (ResidentBpf(max_slots, ma.nframes) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
+  if (g_active_solves.load(std::memory_order_relaxed) > 1) return false;
   if (g_resident_moments.fetch_add(1) >= kMaxResidentMoments) { g_resident_moments.fetch_sub(1); return false; }
   res_args_ = ma;
   res_bpf_ = ma.blocks_per_frame; res_nframes_ = ma.nframes;
@@ -1004,6 +1013,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   lio_solve_report &R = rep ? *rep : local;
   std::memset(&R, 0, sizeof(R));
   bool turn_off = true;
+  struct ActiveSolve { ActiveSolve() { g_active_solves.fetch_add(1); } ~ActiveSolve() { g_active_solves.fetch_sub(1); } } active_solve;
   BuildLocalMap(&R);
   // from here to the end of the solve the lidar passes may come from ONE resident kernel (begun by the first LidarLaunch)
   struct ResidentScope { Estimator *e; ~ResidentScope() { e->ResidentEnd(); } } resident_scope{this};

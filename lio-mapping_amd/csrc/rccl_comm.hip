@@ -30,6 +30,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional: lio_rccl_world / lio_rccl_rank ask the communicator
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 static const RcclApi &rccl_api() {
@@ -49,6 +51,8 @@ static const RcclApi &rccl_api() {
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GetErrorString;
   });
   return api;
@@ -134,8 +138,22 @@ int lio_rccl_bench_all_reduce(lio_rccl *h, int count, int reps, double *avg_us) 
     return LIO_OK;
   } catch (...) { return LIO_ERR_DEVICE; }
 }
-int lio_rccl_rank(const lio_rccl *h) { return h ? h->rank : -1; }
-int lio_rccl_world(const lio_rccl *h) { return h ? h->world : 0; }
+// what the COMMUNICATOR reports (ncclCommUserRank / ncclCommCount), not what the caller passed to lio_rccl_init: bench.py prints
+// it next to n_gpus so that a line claiming N ranks shows RCCL agreeing
+int lio_rccl_rank(const lio_rccl *h) {
+  if (!h) return -1;
+  int r = h->rank;
+  const lio::RcclApi &api = lio::rccl_api();
+  if (h->comm && api.CommUserRank && api.CommUserRank(h->comm, &r) != ncclSuccess) return -1;
+  return r;
+}
+int lio_rccl_world(const lio_rccl *h) {
+  if (!h) return 0;
+  int n = h->world;
+  const lio::RcclApi &api = lio::rccl_api();
+  if (h->comm && api.CommCount && api.CommCount(h->comm, &n) != ncclSuccess) return 0;
+  return n;
+}
 
 }  // extern "C"
 

@@ -184,3 +184,46 @@ def test_stream_sync_fallback_gives_the_same_bits(hip, oracle, resident_rounds):
     assert na == nb and ca == cb
     for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
         np.testing.assert_array_equal(wa[key], wb[key])
+
+
+@pytest.mark.parametrize("kind,W,Wo,frame_dt", [("indoor", 8, 4, 0.2), ("outdoor", 15, 5, 0.3)])
+def test_resident_moments_equal_the_launch_pair(hip, kind, W, Wo, frame_dt):
+    """the resident moments kernel (one launch per solve, one pass per linearisation, doorbell in host memory) and
+    the k_lidar_moments + k_moment_reduce launch pair over the SAME partition of the factor slots (lio_est_config.resident_moments
+    = 3: what a solve gets when the resident form is refused — another solve in flight, factor sharding, stream_sync) share the
+    per-block arithmetic and the fold order, so the solve is the same bit for bit: cost trace, decisions, window — at VLP-16 size
+    and on the HDL-64 headline window.  The pass counter says which of the two actually ran (a silent fallback would make the
+    comparison empty).  Round 2's launch pair (resident_moments = 2) partitions the slots differently: the same sums in another
+    order, compared at 1e-9."""
+    from lio_amd import capi, synth
+    ds = synth.make_dataset(kind, W + 2, frame_dt)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+    runs = {}
+    for resident in (1, 3, 2):
+        cfg = pipeline.config_indoor(hip, W, Wo) if kind == "indoor" else pipeline.config_outdoor64(hip, W, Wo)
+        # keep_features would give the newest frame rounds x M factor slots: 10 rounds x 6.5 k slots need more than the 256 co-resident
+        # blocks of the resident form and the solve takes the launch pairs (same bits; nothing to compare)
+        cfg.prior_factor, cfg.keep_features, cfg.resident_moments = 1, 0, resident
+        pipeline.set_extrinsic(cfg, ds)
+        est = capi.Estimator(hip, cfg)
+        pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)
+        reps = [est.solve()]
+        est.slide()
+        reps.append(pipeline.feed_frame(est, ds, W + 1, clouds[W + 1][0], clouds[W + 1][1]))
+        passes = est.kernel_timing("moments_resident")["launches"]
+        evaluations = sum(r.iterations + 1 for r in reps)
+        if resident == 1:
+            assert passes >= evaluations, (passes, evaluations)   # every linearisation of both solves was a pass of the resident kernel
+        else:
+            assert passes == 0
+        traces = [list(r.cost_trace[:r.iterations + 1]) for r in reps]
+        runs[resident] = (est.get_window(), traces, [(r.iterations, r.termination, r.successful_steps, r.n_lidar_residuals) for r in reps])
+    (wa, ta, da), (wb, tb, db), (wc, tc, dc) = runs[1], runs[3], runs[2]
+    assert da == db and ta == tb
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "t_lb"):
+        np.testing.assert_array_equal(wa[key], wb[key])
+    assert da == dc
+    for x, y in zip(ta, tc):
+        np.testing.assert_allclose(x, y, rtol=1e-9)
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "t_lb"):
+        np.testing.assert_allclose(wa[key], wc[key], atol=1e-8)

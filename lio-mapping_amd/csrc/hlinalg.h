@@ -100,75 +100,136 @@ inline bool chol_upper_portable(double *A, int n, int lda) {
   }
   return true;
 }
-// Same factorisation with AVX-512 FMA for the trailing update (two target rows per pass so every pivot-row load feeds two
-// FMAs).  Selected at run time on hosts that have it (EPYC Genoa/Turin, Xeon SPR: every MI355X host this was run on);
-// the fused multiply-subtract rounds once, so the factor differs from the portable one in the last bits only.
-__attribute__((target("avx512f,fma"))) inline bool chol_upper_avx512(double *A, int n, int lda) {
-  for (int j0 = 0; j0 < n; j0 += 4) {
-    const int jb = (n - j0 < 4) ? n - j0 : 4;
-    for (int j = j0; j < j0 + jb; ++j) {
-      double *rj = A + size_t(j) * lda;
-      const double d = rj[j];
-      if (!(d > 0.0)) return false;
-      const double u = std::sqrt(d);
-      rj[j] = u;
-      const double iu = 1.0 / u;
-      for (int i = j + 1; i < n; ++i) rj[i] *= iu;
-      for (int k = j + 1; k < j0 + jb; ++k) {
-        const double f = rj[k];
-        double *rk = A + size_t(k) * lda;
-        for (int i = k; i < n; ++i) rk[i] -= f * rj[i];
-      }
+// The same factorisation for hosts with AVX-512 FMA (EPYC Genoa / Turin, Xeon SPR: every MI355X host this was run on), selected at
+// run time.  Blocked and UP-looking: per panel of 8 rows (1) the contribution of all rows above is subtracted by a register-tiled
+// 8 x 24 kernel — 24 accumulators, per pivot row 3 vector loads + 8 broadcasts feed 24 FMAs, every panel element is loaded and
+// stored once, every loop has a trip count that is a multiple of 8 —, (2) the 8 x 8 diagonal block is factored in scalars,
+// (3) the rest of the panel is solved against it with the 8 row vectors of a column chunk in registers.  The right-looking form
+// above re-reads and re-writes the trailing matrix once per 4 pivots with row loops of every length (D = 96 on the EPYC 9575F:
+// 6.3 us against ~3 us for this form).  Out of place: A = chol(S + diag(shift)) with S untouched (S == A allowed), which
+// also saves the dogleg its copy of H.  Subtractions are fused multiply-subtracts in ascending pivot order, so the factor differs
+// from the portable one in the last bits only.  The strictly lower triangle of A's diagonal blocks is scratch.
+template <int NV>
+__attribute__((target("avx512f,fma"), always_inline)) inline void chol_blk_update(const double *S, double *A, int lda, int j0, int i, __mmask8 mlast) {
+  __m512d acc[8][NV];
+  for (int r = 0; r < 8; ++r)
+    for (int c = 0; c < NV; ++c) {
+      const double *src = S + size_t(j0 + r) * lda + i + 8 * c;
+      acc[r][c] = (c == NV - 1) ? _mm512_maskz_loadu_pd(mlast, src) : _mm512_loadu_pd(src);
     }
-    if (jb < 4) {
-      for (int j = j0; j < j0 + jb; ++j) {
-        const double *rj = A + size_t(j) * lda;
-        for (int k = j0 + jb; k < n; ++k) { const double f = rj[k]; double *rk = A + size_t(k) * lda; for (int i = k; i < n; ++i) rk[i] -= f * rj[i]; }
-      }
-      continue;
+  for (int k = 0; k < j0; ++k) {
+    const double *uk = A + size_t(k) * lda;
+    __m512d u[NV];
+    for (int c = 0; c < NV; ++c) u[c] = (c == NV - 1) ? _mm512_maskz_loadu_pd(mlast, uk + i + 8 * c) : _mm512_loadu_pd(uk + i + 8 * c);
+#pragma GCC unroll 8
+    for (int r = 0; r < 8; ++r) {
+      const __m512d b = _mm512_set1_pd(uk[j0 + r]);
+      for (int c = 0; c < NV; ++c) acc[r][c] = _mm512_fnmadd_pd(b, u[c], acc[r][c]);
     }
-    const double *r0 = A + size_t(j0) * lda, *r1 = r0 + lda, *r2 = r1 + lda, *r3 = r2 + lda;
-    int k = j0 + 4;
-    for (; k + 1 < n; k += 2) {
-      double *ra = A + size_t(k) * lda, *rb = ra + lda;
-      const double a0 = r0[k], a1 = r1[k], a2 = r2[k], a3 = r3[k];
-      const double b0 = r0[k + 1], b1 = r1[k + 1], b2 = r2[k + 1], b3 = r3[k + 1];
-      ra[k] = ra[k] - a0 * r0[k] - a1 * r1[k] - a2 * r2[k] - a3 * r3[k];  // the element row b does not have
-      const __m512d A0 = _mm512_set1_pd(a0), A1 = _mm512_set1_pd(a1), A2 = _mm512_set1_pd(a2), A3 = _mm512_set1_pd(a3);
-      const __m512d B0 = _mm512_set1_pd(b0), B1 = _mm512_set1_pd(b1), B2 = _mm512_set1_pd(b2), B3 = _mm512_set1_pd(b3);
-      int i = k + 1;
-      for (; i + 8 <= n; i += 8) {
-        const __m512d p0 = _mm512_loadu_pd(r0 + i), p1 = _mm512_loadu_pd(r1 + i), p2 = _mm512_loadu_pd(r2 + i), p3 = _mm512_loadu_pd(r3 + i);
-        __m512d va = _mm512_loadu_pd(ra + i), vb = _mm512_loadu_pd(rb + i);
-        va = _mm512_fnmadd_pd(A0, p0, va); vb = _mm512_fnmadd_pd(B0, p0, vb);
-        va = _mm512_fnmadd_pd(A1, p1, va); vb = _mm512_fnmadd_pd(B1, p1, vb);
-        va = _mm512_fnmadd_pd(A2, p2, va); vb = _mm512_fnmadd_pd(B2, p2, vb);
-        va = _mm512_fnmadd_pd(A3, p3, va); vb = _mm512_fnmadd_pd(B3, p3, vb);
-        _mm512_storeu_pd(ra + i, va); _mm512_storeu_pd(rb + i, vb);
-      }
-      if (i < n) {
-        const __mmask8 m = __mmask8((1u << (n - i)) - 1u);
-        const __m512d p0 = _mm512_maskz_loadu_pd(m, r0 + i), p1 = _mm512_maskz_loadu_pd(m, r1 + i), p2 = _mm512_maskz_loadu_pd(m, r2 + i),
-                      p3 = _mm512_maskz_loadu_pd(m, r3 + i);
-        __m512d va = _mm512_maskz_loadu_pd(m, ra + i), vb = _mm512_maskz_loadu_pd(m, rb + i);
-        va = _mm512_fnmadd_pd(A0, p0, va); vb = _mm512_fnmadd_pd(B0, p0, vb);
-        va = _mm512_fnmadd_pd(A1, p1, va); vb = _mm512_fnmadd_pd(B1, p1, vb);
-        va = _mm512_fnmadd_pd(A2, p2, va); vb = _mm512_fnmadd_pd(B2, p2, vb);
-        va = _mm512_fnmadd_pd(A3, p3, va); vb = _mm512_fnmadd_pd(B3, p3, vb);
-        _mm512_mask_storeu_pd(ra + i, m, va); _mm512_mask_storeu_pd(rb + i, m, vb);
-      }
+  }
+  for (int r = 0; r < 8; ++r)
+    for (int c = 0; c < NV; ++c) {
+      double *dst = A + size_t(j0 + r) * lda + i + 8 * c;
+      if (c == NV - 1) _mm512_mask_storeu_pd(dst, mlast, acc[r][c]); else _mm512_storeu_pd(dst, acc[r][c]);
     }
-    for (; k < n; ++k) {
-      const double f0 = r0[k], f1 = r1[k], f2 = r2[k], f3 = r3[k];
-      double *rk = A + size_t(k) * lda;
-      for (int i = k; i < n; ++i) rk[i] = rk[i] - f0 * r0[i] - f1 * r1[i] - f2 * r2[i] - f3 * r3[i];
+}
+__attribute__((target("avx512f,fma"))) inline bool chol_upper_from_avx512(const double *S, double *A, int n, int lda, const double *shift) {
+  int j0 = 0;
+  for (; j0 + 8 <= n; j0 += 8) {
+    int i = j0;
+    for (; i + 24 <= n; i += 24) chol_blk_update<3>(S, A, lda, j0, i, __mmask8(0xFF));
+    const int rem = n - i;   // 0 .. 23
+    if (rem > 16) chol_blk_update<3>(S, A, lda, j0, i, __mmask8((1u << (rem - 16)) - 1u));
+    else if (rem > 8) chol_blk_update<2>(S, A, lda, j0, i, __mmask8((1u << (rem - 8)) - 1u));
+    else if (rem > 0) chol_blk_update<1>(S, A, lda, j0, i, __mmask8((1u << rem) - 1u));
+    double d[8][8], inv[8];
+    for (int r = 0; r < 8; ++r) for (int c = r; c < 8; ++c) d[r][c] = A[size_t(j0 + r) * lda + j0 + c];
+    if (shift) for (int r = 0; r < 8; ++r) d[r][r] += shift[j0 + r];
+    for (int j = 0; j < 8; ++j) {
+      if (!(d[j][j] > 0.0)) return false;
+      const double u = std::sqrt(d[j][j]);
+      d[j][j] = u; inv[j] = 1.0 / u;
+      for (int c = j + 1; c < 8; ++c) d[j][c] *= inv[j];
+      for (int r = j + 1; r < 8; ++r) for (int c = r; c < 8; ++c) d[r][c] = std::fma(-d[j][r], d[j][c], d[r][c]);
     }
+    for (int r = 0; r < 8; ++r) for (int c = r; c < 8; ++c) A[size_t(j0 + r) * lda + j0 + c] = d[r][c];
+    for (i = j0 + 8; i < n; i += 8) {
+      const __mmask8 m = (n - i >= 8) ? __mmask8(0xFF) : __mmask8((1u << (n - i)) - 1u);
+      __m512d a[8];
+      for (int r = 0; r < 8; ++r) a[r] = _mm512_maskz_loadu_pd(m, A + size_t(j0 + r) * lda + i);
+#pragma GCC unroll 8
+      for (int j = 0; j < 8; ++j) {
+        a[j] = _mm512_mul_pd(a[j], _mm512_set1_pd(inv[j]));
+#pragma GCC unroll 8
+        for (int r = j + 1; r < 8; ++r) a[r] = _mm512_fnmadd_pd(_mm512_set1_pd(d[j][r]), a[j], a[r]);
+      }
+      for (int r = 0; r < 8; ++r) _mm512_mask_storeu_pd(A + size_t(j0 + r) * lda + i, m, a[r]);
+    }
+  }
+  for (int j = j0; j < n; ++j) {   // the last n mod 8 rows: plain recurrence
+    double *rj = A + size_t(j) * lda;
+    const double *sj = S + size_t(j) * lda;
+    for (int i = j; i < n; ++i) rj[i] = sj[i];
+    if (shift) rj[j] += shift[j];
+    for (int k = 0; k < j; ++k) { const double *rk = A + size_t(k) * lda; const double f = rk[j]; for (int i = j; i < n; ++i) rj[i] = std::fma(-f, rk[i], rj[i]); }
+    if (!(rj[j] > 0.0)) return false;
+    const double u = std::sqrt(rj[j]);
+    rj[j] = u;
+    const double iu = 1.0 / u;
+    for (int i = j + 1; i < n; ++i) rj[i] *= iu;
   }
   return true;
 }
-inline bool chol_upper(double *A, int n, int lda) {
+inline bool host_has_avx512() {
   static const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
-  return has512 ? chol_upper_avx512(A, n, lda) : chol_upper_portable(A, n, lda);
+  return has512;
+}
+// A = chol(S + diag(shift)): upper factor in A's upper triangle, S untouched unless S == A; shift may be null
+inline bool chol_upper_from(const double *S, double *A, int n, int lda, const double *shift) {
+  if (host_has_avx512()) return chol_upper_from_avx512(S, A, n, lda, shift);
+  if (S != A) for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) A[size_t(i) * lda + j] = S[size_t(i) * lda + j];
+  if (shift) for (int i = 0; i < n; ++i) A[size_t(i) * lda + i] += shift[i];
+  return chol_upper_portable(A, n, lda);
+}
+inline bool chol_upper(double *A, int n, int lda) { return chol_upper_from(A, A, n, lda, nullptr); }
+
+// x^T H x for a symmetric row-major H (the dogleg's |J g|^2 and s^T H s).  The plain double loop is a chain of n dependent adds
+// per row under strict IEEE semantics (2.8 us at n = 96 on the build host); eight-lane partial sums, two accumulators per row.
+// y (optional) receives H x.
+inline double sym_quad_portable(const double *H, const double *x, int n, int lda, double *y) {
+  double q = 0;
+  for (int i = 0; i < n; ++i) {
+    const double *row = H + size_t(i) * lda;
+    double s = 0;
+    for (int j = 0; j < n; ++j) s += row[j] * x[j];
+    if (y) y[i] = s;
+    q += x[i] * s;
+  }
+  return q;
+}
+__attribute__((target("avx512f,fma"))) inline double sym_quad_avx512(const double *H, const double *x, int n, int lda, double *y) {
+  double q = 0;
+  for (int i = 0; i < n; ++i) {
+    const double *row = H + size_t(i) * lda;
+    __m512d a0 = _mm512_setzero_pd(), a1 = _mm512_setzero_pd();
+    int j = 0;
+    for (; j + 16 <= n; j += 16) {
+      a0 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j), _mm512_loadu_pd(x + j), a0);
+      a1 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j + 8), _mm512_loadu_pd(x + j + 8), a1);
+    }
+    if (j + 8 <= n) { a0 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j), _mm512_loadu_pd(x + j), a0); j += 8; }
+    if (j < n) {
+      const __mmask8 m = __mmask8((1u << (n - j)) - 1u);
+      a1 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, row + j), _mm512_maskz_loadu_pd(m, x + j), a1);
+    }
+    const double s = _mm512_reduce_add_pd(_mm512_add_pd(a0, a1));
+    if (y) y[i] = s;
+    q += x[i] * s;
+  }
+  return q;
+}
+inline double sym_quad(const double *H, const double *x, int n, int lda, double *y = nullptr) {
+  return host_has_avx512() ? sym_quad_avx512(H, x, n, lda, y) : sym_quad_portable(H, x, n, lda, y);
 }
 // solve U^T U x = b in place
 inline void chol_upper_solve_portable(const double *U, int n, int lda, double *b) {
@@ -186,36 +247,78 @@ inline void chol_upper_solve_portable(const double *U, int n, int lda, double *b
   }
 }
 
-// The backward sweep is a chain of dot products: one scalar accumulator makes it latency-bound (n^2/2 dependent
-// multiply-adds, 6 us at n = 96).  Eight-lane partial sums cut the chain eight-fold.
+// Both sweeps are latency chains when done element by element: forward, b[i + 1] waits for the axpy of step i (divide + FMA +
+// store-to-load forwarding per step); backward, a dot product and a divide per row.  Blocked by 8: the 8 x 8 triangle of a block
+// is solved in scalars with reciprocals of the diagonal (computed once, eight at a time), everything outside the triangle is
+// eight independent vector FMAs per column chunk (forward) or eight independent dot products (backward).
 __attribute__((target("avx512f,fma"))) inline void chol_upper_solve_avx512(const double *U, int n, int lda, double *b) {
-  for (int i = 0; i < n; ++i) {  // forward: U^T y = b, column-oriented (axpy)
-    const double y = b[i] / U[size_t(i) * lda + i];
-    b[i] = y;
-    const double *ri = U + size_t(i) * lda;
-    const __m512d Y = _mm512_set1_pd(y);
-    int k = i + 1;
-    for (; k + 8 <= n; k += 8) _mm512_storeu_pd(b + k, _mm512_fnmadd_pd(_mm512_loadu_pd(ri + k), Y, _mm512_loadu_pd(b + k)));
-    if (k < n) {
-      const __mmask8 m = __mmask8((1u << (n - k)) - 1u);
-      _mm512_mask_storeu_pd(b + k, m, _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(m, ri + k), Y, _mm512_maskz_loadu_pd(m, b + k)));
+  double inv[256];
+  std::vector<double> inv_big;
+  double *iv = inv;
+  if (n > 256) { inv_big.resize(n); iv = inv_big.data(); }
+  for (int i = 0; i < n; ++i) iv[i] = U[size_t(i) * lda + i];
+  {
+    const __m512d one = _mm512_set1_pd(1.0);
+    int i = 0;
+    for (; i + 8 <= n; i += 8) _mm512_storeu_pd(iv + i, _mm512_div_pd(one, _mm512_loadu_pd(iv + i)));
+    for (; i < n; ++i) iv[i] = 1.0 / iv[i];
+  }
+  const int nb = n & ~7;
+  // forward: U^T y = b
+  for (int i0 = 0; i0 < nb; i0 += 8) {
+    double y[8];
+    for (int j = 0; j < 8; ++j) y[j] = b[i0 + j];
+    for (int j = 0; j < 8; ++j) {
+      y[j] *= iv[i0 + j];
+      const double *rj = U + size_t(i0 + j) * lda + i0;
+      for (int r = j + 1; r < 8; ++r) y[r] = std::fma(-rj[r], y[j], y[r]);
+    }
+    for (int j = 0; j < 8; ++j) b[i0 + j] = y[j];
+    __m512d Y[8];
+    for (int j = 0; j < 8; ++j) Y[j] = _mm512_set1_pd(y[j]);
+    for (int k = i0 + 8; k < n; k += 8) {
+      const __mmask8 m = (n - k >= 8) ? __mmask8(0xFF) : __mmask8((1u << (n - k)) - 1u);
+      __m512d v = _mm512_maskz_loadu_pd(m, b + k);
+#pragma GCC unroll 8
+      for (int j = 0; j < 8; ++j) v = _mm512_fnmadd_pd(_mm512_maskz_loadu_pd(m, U + size_t(i0 + j) * lda + k), Y[j], v);
+      _mm512_mask_storeu_pd(b + k, m, v);
     }
   }
-  for (int i = n - 1; i >= 0; --i) {  // backward: U x = y
+  for (int i = nb; i < n; ++i) {   // the last n mod 8 rows
+    const double yv = b[i] * iv[i];
+    b[i] = yv;
     const double *ri = U + size_t(i) * lda;
-    __m512d acc = _mm512_setzero_pd();
-    int k = i + 1;
-    for (; k + 8 <= n; k += 8) acc = _mm512_fmadd_pd(_mm512_loadu_pd(ri + k), _mm512_loadu_pd(b + k), acc);
-    if (k < n) {
-      const __mmask8 m = __mmask8((1u << (n - k)) - 1u);
-      acc = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, ri + k), _mm512_maskz_loadu_pd(m, b + k), acc);
+    for (int k = i + 1; k < n; ++k) b[k] = std::fma(-ri[k], yv, b[k]);
+  }
+  // backward: U x = y
+  for (int i = n - 1; i >= nb; --i) {
+    const double *ri = U + size_t(i) * lda;
+    double sres = b[i];
+    for (int k = i + 1; k < n; ++k) sres = std::fma(-ri[k], b[k], sres);
+    b[i] = sres * iv[i];
+  }
+  for (int i0 = nb - 8; i0 >= 0; i0 -= 8) {
+    __m512d acc[8];
+    for (int r = 0; r < 8; ++r) acc[r] = _mm512_setzero_pd();
+    for (int k = i0 + 8; k < n; k += 8) {
+      const __mmask8 m = (n - k >= 8) ? __mmask8(0xFF) : __mmask8((1u << (n - k)) - 1u);
+      const __m512d xv = _mm512_maskz_loadu_pd(m, b + k);
+#pragma GCC unroll 8
+      for (int r = 0; r < 8; ++r) acc[r] = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, U + size_t(i0 + r) * lda + k), xv, acc[r]);
     }
-    b[i] = (b[i] - _mm512_reduce_add_pd(acc)) / ri[i];
+    double x[8];
+    for (int r = 0; r < 8; ++r) x[r] = b[i0 + r] - _mm512_reduce_add_pd(acc[r]);
+    for (int j = 7; j >= 0; --j) {
+      const double *rj = U + size_t(i0 + j) * lda + i0;
+      double sres = x[j];
+      for (int r = j + 1; r < 8; ++r) sres = std::fma(-rj[r], x[r], sres);
+      x[j] = sres * iv[i0 + j];
+    }
+    for (int r = 0; r < 8; ++r) b[i0 + r] = x[r];
   }
 }
 inline void chol_upper_solve(const double *U, int n, int lda, double *b) {
-  static const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
-  if (has512) chol_upper_solve_avx512(U, n, lda, b); else chol_upper_solve_portable(U, n, lda, b);
+  if (host_has_avx512()) chol_upper_solve_avx512(U, n, lda, b); else chol_upper_solve_portable(U, n, lda, b);
 }
 
 // Gauss-Jordan inverse with partial pivoting, n x n.

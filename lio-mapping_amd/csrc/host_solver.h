@@ -338,6 +338,24 @@ class WindowSystem {
       }
     }
     if (H && static_part_hook) static_part_hook(*H, *g);
+    // (the extrinsic prior is evaluated here, ahead of the wait, like everything else that does not need the lidar moments)
+    if ((which & 8) && use_prior_factor) {
+      double r[6], J[42];
+      prior_factor(prior_pos, prior_rot, P.ex.data(), r, H ? J : nullptr);
+      double cost = 0;
+      for (int k = 0; k < 6; ++k) cost += r[k] * r[k];
+      c.prior = 0.5 * cost;
+      if (H && lay.ex >= 0) {
+        double Hb[36], gb[6];
+        for (int a = 0; a < 6; ++a) {
+          for (int b = 0; b < 6; ++b) { double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * J[k * 7 + b]; Hb[a * 6 + b] = s; }
+          double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * r[k];
+          gb[a] = s;
+        }
+        int cols[1] = {lay.ex}, sizes[1] = {6};
+        add_block(*H, *g, cols, sizes, 1, Hb, gb, 6);
+      }
+    }
     // The 18 x 13 linear maps of the frames' lidar factors depend on the poses only: they are formed HERE, while the device
     // pass is still in flight, instead of behind the wait (0.6 us per frame off the critical path of every linearisation).
     const bool lidar_h = lidar_on && (preset || split || lidar_eval) && H;
@@ -371,23 +389,6 @@ class WindowSystem {
       }
     }
     { const double t = clk_now(); eclk.assemble += t - tk0; tk0 = t; }
-    if ((which & 8) && use_prior_factor) {
-      double r[6], J[42];
-      prior_factor(prior_pos, prior_rot, P.ex.data(), r, H ? J : nullptr);
-      double cost = 0;
-      for (int k = 0; k < 6; ++k) cost += r[k] * r[k];
-      c.prior = 0.5 * cost;
-      if (H && lay.ex >= 0) {
-        double Hb[36], gb[6];
-        for (int a = 0; a < 6; ++a) {
-          for (int b = 0; b < 6; ++b) { double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * J[k * 7 + b]; Hb[a * 6 + b] = s; }
-          double s = 0; for (int k = 0; k < 6; ++k) s += J[k * 7 + a] * r[k];
-          gb[a] = s;
-        }
-        int cols[1] = {lay.ex}, sizes[1] = {6};
-        add_block(*H, *g, cols, sizes, 1, Hb, gb, 6);
-      }
-    }
     return c;
   }
 };
@@ -554,7 +555,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
   const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
   bool reuse = false;
-  std::vector<double> diag(n), grad(n), gn(n), step(n), tmp(n);
+  std::vector<double> diag(n), grad(n), gn(n), step(n), tmp(n), shift(n);
   std::vector<double> A(size_t(n) * n);
   int invalid = 0, it = 0;
   DMat Hc; std::vector<double> gc;  // candidate linearisation; swapped with (H, g) on acceptance, never reallocated
@@ -578,7 +579,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       for (int i = 0; i < n; ++i) diag[i] = std::sqrt(std::min(std::max(H(i, i), 1e-6), 1e32));
       double g2 = 0, Jg2 = 0;
       for (int i = 0; i < n; ++i) { grad[i] = g[i] / diag[i]; tmp[i] = grad[i] / diag[i]; g2 += grad[i] * grad[i]; }
-      for (int i = 0; i < n; ++i) { double s = 0; const double *row = &H.a[size_t(i) * n]; for (int j = 0; j < n; ++j) s += row[j] * tmp[j]; Jg2 += tmp[i] * s; }
+      Jg2 = sym_quad(H.a.data(), tmp.data(), n, n);
       alpha = g2 / Jg2;
       lin_ok = false;
       while (mu < max_mu) {
@@ -588,9 +589,8 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
           ok = spec.finish(H, g, diag, gn, A22, t2);
           spec.valid = false;
         } else {
-          A = H.a;
-          for (int i = 0; i < n; ++i) A[size_t(i) * n + i] += diag[i] * diag[i] * mu;
-          ok = chol_upper(A.data(), n, n);
+          for (int i = 0; i < n; ++i) shift[i] = diag[i] * diag[i] * mu;
+          ok = chol_upper_from(H.a.data(), A.data(), n, n, shift.data());   // A = chol(H + mu D^2), H untouched
           if (ok) {
             gn = g;
             chol_upper_solve(A.data(), n, n, gn.data());
@@ -624,7 +624,8 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       }
       double sg = 0, sHs = 0;
       for (int i = 0; i < n; ++i) step[i] /= diag[i];
-      for (int i = 0; i < n; ++i) { double s = 0; const double *row = &H.a[size_t(i) * n]; for (int j = 0; j < n; ++j) s += row[j] * step[j]; sHs += step[i] * s; sg += step[i] * g[i]; }
+      sHs = sym_quad(H.a.data(), step.data(), n, n);
+      for (int i = 0; i < n; ++i) sg += step[i] * g[i];
       model_change = -(sg + 0.5 * sHs);
       if (!(model_change > 0)) valid = false;
     }

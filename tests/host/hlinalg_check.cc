@@ -18,7 +18,13 @@ int main() {
     std::vector<double> xp = g;
     if (okp) lio::chol_upper_solve_portable(Ap.data(), n, n, xp.data());
     const bool eok = lio::sym_eig(H.data(), n, w.data(), V.data());
-    std::printf("%d %d %d\n", int(ok), int(okp), int(eok));
+    // out-of-place factorisation of H + diag(shift) (the dogleg's mu-regularised system; H must stay untouched), and x^T H x
+    std::vector<double> shift(n), As(size_t(n) * n, 0.0), Hkeep(H), xs(g), Hg(n), Hgp(n);
+    for (int i = 0; i < n; ++i) shift[i] = 0.25 * H[size_t(i) * n + i] + 1e-3;
+    const bool oks = lio::chol_upper_from(H.data(), As.data(), n, n, shift.data()) && H == Hkeep;
+    if (oks) lio::chol_upper_solve(As.data(), n, n, xs.data());
+    const double q = lio::sym_quad(H.data(), g.data(), n, n, Hg.data()), qp = lio::sym_quad_portable(H.data(), g.data(), n, n, Hgp.data());
+    std::printf("%d %d %d %d\n", int(ok), int(okp), int(eok), int(oks));
     for (int i = 0; i < n; ++i) std::printf("%.17g ", x[i]);
     std::printf("\n");
     for (int i = 0; i < n; ++i) std::printf("%.17g ", xp[i]);
@@ -26,6 +32,11 @@ int main() {
     for (int i = 0; i < n; ++i) std::printf("%.17g ", w[i]);
     std::printf("\n");
     for (size_t i = 0; i < V.size(); ++i) std::printf("%.17g ", V[i]);
+    std::printf("\n");
+    for (int i = 0; i < n; ++i) std::printf("%.17g ", xs[i]);
+    std::printf("\n");
+    std::printf("%.17g %.17g ", q, qp);
+    for (int i = 0; i < n; ++i) std::printf("%.17g %.17g ", Hg[i], Hgp[i]);
     std::printf("\n");
   }
   return 0;

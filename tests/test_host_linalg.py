@@ -29,9 +29,9 @@ def _run(exe, problems):
     res = []
     for k, (H, g) in enumerate(problems):
         n = H.shape[0]
-        flags = [int(v) for v in out[5 * k].split()]
-        rows = [np.array([float(v) for v in out[5 * k + r].split()]) for r in range(1, 5)]
-        res.append((flags, rows[0], rows[1], rows[2], rows[3].reshape(n, n)))
+        flags = [int(v) for v in out[7 * k].split()]
+        rows = [np.array([float(v) for v in out[7 * k + r].split()]) for r in range(1, 7)]
+        res.append((flags, rows[0], rows[1], rows[2], rows[3].reshape(n, n), rows[4], rows[5]))
     return res
 
 
@@ -42,9 +42,17 @@ def test_cholesky_solve_and_eigen_against_numpy(checker):
         B = rng.normal(size=(n, n))
         problems.append((B @ B.T + n * np.eye(n), rng.normal(size=n)))
     res = _run(checker, problems)
-    for (H, g), (flags, x, xp, w, V) in zip(problems, res):
+    for (H, g), (flags, x, xp, w, V, xs, quad) in zip(problems, res):
         n = H.shape[0]
-        assert flags == [1, 1, 1]
+        assert flags == [1, 1, 1, 1]
+        # chol_upper_from: out of place, H + diag(shift), H untouched (flag 4)
+        ref_s = np.linalg.solve(H + np.diag(0.25 * np.diag(H) + 1e-3), g)
+        assert np.abs(xs - ref_s).max() < 1e-11 * np.abs(ref_s).max() * n
+        # sym_quad: x^T H x and H x, dispatched and portable
+        Hg = H @ g
+        np.testing.assert_allclose(quad[:2], g @ Hg, rtol=1e-12)
+        np.testing.assert_allclose(quad[2::2], Hg, atol=1e-12 * np.abs(Hg).max())
+        np.testing.assert_allclose(quad[3::2], Hg, atol=1e-12 * np.abs(Hg).max())
         ref = np.linalg.solve(H, g)
         scale = np.abs(ref).max()
         assert np.abs(x - ref).max() < 1e-11 * scale * n          # dispatched path (AVX-512 where the host has it)
@@ -62,7 +70,7 @@ def test_rank_deficient_and_indefinite_inputs(checker):
     semi = B @ B.T                                                 # rank 5: the gauge-deficient prior the marginalization sees
     indef = np.diag([1.0, -2.0, 3.0])
     res = _run(checker, [(semi, np.ones(12)), (indef, np.ones(3))])
-    (f1, _, _, w1, V1), (f2, _, _, w2, _) = res
+    (f1, _, _, w1, V1, _, _), (f2, _, _, w2, _, _, _) = res
     assert f1[2] == 1 and np.sum(np.abs(w1) < 1e-9 * abs(w1).max()) == 7       # 7 (near-)zero eigenvalues, thresholded at 1e-8 by the caller
     np.testing.assert_allclose(V1 @ np.diag(w1) @ V1.T, semi, atol=1e-10 * abs(semi).max())
     assert f2[0] == 0 and f2[1] == 0                                            # not positive definite: the dogleg raises mu

@@ -238,6 +238,7 @@ class Estimator {
   void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
   void LidarLaunch(const WindowParams &P);             // asynchronous part: frame transforms + moments kernels
   void LidarWait(std::vector<FrameMoments> &m);        // stream sync (+ all-reduce when sharded) + unpack
+  bool LidarWaitFrame(int i, FrameMoments &fm);       // per-frame form (resident kernel only; false otherwise)
   void PushCloud(DeviceCloud &&c, size_t n, int n_before);
   void PushState(int from);
 
@@ -299,6 +300,10 @@ class Estimator {
   bool ResidentBegin(const MomentArgs &ma);
   void ResidentRing(const MomentArgs &ma);
   void ResidentWait(std::vector<FrameMoments> &m);
+  void ResidentWaitFrame(int f, FrameMoments &fm);   // frame f (0-based) of the pass in flight, as soon as its word is in
+  void ResidentAwaitWord(int f);
+  void ResidentUnpackFrame(int f, FrameMoments &fm);
+  void ResidentPassDone();
   void ResidentLaunchKernel(unsigned first_seq);
  public:
   void ResidentEnd();

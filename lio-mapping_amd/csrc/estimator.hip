@@ -769,51 +769,67 @@ void Estimator::ResidentRing(const MomentArgs &ma) {
   }
 }
 
-void Estimator::ResidentWait(std::vector<FrameMoments> &m) {
+// Waits for frame f's completion word of the pass in flight.  A relay timeout (this host thread was held up for > 200 ms before
+// it rang) can only show while NO frame of the pass has been posted: the relay gives up between passes, and a pass that was
+// started is posted whole.
+void Estimator::ResidentAwaitWord(int f) {
   const unsigned seq = res_seq_;
-  const int nf = res_nframes_;
   const volatile unsigned *w = h_res_words_;
-  int k = 0;
   for (unsigned long it = 1;; ++it) {
-    while (k < nf && __atomic_load_n(w + k, __ATOMIC_ACQUIRE) == seq) ++k;
-    if (k == nf) break;
+    if (__atomic_load_n(w + f, __ATOMIC_ACQUIRE) == seq) return;
     if (__atomic_load_n(w + LIO_MAX_FRAMES, __ATOMIC_ACQUIRE) == LIO_RES_EXPIRED) {
-      // the relay gave up waiting (this host thread was held up for > 200 ms): let that launch drain — a timeout ends it between
-      // passes, so no ticket is half drawn — and start a new one for the pass that is pending; its doorbell is still rung
+      if (__atomic_load_n(w + f, __ATOMIC_ACQUIRE) == seq) return;
+      if (f > 0 && __atomic_load_n(w + 0, __ATOMIC_ACQUIRE) == seq) throw DeviceError("resident moments kernel gave up in the middle of a pass");
+      // let that launch drain and start a new one for the pass that is pending; its doorbell is still rung
       LIO_HIP(hipStreamSynchronize(stream_));
       h_res_words_[LIO_MAX_FRAMES] = 0;
       ResidentLaunchKernel(seq);
-      k = 0;
       continue;
     }
     __builtin_ia32_pause();
     if ((it & 0xFFFFu) == 0) {
       const hipError_t e = hipStreamQuery(stream_);
       if (e != hipErrorNotReady && e != hipSuccess) throw DeviceError(std::string("resident moments pass failed: ") + hipGetErrorString(e));
-      if (e == hipSuccess && h_res_words_[LIO_MAX_FRAMES] != LIO_RES_EXPIRED) {   // the kernel is gone although nobody stopped it
-        bool all = true;
-        for (int f = 0; f < nf; ++f) all = all && h_res_words_[f] == seq;
-        if (!all) throw DeviceError("resident moments kernel ended without posting its pass");
-      }
+      if (e == hipSuccess && h_res_words_[LIO_MAX_FRAMES] != LIO_RES_EXPIRED && __atomic_load_n(w + f, __ATOMIC_ACQUIRE) != seq)
+        throw DeviceError("resident moments kernel ended without posting its pass");   // the kernel is gone although nobody stopped it
     }
   }
-  double busy = 0, fold = 0, polls = 0;
+}
+
+void Estimator::ResidentUnpackFrame(int f, FrameMoments &fm) {
+  const double *rec = h_res_out_ + size_t(f) * LIO_RES_OUT;
+  std::memcpy(fm.S, rec, 256 * sizeof(double));
+  fm.cost = rec[256]; fm.count = rec[257];
+  double *o = h_moment_out_ + size_t(f) * LIO_MOMENT_OUT;   // the landing zone of the launch path doubles as "the last moments"
+  o[256] = fm.cost; o[257] = fm.count;
+}
+
+// bookkeeping of a finished pass (all frames in): device-side phase stamps, busy time, algorithmic bytes
+void Estimator::ResidentPassDone() {
+  const int nf = res_nframes_;
+  double busy = 0, polls = 0;
   for (int f = 0; f < nf; ++f) {
-    FrameMoments &fm = m[f + 1];
     const double *rec = h_res_out_ + size_t(f) * LIO_RES_OUT;
-    std::memcpy(fm.S, rec, 256 * sizeof(double));
-    fm.cost = rec[256]; fm.count = rec[257];
-    double *o = h_moment_out_ + size_t(f) * LIO_MOMENT_OUT;   // the landing zone of the launch path doubles as "the last moments"
-    o[256] = fm.cost; o[257] = fm.count;
     for (int q = 0; q < 4; ++q) res_diag_us_[q] += rec[258 + q] * res_tick_us_ / nf;
     polls += rec[262] / nf;
     res_relay_us_ += rec[263] * res_tick_us_ / nf;
     busy = std::max(busy, rec[261]);
   }
-  (void)fold;
   res_busy_us_ += busy * res_tick_us_;   // doorbell copy seen -> sums posted, slowest frame
   { double nres = 0; for (int f = 0; f < nf; ++f) nres += res_args_.fr[f].nslots; res_bytes_ += 60.0 * nres; }   // 60 B per lidar residual
   res_polls_ += polls; ++res_passes_; ++res_passes_total_;
+}
+
+void Estimator::ResidentWaitFrame(int f, FrameMoments &fm) {
+  ResidentAwaitWord(f);
+  ResidentUnpackFrame(f, fm);
+  if (f == res_nframes_ - 1) ResidentPassDone();
+}
+
+void Estimator::ResidentWait(std::vector<FrameMoments> &m) {
+  for (int f = 0; f < res_nframes_; ++f) ResidentAwaitWord(f);
+  for (int f = 0; f < res_nframes_; ++f) ResidentUnpackFrame(f, m[f + 1]);
+  ResidentPassDone();
 }
 
 void Estimator::ResidentEnd() {
@@ -987,6 +1003,17 @@ bool Estimator::BenchBatchedMoments(int B, int reps, double *avg_ms, double *byt
   return true;
 }
 
+// Frame i (1-based) of the pass in flight, as soon as its completion word is in — only the resident kernel posts per frame.
+bool Estimator::LidarWaitFrame(int i, FrameMoments &fm) {
+  if (!res_active_) return false;
+  const double t_dbg0 = now_ms();
+  ResidentWaitFrame(i - 1, fm);
+  const double t1 = now_ms();
+  dbg_eval_ms_ += t1 - t_dbg0; dbg_sync_ms_ += t1 - t_dbg0;
+  if (i == res_nframes_) { ++dbg_eval_n_; res_ring_to_done_ms_ += t1 - res_t_ring_; }
+  return true;
+}
+
 void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   const double t_dbg0 = now_ms();
   struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; e->dbg_eval_n_++; } } dbg_acc{this, t_dbg0};
@@ -1042,6 +1069,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   sys.lidar_eval = [this](const WindowParams &Pq, std::vector<FrameMoments> &m) { LidarEval(Pq, m); };
   sys.lidar_launch = [this](const WindowParams &Pq) { LidarLaunch(Pq); };
   sys.lidar_wait = [this](std::vector<FrameMoments> &m) { LidarWait(m); };
+  sys.lidar_wait_frame = [this](int i, FrameMoments &fm) { return LidarWaitFrame(i, fm); };
   R.ms_prepare = now_ms() - t_prep0;
   // Group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984).
   // The reference evaluates the three groups, then Ceres linearises again at the same point; here ONE device

@@ -195,6 +195,10 @@ class WindowSystem {
   // split form: launch the device pass first, overlap the host-side prior / IMU factors with it, then collect
   std::function<void(const WindowParams &)> lidar_launch;
   std::function<void(std::vector<FrameMoments> &)> lidar_wait;
+  // optional: frame i's moments as soon as THEY are in (the resident kernel posts a completion word per frame), so that the
+  // frame blocks of the early frames are expanded while the late ones are still on their way; false = not available for this
+  // pass, take lidar_wait
+  std::function<bool(int, FrameMoments &)> lidar_wait_frame;
   // moments already known for the parameters of the NEXT evaluate call (consumed by it): the marginalization linearises
   // at the point the solver stopped at, whose lidar moments its last accepted step computed — they depend only on the relative
   // poses T_{pivot<-i} and the extrinsic, which the yaw re-anchoring of DoubleToVector leaves unchanged
@@ -375,9 +379,15 @@ class WindowSystem {
     if (lidar_on && (preset || split || lidar_eval)) {
       std::vector<FrameMoments> &m = m_out ? *m_out : moments_scratch_;   // the device pass lands in the caller's vector: no copy
       m.resize(Wo + 1);
-      if (preset) m = *preset; else if (split) lidar_wait(m); else lidar_eval(P, m);
+      bool per_frame = split && !preset && lidar_wait_frame && lidar_wait_frame(1, m[1]);
+      if (preset) m = *preset; else if (per_frame) {} else if (split) lidar_wait(m); else lidar_eval(P, m);
       { const double t = clk_now(); eclk.wait += t - tk0; tk0 = t; }
       for (int i = 1; i <= Wo; ++i) {
+        if (per_frame && i > 1) {
+          const double tw = clk_now();
+          if (!lidar_wait_frame(i, m[i])) throw std::runtime_error("lidar_wait_frame gave up in the middle of a pass");
+          const double t = clk_now(); eclk.wait += t - tw; tk0 += t - tw;   // (keeps the wait out of the assemble clock)
+        }
         c.ppp += m[i].cost;
         if (!H || m[i].count == 0) continue;
         const double *L = &lmaps_[size_t(i) * LMAP_STRIDE], *Lt = L + 18 * 13;

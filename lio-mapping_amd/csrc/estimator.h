@@ -266,7 +266,8 @@ class Estimator {
   // the blocks' completion words.  Begun lazily by the first LidarLaunch of a SolveOptimization, stopped when it returns.
   bool resident_moments_ = true;    // configured (lio_est_config.resident_moments / LIO_RESIDENT_MOMENTS)
   bool resident_never_ = false;     // resident_moments = 3: the resident form's partition, launch pairs only (what a refused solve gets)
-  int res_per_lane_ = 4;            // residuals a lane keeps in registers (LIO_RES_PER_LANE: 1, 2, 4, 8)
+  int res_per_lane_ = 0;            // residuals a lane keeps in registers: 0 = chosen per window (ResidentBpf), LIO_RES_PER_LANE forces 1, 2, 4, 8
+  int res_lanes_ = 4;               // ... of the launch in flight
   bool res_allowed_ = false;        // inside SolveOptimization
   bool res_active_ = false;         // a resident kernel is waiting on the doorbell
   int res_bpf_ = 0, res_nframes_ = 0;
@@ -296,7 +297,7 @@ class Estimator {
   int ResidentLaunchStats(double *total_ms);
  private:
   double res_diag_us_[4] = {0, 0, 0, 0}, res_polls_ = 0, res_relay_us_ = 0, res_ring_to_done_ms_ = 0, res_t_ring_ = 0;
-  int ResidentBpf(int max_slots, int nframes) const;
+  int ResidentBpf(int max_slots, int nframes, int *per_lane = nullptr) const;
   bool ResidentBegin(const MomentArgs &ma);
   void ResidentRing(const MomentArgs &ma);
   void ResidentWait(std::vector<FrameMoments> &m);

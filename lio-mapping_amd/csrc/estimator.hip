@@ -699,22 +699,33 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
   }
   ma.blocks_per_frame = moment_blocks_per_frame(max_slots);
   ma.form = moments_form_;
-  // With the resident form configured, BOTH paths use its partition (blocks per frame so that a lane holds <= res_per_lane_
+  // With the resident form configured, BOTH paths use its partition (blocks per frame so that a lane holds <= per_lane
   // 64-slot chunks per wave, fp64-MFMA form): the launch path — taken when a pass cannot use the resident kernel (kernel timing, factor
   // sharding, stream_sync) — then yields bit-identical moments.
   const int rb = ResidentBpf(max_slots, ma.nframes);
   if (rb > 0) { ma.blocks_per_frame = rb; ma.form = 1; }
 }
 
-int Estimator::ResidentBpf(int max_slots, int nframes) const {
+// Blocks per frame of the resident form's partition (0: the window does not fit) and, in *per_lane, the residuals a lane keeps.
+// Fewer residuals per lane = more blocks = a shorter accumulate phase (1.7 us of MFMA per wave at four, 0.85 at two); the frame
+// fold costs one memory round trip as long as a frame's blocks fit one batch of loads (RES_FOLD_BATCH = 64).  So: the smallest
+// per-lane count whose blocks are all co-resident (<= 256) with at most 64 per frame.  A pure function of the window's slot
+// counts, so the partition — and with it every bit of the result — does not depend on how a pass is executed.
+int Estimator::ResidentBpf(int max_slots, int nframes, int *per_lane) const {
+  if (per_lane) *per_lane = 0;
   if (!resident_moments_ || fold_in_kernel_ || moments_form_ == 2) return 0;
-  return resident_blocks_per_frame(max_slots, nframes, res_per_lane_);
+  for (int r : {1, 2, 4, 8}) {
+    if (res_per_lane_ > 0 && r != res_per_lane_) continue;
+    const int b = resident_blocks_per_frame(max_slots, nframes, r);
+    if (b > 0 && (b <= 64 || r == 8 || res_per_lane_ > 0)) { if (per_lane) *per_lane = r; return b; }
+  }
+  return 0;
 }
 
 void Estimator::ResidentLaunchKernel(unsigned first_seq) {
   ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p};
   res_launch_seq_ = first_seq;   // (the HBM copy of the doorbell needs no clearing: sequence numbers only grow and STOP is per launch)
-  launch_lidar_moments_resident(res_args_, ra, res_per_lane_, f_valid_.p, f_coef_.p, stream_);
+  launch_lidar_moments_resident(res_args_, ra, res_lanes_, f_valid_.p, f_coef_.p, stream_);
 }
 
 // The resident kernel of this solve: launched behind everything the feature stage enqueued on stream_; it returns when the host
@@ -723,10 +734,11 @@ bool Estimator::ResidentBegin(const MomentArgs &ma) {
   if (!res_allowed_ || resident_never_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_ || device_solve_) return false;
   int max_slots = 0;
   for (int k = 0; k < ma.nframes; ++k) max_slots = std::max(max_slots, ma.fr[k].nslots);
-  if (ResidentBpf(max_slots, ma.nframes) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
+  int per_lane = 0;
+  if (ResidentBpf(max_slots, ma.nframes, &per_lane) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
   if (g_active_solves.load(std::memory_order_relaxed) > 1) return false;
   if (g_resident_moments.fetch_add(1) >= kMaxResidentMoments) { g_resident_moments.fetch_sub(1); return false; }
-  res_args_ = ma;
+  res_args_ = ma; res_lanes_ = per_lane;
   res_bpf_ = ma.blocks_per_frame; res_nframes_ = ma.nframes;
   for (int f = 0; f < res_nframes_; ++f) {   // idle doorbell: neither the expected sequence number nor STOP
     __atomic_store_n(reinterpret_cast<unsigned long long *>(h_res_door_ + f * LIO_RES_DOOR + 7), 0ull, __ATOMIC_RELEASE);

@@ -352,8 +352,46 @@ __device__ __forceinline__ double door_poll(const double *door, int lane, double
 // The relay block: the only poller of host memory.  It waits until EVERY frame's two lines carry the expected sequence number (a
 // line is read whole, and the host stores a line's payload before its sequence slot), republishes what that poll read in HBM —
 // payload first, acknowledged, then the sequence slots — and goes back to polling.  STOP and the timeout travel the same way.
-#define RES_COST_AT (13 * 16 + 13)   // padding entries of the 16x16 tile that carry cost / count through the frame fold
-#define RES_CNT_AT (13 * 16 + 14)
+// A block parks a COMPACT record: the 91 entries of the 13 x 13 upper triangle (row-major), then cost and count — 93 doubles in
+// 12 cache lines instead of the padded 16 x 16 tile's 33: the frame fold is bound by the number of lines its agent-scope loads
+// keep in flight (measured: ~50 ns per 256-double block record), and the tile is symmetric bit for bit (A = B in the MFMA,
+// the same order of additions for every entry), so the lower triangle is the upper one mirrored.
+#define RES_NTRI 91
+#define RES_NREC 93   // + cost, count
+__device__ __forceinline__ int res_tri_index(int a, int b) { return a * 13 - a * (a - 1) / 2 + (b - a); }   // a <= b < 13
+// One batch of the frame fold for one lane: NG groups of four blocks starting at block b0, of which this lane takes the two
+// blocks 4 g + 2 h and 4 g + 2 h + 1 of every group (h = 0: chains 0 and 1 of k_moment_reduce's order, h = 1: chains 2 and 3) —
+// two lanes per value, so a lane has HALF the loads in flight: the fold's time is proportional to the loads per lane (measured:
+// ~50 ns per load instruction whatever their kind), not to the bytes.  The loads are unconditional (a block past the end re-reads
+// the last one and is masked out of the sum with +0.0, which leaves a chain unchanged bit for bit: the chains start at +0.0 and can
+// never be -0.0).  The blocks beyond the last multiple of four continue chain 0, in block order, after its last full group.
+#ifndef RES_FOLD_PLAIN
+#define RES_FOLD_PLAIN 0   // 1: one agent-scope acquire fence after the flags, then ordinary loads (measured: no faster); 0: agent-scope loads
+#endif
+__device__ __forceinline__ double resident_fold_load(const double *p) {
+  return RES_FOLD_PLAIN ? __builtin_nontemporal_load(p) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NG>
+__device__ __forceinline__ void resident_fold_batch(const double *src, int h, int b0, int nblk, int b4, double &va, double &vb) {
+  double xa[NG], xb[NG], xr[3];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int b = b0 + 4 * g + 2 * h;
+    xa[g] = resident_fold_load(src + size_t(min(b, nblk - 1)) * LIO_MOMENT_OUT);
+    xb[g] = resident_fold_load(src + size_t(min(b + 1, nblk - 1)) * LIO_MOMENT_OUT);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) xr[r] = resident_fold_load(src + size_t(min(b4 + r, nblk - 1)) * LIO_MOMENT_OUT);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const bool full = b0 + 4 * g + 4 <= b4;
+    va += full ? xa[g] : 0.0; vb += full ? xb[g] : 0.0;
+  }
+  if (b0 + 4 * NG >= b4) {   // the last batch: chain 0 takes the remainder
+#pragma unroll
+    for (int r = 0; r < 3; ++r) va += (h == 0 && b4 + r < nblk) ? xr[r] : 0.0;
+  }
+}
 #define RES_RELAY_SLOTS 8   // doubles per lane: LIO_MAX_FRAMES * LIO_RES_DOOR / 64
 __device__ __forceinline__ void resident_relay(const MomentArgs &a, const ResidentArgs &ra) {
   const int lane = threadIdx.x & 63;
@@ -472,6 +510,9 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
   double *zb = zbuf[wv];
   const double *door = ra.relay + size_t(f) * LIO_RES_DOOR;
   double *mine = ra.block_part + size_t(blockIdx.x) * LIO_MOMENT_OUT;
+  int rec_src = 0;   // where this lane's entry of the compact record sits in the block's 16 x 16 (+ cost, count) LDS record
+  if (tid < RES_NTRI) { int a = 0, c = tid; while (c >= 13 - a) { c -= 13 - a; ++a; } rec_src = a * 16 + a + c; }
+  else if (tid < RES_NREC) rec_src = 256 + (tid - RES_NTRI);
   const double *frame_part = ra.block_part + size_t(f) * nblk * LIO_MOMENT_OUT;
   unsigned seq = ra.first_seq;
   for (;; ++seq) {
@@ -537,12 +578,10 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
     // ---- park the block's record in HBM (agent-scope stores: written through, visible to every XCD); once every wave's stores
     // are acknowledged, the pass number goes into slot 259: the flag the frame's folding block waits for.  No atomics: a ticket
     // drawn by twenty blocks at once serialises on one address.
-    // (the tile is 13 x 13 in a 16 x 16 frame: entries RES_COST_AT / RES_CNT_AT of the padding carry cost / count, so that the
-    // 256 threads move the whole record in one round — a second round costs the folding block two more memory round trips)
-    {
-      const int ksrc = tid == RES_COST_AT ? 256 : (tid == RES_CNT_AT ? 257 : tid);
+    // (the record is compact — RES_NREC doubles: upper triangle, cost, count — so that two waves move it in one round)
+    if (tid < RES_NREC) {
       double v = 0;
-      for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][ksrc];
+      for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][rec_src];
       __hip_atomic_store(mine + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -573,29 +612,28 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
     if (!go) return;
     const long long t_ready = wall_clock64();
     const int b4 = nblk & ~3;
+    // the records were written through to memory by blocks on other XCDs (agent-scope stores) and their flags have been seen:
+    // one acquire fence drops whatever this XCD still caches of them from the previous pass, then the loads are ordinary ones
+    if (RES_FOLD_PLAIN) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
-      const int k = tid;
-      const double *src = frame_part + k;
-      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-      for (int b0 = 0; b0 < nblk; b0 += 32) {   // up to thirty-two loads in flight per lane, then the sums in block order
-        double x[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u)
-          x[u] = (b0 + u < nblk) ? __hip_atomic_load(src + size_t(b0 + u) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 32; u += 4) {
-          if (b0 + u < b4) { v0 += x[u]; v1 += x[u + 1]; v2 += x[u + 2]; v3 += x[u + 3]; }
-          else {   // the remainder beyond the last multiple of four: chain 0, in block order
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (b0 + u + r < nblk) v0 += x[u + r];
-          }
-        }
+      const int h = tid >> 7, c = tid & 127;   // waves 0, 1: chains 0 and 1; waves 2, 3: chains 2 and 3
+      double va = 0.0, vb = 0.0;
+      if (c < RES_NREC) {
+        const double *src = frame_part + c;
+        if (nblk <= 32) resident_fold_batch<8>(src, h, 0, nblk, b4, va, vb);
+        else for (int b0 = 0; b0 < nblk; b0 += 64) resident_fold_batch<16>(src, h, b0, nblk, b4, va, vb);
+        if (h == 1) { sm[1][c] = va; sm[2][c] = vb; }
       }
-      const double sum = (v0 + v1) + (v2 + v3);
+      __syncthreads();
+      if (h == 0 && c < RES_NREC) sm[0][c] = (va + vb) + (sm[1][c] + sm[2][c]);
+    }
+    __syncthreads();
+    {
+      // the host's record is the padded 16 x 16 tile + cost + count, as from k_moment_reduce: lane (i, j) posts entry (min, max)
       double *o = ra.out + size_t(f) * LIO_RES_OUT;
-      if (k == RES_COST_AT) { host_store(o + 256, sum); host_store(o + k, 0.0); }
-      else if (k == RES_CNT_AT) { host_store(o + 257, sum); host_store(o + k, 0.0); }
-      else host_store(o + k, sum);
+      const int i = tid >> 4, jj = tid & 15;
+      host_store(o + tid, (i < 13 && jj < 13) ? sm[0][res_tri_index(min(i, jj), max(i, jj))] : 0.0);
+      if (tid < 2) host_store(o + 256 + tid, sm[0][RES_NTRI + tid]);
     }
     // diagnostics (wall-clock ticks from the doorbell copy seen): accumulated, parked, every flag in, sums formed; polls
     if (tid == 0) {

@@ -41,9 +41,10 @@ int moment_blocks_per_frame(int max_slots);
 
 // ---- resident form: ONE launch per solve.  The worker blocks keep their residuals in registers and wait for
 // every linearisation point (Wo relative poses + a sequence number) on a doorbell; each pass a wave pushes its cached residuals
-// through the fp64 MFMA tile, the block parks its 16x16 sums (+ cost, count) in HBM behind a per-block flag; block 0 of each frame
-// waits for its frame's flags, folds the blocks in k_moment_reduce's order and posts the frame's moments + a completion word to
-// coherent host memory.  One extra block — the
+// through the fp64 MFMA tile, the block parks a compact record (the 13 x 13 upper triangle, cost, count: 93 doubles) in HBM behind
+// a per-block flag; block 0 of each frame waits for its frame's flags, folds the blocks in k_moment_reduce's order (two lanes per
+// value) and posts the frame's moments (the triangle mirrored into the padded 16 x 16 tile) + a completion word to coherent host
+// memory.  One extra block — the
 // relay — is the only poller of host memory: measured on the MI355X box (tools/micro/pingpong.hip) a host -> kernel -> host
 // round trip is 2.3 us with one polling block and 13-19 us with a hundred, so the relay republishes the doorbell in HBM and the
 // workers poll that copy.  Arithmetic per block = k_lidar_moments (MFMA form) at the same blocks per frame and the fold =

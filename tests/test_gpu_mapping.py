@@ -189,3 +189,28 @@ def test_map_builder_matches_oracle(hip, oracle, enable_4d):
     _, vo = mo.cube_state()
     assert _compare_cubes(mh, mo, vo, atol=5e-4, strict=False) > 5000
     assert len(mh.score_point_coeff()[0]) == len(mo.score_point_coeff()[0])
+
+
+def test_mapping_with_stack_points_beyond_the_fast_voxel_key_range(hip, oracle):
+    """A surf and a corner point > 409 m from the sensor (0.2 / 0.4 m leaves: the absolute-cell voxel keys hold +-204 / +-409 m)
+    make the stack VoxelGrids re-run with PCL's own index — the surf one on the handle's second stream, whose consumers on the
+    main stream must be ordered behind the RE-RUN, not behind the pass that raised the overflow (a stale or half-written
+    down-sampled stack would change the stack itself and the pose).  Same sequence as the plain test, same bounds."""
+    frames = drifting_inputs(oracle, "indoor", 4)
+    mh, mo = capi.PointMapping(hip), capi.PointMapping(oracle)
+    for k, (corner, surf, T_sum, _) in enumerate(frames):
+        far = np.array([[450.0 + k, -3.0, 1.5, 0.0], [-470.0, 12.0 + k, 2.0, 0.0]], np.float32)
+        surf = np.vstack([surf, far]).astype(np.float32)
+        corner = np.vstack([corner, far[:1] + np.float32([0, 5, 0, 0])]).astype(np.float32)
+        rh, ro = mh.process(corner, surf, T_sum), mo.process(corner, surf, T_sum)
+        for which in (capi.PointMapping.CORNER_STACK_DS, capi.PointMapping.SURF_STACK_DS):
+            a, b = mh.cloud(which), mo.cloud(which)
+            assert np.abs(b[:, :3]).max() > 400          # the far points survive the filter on the oracle's side ...
+            if k == 0:
+                assert a.shape == b.shape
+                np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)   # (ulp of a 450 m coordinate: 3e-5)
+            else:
+                assert _cloud_mismatch(a, b, 1e-4) <= max(4, len(b) // 200), (k, which, a.shape, b.shape)
+        assert rh["iterations"] == ro["iterations"], (k, rh, ro)
+        _assert_pose_close(rh["T_aft"], ro["T_aft"])
+        _assert_pose_close(mh.transform_tobe_mapped(), mo.transform_tobe_mapped())

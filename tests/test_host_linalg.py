@@ -89,3 +89,36 @@ def test_lidar_linear_maps_reproduce_the_factor(tmp_path):
                    check=True)
     jac_err, res_err = (float(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
     assert jac_err < 1e-11 and res_err < 1e-11
+
+
+def test_degeneracy_count_against_numpy(tmp_path):
+    """kz = the number of eigenvalues of the 6x6 AtA below the threshold (100 in the estimator / scan-to-map /
+    MapBuilder loops, 10 scan-to-scan).  The reference takes them from Eigen's SelfAdjointEigenSolver<float>; the product counts
+    the negative pivots of LDL^T(AtA - tau I) in double (hmath.h: count_eigs_below<6>, device and host code).  Here: matrices
+    with prescribed spectra on both sides of the thresholds, rotated by random orthogonal bases, in float32 as the kernels hold
+    them — the count must equal numpy's on the SAME float32 matrix whenever no eigenvalue sits within fp32 rounding of tau."""
+    exe = str(tmp_path / "degeneracy_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "lio-mapping_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "degeneracy_check.cc"), "-o", exe], check=True)
+    rng = np.random.default_rng(7)
+    cases = []
+    spectra = [[40.0, 75.0, 3e3, 8e3, 5e4, 2e5], [99.0, 101.0, 500.0, 4e3, 9e4, 2e5], [125.0, 130.0, 2e3, 8e3, 5e4, 2e5],
+               [1e-3, 2.0, 9.5, 10.5, 300.0, 2e4], [0.0, 0.0, 0.0, 150.0, 2e3, 1e5], [5.0, 50.0, 90.0, 99.9, 100.1, 1e5]]
+    for lam in spectra:
+        for tau in (10.0, 100.0):
+            for _ in range(8):
+                Q, _r = np.linalg.qr(rng.normal(size=(6, 6)))
+                A = (Q @ np.diag(lam) @ Q.T).astype(np.float32)
+                A = ((A + A.T) * np.float32(0.5)).astype(np.float32)
+                cases.append((A, tau))
+    text = "\n".join(" ".join(repr(float(v)) for v in A.ravel()) + f" {tau!r}" for A, tau in cases) + "\n"
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == len(cases)
+    checked = 0
+    for (A, tau), got in zip(cases, out):
+        w = np.linalg.eigvalsh(A.astype(np.float64))
+        if np.min(np.abs(w - tau)) < 1e-6 * np.abs(w).max():      # 0.2 at max|w| = 2e5: nothing of the float32 matrix's own rounding is left to decide
+            continue
+        assert int(got) == int(np.sum(w < tau)), (w, tau, got)
+        checked += 1
+    assert checked >= 88

@@ -296,7 +296,7 @@ class Estimator {
   void ResidentLaunchTiming(bool on) { res_time_launch_ = on; }
   int ResidentLaunchStats(double *total_ms);
  private:
-  double res_diag_us_[4] = {0, 0, 0, 0}, res_polls_ = 0, res_relay_us_ = 0, res_ring_to_done_ms_ = 0, res_t_ring_ = 0;
+  double res_diag_us_[4] = {0, 0, 0, 0}, res_polls_ = 0, res_relay_us_ = 0, res_ring_to_done_ms_ = 0, res_t_ring_ = 0, res_echo_ms_ = 0;
   int ResidentBpf(int max_slots, int nframes, int *per_lane = nullptr) const;
   bool ResidentBegin(const MomentArgs &ma);
   void ResidentRing(const MomentArgs &ma);

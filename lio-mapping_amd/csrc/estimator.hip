@@ -113,9 +113,9 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   if (const char *e = std::getenv("LIO_RES_PER_LANE")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) res_per_lane_ = v; }
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_door_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, hipHostMallocCoherent));
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_OUT, hipHostMallocCoherent));
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_words_), sizeof(unsigned) * (LIO_MAX_FRAMES + 1), hipHostMallocCoherent));   // + the relay block's word
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_words_), sizeof(unsigned) * (LIO_MAX_FRAMES + 2), hipHostMallocCoherent));   // + the relay block's word + its echo
   std::memset(h_res_door_, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR);
-  std::memset(h_res_words_, 0, sizeof(unsigned) * (LIO_MAX_FRAMES + 1));
+  std::memset(h_res_words_, 0, sizeof(unsigned) * (LIO_MAX_FRAMES + 2));
   {
     int khz = 0, dev = 0;
     LIO_HIP(hipGetDevice(&dev));
@@ -723,7 +723,7 @@ int Estimator::ResidentBpf(int max_slots, int nframes, int *per_lane) const {
 }
 
 void Estimator::ResidentLaunchKernel(unsigned first_seq) {
-  ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p};
+  ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p, g_debug_timing ? 1 : 0};
   res_launch_seq_ = first_seq;   // (the HBM copy of the doorbell needs no clearing: sequence numbers only grow and STOP is per launch)
   launch_lidar_moments_resident(res_args_, ra, res_lanes_, f_valid_.p, f_coef_.p, stream_);
 }
@@ -809,9 +809,11 @@ void Estimator::ResidentAwaitWord(int f) {
 }
 
 void Estimator::ResidentUnpackFrame(int f, FrameMoments &fm) {
+  // the device posts the upper triangle of the 13 x 13 tile (it is symmetric bit for bit); S is the padded 16 x 16 tile
+  static const struct TriMap { int at[256]; TriMap() { for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { const int a = std::min(i, j), b = std::max(i, j); at[i * 16 + j] = (b < 13) ? a * 13 - a * (a - 1) / 2 + (b - a) : -1; } } } tri;
   const double *rec = h_res_out_ + size_t(f) * LIO_RES_OUT;
-  std::memcpy(fm.S, rec, 256 * sizeof(double));
-  fm.cost = rec[256]; fm.count = rec[257];
+  for (int k = 0; k < 256; ++k) fm.S[k] = tri.at[k] >= 0 ? rec[tri.at[k]] : 0.0;
+  fm.cost = rec[LIO_RES_NTRI]; fm.count = rec[LIO_RES_NTRI + 1];
   double *o = h_moment_out_ + size_t(f) * LIO_MOMENT_OUT;   // the landing zone of the launch path doubles as "the last moments"
   o[256] = fm.cost; o[257] = fm.count;
 }
@@ -938,7 +940,16 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   int max_slots = 0;
   FillMomentArgs(ma, max_slots);
   for (int i = 1; i <= Wo_; ++i) relative_lidar_pose(P.pose[0].data(), P.pose[i].data(), P.ex.data(), ma.fr[i - 1].R, ma.fr[i - 1].t);
-  if (res_active_ || ResidentBegin(ma)) { res_t_ring_ = now_ms(); ResidentRing(ma); return; }
+  if (res_active_ || ResidentBegin(ma)) {
+    res_t_ring_ = now_ms();
+    ResidentRing(ma);
+    if (g_debug_timing) {   // ring -> the relay's echo of the sequence number: the inbound PCIe leg + one word back
+      const volatile unsigned *echo = h_res_words_ + LIO_MAX_FRAMES + 1;
+      for (unsigned long it = 0; it < 2000000ul && __atomic_load_n(echo, __ATOMIC_ACQUIRE) != res_seq_; ++it) __builtin_ia32_pause();
+      res_echo_ms_ += now_ms() - res_t_ring_;
+    }
+    return;
+  }
   d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
   d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
   double nres = 0;
@@ -1191,6 +1202,9 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     std::fprintf(stderr, "[lio_hip timing] resident moments: %d passes; folding block, from the doorbell copy seen (us): accumulated %.2f, parked %.2f, all flags in %.2f, sums posted %.2f; relay detect -> copy seen %.2f; host ring -> moments unpacked %.2f; HBM polls %.1f; %d worker blocks\n",
                  res_passes_, res_diag_us_[0] / res_passes_, res_diag_us_[1] / res_passes_, res_diag_us_[2] / res_passes_, res_diag_us_[3] / res_passes_,
                  res_relay_us_ / res_passes_, 1e3 * res_ring_to_done_ms_ / res_passes_, res_polls_ / res_passes_, res_bpf_ * res_nframes_);
+    std::fprintf(stderr, "[lio_hip timing] resident moments: host ring -> relay's echo seen %.2f us (the host waits for it only under LIO_DEBUG_TIMING)\n",
+                 1e3 * res_echo_ms_ / res_passes_);
+    res_echo_ms_ = 0;
     res_diag_us_[0] = res_diag_us_[1] = res_diag_us_[2] = res_diag_us_[3] = res_polls_ = res_relay_us_ = res_ring_to_done_ms_ = 0; res_passes_ = 0;
   }
   if (g_debug_timing) std::fprintf(stderr, "[lio_hip timing] of which hipStreamSynchronize %.3f ms\n", dbg_sync_ms_);

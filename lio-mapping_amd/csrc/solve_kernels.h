@@ -49,7 +49,9 @@ int moment_blocks_per_frame(int max_slots);
 // round trip is 2.3 us with one polling block and 13-19 us with a hundred, so the relay republishes the doorbell in HBM and the
 // workers poll that copy.  Arithmetic per block = k_lidar_moments (MFMA form) at the same blocks per frame and the fold =
 // k_moment_reduce's, so the moments are bit-identical to the two-launch path in that configuration.
-#define LIO_RES_OUT 264            // doubles per frame in the host landing zone: 256 S entries + cost + count + 5 diagnostics + pad
+#define LIO_RES_OUT 264            // doubles per frame in the host landing zone: [0, 91) the 13 x 13 upper triangle of S (row-major), 91 cost,
+                                   // 92 count, [258, 264) diagnostics
+#define LIO_RES_NTRI 91
 #define LIO_RES_DOOR 16            // doubles per frame in the doorbell: [R0..R6, seq | R7, R8, t0, t1, t2, 0, 0, seq] (two cache lines)
 #define LIO_RES_EXPIRED 0xFFFFFFFFu
 // the doorbell value that ends a launch: minus the sequence number of its first pass — unique per launch, so whatever an earlier
@@ -58,12 +60,14 @@ int moment_blocks_per_frame(int max_slots);
 #define LIO_RES_MAX_BLOCKS 256     // one per CU: every block must be co-resident with nothing but the host to wait for
 struct ResidentArgs {
   const double *door;        // host, coherent
-  double *out;               // host, coherent: frame f's folded moments at f * LIO_RES_OUT (layout of LIO_MOMENT_OUT, then diagnostics)
-  unsigned *words;           // host, coherent: one completion word per frame, [LIO_MAX_FRAMES] = the relay's (LIO_RES_EXPIRED on a timeout)
+  double *out;               // host, coherent: frame f's folded moments at f * LIO_RES_OUT (compact: see LIO_RES_OUT)
+  unsigned *words;           // host, coherent: one completion word per frame, [LIO_MAX_FRAMES] = the relay's (LIO_RES_EXPIRED on a timeout),
+                             // [LIO_MAX_FRAMES + 1] = the relay's echo of every sequence number it has seen
   unsigned first_seq;        // the sequence number of the first pass this launch serves
   long long timeout_ticks;   // wall-clock ticks (hipDeviceAttributeWallClockRate) without a doorbell before the kernel gives up
   double *relay;             // device: the doorbell republished by the relay block (same layout)
   double *block_part;        // device: block b's record at b * LIO_MOMENT_OUT; slot LIO_MOMENT_OUT - 1 = the pass it belongs to (the flag)
+  int diag;                  // 1: every phase stamp goes into the frame record (LIO_DEBUG_TIMING), 0: only the pass time
 };
 // blocks per frame so that a lane holds at most `per_lane` residuals (0 when the window does not fit LIO_RES_MAX_BLOCKS)
 int resident_blocks_per_frame(int max_slots, int nframes, int per_lane);

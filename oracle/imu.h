@@ -7,7 +7,10 @@
 //   src/factor/PriorFactor.cc:35-67                 (PriorFactor::Evaluate)
 //   src/factor/PoseLocalParameterization.cc:35-59   (Plus / ComputeJacobian)
 // Pinned against the reference's only fixture for this path (test/data/imu_pose_vel.txt, intent of
-// test_imu_factor.cc:435-444: residual at ground truth ~ 0) in tests/test_oracle_imu.py.
+// test_imu_factor.cc:435-444: residual at ground truth ~ 0) in tests/test_oracle_imu.py, and — since round 3 — against the
+// outputs of those five reference sources THEMSELVES, compiled where they lie against stand-in headers (oracle/ref_shim,
+// oracle/ref_factors.cc, `make ref`; committed as tests/golden/ref_factor_vectors.npz): tests/test_ref_factor_vectors.py,
+// bit for bit.
 #pragma once
 #include <memory>
 

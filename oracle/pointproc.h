@@ -6,6 +6,8 @@
 //   :647-783 (ExtractFeaturePoints); include/point_processor/PointProcessor.h:104-120,153-156.
 // Float/double mixing follows SURVEY.md Appendix A.1/A.2 literally.  Parity object: the ordered
 // (ring, in-ring index) pick lists (bit-exact) and the clouds.
+// Pinned (round 3) against the reference's own PointProcessor.cc compiled where it lies (oracle/ref_pointproc.cc, oracle/ref_shim,
+// `make ref`): tests/golden/ref_pointproc_digests.json, tests/test_ref_pointproc_digests.py — bit for bit, in order.
 #pragma once
 #include "cloud.h"
 #include "liomath.h"

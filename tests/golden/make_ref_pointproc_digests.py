@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_pointproc_digests.json: digests of what THE REFERENCE'S OWN PointProcessor produces on the sweeps of
+tests/ref_pp_cases.py.  oracle/_ref/libref_pointproc.so (`make -C oracle ref`, needs /root/reference) is
+src/point_processor/PointProcessor.cc compiled where it lies against the stand-in headers of oracle/ref_shim (PCL containers, ROS
+types that do nothing; pcl::VoxelGrid forwards to the oracle's restatement, so the less-flat cloud pins everything in front of
+the voxel filter but not the filter).  Runs only in the build container; the digests are committed."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+from ref_pp_cases import CLOUDS, cases, digest  # noqa: E402
+
+ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_pointproc.so"))
+fp = C.POINTER(C.c_float)
+ref.ref_pp_create.restype = C.c_void_p
+ref.ref_pp_create.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+ref.ref_pp_destroy.argtypes = [C.c_void_p]
+ref.ref_pp_process.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint16)]
+ref.ref_pp_count.restype = C.c_size_t
+ref.ref_pp_count.argtypes = [C.c_void_p, C.c_int]
+ref.ref_pp_get.argtypes = [C.c_void_p, C.c_int, fp]
+WHICH = [5, 1, 2, 3, 4]
+
+
+def main():
+    out = {}
+    for name, lid, cfg, sweeps in cases():
+        ci = (C.c_int * 6)(cfg.get("num_scan_subregions", 8), cfg.get("num_curvature_regions", 5), cfg.get("max_corner_sharp", 2),
+                           cfg.get("max_corner_less_sharp", 20), cfg.get("max_surf_flat", 4), cfg.get("infer_start_ori", 0))
+        cf = (C.c_double * 4)(cfg.get("surf_curv_th", 0.1), cfg.get("less_flat_filter_size", 0.2), 0.1, 0.2)
+        h = ref.ref_pp_create(lid.lower_deg, lid.upper_deg, lid.rings, cfg.get("uneven", 0), ci, cf)
+        rows = []
+        for scan, ring in sweeps:
+            scan = np.ascontiguousarray(scan, np.float32)
+            rp = None if ring is None else np.ascontiguousarray(ring, np.uint16).ctypes.data_as(C.POINTER(C.c_uint16))
+            ref.ref_pp_process(h, scan.ctypes.data_as(fp), len(scan), rp)
+            row = {}
+            for cname, w in zip(CLOUDS, WHICH):
+                n = ref.ref_pp_count(h, w)
+                a = np.zeros((n, 4), np.float32)
+                ref.ref_pp_get(h, w, a.ctypes.data_as(fp))
+                row[cname] = digest(a)
+            rows.append(row)
+        ref.ref_pp_destroy(h)
+        out[name] = rows
+    path = os.path.join(HERE, "ref_pointproc_digests.json")
+    json.dump(out, open(path, "w"), indent=0, sort_keys=True)
+    print(path, os.path.getsize(path), "bytes;", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,9 @@
 //   plane coefficients :497-531, 6x6 Gauss-Newton :539-580, degeneracy mask :584-615 (threshold 10, A.6),
 //   update :617-640, abort test :642-650, accumulation :654-663, cloud swap :667-676).
 // Weights / damping follow SURVEY.md A.7-A.8.  K=1 nearest neighbour = exact (B.2), ties -> lower index.
+// Pinned (round 3) against the reference's own PointOdometry.cc compiled where it lies (oracle/ref_odometry.cc, oracle/ref_shim,
+// `make ref`): tests/golden/ref_odometry_digests.json, tests/test_ref_odometry_digests.py — transforms, TransformToEnd clouds and
+// /compact_data messages bit for bit (kd-tree = exact search; QR / eigen-solver forwarded to liomath.h, so not pinned by it).
 #pragma once
 #include "cloud.h"
 #include "liomath.h"

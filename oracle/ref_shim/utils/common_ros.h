@@ -4,6 +4,7 @@
 #include <iostream>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../pcl/point_types.h"
 
@@ -25,16 +26,30 @@ struct RefShimNullStream {
 #endif
 
 namespace ros {
+struct Duration { double sec = 0; double toSec() const { return sec; } };
 struct Time {
   double sec = 0;
+  Time() {}
+  explicit Time(double s) : sec(s) {}
   static Time now() { return Time(); }
   double toSec() const { return sec; }
+  Time &fromSec(double s) { sec = s; return *this; }
+  Duration operator-(const Time &o) const { Duration d; d.sec = sec - o.sec; return d; }
+  bool operator==(const Time &o) const { return sec == o.sec; }
 };
-struct Publisher { template <typename M> void publish(const M &) const {} };
+// a publisher that keeps the last message of each kind it was given (the stand-in messages are plain structs)
+struct PublishedLog;
+struct Publisher { template <typename M> void publish(const M &m) const; };
 struct Subscriber {};
+struct ServiceServer {};
+struct Rate { explicit Rate(double) {} void sleep() {} };
+inline bool ok() { return false; }
+inline void spinOnce() {}
 struct NodeHandle {
   template <typename M> Publisher advertise(const std::string &, int) { return Publisher(); }
   template <typename M, typename C> Subscriber subscribe(const std::string &, int, void (C::*)(const std::shared_ptr<const M> &), C *) { return Subscriber(); }
+  template <typename C, typename Rq, typename Rs> ServiceServer advertiseService(const std::string &, bool (C::*)(Rq &, Rs &), C *) { return ServiceServer(); }
+  template <typename T> bool param(const std::string &, T &v, const T &dflt) const { v = dflt; return false; }
 };
 }  // namespace ros
 namespace std_msgs {
@@ -42,19 +57,69 @@ struct Header { ros::Time stamp; std::string frame_id; };
 struct Float32 { float data = 0.f; };
 }  // namespace std_msgs
 namespace sensor_msgs {
-struct PointCloud2 { std_msgs::Header header; };
+// the payload of a cloud message here: x, y, z, intensity per point (what the reference's nodes exchange)
+struct PointCloud2 { std_msgs::Header header; std::vector<float> xyzi; };
 typedef std::shared_ptr<const PointCloud2> PointCloud2ConstPtr;
 }  // namespace sensor_msgs
+namespace geometry_msgs {
+struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
+struct Point { double x = 0, y = 0, z = 0; };
+struct Pose { Point position; Quaternion orientation; };
+struct PoseWithCovariance { Pose pose; };
+}  // namespace geometry_msgs
+namespace nav_msgs {
+struct Odometry { std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
+}  // namespace nav_msgs
+namespace std_srvs {
+struct SetBoolRequest { bool data = false; };
+struct SetBoolResponse { bool success = false; std::string message; };
+}  // namespace std_srvs
+namespace tf {
+struct Quaternion { double x_, y_, z_, w_; Quaternion(double x = 0, double y = 0, double z = 0, double w = 1) : x_(x), y_(y), z_(z), w_(w) {} };
+struct Vector3 { double x_, y_, z_; Vector3(double x = 0, double y = 0, double z = 0) : x_(x), y_(y), z_(z) {} };
+struct StampedTransform {
+  ros::Time stamp_; std::string frame_id_, child_frame_id_;
+  Quaternion q_; Vector3 o_;
+  void setRotation(const Quaternion &q) { q_ = q; }
+  void setOrigin(const Vector3 &o) { o_ = o; }
+};
+struct TransformBroadcaster { void sendTransform(const StampedTransform &) {} };
+}  // namespace tf
+namespace ros {
+struct PublishedLog { static sensor_msgs::PointCloud2 &last_cloud() { static sensor_msgs::PointCloud2 m; return m; } static nav_msgs::Odometry &last_odom() { static nav_msgs::Odometry m; return m; } };
+template <typename M> inline void Publisher::publish(const M &) const {}
+template <> inline void Publisher::publish<sensor_msgs::PointCloud2>(const sensor_msgs::PointCloud2 &m) const { PublishedLog::last_cloud() = m; }
+template <> inline void Publisher::publish<nav_msgs::Odometry>(const nav_msgs::Odometry &m) const { PublishedLog::last_odom() = m; }
+}  // namespace ros
 namespace pcl {
-template <typename PointT> void fromROSMsg(const sensor_msgs::PointCloud2 &, PointCloud<PointT> &) {}
-template <typename PointT> void toROSMsg(const PointCloud<PointT> &, sensor_msgs::PointCloud2 &) {}
+struct PointXYZ { PCL_ADD_POINT4D; PointXYZ() { x = y = z = 0.f; data[3] = 1.f; } };
+template <typename PointT> void shim_set_intensity(PointT &, float) {}
+inline void shim_set_intensity(PointXYZI &p, float v) { p.intensity = v; }
+template <typename PointT> float shim_get_intensity(const PointT &) { return 0.f; }
+inline float shim_get_intensity(const PointXYZI &p) { return p.intensity; }
+template <typename PointT> void fromROSMsg(const sensor_msgs::PointCloud2 &m, PointCloud<PointT> &c) {
+  c.clear();
+  for (size_t i = 0; i + 3 < m.xyzi.size(); i += 4) { PointT p; p.x = m.xyzi[i]; p.y = m.xyzi[i + 1]; p.z = m.xyzi[i + 2]; shim_set_intensity(p, m.xyzi[i + 3]); c.push_back(p); }
+}
+template <typename PointT> void toROSMsg(const PointCloud<PointT> &c, sensor_msgs::PointCloud2 &m) {
+  m.xyzi.clear();
+  for (size_t i = 0; i < c.size(); ++i) { m.xyzi.push_back(c[i].x); m.xyzi.push_back(c[i].y); m.xyzi.push_back(c[i].z); m.xyzi.push_back(shim_get_intensity(c[i])); }
+}
 template <typename PointT> void removeNaNFromPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, std::vector<int> &idx) {
+  const std::vector<PointT> src(in.points);   // (the reference filters clouds in place: in and out may be the same object)
   out.clear(); idx.clear();
-  for (size_t i = 0; i < in.size(); ++i)
-    if (std::isfinite(in[i].x) && std::isfinite(in[i].y) && std::isfinite(in[i].z)) { out.push_back(in[i]); idx.push_back(int(i)); }
+  for (size_t i = 0; i < src.size(); ++i)
+    if (std::isfinite(src[i].x) && std::isfinite(src[i].y) && std::isfinite(src[i].z)) { out.push_back(src[i]); idx.push_back(int(i)); }
 }
 }  // namespace pcl
 namespace lio {
+// as in the reference's utils/common_ros.h: convert, stamp, publish (the stand-in publisher keeps the last cloud message)
 template <typename PointT>
-inline void PublishCloudMsg(ros::Publisher &, const pcl::PointCloud<PointT> &, const ros::Time &, std::string) {}
+inline void PublishCloudMsg(ros::Publisher &publisher, const pcl::PointCloud<PointT> &cloud, const ros::Time &stamp, std::string frame_id) {
+  sensor_msgs::PointCloud2 msg;
+  pcl::toROSMsg(cloud, msg);
+  msg.header.stamp = stamp;
+  msg.header.frame_id = frame_id;
+  publisher.publish(msg);
+}
 }  // namespace lio

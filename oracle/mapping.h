@@ -9,6 +9,9 @@
 //     :1112-1208 UpdateMapDatabase
 //   include/point_processor/PointMapping.h:148-160 (ToIndex / FromIndex), :243-249 (score map, thresholds)
 // Parity UNPINNED vs PCL/Eigen (absent here, see cloud.h / liomath.h headers).
+// Pinned (round 3) against the reference's own PointMapping.cc compiled where it lies (oracle/ref_mapping.cc, oracle/ref_shim,
+// `make ref`): tests/golden/ref_mapping_digests.json, tests/test_ref_mapping_digests.py — transforms, stacks, from-map clouds, window
+// state and cube contents bit for bit (VoxelGrid / QR / eigen-solver forwarded to this oracle's own restatements, so not pinned by it).
 #pragma once
 #include <array>
 #include <cstdio>

@@ -68,7 +68,7 @@ struct Pose { Point position; Quaternion orientation; };
 struct PoseWithCovariance { Pose pose; };
 }  // namespace geometry_msgs
 namespace nav_msgs {
-struct Odometry { std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
+struct Odometry { typedef std::shared_ptr<const Odometry> ConstPtr; std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
 }  // namespace nav_msgs
 namespace std_srvs {
 struct SetBoolRequest { bool data = false; };

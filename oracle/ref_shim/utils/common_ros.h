@@ -1,6 +1,7 @@
 // Stand-in for the reference's utils/common_ros.h (ROS + PCL headers) and for the ROS / glog names its sources mention: logging
 // macros that swallow their arguments, message / publisher / node-handle types that do nothing.  oracle/ref_shim: test infrastructure.
 #pragma once
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -20,6 +21,20 @@ struct RefShimNullStream {
 #endif
 #ifndef ROS_DEBUG
 #define ROS_DEBUG(...) do { } while (0)
+#endif
+#ifndef ROS_BREAK
+#define ROS_BREAK() std::abort()
+#endif
+#ifndef ROS_ASSERT
+#define ROS_ASSERT(c) do { if (!(c)) std::abort(); } while (0)
+#endif
+#ifndef ROS_WARN
+#define ROS_WARN(...) do { } while (0)
+#define ROS_INFO(...) do { } while (0)
+#define ROS_ERROR(...) do { } while (0)
+#define ROS_INFO_STREAM(a) do { } while (0)
+#define ROS_WARN_STREAM(a) do { } while (0)
+#define ROS_ERROR_STREAM(a) do { } while (0)
 #endif
 #ifndef ROS_DEBUG_STREAM
 #define ROS_DEBUG_STREAM(args) do { } while (0)

@@ -5,9 +5,14 @@
 // `make -C oracle ref` into oracle/_ref/libref_factors.so when /root/reference exists; tests/golden/make_ref_factor_vectors.py
 // turns its outputs into committed vectors, tests/test_oracle_ref_factors.py checks the oracle (and with it the product's host
 // code, which is bit-identical to the oracle) against them.  Nothing of the reference is copied: this file only calls it.
+#include <array>
+#include <cstring>
 #include <memory>
+#include <unordered_map>
+#include <vector>
 
 #include "factor/ImuFactor.h"
+#include "factor/MarginalizationFactor.h"
 #include "factor/PivotPointPlaneFactor.h"
 #include "factor/PoseLocalParameterization.h"
 #include "factor/PriorFactor.h"
@@ -77,6 +82,96 @@ void ref_pose_plus(const double *x, const double *delta, double *out) {
 void ref_pose_jacobian(const double *x, double *J42) {
   lio::PoseLocalParameterization p;
   static_cast<const ceres::LocalParameterization &>(p).ComputeJacobian(x, J42);
+}
+
+
+// ---- MarginalizationInfo driven the way Estimator::SolveOptimization drives it (Estimator.cc:2152-2245): the previous prior as a
+// MarginalizationFactor dropping pose 0 / speed-bias 0, the ImuFactor of the first interval dropping both, one PivotPointPlaneFactor
+// per lidar feature of the frames 1..Wo under CauchyLoss(1.0) dropping the pivot pose; PreMarginalize, Marginalize,
+// GetParameterBlocks with the address shift i -> i - 1.
+//   poses: (Wo + 1) x 7, sbs: (Wo + 1) x 9, ex: 7 (ambient layouts of the reference's para_* arrays)
+//   prev (n_prev > 0): linearized_jacobians n_prev x n_prev row-major, linearized_residuals, and its kept blocks in ITS order:
+//     prev_kind[k] = 0 pose / 1 speed-bias / 2 extrinsic, prev_index[k] = the window slot the block refers to NOW (after the shift),
+//     prev_x0 = keep_block_data concatenated (ambient)
+//   pim: handle of ref_pim_create (null: no IMU factor)
+//   feat_n[i - 1], points (3 each), coeffs (4 each) of frame i = 1..Wo, concatenated
+// out: returns n (< 0 on failure); m; lin_jac (n x n row-major), lin_res (n); the kept blocks in the reference's order:
+//   kind / index (AFTER the shift, i.e. in the next window) / offset into the n residual columns / ambient size; x0 concatenated.
+int ref_marginalize(int Wo, const double *poses, const double *sbs, const double *ex, int n_prev, const double *prev_jac, const double *prev_res,
+                    int n_prev_blocks, const int *prev_kind, const int *prev_index, const double *prev_x0, void *pim, const int *feat_n,
+                    const double *points, const double *coeffs, int *m_out, double *lin_jac, double *lin_res, int *n_blocks_out, int *kind_out,
+                    int *index_out, int *offset_out, int *size_out, double *x0_out, int capacity_n) {
+  std::vector<std::array<double, 7> > para_pose(Wo + 1);
+  std::vector<std::array<double, 9> > para_sb(Wo + 1);
+  std::array<double, 7> para_ex;
+  for (int i = 0; i <= Wo; ++i) { std::memcpy(para_pose[i].data(), poses + 7 * i, 56); std::memcpy(para_sb[i].data(), sbs + 9 * i, 72); }
+  std::memcpy(para_ex.data(), ex, 56);
+  auto addr_of = [&](int kind, int index) -> double * { return kind == 0 ? para_pose[index].data() : (kind == 1 ? para_sb[index].data() : para_ex.data()); };
+
+  lio::MarginalizationInfo *info = new lio::MarginalizationInfo();
+  lio::MarginalizationInfo *last = nullptr;
+  std::vector<double *> last_blocks;
+  if (n_prev > 0) {
+    last = new lio::MarginalizationInfo();
+    last->n = n_prev; last->m = 0;
+    last->linearized_jacobians = Eigen::MatrixXd(n_prev, n_prev);
+    last->linearized_residuals = Eigen::VectorXd(n_prev);
+    for (int i = 0; i < n_prev; ++i) { last->linearized_residuals(i) = prev_res[i]; for (int j = 0; j < n_prev; ++j) last->linearized_jacobians(i, j) = prev_jac[size_t(i) * n_prev + j]; }
+    int off = 0, xo = 0;
+    for (int k = 0; k < n_prev_blocks; ++k) {
+      const int size = prev_kind[k] == 1 ? 9 : 7;
+      last->keep_block_size.push_back(size);
+      last->keep_block_idx.push_back(off);          // (m = 0: the offsets are the columns)
+      double *d = new double[size];
+      std::memcpy(d, prev_x0 + xo, sizeof(double) * size);
+      last->keep_block_data.push_back(d);
+      last->parameter_block_data[long(k) + 1] = d;  // owned by `last` (its destructor frees parameter_block_data)
+      last_blocks.push_back(addr_of(prev_kind[k], prev_index[k]));
+      off += size == 7 ? 6 : size; xo += size;
+    }
+    std::vector<int> drop_set;
+    for (int i = 0; i < int(last_blocks.size()); ++i) if (last_blocks[i] == para_pose[0].data() || last_blocks[i] == para_sb[0].data()) drop_set.push_back(i);
+    lio::MarginalizationFactor *mf = new lio::MarginalizationFactor(last);
+    info->AddResidualBlockInfo(new lio::ResidualBlockInfo(mf, NULL, last_blocks, drop_set));
+  }
+  if (pim) {
+    lio::ImuFactor *f = new lio::ImuFactor(static_cast<Pim *>(pim)->p);
+    info->AddResidualBlockInfo(new lio::ResidualBlockInfo(f, NULL, std::vector<double *>{para_pose[0].data(), para_sb[0].data(), para_pose[1].data(), para_sb[1].data()},
+                                                          std::vector<int>{0, 1}));
+  }
+  ceres::LossFunction *loss = new ceres::CauchyLoss(1.0);
+  size_t at = 0;
+  for (int i = 1; i <= Wo; ++i)
+    for (int j = 0; j < feat_n[i - 1]; ++j, ++at) {
+      lio::PivotPointPlaneFactor *f = new lio::PivotPointPlaneFactor(v3(points + 3 * at), Eigen::Vector4d(coeffs[4 * at], coeffs[4 * at + 1], coeffs[4 * at + 2], coeffs[4 * at + 3]));
+      info->AddResidualBlockInfo(new lio::ResidualBlockInfo(f, loss, std::vector<double *>{para_pose[0].data(), para_pose[i].data(), para_ex.data()}, std::vector<int>{0}));
+    }
+  info->PreMarginalize();
+  info->Marginalize();
+  std::unordered_map<long, double *> addr_shift;
+  for (int i = 1; i <= Wo; ++i) { addr_shift[reinterpret_cast<long>(para_pose[i].data())] = para_pose[i - 1].data(); addr_shift[reinterpret_cast<long>(para_sb[i].data())] = para_sb[i - 1].data(); }
+  addr_shift[reinterpret_cast<long>(para_ex.data())] = para_ex.data();
+  std::vector<double *> blocks = info->GetParameterBlocks(addr_shift);
+  const int n = info->n;
+  int rc = n;
+  if (n > capacity_n) rc = -1;
+  else {
+    *m_out = info->m;
+    for (int i = 0; i < n; ++i) { lin_res[i] = info->linearized_residuals(i); for (int j = 0; j < n; ++j) lin_jac[size_t(i) * n + j] = info->linearized_jacobians(i, j); }
+    *n_blocks_out = int(blocks.size());
+    int xo = 0;
+    for (size_t k = 0; k < blocks.size(); ++k) {
+      int kind = 2, index = 0;
+      for (int i = 0; i <= Wo; ++i) { if (blocks[k] == para_pose[i].data()) { kind = 0; index = i; } if (blocks[k] == para_sb[i].data()) { kind = 1; index = i; } }
+      kind_out[k] = kind; index_out[k] = index; offset_out[k] = info->keep_block_idx[k] - info->m; size_out[k] = info->keep_block_size[k];
+      std::memcpy(x0_out + xo, info->keep_block_data[k], sizeof(double) * info->keep_block_size[k]);
+      xo += info->keep_block_size[k];
+    }
+  }
+  delete info;      // frees its factors (and with them the MarginalizationFactor object, not `last`)
+  if (last) { last->keep_block_data.clear(); delete last; }
+  delete loss;
+  return rc;
 }
 
 }  // extern "C"

@@ -6,6 +6,8 @@
 //   :331-397 EstimateExtrinsicRotation         :399-436 Initialization
 // Eigen's ldlt()/JacobiSVD are replaced by the documented algorithms (partial-pivot elimination on the symmetric
 // system; smallest right singular vector = eigenvector of A^T A) — parity with Eigen itself is UNPINNED.
+// Everything ELSE in this file is pinned (round 3) against the reference's own ImuInitializer.cc compiled where it lies (oracle/ref_factors.cc,
+// oracle/ref_shim, `make ref`): tests/golden/ref_imu_init_vectors.npz, tests/test_ref_imu_init_vectors.py.
 #pragma once
 #include <memory>
 #include <vector>

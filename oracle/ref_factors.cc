@@ -16,6 +16,7 @@
 #include "factor/PivotPointPlaneFactor.h"
 #include "factor/PoseLocalParameterization.h"
 #include "factor/PriorFactor.h"
+#include "imu_processor/ImuInitializer.h"
 #include "imu_processor/IntegrationBase.h"
 
 namespace {
@@ -84,6 +85,41 @@ void ref_pose_jacobian(const double *x, double *J42) {
   static_cast<const ceres::LocalParameterization &>(p).ComputeJacobian(x, J42);
 }
 
+
+// ---- ImuInitializer (src/imu_processor/ImuInitializer.cc): transforms = n x (q xyzw, p) floats, pims = n handles of ref_pim_create
+// (pims[0] may be null: the reference never reads the motion of frame 0), T_lb = q xyzw, p
+static void fill_frames(int n, const float *transforms, void *const *pims, lio::CircularBuffer<lio::PairTimeLaserTransform> &all) {
+  for (int i = 0; i < n; ++i) {
+    const float *t = transforms + 7 * i;
+    lio::LaserTransform lt(double(i), lio::Transform(Eigen::Quaternionf(t[3], t[0], t[1], t[2]), Eigen::Vector3f(t[4], t[5], t[6])));
+    if (pims[i]) lt.pre_integration = static_cast<Pim *>(pims[i])->p;
+    all.push(lio::PairTimeLaserTransform(double(i), lt));
+  }
+}
+int ref_imu_estimate_extrinsic_rotation(int n, const float *transforms, void *const *pims, float *T_lb) {
+  lio::CircularBuffer<lio::PairTimeLaserTransform> all(size_t(n) + 1);
+  fill_frames(n, transforms, pims, all);
+  lio::Transform lb(Eigen::Quaternionf(T_lb[3], T_lb[0], T_lb[1], T_lb[2]), Eigen::Vector3f(T_lb[4], T_lb[5], T_lb[6]));
+  const bool ok = lio::ImuInitializer::EstimateExtrinsicRotation(all, lb);
+  T_lb[0] = lb.rot.x(); T_lb[1] = lb.rot.y(); T_lb[2] = lb.rot.z(); T_lb[3] = lb.rot.w();
+  return ok ? 1 : 0;
+}
+int ref_imu_initialization(int n, const float *transforms, void *const *pims, const float *T_lb, double *Vs_out, double *Bgs_inout, double *g_out,
+                           double *R_WI_out) {
+  lio::CircularBuffer<lio::PairTimeLaserTransform> all(size_t(n) + 1);
+  fill_frames(n, transforms, pims, all);
+  lio::CircularBuffer<Eigen::Vector3d> Vs(size_t(n) + 1), Bas(size_t(n) + 1), Bgs(size_t(n) + 1);
+  for (int i = 0; i < n; ++i) { Vs.push(Eigen::Vector3d(0, 0, 0)); Bas.push(Eigen::Vector3d(0, 0, 0)); Bgs.push(v3(Bgs_inout + 3 * i)); }
+  lio::Transform lb(Eigen::Quaternionf(T_lb[3], T_lb[0], T_lb[1], T_lb[2]), Eigen::Vector3f(T_lb[4], T_lb[5], T_lb[6]));
+  Eigen::Vector3d g(0, 0, 0);
+  Eigen::Matrix3d R_WI;
+  R_WI.setIdentity();
+  const bool ok = lio::ImuInitializer::Initialization(all, Vs, Bas, Bgs, g, lb, R_WI);
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { Vs_out[3 * i + k] = Vs[i](k); Bgs_inout[3 * i + k] = Bgs[i](k); }
+  for (int k = 0; k < 3; ++k) g_out[k] = g(k);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R_WI_out[3 * i + j] = R_WI(i, j);
+  return ok ? 1 : 0;
+}
 
 // ---- MarginalizationInfo driven the way Estimator::SolveOptimization drives it (Estimator.cc:2152-2245): the previous prior as a
 // MarginalizationFactor dropping pose 0 / speed-bias 0, the ImuFactor of the first interval dropping both, one PivotPointPlaneFactor

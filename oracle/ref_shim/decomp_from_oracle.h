@@ -4,6 +4,7 @@
 #pragma once
 #include <vector>
 
+#include "../imu_init.h"
 #include "../liomath.h"
 #include "Eigen/Eigen"
 namespace Eigen {
@@ -12,17 +13,12 @@ template <typename T> void shim_colpiv_qr_solve(int m, int n, const T *A, const 
   orc::colpiv_qr_solve<T>(m, n, a.data(), bb.data(), x);
 }
 template <typename T> void shim_sym_eigen(int n, const T *A, T *w, T *V) { orc::sym_eigen<T>(n, A, w, V); }
-// (A.ldlt().solve(b) for the small symmetric systems of the IMU initialiser: a pivot-free L D L^T, the textbook recurrence)
+// A.ldlt().solve(b): the oracle restates it as Gaussian elimination with partial pivoting (oracle/imu_init.h: DenseSolve)
 template <typename T> void shim_ldlt_solve(int n, const T *A, const T *b, T *x) {
-  std::vector<T> L(size_t(n) * n, T(0)), D(n), y(n);
-  for (int j = 0; j < n; ++j) {
-    T d = A[size_t(j) * n + j];
-    for (int k = 0; k < j; ++k) d -= L[size_t(j) * n + k] * L[size_t(j) * n + k] * D[k];
-    D[j] = d; L[size_t(j) * n + j] = T(1);
-    for (int i = j + 1; i < n; ++i) { T s = A[size_t(i) * n + j]; for (int k = 0; k < j; ++k) s -= L[size_t(i) * n + k] * L[size_t(j) * n + k] * D[k]; L[size_t(i) * n + j] = s / d; }
-  }
-  for (int i = 0; i < n; ++i) { T s = b[i]; for (int k = 0; k < i; ++k) s -= L[size_t(i) * n + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < n; ++i) y[i] /= D[i];
-  for (int i = n - 1; i >= 0; --i) { T s = y[i]; for (int k = i + 1; k < n; ++k) s -= L[size_t(k) * n + i] * x[k]; x[i] = s; }
+  orc::Mat M(n, n);
+  std::vector<double> bb(n);
+  for (int i = 0; i < n; ++i) { bb[i] = double(b[i]); for (int k = 0; k < n; ++k) M(i, k) = double(A[size_t(i) * n + k]); }
+  const std::vector<double> r = orc::DenseSolve(M, bb);
+  for (int i = 0; i < n; ++i) x[i] = T(r[i]);
 }
 }  // namespace Eigen

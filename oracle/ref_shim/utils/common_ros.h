@@ -22,6 +22,13 @@ struct RefShimNullStream {
 #ifndef ROS_DEBUG
 #define ROS_DEBUG(...) do { } while (0)
 #endif
+inline RefShimNullStream RefShimCheck(bool ok) { if (!ok) std::abort(); return RefShimNullStream(); }
+#ifndef LOG_ASSERT
+#define LOG_ASSERT(c) RefShimCheck(bool(c))
+#endif
+#ifndef CHECK
+#define CHECK(c) RefShimCheck(bool(c))
+#endif
 #ifndef ROS_BREAK
 #define ROS_BREAK() std::abort()
 #endif

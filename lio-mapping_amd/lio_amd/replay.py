@@ -30,6 +30,7 @@ class Replay:
         self.imu_buf = collections.deque()      # (t, acc[3], gyr[3])
         self.compact_buf = collections.deque()  # (stamp, compact cloud)
         self.curr_time = -1.0
+        self.imu_last_time = -1.0
         self.odom_frame_count = 0
         self.odom_started = False
         self.odom_enabled = True
@@ -52,6 +53,9 @@ class Replay:
         self._drain()
 
     def add_imu(self, t: float, acc, gyr):
+        if float(t) <= self.imu_last_time:          # "imu message in disorder!": dropped (MeasurementManager.cc:111-115)
+            return
+        self.imu_last_time = float(t)
         self.imu_buf.append((float(t), np.asarray(acc, float), np.asarray(gyr, float)))
         self._drain()
 

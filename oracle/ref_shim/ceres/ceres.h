@@ -64,3 +64,5 @@ class LocalParameterization {
   virtual int LocalSize() const = 0;
 };
 }  // namespace ceres
+
+#include "problem.h"   // ceres::Problem / ceres::Solve stand-ins (used by the reference's Estimator.cc only)

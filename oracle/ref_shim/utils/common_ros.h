@@ -47,6 +47,11 @@ inline RefShimNullStream RefShimCheck(bool ok) { if (!ok) std::abort(); return R
 #define ROS_DEBUG_STREAM(args) do { } while (0)
 #endif
 
+namespace boost {
+using std::shared_ptr;
+using std::make_shared;
+struct mutex { void lock() {} void unlock() {} };
+}  // namespace boost
 namespace ros {
 struct Duration { double sec = 0; double toSec() const { return sec; } };
 struct Time {
@@ -64,37 +69,56 @@ struct PublishedLog;
 struct Publisher { template <typename M> void publish(const M &m) const; };
 struct Subscriber {};
 struct ServiceServer {};
+struct TransportHints { TransportHints &tcpNoDelay() { return *this; } };
+struct ServiceClient { template <typename S> bool call(S &) { return true; } };
 struct Rate { explicit Rate(double) {} void sleep() {} };
 inline bool ok() { return false; }
 inline void spinOnce() {}
 struct NodeHandle {
   template <typename M> Publisher advertise(const std::string &, int) { return Publisher(); }
   template <typename M, typename C> Subscriber subscribe(const std::string &, int, void (C::*)(const std::shared_ptr<const M> &), C *) { return Subscriber(); }
+  template <typename M, typename C> Subscriber subscribe(const std::string &, int, void (C::*)(const std::shared_ptr<const M> &), C *, const TransportHints &) { return Subscriber(); }
   template <typename C, typename Rq, typename Rs> ServiceServer advertiseService(const std::string &, bool (C::*)(Rq &, Rs &), C *) { return ServiceServer(); }
   template <typename T> bool param(const std::string &, T &v, const T &dflt) const { v = dflt; return false; }
+  template <typename S> ServiceClient serviceClient(const std::string &) { return ServiceClient(); }
 };
 }  // namespace ros
 namespace std_msgs {
-struct Header { ros::Time stamp; std::string frame_id; };
+struct Header { ros::Time stamp; std::string frame_id; unsigned seq = 0; };
 struct Float32 { float data = 0.f; };
 }  // namespace std_msgs
+struct geometry_msgs_Quaternion_fwd { double x = 0, y = 0, z = 0, w = 1; };
 namespace sensor_msgs {
 // the payload of a cloud message here: x, y, z, intensity per point (what the reference's nodes exchange)
 struct PointCloud2 { std_msgs::Header header; std::vector<float> xyzi; };
 typedef std::shared_ptr<const PointCloud2> PointCloud2ConstPtr;
+struct Vec3 { double x = 0, y = 0, z = 0; };
+struct Imu { std_msgs::Header header; Vec3 linear_acceleration, angular_velocity; geometry_msgs_Quaternion_fwd orientation; };
+typedef std::shared_ptr<const Imu> ImuConstPtr;
 }  // namespace sensor_msgs
 namespace geometry_msgs {
 struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
 struct Point { double x = 0, y = 0, z = 0; };
 struct Pose { Point position; Quaternion orientation; };
 struct PoseWithCovariance { Pose pose; };
+struct PoseStamped { std_msgs::Header header; Pose pose; };
+struct Vector3 { double x = 0, y = 0, z = 0; };
+struct Twist { Vector3 linear, angular; };
+struct TwistWithCovariance { Twist twist; };
 }  // namespace geometry_msgs
 namespace nav_msgs {
-struct Odometry { typedef std::shared_ptr<const Odometry> ConstPtr; std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
+struct Odometry { typedef std::shared_ptr<const Odometry> ConstPtr; std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; geometry_msgs::TwistWithCovariance twist; };
+typedef std::shared_ptr<const Odometry> OdometryConstPtr;
+struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; };
 }  // namespace nav_msgs
+namespace visualization_msgs {
+struct Marker { std_msgs::Header header; };
+struct MarkerArray { std::vector<Marker> markers; };
+}  // namespace visualization_msgs
 namespace std_srvs {
 struct SetBoolRequest { bool data = false; };
 struct SetBoolResponse { bool success = false; std::string message; };
+struct SetBool { SetBoolRequest request; SetBoolResponse response; };
 }  // namespace std_srvs
 namespace tf {
 struct Quaternion { double x_, y_, z_, w_; Quaternion(double x = 0, double y = 0, double z = 0, double w = 1) : x_(x), y_(y), z_(z), w_(w) {} };
@@ -104,6 +128,7 @@ struct StampedTransform {
   Quaternion q_; Vector3 o_;
   void setRotation(const Quaternion &q) { q_ = q; }
   void setOrigin(const Vector3 &o) { o_ = o; }
+  void setIdentity() { q_ = Quaternion(); o_ = Vector3(); }
 };
 struct TransformBroadcaster { void sendTransform(const StampedTransform &) {} };
 }  // namespace tf
@@ -114,7 +139,12 @@ template <> inline void Publisher::publish<sensor_msgs::PointCloud2>(const senso
 template <> inline void Publisher::publish<nav_msgs::Odometry>(const nav_msgs::Odometry &m) const { PublishedLog::last_odom() = m; }
 }  // namespace ros
 namespace pcl {
-struct PointXYZ { PCL_ADD_POINT4D; PointXYZ() { x = y = z = 0.f; data[3] = 1.f; } };
+struct PointXYZ { PCL_ADD_POINT4D; PointXYZ() { x = y = z = 0.f; data[3] = 1.f; } PointXYZ(float a, float b, float c) { x = a; y = b; z = c; data[3] = 1.f; } };
+struct Normal { float normal_x, normal_y, normal_z, curvature; Normal(float a = 0, float b = 0, float c = 0) : normal_x(a), normal_y(b), normal_z(c), curvature(0) {} };
+template <typename A, typename B> void copyPointCloud(const PointCloud<A> &in, PointCloud<B> &out) {
+  out.clear();
+  for (size_t i = 0; i < in.size(); ++i) { B p; p.x = in[i].x; p.y = in[i].y; p.z = in[i].z; out.push_back(p); }
+}
 template <typename PointT> void shim_set_intensity(PointT &, float) {}
 inline void shim_set_intensity(PointXYZI &p, float v) { p.intensity = v; }
 template <typename PointT> float shim_get_intensity(const PointT &) { return 0.f; }

@@ -6,9 +6,10 @@ from lio_amd import capi, pipeline, replay, synth
 
 
 def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kind="indoor", imu_rate=200.0, sweeps=None, traj=None, t0=1.0,
-                  configure=None, on_step=None):
+                  configure=None, on_step=None, est_factory=None):
     """traj / t0: the trajectory object behind `sweeps` when it is not the kind's default (e.g. synth.FixtureTrajectory with
-    t0 = 0); configure(cfg) may edit the estimator config; on_step(rp, k, log_entry) is called after every processed message."""
+    t0 = 0); configure(cfg) may edit the estimator config; on_step(rp, k, log_entry) is called after every processed message; est_factory(cfg) replaces
+    the library's estimator by another object with the same methods (tests/ref_est_util.py: the reference's own Estimator)."""
     if sweeps is None:
         sweeps = synth.make_sweeps(kind, n_sweeps)
     sw, pose_fn, lid = sweeps
@@ -29,6 +30,8 @@ def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kin
     if configure:
         configure(cfg)
     rp = replay.Replay(lib, cfg, lid, odom_io=odom_io)
+    if est_factory:
+        rp.est = est_factory(cfg)
     h = 1.0 / imu_rate
     t_imu = t0
     for k, s in enumerate(sw[:n_sweeps]):

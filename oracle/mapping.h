@@ -28,7 +28,8 @@ struct MappingConfig {
   float corner_filter_size = 0.2f, surf_filter_size = 0.4f;  // PointMapping.cc:122-123; Estimator.cc:189-191
   float min_match_sq_dis = 1.0f, min_plane_dis = 0.2f;       // PointMapping.h:245-246
   int num_max_iterations = 10;                               // PointMapping.h:171
-  // MapBuilder (src/map_builder/MapBuilder.cc): the same stage driven as ProcessMap / OptimizeMap
+  // MapBuilder (src/map_builder/MapBuilder.cc): the same stage driven as ProcessMap / OptimizeMap.  Pinned (round 3) against the
+  // reference's own MapBuilder.cc compiled where it lies (oracle/ref_mapbuilder.cc, tests/test_ref_mapbuilder_digests.py)
   bool map_builder = false;
   bool enable_4d = true;   // MapBuilder.h:66
   int skip_count = 2;      // MapBuilder.h:67

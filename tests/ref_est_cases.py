@@ -16,9 +16,27 @@ CASES = {
     "outdoor64": dict(kind="outdoor", n_sweeps=24, W=6, Wo=3, iwf=1, io=2, cfg={}),
     # every second laser message only while the window fills (init_window_factor = 2), each sweep a message (io_ratio 1)
     "indoor_iwf2": dict(kind="indoor", n_sweeps=22, W=5, Wo=2, iwf=2, io=1, cfg=dict(keep_features=0, cutoff_deskew=1)),
+    # the two window sizes of BASELINE.json: indoor_test_config.yaml's 12 / 7 on the VLP-16 and the compiled default 15 / 5 on the
+    # HDL-64E with every third sweep a message (the headline configuration: 64 rings, ~130 k points a sweep, window 15)
+    "indoor_12_7": dict(kind="indoor", n_sweeps=34, W=12, Wo=7, iwf=1, io=2, cfg={}),
+    "outdoor64_15_5": dict(kind="outdoor", n_sweeps=57, W=15, Wo=5, iwf=1, io=3, cfg={}),
     # estimate_extrinsic = 2: the hand-eye rotation has to converge first (it does not on this motion: same refusals on both sides)
     "indoor_extrinsic2": dict(kind="indoor", n_sweeps=18, W=6, Wo=3, iwf=1, io=2, cfg=dict(extrinsic_stage=2)),
 }
+
+
+_SWEEPS = {}
+
+
+def sweeps_of(kind, n):
+    """synth.make_sweeps(kind, n), generated once per process for the longest n asked for (sweep k does not depend on n; ray casting
+    an HDL-64E sweep takes about a second)"""
+    from lio_amd import synth
+
+    have = _SWEEPS.get(kind)
+    if have is None or len(have[0]) < n:
+        _SWEEPS[kind] = have = synth.make_sweeps(kind, max(n, max(c["n_sweeps"] for c in CASES.values() if c["kind"] == kind)))
+    return have
 
 
 def feature_digest(pt, co):
@@ -71,7 +89,7 @@ def run_case(lib, name, est_factory=None, features_of=None, force_from=None):
         rows.append(r)
 
     run_from_zero(lib, c["n_sweeps"], W=W, Wo=Wo, init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], configure=configure,
-                  on_step=on_step, est_factory=est_factory)
+                  on_step=on_step, est_factory=est_factory, sweeps=sweeps_of(c["kind"], c["n_sweeps"]))
     return rows
 
 

@@ -171,6 +171,56 @@ int ref_est_get_prior(void *hv, double *lin_jac, double *lin_res, int *n_blocks,
   return n;
 }
 
+// ---- the problem of the last solve, as the reference handed it to ceres::Solve (for tests/host/ref_solve_check.hip: the PRODUCT's
+// host solver on the same problem)
+// params: for opt frame i = 0..Wo pose (7) then speed-bias (9), then the extrinsic (7): values at the start and at the end of the
+// solve; flags[0] = extrinsic constant, flags[1] = a MarginalizationFactor block is present, flags[2] = a PriorFactor block is present
+void ref_est_get_solve_params(void *hv, double *initial, double *final_, int *flags, double *prior_pos_rot7) {
+  lio::Estimator &e = *static_cast<Handle *>(hv)->est;
+  const int Wo = int(e.estimator_config_.opt_window_size);
+  auto find = [&](double *p) -> const ceres::ParamRecord * { for (const ceres::ParamRecord &r : ceres::last_params()) if (r.ptr == p) return &r; return nullptr; };
+  int o = 0;
+  auto put_block = [&](double *p) { const ceres::ParamRecord *r = find(p); for (size_t k = 0; k < r->initial.size(); ++k) { initial[o] = r->initial[k]; final_[o] = r->final_[k]; ++o; } };
+  for (int i = 0; i <= Wo; ++i) { put_block(e.para_pose_[i]); put_block(e.para_speed_bias_[i]); }
+  put_block(e.para_ex_pose_);
+  flags[0] = find(e.para_ex_pose_)->constant ? 1 : 0; flags[1] = 0; flags[2] = 0;
+  for (const ceres::internal::ResidualBlock &b : ceres::last_blocks()) {
+    if (dynamic_cast<lio::MarginalizationFactor *>(b.cost)) flags[1] = 1;
+    if (lio::PriorFactor *f = dynamic_cast<lio::PriorFactor *>(b.cost)) {
+      flags[2] = 1;
+      for (int k = 0; k < 3; ++k) prior_pos_rot7[k] = f->pos_(k);
+      prior_pos_rot7[3] = f->rot_.x(); prior_pos_rot7[4] = f->rot_.y(); prior_pos_rot7[5] = f->rot_.z(); prior_pos_rot7[6] = f->rot_.w();
+    }
+  }
+}
+// the parameter arrays as they stand (after ProcessCompactData: what VectorToDouble wrote for the marginalization, Estimator.cc:2152)
+void ref_est_get_para(void *hv, double *out) {
+  lio::Estimator &e = *static_cast<Handle *>(hv)->est;
+  const int Wo = int(e.estimator_config_.opt_window_size);
+  int o = 0;
+  for (int i = 0; i <= Wo; ++i) { for (int k = 0; k < 7; ++k) out[o++] = e.para_pose_[i][k]; for (int k = 0; k < 9; ++k) out[o++] = e.para_speed_bias_[i][k]; }
+  for (int k = 0; k < 7; ++k) out[o++] = e.para_ex_pose_[k];
+}
+// the ImuFactor between opt frames i and i + 1 of the last solve: returns the number of samples (-1: no such factor); head = acc0 (3),
+// gyr0 (3), ba (3), bg (3) the integration was (re)started from; samples = dt, acc (3), gyr (3) each
+int ref_est_get_imu_factor(void *hv, int i, double *head12, double *samples, int capacity) {
+  lio::Estimator &e = *static_cast<Handle *>(hv)->est;
+  for (const ceres::internal::ResidualBlock &b : ceres::last_blocks()) {
+    lio::ImuFactor *f = dynamic_cast<lio::ImuFactor *>(b.cost);
+    if (!f || b.params[0] != e.para_pose_[i]) continue;
+    const lio::IntegrationBase &p = *f->pre_integration_;
+    const int n = int(p.dt_buf_.size());
+    if (n > capacity) return -2;
+    for (int k = 0; k < 3; ++k) { head12[k] = p.linearized_acc_(k); head12[3 + k] = p.linearized_gyr_(k); head12[6 + k] = p.linearized_ba_(k); head12[9 + k] = p.linearized_bg_(k); }
+    for (int s = 0; s < n; ++s) {
+      samples[7 * s] = p.dt_buf_[s];
+      for (int k = 0; k < 3; ++k) { samples[7 * s + 1 + k] = p.acc_buf_[s](k); samples[7 * s + 4 + k] = p.gyr_buf_[s](k); }
+    }
+    return n;
+  }
+  return -1;
+}
+
 // ---- MeasurementManager::GetMeasurements alone (MeasurementManager.cc:54-108): messages in, pairings out
 void *ref_mm_create(double msg_time_delay) {
   lio::MeasurementManager *m = new lio::MeasurementManager();

@@ -11,6 +11,7 @@
 // options.max_solver_time_in_seconds is ignored (a wall-clock limit cannot be compared).
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 
@@ -179,6 +180,9 @@ inline Solver::Summary &last_summary() { static Solver::Summary s; return s; }
 // these stand-ins, so the pointers stay valid), and the cost of every Problem::Evaluate call since it was last cleared
 inline std::vector<internal::ResidualBlock> &last_blocks() { static std::vector<internal::ResidualBlock> v; return v; }
 inline std::vector<double> &evaluate_log() { static std::vector<double> v; return v; }
+// the parameter blocks of the last Solve: address, whether constant, the values it started from and ended with
+struct ParamRecord { double *ptr; bool constant; std::vector<double> initial, final_; };
+inline std::vector<ParamRecord> &last_params() { static std::vector<ParamRecord> v; return v; }
 
 inline void Problem::evaluate_log_hook(double c) { evaluate_log().push_back(c); }
 
@@ -187,6 +191,8 @@ inline void Solve(const Solver::Options &opt, Problem *problem, Solver::Summary 
   Problem &Q = *problem;
   last_blocks().clear();
   for (internal::ResidualBlock *b : Q.blocks_) last_blocks().push_back(*b);
+  last_params().clear();
+  for (const Problem::ParamBlock &pb : Q.params_) last_params().push_back({pb.ptr, pb.constant, std::vector<double>(pb.ptr, pb.ptr + pb.size), {}});
   Solver::Summary sum;
   const size_t NP = Q.params_.size();
   // the state: one ambient vector per parameter block (the user's memory is written at the end only)
@@ -231,6 +237,9 @@ inline void Solve(const Solver::Options &opt, Problem *problem, Solver::Summary 
   orc::Mat H; std::vector<double> g;
   double x_cost = evaluate(x, &H, &g);
   sum.initial_cost = x_cost; sum.cost_trace.push_back(x_cost);
+  if (const char *dump = std::getenv("REF_SHIM_DUMP_HG")) {   // debugging aid: the first linearisation of every solve, appended
+    if (FILE *f = std::fopen(dump, "ab")) { double nn = n; std::fwrite(&nn, 8, 1, f); std::fwrite(H.a.data(), 8, H.a.size(), f); std::fwrite(g.data(), 8, g.size(), f); std::fclose(f); }
+  }
   std::vector<double> scale(n);
   for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H(i, i)));
   auto scaleSystem = [&](orc::Mat &Hs, std::vector<double> &gs) {
@@ -350,6 +359,7 @@ inline void Solve(const Solver::Options &opt, Problem *problem, Solver::Summary 
   sum.iterations = iteration;
   sum.final_cost = x_cost;
   for (size_t k = 0; k < NP; ++k) if (col[k] >= 0) std::copy(x[k].begin(), x[k].end(), Q.params_[k].ptr);
+  for (ParamRecord &r : last_params()) r.final_.assign(r.ptr, r.ptr + r.initial.size());
   last_summary() = sum;
   if (out) *out = sum;
 }

@@ -1,0 +1,85 @@
+"""Generates tests/golden/ref_solve_problems.npz: sliding-window problems exactly as THE REFERENCE's Estimator::SolveOptimization handed
+them to ceres::Solve, with what came out — dumped from the reference's own Estimator.cc (oracle/_ref/libref_estimator.so, see
+oracle/ref_estimator.cc) while it runs the `indoor_iwf2` replay of tests/ref_est_cases.py.  Per dumped solve: the parameter blocks at
+the start, the raw IMU samples of every ImuFactor, every PivotPointPlaneFactor's point and plane, the marginalization prior that went
+in (canonical kept order), the extrinsic PriorFactor's constants; and the results: parameters at the end, iteration count, cost trace,
+the parameters the marginalization was linearised at and the prior it produced; and the first linearisation of the solve (J^T J,
+J^T r as the stand-in ceres::Solve assembled them from the reference's factor classes).  tests/test_ref_solve_problem.py runs the PRODUCT's host
+solver on them.  Build container only.   python tests/golden/make_ref_solve_problems.py"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "..", "..")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "lio-mapping_amd"))
+
+from lio_amd import capi  # noqa: E402
+import ref_est_cases as cases  # noqa: E402
+import ref_est_util  # noqa: E402
+
+CASE, STEPS = "indoor_iwf2", (1, 2)      # estimator steps after the initialisation: 1 = first solve with no prior going in, 2 = with one
+
+
+def main():
+    from replay_util import run_from_zero
+
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liblio_oracle.so", "ref"], check=True)
+    orc = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
+    ref = ref_est_util.load()
+    c = cases.CASES[CASE]
+    out, state = {}, dict(s=-1, prior_in=None)
+
+    def configure(cfg):
+        for k, v in c["cfg"].items():
+            setattr(cfg, k, v)
+        state["cfg"] = cfg
+
+    def on_step(rp, k, e):
+        est = rp.est
+        if not est.stage()["inited"]:
+            return
+        state["s"] += 1
+        s = state["s"]
+        if s in STEPS:
+            pb, cfg, rep, key = est.solve_problem(), state["cfg"], e["report"], "s%d/" % s
+            out[key + "header"] = np.array([est.Wo, pb["ex_constant"], pb["has_prior"], pb["use_prior_factor"], 10, cfg.acc_n, cfg.gyr_n, cfg.acc_w,
+                                            cfg.gyr_w, cfg.g_norm] + list(pb["prior7"]), float)
+            out[key + "initial"], out[key + "final"], out[key + "para"] = pb["initial"], pb["final"], pb["para"]
+            for j, f in enumerate(pb["imu"]):
+                if f is not None:
+                    out[key + "imu%d_head" % j], out[key + "imu%d_samples" % j] = f
+            for i in range(1, est.Wo + 1):
+                out[key + "pts%d" % i], out[key + "coef%d" % i] = est.features(i)
+            if pb["has_prior"]:
+                pin = state["prior_in"]
+                out[key + "prior_in_blocks"] = np.array(pin["blocks"], np.int32)       # kind, index, column offset, ambient size
+                out[key + "prior_in_x0"], out[key + "prior_in_jac"], out[key + "prior_in_res"] = pin["x0"], pin["lin_jac"], pin["lin_res"]
+            out[key + "iterations"], out[key + "trace"] = np.array([rep.iterations, rep.termination]), np.asarray(rep.cost_trace[:11], float)
+            po = est.prior()
+            out[key + "JtJ"], out[key + "Jtr"], out[key + "x0"] = po["JtJ"], po["Jtr"], po["x0"]
+        state["prior_in"] = est.prior()          # what this step left behind goes into the next solve
+
+    hg_path = os.path.join(HERE, "_hg_dump.bin")            # the stand-in ceres::Solve appends every solve's first (H, g) there
+    if os.path.exists(hg_path):
+        os.remove(hg_path)
+    os.environ["REF_SHIM_DUMP_HG"] = hg_path
+    run_from_zero(orc, c["n_sweeps"], W=c["W"], Wo=c["Wo"], init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], configure=configure,
+                  on_step=on_step, est_factory=lambda cfg: ref_est_util.RefEstimator(ref, cfg), sweeps=cases.sweeps_of(c["kind"], c["n_sweeps"]))
+    d, at, k = np.fromfile(hg_path), 0, 0                   # records: n, H (n x n, unscaled J^T J), g (J^T r); one per solve = per step
+    while at < len(d):
+        n = int(d[at])
+        if k in STEPS:
+            out["s%d/H0" % k], out["s%d/g0" % k] = d[at + 1:at + 1 + n * n].reshape(n, n).copy(), d[at + 1 + n * n:at + 1 + n * n + n].copy()
+        at += 1 + n * n + n
+        k += 1
+    os.remove(hg_path)
+    np.savez_compressed(os.path.join(HERE, "ref_solve_problems.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

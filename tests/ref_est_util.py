@@ -31,6 +31,10 @@ def load():
     lib.ref_est_get_surf_stack.restype = C.c_size_t
     lib.ref_est_get_prior.argtypes = [C.c_void_p] * 9 + [C.c_int]
     lib.ref_est_get_prior.restype = C.c_int
+    lib.ref_est_get_solve_params.argtypes = [C.c_void_p] * 5
+    lib.ref_est_get_para.argtypes = [C.c_void_p] * 2
+    lib.ref_est_get_imu_factor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.ref_est_get_imu_factor.restype = C.c_int
     lib.ref_mm_create.restype = C.c_void_p
     lib.ref_mm_create.argtypes = [C.c_double]
     lib.ref_mm_destroy.argtypes = [C.c_void_p]
@@ -127,6 +131,22 @@ class RefEstimator:
         if n:
             self.lib.ref_est_get_surf_stack(self.h, frame, _p(out))
         return out
+
+    def solve_problem(self):
+        """the problem of the last solve as the reference handed it to ceres::Solve: start / end parameters ((Wo + 1) x (7 + 9) + 7),
+        flags, the extrinsic prior's constants, the parameter arrays as they stand now (the marginalization's linearisation point),
+        and per interval the raw IMU samples (None where the reference added no ImuFactor)"""
+        n = (self.Wo + 1) * 16 + 7
+        ini, fin, para, flags, pr7 = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(3, np.int32), np.zeros(7)
+        self.lib.ref_est_get_solve_params(self.h, _p(ini), _p(fin), _p(flags), _p(pr7))
+        self.lib.ref_est_get_para(self.h, _p(para))
+        imu = []
+        for i in range(self.Wo):
+            head, smp = np.zeros(12), np.zeros(7 * 4096)
+            k = self.lib.ref_est_get_imu_factor(self.h, i, _p(head), _p(smp), 4096)
+            assert k >= -1
+            imu.append(None if k < 0 else (head, smp[:7 * k].reshape(k, 7).copy()))
+        return dict(initial=ini, final=fin, para=para, ex_constant=int(flags[0]), has_prior=int(flags[1]), use_prior_factor=int(flags[2]), prior7=pr7, imu=imu)
 
     def prior(self):
         """dict(n, JtJ, Jtr, x0) in the oracle's canonical kept order (pose1, sb1, pose2 .. poseWo, extrinsic -> after the address shift:

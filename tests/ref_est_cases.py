@@ -20,6 +20,14 @@ CASES = {
     # HDL-64E with every third sweep a message (the headline configuration: 64 rings, ~130 k points a sweep, window 15)
     "indoor_12_7": dict(kind="indoor", n_sweeps=34, W=12, Wo=7, iwf=1, io=2, cfg={}),
     "outdoor64_15_5": dict(kind="outdoor", n_sweeps=57, W=15, Wo=5, iwf=1, io=3, cfg={}),
+    # switches of EstimatorConfig one at a time (indoor configuration otherwise)
+    "indoor_fixed_extrinsic": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(opt_extrinsic=0)),
+    "indoor_no_marginalization": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(marginalization_factor=0)),
+    "indoor_prior_factor": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(prior_factor=1, keep_features=0)),
+    # point_distance_factor off: no lidar factor reaches the solver (IMU factors and the prior only).  The reference's marginalization
+    # then keeps only the blocks its remaining factors touch (pose 1, speed-bias 1: n = 15) where the oracle and the product keep
+    # their fixed layout with empty rows for the rest (n = 33) — the same information; the prior is not compared in this case
+    "indoor_imu_only": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(point_distance_factor=0), prior_layout_differs=True),
     # estimate_extrinsic = 2: the hand-eye rotation has to converge first (it does not on this motion: same refusals on both sides)
     "indoor_extrinsic2": dict(kind="indoor", n_sweeps=18, W=6, Wo=3, iwf=1, io=2, cfg=dict(extrinsic_stage=2)),
 }

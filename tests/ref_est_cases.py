@@ -20,6 +20,9 @@ CASES = {
     # HDL-64E with every third sweep a message (the headline configuration: 64 rings, ~130 k points a sweep, window 15)
     "indoor_12_7": dict(kind="indoor", n_sweeps=34, W=12, Wo=7, iwf=1, io=2, cfg={}),
     "outdoor64_15_5": dict(kind="outdoor", n_sweeps=57, W=15, Wo=5, iwf=1, io=3, cfg={}),
+    # SURVEY.md 8(d) config 3 as written: the reference's own noisy IMU fixture (test/data/imu_pose_vel_noise.txt) drives the estimator,
+    # VLP-16 sweeps ray-cast along its trajectory columns, indoor_test_config.yaml's 12 / 7 window, every third message while filling
+    "fixture_12_7": dict(kind="indoor", n_sweeps=90, W=12, Wo=7, iwf=3, io=2, cfg={}, fixture=True),
     # switches of EstimatorConfig one at a time (indoor configuration otherwise)
     "indoor_fixed_extrinsic": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(opt_extrinsic=0)),
     "indoor_no_marginalization": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(marginalization_factor=0)),
@@ -43,7 +46,7 @@ def sweeps_of(kind, n):
 
     have = _SWEEPS.get(kind)
     if have is None or len(have[0]) < n:
-        _SWEEPS[kind] = have = synth.make_sweeps(kind, max(n, max(c["n_sweeps"] for c in CASES.values() if c["kind"] == kind)))
+        _SWEEPS[kind] = have = synth.make_sweeps(kind, max(n, max(c["n_sweeps"] for c in CASES.values() if c["kind"] == kind and not c.get("fixture"))))
     return have
 
 
@@ -96,8 +99,18 @@ def run_case(lib, name, est_factory=None, features_of=None, force_from=None):
                     est.set_prior_factor(dict(n=int(f["prior_n"]), lin_jac=f["prior_jac"], lin_res=f["prior_res"], x0=f["x0"]))
         rows.append(r)
 
+    extra = {}
+    if c.get("fixture"):
+        from fixture_util import fixture_sweeps
+
+        if "fixture" not in _SWEEPS:
+            _SWEEPS["fixture"] = fixture_sweeps(c["n_sweeps"])
+        sweeps, traj = _SWEEPS["fixture"]
+        extra = dict(sweeps=sweeps, traj=traj, t0=0.0)
+    else:
+        extra = dict(sweeps=sweeps_of(c["kind"], c["n_sweeps"]))
     run_from_zero(lib, c["n_sweeps"], W=W, Wo=Wo, init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], configure=configure,
-                  on_step=on_step, est_factory=est_factory, sweeps=sweeps_of(c["kind"], c["n_sweeps"]))
+                  on_step=on_step, est_factory=est_factory, **extra)
     return rows
 
 

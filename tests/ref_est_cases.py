@@ -23,6 +23,9 @@ CASES = {
     # SURVEY.md 8(d) config 3 as written: the reference's own noisy IMU fixture (test/data/imu_pose_vel_noise.txt) drives the estimator,
     # VLP-16 sweeps ray-cast along its trajectory columns, indoor_test_config.yaml's 12 / 7 window, every third message while filling
     "fixture_12_7": dict(kind="indoor", n_sweeps=90, W=12, Wo=7, iwf=3, io=2, cfg={}, fixture=True),
+    # the same with estimate_extrinsic = 2: on this motion the hand-eye rotation (ImuInitializer::EstimateExtrinsicRotation) converges,
+    # replaces the configured lidar-IMU rotation, and the initialisation follows in the same message
+    "fixture_extrinsic2": dict(kind="indoor", n_sweeps=84, W=12, Wo=7, iwf=3, io=2, cfg=dict(extrinsic_stage=2), fixture=True),
     # switches of EstimatorConfig one at a time (indoor configuration otherwise)
     "indoor_fixed_extrinsic": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(opt_extrinsic=0)),
     "indoor_no_marginalization": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(marginalization_factor=0)),
@@ -104,7 +107,7 @@ def run_case(lib, name, est_factory=None, features_of=None, force_from=None):
         from fixture_util import fixture_sweeps
 
         if "fixture" not in _SWEEPS:
-            _SWEEPS["fixture"] = fixture_sweeps(c["n_sweeps"])
+            _SWEEPS["fixture"] = fixture_sweeps(max(k["n_sweeps"] for k in CASES.values() if k.get("fixture")))
         sweeps, traj = _SWEEPS["fixture"]
         extra = dict(sweeps=sweeps, traj=traj, t0=0.0)
     else:

@@ -64,14 +64,11 @@ int ref_est_process_compact(void *hv, const float *xyzi, size_t n, double stamp,
   m->xyzi.assign(xyzi, xyzi + 4 * n);
   m->header.stamp = ros::Time(stamp);
   const bool was_inited = e.stage_flag_ == lio::INITED;
-  const size_t count_before = e.cir_buf_count_, recv_before = e.laser_odom_recv_count_;
-  const size_t headers_before = e.Headers_.size();
+  const size_t count_before = e.cir_buf_count_;
   ceres::evaluate_log().clear();
   ceres::last_blocks().clear();
   ceres::last_summary() = ceres::Solver::Summary();
-  const double t_init_before = e.initial_time_;
   e.ProcessCompactData(m, m->header);
-  (void)recv_before; (void)headers_before;
   const bool inited = e.stage_flag_ == lio::INITED;
   int ev;
   if (was_inited) ev = 4;
@@ -79,7 +76,6 @@ int ref_est_process_compact(void *hv, const float *xyzi, size_t n, double stamp,
   else if (e.laser_odom_recv_count_ % size_t(e.estimator_config_.init_window_factor) != 0) ev = 0;
   else if (count_before < e.estimator_config_.window_size) ev = 1;
   else ev = 2;
-  (void)t_init_before;
   h->last_event = ev;
   if (T_out7) put(e.transform_aft_mapped_, T_out7);
   if (rep) {

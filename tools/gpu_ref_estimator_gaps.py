@@ -9,7 +9,11 @@ reference's state.  Prints, per step, the product's gap to the reference (and th
 velocity, biases, extrinsic, number of lidar factors, iteration count, final cost and the prior's JtJ.
     gpurun -- 'python tools/gpu_ref_estimator_gaps.py [case ...] > gpurun_out/ref_estimator_gaps.txt'
 The front end (PointProcessor / PointOdometry -> /compact_data) is the oracle's on both sides, as in the golden file: what differs is
-the estimator alone (before the initialisation that includes the product's scan-to-map stage on the GPU)."""
+the estimator alone (before the initialisation that includes the product's scan-to-map stage on the GPU).
+What to expect: the step at which the estimator initialises cannot be forced beforehand, and the product reaches it through its own
+fp32 scan-to-map chain (millimetres away from the reference's, tests/test_gpu_end_to_end.py); its SlideWindow then moves the stacked
+clouds with those states, and those clouds stay in the window for W more steps — so the first W steps after the initialisation carry
+that offset in their local map even though the states are forced, and only the later ones are a clean one-step comparison."""
 import os
 import sys
 

@@ -168,10 +168,10 @@ namespace lio {
 // as in the reference's utils/common_ros.h: convert, stamp, publish (the stand-in publisher keeps the last cloud message)
 template <typename PointT>
 inline void PublishCloudMsg(ros::Publisher &publisher, const pcl::PointCloud<PointT> &cloud, const ros::Time &stamp, std::string frame_id) {
-  sensor_msgs::PointCloud2 msg;
-  pcl::toROSMsg(cloud, msg);
-  msg.header.stamp = stamp;
-  msg.header.frame_id = frame_id;
-  publisher.publish(msg);
+  sensor_msgs::PointCloud2 out;
+  out.header.frame_id = frame_id;
+  out.header.stamp = stamp;
+  pcl::toROSMsg(cloud, out);      // (the stand-in conversion fills the xyzi payload only, the header set above stays)
+  publisher.publish(out);
 }
 }  // namespace lio

@@ -1,6 +1,6 @@
 """Generates tests/golden/ref_solve_problems.npz: sliding-window problems exactly as THE REFERENCE's Estimator::SolveOptimization handed
 them to ceres::Solve, with what came out — dumped from the reference's own Estimator.cc (oracle/_ref/libref_estimator.so, see
-oracle/ref_estimator.cc) while it runs the `indoor_iwf2` replay of tests/ref_est_cases.py.  Per dumped solve: the parameter blocks at
+oracle/ref_estimator.cc) while it runs two replays of tests/ref_est_cases.py.  Per dumped solve: the parameter blocks at
 the start, the raw IMU samples of every ImuFactor, every PivotPointPlaneFactor's point and plane, the marginalization prior that went
 in (canonical kept order), the extrinsic PriorFactor's constants; and the results: parameters at the end, iteration count, cost trace,
 the parameters the marginalization was linearised at and the prior it produced; and the first linearisation of the solve (J^T J,
@@ -21,15 +21,27 @@ from lio_amd import capi  # noqa: E402
 import ref_est_cases as cases  # noqa: E402
 import ref_est_util  # noqa: E402
 
-CASE, STEPS = "indoor_iwf2", (1, 2)      # estimator steps after the initialisation: 1 = first solve with no prior going in, 2 = with one
+# (case of tests/ref_est_cases.py, estimator steps after the initialisation to dump)
+#   indoor_iwf2: a 5 / 2 window — step 1 = the first solve with no prior going in (gauge-free), step 2 = with a prior and a free extrinsic
+#   indoor_prior_factor: a 6 / 3 window with the extrinsic PriorFactor — step 2, a well-posed problem
+DUMPS = (("indoor_iwf2", (1, 2)), ("indoor_prior_factor", (2,)))
 
 
 def main():
-    from replay_util import run_from_zero
-
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liblio_oracle.so", "ref"], check=True)
     orc = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
     ref = ref_est_util.load()
+    out = {}
+    for case, steps in DUMPS:
+        for k, v in dump_case(orc, ref, case, steps).items():
+            out[case + "/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "ref_solve_problems.npz"), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+def dump_case(orc, ref, CASE, STEPS):
+    from replay_util import run_from_zero
+
     c = cases.CASES[CASE]
     out, state = {}, dict(s=-1, prior_in=None)
 
@@ -77,8 +89,8 @@ def main():
         at += 1 + n * n + n
         k += 1
     os.remove(hg_path)
-    np.savez_compressed(os.path.join(HERE, "ref_solve_problems.npz"), **out)
-    print({k: v.shape for k, v in out.items()})
+    del os.environ["REF_SHIM_DUMP_HG"]
+    return out
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """The PRODUCT's host solver against the reference's own solve, on the CPU (no GPU, no oracle in between).
 
-tests/golden/ref_solve_problems.npz holds two sliding-window problems exactly as hyye/lio-mapping's Estimator::SolveOptimization handed
+tests/golden/ref_solve_problems.npz holds three sliding-window problems exactly as hyye/lio-mapping's Estimator::SolveOptimization handed
 them to ceres::Solve during a replay (dumped from the reference's own Estimator.cc compiled where it lies, see
 tests/golden/make_ref_solve_problems.py): parameter blocks, the raw IMU samples behind every ImuFactor, ~13.8 k PivotPointPlaneFactor
 points and planes, the marginalization prior that went in, the extrinsic-prior constants — and what came out: the parameters after the
@@ -13,11 +13,13 @@ PriorFactor): the product's moment form of the lidar normal equations (H_i = L S
 marginalization.  The minimizer on the reference's side is the stand-in of oracle/ref_shim/ceres/problem.h (Ceres itself is absent), so
 the iteration sequence is compared between two restatements of Ceres 1.14's dogleg.
 
-The two problems are the hard ones of the replay: a 5 / 2 window, first without any prior (the absolute pose is a gauge freedom: the
+Two of the problems are the hard ones of a replay: a 5 / 2 window, first without any prior (the absolute pose is a gauge freedom: the
 scaled normal matrix has its smallest eigenvalue at the 1e-8 regularisation), then with a prior and a free, nearly unobservable
 extrinsic.  Measured: first linearisation (H, g) equal to 1e-14 / 6e-13 relative; the same 10 iterations; every cost of the trace
 within 2e-9 / 2e-7 relative; positions after the solve within 2e-8 / 1.4e-7 m (relative positions 2.5e-9 / 2.8e-7), velocities 1e-8 /
 1.4e-6, the free extrinsic 9e-6 m; the new prior's JtJ within 1e-9 / 4e-9 of its largest entry, Jtr 3e-10 / 8e-7, x0 equal.
+The third is a well-posed one (a 6 / 3 window with the extrinsic PriorFactor, ~20 k plane factors): first linearisation 9e-15 / 5e-12,
+trace 2e-11, positions 3e-9 m, the new prior's JtJ 1.6e-9.
 Bounds: 1e-6 m and rad on poses (the north star asks 1e-4 after the same iteration count), 1e-5 on velocities, 1e-4 on the extrinsic,
 1e-6 relative on the trace, 1e-7 / 1e-5 on JtJ / Jtr."""
 import os
@@ -38,8 +40,11 @@ def exe(tmp_path_factory):
     return out
 
 
-def pack(step):
-    k = "s%d/" % step
+PROBLEMS = [("indoor_iwf2", 1), ("indoor_iwf2", 2), ("indoor_prior_factor", 2)]
+
+
+def pack(case, step):
+    k = "%s/s%d/" % (case, step)
     h = G[k + "header"]
     Wo, has_prior = int(h[0]), int(h[2])
     parts = [h, G[k + "initial"], G[k + "para"]]
@@ -63,11 +68,11 @@ def pack(step):
     return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts])
 
 
-@pytest.mark.parametrize("step", [1, 2])
-def test_product_host_solver_on_the_reference_problem(exe, tmp_path, step):
-    k = "s%d/" % step
+@pytest.mark.parametrize("case,step", PROBLEMS)
+def test_product_host_solver_on_the_reference_problem(exe, tmp_path, case, step):
+    k = "%s/s%d/" % (case, step)
     path = str(tmp_path / "problem.f64")
-    pack(step).tofile(path)
+    pack(case, step).tofile(path)
     r = subprocess.run([exe, path], capture_output=True, text=True, env=dict(os.environ, LIO_SPLIT_FACTOR="0", LIO_CHECK_DUMP_HG="1"))
     assert r.returncode == 0, r.stderr
     out = {ln.split()[0]: np.array(ln.split()[1:], float) for ln in r.stdout.strip().split("\n")}
@@ -98,5 +103,5 @@ def test_product_host_solver_on_the_reference_problem(exe, tmp_path, step):
     rr = float(np.abs(out["Jtr"] - G[k + "Jtr"]).max() / np.abs(G[k + "Jtr"]).max())
     assert rj <= 1e-7 and rr <= 1e-5, (rj, rr)
     np.testing.assert_allclose(out["x0"], G[k + "x0"], rtol=0, atol=1e-15)
-    print("step", step, "first linearisation dH %.1e dg %.1e" % (dH, dg), "has prior", int(G[k + "header"][2]), "iterations", it, "param gap %.1e" % gap,
+    print(case, "step", step, "first linearisation dH %.1e dg %.1e" % (dH, dg), "has prior", int(G[k + "header"][2]), "iterations", it, "param gap %.1e" % gap,
           "trace gap %.1e" % float(np.abs(out["trace"][:want_it + 1] / trace - 1).max()), "JtJ %.1e Jtr %.1e" % (rj, rr))

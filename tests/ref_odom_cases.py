@@ -15,7 +15,7 @@ def bits(a):
 def cases():
     """-> list of (name, kind, n_sweeps, io_ratio, no_deskew, disable_after)"""
     return [("indoor_io2", "indoor", 4, 2, 0, None), ("outdoor_io3", "outdoor", 3, 3, 0, None), ("indoor_no_deskew", "indoor", 3, 2, 1, None),
-            ("indoor_packer_after_1", "indoor", 3, 2, 0, 1)]
+            ("indoor_packer_after_1", "indoor", 3, 2, 0, 1), ("indoor_io1_long", "indoor", 8, 1, 0, None), ("outdoor_no_deskew", "outdoor", 3, 2, 1, None)]
 
 
 def full_cloud_for(case, cl, k):

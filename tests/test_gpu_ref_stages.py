@@ -100,3 +100,22 @@ def test_map_builder_matches_the_reference(hip, oracle):
             worst = [max(worst[0], dp), max(worst[1], dq)]
             assert dp < 1e-4 and dq < 1e-4, (k, key, dp, dq)
     print("product vs MapBuilder.cc: worst |dp|", worst[0], "worst |dq|", worst[1])
+
+
+@pytest.mark.parametrize("scene,kz", [("corridor_below_threshold", 1), ("corridor_above_threshold", 0)])
+def test_scan_to_map_degeneracy_matches_the_reference(hip, oracle, scene, kz):
+    """The corridor on either side of the eigenvalue threshold (PointMapping.cc:650-680), frame 1 as in tests/test_gpu_degenerate.py,
+    against the transform the reference's PointMapping.cc wrote (tests/golden/ref_degenerate_mapping.json)."""
+    import degenerate_util as du
+    from mapping_util import drifting_inputs
+
+    factory, sigma, _ = du.MAPPING_SCENES[scene]
+    frames = drifting_inputs(oracle, "indoor", 2, scene=factory(), traj=synth.traj_corridor(), range_sigma=sigma)
+    want = _gold("ref_degenerate_mapping.json")[scene]
+    m = capi.PointMapping(hip)
+    m.process(*frames[0][:3])
+    r = m.process(*frames[1][:3])
+    assert r["kz"] == kz
+    dp, dq = _pose_gap(np.concatenate([r["T_aft"][0], r["T_aft"][1]]).astype(float), _f(want[1]))
+    print(scene, "product vs PointMapping.cc: |dp|", dp, "|dq|", dq)
+    assert dp < 1e-4 and dq < 1e-4

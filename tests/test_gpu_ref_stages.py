@@ -119,3 +119,25 @@ def test_scan_to_map_degeneracy_matches_the_reference(hip, oracle, scene, kz):
     dp, dq = _pose_gap(np.concatenate([r["T_aft"][0], r["T_aft"][1]]).astype(float), _f(want[1]))
     print(scene, "product vs PointMapping.cc: |dp|", dp, "|dq|", dq)
     assert dp < 1e-4 and dq < 1e-4
+
+
+def test_scan_to_scan_on_the_two_pole_ground_matches_the_reference(hip, oracle):
+    """The regular member of the ground-plane family (kz = 0, smallest eigenvalue just above the scan-to-scan threshold of 10), as in
+    tests/test_gpu_degenerate.py, against the transform_es_ the reference's PointOdometry.cc wrote
+    (tests/golden/ref_degenerate_odometry.json)."""
+    import degenerate_util as du
+
+    cl, singular = du.odometry_sweeps(oracle, "ground_two_poles", 3)
+    assert not singular
+    want = _gold("ref_degenerate_odometry.json")["ground_two_poles"]
+    od = capi.PointOdometry(hip, 0.1, 2, 25, False)
+    worst = 0.0
+    for k, c in enumerate(cl):
+        r = od.process(*c)
+        if k == 0:
+            continue
+        assert r["kz"] == 0
+        es = np.concatenate([r["T_es"][0], r["T_es"][1]]).astype(float)
+        worst = max(worst, float(np.abs(es - _f(want[k])).max()))
+        np.testing.assert_allclose(es, _f(want[k]), atol=1e-5)
+    print("product vs PointOdometry.cc on the two-pole ground: worst |dT_es|", worst)

@@ -8,7 +8,7 @@
 //   :2440-2568 VectorToDouble / DoubleToVector        :2570-2666 SlideWindow
 //   include/utils/CircularBuffer.h:164-172 (push-on-full semantics, A.12)
 // Pinned (round 3) against the reference's own Estimator.cc, compiled where it lies against oracle/ref_shim (oracle/ref_estimator.cc ->
-// _ref/libref_estimator.so; Ceres' Problem / Solve stood in): twelve replays from t = 0 (BASELINE.json's HDL-64E / window-15 configuration among them), tests/golden/ref_estimator_run.npz,
+// _ref/libref_estimator.so; Ceres' Problem / Solve stood in): thirteen replays from t = 0 (BASELINE.json's HDL-64E / window-15 configuration among them), tests/golden/ref_estimator_run.npz,
 // tests/test_ref_estimator_run.py — events, factor counts, iteration counts equal; states within 3e-9 m step by step (1.2e-7 once).
 // Compile-time switches of the reference kept at their shipped values: USE_CORNER off, FIX_MAP off
 // (Estimator.h:55-56).  The wall-clock solver cap (A.14) is a config knob (max_solver_time).

@@ -14,7 +14,7 @@
 //     1e-6, parameter_tolerance 1e-8, gradient_tolerance 1e-10, max_consecutive_invalid_steps 5.
 //     Round 3: the PROBLEM of (1) is pinned against the reference's own SolveOptimization (oracle/ref_estimator.cc; the stand-in
 //     ceres::Solve there is this same restatement over generic blocks, so the minimizer stays unpinned) — equal factor counts and
-//     costs within 1e-8 on 59 estimator steps, tests/test_ref_estimator_run.py.
+//     costs within 1e-8 on 63 estimator steps, tests/test_ref_estimator_run.py.
 // (3) MarginalizationInfo::Marginalize (MarginalizationFactor.cc:185-311) and
 //     MarginalizationFactor::Evaluate (:343-393) in the canonical block order of SURVEY.md A.13.
 #pragma once

@@ -34,6 +34,8 @@ CASES = {
     # then keeps only the blocks its remaining factors touch (pose 1, speed-bias 1: n = 15) where the oracle and the product keep
     # their fixed layout with empty rows for the rest (n = 33) — the same information; the prior is not compared in this case
     "indoor_imu_only": dict(kind="indoor", n_sweeps=20, W=6, Wo=3, iwf=1, io=2, cfg=dict(point_distance_factor=0), prior_layout_differs=True),
+    # SURVEY.md 8(d) config 4's stress setting: the whole window optimised (Wo = W = 15) on the HDL-64E
+    "outdoor64_15_15": dict(kind="outdoor", n_sweeps=57, W=15, Wo=15, iwf=1, io=3, cfg={}),
     # estimate_extrinsic = 2: the hand-eye rotation has to converge first (it does not on this motion: same refusals on both sides)
     "indoor_extrinsic2": dict(kind="indoor", n_sweeps=18, W=6, Wo=3, iwf=1, io=2, cfg=dict(extrinsic_stage=2)),
 }

@@ -24,7 +24,8 @@ import ref_est_util  # noqa: E402
 # (case of tests/ref_est_cases.py, estimator steps after the initialisation to dump)
 #   indoor_iwf2: a 5 / 2 window — step 1 = the first solve with no prior going in (gauge-free), step 2 = with a prior and a free extrinsic
 #   indoor_prior_factor: a 6 / 3 window with the extrinsic PriorFactor — step 2, a well-posed problem
-DUMPS = (("indoor_iwf2", (1, 2)), ("indoor_prior_factor", (2,)))
+#   outdoor64_15_5: BASELINE.json's headline configuration (HDL-64E, window 15 / 5, ~46 k plane factors, 96 unknowns) — step 2
+DUMPS = (("indoor_iwf2", (1, 2)), ("indoor_prior_factor", (2,)), ("outdoor64_15_5", (2,)))
 
 
 def main():
@@ -65,7 +66,9 @@ def dump_case(orc, ref, CASE, STEPS):
                 if f is not None:
                     out[key + "imu%d_head" % j], out[key + "imu%d_samples" % j] = f
             for i in range(1, est.Wo + 1):
-                out[key + "pts%d" % i], out[key + "coef%d" % i] = est.features(i)
+                pt, co = est.features(i)
+                assert np.array_equal(pt, pt.astype(np.float32)) and np.array_equal(co, co.astype(np.float32))   # (float-valued: stored as such)
+                out[key + "pts%d" % i], out[key + "coef%d" % i] = pt.astype(np.float32), co.astype(np.float32)
             if pb["has_prior"]:
                 pin = state["prior_in"]
                 out[key + "prior_in_blocks"] = np.array(pin["blocks"], np.int32)       # kind, index, column offset, ambient size

@@ -1,6 +1,6 @@
 """The PRODUCT's host solver against the reference's own solve, on the CPU (no GPU, no oracle in between).
 
-tests/golden/ref_solve_problems.npz holds three sliding-window problems exactly as hyye/lio-mapping's Estimator::SolveOptimization handed
+tests/golden/ref_solve_problems.npz holds four sliding-window problems exactly as hyye/lio-mapping's Estimator::SolveOptimization handed
 them to ceres::Solve during a replay (dumped from the reference's own Estimator.cc compiled where it lies, see
 tests/golden/make_ref_solve_problems.py): parameter blocks, the raw IMU samples behind every ImuFactor, ~13.8 k PivotPointPlaneFactor
 points and planes, the marginalization prior that went in, the extrinsic-prior constants — and what came out: the parameters after the
@@ -19,7 +19,8 @@ extrinsic.  Measured: first linearisation (H, g) equal to 1e-14 / 6e-13 relative
 within 2e-9 / 2e-7 relative; positions after the solve within 2e-8 / 1.4e-7 m (relative positions 2.5e-9 / 2.8e-7), velocities 1e-8 /
 1.4e-6, the free extrinsic 9e-6 m; the new prior's JtJ within 1e-9 / 4e-9 of its largest entry, Jtr 3e-10 / 8e-7, x0 equal.
 The third is a well-posed one (a 6 / 3 window with the extrinsic PriorFactor, ~20 k plane factors): first linearisation 9e-15 / 5e-12,
-trace 2e-11, positions 3e-9 m, the new prior's JtJ 1.6e-9.
+trace 2e-11, positions 3e-9 m, the new prior's JtJ 1e-9.  The fourth is BASELINE.json's headline configuration (HDL-64E, window 15 / 5,
+~46 k plane factors, 96 unknowns): first linearisation 4e-14 / 4e-12, trace 4e-11, positions 6e-8 m, JtJ 2e-10.
 Bounds: 1e-6 m and rad on poses (the north star asks 1e-4 after the same iteration count), 1e-5 on velocities, 1e-4 on the extrinsic,
 1e-6 relative on the trace, 1e-7 / 1e-5 on JtJ / Jtr."""
 import os
@@ -40,7 +41,7 @@ def exe(tmp_path_factory):
     return out
 
 
-PROBLEMS = [("indoor_iwf2", 1), ("indoor_iwf2", 2), ("indoor_prior_factor", 2)]
+PROBLEMS = [("indoor_iwf2", 1), ("indoor_iwf2", 2), ("indoor_prior_factor", 2), ("outdoor64_15_5", 2)]
 
 
 def pack(case, step):

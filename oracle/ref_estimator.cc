@@ -217,6 +217,29 @@ int ref_est_get_imu_factor(void *hv, int i, double *head12, double *samples, int
   return -1;
 }
 
+// ---- the estimator's buffers as they stand (after ProcessCompactData: post-slide), by logical index of the reference's CircularBuffers,
+// for tests that inject this state into another implementation and take ONE step from it
+// the pre-integration in window slot `slot` (0..W): returns the number of samples (-1: none); head / samples as ref_est_get_imu_factor
+int ref_est_get_preintegration(void *hv, int slot, double *head12, double *samples, int capacity) {
+  lio::Estimator &e = *static_cast<Handle *>(hv)->est;
+  if (slot < 0 || size_t(slot) >= e.pre_integrations_.size() || !e.pre_integrations_[slot]) return -1;
+  const lio::IntegrationBase &p = *e.pre_integrations_[slot];
+  const int n = int(p.dt_buf_.size());
+  if (n > capacity) return -2;
+  for (int k = 0; k < 3; ++k) { head12[k] = p.linearized_acc_(k); head12[3 + k] = p.linearized_gyr_(k); head12[6 + k] = p.linearized_ba_(k); head12[9 + k] = p.linearized_bg_(k); }
+  for (int s = 0; s < n; ++s) {
+    samples[7 * s] = p.dt_buf_[s];
+    for (int k = 0; k < 3; ++k) { samples[7 * s + 1 + k] = p.acc_buf_[s](k); samples[7 * s + 4 + k] = p.gyr_buf_[s](k); }
+  }
+  return n;
+}
+// the pre-integration in flight (tmp_pre_integration_): acc, gyr, ba, bg it was started from
+void ref_est_get_tmp_preintegration(void *hv, double *head12) {
+  lio::Estimator &e = *static_cast<Handle *>(hv)->est;
+  const lio::IntegrationBase &p = *e.tmp_pre_integration_;
+  for (int k = 0; k < 3; ++k) { head12[k] = p.linearized_acc_(k); head12[3 + k] = p.linearized_gyr_(k); head12[6 + k] = p.linearized_ba_(k); head12[9 + k] = p.linearized_bg_(k); }
+}
+
 // ---- MeasurementManager::GetMeasurements alone (MeasurementManager.cc:54-108): messages in, pairings out
 void *ref_mm_create(double msg_time_delay) {
   lio::MeasurementManager *m = new lio::MeasurementManager();

@@ -35,6 +35,9 @@ def load():
     lib.ref_est_get_para.argtypes = [C.c_void_p] * 2
     lib.ref_est_get_imu_factor.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     lib.ref_est_get_imu_factor.restype = C.c_int
+    lib.ref_est_get_preintegration.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.ref_est_get_preintegration.restype = C.c_int
+    lib.ref_est_get_tmp_preintegration.argtypes = [C.c_void_p, C.c_void_p]
     lib.ref_mm_create.restype = C.c_void_p
     lib.ref_mm_create.argtypes = [C.c_double]
     lib.ref_mm_destroy.argtypes = [C.c_void_p]
@@ -147,6 +150,27 @@ class RefEstimator:
             assert k >= -1
             imu.append(None if k < 0 else (head, smp[:7 * k].reshape(k, 7).copy()))
         return dict(initial=ini, final=fin, para=para, ex_constant=int(flags[0]), has_prior=int(flags[1]), use_prior_factor=int(flags[2]), prior7=pr7, imu=imu)
+
+    def state_dump(self):
+        """everything another implementation needs to continue from where this estimator stands (after a processed message): the
+        window, extrinsic, gravity, per window slot the surf stack and the pre-integration's raw samples, what the pre-integration in
+        flight was started from, the prior (canonical order)"""
+        w, st = self.get_window(), self.stage()
+        d = dict(Ps=w["Ps"], Rs=w["Rs"], Vs=w["Vs"], Bas=w["Bas"], Bgs=w["Bgs"], lb=np.concatenate([w["q_lb"], w["t_lb"]]).astype(float), g_vec=st["g_vec"])
+        for i in range(self.W + 1):
+            d["stack%d" % i] = self.surf_stack(i)
+            head, smp = np.zeros(12), np.zeros(7 * 4096)
+            k = self.lib.ref_est_get_preintegration(self.h, i, _p(head), _p(smp), 4096)
+            assert k >= -1
+            if k >= 0:
+                d["pre%d_head" % i], d["pre%d_samples" % i] = head, smp[:7 * k].reshape(k, 7).copy()
+        tmp = np.zeros(12)
+        self.lib.ref_est_get_tmp_preintegration(self.h, _p(tmp))
+        d["tmp_head"] = tmp
+        pr = self.prior()
+        if pr is not None:
+            d.update(prior_n=np.array(pr["n"]), prior_jac=pr["lin_jac"], prior_res=pr["lin_res"], prior_x0=pr["x0"])
+        return d
 
     def prior(self):
         """dict(n, JtJ, Jtr, x0) in the oracle's canonical kept order (pose1, sb1, pose2 .. poseWo, extrinsic -> after the address shift:

@@ -1,0 +1,133 @@
+"""One estimator step taken from THE REFERENCE'S state (shared by tests/test_ref_estimator_state.py — oracle, CPU — and
+tests/test_gpu_ref_estimator.py — product, GPU).
+
+tests/golden/ref_estimator_states.npz holds what the reference's own Estimator.cc (oracle/ref_estimator.cc) had in its buffers after
+two consecutive laser messages of the `indoor` replay of tests/ref_est_cases.py — window states, extrinsic, gravity, the surf stack and
+the raw IMU samples of the pre-integration of every window slot, what the pre-integration in flight was started from, the
+marginalization prior — and what it had one message later.  `one_step(lib)` builds an estimator of
+`lib`, injects the first state through the test hooks of the C-ABI (lio_est_set_window / set_surf_stack / set_preintegration /
+begin_frame / set_extrinsic), feeds the next message (so that the estimator owns a prior of the right shape), overwrites EVERYTHING with
+the reference's second state (now including the prior), feeds the following message, and returns what came out: one
+ProcessImu ... ProcessLaserOdom -> SolveOptimization -> SlideWindow step from exactly the reference's state, to be compared with the
+reference's own next state.  Index conventions are the reference's: buffers are dumped by the logical index of its CircularBuffers after
+SlideWindow (states already shifted, stacks and pre-integrations shifted by the next push), which is also how the oracle and the product
+hold them."""
+import os
+
+import numpy as np
+
+import ref_est_cases as cases
+from lio_amd import capi, pipeline
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STATES = os.path.join(HERE, "golden", "ref_estimator_states.npz")
+RUN = os.path.join(HERE, "golden", "ref_estimator_run.npz")
+CASE = "indoor"
+STEP_A, STEP_B = 3, 4          # estimator steps after the initialisation (0 = the step that initialised); compared: step 5
+
+
+class Recorder:
+    """stands in for the estimator inside lio_amd.replay.Replay and keeps what it was fed: per laser message the IMU batch, the
+    /compact_data message and the stamp.  It answers stage() from the reference's recorded events (the replay switches the odometry to
+    its packer mode once the estimator is initialised)."""
+
+    def __init__(self, events, W):
+        self.events, self.W, self.batch, self.msgs = events, W, [], []
+
+    def process_imu(self, dt, acc, gyr, t):
+        self.batch.append((float(dt), np.array(acc, float), np.array(gyr, float), float(t)))
+
+    def process_compact(self, compact, stamp):
+        self.msgs.append((self.batch, np.array(compact, np.float32), float(stamp)))
+        self.batch = []
+        return (np.array([0, 0, 0, 1.0], np.float32), np.zeros(3, np.float32)), None
+
+    def stage(self):
+        k = len(self.msgs) - 1
+        ev = self.events[k] if k < len(self.events) else "solved"
+        inited = ("initialised" in self.events[:k + 1])
+        return dict(inited=inited, event=ev, cir_buf_count=0, extrinsic_stage=1, R_WI=np.eye(3), g_vec=np.zeros(3))
+
+    def get_window(self):
+        return None
+
+
+def messages(oracle):
+    """the laser messages of the case, as the estimator is fed them (front end: the oracle's, as for the golden files)"""
+    from replay_util import run_from_zero
+
+    c = cases.CASES[CASE]
+    events = [str(e) for e in np.load(RUN)[CASE + "/events"]]
+    holder = {}
+
+    def factory(cfg):
+        holder["rec"], holder["cfg"] = Recorder(events, c["W"]), cfg
+        return holder["rec"]
+
+    run_from_zero(oracle, c["n_sweeps"], W=c["W"], Wo=c["Wo"], init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], est_factory=factory,
+                  sweeps=cases.sweeps_of(c["kind"], c["n_sweeps"]))
+    return holder["rec"].msgs, events
+
+
+def config_for(lib):
+    c = cases.CASES[CASE]
+    cfg = pipeline.config_indoor(lib, c["W"], c["Wo"])          # (what run_from_zero builds for the indoor kind)
+    cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
+    cfg.init_window_factor, cfg.extrinsic_stage = c["iwf"], 1
+    for k, v in c["cfg"].items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def inject(est, d, with_prior):
+    W = est.W
+    # the pre-integration in flight keeps the biases it was started with (the newest frame's BEFORE the solve): hand those to begin_frame
+    # through slot W, then set the real window
+    Bas, Bgs = np.array(d["Bas"]), np.array(d["Bgs"])
+    Bas[W], Bgs[W] = d["tmp_head"][6:9], d["tmp_head"][9:12]
+    est.set_window(d["Ps"], d["Rs"], d["Vs"], Bas, Bgs, d["g_vec"])
+    est.begin_frame(d["tmp_head"][0:3], d["tmp_head"][3:6])
+    est.set_window(d["Ps"], d["Rs"], d["Vs"], d["Bas"], d["Bgs"], d["g_vec"])
+    est.set_extrinsic(d["lb"][:4], d["lb"][4:])
+    for i in range(W + 1):
+        # slots behind the pivot are not stored (spent local maps, never read again by a solve): one point far from the scene stands in
+        est.set_surf_stack(i, d["stack%d" % i] if "stack%d" % i in d else np.array([[200.0, 200.0, 50.0, 0.0]], np.float32))
+        if "pre%d_head" % i in d:
+            h, s = d["pre%d_head" % i], d["pre%d_samples" % i]
+            est.set_preintegration(i, h[0:3], h[3:6], h[6:9], h[9:12], s[:, 0], s[:, 1:4], s[:, 4:7])
+    if with_prior:
+        est.set_prior_factor(dict(n=int(d["prior_n"]), lin_jac=d["prior_jac"], lin_res=d["prior_res"], x0=d["prior_x0"]))
+
+
+def feed(est, msg):
+    """one laser message after the initialisation: ProcessImu per sample, then ProcessLaserOdom on the message's clouds — what
+    lio_est_process_compact does then (the transform it hands over only goes into the initialisation's buffers), through the entry point
+    the injected-window tests use (lio_amd.pipeline.feed_frame)"""
+    batch, compact, stamp = msg
+    for dt, acc, gyr, t in batch:
+        est.process_imu(dt, acc, gyr, t)
+    _, corner, surf, _ = est.lib.compact_decode(compact)
+    return None, est.process_laser_odom(capi.TransformF.make([0, 0, 0, 1], [0, 0, 0]), surf, corner, stamp)
+
+
+def load_states():
+    g = np.load(STATES)
+    out = {}
+    for key in g.files:
+        tag, field = key.split("/")
+        out.setdefault(tag, {})[field] = g[key]
+    return out["A"], out["B"], out["C"]
+
+
+def one_step(lib, oracle):
+    """-> `lib`'s estimator after ONE step from the reference's state B, its solve report, and what the reference itself had after that
+    step (C: window, extrinsic, prior, solve summary, local-map digest — from the same run of the reference as A and B)"""
+    msgs, events = messages(oracle)
+    k0 = events.index("initialised")
+    A, B, C = load_states()
+    est = capi.Estimator(lib, config_for(lib))
+    inject(est, A, with_prior=False)
+    feed(est, msgs[k0 + STEP_A + 1])
+    inject(est, B, with_prior=True)
+    _, rep = feed(est, msgs[k0 + STEP_B + 1])
+    return est, rep, C

@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r4a
 mkdir -p $O
 cd $R
-(timeout 400 python -m pytest tests/test_gpu_ref_estimator.py tests/test_gpu_ref_stages.py tests/test_gpu_ref_pointproc.py -q -s -m gpu > $O/pytest_gpu_ref.log 2>&1; echo rc=$? >> $O/pytest_gpu_ref.log)
+(timeout 400 python -m pytest tests/test_gpu_zz_ref_state.py tests/test_gpu_ref_estimator.py tests/test_gpu_ref_stages.py tests/test_gpu_ref_pointproc.py -q -s -m gpu > $O/pytest_gpu_ref.log 2>&1; echo rc=$? >> $O/pytest_gpu_ref.log)
 (timeout 1000 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log)
 (timeout 600 python tools/gpu_ref_estimator_gaps.py indoor indoor_12_7 outdoor64 > $O/ref_estimator_gaps.txt 2> $O/ref_estimator_gaps.err)
 (timeout 400 python bench.py > $O/bench.json 2> $O/bench.err)

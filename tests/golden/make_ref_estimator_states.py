@@ -24,7 +24,19 @@ def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liblio_oracle.so", "ref"], check=True)
     orc = capi.LioLib(os.path.join(ROOT, "oracle", "liblio_oracle.so"))
     ref = ref_est_util.load()
-    c = cases.CASES[su.CASE]
+    out = {}
+    for case in su.STEPS:
+        for k, v in dump_case(orc, ref, case).items():
+            out[case + "/" + k] = v
+    np.savez_compressed(su.STATES, **out)
+    print({k: v.shape for k, v in out.items() if "stack" in k or k.endswith("/C/solve")})
+
+
+def dump_case(orc, ref, CASE):
+    from replay_util import run_from_zero
+
+    c = cases.CASES[CASE]
+    STEP_A, STEP_B = su.STEPS[CASE]
     out, state = {}, dict(s=-1)
 
     def configure(cfg):
@@ -35,15 +47,15 @@ def main():
         if not rp.est.stage()["inited"]:
             return
         state["s"] += 1
-        for tag, step in (("A", su.STEP_A), ("B", su.STEP_B)):
+        for tag, step in (("A", STEP_A), ("B", STEP_B)):
             if state["s"] == step:
                 pivot = c["W"] - c["Wo"]
                 for key, v in rp.est.state_dump().items():
-                    if key.startswith("stack") and int(key[5:]) < pivot:
-                        continue                  # slots behind the pivot are never read again by a solve (their clouds are spent local maps)
+                    if key.startswith("stack") and int(key[5:]) <= pivot:
+                        continue                  # after the next push these are the slots behind the pivot: spent local maps, never read again
                     out[tag + "/" + key] = np.asarray(v)
 
-        if state["s"] == su.STEP_B + 1:        # what the reference itself had one message after B — from the SAME run (two runs of
+        if state["s"] == STEP_B + 1:        # what the reference itself had one message after B — from the SAME run (two runs of
             rep, w, pr = e["report"], rp.est.get_window(), rp.est.prior()   # the reference part ways at the 1e-15 level and drift)
             lm = rp.est.local_map()
             out.update({"C/Ps": w["Ps"], "C/Rs": w["Rs"], "C/Vs": w["Vs"], "C/Bas": w["Bas"], "C/Bgs": w["Bgs"],
@@ -55,8 +67,7 @@ def main():
     n = c["n_sweeps"]
     run_from_zero(orc, n, W=c["W"], Wo=c["Wo"], init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], configure=configure, on_step=on_step,
                   est_factory=lambda cfg: ref_est_util.RefEstimator(ref, cfg), sweeps=cases.sweeps_of(c["kind"], n))
-    np.savez_compressed(su.STATES, **out)
-    print({k: v.shape for k, v in out.items()})
+    return out
 
 
 if __name__ == "__main__":

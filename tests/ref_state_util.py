@@ -2,7 +2,7 @@
 tests/test_gpu_ref_estimator.py — product, GPU).
 
 tests/golden/ref_estimator_states.npz holds what the reference's own Estimator.cc (oracle/ref_estimator.cc) had in its buffers after
-two consecutive laser messages of the `indoor` replay of tests/ref_est_cases.py — window states, extrinsic, gravity, the surf stack and
+two consecutive laser messages of the `indoor` and `outdoor64` replays of tests/ref_est_cases.py — window states, extrinsic, gravity, the surf stack and
 the raw IMU samples of the pre-integration of every window slot, what the pre-integration in flight was started from, the
 marginalization prior — and what it had one message later.  `one_step(lib)` builds an estimator of
 `lib`, injects the first state through the test hooks of the C-ABI (lio_est_set_window / set_surf_stack / set_preintegration /
@@ -22,8 +22,10 @@ from lio_amd import capi, pipeline
 HERE = os.path.dirname(os.path.abspath(__file__))
 STATES = os.path.join(HERE, "golden", "ref_estimator_states.npz")
 RUN = os.path.join(HERE, "golden", "ref_estimator_run.npz")
-CASE = "indoor"
-STEP_A, STEP_B = 3, 4          # estimator steps after the initialisation (0 = the step that initialised); compared: step 5
+# case of tests/ref_est_cases.py -> (STEP_A, STEP_B): estimator steps after the initialisation (0 = the step that initialised) whose states
+# are stored; compared: step STEP_B + 1.  `indoor`: VLP-16, kept features, IMU de-skew, free extrinsic, no prior factor;
+# `outdoor64`: HDL-64E, extrinsic PriorFactor, cut-off de-skew
+STEPS = {"indoor": (3, 4), "outdoor64": (1, 2)}
 
 
 class Recorder:
@@ -52,7 +54,7 @@ class Recorder:
         return None
 
 
-def messages(oracle):
+def messages(oracle, CASE):
     """the laser messages of the case, as the estimator is fed them (front end: the oracle's, as for the golden files)"""
     from replay_util import run_from_zero
 
@@ -69,10 +71,14 @@ def messages(oracle):
     return holder["rec"].msgs, events
 
 
-def config_for(lib):
+def config_for(lib, CASE):
     c = cases.CASES[CASE]
-    cfg = pipeline.config_indoor(lib, c["W"], c["Wo"])          # (what run_from_zero builds for the indoor kind)
-    cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
+    if c["kind"] == "indoor":                                    # (what run_from_zero builds for the two kinds)
+        cfg = pipeline.config_indoor(lib, c["W"], c["Wo"])
+        cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [0.0, 0.0, -0.081939])
+    else:
+        cfg = pipeline.config_outdoor64(lib, c["W"], c["Wo"])
+        cfg.transform_lb = capi.TransformF.make([0, 0, 0, 1], [-8.086759e-01, 3.195559e-01, -7.997231e-01])
     cfg.init_window_factor, cfg.extrinsic_stage = c["iwf"], 1
     for k, v in c["cfg"].items():
         setattr(cfg, k, v)
@@ -90,7 +96,8 @@ def inject(est, d, with_prior):
     est.set_window(d["Ps"], d["Rs"], d["Vs"], d["Bas"], d["Bgs"], d["g_vec"])
     est.set_extrinsic(d["lb"][:4], d["lb"][4:])
     for i in range(W + 1):
-        # slots behind the pivot are not stored (spent local maps, never read again by a solve): one point far from the scene stands in
+        # slots that lie behind the pivot after the next push are not stored (spent local maps, never read again by a solve): one point far
+        # from the scene stands in
         est.set_surf_stack(i, d["stack%d" % i] if "stack%d" % i in d else np.array([[200.0, 200.0, 50.0, 0.0]], np.float32))
         if "pre%d_head" % i in d:
             h, s = d["pre%d_head" % i], d["pre%d_samples" % i]
@@ -110,22 +117,24 @@ def feed(est, msg):
     return None, est.process_laser_odom(capi.TransformF.make([0, 0, 0, 1], [0, 0, 0]), surf, corner, stamp)
 
 
-def load_states():
+def load_states(CASE):
     g = np.load(STATES)
     out = {}
     for key in g.files:
-        tag, field = key.split("/")
-        out.setdefault(tag, {})[field] = g[key]
+        case, tag, field = key.split("/")
+        if case == CASE:
+            out.setdefault(tag, {})[field] = g[key]
     return out["A"], out["B"], out["C"]
 
 
-def one_step(lib, oracle):
+def one_step(lib, oracle, CASE="indoor"):
     """-> `lib`'s estimator after ONE step from the reference's state B, its solve report, and what the reference itself had after that
     step (C: window, extrinsic, prior, solve summary, local-map digest — from the same run of the reference as A and B)"""
-    msgs, events = messages(oracle)
+    msgs, events = messages(oracle, CASE)
     k0 = events.index("initialised")
-    A, B, C = load_states()
-    est = capi.Estimator(lib, config_for(lib))
+    STEP_A, STEP_B = STEPS[CASE]
+    A, B, C = load_states(CASE)
+    est = capi.Estimator(lib, config_for(lib, CASE))
     inject(est, A, with_prior=False)
     feed(est, msgs[k0 + STEP_A + 1])
     inject(est, B, with_prior=True)

@@ -18,11 +18,12 @@ from window_util import assert_windows_close
 pytestmark = pytest.mark.gpu
 
 
-def test_product_one_step_from_the_reference_state(hip, oracle):
-    est, rep, C = su.one_step(hip, oracle)
+@pytest.mark.parametrize("case", list(su.STEPS))
+def test_product_one_step_from_the_reference_state(hip, oracle, case):
+    est, rep, C = su.one_step(hip, oracle, case)
     w = est.get_window()
     it, term, n_lidar, c0, c1 = C["solve"]
-    print("product vs the reference's Estimator.cc, one step from its state: |dP|", float(np.abs(w["Ps"] - C["Ps"]).max()), "|dV|",
+    print(case, "product vs the reference's Estimator.cc, one step from its state: |dP|", float(np.abs(w["Ps"] - C["Ps"]).max()), "|dV|",
           float(np.abs(w["Vs"] - C["Vs"]).max()), "iterations", rep.iterations, int(it), "plane factors", rep.n_lidar_residuals, int(n_lidar),
           "final cost", rep.final_cost, float(c1))
     assert_windows_close(w, dict(Ps=C["Ps"], Rs=C["Rs"], Vs=C["Vs"], Bas=C["Bas"], Bgs=C["Bgs"]))     # 1e-4 m / 1e-4 rad

@@ -16,8 +16,12 @@ import ref_state_util as su
 from window_util import rot_angle
 
 
-def test_one_step_from_the_reference_state(oracle):
-    est, rep, C = su.one_step(oracle, oracle)
+import pytest
+
+
+@pytest.mark.parametrize("case", list(su.STEPS))
+def test_one_step_from_the_reference_state(oracle, case):
+    est, rep, C = su.one_step(oracle, oracle, case)
     w, pr, lm = est.get_window(), est.prior(), est.local_map()
     assert np.abs(w["Ps"] - C["Ps"]).max() <= 1e-9 and max(rot_angle(a, b) for a, b in zip(w["Rs"], C["Rs"])) <= 3e-8
     assert np.abs(w["Vs"] - C["Vs"]).max() <= 1e-8 and np.abs(w["Bas"] - C["Bas"]).max() <= 1e-8 and np.abs(w["Bgs"] - C["Bgs"]).max() <= 1e-9

@@ -85,4 +85,30 @@ void ref_mb_get_cube(void *h, int cls, long long idx, float *out) {
   copy_out(cls == 0 ? *p->laser_cloud_corner_array_[size_t(idx)] : *p->laser_cloud_surf_array_[size_t(idx)], out);
 }
 
+// One keyframe of the batched refinement (BASELINE.json configs[4], lio_kf_batch_*): the reference's own Gauss-Newton loop —
+// PointMapping::OptimizeTransformTobeMapped, or MapBuilder::OptimizeMap with four_dof — run on caller-supplied from-map clouds and
+// down-sampled stacks from the pose T7_in (q = x y z w, then p).  point_on_z_axis_ is fixed before the loop as Process() / ProcessMap()
+// do (PointMapping.cc:803-806).  T7_out = transform_tobe_mapped_ after the loop.
+void ref_kf_refine(const float *fp, int four_dof, const float *corner_map, size_t ncm, const float *surf_map, size_t nsm, const float *corner_stack,
+                   size_t ncs, const float *surf_stack, size_t nss, const float *T7_in, float *T7_out) {
+  lio::MapBuilderConfig c;
+  c.corner_filter_size = fp[0]; c.surf_filter_size = fp[1]; c.map_filter_size = fp[2]; c.min_match_sq_dis = fp[3]; c.min_plane_dis = fp[4];
+  lio::MapBuilder m(c);
+  auto fill = [](lio::PointCloudPtr &dst, const float *src, size_t n) {
+    dst->clear();
+    for (size_t i = 0; i < n; ++i) { lio::PointT p; p.x = src[4 * i]; p.y = src[4 * i + 1]; p.z = src[4 * i + 2]; p.intensity = src[4 * i + 3]; dst->push_back(p); }
+  };
+  fill(m.laser_cloud_corner_from_map_, corner_map, ncm);
+  fill(m.laser_cloud_surf_from_map_, surf_map, nsm);
+  fill(m.laser_cloud_corner_stack_downsampled_, corner_stack, ncs);
+  fill(m.laser_cloud_surf_stack_downsampled_, surf_stack, nss);
+  m.transform_tobe_mapped_ = lio::Transform(Eigen::Quaternionf(T7_in[3], T7_in[0], T7_in[1], T7_in[2]), Eigen::Vector3f(T7_in[4], T7_in[5], T7_in[6]));
+  m.transform_sum_ = m.transform_tobe_mapped_;      // (OptimizeMap derives its — unused — constrained axis from it)
+  m.transform_bef_mapped_ = m.transform_tobe_mapped_;
+  m.point_on_z_axis_.x = 0.0; m.point_on_z_axis_.y = 0.0; m.point_on_z_axis_.z = 10.0;
+  m.PointAssociateToMap(m.point_on_z_axis_, m.point_on_z_axis_, m.transform_tobe_mapped_);
+  if (four_dof) m.OptimizeMap(); else m.OptimizeTransformTobeMapped();
+  put(m.transform_tobe_mapped_, T7_out);
+}
+
 }  // extern "C"

@@ -2,12 +2,12 @@
 tests/test_gpu_ref_estimator.py — product, GPU).
 
 tests/golden/ref_estimator_states.npz holds what the reference's own Estimator.cc (oracle/ref_estimator.cc) had in its buffers after
-two consecutive laser messages of the `indoor` and `outdoor64` replays of tests/ref_est_cases.py — window states, extrinsic, gravity, the surf stack and
+a laser message of three replays of tests/ref_est_cases.py — window states, extrinsic, gravity, the surf stack and
 the raw IMU samples of the pre-integration of every window slot, what the pre-integration in flight was started from, the
-marginalization prior — and what it had one message later.  `one_step(lib)` builds an estimator of
-`lib`, injects the first state through the test hooks of the C-ABI (lio_est_set_window / set_surf_stack / set_preintegration /
-begin_frame / set_extrinsic), feeds the next message (so that the estimator owns a prior of the right shape), overwrites EVERYTHING with
-the reference's second state (now including the prior), feeds the following message, and returns what came out: one
+marginalization prior —, the next message as it was fed (IMU batch, /compact_data) and what the reference had after it.  `one_step(lib)` builds an estimator of
+`lib`, injects the state through the test hooks of the C-ABI (lio_est_set_window / set_surf_stack / set_preintegration /
+begin_frame / set_extrinsic), feeds the next message once (so that the estimator owns a prior of the right shape), overwrites EVERYTHING
+with the reference's state again (now including the prior), feeds the same message, and returns what came out: one
 ProcessImu ... ProcessLaserOdom -> SolveOptimization -> SlideWindow step from exactly the reference's state, to be compared with the
 reference's own next state.  Index conventions are the reference's: buffers are dumped by the logical index of its CircularBuffers after
 SlideWindow (states already shifted, stacks and pre-integrations shifted by the next push), which is also how the oracle and the product
@@ -22,53 +22,10 @@ from lio_amd import capi, pipeline
 HERE = os.path.dirname(os.path.abspath(__file__))
 STATES = os.path.join(HERE, "golden", "ref_estimator_states.npz")
 RUN = os.path.join(HERE, "golden", "ref_estimator_run.npz")
-# case of tests/ref_est_cases.py -> (STEP_A, STEP_B): estimator steps after the initialisation (0 = the step that initialised) whose states
-# are stored; compared: step STEP_B + 1.  `indoor`: VLP-16, kept features, IMU de-skew, free extrinsic, no prior factor;
-# `outdoor64`: HDL-64E, extrinsic PriorFactor, cut-off de-skew
-STEPS = {"indoor": (3, 4), "outdoor64": (1, 2)}
-
-
-class Recorder:
-    """stands in for the estimator inside lio_amd.replay.Replay and keeps what it was fed: per laser message the IMU batch, the
-    /compact_data message and the stamp.  It answers stage() from the reference's recorded events (the replay switches the odometry to
-    its packer mode once the estimator is initialised)."""
-
-    def __init__(self, events, W):
-        self.events, self.W, self.batch, self.msgs = events, W, [], []
-
-    def process_imu(self, dt, acc, gyr, t):
-        self.batch.append((float(dt), np.array(acc, float), np.array(gyr, float), float(t)))
-
-    def process_compact(self, compact, stamp):
-        self.msgs.append((self.batch, np.array(compact, np.float32), float(stamp)))
-        self.batch = []
-        return (np.array([0, 0, 0, 1.0], np.float32), np.zeros(3, np.float32)), None
-
-    def stage(self):
-        k = len(self.msgs) - 1
-        ev = self.events[k] if k < len(self.events) else "solved"
-        inited = ("initialised" in self.events[:k + 1])
-        return dict(inited=inited, event=ev, cir_buf_count=0, extrinsic_stage=1, R_WI=np.eye(3), g_vec=np.zeros(3))
-
-    def get_window(self):
-        return None
-
-
-def messages(oracle, CASE):
-    """the laser messages of the case, as the estimator is fed them (front end: the oracle's, as for the golden files)"""
-    from replay_util import run_from_zero
-
-    c = cases.CASES[CASE]
-    events = [str(e) for e in np.load(RUN)[CASE + "/events"]]
-    holder = {}
-
-    def factory(cfg):
-        holder["rec"], holder["cfg"] = Recorder(events, c["W"]), cfg
-        return holder["rec"]
-
-    run_from_zero(oracle, c["n_sweeps"], W=c["W"], Wo=c["Wo"], init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], est_factory=factory,
-                  sweeps=cases.sweeps_of(c["kind"], c["n_sweeps"]))
-    return holder["rec"].msgs, events
+# case of tests/ref_est_cases.py -> the estimator step after the initialisation (0 = the step that initialised) whose state is stored;
+# compared: the step after it.  `indoor`: VLP-16, kept features, IMU de-skew, free extrinsic, no prior factor; `outdoor64`: HDL-64E,
+# extrinsic PriorFactor, cut-off de-skew; `outdoor64_15_5`: the same at BASELINE.json's headline window (15 / 5, every third sweep)
+STEPS = {"indoor": 4, "outdoor64": 2, "outdoor64_15_5": 2}
 
 
 def config_for(lib, CASE):
@@ -118,25 +75,25 @@ def feed(est, msg):
 
 
 def load_states(CASE):
+    """-> B (the injected state), C (what the reference had one message later), M (that message: IMU batch, /compact_data, stamp)"""
     g = np.load(STATES)
     out = {}
     for key in g.files:
         case, tag, field = key.split("/")
         if case == CASE:
             out.setdefault(tag, {})[field] = g[key]
-    return out["A"], out["B"], out["C"]
+    m = out["M"]
+    msg = ([(float(r[0]), r[1:4].copy(), r[4:7].copy(), float(r[7])) for r in m["imu"]], m["compact"], float(m["stamp"]))
+    return out["B"], out["C"], msg
 
 
-def one_step(lib, oracle, CASE="indoor"):
+def one_step(lib, CASE="indoor"):
     """-> `lib`'s estimator after ONE step from the reference's state B, its solve report, and what the reference itself had after that
-    step (C: window, extrinsic, prior, solve summary, local-map digest — from the same run of the reference as A and B)"""
-    msgs, events = messages(oracle, CASE)
-    k0 = events.index("initialised")
-    STEP_A, STEP_B = STEPS[CASE]
-    A, B, C = load_states(CASE)
+    step (C: window, extrinsic, prior, solve summary, local-map digest — from the same run of the reference as B and the message)"""
+    B, C, msg = load_states(CASE)
     est = capi.Estimator(lib, config_for(lib, CASE))
-    inject(est, A, with_prior=False)
-    feed(est, msgs[k0 + STEP_A + 1])
+    inject(est, B, with_prior=False)
+    feed(est, msg)                 # (only so that the estimator owns a prior of the right shape: everything it did is overwritten next)
     inject(est, B, with_prior=True)
-    _, rep = feed(est, msgs[k0 + STEP_B + 1])
+    _, rep = feed(est, msg)
     return est, rep, C

@@ -3,7 +3,7 @@ produced (tests/golden/ref_{odometry,mapping,mapbuilder}_digests.json: PointOdom
 where they lie, see oracle/ref_*.cc; the oracle equals those files bit for bit, tests/test_ref_*_digests.py).
 
 Same sequences and the same bounds as the product-vs-oracle tests of these stages (tests/test_gpu_parity.py: transform_es_ 1e-5,
-transform_sum_ 1e-4; tests/test_gpu_mapping.py: 1e-4 m / 1e-4 rad, equal window state, equal stack sizes) — what changes is the
+transform_sum_ 1e-4; tests/test_gpu_mapping.py: 1e-4 m / 1e-4 rad, equal window state, clouds up to counted voxel-face flips) — what changes is the
 right-hand side: the transforms compared against are the bit patterns the reference's code wrote.  (fp32 sums in a different order
 are why these are tolerances and not equal bits; the PointProcessor, which has no such sums, is held to the reference bit for bit by
 tests/test_gpu_ref_pointproc.py.)"""
@@ -61,14 +61,23 @@ def test_point_odometry_matches_the_reference(hip, oracle, name):
 
 @pytest.mark.parametrize("name", ["indoor_sequence", "outdoor_sequence"])
 def test_point_mapping_matches_the_reference(hip, oracle, name):
+    """Transforms and the cube window against the reference's bit patterns / lists.  The clouds are committed as count:sha256 only, and
+    a VoxelGrid that sits downstream of transform_tobe_mapped_ (matched to 1e-4, not to the bit) cannot reproduce a digest; so, as in
+    tests/test_gpu_ref_pointproc.py: (1) the ORACLE run beside the product reproduces the reference's digest of every cloud bit for bit
+    (the oracle's clouds ARE PointMapping.cc's), (2) the product's clouds are compared with those clouds point by point, voxel-face
+    flips counted (tests/test_gpu_mapping._cloud_mismatch), bounded by max(4, 0.5 %) and printed."""
     import ref_map_cases as mc
+    from ref_pp_cases import digest
+    from test_gpu_mapping import _cloud_mismatch
 
     frames = dict(mc.cases(oracle))[name]
     want = _gold("ref_mapping_digests.json")[name]
-    m = capi.PointMapping(hip)
+    m, mo = capi.PointMapping(hip), capi.PointMapping(oracle)
     worst = [0.0, 0.0]
+    flips = {}
     for k, (corner, surf, T_sum, _) in enumerate(frames):
         r = m.process(corner, surf, T_sum)
+        mo.process(corner, surf, T_sum)
         q, p = m.transform_tobe_mapped()
         for got, key in ((np.concatenate([q, p]).astype(float), "tobe"), (np.concatenate([r["T_aft"][0], r["T_aft"][1]]).astype(float), "aft")):
             dp, dq = _pose_gap(got, _f(want[k][key]))
@@ -76,12 +85,16 @@ def test_point_mapping_matches_the_reference(hip, oracle, name):
             assert dp < 1e-4 and dq < 1e-4, (name, k, key, dp, dq)
         cen, valid = m.cube_state()
         assert [int(v) for v in cen] == want[k]["center"] and [int(v) for v in valid] == want[k]["valid"], (name, k)
-        for w in (capi.PointMapping.CORNER_STACK_DS, capi.PointMapping.SURF_STACK_DS):
-            assert len(m.cloud(w)) == _count(want[k]["clouds"][w]), (name, k, w)
-        for w in (capi.PointMapping.CORNER_FROM_MAP, capi.PointMapping.SURF_FROM_MAP):
-            n_ref = _count(want[k]["clouds"][w])
-            assert abs(len(m.cloud(w)) - n_ref) <= max(4, n_ref // 200), (name, k, w)
+        for w, atol in ((capi.PointMapping.CORNER_STACK_DS, 1e-4), (capi.PointMapping.SURF_STACK_DS, 1e-4),
+                        (capi.PointMapping.CORNER_FROM_MAP, 5e-4), (capi.PointMapping.SURF_FROM_MAP, 5e-4)):
+            ref_cloud = mo.cloud(w)
+            assert digest(ref_cloud) == want[k]["clouds"][w], (name, k, w)        # the oracle's cloud is the reference's, bit for bit
+            got_cloud = m.cloud(w)
+            bad = _cloud_mismatch(got_cloud, ref_cloud, atol)
+            flips[(k, w)] = (bad, len(got_cloud), len(ref_cloud))
+            assert bad <= max(4, len(ref_cloud) // 200), (name, k, w, bad, got_cloud.shape, ref_cloud.shape)
     print(name, "product vs PointMapping.cc: worst |dp|", worst[0], "worst |dq|", worst[1])
+    print(name, "clouds (frame, which) -> (points without a partner + size gap, product size, reference size):", flips)
 
 
 def test_map_builder_matches_the_reference(hip, oracle):

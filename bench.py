@@ -477,20 +477,31 @@ def main():
             ppl = resident["launches"] / n_solves
             l_us = 1e3 * resident_launch["total_ms"] / max(resident_launch["launches"], 1)
             rt, rnote = pmc_traffic(pmc, "k_lidar_moments_resident")
+            # `achieved` / `frac` are over the WHOLE launch (dispatch -> exit, HIP events = what rocprofv3 --stats reports as this kernel's
+            # duration): algorithmic bytes of all passes of a launch / the launch duration.  The per-pass figure (device clock inside
+            # the kernel, excludes the time the kernel idles between passes while the host factors) is carried as `frac_per_pass`.
+            whole_gbps = b * ppl / (l_us * 1e-6) / 1e9 if l_us > 0 else None
+            flop_launch = b / 60.0 * 684.0 * ppl          # 684 MFMA-flop per residual
             res = {
                 "kernel": "k_lidar_moments_resident (fp64-MFMA form; 1 launch per solve, 1 pass per linearisation)",
                 "stage": "moments", "bound": "hbm",
-                "achieved": round(b / (p_us * 1e-6) / 1e9, 3) if p_us > 0 else None, "peak": 8000.0, "unit": "GB/s",
-                "frac": round(b / (p_us * 1e-6) / 8e12, 6) if p_us > 0 else None,
-                "traffic": round(rt / ppl, 1) if rt else None,
-                "traffic_source": pmc_note + "; " + rnote + f"; per LAUNCH {rt} B (the features are read once per launch and stay in registers), divided by {ppl:.2f} passes per launch",
-                "unit_of_work": "one PASS = one linearisation of the window's lidar factors (what one k_lidar_moments + k_moment_reduce launch pair did in round 2)",
-                "passes": resident["launches"], "avg_pass_us": round(p_us, 3), "algorithmic_bytes_per_pass": round(b, 1), "passes_per_launch": round(ppl, 2),
-                "pass_timing": "device wall clock inside the kernel, doorbell seen -> sums posted, slowest frame (HIP events cannot bracket a pass of a resident kernel)",
-                "avg_launch_us": round(l_us, 2), "launches_timed": resident_launch["launches"],
-                "achieved_over_whole_launch_GBps": round(b * ppl / (l_us * 1e-6) / 1e9, 2) if l_us > 0 else None,
-                "frac_over_whole_launch": round(b * ppl / (l_us * 1e-6) / 8e12, 6) if l_us > 0 else None,
+                "achieved": round(whole_gbps, 3) if whole_gbps else None, "peak": 8000.0, "unit": "GB/s",
+                "frac": round(whole_gbps / 8000.0, 6) if whole_gbps else None,
+                "frac_basis": "algorithmic bytes of one LAUNCH (60 B x residual slots x passes per launch) / average launch duration (HIP events, dispatch -> exit); reproducible from profiles/*_kernel_stats.md",
+                "traffic": round(rt, 1) if rt else None,
+                "traffic_source": pmc_note + "; " + rnote + f"; per LAUNCH (the features are read once per launch and stay in registers; {ppl:.2f} passes per launch)",
+                "mfma_f64": {"achieved_TFLOPs": round(flop_launch / (l_us * 1e-6) / 1e12, 3) if l_us > 0 else None, "peak_TFLOPs": 78.6,
+                             "frac": round(flop_launch / (l_us * 1e-6) / 78.6e12, 6) if l_us > 0 else None,
+                             "frac_per_pass": round(b / 60.0 * 684.0 / (p_us * 1e-6) / 78.6e12, 6) if p_us > 0 else None,
+                             "note": "684 flop per residual (SURVEY.md 8d) over the same launch duration / pass time"},
+                "unit_of_work": "one LAUNCH = one solve's dogleg loop; one PASS = one linearisation of the window's lidar factors (what one k_lidar_moments + k_moment_reduce launch pair did in round 2)",
+                "avg_launch_us": round(l_us, 2), "launches_timed": resident_launch["launches"], "passes_per_launch": round(ppl, 2),
+                "algorithmic_bytes_per_launch": round(b * ppl, 1),
                 "launch_timing": "HIP events around the kernel's launches in a separate untimed block: dispatch -> exit = the whole dogleg loop of a solve incl. the host's factorisations between passes (what rocprofv3 --stats reports as this kernel's duration)",
+                "passes": resident["launches"], "avg_pass_us": round(p_us, 3), "algorithmic_bytes_per_pass": round(b, 1),
+                "achieved_per_pass_GBps": round(b / (p_us * 1e-6) / 1e9, 3) if p_us > 0 else None,
+                "frac_per_pass": round(b / (p_us * 1e-6) / 8e12, 6) if p_us > 0 else None,
+                "pass_timing": "device wall clock inside the kernel, doorbell seen -> sums posted, slowest frame (HIP events cannot bracket a pass of a resident kernel)",
             }
             if dom == "moments":   # the resident kernel IS the dominant kernel of the timed region: it leads, the launch form follows as a cross-check
                 launch_form = {k: v for k, v in roofline.items() if k != "others"}

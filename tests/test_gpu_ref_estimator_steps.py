@@ -1,0 +1,125 @@
+"""The PRODUCT against the reference's own Estimator.cc STEP BY STEP, at the contract tolerance (1e-4 m / 1e-4 rad), on the GPU.
+
+Whole replays of tests/ref_est_cases.py from t = 0 — the VLP-16 indoor configuration at 6 / 3 and at indoor_test_config.yaml's 12 / 7,
+BASELINE.json's headline HDL-64E window (15 / 5, every third sweep a message) and its Wo = 15 stress variant — go through the HIP library
+with the teacher forcing of tests/test_ref_estimator_run.py: after every laser message of an initialised estimator the window, the
+extrinsic and the marginalization prior are overwritten with what the REFERENCE's Estimator.cc produced
+(tests/golden/ref_estimator_run.npz: the reference's sources compiled where they lie, oracle/ref_estimator.cc), so every
+SolveOptimization + SlideWindow starts from the reference's state and is judged on its own against the reference's next state.
+
+The surf stacks of the window are forced too.  The golden file holds digests of them, not the clouds (hundreds of MB over these
+replays); the clouds come from the ORACLE's estimator, which runs beside the product on the same messages under the same forcing and is
+held to the reference on the CPU at every one of these steps (tests/test_ref_estimator_run.py: plane factors, local map and states of
+each step equal to the reference's, 1e-14 .. 2e-9 m) — and this test re-asserts that equality (1e-6 m) before it uses a stack.  Without
+the stacks the first W steps after the initialisation carry the product's own fp32 scan-to-map chain (millimetres, tests/
+test_gpu_end_to_end.py) in their local map although the states are forced; measured without them on the MI355X (round 4,
+tools/gpu_ref_estimator_gaps.py, kept as the measurement tool): 6e-4 m at worst inside those W steps, <= 2e-5 m after them.
+
+Asserted per step: equal events, positions within 1e-4 m, rotations within 1e-4 rad, velocities / accelerometer biases within 1e-3 (the
+bound tests/window_util.py uses for them), gyroscope biases within 1e-4, equal iteration counts, plane-factor count within 0.2 %, final
+cost within 1e-3 relative.  The step that initialises is compared too, at the bounds of the free-running end-to-end test (it cannot be
+forced beforehand), and printed."""
+import os
+
+import numpy as np
+import pytest
+
+import ref_est_cases as cases
+from lio_amd import capi
+from replay_util import run_from_zero
+from window_util import rot_angle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_estimator_run.npz")
+# case -> number of sweeps replayed (None: all of the case)
+RUNS = {"indoor": None, "indoor_12_7": None, "outdoor64_15_5": None, "outdoor64_15_15": None}
+
+
+class Pair:
+    """the two estimators behind lio_amd.replay.Replay: `ref_side` (the oracle, standing in for the reference's clouds) and `prod`"""
+
+    def __init__(self, ref_side, prod):
+        self.ref_side, self.prod = ref_side, prod
+        self.W = prod.W
+
+    def process_imu(self, *a):
+        self.ref_side.process_imu(*a)
+        return self.prod.process_imu(*a)
+
+    def process_compact(self, compact, stamp):
+        self.ref_out = self.ref_side.process_compact(compact, stamp)
+        return self.prod.process_compact(compact, stamp)
+
+    def stage(self):
+        return self.prod.stage()
+
+    def get_window(self):
+        return self.prod.get_window()
+
+
+def _force(est, f, stacks):
+    est.set_window(f["Ps"], f["Rs"], f["Vs"], f["Bas"], f["Bgs"], f["g_vec"])
+    est.set_extrinsic(f["lb"][:4], f["lb"][4:])
+    pr = est.prior()
+    if "prior_jac" in f and pr is not None and int(f["prior_n"]) == pr["n"]:
+        est.set_prior_factor(dict(n=int(f["prior_n"]), lin_jac=f["prior_jac"], lin_res=f["prior_res"], x0=f["x0"]))
+    if stacks is not None:
+        for i, s in enumerate(stacks):
+            est.set_surf_stack(i, s)
+
+
+@pytest.mark.parametrize("name", list(RUNS))
+def test_product_steps_match_the_reference_estimator(hip, oracle, name):
+    c = cases.CASES[name]
+    ref = cases.unpack(np.load(GOLDEN), name)
+    n_sweeps = RUNS[name] or c["n_sweeps"]
+    W = c["W"]
+    steps = []
+
+    def configure(cfg):
+        for k, v in c["cfg"].items():
+            setattr(cfg, k, v)
+
+    def on_step(rp, k, e):
+        pair = rp.est
+        f = ref[len(steps)]
+        st_p, st_o = pair.prod.stage(), pair.ref_side.stage()
+        assert st_p["event"] == st_o["event"] == str(f["event"]), (len(steps), st_p["event"], st_o["event"], f["event"])
+        row = dict(inited=st_p["inited"])
+        if st_p["inited"]:
+            rep, rep_o = e["report"], pair.ref_out[1]
+            w, wo = pair.prod.get_window(), pair.ref_side.get_window()
+            # the oracle beside the product IS the reference at this step (CPU-proven; re-asserted before its clouds are used)
+            first = not any(r["inited"] for r in steps)
+            assert np.abs(wo["Ps"] - f["Ps"]).max() < 1e-6 and int(rep_o.n_lidar_residuals) == int(f["n_lidar"]), (name, len(steps))
+            row.update(first=first, dP=float(np.abs(w["Ps"] - f["Ps"]).max()), dR=max(rot_angle(x, y) for x, y in zip(w["Rs"], f["Rs"])),
+                       dV=float(np.abs(w["Vs"] - f["Vs"]).max()), dBa=float(np.abs(w["Bas"] - f["Bas"]).max()),
+                       dBg=float(np.abs(w["Bgs"] - f["Bgs"]).max()), dlb=float(np.abs(np.concatenate([w["q_lb"], w["t_lb"]]) - f["lb"]).max()),
+                       it=(int(rep.iterations), int(f["iterations"])), n=(int(rep.n_lidar_residuals), int(f["n_lidar"])),
+                       dcost=abs(float(rep.final_cost) - float(f["final_cost"])) / float(f["final_cost"]))
+            stacks = [pair.ref_side.get_surf_stack(i) for i in range(W + 1)]
+            _force(pair.ref_side, f, None)
+            _force(pair.prod, f, stacks)
+        steps.append(row)
+
+    def factory(cfg):
+        return Pair(capi.Estimator(oracle, cfg), capi.Estimator(hip, cfg))
+
+    run_from_zero(oracle, n_sweeps, W=W, Wo=c["Wo"], init_window_factor=c["iwf"], odom_io=c["io"], kind=c["kind"], configure=configure,
+                  on_step=on_step, est_factory=factory, sweeps=cases.sweeps_of(c["kind"], n_sweeps))
+    solved = [r for r in steps if r["inited"]]
+    assert len(solved) >= 3, len(solved)
+    worst = {k: max(r[k] for r in solved if not r["first"]) for k in ("dP", "dR", "dV", "dBa", "dBg", "dlb", "dcost")}
+    print(name, "product vs the reference's Estimator.cc, teacher-forced,", len(solved) - 1, "steps after the initialisation: worst", worst)
+    for s, r in enumerate(solved):
+        print("  step", s, {k: (("%.2e" % v) if isinstance(v, float) else v) for k, v in r.items() if k not in ("inited", "first")})
+    for s, r in enumerate(solved):
+        if r["first"]:
+            # the initialising step: reached through the product's own fp32 scan-to-map chain, which cannot be forced beforehand
+            assert r["dP"] < 0.03 and r["dR"] < 0.01, (name, s, r)
+            continue
+        assert r["dP"] < 1e-4 and r["dR"] < 1e-4, (name, s, r)                 # the north star: 1e-4 m / 1e-4 rad
+        assert r["dV"] < 1e-3 and r["dBa"] < 1e-3 and r["dBg"] < 1e-4, (name, s, r)
+        assert r["it"][0] == r["it"][1], (name, s, r)                          # after the same iteration count
+        assert abs(r["n"][0] - r["n"][1]) <= 0.002 * r["n"][1] + 1, (name, s, r)
+        assert r["dcost"] < 1e-3, (name, s, r)

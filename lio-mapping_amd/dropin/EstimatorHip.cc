@@ -70,6 +70,7 @@ void EstimatorHip::CreateHandle() {
   k.enable_deskew = c.enable_deskew; k.cutoff_deskew = c.cutoff_deskew; k.keep_features = c.keep_features;
   k.acc_n = c.pim_config.acc_n; k.gyr_n = c.pim_config.gyr_n; k.acc_w = c.pim_config.acc_w; k.gyr_w = c.pim_config.gyr_w;
   k.g_norm = c.pim_config.g_norm;
+  k.max_num_iterations = max_num_iterations_; k.max_solver_time = max_solver_time_in_seconds_;   // Estimator.cc:1916,1921
   if (est_) lio_est_destroy(est_);
   est_ = lio_est_create(&k);
   if (!est_) {

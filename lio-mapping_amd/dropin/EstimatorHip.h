@@ -54,6 +54,10 @@ class EstimatorHip : public MeasurementManager {
   lio_est *handle() { return est_; }                             // for callers that want an entry point this class does not wrap
   int last_error() const { return last_error_; }                 // LIO_OK or the code the last library call returned (also logged)
 
+  // ceres::Solver::Options the reference hard-codes in SolveOptimization (Estimator.cc:1916,1921); read by ClearState() (a new handle)
+  int max_num_iterations_ = 10;
+  double max_solver_time_in_seconds_ = 0.10;
+
   // ---- state, under the reference's names (refreshed from the library after every Process* / Solve / Slide call)
   EstimatorStageFlag stage_flag_ = NOT_INITED;
   EstimatorConfig estimator_config_;

@@ -19,7 +19,7 @@ from .capi import Estimator, EstConfig, LioLib, PointOdometry, PointProcessor, T
 
 
 class Replay:
-    def __init__(self, lib: LioLib, cfg: EstConfig, lidar, odom_io: int = 2, msg_time_delay: float = 0.0, scan_period: float = 0.1):
+    def __init__(self, lib: LioLib, cfg: EstConfig, lidar, odom_io: int = 2, msg_time_delay: float = 0.0, scan_period: float = 0.1, tap=None):
         self.lib = lib
         self.pp = PointProcessor(lib, lidar.lower_deg, lidar.upper_deg, lidar.rings)
         self.od = PointOdometry(lib, scan_period, odom_io, 25, False)
@@ -35,6 +35,7 @@ class Replay:
         self.odom_started = False
         self.odom_enabled = True
         self.log = []                           # one dict per processed compact message
+        self.tap = tap                          # tap("imu", t, acc, gyr) / tap("compact", stamp, cloud): every raw message as the ROS callbacks see it
 
     # ---- processor_node + PointOdometry::Process / PublishResults (PointOdometry.cc:294-683, 685-770)
     def add_sweep(self, points: np.ndarray, stamp: float):
@@ -50,6 +51,8 @@ class Replay:
             corner, surf = self.od.last_cloud(0), self.od.last_cloud(1)
             full = np.zeros((0, 4), np.float32)  # full_cloud_ is only republished for display
             self.compact_buf.append((stamp, self.lib.compact_encode(T, corner, surf, full)))
+            if self.tap:
+                self.tap("compact", stamp, self.compact_buf[-1][1])
         self._drain()
 
     def add_imu(self, t: float, acc, gyr):
@@ -57,6 +60,8 @@ class Replay:
             return
         self.imu_last_time = float(t)
         self.imu_buf.append((float(t), np.asarray(acc, float), np.asarray(gyr, float)))
+        if self.tap:
+            self.tap("imu", float(t), self.imu_buf[-1][1], self.imu_buf[-1][2])
         self._drain()
 
     # ---- MeasurementManager::GetMeasurements + Estimator::ProcessEstimation

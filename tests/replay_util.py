@@ -6,10 +6,11 @@ from lio_amd import capi, pipeline, replay, synth
 
 
 def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kind="indoor", imu_rate=200.0, sweeps=None, traj=None, t0=1.0,
-                  configure=None, on_step=None, est_factory=None):
+                  configure=None, on_step=None, est_factory=None, tap=None):
     """traj / t0: the trajectory object behind `sweeps` when it is not the kind's default (e.g. synth.FixtureTrajectory with
     t0 = 0); configure(cfg) may edit the estimator config; on_step(rp, k, log_entry) is called after every processed message; est_factory(cfg) replaces
-    the library's estimator by another object with the same methods (tests/ref_est_util.py: the reference's own Estimator)."""
+    the library's estimator by another object with the same methods (tests/ref_est_util.py: the reference's own Estimator); tap(cfg, kind, ...)
+    sees every raw IMU / compact message in arrival order (tests/test_gpu_dropin.py feeds them to the drop-in class's ROS callbacks)."""
     if sweeps is None:
         sweeps = synth.make_sweeps(kind, n_sweeps)
     sw, pose_fn, lid = sweeps
@@ -29,7 +30,7 @@ def run_from_zero(lib, n_sweeps, W=6, Wo=3, init_window_factor=1, odom_io=2, kin
     cfg.extrinsic_stage = 1
     if configure:
         configure(cfg)
-    rp = replay.Replay(lib, cfg, lid, odom_io=odom_io)
+    rp = replay.Replay(lib, cfg, lid, odom_io=odom_io, tap=(lambda *m: tap(cfg, *m)) if tap else None)
     if est_factory:
         rp.est = est_factory(cfg)
     h = 1.0 / imu_rate

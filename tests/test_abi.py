@@ -234,3 +234,32 @@ def test_process_imu_batch_equals_the_loop(oracle, hip):
             states.append(est.get_window())
         for key in ("Ps", "Rs", "Vs"):
             np.testing.assert_array_equal(states[0][key], states[1][key])
+
+
+def test_dropin_class_is_compiled_and_fails_loudly_without_a_gpu():
+    """SURVEY.md 8(b): the drop-in for lio::Estimator (lio-mapping_amd/dropin/EstimatorHip.cc over the reference's MeasurementManager.cc,
+    oracle/dropin_harness.cc) is a COMPILED binding: the library exists (rebuilt here when the reference tree is present), exports the
+    harness entry points, and on a host without a GPU its constructor reports the failure instead of substituting anything."""
+    import ctypes as C
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_ref", "libdropin_estimator.so")
+    if os.path.isdir("/root/reference/src/imu_processor"):
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "lio-mapping_amd", "csrc")], check=True)
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref/libdropin_estimator.so"], check=True)
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdropin_estimator.so not built (needs the reference tree)")
+    lib = C.CDLL(so)
+    for sym in ("dropin_create", "dropin_destroy", "dropin_push_imu", "dropin_push_compact", "dropin_wait_processed", "dropin_get_stage",
+                "dropin_get_window", "dropin_get_published"):
+        assert hasattr(lib, sym), sym
+    import torch
+
+    if not torch.cuda.is_available():
+        lib.dropin_create.restype = C.c_void_p
+        lib.dropin_create.argtypes = [C.c_void_p] * 3 + [C.c_double] * 2
+        ip = np.array([6, 3, 1, 1, 1, 1, 1, 0, 1, 1, 0, 1], np.int32)
+        fp = np.array([0.2, 0.4, 1.0, 0.2, 0, 0, 0, 1, 0, 0, -0.08], np.float32)
+        dp = np.array([0.1, 0.01, 0.0002, 2e-5, 9.805])
+        assert lib.dropin_create(ip.ctypes.data, fp.ctypes.data, dp.ctypes.data, 0.0, 0.1) is None

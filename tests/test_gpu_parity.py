@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from lio_amd import capi, pipeline, synth
+from window_util import force_all
 
 pytestmark = pytest.mark.gpu
 
@@ -301,8 +302,9 @@ def test_build_local_map_and_features(hip, oracle, keep):
         total += pb.shape[0]
     assert total > 1000
     (qa, ta), (qb, tb) = ea.laser_odom_transform(), eb.laser_odom_transform()
-    np.testing.assert_allclose(ta, tb, atol=2e-4)   # fp32 GN loop, tolerance 2e-4 m
-    np.testing.assert_allclose(qa, qb, atol=2e-4)
+    print(f"newest-frame transform after CalculateLaserOdom (keep={keep}): |dt| {np.max(np.abs(ta - tb)):.2e} m, |dq| {np.max(np.abs(qa - qb)):.2e}")
+    np.testing.assert_allclose(ta, tb, atol=1e-4)   # fp32 GN loop: the contract's 1e-4 m / 1e-4 rad
+    np.testing.assert_allclose(qa, qb, atol=1e-4)
 
 
 def test_single_solve_matches_oracle(hip, oracle):
@@ -320,24 +322,29 @@ def test_sequence_with_marginalization(hip, oracle):
         est.solve()
         est.slide()
     W = ea.W
+    force_all(ea, eb, ds)
+    worst = 0.0
     for k in range(W + 1, 10):
         ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
         rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
         assert ra.convergence_flag == rb.convergence_flag and ra.turn_off == rb.turn_off
-        _assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)
+        worst = max(worst, float(np.max(np.abs(ea.get_window()["Ps"] - eb.get_window()["Ps"]))))
+        _assert_windows_close(ea.get_window(), eb.get_window())      # 1e-4 m / 1e-4 rad on every teacher-forced step
+        if k < 9:
+            force_all(ea, eb, ds)     # the next step starts from the oracle's states, extrinsic and prior on both sides (tests/window_util.py)
+    print(f"sequence with marginalization: worst |dP| over the teacher-forced steps {worst:.2e} m")
     pa, pb = ea.prior(), eb.prior()
     assert pa is not None and pb is not None and pa["n"] == pb["n"]
-    # marginalization parity on the order-equivariant invariants
-    # The two chains are NOT teacher-forced here: the linearisation points differ by the windows' ~1e-9 m gap and by the odd
-    # borderline newest-frame feature, which is what bounds |dJtJ| (measured value printed; the 1e-8 eigenvalue cut of
-    # MarginalizationFactor.cc:275-302 is not crossed differently: pa and pb have the same rank, checked below).
+    # marginalization parity on the order-equivariant invariants: the priors compared are the ones each side produced
+    # ITSELF in the last step (from the same forced state); the 1e-8 eigenvalue cut of MarginalizationFactor.cc:275-302 is not crossed
+    # differently: pa and pb have the same rank, checked below.
     scale = np.abs(pb["JtJ"]).max()
     rel = np.max(np.abs(pa["JtJ"] - pb["JtJ"])) / scale
     print(f"prior after 5 chained steps: |dJtJ|/max {rel:.2e}, |dx0| {np.max(np.abs(pa['x0'] - pb['x0'])):.2e}")
     assert rel < 1e-4
     ea_, eb_ = np.linalg.eigvalsh(pa["JtJ"]), np.linalg.eigvalsh(pb["JtJ"])
     assert (ea_ > 1e-8 * ea_.max()).sum() == (eb_ > 1e-8 * eb_.max()).sum()
-    np.testing.assert_allclose(pa["x0"], pb["x0"], atol=2e-4)
+    np.testing.assert_allclose(pa["x0"], pb["x0"], atol=1e-4)
 
 
 def test_deferred_marginalization_equals_inline(hip, monkeypatch):
@@ -382,13 +389,16 @@ def test_deskew_path(hip, oracle):
     for est in (ea, eb):
         est.solve()
         est.slide()
+    force_all(ea, eb, ds)
     k = ea.W + 1
     pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
     pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
     sa, sb = ea.get_surf_stack(ea.W - 1), eb.get_surf_stack(eb.W - 1)
     assert sa.shape == sb.shape
-    np.testing.assert_allclose(sa[:, :3], sb[:, :3], atol=2e-4)  # slerp/acos differ by ulps between libm and ocml
-    _assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)
+    print(f"deskew path: worst |d point| of the de-skewed, filtered stack {np.max(np.abs(sa[:, :3] - sb[:, :3])):.2e} m, "
+          f"|dP| {np.max(np.abs(ea.get_window()['Ps'] - eb.get_window()['Ps'])):.2e} m")
+    np.testing.assert_allclose(sa[:, :3], sb[:, :3], atol=1e-4)  # slerp's acos / sin: libm on the host, ocml on the device
+    _assert_windows_close(ea.get_window(), eb.get_window())      # 1e-4 m / 1e-4 rad
 
 
 def test_snapshot_restore_is_idempotent(hip):
@@ -452,11 +462,13 @@ def test_full_size_hdl64_window(hip, oracle):
     # next frame through push + solve + slide on both
     for est in (ea, eb):
         est.slide()
+    force_all(ea, eb, ds)
     k = W + 1
     ra = pipeline.feed_frame(ea, ds, k, clouds[k][0], clouds[k][1])
     rb = pipeline.feed_frame(eb, ds, k, clouds[k][0], clouds[k][1])
     assert ra.marginalized == rb.marginalized == 1
-    _assert_windows_close(ea.get_window(), eb.get_window(), tol_p=2e-4, tol_r=2e-4)
+    print(f"full-size HDL-64 window, second step (teacher-forced): |dP| {np.max(np.abs(ea.get_window()['Ps'] - eb.get_window()['Ps'])):.2e} m")
+    _assert_windows_close(ea.get_window(), eb.get_window())      # 1e-4 m / 1e-4 rad
 
 
 # ------------------------------------------------------------------------------------------------ scan-to-scan odometry

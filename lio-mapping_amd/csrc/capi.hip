@@ -64,7 +64,11 @@ lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   for (int v : caps)
     if (v < 0 || v > 4096) return nullptr;
   // k_ring_pick keeps the picks of a subregion one per lane of a wave (corner picks + flat picks in 64 slots)
-  if (cfg.max_corner_less_sharp + cfg.max_surf_flat > 64 || cfg.max_corner_sharp > cfg.max_corner_less_sharp) return nullptr;
+  if (cfg.max_corner_less_sharp + cfg.max_surf_flat > 64 || cfg.max_corner_sharp > cfg.max_corner_less_sharp) {
+    std::fprintf(stderr, "lio_pp_create: max_corner_less_sharp + max_surf_flat = %d > 64 picks per subregion (or max_corner_sharp > max_corner_less_sharp): "
+                         "not supported by k_ring_pick (the reference's defaults are 20 + 4)\n", cfg.max_corner_less_sharp + cfg.max_surf_flat);
+    return nullptr;
+  }
   if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return nullptr;
   if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return nullptr;
   if (cfg.infer_start_ori && !(cfg.rad_diff >= 0.0)) return nullptr;

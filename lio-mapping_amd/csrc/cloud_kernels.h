@@ -88,6 +88,7 @@ class KnnGrid {
   DBuf<uint32_t> keys_, keys2_, vals_, vals2_;
   DBuf<float4> sorted_;
   DBuf<int> cells_, cnt_;
+  bool cnt_dirty_ = false;   // k_cell_count ran, k_cell_place (which re-zeroes cnt_) did not
   DBuf<char> tmp_;
 };
 

@@ -472,10 +472,11 @@ void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float 
   }
   if (ncells > (size_t(1) << 30)) throw DeviceError("KnnGrid: cell table too large");
   cells_.reserve(ncells + 1);
-  if (cnt_.cap < ncells + 1) {   // a fresh table starts zeroed; after that k_cell_place leaves it zeroed (no fill per build)
+  if (cnt_.cap < ncells + 1 || cnt_dirty_) {   // a fresh table starts zeroed; after that k_cell_place leaves it zeroed (no fill per build)
     cnt_.reserve(ncells + 1);
     LIO_HIP(hipMemsetAsync(cnt_.p, 0, cnt_.cap * sizeof(int), s));
   }
+  cnt_dirty_ = true;   // until k_cell_place has been enqueued: a build that throws in between leaves counts behind, the next one clears them
   keys_.reserve(std::max<size_t>(n, 1)); vals_.reserve(std::max<size_t>(n, 1)); sorted_.reserve(std::max<size_t>(n, 1));
   const int ni = int(n);
   if (ni) hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, ni, desc_, keys_.p, vals_.p, cnt_.p);
@@ -485,6 +486,7 @@ void KnnGrid::build(const float4 *pts, size_t n, const float mn[3], const float 
   LIO_HIP(rocprim::exclusive_scan(tmp_.p, tmp_bytes, cnt_.p, cells_.p, 0, ncells + 1, rocprim::plus<int>(), s));
   if (ni) hipLaunchKernelGGL(k_cell_place, dim3(cdiv(ni, 256)), dim3(256), 0, s, pts, keys_.p, vals_.p, ni, cells_.p, sorted_.p, cnt_.p);
   LIO_HIP(hipGetLastError());
+  cnt_dirty_ = false;
 }
 
 // K nearest (K <= 5 kept in registers) over the 27 neighbouring cells; total order (d2, original index).

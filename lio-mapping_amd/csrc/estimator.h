@@ -272,6 +272,7 @@ class Estimator {
   bool res_active_ = false;         // a resident kernel is waiting on the doorbell
   int res_bpf_ = 0, res_nframes_ = 0;
   unsigned res_seq_ = 0;            // sequence number of the last pass rung (monotonic over the life of the handle)
+  int res_relaunches_ = 0;          // launches that replaced an expired one within this solve (bounded: ResidentAwaitWord)
   unsigned res_launch_seq_ = 0;     // first sequence number of the launch in flight (its STOP value is derived from it)
   double *h_res_door_ = nullptr, *h_res_out_ = nullptr;    // coherent pinned host memory: doorbell, per-frame folded records
   unsigned *h_res_words_ = nullptr;

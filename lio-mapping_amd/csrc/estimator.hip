@@ -116,6 +116,7 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_words_), sizeof(unsigned) * (LIO_MAX_FRAMES + 2), hipHostMallocCoherent));   // + the relay block's word + its echo
   std::memset(h_res_door_, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR);
   std::memset(h_res_words_, 0, sizeof(unsigned) * (LIO_MAX_FRAMES + 2));
+  std::memset(h_res_out_, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_OUT);   // the diagnostic slots are read whether or not the kernel fills them
   {
     int khz = 0, dev = 0;
     LIO_HIP(hipGetDevice(&dev));
@@ -724,7 +725,7 @@ int Estimator::ResidentBpf(int max_slots, int nframes, int *per_lane) const {
 
 void Estimator::ResidentLaunchKernel(unsigned first_seq) {
   ResidentArgs ra{h_res_door_, h_res_out_, h_res_words_, first_seq, res_timeout_ticks_, d_res_relay_.p, d_res_part_.p, g_debug_timing ? 1 : 0};
-  res_launch_seq_ = first_seq;   // (the HBM copy of the doorbell needs no clearing: sequence numbers only grow and STOP is per launch)
+  res_launch_seq_ = first_seq;   // (a launch's STOP value is derived from it; see ResidentAwaitWord for the one case where the HBM copy must be cleared)
   launch_lidar_moments_resident(res_args_, ra, res_lanes_, f_valid_.p, f_coef_.p, stream_);
 }
 
@@ -737,7 +738,14 @@ bool Estimator::ResidentBegin(const MomentArgs &ma) {
   int per_lane = 0;
   if (ResidentBpf(max_slots, ma.nframes, &per_lane) != ma.blocks_per_frame || ma.blocks_per_frame <= 0) return false;
   if (g_active_solves.load(std::memory_order_relaxed) > 1) return false;
+  if (res_seq_ > 0xF0000000u) {   // 32-bit sequence numbers: start over long before they wrap (no launch is in flight here)
+    LIO_HIP(hipStreamSynchronize(stream_));
+    LIO_HIP(hipMemset(d_res_part_.p, 0, sizeof(double) * LIO_RES_MAX_BLOCKS * LIO_MOMENT_OUT));
+    std::memset(h_res_words_, 0, sizeof(unsigned) * (LIO_MAX_FRAMES + 2));
+    res_seq_ = 0;
+  }
   if (g_resident_moments.fetch_add(1) >= kMaxResidentMoments) { g_resident_moments.fetch_sub(1); return false; }
+  struct Admission { bool keep = false; ~Admission() { if (!keep) g_resident_moments.fetch_sub(1); } } admission;   // released if the launch throws
   res_args_ = ma; res_lanes_ = per_lane;
   res_bpf_ = ma.blocks_per_frame; res_nframes_ = ma.nframes;
   for (int f = 0; f < res_nframes_; ++f) {   // idle doorbell: neither the expected sequence number nor STOP
@@ -750,8 +758,9 @@ bool Estimator::ResidentBegin(const MomentArgs &ma) {
     LIO_HIP(hipEventRecord(a, stream_));
     res_launch_events_.push_back({a, b});
   }
+  res_relaunches_ = 0;
   ResidentLaunchKernel(res_seq_ + 1);
-  res_active_ = true;
+  res_active_ = true; admission.keep = true;
   return true;
 }
 
@@ -792,9 +801,15 @@ void Estimator::ResidentAwaitWord(int f) {
     if (__atomic_load_n(w + LIO_MAX_FRAMES, __ATOMIC_ACQUIRE) == LIO_RES_EXPIRED) {
       if (__atomic_load_n(w + f, __ATOMIC_ACQUIRE) == seq) return;
       if (f > 0 && __atomic_load_n(w + 0, __ATOMIC_ACQUIRE) == seq) throw DeviceError("resident moments kernel gave up in the middle of a pass");
-      // let that launch drain and start a new one for the pass that is pending; its doorbell is still rung
+      // let that launch drain and start a new one for the pass that is pending; its doorbell is still rung.  Twice at most: a
+      // kernel that keeps expiring is not being scheduled whole (its blocks are not co-resident) and no retry will change that.
       LIO_HIP(hipStreamSynchronize(stream_));
+      if (++res_relaunches_ > 2) throw DeviceError("resident moments kernel expired three times within one solve (its blocks are not co-resident?)");
       h_res_words_[LIO_MAX_FRAMES] = 0;
+      // The expired relay left ITS stop value in the HBM copy of the doorbell.  If that launch never served a pass, the one that
+      // replaces it starts at the same sequence number and has the same stop value: clear the copy, or the new workers leave on it
+      // before the new relay republishes the pending pass.
+      LIO_HIP(hipMemsetAsync(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, stream_));
       ResidentLaunchKernel(seq);
       continue;
     }

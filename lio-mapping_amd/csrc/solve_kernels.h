@@ -57,7 +57,7 @@ int moment_blocks_per_frame(int max_slots);
 // the doorbell value that ends a launch: minus the sequence number of its first pass — unique per launch, so whatever an earlier
 // launch left in the HBM copy of the doorbell (its STOP, its last sequence number) means nothing to this one and needs no clearing
 #define LIO_RES_STOP(first_seq) (-double(first_seq))
-#define LIO_RES_MAX_BLOCKS 256     // one per CU: every block must be co-resident with nothing but the host to wait for
+#define LIO_RES_MAX_BLOCKS 256     // size of the per-block record array; the admission limit is resident_max_blocks() (asked of the device)
 struct ResidentArgs {
   const double *door;        // host, coherent
   double *out;               // host, coherent: frame f's folded moments at f * LIO_RES_OUT (compact: see LIO_RES_OUT)
@@ -69,7 +69,9 @@ struct ResidentArgs {
   double *block_part;        // device: block b's record at b * LIO_MOMENT_OUT; slot LIO_MOMENT_OUT - 1 = the pass it belongs to (the flag)
   int diag;                  // 1: every phase stamp goes into the frame record (LIO_DEBUG_TIMING), 0: only the pass time
 };
-// blocks per frame so that a lane holds at most `per_lane` residuals (0 when the window does not fit LIO_RES_MAX_BLOCKS)
+// worker blocks the current device keeps co-resident beside the relay (occupancy x CUs - 1, <= LIO_RES_MAX_BLOCKS; 0 without a device)
+int resident_max_blocks(int per_lane);
+// blocks per frame so that a lane holds at most `per_lane` residuals (0 when the window does not fit resident_max_blocks)
 int resident_blocks_per_frame(int max_slots, int nframes, int per_lane);
 void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, int per_lane, const uint8_t *valid, const float4 *coef, hipStream_t s);
 int moment_blocks_per_frame_batched(int max_slots, int nframes);

@@ -477,8 +477,10 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int e = lane & 15, grp = lane >> 4;
   const int nblk = a.blocks_per_frame;
-  if (int(blockIdx.x) == nblk * a.nframes) { resident_relay(a, ra); return; }
-  const int f = blockIdx.x / nblk, j = blockIdx.x - f * nblk;
+  // the relay is block 0: the dispatcher places blocks in index order, so the one block every worker depends on is resident first
+  if (blockIdx.x == 0) { resident_relay(a, ra); return; }
+  const int wb = int(blockIdx.x) - 1;   // worker index
+  const int f = wb / nblk, j = wb - f * nblk;
   const MomentFrame &fr = a.fr[f];
   // ---- the wave's residuals, loaded ONCE (features do not change during a solve); chunks past the frame's end stay empty
   float px[R], py[R], pz[R];
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_resident(Momen
   __shared__ double t_relay;
   double *zb = zbuf[wv];
   const double *door = ra.relay + size_t(f) * LIO_RES_DOOR;
-  double *mine = ra.block_part + size_t(blockIdx.x) * LIO_MOMENT_OUT;
+  double *mine = ra.block_part + size_t(wb) * LIO_MOMENT_OUT;
   int rec_src = 0;   // where this lane's entry of the compact record sits in the block's 16 x 16 (+ cost, count) LDS record
   if (tid < RES_NTRI) { int a = 0, c = tid; while (c >= 13 - a) { c -= 13 - a; ++a; } rec_src = a * 16 + a + c; }
   else if (tid < RES_NREC) rec_src = 256 + (tid - RES_NTRI);
@@ -706,14 +708,38 @@ __global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *
   }
 }
 
+// Worker blocks of the resident form that the CURRENT device keeps co-resident beside the relay: occupancy of the kernel x compute
+// units - 1, never more than LIO_RES_MAX_BLOCKS (the size of the record arrays).  0 when the device cannot be asked (no GPU) —
+// the resident form is then never chosen.  A partitioned (CPX) or smaller part gets a smaller figure and with it the launch path
+// for windows that do not fit; nothing is assumed about "256 CUs".
+int resident_max_blocks(int per_lane) {
+  static int cache[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  if (per_lane < 1 || per_lane > 8) return 0;
+  if (cache[per_lane] >= 0) return cache[per_lane];
+  int dev = 0, cus = 0, per_cu = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) {
+    switch (per_lane) {
+      case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lidar_moments_resident<1>, MOMENT_THREADS, 0); break;
+      case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lidar_moments_resident<2>, MOMENT_THREADS, 0); break;
+      case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lidar_moments_resident<4>, MOMENT_THREADS, 0); break;
+      case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lidar_moments_resident<8>, MOMENT_THREADS, 0); break;
+      default: per_cu = 0; break;
+    }
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); return cache[per_lane] = 0; }
+  return cache[per_lane] = std::max(0, std::min(LIO_RES_MAX_BLOCKS, cus * per_cu - 1));
+}
+
 int resident_blocks_per_frame(int max_slots, int nframes, int per_lane) {
   if (max_slots <= 0 || nframes <= 0 || per_lane < 1) return 0;
   const int b = cdiv(max_slots, MOMENT_THREADS * per_lane);
-  return (b * nframes <= LIO_RES_MAX_BLOCKS) ? b : 0;
+  return (b * nframes <= resident_max_blocks(per_lane)) ? b : 0;
 }
 
 void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, int per_lane, const uint8_t *valid, const float4 *coef, hipStream_t s) {
-  const dim3 grid(a.blocks_per_frame * a.nframes + 1), block(MOMENT_THREADS);   // workers + the relay
+  const dim3 grid(a.blocks_per_frame * a.nframes + 1), block(MOMENT_THREADS);   // the relay (block 0) + the workers
   switch (per_lane) {
     case 1: hipLaunchKernelGGL(k_lidar_moments_resident<1>, grid, block, 0, s, a, ra, valid, coef); break;
     case 2: hipLaunchKernelGGL(k_lidar_moments_resident<2>, grid, block, 0, s, a, ra, valid, coef); break;

@@ -10,15 +10,19 @@ SolveOptimization + SlideWindow starts from the reference's state and is judged 
 The surf stacks of the window are forced too.  The golden file holds digests of them, not the clouds (hundreds of MB over these
 replays); the clouds come from the ORACLE's estimator, which runs beside the product on the same messages under the same forcing and is
 held to the reference on the CPU at every one of these steps (tests/test_ref_estimator_run.py: plane factors, local map and states of
-each step equal to the reference's, 1e-14 .. 2e-9 m) — and this test re-asserts that equality (1e-6 m) before it uses a stack.  Without
-the stacks the first W steps after the initialisation carry the product's own fp32 scan-to-map chain (millimetres, tests/
-test_gpu_end_to_end.py) in their local map although the states are forced; measured without them on the MI355X (round 4,
-tools/gpu_ref_estimator_gaps.py, kept as the measurement tool): 6e-4 m at worst inside those W steps, <= 2e-5 m after them.
+each step equal to the reference's, 1e-14 .. 2e-9 m) — and this test re-asserts that equality (1e-6 m) before it uses a stack.
 
-Asserted per step: equal events, positions within 1e-4 m, rotations within 1e-4 rad, velocities / accelerometer biases within 1e-3 (the
-bound tests/window_util.py uses for them), gyroscope biases within 1e-4, equal iteration counts, plane-factor count within 0.2 %, final
-cost within 1e-3 relative.  The step that initialises is compared too, at the bounds of the free-running end-to-end test (it cannot be
-forced beforehand), and printed."""
+Before the initialisation the estimator's inputs are forced the same way: the product's ProcessLaserOdom receives the scan-to-map
+transform and the down-sampled surf cloud of the reference side (`Pair.process_compact`), so the step that INITIALISES (ImuInitializer
++ first SolveOptimization over the whole window) is judged at the contract tolerance too.  Measured on the MI355X without that forcing
+(round 4, profiles/r4_ref_estimator_steps.txt): the initialising step then carries the product's own fp32 scan-to-map chain from t = 0
+through an ill-conditioned 1.5 s initialisation — 6e-4 m (indoor), 3e-3 m (12 / 7, Wo = 15), 3.3e-2 m (headline 15 / 5) — and the W steps
+after it 6e-4 m at worst if the stacks are left alone (tools/gpu_ref_estimator_gaps.py, kept as the measurement tool); every forced
+step: <= 3.1e-6 m.  The free-running chain is what tests/test_gpu_ref_estimator.py and tests/test_gpu_end_to_end.py bound.
+
+Asserted per step, the initialising one included: equal events, positions within 1e-4 m, rotations within 1e-4 rad, velocities /
+accelerometer biases within 1e-3 (the bound tests/window_util.py uses for them), gyroscope biases within 1e-4, equal iteration counts,
+plane-factor count within 0.2 %, final cost within 1e-3 relative."""
 import os
 
 import numpy as np
@@ -41,14 +45,30 @@ class Pair:
     def __init__(self, ref_side, prod):
         self.ref_side, self.prod = ref_side, prod
         self.W = prod.W
+        self.pushes = 0   # laser messages pushed into the window so far (the slot of the newest stack is min(pushes, W))
 
     def process_imu(self, *a):
         self.ref_side.process_imu(*a)
         return self.prod.process_imu(*a)
 
     def process_compact(self, compact, stamp):
+        was_inited = self.prod.stage()["inited"]
         self.ref_out = self.ref_side.process_compact(compact, stamp)
-        return self.prod.process_compact(compact, stamp)
+        if was_inited:
+            return self.prod.process_compact(compact, stamp)
+        # Before the initialisation the estimator takes two things from a message (Estimator.cc:430-487): the scan-to-map stage's
+        # transform and its down-sampled surf cloud.  Both are forced here from the reference side — the product's ProcessLaserOdom
+        # is handed the oracle's transform_aft_mapped_ and the stack the oracle just pushed — so the step that initialises starts
+        # from the reference's buffers like every step after it.  (The product's own scan-to-map chain from t = 0 is what
+        # tests/test_gpu_ref_stages.py and the free-running tests/test_gpu_ref_estimator.py cover.)
+        (q, p), _ = self.ref_out
+        skipped = self.ref_side.stage()["event"] == "skipped"
+        surf = np.zeros((0, 4), np.float32)
+        if not skipped:
+            surf = self.ref_side.get_surf_stack(min(self.pushes, self.W))
+            self.pushes += 1
+        rep = self.prod.process_laser_odom(capi.TransformF.make(q, p), surf, np.zeros((0, 4), np.float32), stamp)
+        return (q, p), rep
 
     def stage(self):
         return self.prod.stage()
@@ -109,15 +129,11 @@ def test_product_steps_match_the_reference_estimator(hip, oracle, name):
                   on_step=on_step, est_factory=factory, sweeps=cases.sweeps_of(c["kind"], n_sweeps))
     solved = [r for r in steps if r["inited"]]
     assert len(solved) >= 3, len(solved)
-    worst = {k: max(r[k] for r in solved if not r["first"]) for k in ("dP", "dR", "dV", "dBa", "dBg", "dlb", "dcost")}
-    print(name, "product vs the reference's Estimator.cc, teacher-forced,", len(solved) - 1, "steps after the initialisation: worst", worst)
+    worst = {k: max(r[k] for r in solved) for k in ("dP", "dR", "dV", "dBa", "dBg", "dlb", "dcost")}
+    print(name, "product vs the reference's Estimator.cc, teacher-forced,", len(solved), "steps (step 0 = the one that initialises): worst", worst)
     for s, r in enumerate(solved):
         print("  step", s, {k: (("%.2e" % v) if isinstance(v, float) else v) for k, v in r.items() if k not in ("inited", "first")})
     for s, r in enumerate(solved):
-        if r["first"]:
-            # the initialising step: reached through the product's own fp32 scan-to-map chain, which cannot be forced beforehand
-            assert r["dP"] < 0.03 and r["dR"] < 0.01, (name, s, r)
-            continue
         assert r["dP"] < 1e-4 and r["dR"] < 1e-4, (name, s, r)                 # the north star: 1e-4 m / 1e-4 rad
         assert r["dV"] < 1e-3 and r["dBa"] < 1e-3 and r["dBg"] < 1e-4, (name, s, r)
         assert r["it"][0] == r["it"][1], (name, s, r)                          # after the same iteration count

@@ -109,16 +109,23 @@ inline bool chol_upper_portable(double *A, int n, int lda) {
 // 6.3 us against ~3 us for this form).  Out of place: A = chol(S + diag(shift)) with S untouched (S == A allowed), which
 // also saves the dogleg its copy of H.  Subtractions are fused multiply-subtracts in ascending pivot order, so the factor differs
 // from the portable one in the last bits only.  The strictly lower triangle of A's diagonal blocks is scratch.
+// acc <- S[j0 + r][i ..] (zero if S is null);  acc -= sum_{k in [k0, k1)} U[k][j0 + r] * U[k][i ..];  A[j0 + r][i ..] <- acc
+// (r = 0 .. 7, NV vectors of 8 columns from i, the last one masked).  Rows k whose eight multipliers are all zero are skipped:
+// the speed-bias block of the window's normal matrix is block tridiagonal, its factor block bidiagonal.
 template <int NV>
-__attribute__((target("avx512f,fma"), always_inline)) inline void chol_blk_update(const double *S, double *A, int lda, int j0, int i, __mmask8 mlast) {
+__attribute__((target("avx512f,fma"), always_inline)) inline void chol_blk_update(const double *S, const double *U, double *A, int lda, int j0, int i,
+                                                                                  __mmask8 mlast, int k0, int k1) {
   __m512d acc[8][NV];
   for (int r = 0; r < 8; ++r)
     for (int c = 0; c < NV; ++c) {
+      if (!S) { acc[r][c] = _mm512_setzero_pd(); continue; }
       const double *src = S + size_t(j0 + r) * lda + i + 8 * c;
       acc[r][c] = (c == NV - 1) ? _mm512_maskz_loadu_pd(mlast, src) : _mm512_loadu_pd(src);
     }
-  for (int k = 0; k < j0; ++k) {
-    const double *uk = A + size_t(k) * lda;
+  const __m512d zero = _mm512_setzero_pd();
+  for (int k = k0; k < k1; ++k) {
+    const double *uk = U + size_t(k) * lda;
+    if (_mm512_cmp_pd_mask(_mm512_loadu_pd(uk + j0), zero, _CMP_NEQ_UQ) == 0) continue;
     __m512d u[NV];
     for (int c = 0; c < NV; ++c) u[c] = (c == NV - 1) ? _mm512_maskz_loadu_pd(mlast, uk + i + 8 * c) : _mm512_loadu_pd(uk + i + 8 * c);
 #pragma GCC unroll 8
@@ -133,15 +140,25 @@ __attribute__((target("avx512f,fma"), always_inline)) inline void chol_blk_updat
       if (c == NV - 1) _mm512_mask_storeu_pd(dst, mlast, acc[r][c]); else _mm512_storeu_pd(dst, acc[r][c]);
     }
 }
-__attribute__((target("avx512f,fma"))) inline bool chol_upper_from_avx512(const double *S, double *A, int n, int lda, const double *shift) {
-  int j0 = 0;
-  for (; j0 + 8 <= n; j0 += 8) {
-    int i = j0;
-    for (; i + 24 <= n; i += 24) chol_blk_update<3>(S, A, lda, j0, i, __mmask8(0xFF));
-    const int rem = n - i;   // 0 .. 23
-    if (rem > 16) chol_blk_update<3>(S, A, lda, j0, i, __mmask8((1u << (rem - 16)) - 1u));
-    else if (rem > 8) chol_blk_update<2>(S, A, lda, j0, i, __mmask8((1u << (rem - 8)) - 1u));
-    else if (rem > 0) chol_blk_update<1>(S, A, lda, j0, i, __mmask8((1u << rem) - 1u));
+// the 8-row band j0 of chol_blk_update over the columns [j0, ncols)
+__attribute__((target("avx512f,fma"))) inline void chol_band_update(const double *S, const double *U, double *A, int lda, int j0, int ncols, int k0, int k1) {
+  int i = j0;
+  for (; i + 24 <= ncols; i += 24) chol_blk_update<3>(S, U, A, lda, j0, i, __mmask8(0xFF), k0, k1);
+  const int rem = ncols - i;   // 0 .. 23
+  if (rem > 16) chol_blk_update<3>(S, U, A, lda, j0, i, __mmask8((1u << (rem - 16)) - 1u), k0, k1);
+  else if (rem > 8) chol_blk_update<2>(S, U, A, lda, j0, i, __mmask8((1u << (rem - 8)) - 1u), k0, k1);
+  else if (rem > 0) chol_blk_update<1>(S, U, A, lda, j0, i, __mmask8((1u << rem) - 1u), k0, k1);
+}
+// Rows [j_begin, j_end) of the factorisation A = chol(S + diag(shift)) of an n x n matrix carried with ncols >= n columns (the
+// columns from n on are right-hand sides: they come out as U^-T b).  j_begin a multiple of 8; j_end a multiple of 8 or n.  The
+// rows above j_begin must already hold their part of the factor in A, and the rows from j_begin on of S must already carry the
+// contribution of the rows [0, k_begin) (chol_gram_avx512) — k_begin = 0 for a factorisation in one go.  lda >= ncols rounded
+// up to 8 is NOT required (all accesses are masked), lda >= ncols is.
+__attribute__((target("avx512f,fma"))) inline bool chol_upper_panels_avx512(const double *S, double *A, int n, int ncols, int lda, const double *shift,
+                                                                            int j_begin, int j_end, int k_begin) {
+  int j0 = j_begin;
+  for (; j0 + 8 <= j_end; j0 += 8) {
+    chol_band_update(S, A, A, lda, j0, ncols, k_begin, j0);
     double d[8][8], inv[8];
     for (int r = 0; r < 8; ++r) for (int c = r; c < 8; ++c) d[r][c] = A[size_t(j0 + r) * lda + j0 + c];
     if (shift) for (int r = 0; r < 8; ++r) d[r][r] += shift[j0 + r];
@@ -153,8 +170,8 @@ __attribute__((target("avx512f,fma"))) inline bool chol_upper_from_avx512(const 
       for (int r = j + 1; r < 8; ++r) for (int c = r; c < 8; ++c) d[r][c] = std::fma(-d[j][r], d[j][c], d[r][c]);
     }
     for (int r = 0; r < 8; ++r) for (int c = r; c < 8; ++c) A[size_t(j0 + r) * lda + j0 + c] = d[r][c];
-    for (i = j0 + 8; i < n; i += 8) {
-      const __mmask8 m = (n - i >= 8) ? __mmask8(0xFF) : __mmask8((1u << (n - i)) - 1u);
+    for (int i = j0 + 8; i < ncols; i += 8) {
+      const __mmask8 m = (ncols - i >= 8) ? __mmask8(0xFF) : __mmask8((1u << (ncols - i)) - 1u);
       __m512d a[8];
       for (int r = 0; r < 8; ++r) a[r] = _mm512_maskz_loadu_pd(m, A + size_t(j0 + r) * lda + i);
 #pragma GCC unroll 8
@@ -166,19 +183,35 @@ __attribute__((target("avx512f,fma"))) inline bool chol_upper_from_avx512(const 
       for (int r = 0; r < 8; ++r) _mm512_mask_storeu_pd(A + size_t(j0 + r) * lda + i, m, a[r]);
     }
   }
+  if (j_end < n) return true;
   for (int j = j0; j < n; ++j) {   // the last n mod 8 rows: plain recurrence
     double *rj = A + size_t(j) * lda;
     const double *sj = S + size_t(j) * lda;
-    for (int i = j; i < n; ++i) rj[i] = sj[i];
+    for (int i = j; i < ncols; ++i) rj[i] = sj[i];
     if (shift) rj[j] += shift[j];
-    for (int k = 0; k < j; ++k) { const double *rk = A + size_t(k) * lda; const double f = rk[j]; for (int i = j; i < n; ++i) rj[i] = std::fma(-f, rk[i], rj[i]); }
+    for (int k = k_begin; k < j; ++k) { const double *rk = A + size_t(k) * lda; const double f = rk[j]; for (int i = j; i < ncols; ++i) rj[i] = std::fma(-f, rk[i], rj[i]); }
     if (!(rj[j] > 0.0)) return false;
     const double u = std::sqrt(rj[j]);
     rj[j] = u;
     const double iu = 1.0 / u;
-    for (int i = j + 1; i < n; ++i) rj[i] *= iu;
+    for (int i = j + 1; i < ncols; ++i) rj[i] *= iu;
   }
   return true;
+}
+// T[j][i] = - sum_{k in [k0, k1)} U[k][j] U[k][i] for the rows j in [j_begin, n) and the columns i from the start of j's 8-row band
+// (the row itself for the last n mod 8 rows) to ncols: what the factor rows [k0, k1) take from the rows below them, formed ahead
+// of time (SplitFactor: the speed-bias rows' contribution to the pose block while the lidar moments are still on their way).
+__attribute__((target("avx512f,fma"))) inline void chol_gram_avx512(const double *U, double *T, int n, int ncols, int lda, int j_begin, int k0, int k1) {
+  int j0 = j_begin;
+  for (; j0 + 8 <= n; j0 += 8) chol_band_update(nullptr, U, T, lda, j0, ncols, k0, k1);
+  for (int j = j0; j < n; ++j) {
+    double *tj = T + size_t(j) * lda;
+    for (int i = j; i < ncols; ++i) tj[i] = 0.0;
+    for (int k = k0; k < k1; ++k) { const double *rk = U + size_t(k) * lda; const double f = rk[j]; if (f == 0.0) continue; for (int i = j; i < ncols; ++i) tj[i] = std::fma(-f, rk[i], tj[i]); }
+  }
+}
+__attribute__((target("avx512f,fma"))) inline bool chol_upper_from_avx512(const double *S, double *A, int n, int lda, const double *shift) {
+  return chol_upper_panels_avx512(S, A, n, n, lda, shift, 0, n, 0);
 }
 inline bool host_has_avx512() {
   static const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
@@ -231,6 +264,31 @@ __attribute__((target("avx512f,fma"))) inline double sym_quad_avx512(const doubl
 inline double sym_quad(const double *H, const double *x, int n, int lda, double *y = nullptr) {
   return host_has_avx512() ? sym_quad_avx512(H, x, n, lda, y) : sym_quad_portable(H, x, n, lda, y);
 }
+// y = y0 + A x for a row-major n x n A (the marginalization prior's r0 + J0 dx and J^T r0 + J^T J dx, twice per linearisation): a
+// row's dot product is a chain of n dependent adds under strict IEEE semantics; eight-lane partial sums on hosts with AVX-512.
+inline void affine_matvec_portable(const double *A, int n, int lda, const double *x, const double *y0, double *y) {
+  for (int i = 0; i < n; ++i) { double s = y0[i]; const double *row = A + size_t(i) * lda; for (int j = 0; j < n; ++j) s += row[j] * x[j]; y[i] = s; }
+}
+__attribute__((target("avx512f,fma"))) inline void affine_matvec_avx512(const double *A, int n, int lda, const double *x, const double *y0, double *y) {
+  const int nb = n & ~7;
+  const __mmask8 m = __mmask8((1u << (n - nb)) - 1u);
+  for (int i = 0; i < n; ++i) {
+    const double *row = A + size_t(i) * lda;
+    __m512d a0 = _mm512_setzero_pd(), a1 = _mm512_setzero_pd();
+    int j = 0;
+    for (; j + 16 <= nb; j += 16) {
+      a0 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j), _mm512_loadu_pd(x + j), a0);
+      a1 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j + 8), _mm512_loadu_pd(x + j + 8), a1);
+    }
+    if (j + 8 <= nb) { a0 = _mm512_fmadd_pd(_mm512_loadu_pd(row + j), _mm512_loadu_pd(x + j), a0); j += 8; }
+    if (m) a1 = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, row + j), _mm512_maskz_loadu_pd(m, x + j), a1);
+    y[i] = y0[i] + _mm512_reduce_add_pd(_mm512_add_pd(a0, a1));
+  }
+}
+inline void affine_matvec(const double *A, int n, int lda, const double *x, const double *y0, double *y) {
+  if (host_has_avx512()) affine_matvec_avx512(A, n, lda, x, y0, y); else affine_matvec_portable(A, n, lda, x, y0, y);
+}
+
 // solve U^T U x = b in place
 inline void chol_upper_solve_portable(const double *U, int n, int lda, double *b) {
   for (int i = 0; i < n; ++i) {  // forward: U^T y = b, column-oriented (axpy)
@@ -291,6 +349,40 @@ __attribute__((target("avx512f,fma"))) inline void chol_upper_solve_avx512(const
     for (int k = i + 1; k < n; ++k) b[k] = std::fma(-ri[k], yv, b[k]);
   }
   // backward: U x = y
+  for (int i = n - 1; i >= nb; --i) {
+    const double *ri = U + size_t(i) * lda;
+    double sres = b[i];
+    for (int k = i + 1; k < n; ++k) sres = std::fma(-ri[k], b[k], sres);
+    b[i] = sres * iv[i];
+  }
+  for (int i0 = nb - 8; i0 >= 0; i0 -= 8) {
+    __m512d acc[8];
+    for (int r = 0; r < 8; ++r) acc[r] = _mm512_setzero_pd();
+    for (int k = i0 + 8; k < n; k += 8) {
+      const __mmask8 m = (n - k >= 8) ? __mmask8(0xFF) : __mmask8((1u << (n - k)) - 1u);
+      const __m512d xv = _mm512_maskz_loadu_pd(m, b + k);
+#pragma GCC unroll 8
+      for (int r = 0; r < 8; ++r) acc[r] = _mm512_fmadd_pd(_mm512_maskz_loadu_pd(m, U + size_t(i0 + r) * lda + k), xv, acc[r]);
+    }
+    double x[8];
+    for (int r = 0; r < 8; ++r) x[r] = b[i0 + r] - _mm512_reduce_add_pd(acc[r]);
+    for (int j = 7; j >= 0; --j) {
+      const double *rj = U + size_t(i0 + j) * lda + i0;
+      double sres = x[j];
+      for (int r = j + 1; r < 8; ++r) sres = std::fma(-rj[r], x[r], sres);
+      x[j] = sres * iv[i0 + j];
+    }
+    for (int r = 0; r < 8; ++r) b[i0 + r] = x[r];
+  }
+}
+// x <- U^-1 x (the backward sweep of chol_upper_solve_avx512 on its own: SplitFactor gets U^-T b from the factorisation itself)
+__attribute__((target("avx512f,fma"))) inline void upper_backsolve_avx512(const double *U, int n, int lda, double *b) {
+  double inv[256];
+  std::vector<double> inv_big;
+  double *iv = inv;
+  if (n > 256) { inv_big.resize(n); iv = inv_big.data(); }
+  for (int i = 0; i < n; ++i) iv[i] = 1.0 / U[size_t(i) * lda + i];
+  const int nb = n & ~7;
   for (int i = n - 1; i >= nb; --i) {
     const double *ri = U + size_t(i) * lda;
     double sres = b[i];

@@ -294,6 +294,108 @@ inline bool imu_factor(const Preintegration &pim, const double *pose_i, const do
   return true;
 }
 
+// ---- the same factor as ONE block of the normal equations (what WindowSystem::evaluate adds per IMU factor), for hosts with
+// AVX-512.  imu_raw_local forms the unwhitened residual and the 15 x 30 Jacobian in the LOCAL column layout
+// [pose_i 6 | speed-bias_i 9 | pose_j 6 | speed-bias_j 9] (padded to 32) with the shared quantities — R_i^T, the corrected delta
+// rotation, the bias Jacobians — computed once (imu_raw_jacobian above forms them per block); the entries are the expressions of
+// imu_raw_jacobian, the local columns of a pose being the first six ambient ones.  imu_block_avx512 whitens with the upper
+// factor S of the information matrix (rows of 4 vectors), then H_b = J_w^T J_w and g_b = J_w^T r_w in register tiles of 6 x 4
+// vectors.  The whitened residual is summed exactly as imu_factor sums it, so the cost is bit-identical; H_b and g_b differ from
+// the scalar path in the last bits (fused multiply-adds).
+#define LIO_IMU_LD 32
+inline void imu_raw_local(const PimCore &c, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j, double r[15],
+                          double *J /* 15 x LIO_IMU_LD, zero-filled here */) {
+  V3d Pi, Pj; Qd Qi, Qj;
+  unpack_pose(pose_i, Pi, Qi); unpack_pose(pose_j, Pj, Qj);
+  const V3d Vi(sb_i[0], sb_i[1], sb_i[2]), Bai(sb_i[3], sb_i[4], sb_i[5]), Bgi(sb_i[6], sb_i[7], sb_i[8]);
+  const V3d Vj(sb_j[0], sb_j[1], sb_j[2]), Baj(sb_j[3], sb_j[4], sb_j[5]), Bgj(sb_j[6], sb_j[7], sb_j[8]);
+  pim_residual(c, Pi, Qi, Vi, Bai, Bgi, Pj, Qj, Vj, Baj, Bgj, r);
+  const double sum_dt = c.sum_dt;
+  const V3d g(c.g[0], c.g[1], c.g[2]), pbg(c.bg[0], c.bg[1], c.bg[2]);
+  const Qd pdq(c.dq[0], c.dq[1], c.dq[2], c.dq[3]);
+  const M3d dp_dba = get3(c.jac, 15, kOP, kOBA), dp_dbg = get3(c.jac, 15, kOP, kOBG), dq_dbg = get3(c.jac, 15, kOR, kOBG);
+  const M3d dv_dba = get3(c.jac, 15, kOV, kOBA), dv_dbg = get3(c.jac, 15, kOV, kOBG);
+  const Qd Qii = qinverse(Qi);
+  const M3d RiT = toRot(Qii);
+  const Qd cq = pdq * deltaQ(dq_dbg * (Bgi - pbg));
+  for (int k = 0; k < 15 * LIO_IMU_LD; ++k) J[k] = 0.0;
+  const int cPi = 0, cRi = 3, cVi = 6, cBai = 9, cBgi = 12, cPj = 15, cRj = 18, cVj = 21, cBaj = 24, cBgj = 27;
+  const M3d I = M3d::identity();
+  // d r / d pose_i
+  put3(J, LIO_IMU_LD, kOP, cPi, -RiT);
+  put3(J, LIO_IMU_LD, kOP, cRi, skew(rotate(Qii, (-0.5) * g * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt)));
+  put3(J, LIO_IMU_LD, kOR, cRi, -left_right_tl3(qinverse(Qj) * Qi, cq));
+  put3(J, LIO_IMU_LD, kOV, cRi, skew(rotate(Qii, (-1.0) * g * sum_dt + Vj - Vi)));
+  // d r / d speed-bias_i
+  put3(J, LIO_IMU_LD, kOP, cVi, -RiT * sum_dt);
+  put3(J, LIO_IMU_LD, kOP, cBai, -dp_dba);
+  put3(J, LIO_IMU_LD, kOP, cBgi, -dp_dbg);
+  put3(J, LIO_IMU_LD, kOR, cBgi, -left_tl3(qinverse(Qj) * Qi * cq) * dq_dbg);
+  put3(J, LIO_IMU_LD, kOV, cVi, -RiT);
+  put3(J, LIO_IMU_LD, kOV, cBai, -dv_dba);
+  put3(J, LIO_IMU_LD, kOV, cBgi, -dv_dbg);
+  put3(J, LIO_IMU_LD, kOBA, cBai, -I);
+  put3(J, LIO_IMU_LD, kOBG, cBgi, -I);
+  // d r / d pose_j
+  put3(J, LIO_IMU_LD, kOP, cPj, RiT);
+  put3(J, LIO_IMU_LD, kOR, cRj, left_tl3(qinverse(cq) * Qii * Qj));
+  // d r / d speed-bias_j
+  put3(J, LIO_IMU_LD, kOV, cVj, RiT);
+  put3(J, LIO_IMU_LD, kOBA, cBaj, I);
+  put3(J, LIO_IMU_LD, kOBG, cBgj, I);
+}
+
+// Hb: 30 x LIO_IMU_LD (columns 30, 31 zero), gb: LIO_IMU_LD, rw: the whitened residual (15)
+__attribute__((target("avx512f,fma"))) inline void imu_block_avx512(const double *S /* 15 x 15 upper */, const double *J /* 15 x LIO_IMU_LD */,
+                                                                      const double *r, double *Hb, double *gb, double *rw) {
+  alignas(64) double Jw[15 * LIO_IMU_LD];
+  for (int i = 0; i < 15; ++i) {
+    __m512d a0 = _mm512_setzero_pd(), a1 = a0, a2 = a0, a3 = a0;
+    double sres = 0;
+    for (int k = i; k < 15; ++k) {
+      const double f = S[i * 15 + k];
+      const __m512d fv = _mm512_set1_pd(f);
+      const double *jr = J + k * LIO_IMU_LD;
+      a0 = _mm512_fmadd_pd(fv, _mm512_loadu_pd(jr), a0); a1 = _mm512_fmadd_pd(fv, _mm512_loadu_pd(jr + 8), a1);
+      a2 = _mm512_fmadd_pd(fv, _mm512_loadu_pd(jr + 16), a2); a3 = _mm512_fmadd_pd(fv, _mm512_loadu_pd(jr + 24), a3);
+      sres += f * r[k];
+    }
+    double *o = Jw + i * LIO_IMU_LD;
+    _mm512_store_pd(o, a0); _mm512_store_pd(o + 8, a1); _mm512_store_pd(o + 16, a2); _mm512_store_pd(o + 24, a3);
+    rw[i] = sres;
+  }
+  {
+    __m512d g0 = _mm512_setzero_pd(), g1 = g0, g2 = g0, g3 = g0;
+    for (int k = 0; k < 15; ++k) {
+      const __m512d fv = _mm512_set1_pd(rw[k]);
+      const double *jr = Jw + k * LIO_IMU_LD;
+      g0 = _mm512_fmadd_pd(fv, _mm512_load_pd(jr), g0); g1 = _mm512_fmadd_pd(fv, _mm512_load_pd(jr + 8), g1);
+      g2 = _mm512_fmadd_pd(fv, _mm512_load_pd(jr + 16), g2); g3 = _mm512_fmadd_pd(fv, _mm512_load_pd(jr + 24), g3);
+    }
+    _mm512_storeu_pd(gb, g0); _mm512_storeu_pd(gb + 8, g1); _mm512_storeu_pd(gb + 16, g2); _mm512_storeu_pd(gb + 24, g3);
+  }
+  for (int a0 = 0; a0 < 30; a0 += 6) {
+    __m512d acc[6][4];
+#pragma GCC unroll 6
+    for (int q = 0; q < 6; ++q) { acc[q][0] = _mm512_setzero_pd(); acc[q][1] = acc[q][0]; acc[q][2] = acc[q][0]; acc[q][3] = acc[q][0]; }
+    for (int k = 0; k < 15; ++k) {
+      const double *jr = Jw + k * LIO_IMU_LD;
+      const __m512d v0 = _mm512_load_pd(jr), v1 = _mm512_load_pd(jr + 8), v2 = _mm512_load_pd(jr + 16), v3 = _mm512_load_pd(jr + 24);
+#pragma GCC unroll 6
+      for (int q = 0; q < 6; ++q) {
+        const __m512d fv = _mm512_set1_pd(jr[a0 + q]);
+        acc[q][0] = _mm512_fmadd_pd(fv, v0, acc[q][0]); acc[q][1] = _mm512_fmadd_pd(fv, v1, acc[q][1]);
+        acc[q][2] = _mm512_fmadd_pd(fv, v2, acc[q][2]); acc[q][3] = _mm512_fmadd_pd(fv, v3, acc[q][3]);
+      }
+    }
+#pragma GCC unroll 6
+    for (int q = 0; q < 6; ++q) {
+      double *o = Hb + (a0 + q) * LIO_IMU_LD;
+      _mm512_storeu_pd(o, acc[q][0]); _mm512_storeu_pd(o + 8, acc[q][1]); _mm512_storeu_pd(o + 16, acc[q][2]); _mm512_storeu_pd(o + 24, acc[q][3]);
+    }
+  }
+}
+
 // residual + 1x7 Jacobians (null = skip)
 // The pose-dependent part of PivotPointPlaneFactor::Evaluate (PivotPointPlaneFactor.cc:58-70 and the rotation matrices of
 // :85-128), shared by every residual of a (pivot, frame i, extrinsic) triple.

@@ -260,6 +260,7 @@ class WindowSystem {
   EvalClock eclk;
   static constexpr int LMAP_STRIDE = 18 * 13 + 13 * LIO_LT_LD;
   std::vector<double> lmaps_;                    // per frame: L (18 x 13) and [L^T | l] (13 x LIO_LT_LD) of the current evaluate() call
+  std::vector<double> prior_scratch_;            // the prior's residual and gradient (no allocation per linearisation)
   std::vector<FrameMoments> moments_scratch_;    // landing zone of the device pass (no allocation per linearisation)
   static double clk_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -285,11 +286,13 @@ class WindowSystem {
       prior_dx(pr, P, dx);
       // r = r0 + J0 dx;  cost = 0.5 |r|^2;  J^T r = Jtr0 + JtJ dx
       double cost = 0;
-      for (int i = 0; i < pr.n; ++i) { double s = pr.lin_res[i]; for (int j = 0; j < pr.n; ++j) s += pr.lin_jac(i, j) * dx[j]; cost += s * s; }
+      prior_scratch_.resize(2 * size_t(pr.n));
+      double *rb = prior_scratch_.data(), *gb = rb + pr.n;
+      affine_matvec(pr.lin_jac.a.data(), pr.n, pr.n, dx.data(), pr.lin_res.data(), rb);
+      for (int i = 0; i < pr.n; ++i) cost += rb[i] * rb[i];
       c.marg = 0.5 * cost;
       if (H) {
-        std::vector<double> gb(pr.n);
-        for (int i = 0; i < pr.n; ++i) { double s = pr.Jtr0[i]; for (int j = 0; j < pr.n; ++j) s += pr.JtJ(i, j) * dx[j]; gb[i] = s; }
+        affine_matvec(pr.JtJ.a.data(), pr.n, pr.n, dx.data(), pr.Jtr0.data(), gb);
         for (size_t a = 0; a < pr.keep.size(); ++a) {
           const KeepBlock &ka = pr.keep[a];
           int ca = ka.kind == 0 ? lay.pose[ka.index] : (ka.kind == 1 ? lay.sb[ka.index] : lay.ex);
@@ -311,6 +314,22 @@ class WindowSystem {
       int last = imu_only_first ? 1 : Wo;
       for (int i = 0; i < last; ++i) {
         if (!pim[i]) continue;
+        if (H && host_has_avx512()) {
+          // one block per factor: raw Jacobian once, whitening and J^T J in vector registers (host_factors.h: imu_block_avx512)
+          const double *Sq = pim[i]->sqrt_info();
+          if (Sq) {
+            alignas(64) double Jl[15 * LIO_IMU_LD], Hb[30 * LIO_IMU_LD], gb[LIO_IMU_LD];
+            double r0[15], rw[15];
+            imu_raw_local(pim[i]->core(), P.pose[i].data(), P.sb[i].data(), P.pose[i + 1].data(), P.sb[i + 1].data(), r0, Jl);
+            imu_block_avx512(Sq, Jl, r0, Hb, gb, rw);
+            double cost = 0;
+            for (int k = 0; k < 15; ++k) cost += rw[k] * rw[k];
+            c.pim += 0.5 * cost;
+            int cols[4] = {lay.pose[i], lay.sb[i], lay.pose[i + 1], lay.sb[i + 1]}, sizes[4] = {6, 9, 6, 9};
+            add_block(*H, *g, cols, sizes, 4, Hb, gb, LIO_IMU_LD);
+            continue;
+          }
+        }
         double r[15], J0[105], J1[135], J2[105], J3[135];
         imu_factor(*pim[i], P.pose[i].data(), P.sb[i].data(), P.pose[i + 1].data(), P.sb[i + 1].data(), r, H ? J0 : nullptr, H ? J1 : nullptr,
                    H ? J2 : nullptr, H ? J3 : nullptr);
@@ -443,87 +462,62 @@ inline double ambient_norm(const WindowParams &P, const WindowParams *o, double 
 struct SplitFactor {
   bool valid = false;
   double mu = 0;
-  int n1 = 0, n2 = 0;
-  std::vector<int> S, Q;          // speed-bias columns / the rest, ascending
-  std::vector<double> U11, W, y1; // n1 x n1 upper factor, n1 x n2, n1
-  std::vector<double> WtW, Wty;   // n2 x n2 (upper), n2: the Schur update of the pose block, also formed ahead of the wait
-  std::vector<double> diagS;      // sqrt(clamp(H_ii)) of the speed-bias columns as used in A11
+  int n1 = 0, n1p = 0, n2 = 0, n = 0, ld = 0;   // speed-bias columns, the same padded to whole 8-row bands, the rest, n1p + n2, row stride
+  std::vector<int> perm;          // position in the permuted system -> column of the solver's layout (-1: padding)
+  std::vector<double> M, T, shift, xs;   // M: the permuted system / its factor, n x ld, column n = the right-hand side; T: what the
+                                         // speed-bias rows of the factor take from the rows below them (chol_gram_avx512)
   void set_layout(const Layout &lay) {
-    S.clear(); Q.clear();
     std::vector<char> is_sb(lay.dim, 0);
     for (int c : lay.sb) if (c >= 0) for (int k = 0; k < 9; ++k) is_sb[c + k] = 1;
-    for (int i = 0; i < lay.dim; ++i) (is_sb[i] ? S : Q).push_back(i);
-    n1 = int(S.size()); n2 = int(Q.size());
+    perm.clear();
+    for (int i = 0; i < lay.dim; ++i) if (is_sb[i]) perm.push_back(i);
+    n1 = int(perm.size()); n1p = (n1 + 7) & ~7;
+    perm.resize(n1p, -1);
+    for (int i = 0; i < lay.dim; ++i) if (!is_sb[i]) perm.push_back(i);
+    n = int(perm.size()); n2 = n - n1p;
+    ld = (n + 1 + 7) & ~7;
+    M.assign(size_t(n) * ld, 0.0); T.assign(size_t(n) * ld, 0.0); shift.assign(n, 0.0); xs.assign(n, 0.0);
+    valid = false;
   }
-  // Hs, gs: UNSCALED prior + IMU part at the candidate; scale: the solver's fixed Jacobi scaling
-  void prefactor(const DMat &Hs, const std::vector<double> &gs, const std::vector<double> &scale, double mu_) {
+  // Hs, gs: UNSCALED prior + IMU part at the candidate (complete in the speed-bias rows); scale: the solver's fixed Jacobi scaling.
+  // Factors the speed-bias rows of the permuted system [sb | rest] — U11, W = U11^-T A12 and U11^-T g1 fall out of the same band
+  // sweep — and forms -W^T [W | y1], all of it while the device pass over the lidar factors is in flight.
+  __attribute__((target("avx512f,fma"))) void prefactor(const DMat &Hs, const std::vector<double> &gs, const std::vector<double> &scale, double mu_) {
     valid = false; mu = mu_;
-    U11.assign(size_t(n1) * n1, 0.0); W.assign(size_t(n1) * n2, 0.0); y1.assign(n1, 0.0); diagS.assign(n1, 0.0);
-    for (int a = 0; a < n1; ++a) {
-      const int i = S[a];
+    for (int p = 0; p < n1p; ++p) {
+      double *row = &M[size_t(p) * ld];
+      const int i = perm[p];
+      if (i < 0) { for (int q = p; q <= n; ++q) row[q] = 0.0; row[p] = 1.0; shift[p] = 0.0; continue; }
       const double si = scale[i];
-      for (int b = a; b < n1; ++b) U11[size_t(a) * n1 + b] = Hs(i, S[b]) * (si * scale[S[b]]);
-      for (int b = 0; b < n2; ++b) W[size_t(a) * n2 + b] = Hs(i, Q[b]) * (si * scale[Q[b]]);
-      const double hii = U11[size_t(a) * n1 + a];
-      diagS[a] = std::sqrt(std::min(std::max(hii, 1e-6), 1e32));
-      U11[size_t(a) * n1 + a] = hii + diagS[a] * diagS[a] * mu;
-      y1[a] = gs[i] * si;
+      const double *hrow = &Hs.a[size_t(i) * Hs.c];
+      for (int q = p; q < n; ++q) { const int j = perm[q]; row[q] = j < 0 ? 0.0 : hrow[j] * (si * scale[j]); }
+      row[n] = gs[i] * si;
+      const double d = std::sqrt(std::min(std::max(row[p], 1e-6), 1e32));
+      shift[p] = d * d * mu;
     }
-    if (!chol_upper(U11.data(), n1, n1)) return;
-    // W <- U11^-T A12 and y1 <- U11^-T g1: forward substitution, row-axpy form
-    for (int i = 0; i < n1; ++i) {
-      const double inv = 1.0 / U11[size_t(i) * n1 + i];
-      double *wi = &W[size_t(i) * n2];
-      for (int b = 0; b < n2; ++b) wi[b] *= inv;
-      y1[i] *= inv;
-      const double yi = y1[i];
-      for (int k = i + 1; k < n1; ++k) {
-        const double f = U11[size_t(i) * n1 + k];
-        if (f == 0.0) continue;
-        double *wk = &W[size_t(k) * n2];
-        for (int b = 0; b < n2; ++b) wk[b] -= f * wi[b];
-        y1[k] -= f * yi;
-      }
-    }
-    WtW.assign(size_t(n2) * n2, 0.0); Wty.assign(n2, 0.0);
-    for (int k = 0; k < n1; ++k) {   // one outer product per row of W (upper triangle)
-      const double *wk = &W[size_t(k) * n2];
-      const double yk = y1[k];
-      for (int a = 0; a < n2; ++a) {
-        const double f = wk[a];
-        if (f == 0.0) continue;
-        double *row = &WtW[size_t(a) * n2];
-        for (int b = a; b < n2; ++b) row[b] += f * wk[b];
-        Wty[a] += f * yk;
-      }
-    }
+    if (!chol_upper_panels_avx512(M.data(), M.data(), n, n + 1, ld, shift.data(), 0, n1p, 0)) return;
+    chol_gram_avx512(M.data(), T.data(), n, n + 1, ld, n1p, 0, n1p);
     valid = true;
   }
-  // H, g: the SCALED full system of the accepted candidate; diag as the minimizer computed it.  x <- (H + mu D^2)^-1 g
-  bool finish(const DMat &H, const std::vector<double> &g, const std::vector<double> &diag, std::vector<double> &x, std::vector<double> &A22, std::vector<double> &t2) const {
-    A22.assign(size_t(n2) * n2, 0.0); t2.assign(n2, 0.0);
-    for (int a = 0; a < n2; ++a) {
-      const int i = Q[a];
-      double *row = &A22[size_t(a) * n2];
-      const double *sw = &WtW[size_t(a) * n2];
-      for (int b = a; b < n2; ++b) row[b] = H(i, Q[b]) - sw[b];
-      row[a] += diag[i] * diag[i] * mu;
-      t2[a] = g[i] - Wty[a];
+  // H, g: the SCALED full system of the accepted candidate; diag as the minimizer computed it.  x <- (H + mu D^2)^-1 g: only the
+  // pose / extrinsic rows are left to factor.
+  __attribute__((target("avx512f,fma"))) bool finish(const DMat &H, const std::vector<double> &g, const std::vector<double> &diag, std::vector<double> &x) {
+    const int nfull = n & ~7;
+    for (int p = n1p; p < n; ++p) {
+      const int i = perm[p];
+      double *row = &M[size_t(p) * ld];
+      const double *trow = &T[size_t(p) * ld];
+      const double *hrow = &H.a[size_t(i) * H.c];
+      const int q0 = p < nfull ? (p & ~7) : p;   // chol_band_update reads a band from its first column on
+      for (int q = q0; q < n; ++q) row[q] = hrow[perm[q]] + trow[q];
+      row[n] = g[i] + trow[n];
+      shift[p] = diag[i] * diag[i] * mu;
     }
-    if (!chol_upper(A22.data(), n2, n2)) return false;
-    chol_upper_solve(A22.data(), n2, n2, t2.data());
-    x.assign(n1 + n2, 0.0);
-    // x1 = U11^-1 (y1 - W x2)
-    std::vector<double> r1(y1);
-    for (int k = 0; k < n1; ++k) { const double *wk = &W[size_t(k) * n2]; double sres = 0; for (int b = 0; b < n2; ++b) sres += wk[b] * t2[b]; r1[k] -= sres; }
-    for (int i = n1 - 1; i >= 0; --i) {
-      const double *ri = &U11[size_t(i) * n1];
-      double sres = r1[i];
-      for (int k = i + 1; k < n1; ++k) sres -= ri[k] * r1[k];
-      r1[i] = sres / ri[i];
-    }
-    for (int a = 0; a < n1; ++a) x[S[a]] = r1[a];
-    for (int a = 0; a < n2; ++a) x[Q[a]] = t2[a];
+    if (!chol_upper_panels_avx512(M.data(), M.data(), n, n + 1, ld, shift.data(), n1p, n, n1p)) return false;
+    for (int p = 0; p < n; ++p) xs[p] = M[size_t(p) * ld + n];
+    upper_backsolve_avx512(M.data(), n, ld, xs.data());
+    x.assign(H.r, 0.0);
+    for (int p = 0; p < n; ++p) if (perm[p] >= 0) x[perm[p]] = xs[p];
     return true;
   }
 };
@@ -531,6 +525,17 @@ struct SplitFactor {
 // Ceres 1.14 TrustRegionMinimizer + DoglegStrategy (TRADITIONAL_DOGLEG), jacobi_scaling = true.
 // first_eval (optional) lets the caller reuse the linearisation it already made for the group costs.
 struct Linearization { DMat H; std::vector<double> g; WindowSystem::Costs costs; std::vector<FrameMoments> m; bool valid = false; };
+
+// phase clock of the loop's own arithmetic (tools/micro/host_eval_timing.hip builds with -DLIO_DOGLEG_CLOCK; off otherwise)
+#ifdef LIO_DOGLEG_CLOCK
+struct DoglegClock { double t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double last = 0; };
+inline DoglegClock &dogleg_clock() { static DoglegClock c; return c; }
+#define LIO_DCLK_START() (dogleg_clock().last = WindowSystem::clk_now())
+#define LIO_DCLK(k) do { const double t_ = WindowSystem::clk_now(); dogleg_clock().t[k] += t_ - dogleg_clock().last; dogleg_clock().last = t_; } while (0)
+#else
+#define LIO_DCLK_START() ((void)0)
+#define LIO_DCLK(k) ((void)0)
+#endif
 
 inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_iterations, double max_time_s, Linearization *first = nullptr) {
   using clock = std::chrono::steady_clock;
@@ -570,12 +575,12 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
   int invalid = 0, it = 0;
   DMat Hc; std::vector<double> gc;  // candidate linearisation; swapped with (H, g) on acceptance, never reallocated
   SplitFactor spec;                 // speed-bias block of the candidate, factored under its device pass
-  std::vector<double> A22, t2;
-  // Opt-in (LIO_SPLIT_FACTOR=1).  Measured on the MI355X box (EPYC 9575F, D = 96): the pose-block factorisation left on the
-  // critical path costs 4.1 us instead of 8.7 us, but the dense pre-factor takes 10.6 us and the host is not the long pole of an
-  // evaluation — the device pass becomes visible to the host ~24 us after the first launch call whatever the host does meanwhile
-  // (hipStreamSynchronize measures 9.5-10 us per call with or without the extra hidden work) — so t_opt went 0.43 -> 0.51 ms.
-  static const bool use_split = [] { const char *e = std::getenv("LIO_SPLIT_FACTOR"); return e && std::atoi(e) != 0; }();
+  // On by default where the host has AVX-512 (LIO_SPLIT_FACTOR=0 turns it off).  History: the first form (round 2: scalar loops, a
+  // 10.6 us pre-factor on the EPYC 9575F against 4.6 us saved behind the wait) lost, because the host was not the long pole of an
+  // evaluation then.  Since the resident kernel a pass takes ~15 us from ring to moments and the host's serial tail
+  // behind it is a third of a linearisation; the pre-factor now runs on the band kernels of the blocked Cholesky (hlinalg.h) and
+  // skips the structural zeros of the block-bidiagonal speed-bias factor.
+  static const bool use_split = [] { const char *e = std::getenv("LIO_SPLIT_FACTOR"); return (e ? std::atoi(e) != 0 : true) && host_has_avx512(); }();
   if (use_split) spec.set_layout(lay);
   while (true) {
     if (it >= max_iterations) { sum.termination = 0; break; }
@@ -584,6 +589,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     if (radius <= 1e-32) { sum.termination = 1; break; }
     ++it;
     bool lin_ok = true;
+    LIO_DCLK_START();
     if (!reuse) {
       reuse = true;
       for (int i = 0; i < n; ++i) diag[i] = std::sqrt(std::min(std::max(H(i, i), 1e-6), 1e32));
@@ -592,11 +598,12 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       Jg2 = sym_quad(H.a.data(), tmp.data(), n, n);
       alpha = g2 / Jg2;
       lin_ok = false;
+      LIO_DCLK(0);   // diag + Cauchy step length
       while (mu < max_mu) {
         const auto tc0 = clock::now();
         bool ok;
         if (spec.valid && spec.mu == mu) {   // only the pose / extrinsic block is left to factor
-          ok = spec.finish(H, g, diag, gn, A22, t2);
+          ok = spec.finish(H, g, diag, gn);
           spec.valid = false;
         } else {
           for (int i = 0; i < n; ++i) shift[i] = diag[i] * diag[i] * mu;
@@ -613,6 +620,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
         break;
       }
       if (lin_ok) for (int i = 0; i < n; ++i) gn[i] *= -diag[i];
+      LIO_DCLK(1);   // factorisation + Gauss-Newton step
     }
     bool valid = lin_ok;
     double model_change = 0;
@@ -638,6 +646,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       for (int i = 0; i < n; ++i) sg += step[i] * g[i];
       model_change = -(sg + 0.5 * sHs);
       if (!(model_change > 0)) valid = false;
+      LIO_DCLK(2);   // dogleg combination + model change
     }
     if (!valid) {
       if (++invalid >= 5) { sum.termination = 5; break; }
@@ -652,6 +661,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     plus_all(P, lay, delta, cand);
     // Evaluate cost AND linearisation at the candidate in one device pass: if the step is accepted the
     // Jacobian evaluation Ceres performs next (HandleSuccessfulStep) is already done.
+    LIO_DCLK(3);   // candidate parameters
     const auto te0 = clock::now();
     if (use_split && spec.n1 > 0) {
       // if this candidate is accepted the next factorisation uses mu' = max(min_mu, 2 mu / mu_inc) (below): factor its
@@ -662,6 +672,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
     double cand_cost = sys.evaluate(cand, lay, which, false, &Hc, &gc, &m_cand).total();
     sys.static_part_hook = nullptr;
     sum.ms_eval += std::chrono::duration<double, std::milli>(clock::now() - te0).count();
+    LIO_DCLK_START();
     double step_norm = ambient_norm(P, &cand);
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 1; sum.trace.push_back(x_cost); break; }
     double cost_change = x_cost - cand_cost;
@@ -685,6 +696,7 @@ inline SolveSummary solve_dogleg(WindowSystem &sys, WindowParams &P, int max_ite
       spec.valid = false;   // the pre-factored block belonged to the rejected candidate
     }
     sum.trace.push_back(x_cost);
+    LIO_DCLK(4);   // acceptance: norms, gradient maximum, scaling of the new (H, g)
   }
   sum.iterations = it;
   sum.final_cost = x_cost;

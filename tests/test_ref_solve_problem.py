@@ -69,12 +69,13 @@ def pack(case, step):
     return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts])
 
 
+@pytest.mark.parametrize("split", ["0", "1"])   # LIO_SPLIT_FACTOR: the full factorisation / the speed-bias rows factored ahead of the moments
 @pytest.mark.parametrize("case,step", PROBLEMS)
-def test_product_host_solver_on_the_reference_problem(exe, tmp_path, case, step):
+def test_product_host_solver_on_the_reference_problem(exe, tmp_path, case, step, split):
     k = "%s/s%d/" % (case, step)
     path = str(tmp_path / "problem.f64")
     pack(case, step).tofile(path)
-    r = subprocess.run([exe, path], capture_output=True, text=True, env=dict(os.environ, LIO_SPLIT_FACTOR="0", LIO_CHECK_DUMP_HG="1"))
+    r = subprocess.run([exe, path], capture_output=True, text=True, env=dict(os.environ, LIO_SPLIT_FACTOR=split, LIO_CHECK_DUMP_HG="1"))
     assert r.returncode == 0, r.stderr
     out = {ln.split()[0]: np.array(ln.split()[1:], float) for ln in r.stdout.strip().split("\n")}
     # the first linearisation: the product's normal equations (lidar part from the moments, H_i = L S L^T) against J^T J / J^T r summed
@@ -104,5 +105,5 @@ def test_product_host_solver_on_the_reference_problem(exe, tmp_path, case, step)
     rr = float(np.abs(out["Jtr"] - G[k + "Jtr"]).max() / np.abs(G[k + "Jtr"]).max())
     assert rj <= 1e-7 and rr <= 1e-5, (rj, rr)
     np.testing.assert_allclose(out["x0"], G[k + "x0"], rtol=0, atol=1e-15)
-    print(case, "step", step, "first linearisation dH %.1e dg %.1e" % (dH, dg), "has prior", int(G[k + "header"][2]), "iterations", it, "param gap %.1e" % gap,
+    print(case, "step", step, "split", split, "first linearisation dH %.1e dg %.1e" % (dH, dg), "has prior", int(G[k + "header"][2]), "iterations", it, "param gap %.1e" % gap,
           "trace gap %.1e" % float(np.abs(out["trace"][:want_it + 1] / trace - 1).max()), "JtJ %.1e Jtr %.1e" % (rj, rr))

@@ -234,6 +234,11 @@ int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *xyzi_out, siz
  * stream, timed with HIP events; avg_ms_out = one filter (keys, sort, run heads, centroids, the count's way back to the host).
  * The oracle returns LIO_ERR_DEVICE. */
 int lio_bench_voxel_grid(const float *xyzi, size_t n, float leaf, int reps, double *avg_ms_out, size_t *n_out_or_null);
+/* Test hook (no reference counterpart): how many filters of this process took the one-launch form (a counting sort over the cloud's
+ * own box of cells inside one kernel, csrc/cloud_kernels.hip: k_vox_fused) and how many of those handed the cloud back to the sorted
+ * path (box larger than the counter table, a voxel with more than 32 points, no finite point, a grid barrier that timed out).  Either
+ * output may be null.  The oracle reports 0 / 0. */
+void lio_vox_fused_stats(long long *launched_or_null, long long *fell_back_or_null);
 /* pcl::KdTreeFLANN::nearestKSearch (B.2): exact K-NN, ascending squared distance, index tiebreak.
  * idx_out / sqd_out are m*k.  The product restricts the search to radius_sq (entries beyond it
  * come back as idx -1 / sqd +inf); pass radius_sq <= 0 for an unbounded search (oracle only).  */

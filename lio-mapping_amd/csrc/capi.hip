@@ -410,6 +410,12 @@ static void host_bounds(const float *xyzi, size_t n, float mn[3], float mx[3]) {
     for (int d = 0; d < 3; ++d) { float v = xyzi[4 * i + d]; if (std::isfinite(v)) { mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); } }
 }
 
+void lio_vox_fused_stats(long long *launched, long long *fell_back) {
+  long long a = 0, b = 0;
+  vox_fused_stats(&a, &b);
+  if (launched) *launched = a;
+  if (fell_back) *fell_back = b;
+}
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
   if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
   return guarded([&] {

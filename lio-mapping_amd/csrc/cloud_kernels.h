@@ -52,6 +52,22 @@ class VoxelGridDev {
   const float4 *p_in_ = nullptr; size_t p_n_ = 0; DBuf<float4> *p_out_ = nullptr; hipStream_t p_stream_ = nullptr;  // the pending launch
   float p_leaf_ = 0.f;
   void enqueue(bool exact);
+  // the filter as one launch (k_vox_fused: counting sort over the cloud's own box of cells, grid barriers inside)
+  bool fused_eligible() const;
+  void enqueue_fused();
+  DBuf<uint32_t> f_table_, f_sorted_;
+  DBuf<float4> f_ordered_;
+  DBuf<long long> f_stamps_;
+  DBuf<unsigned long long> f_prefix_, f_wtot_;
+  DBuf<unsigned> f_acc_;
+  void reset_fused_acc(hipStream_t s);
+  DBuf<unsigned> f_bar_;
+  unsigned f_epoch_ = 0;
+  bool fused_pending_ = false, fused_off_ = false, fused_slot_ = false;
+  int fused_fallbacks_ = 0;
+ public:
+  int fused_fallbacks() const { return fused_fallbacks_; }   // filters of this object that fell back to the sorted path
+ private:
   int *h_count_ = nullptr;          // pinned: output count, followed by the VoxParams
   VoxParams *h_params_ = nullptr;
   DBuf<float> partial_;
@@ -64,6 +80,8 @@ class VoxelGridDev {
   HostSignal sig_{};
   bool use_signal_ = true;
 };
+// process-wide counters of the one-launch filter: launches, and those that fell back to the sorted path (lio_vox_fused_stats)
+void vox_fused_stats(long long *launched, long long *fell_back);
 // LIO_HOST_SIGNAL=0: every wait is a hipStreamSynchronize again
 bool host_signal_enabled();
 

@@ -13,6 +13,8 @@
 #include <climits>
 
 #include "cloud_kernels.h"
+
+#include <atomic>
 #include "hmath.h"
 
 namespace lio {
@@ -306,6 +308,380 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
   out[pos] = make_float4(ax / c, ay / c, az / c, ai / c);
 }
 
+// ================================================================================================
+// The filter as ONE launch (round 4).  The library sort of the (voxel, index) keys is launch latency — a block sort and seven
+// merges of ~6 us for 150 k keys — so the sort is replaced by what the voxel index allows: a COUNTING sort over the cloud's own
+// box of cells, all phases inside one kernel whose blocks are co-resident and meet at five grid barriers:
+//   0  every thread keeps its <= VOXF_PPT points in registers; bounds of the cloud (block partials, folded by every block after
+//      barrier 1) -> VoxParams exactly as k_bounds_final forms it, and with it PCL's own voxel index c = i0 + i1 d0 + i2 d0 d1
+//   1  per-cell counters, one BYTE per cell (four cells to a word), incremented by agent-scope atomics (executed at the memory
+//      side, hence coherent over the eight L2s); the old value hands the point its arrival slot in the voxel
+//   2  (after barrier 2) the counter table is read once, 64-cell segments at a time: per segment the number of points and of
+//      occupied cells in front of it inside the reading wave's stretch (a wave scan), per wave the totals
+//   3  (after barrier 3) a point looks up  points-before / voxels-before  = wave base + segment prefix + the bytes in front of its
+//      cell in its own 64-byte segment; it writes its index to sorted_idx[points-before + slot]
+//   4  (after barrier 4) a point of a voxel with company counts the voxel's indices below its own — its position in the order the
+//      stable sort gave, which is the order the oracle's sum runs in — and puts its coordinates there in `ordered`
+//   5  (after barrier 5) the point that arrived first in a voxel adds the voxel's points up in that order (contiguous, eight loads
+//      in flight) and writes the centroid at voxels-before; every point zeroes its counter word: the table is clean for the next run.
+// No fence anywhere (an agent-scope release writes back the L2's dirty lines, dev.h): everything one block reads of another is
+// written with agent-scope stores (written through) and read with agent-scope loads, behind `s_waitcnt vmcnt(0)` + the barrier.
+// Falls back to the sorted path (status 2 in the mail) when the box has more cells than the table, a voxel holds more than
+// VOXF_MAX_CNT points, or the cloud is larger than the grid's registers; status 3 = a barrier timed out (blocks not co-resident).
+#define VOXF_THREADS 1024           // one block per CU: the grid barrier sees <= 256 arrivals, the CU still runs 16 waves
+#define VOXF_PPT 1
+#define VOXF_BAR_LINES 16             // arrival counters per barrier, one cache line each (same-address atomics serialise at the memory side)
+#define VOXF_MAX_CNT 32
+#define VOXF_SEG_WORDS 16            // 64 cells
+#define VOXF_DEAL 4096                // points are dealt to the threads in 4096 strands (see k_vox_fused)
+struct VoxFusedArgs {
+  const float4 *pts; int n; float inv_leaf;
+  uint32_t *table; unsigned table_words;      // capacity; a multiple of 256 (one wave iteration of the scan)
+  unsigned long long *prefix;                 // per segment: (points << 32 | voxels) in front of it inside its block's stretch
+  unsigned long long *wtot;                   // per block: the stretch's totals
+  uint32_t *sorted_idx;
+  float4 *ordered;                            // the points of crowded voxels in voxel order, ascending original index inside a voxel
+  long long *stamps;                          // optional (LIO_DEBUG_TIMING): wall clock of block 0 and of the last block at the phase boundaries
+  unsigned *acc;                              // the bounds of the cloud: seven accumulators, VOXF_ACC_STRIDE words apart (mn[3] and mx[3] as
+                                              // order-preserving codes, the count of finite points); reset by the kernel itself
+  unsigned *bar; unsigned target;             // 4 barriers x VOXF_BAR_LINES arrival counters (16 words apart) that only grow; a line is
+                                              // complete for this launch at `target` (the grid is a multiple of VOXF_BAR_LINES blocks)
+  unsigned *abort_flag; int *bail_flag;
+  float4 *out; int *count; VoxParams *params; VoxMail *mail; HostSignal sig;
+  long long timeout_ticks;
+};
+template <typename T> __device__ __forceinline__ void agent_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ T agent_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all blocks of the grid; false: timed out or another block gave up (the caller leaves).  Every thread's agent-scope stores are
+// acknowledged before its block arrives.
+__device__ __forceinline__ bool voxf_grid_sync(unsigned *ctr, unsigned target, unsigned *abort_flag, long long timeout_ticks) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    // block b arrives on line b mod 16; `target` = arrivals per line once every block of this launch (and of all launches before
+    // it) is in.  The 16 lines are polled by 16 lanes of the block's first wave.
+    const int lane = threadIdx.x;
+    if (lane == 0) __hip_atomic_fetch_add(ctr + (blockIdx.x % VOXF_BAR_LINES) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    for (;;) {
+      const bool in = lane >= VOXF_BAR_LINES || int(agent_load(ctr + lane * 16) - target) >= 0;
+      if (__all(in)) break;
+      if (agent_load(abort_flag) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > timeout_ticks) { if (lane == 0) agent_store(abort_flag, 1u); ok = 0; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+__device__ __forceinline__ unsigned voxf_bytes_sum(uint32_t x) { return __builtin_amdgcn_sad_u8(x, 0u, 0u); }
+__device__ __forceinline__ unsigned voxf_bytes_nonzero(uint32_t x) { return __popc((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u); }
+#define VOXF_STAMP(k) do { if (a.stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) a.stamps[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+// order-preserving code of a float for unsigned atomicMin / atomicMax (the bounds of the cloud are folded at the memory side: one
+// atomic per block and value instead of every block reading every block's partials — 458 k coherent loads of the same 8 KB took
+// 10-25 us in the first form of this kernel)
+__device__ __forceinline__ unsigned voxf_enc(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float voxf_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+#define VOXF_ACC_STRIDE 16   // words between the seven accumulators (a cache line each): mn[3], mx[3], count
+
+__global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int G = int(gridDim.x), nthreads = G * VOXF_THREADS, gid = int(blockIdx.x) * VOXF_THREADS + tid;
+  constexpr int WPB = VOXF_THREADS / 64;   // waves per block
+  const int nwaves = G * WPB, gwave = int(blockIdx.x) * WPB + wv;
+  __shared__ float sred[7][WPB];
+  __shared__ VoxParams svp;
+  __shared__ int s_bail;
+  __shared__ unsigned long long swtot[WPB], sbase[256];   // wave totals of this block; exclusive scan of the blocks' totals (G <= 256)
+  __shared__ unsigned long long s_grand;
+  __shared__ VoxMail smail;
+  VOXF_STAMP(0);
+  // ---- phase 0: the thread's points and the bounds
+  float4 pt[VOXF_PPT];
+  bool fin[VOXF_PPT];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float cnt = 0;
+  // Which point a thread takes: neighbouring lanes get points K apart, not neighbours.  The clouds this filter sees are mostly
+  // concatenations of voxel-ordered stacks, where 64 neighbouring points sit in 64 neighbouring cells — one 64-byte line of the
+  // counter table — and the wave's 64 atomics would queue on that line at the memory side (measured: 15 us for the count phase).
+  const int deal_k = (a.n + VOXF_DEAL - 1) / VOXF_DEAL;   // <= nthreads / VOXF_DEAL
+  int pidx[VOXF_PPT];
+#pragma unroll
+  for (int q = 0; q < VOXF_PPT; ++q) {
+    const int g2 = q * nthreads + gid;
+    const int i = (g2 % VOXF_DEAL) * deal_k + g2 / VOXF_DEAL;
+    pidx[q] = (g2 / VOXF_DEAL < deal_k) ? i : a.n;
+  }
+#pragma unroll
+  for (int q = 0; q < VOXF_PPT; ++q) {
+    const int i = pidx[q];
+    fin[q] = false;
+    pt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < a.n) {
+      pt[q] = a.pts[i];
+      fin[q] = finite3(pt[q]);
+      if (fin[q]) {
+        cnt += 1.f;
+        mn[0] = fminf(mn[0], pt[q].x); mn[1] = fminf(mn[1], pt[q].y); mn[2] = fminf(mn[2], pt[q].z);
+        mx[0] = fmaxf(mx[0], pt[q].x); mx[1] = fmaxf(mx[1], pt[q].y); mx[2] = fmaxf(mx[2], pt[q].z);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) { for (int d = 0; d < 3; ++d) { sred[d][wv] = mn[d]; sred[3 + d][wv] = mx[d]; } sred[6][wv] = cnt; }
+  __syncthreads();
+  if (tid < 7) {
+    float v = sred[tid][0];
+    for (int w = 1; w < WPB; ++w) v = tid < 3 ? fminf(v, sred[tid][w]) : (tid < 6 ? fmaxf(v, sred[tid][w]) : v + sred[tid][w]);
+    unsigned *acc = a.acc + tid * VOXF_ACC_STRIDE;
+    if (tid < 3) { if (v != FLT_MAX) __hip_atomic_fetch_min(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (tid < 6) { if (v != -FLT_MAX) __hip_atomic_fetch_max(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (v > 0.f) __hip_atomic_fetch_add(acc, unsigned(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  VOXF_STAMP(1);
+  if (!voxf_grid_sync(a.bar + 0 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+  VOXF_STAMP(2);
+  if (tid == 0) {
+    // VoxParams exactly as k_bounds_final forms it (min / max are order-free, the count is an integer)
+    VoxParams v;
+    long long dd[3];
+    const unsigned total = agent_load(a.acc + 6 * VOXF_ACC_STRIDE);
+    for (int d = 0; d < 3; ++d) {
+      const float lo = total ? voxf_dec(agent_load(a.acc + d * VOXF_ACC_STRIDE)) : FLT_MAX, hi = total ? voxf_dec(agent_load(a.acc + (3 + d) * VOXF_ACC_STRIDE)) : -FLT_MAX;
+      v.mn[d] = lo; v.mx[d] = hi;
+      dd[d] = (long long)((hi - lo) * a.inv_leaf) + 1;
+      v.minb[d] = int(floorf(lo * a.inv_leaf));
+      const int maxb = int(floorf(hi * a.inv_leaf));
+      v.divb[d] = maxb - v.minb[d] + 1;
+    }
+    v.overflow = (total > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+    v.n_valid = int(total);
+    svp = v;
+    const long long cells = total > 0 ? (long long)v.divb[0] * v.divb[1] * v.divb[2] : 0;
+    // the scan reads whole wave iterations (256 words = 1024 cells): the box must fit the table with that rounding
+    s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 1023) / 1024 * 256 > (long long)a.table_words) ? 1 : 0;
+  }
+  __syncthreads();
+  VOXF_STAMP(12);
+  {
+    const VoxParams vp = svp;
+    bool bail = s_bail != 0;   // uniform over the grid (a function of the folded bounds)
+    // ---- phase 1: counters
+    unsigned cell[VOXF_PPT], slot[VOXF_PPT];
+    int over = 0;
+#pragma unroll
+    for (int q = 0; q < VOXF_PPT; ++q) {
+      cell[q] = 0xFFFFFFFFu; slot[q] = 0;
+      if (!bail && fin[q]) {
+        const int i0 = int(floorf(pt[q].x * a.inv_leaf) - float(vp.minb[0]));
+        const int i1 = int(floorf(pt[q].y * a.inv_leaf) - float(vp.minb[1]));
+        const int i2 = int(floorf(pt[q].z * a.inv_leaf) - float(vp.minb[2]));
+        const unsigned c = unsigned(i0 + i1 * vp.divb[0] + i2 * vp.divb[0] * vp.divb[1]);
+        cell[q] = c;
+        const unsigned sh = 8u * (c & 3u);
+        const unsigned old = __hip_atomic_fetch_add(a.table + (c >> 2), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot[q] = (old >> sh) & 0xFFu;
+        if (slot[q] >= VOXF_MAX_CNT) over = 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
+      }
+    }
+    if (over) __hip_atomic_store(a.bail_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    VOXF_STAMP(3);
+    if (!voxf_grid_sync(a.bar + 1 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+    VOXF_STAMP(4);
+    if (tid == 0) s_bail = (bail || agent_load(a.bail_flag) != 0) ? 1 : 0;   // one reader per block: written before the barrier, read behind it
+    __syncthreads();
+    bail = s_bail != 0;   // uniform over the grid again
+    // ---- phase 2: one pass over the counters of the box; a wave keeps its <= 8 iterations in registers until the block has
+    // scanned its waves' totals, so the segment prefixes go out relative to the BLOCK's stretch (one total per block to exchange)
+    const unsigned cells = bail ? 0u : unsigned(vp.divb[0]) * unsigned(vp.divb[1]) * unsigned(vp.divb[2]);
+    const unsigned iters_total = (cells + 1023u) / 1024u;                          // wave iterations of 256 words
+    const unsigned iters_per_wave = (iters_total + unsigned(nwaves) - 1u) / unsigned(nwaves);   // <= 8 (table_words / 256 / nwaves)
+    {
+      unsigned run_p = 0, run_v = 0;
+      const unsigned it0 = unsigned(gwave) * iters_per_wave;
+      const unsigned it_end = min(it0 + min(iters_per_wave, 8u), iters_total);
+      unsigned long long lo[8], hi[8];
+      unsigned ep[8], ev[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lo[j] = 0; hi[j] = 0;
+        if (it0 + j < it_end) {
+          const unsigned w0 = (it0 + j) * 256u + unsigned(lane) * 4u;
+          lo[j] = agent_load(reinterpret_cast<const unsigned long long *>(a.table + w0));
+          hi[j] = agent_load(reinterpret_cast<const unsigned long long *>(a.table + w0 + 2));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ep[j] = 0; ev[j] = 0;
+        if (it0 + j < it_end) {   // wave-uniform
+          const uint32_t x0 = uint32_t(lo[j]), x1 = uint32_t(lo[j] >> 32), x2 = uint32_t(hi[j]), x3 = uint32_t(hi[j] >> 32);
+          const unsigned p = voxf_bytes_sum(x0) + voxf_bytes_sum(x1) + voxf_bytes_sum(x2) + voxf_bytes_sum(x3);
+          const unsigned v = voxf_bytes_nonzero(x0) + voxf_bytes_nonzero(x1) + voxf_bytes_nonzero(x2) + voxf_bytes_nonzero(x3);
+          unsigned ip = p, iv = v;   // inclusive scan over the lanes
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned tp = __shfl_up(ip, o, 64), tv = __shfl_up(iv, o, 64);
+            if (lane >= o) { ip += tp; iv += tv; }
+          }
+          ep[j] = run_p + ip - p; ev[j] = run_v + iv - v;
+          run_p += __shfl(ip, 63, 64); run_v += __shfl(iv, 63, 64);
+        }
+      }
+      if (lane == 0) swtot[wv] = (static_cast<unsigned long long>(run_p) << 32) | run_v;
+      __syncthreads();
+      unsigned long long woff = 0, btot = 0;
+      for (int w = 0; w < WPB; ++w) { if (w < wv) woff += swtot[w]; btot += swtot[w]; }
+      const unsigned op = unsigned(woff >> 32), ov = unsigned(woff);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (it0 + j < it_end && (lane & 3) == 0)   // first lane of a segment (4 lanes x 4 words)
+          agent_store(a.prefix + (size_t(it0 + j) * 16u + unsigned(lane >> 2)), (static_cast<unsigned long long>(op + ep[j]) << 32) | (ov + ev[j]));
+      if (tid == 0) agent_store(a.wtot + blockIdx.x, btot);
+    }
+    VOXF_STAMP(5);
+    if (!voxf_grid_sync(a.bar + 2 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+    VOXF_STAMP(6);
+    // ---- phase 3: bases of the blocks' stretches (256 loads per block), then every point's place
+    {
+      unsigned long long v = 0;
+      if (tid < 256) v = (tid < G && !bail) ? agent_load(a.wtot + tid) : 0ull;
+      unsigned long long inc = v;
+      if (tid < 256) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned lo_ = __shfl_up(unsigned(inc), o, 64), hi_ = __shfl_up(unsigned(inc >> 32), o, 64);
+          if (lane >= o) inc += (static_cast<unsigned long long>(hi_) << 32) | lo_;   // (no carry between the halves: both totals are < 2^32)
+        }
+        if (lane == 63) swtot[wv] = inc;   // waves 0..3
+      }
+      __syncthreads();
+      if (tid < 256) {
+        unsigned long long before = inc - v;
+        for (int w = 0; w < wv; ++w) before += swtot[w];
+        sbase[tid] = before;
+        if (tid == 255) s_grand = before + v;
+      }
+      __syncthreads();
+    }
+    const int n_out = bail ? 0 : int(unsigned(s_grand));   // occupied cells
+    unsigned start[VOXF_PPT], rank[VOXF_PPT], ccount[VOXF_PPT];
+#pragma unroll
+    for (int q = 0; q < VOXF_PPT; ++q) {
+      start[q] = 0; rank[q] = 0; ccount[q] = 0;
+      if (!bail && cell[q] != 0xFFFFFFFFu) {
+        const unsigned c = cell[q], seg = c >> 6, it = c >> 10;
+        const unsigned long long pre = agent_load(a.prefix + seg) + sbase[(it / iters_per_wave) / unsigned(WPB)];
+        unsigned p = unsigned(pre >> 32), v = unsigned(pre);
+        const unsigned wsel = (c >> 2) & 15u, bsel = c & 3u;
+        const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(a.table + size_t(seg) * VOXF_SEG_WORDS);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned long long x = agent_load(sp + k);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t wd = h ? uint32_t(x >> 32) : uint32_t(x);
+            const unsigned wi = unsigned(2 * k + h);
+            const uint32_t below = wi < wsel ? wd : (wi == wsel ? (wd & ((1u << (8u * bsel)) - 1u)) : 0u);
+            p += voxf_bytes_sum(below); v += voxf_bytes_nonzero(below);
+            if (wi == wsel) ccount[q] = (wd >> (8u * bsel)) & 0xFFu;
+          }
+        }
+        start[q] = p; rank[q] = v;
+        if (ccount[q] > 1u) agent_store(a.sorted_idx + p + slot[q], uint32_t(pidx[q]));   // a voxel of one point needs no list
+      }
+    }
+    VOXF_STAMP(7);
+    if (!voxf_grid_sync(a.bar + 3 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+    VOXF_STAMP(8);
+    // ---- phase 4: a point's position inside its voxel = the voxel's points with a smaller original index (the order the stable
+    // sort gave and the oracle's sum runs in); the points of voxels with company go to `ordered` at that position
+#pragma unroll
+    for (int q = 0; q < VOXF_PPT; ++q) {
+      if (!bail && cell[q] != 0xFFFFFFFFu && ccount[q] > 1u) {
+        const uint32_t me = uint32_t(pidx[q]);
+        unsigned r = 0;
+#pragma unroll
+        for (int k = 0; k < VOXF_MAX_CNT; ++k)
+          if (unsigned(k) < ccount[q]) r += (agent_load(a.sorted_idx + start[q] + k) < me) ? 1u : 0u;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.ordered + start[q] + r);
+        agent_store(dst, (static_cast<unsigned long long>(__float_as_uint(pt[q].y)) << 32) | __float_as_uint(pt[q].x));
+        agent_store(dst + 1, (static_cast<unsigned long long>(__float_as_uint(pt[q].w)) << 32) | __float_as_uint(pt[q].z));
+      }
+    }
+    VOXF_STAMP(9);
+    if (!voxf_grid_sync(a.bar + 4 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+    VOXF_STAMP(10);
+    // ---- phase 5: centroids by the first arrival of every voxel, eight loads in flight at a time; counters back to zero
+    if (!bail) {
+#pragma unroll
+      for (int q = 0; q < VOXF_PPT; ++q) {
+        const bool leader = cell[q] != 0xFFFFFFFFu && slot[q] == 0;
+        const int m = leader ? int(ccount[q]) : 0;
+        int wmax = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
+        if (wmax == 0) continue;   // wave-uniform
+        float ax = 0, ay = 0, az = 0, ai = 0;
+        if (m == 1) { ax += pt[q].x; ay += pt[q].y; az += pt[q].z; ai += pt[q].w; }
+        if (wmax > 1) {
+          const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.ordered + start[q]);
+          for (int k0 = 0; k0 < wmax; k0 += 8) {   // wave-uniform trip count
+            unsigned long long lo[8], hi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              lo[j] = 0; hi[j] = 0;
+              if (m > 1 && k0 + j < m) { lo[j] = agent_load(src + 2 * (k0 + j)); hi[j] = agent_load(src + 2 * (k0 + j) + 1); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (m > 1 && k0 + j < m) {
+                ax += __uint_as_float(uint32_t(lo[j])); ay += __uint_as_float(uint32_t(lo[j] >> 32));
+                az += __uint_as_float(uint32_t(hi[j])); ai += __uint_as_float(uint32_t(hi[j] >> 32));
+              }
+          }
+        }
+        if (leader) { const float c = float(m); a.out[rank[q]] = make_float4(ax / c, ay / c, az / c, ai / c); }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < VOXF_PPT; ++q)
+      if (cell[q] != 0xFFFFFFFFu) a.table[cell[q] >> 2] = 0u;   // plain store: the next launch starts behind this kernel's end
+    VOXF_STAMP(11);
+    if (blockIdx.x == 0) {
+      if (tid < 7) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 ? 0xFFFFFFFFu : 0u;   // the accumulators of the bounds, ready for the next launch
+      if (tid == 0) {
+        *a.count = n_out;
+        *a.params = vp;
+        smail.count = n_out; smail.params = vp; smail.range_overflow = bail ? 2 : 0;
+        if (bail) __hip_atomic_store(a.bail_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody reads it any more in this launch)
+      }
+      if (a.sig.flag) {
+        __syncthreads();
+        if (tid < 64) post_host_mail(a.sig, a.mail, &smail, int(sizeof(VoxMail) / 4), tid);
+      }
+    }
+    return;
+  }
+aborted:
+  // a barrier timed out: the blocks are not all resident.  Status 3 goes to the host, which clears the table and takes the sorted path.
+  if (blockIdx.x == 0) {
+    if (tid == 0) { smail.count = 0; smail.params = VoxParams(); smail.range_overflow = 3; *a.count = 0; }
+    if (a.sig.flag) {
+      __syncthreads();
+      if (tid < 64) post_host_mail(a.sig, a.mail, &smail, int(sizeof(VoxMail) / 4), tid);
+    }
+  }
+}
+
 void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxParams *d_out, hipStream_t s) {
   const int nb = std::max(1, std::min(cdiv(n, 256), 512));
   partial.reserve(size_t(nb) * 8);
@@ -319,17 +695,111 @@ bool host_signal_enabled() {
   return on;
 }
 
+// One k_vox_fused at a time per process: its blocks take a whole CU each, so two of them in flight on two streams could each
+// hold half the chip and wait for the other half at their first barrier.  A filter that finds the slot taken uses the sorted path.
+static std::atomic<int> g_vox_fused_inflight{0};
+static std::atomic<long long> g_vox_fused_launched{0}, g_vox_fused_fell_back{0};
+void vox_fused_stats(long long *launched, long long *fell_back) { *launched = g_vox_fused_launched.load(); *fell_back = g_vox_fused_fell_back.load(); }
+
 // launch() enqueues the whole filter on `s` (no host sync); finish() waits for it and returns the output count.  Two
 // filters launched on two streams overlap (the scan-to-map step filters its corner and surf stacks that way).
 void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s) {
   p_in_ = in; p_n_ = n; p_out_ = &out; p_stream_ = s; p_leaf_ = leaf;
   if (n == 0) return;
-  enqueue(false);
+  int expect = 0;
+  if (fused_eligible() && g_vox_fused_inflight.compare_exchange_strong(expect, 1)) {
+    fused_slot_ = true;
+    try { enqueue_fused(); } catch (...) { fused_slot_ = false; g_vox_fused_inflight.store(0); throw; }
+  } else {
+    enqueue(false);
+  }
+}
+
+// LIO_VOX_FUSED=0: every filter takes the sorted path
+static bool vox_fused_enabled() {
+  static const bool on = [] { const char *e = std::getenv("LIO_VOX_FUSED"); return e ? std::atoi(e) != 0 : true; }();
+  return on;
+}
+// blocks of k_vox_fused the device keeps resident at once (a multiple of VOXF_BAR_LINES, at most one per CU up to 256)
+static int vox_fused_grid() {
+  static const int g = [] {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_vox_fused, VOXF_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int blocks = std::min(256, cus * std::min(per_cu, 1));
+    return blocks / VOXF_BAR_LINES * VOXF_BAR_LINES;
+  }();
+  return g;
+}
+#define VOXF_TABLE_WORDS (8u << 20)   // 32 M cells (a 200 x 200 x 50 m box at a 0.4 m leaf is 15.6 M), 32 MB, zero between runs
+
+bool VoxelGridDev::fused_eligible() const {
+  if (!vox_fused_enabled() || fused_off_ || !(use_signal_ && host_signal_enabled())) return false;
+  const int g = vox_fused_grid();
+  return g >= VOXF_BAR_LINES && p_n_ <= size_t(g) * VOXF_THREADS * VOXF_PPT;
+}
+
+// the bounds accumulators as a launch expects them (the kernel leaves them like this; needed once, and after an aborted launch)
+void VoxelGridDev::reset_fused_acc(hipStream_t s) {
+  unsigned init[7 * VOXF_ACC_STRIDE];
+  for (unsigned &v : init) v = 0u;
+  for (int d = 0; d < 3; ++d) init[d * VOXF_ACC_STRIDE] = 0xFFFFFFFFu;
+  LIO_HIP(hipMemcpyAsync(f_acc_.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  LIO_HIP(hipStreamSynchronize(s));   // `init` is on the stack
+}
+
+// the one-launch form (k_vox_fused); finish() falls back to enqueue(false) when the kernel reports that it could not run
+void VoxelGridDev::enqueue_fused() {
+  hipStream_t s = p_stream_;
+  const int g = vox_fused_grid();
+  if (!f_table_.p) {
+    f_table_.reserve(VOXF_TABLE_WORDS);
+    LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), s));
+    f_prefix_.reserve(VOXF_TABLE_WORDS / VOXF_SEG_WORDS);
+    f_wtot_.reserve(256);
+    f_acc_.reserve(7 * VOXF_ACC_STRIDE);
+    reset_fused_acc(s);
+    f_bar_.reserve(5 * VOXF_BAR_LINES * 16 + 32);   // the barrier lines, then the abort flag and the bail flag (a line each)
+    LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), s));
+    f_epoch_ = 0;
+  }
+  f_sorted_.reserve(p_n_); f_ordered_.reserve(p_n_);
+  static const bool dbg_stamps = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+  if (dbg_stamps && !f_stamps_.p) { f_stamps_.reserve(32); LIO_HIP(hipMemsetAsync(f_stamps_.p, 0, 32 * sizeof(long long), s)); }
+  params_.reserve(1);
+  if (count_.cap < 2) { count_.reserve(2); LIO_HIP(hipMemsetAsync(count_.p, 0, count_.cap * sizeof(int), s)); }
+  p_out_->reserve(p_n_);
+  if (!h_count_) {
+    LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_count_), 256, hipHostMallocCoherent));
+    std::memset(h_count_, 0, 256);
+    h_params_ = reinterpret_cast<VoxParams *>(h_count_ + 1);
+    h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_count_) + 128);
+  }
+  ++f_epoch_;
+  VoxFusedArgs a{};
+  a.pts = p_in_; a.n = int(p_n_); a.inv_leaf = 1.0f / p_leaf_;
+  a.table = f_table_.p; a.table_words = VOXF_TABLE_WORDS;
+  a.prefix = f_prefix_.p; a.wtot = f_wtot_.p; a.sorted_idx = f_sorted_.p; a.ordered = f_ordered_.p; a.stamps = f_stamps_.p; a.acc = f_acc_.p;
+  a.bar = f_bar_.p; a.target = f_epoch_ * unsigned(g / VOXF_BAR_LINES);
+  a.abort_flag = f_bar_.p + 5 * VOXF_BAR_LINES * 16; a.bail_flag = reinterpret_cast<int *>(f_bar_.p + 5 * VOXF_BAR_LINES * 16 + 16);
+  a.out = p_out_->p; a.count = count_.p; a.params = params_.p; a.mail = reinterpret_cast<VoxMail *>(h_count_);
+  sig_ = HostSignal();
+  sig_.flag = h_flag_; sig_.seq = ++seq_;
+  a.sig = sig_;
+  int khz = 0, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+  a.timeout_ticks = (long long)(0.05 * 1e3 * khz);   // 50 ms at a barrier: the blocks are not all resident
+  hipLaunchKernelGGL(k_vox_fused, dim3(g), dim3(VOXF_THREADS), 0, s, a);
+  LIO_HIP(hipGetLastError());
+  fused_pending_ = true;
+  g_vox_fused_launched.fetch_add(1);
 }
 
 // exact == false: absolute-cell keys, bounds folded on the side (4 stages: keys, sort, tile heads, centroids);
 // exact == true: PCL's own index from the bounds (two more launches in front), used when the cloud leaves the key's range.
 void VoxelGridDev::enqueue(bool exact) {
+  fused_pending_ = false;
   const float4 *in = p_in_;
   const size_t n = p_n_;
   DBuf<float4> &out = *p_out_;
@@ -390,16 +860,54 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
     return 0;
   }
   const VoxMail *m = reinterpret_cast<const VoxMail *>(h_count_);
-  for (int attempt = 0;; ++attempt) {
+  struct SlotRelease { bool &held; ~SlotRelease() { if (held) { held = false; g_vox_fused_inflight.store(0); } } } slot_release{fused_slot_};
+  bool redone = false, exact_done = false;
+  for (;;) {
     if (sig_.flag) wait_host_signal(sig_, p_stream_);   // the count is out; the centroids follow in stream order
     else LIO_HIP(hipStreamSynchronize(p_stream_));
-    if (!m->range_overflow || attempt) {
-      // cold path: the exact pass was enqueued AFTER launch() returned, i.e. after the caller may have recorded the event other
-      // streams wait on — those consumers are not ordered behind it, so the output must be complete before finish() returns
-      if (attempt) LIO_HIP(hipStreamSynchronize(p_stream_));
-      break;
+    const int status = m->range_overflow;
+    if (fused_pending_ && f_stamps_.p && status == 0) {   // LIO_DEBUG_TIMING: the phase boundaries of block 0 and of the last block
+      static int printed = 0;
+      if (printed < 6) {
+        ++printed;
+        long long st[32];
+        LIO_HIP(hipStreamSynchronize(p_stream_));
+        LIO_HIP(hipMemcpy(st, f_stamps_.p, sizeof(st), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[lio_hip timing] k_vox_fused n %zu, 10 ns ticks from the first block's start (block 0 | last block): ", p_n_);
+        static const char *nm[12] = {"start", "bounds", "B1", "count", "B2", "scan", "B3", "place", "B4", "order", "B5", "centroids+clean"};
+        for (int k = 0; k < 12; ++k) std::fprintf(stderr, "%s %lld|%lld  ", nm[k], st[k] - st[0], st[16 + k] - st[0]);
+        std::fprintf(stderr, "(box known %lld|%lld)", st[12] - st[0], st[16 + 12] - st[0]);
+        std::fprintf(stderr, "\n");
+      }
     }
-    enqueue(true);   // the cloud spans more cells than the absolute key holds
+    if (fused_slot_ && status != 3) { fused_slot_ = false; g_vox_fused_inflight.store(0); }   // posted = past its last barrier
+    if (fused_pending_ && (status == 2 || status == 3)) {
+      // the one-launch form could not run (2: box larger than the counter table, a crowded voxel, no finite point; 3: a grid
+      // barrier timed out): the sorted path takes the filter
+      if (status == 3) {
+        LIO_HIP(hipStreamSynchronize(p_stream_));
+        LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), p_stream_));
+        LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), p_stream_));
+        reset_fused_acc(p_stream_);
+        f_epoch_ = 0;
+        fused_off_ = true;
+        std::fprintf(stderr, "[lio_hip] VoxelGrid: the one-launch form timed out at a grid barrier (blocks not co-resident); this filter takes the sorted path from now on\n");
+      }
+      ++fused_fallbacks_;
+      g_vox_fused_fell_back.fetch_add(1);
+      enqueue(false);
+      redone = true;
+      continue;
+    }
+    if (status == 1 && !exact_done) {
+      enqueue(true);   // the cloud spans more cells than the absolute key holds
+      exact_done = true; redone = true;
+      continue;
+    }
+    // cold path: a second pass was enqueued AFTER launch() returned, i.e. after the caller may have recorded the event other
+    // streams wait on — those consumers are not ordered behind it, so the output must be complete before finish() returns
+    if (redone) LIO_HIP(hipStreamSynchronize(p_stream_));
+    break;
   }
   int count = m->count;
   const VoxParams hp = m->params;
@@ -419,6 +927,7 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
 }
 
 VoxelGridDev::~VoxelGridDev() {
+  if (fused_slot_) { fused_slot_ = false; g_vox_fused_inflight.store(0); }
   if (h_count_) (void)hipHostFree(h_count_);
 }
 

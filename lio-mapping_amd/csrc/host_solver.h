@@ -134,8 +134,24 @@ LIO_HD void lidar_linear_maps(const double *pose_p, const double *pose_i, const 
   const LidarMapPrep m = lidar_map_prepare(pose_p, pose_i, pose_ex);
   double J4[4 * 3 * 18], r4[4 * 3];
   for (int b = 0; b < 4; ++b) lidar_map_probe(m, b, J4 + b * 54, r4 + b * 3);
-  for (int e = 0; e < 18 * 13; ++e) L[e] = lidar_map_entry(J4, r4, e);
-  for (int c = 0; c < 13; ++c) l[c] = lidar_map_entry(J4, r4, 18 * 13 + c);
+  // the combination of lidar_map_entry, as plain loops (no division per entry): column 4 a + b of row k is the probe difference
+  // (b < 3) or the origin probe (b == 3), column 12 is zero; l likewise with a trailing one
+  for (int k = 0; k < 18; ++k) {
+    double *row = L + k * 13;
+    for (int a = 0; a < 3; ++a) {
+      const double o = J4[(0 * 3 + a) * 18 + k];
+      row[4 * a + 0] = J4[(1 * 3 + a) * 18 + k] - o;
+      row[4 * a + 1] = J4[(2 * 3 + a) * 18 + k] - o;
+      row[4 * a + 2] = J4[(3 * 3 + a) * 18 + k] - o;
+      row[4 * a + 3] = o;
+    }
+    row[12] = 0.0;
+  }
+  for (int a = 0; a < 3; ++a) {
+    const double o = r4[0 * 3 + a];
+    l[4 * a + 0] = r4[1 * 3 + a] - o; l[4 * a + 1] = r4[2 * 3 + a] - o; l[4 * a + 2] = r4[3 * 3 + a] - o; l[4 * a + 3] = o;
+  }
+  l[12] = 1.0;
 }
 
 // One frame's lidar block of the normal equations from its moments: [Hb | gb] = (L S) [L^T | l], with

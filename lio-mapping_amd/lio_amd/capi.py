@@ -145,6 +145,7 @@ _SIGS = {
     "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
     "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
+    "lio_vox_fused_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
@@ -331,6 +332,12 @@ class LioLib:
         J, r, s = np.zeros((n, n)), np.zeros(n), np.zeros(n)
         _chk(self.dll.lio_marginalize_schur(_dp(A), _dp(b), m, n, _dp(J), _dp(r), _dp(s)), "lio_marginalize_schur")
         return J, r, s
+
+    def vox_fused_stats(self):
+        """(filters that took the one-launch form, of those: handed back to the sorted path) — process-wide counters"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self.dll.lio_vox_fused_stats(C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def bench_voxel_grid(self, xyzi, leaf, reps=10):
         """device time of one VoxelGrid of a resident cloud (HIP events over `reps` runs) -> (ms, output points)"""

@@ -239,6 +239,9 @@ int lio_bench_voxel_grid(const float *xyzi, size_t n, float leaf, int reps, doub
  * path (box larger than the counter table, a voxel with more than 32 points, no finite point, a grid barrier that timed out).  Either
  * output may be null.  The oracle reports 0 / 0. */
 void lio_vox_fused_stats(long long *launched_or_null, long long *fell_back_or_null);
+/* Test hook: 1 / 0 = the filters of this process take / do not take the one-launch form from now on, -1 = the environment decides
+ * again (LIO_VOX_FUSED, off unless set to 1: DESIGN.md 5.4 has the measurement).  Returns the previous setting.  The oracle ignores it. */
+int lio_vox_fused_set(int on);
 /* pcl::KdTreeFLANN::nearestKSearch (B.2): exact K-NN, ascending squared distance, index tiebreak.
  * idx_out / sqd_out are m*k.  The product restricts the search to radius_sq (entries beyond it
  * come back as idx -1 / sqd +inf); pass radius_sq <= 0 for an unbounded search (oracle only).  */

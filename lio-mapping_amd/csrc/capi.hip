@@ -416,6 +416,7 @@ void lio_vox_fused_stats(long long *launched, long long *fell_back) {
   if (launched) *launched = a;
   if (fell_back) *fell_back = b;
 }
+int lio_vox_fused_set(int on) { return vox_fused_set(on); }
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
   if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
   return guarded([&] {

@@ -82,6 +82,8 @@ class VoxelGridDev {
 };
 // process-wide counters of the one-launch filter: launches, and those that fell back to the sorted path (lio_vox_fused_stats)
 void vox_fused_stats(long long *launched, long long *fell_back);
+// 1 / 0: filters take / do not take the one-launch form from now on, -1: back to LIO_VOX_FUSED; returns the previous setting
+int vox_fused_set(int on);
 // LIO_HOST_SIGNAL=0: every wait is a hipStreamSynchronize again
 bool host_signal_enabled();
 

@@ -333,7 +333,6 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
 #define VOXF_BAR_LINES 16             // arrival counters per barrier, one cache line each (same-address atomics serialise at the memory side)
 #define VOXF_MAX_CNT 32
 #define VOXF_SEG_WORDS 16            // 64 cells
-#define VOXF_DEAL 4096                // points are dealt to the threads in 4096 strands (see k_vox_fused)
 struct VoxFusedArgs {
   const float4 *pts; int n; float inv_leaf;
   uint32_t *table; unsigned table_words;      // capacity; a multiple of 256 (one wave iteration of the scan)
@@ -386,7 +385,9 @@ __device__ __forceinline__ unsigned voxf_bytes_nonzero(uint32_t x) { return __po
 // 10-25 us in the first form of this kernel)
 __device__ __forceinline__ unsigned voxf_enc(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float voxf_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
-#define VOXF_ACC_STRIDE 16   // words between the seven accumulators (a cache line each): mn[3], mx[3], count
+#define VOXF_ACC_STRIDE 16   // words between accumulators (a cache line each)
+#define VOXF_ACC_WAYS 16     // copies of each of the seven accumulators mn[3], mx[3], count: same-address atomics serialise at
+                            // ~27 ns each at the memory side (tools/micro/grid_sync.hip), 256 of them cost a barrier and a half
 
 __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -405,17 +406,12 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
   bool fin[VOXF_PPT];
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   float cnt = 0;
-  // Which point a thread takes: neighbouring lanes get points K apart, not neighbours.  The clouds this filter sees are mostly
-  // concatenations of voxel-ordered stacks, where 64 neighbouring points sit in 64 neighbouring cells — one 64-byte line of the
-  // counter table — and the wave's 64 atomics would queue on that line at the memory side (measured: 15 us for the count phase).
-  const int deal_k = (a.n + VOXF_DEAL - 1) / VOXF_DEAL;   // <= nthreads / VOXF_DEAL
+  // (Dealing the points out so that neighbouring lanes do not hit the same 64-byte line of the counter table — the clouds are mostly
+  // concatenations of voxel-ordered stacks — was measured and lost: the count phase got shorter, the gathers and the scattered
+  // list accesses of the later phases cost more than that, profiles/r4_vox_fused_v3_stamps.txt.)
   int pidx[VOXF_PPT];
 #pragma unroll
-  for (int q = 0; q < VOXF_PPT; ++q) {
-    const int g2 = q * nthreads + gid;
-    const int i = (g2 % VOXF_DEAL) * deal_k + g2 / VOXF_DEAL;
-    pidx[q] = (g2 / VOXF_DEAL < deal_k) ? i : a.n;
-  }
+  for (int q = 0; q < VOXF_PPT; ++q) pidx[q] = q * nthreads + gid;
 #pragma unroll
   for (int q = 0; q < VOXF_PPT; ++q) {
     const int i = pidx[q];
@@ -441,7 +437,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
   if (tid < 7) {
     float v = sred[tid][0];
     for (int w = 1; w < WPB; ++w) v = tid < 3 ? fminf(v, sred[tid][w]) : (tid < 6 ? fmaxf(v, sred[tid][w]) : v + sred[tid][w]);
-    unsigned *acc = a.acc + tid * VOXF_ACC_STRIDE;
+    unsigned *acc = a.acc + (tid * VOXF_ACC_WAYS + int(blockIdx.x) % VOXF_ACC_WAYS) * VOXF_ACC_STRIDE;
     if (tid < 3) { if (v != FLT_MAX) __hip_atomic_fetch_min(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     else if (tid < 6) { if (v != -FLT_MAX) __hip_atomic_fetch_max(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     else if (v > 0.f) __hip_atomic_fetch_add(acc, unsigned(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -449,13 +445,24 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
   VOXF_STAMP(1);
   if (!voxf_grid_sync(a.bar + 0 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
   VOXF_STAMP(2);
-  if (tid == 0) {
-    // VoxParams exactly as k_bounds_final forms it (min / max are order-free, the count is an integer)
+  if (tid < 64) {
+    // VoxParams exactly as k_bounds_final forms it (min / max are order-free, the count is an integer): lanes 0..15 fold the copies
+    unsigned e[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      e[k] = lane < VOXF_ACC_WAYS ? agent_load(a.acc + (k * VOXF_ACC_WAYS + lane) * VOXF_ACC_STRIDE) : (k < 3 ? 0xFFFFFFFFu : 0u);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(e[k], o, 64);
+        e[k] = k < 3 ? min(e[k], t) : (k < 6 ? max(e[k], t) : e[k] + t);
+      }
+    }
+    if (tid == 0) {
     VoxParams v;
     long long dd[3];
-    const unsigned total = agent_load(a.acc + 6 * VOXF_ACC_STRIDE);
+    const unsigned total = e[6];
     for (int d = 0; d < 3; ++d) {
-      const float lo = total ? voxf_dec(agent_load(a.acc + d * VOXF_ACC_STRIDE)) : FLT_MAX, hi = total ? voxf_dec(agent_load(a.acc + (3 + d) * VOXF_ACC_STRIDE)) : -FLT_MAX;
+      const float lo = total ? voxf_dec(e[d]) : FLT_MAX, hi = total ? voxf_dec(e[3 + d]) : -FLT_MAX;
       v.mn[d] = lo; v.mx[d] = hi;
       dd[d] = (long long)((hi - lo) * a.inv_leaf) + 1;
       v.minb[d] = int(floorf(lo * a.inv_leaf));
@@ -468,6 +475,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     const long long cells = total > 0 ? (long long)v.divb[0] * v.divb[1] * v.divb[2] : 0;
     // the scan reads whole wave iterations (256 words = 1024 cells): the box must fit the table with that rounding
     s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 1023) / 1024 * 256 > (long long)a.table_words) ? 1 : 0;
+    }
   }
   __syncthreads();
   VOXF_STAMP(12);
@@ -657,7 +665,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
       if (cell[q] != 0xFFFFFFFFu) a.table[cell[q] >> 2] = 0u;   // plain store: the next launch starts behind this kernel's end
     VOXF_STAMP(11);
     if (blockIdx.x == 0) {
-      if (tid < 7) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 ? 0xFFFFFFFFu : 0u;   // the accumulators of the bounds, ready for the next launch
+      if (tid < 7 * VOXF_ACC_WAYS) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 * VOXF_ACC_WAYS ? 0xFFFFFFFFu : 0u;   // the bounds' accumulators, ready for the next launch
       if (tid == 0) {
         *a.count = n_out;
         *a.params = vp;
@@ -715,10 +723,16 @@ void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &
   }
 }
 
-// LIO_VOX_FUSED=0: every filter takes the sorted path
+// LIO_VOX_FUSED=1 turns the one-launch form on (opt-in: measured on the MI355X it takes 47-56 us for 44 k points against ~52 us for
+// the sorted path and 63 against 75 us for 150 k — every phase is one or two round trips to the memory side, where the agent-scope
+// accesses that keep the eight L2s out of the picture are served, and there are nine of them between the five barriers; the solve as
+// a whole gained 1.3-1.5 %, inside the run-to-run spread.  profiles/r4_vox_fused_*_stamps.txt, profiles/r4_grid_sync_micro.txt.)
+static std::atomic<int> g_vox_fused_override{-1};   // lio_vox_fused_set: -1 = the environment decides, 0 / 1 = off / on
+int vox_fused_set(int on) { return g_vox_fused_override.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
 static bool vox_fused_enabled() {
-  static const bool on = [] { const char *e = std::getenv("LIO_VOX_FUSED"); return e ? std::atoi(e) != 0 : true; }();
-  return on;
+  static const bool env_on = [] { const char *e = std::getenv("LIO_VOX_FUSED"); return e ? std::atoi(e) != 0 : false; }();
+  const int o = g_vox_fused_override.load(std::memory_order_relaxed);
+  return o < 0 ? env_on : o != 0;
 }
 // blocks of k_vox_fused the device keeps resident at once (a multiple of VOXF_BAR_LINES, at most one per CU up to 256)
 static int vox_fused_grid() {
@@ -741,9 +755,9 @@ bool VoxelGridDev::fused_eligible() const {
 
 // the bounds accumulators as a launch expects them (the kernel leaves them like this; needed once, and after an aborted launch)
 void VoxelGridDev::reset_fused_acc(hipStream_t s) {
-  unsigned init[7 * VOXF_ACC_STRIDE];
+  static unsigned init[7 * VOXF_ACC_WAYS * VOXF_ACC_STRIDE];
   for (unsigned &v : init) v = 0u;
-  for (int d = 0; d < 3; ++d) init[d * VOXF_ACC_STRIDE] = 0xFFFFFFFFu;
+  for (int k = 0; k < 3 * VOXF_ACC_WAYS; ++k) init[k * VOXF_ACC_STRIDE] = 0xFFFFFFFFu;
   LIO_HIP(hipMemcpyAsync(f_acc_.p, init, sizeof(init), hipMemcpyHostToDevice, s));
   LIO_HIP(hipStreamSynchronize(s));   // `init` is on the stack
 }
@@ -757,7 +771,7 @@ void VoxelGridDev::enqueue_fused() {
     LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), s));
     f_prefix_.reserve(VOXF_TABLE_WORDS / VOXF_SEG_WORDS);
     f_wtot_.reserve(256);
-    f_acc_.reserve(7 * VOXF_ACC_STRIDE);
+    f_acc_.reserve(7 * VOXF_ACC_WAYS * VOXF_ACC_STRIDE);
     reset_fused_acc(s);
     f_bar_.reserve(5 * VOXF_BAR_LINES * 16 + 32);   // the barrier lines, then the abort flag and the bail flag (a line each)
     LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), s));

@@ -146,6 +146,7 @@ _SIGS = {
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
     "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "lio_vox_fused_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "lio_vox_fused_set": (C.c_int, [C.c_int]),
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
@@ -338,6 +339,10 @@ class LioLib:
         a, b = C.c_longlong(0), C.c_longlong(0)
         self.dll.lio_vox_fused_stats(C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
+
+    def vox_fused_set(self, on):
+        """1 / 0: filters take / do not take the one-launch form; -1: LIO_VOX_FUSED decides.  Returns the previous setting."""
+        return int(self.dll.lio_vox_fused_set(int(on)))
 
     def bench_voxel_grid(self, xyzi, leaf, reps=10):
         """device time of one VoxelGrid of a resident cloud (HIP events over `reps` runs) -> (ms, output points)"""

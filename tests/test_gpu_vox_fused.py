@@ -13,6 +13,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _one_launch_form_on(hip):
+    """the one-launch form is opt-in (LIO_VOX_FUSED=1): these tests switch it on through the C-ABI hook"""
+    before = hip.vox_fused_set(1)
+    yield
+    hip.vox_fused_set(before)
+
+
 def _cloud(rng, n, extent=40.0, height=6.0):
     pts = np.zeros((n, 4), np.float32)
     pts[:, 0] = rng.uniform(-extent, extent, n)
@@ -105,6 +113,11 @@ def test_one_launch_filter_timing(hip):
     """not a bound, a record: the filter on the 150 k-point local-map shape, as lio_bench_voxel_grid times it"""
     rng = np.random.default_rng(3)
     pts = _cloud(rng, 150000, 100.0)
-    ms, m = hip.bench_voxel_grid(pts, 0.4, reps=50)
-    a, b = hip.vox_fused_stats()
-    print("VoxelGrid of 150 k points -> %d voxels: %.1f us per filter (one-launch filters so far %d, hand-overs %d)" % (m, 1e3 * ms, a, b))
+    for n in (44000, 150000):
+        sub = pts[:n]
+        ms, m = hip.bench_voxel_grid(sub, 0.4, reps=50)
+        hip.vox_fused_set(0)
+        ms0, m0 = hip.bench_voxel_grid(sub, 0.4, reps=50)
+        hip.vox_fused_set(1)
+        assert m == m0
+        print("VoxelGrid of %d points -> %d voxels: one launch %.1f us per filter, sorted path %.1f us" % (n, m, 1e3 * ms, 1e3 * ms0))

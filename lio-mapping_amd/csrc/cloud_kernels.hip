@@ -15,6 +15,7 @@
 #include "cloud_kernels.h"
 
 #include <atomic>
+#include <string>
 #include "hmath.h"
 
 namespace lio {
@@ -848,9 +849,19 @@ void VoxelGridDev::enqueue(bool exact) {
     npartial = nkb;
   }
   size_t tmp_bytes = 0;
-  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-  tmp_.reserve(tmp_bytes + 256);
-  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  // LIO_VOX_SORT=onesweep: the library's radix form (histograms + four 8-bit passes) instead of the block sort + merges it picks
+  // below a million keys — an A/B switch; the result is the same stable order either way
+  static const bool onesweep = [] { const char *e = std::getenv("LIO_VOX_SORT"); return e && std::string(e) == "onesweep"; }();
+  using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
+  if (onesweep) {
+    LIO_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+    tmp_.reserve(tmp_bytes + 256);
+    LIO_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  } else {
+    LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+    tmp_.reserve(tmp_bytes + 256);
+    LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  }
   const int ntiles = cdiv(ni, VOX_TILE);
   tile_heads_.reserve(ntiles);
   hipLaunchKernelGGL(k_vox_tile_heads, dim3(ntiles + 1), dim3(VOX_TILE), 0, s, keys2_.p, ni, tile_heads_.p, partial_.p, npartial, inv_leaf, params_.p);

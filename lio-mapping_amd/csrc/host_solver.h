@@ -277,6 +277,9 @@ class WindowSystem {
   static constexpr int LMAP_STRIDE = 18 * 13 + 13 * LIO_LT_LD;
   std::vector<double> lmaps_;                    // per frame: L (18 x 13) and [L^T | l] (13 x LIO_LT_LD) of the current evaluate() call
   std::vector<double> prior_scratch_;            // the prior's residual and gradient (no allocation per linearisation)
+  DMat prior_base_;                              // the prior's J^T J in the solve's layout (evaluate())
+  const MargPrior *prior_base_for_ = nullptr;
+  int prior_base_ex_ = -2;
   std::vector<FrameMoments> moments_scratch_;    // landing zone of the device pass (no allocation per linearisation)
   static double clk_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -292,11 +295,39 @@ class WindowSystem {
     double tk0 = clk_now();
     if (split) lidar_launch(P);  // asynchronous: the kernels run while the host evaluates the prior and the IMU factors
     { const double t = clk_now(); eclk.launch += t - tk0; tk0 = t; ++eclk.n; }
+    // The prior's J^T J does not move during a solve: scattered into the solve's layout ONCE (prior_base_), every linearisation then
+    // starts from a copy of that matrix instead of a cleared one plus 49 block additions.
+    const bool prior_on = (which & 1) && prior;
+    bool from_base = false;
     if (H) {
-      if (H->r == lay.dim && H->c == lay.dim) H->zero(); else *H = DMat(lay.dim, lay.dim);  // the dogleg loop recycles two buffers
+      if (!(H->r == lay.dim && H->c == lay.dim)) *H = DMat(lay.dim, lay.dim);  // (the dogleg loop recycles two buffers)
+      if (prior_on) {
+        if (prior_base_for_ != prior.get() || prior_base_.r != lay.dim || prior_base_ex_ != lay.ex) {
+          const MargPrior &pr = *prior;
+          prior_base_ = DMat(lay.dim, lay.dim);
+          for (size_t a = 0; a < pr.keep.size(); ++a) {
+            const KeepBlock &ka = pr.keep[a];
+            const int ca = ka.kind == 0 ? lay.pose[ka.index] : (ka.kind == 1 ? lay.sb[ka.index] : lay.ex);
+            if (ca < 0) continue;
+            const int la = ka.size == 7 ? 6 : ka.size;
+            for (size_t b = 0; b < pr.keep.size(); ++b) {
+              const KeepBlock &kb = pr.keep[b];
+              const int cb = kb.kind == 0 ? lay.pose[kb.index] : (kb.kind == 1 ? lay.sb[kb.index] : lay.ex);
+              if (cb < 0) continue;
+              const int lb = kb.size == 7 ? 6 : kb.size;
+              for (int i = 0; i < la; ++i) for (int j = 0; j < lb; ++j) prior_base_(ca + i, cb + j) += pr.JtJ(ka.idx + i, kb.idx + j);
+            }
+          }
+          prior_base_for_ = prior.get(); prior_base_ex_ = lay.ex;
+        }
+        std::memcpy(H->a.data(), prior_base_.a.data(), sizeof(double) * size_t(lay.dim) * lay.dim);
+        from_base = true;
+      } else {
+        H->zero();
+      }
       g->assign(lay.dim, 0.0);
     }
-    if ((which & 1) && prior) {
+    if (prior_on) {
       const MargPrior &pr = *prior;
       std::vector<double> dx;
       prior_dx(pr, P, dx);
@@ -319,7 +350,7 @@ class WindowSystem {
             int cb = kb.kind == 0 ? lay.pose[kb.index] : (kb.kind == 1 ? lay.sb[kb.index] : lay.ex);
             if (cb < 0) continue;
             int lb = kb.size == 7 ? 6 : kb.size;
-            for (int i = 0; i < la; ++i) for (int j = 0; j < lb; ++j) (*H)(ca + i, cb + j) += pr.JtJ(ka.idx + i, kb.idx + j);
+            if (!from_base) for (int i = 0; i < la; ++i) for (int j = 0; j < lb; ++j) (*H)(ca + i, cb + j) += pr.JtJ(ka.idx + i, kb.idx + j);
           }
           for (int i = 0; i < la; ++i) (*g)[ca + i] += gb[ka.idx + i];
         }

@@ -19,6 +19,7 @@ from .capi import Estimator, EstConfig, LioLib, PointOdometry, PointProcessor, T
 
 
 class Replay:
+    tap = None   # (class default: subclasses that build only the pairing buffers need not set it)
     def __init__(self, lib: LioLib, cfg: EstConfig, lidar, odom_io: int = 2, msg_time_delay: float = 0.0, scan_period: float = 0.1, tap=None):
         self.lib = lib
         self.pp = PointProcessor(lib, lidar.lower_deg, lidar.upper_deg, lidar.rings)

@@ -54,7 +54,7 @@ class VoxelGridDev {
   void enqueue(bool exact);
   // the filter as one launch (k_vox_fused: counting sort over the cloud's own box of cells, grid barriers inside)
   bool fused_eligible() const;
-  void enqueue_fused();
+  void enqueue_fused(bool with_box);
   DBuf<uint32_t> f_table_, f_sorted_;
   DBuf<float4> f_ordered_;
   DBuf<long long> f_stamps_;
@@ -62,7 +62,11 @@ class VoxelGridDev {
   DBuf<unsigned> f_acc_;
   void reset_fused_acc(hipStream_t s);
   DBuf<unsigned> f_bar_;
-  unsigned f_epoch_ = 0;
+  unsigned f_epoch_ = 0, f_epoch0_ = 0;       // launches so far / launches that took their bounds inside the kernel (barrier 0)
+  bool spec_valid_ = false, fused_with_box_ = false;
+  float spec_leaf_ = 0.f;
+  int spec_lo_[3] = {0, 0, 0}, spec_hi_[3] = {0, 0, 0};   // union of the boxes (in cells) of the clouds filtered so far at spec_leaf_
+  int fused_reboxed_ = 0;
   bool fused_pending_ = false, fused_off_ = false, fused_slot_ = false;
   int fused_fallbacks_ = 0;
  public:

@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
 #define VOXF_BAR_LINES 16             // arrival counters per barrier, one cache line each (same-address atomics serialise at the memory side)
 #define VOXF_MAX_CNT 32
 #define VOXF_SEG_WORDS 16            // 64 cells
+#define VOXF_LEADER_MAX 8u           // voxels of up to this many points are ordered by their leader in registers (phase 5)
 struct VoxFusedArgs {
   const float4 *pts; int n; float inv_leaf;
   uint32_t *table; unsigned table_words;      // capacity; a multiple of 256 (one wave iteration of the scan)
@@ -344,8 +345,11 @@ struct VoxFusedArgs {
   long long *stamps;                          // optional (LIO_DEBUG_TIMING): wall clock of block 0 and of the last block at the phase boundaries
   unsigned *acc;                              // the bounds of the cloud: seven accumulators, VOXF_ACC_STRIDE words apart (mn[3] and mx[3] as
                                               // order-preserving codes, the count of finite points); reset by the kernel itself
-  unsigned *bar; unsigned target;             // 4 barriers x VOXF_BAR_LINES arrival counters (16 words apart) that only grow; a line is
+  unsigned *bar; unsigned target;             // 5 barriers x VOXF_BAR_LINES arrival counters (16 words apart) that only grow; a line is
                                               // complete for this launch at `target` (the grid is a multiple of VOXF_BAR_LINES blocks)
+  unsigned target0;                           // the same for barrier 0, which only the launches WITHOUT a given box pass
+  int box_given;                              // 1: the box of cells comes with the launch (the union of the boxes this filter has seen, plus a
+  int box_minb[3], box_divb[3];               // margin): no bounds phase, no barrier 0; a point outside it ends the launch with status 4
   unsigned *abort_flag; int *bail_flag;
   float4 *out; int *count; VoxParams *params; VoxMail *mail; HostSignal sig;
   long long timeout_ticks;
@@ -444,7 +448,17 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     else if (v > 0.f) __hip_atomic_fetch_add(acc, unsigned(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   VOXF_STAMP(1);
-  if (!voxf_grid_sync(a.bar + 0 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
+  if (a.box_given) {
+    // The voxel ORDER does not depend on where the box starts (PCL's index orders the cells by (z, y, x) whatever its minimum), so any
+    // box that holds the cloud gives the same output; the true bounds still go to the accumulators and are read at the very end.
+    if (tid == 0) {
+      VoxParams v{};
+      for (int d = 0; d < 3; ++d) { v.minb[d] = a.box_minb[d]; v.divb[d] = a.box_divb[d]; }
+      svp = v;
+      s_bail = 0;
+    }
+  } else {
+  if (!voxf_grid_sync(a.bar + 0 * VOXF_BAR_LINES * 16, a.target0, a.abort_flag, a.timeout_ticks)) goto aborted;
   VOXF_STAMP(2);
   if (tid < 64) {
     // VoxParams exactly as k_bounds_final forms it (min / max are order-free, the count is an integer): lanes 0..15 fold the copies
@@ -478,6 +492,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 1023) / 1024 * 256 > (long long)a.table_words) ? 1 : 0;
     }
   }
+  }
   __syncthreads();
   VOXF_STAMP(12);
   {
@@ -493,21 +508,23 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
         const int i0 = int(floorf(pt[q].x * a.inv_leaf) - float(vp.minb[0]));
         const int i1 = int(floorf(pt[q].y * a.inv_leaf) - float(vp.minb[1]));
         const int i2 = int(floorf(pt[q].z * a.inv_leaf) - float(vp.minb[2]));
+        if (a.box_given && (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= vp.divb[0] || i1 >= vp.divb[1] || i2 >= vp.divb[2])) { over = 2; continue; }
         const unsigned c = unsigned(i0 + i1 * vp.divb[0] + i2 * vp.divb[0] * vp.divb[1]);
         cell[q] = c;
         const unsigned sh = 8u * (c & 3u);
         const unsigned old = __hip_atomic_fetch_add(a.table + (c >> 2), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         slot[q] = (old >> sh) & 0xFFu;
-        if (slot[q] >= VOXF_MAX_CNT) over = 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
+        if (slot[q] >= VOXF_MAX_CNT) over = over ? over : 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
       }
     }
-    if (over) __hip_atomic_store(a.bail_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (over) __hip_atomic_fetch_max(a.bail_flag, over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 (outside the given box) wins over 1
     VOXF_STAMP(3);
     if (!voxf_grid_sync(a.bar + 1 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
     VOXF_STAMP(4);
-    if (tid == 0) s_bail = (bail || agent_load(a.bail_flag) != 0) ? 1 : 0;   // one reader per block: written before the barrier, read behind it
+    if (tid == 0) s_bail = bail ? 1 : agent_load(a.bail_flag);   // one reader per block: written before the barrier, read behind it (0, 1 or 2)
     __syncthreads();
-    bail = s_bail != 0;   // uniform over the grid again
+    const int bail_code = s_bail;
+    bail = bail_code != 0;   // uniform over the grid again
     // ---- phase 2: one pass over the counters of the box; a wave keeps its <= 8 iterations in registers until the block has
     // scanned its waves' totals, so the segment prefixes go out relative to the BLOCK's stretch (one total per block to exchange)
     const unsigned cells = bail ? 0u : unsigned(vp.divb[0]) * unsigned(vp.divb[1]) * unsigned(vp.divb[2]);
@@ -615,7 +632,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     // sort gave and the oracle's sum runs in); the points of voxels with company go to `ordered` at that position
 #pragma unroll
     for (int q = 0; q < VOXF_PPT; ++q) {
-      if (!bail && cell[q] != 0xFFFFFFFFu && ccount[q] > 1u) {
+      if (!bail && cell[q] != 0xFFFFFFFFu && ccount[q] > VOXF_LEADER_MAX) {   // (up to VOXF_LEADER_MAX points the leader orders them itself)
         const uint32_t me = uint32_t(pidx[q]);
         unsigned r = 0;
 #pragma unroll
@@ -641,18 +658,49 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
         if (wmax == 0) continue;   // wave-uniform
         float ax = 0, ay = 0, az = 0, ai = 0;
         if (m == 1) { ax += pt[q].x; ay += pt[q].y; az += pt[q].z; ai += pt[q].w; }
-        if (wmax > 1) {
+        int wsmall = (m > 1 && m <= int(VOXF_LEADER_MAX)) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wsmall |= __shfl_xor(wsmall, o, 64);
+        if (wsmall) {   // wave-uniform: some leader of the wave has 2 .. 8 points to order itself
+          const bool mine = m > 1 && m <= int(VOXF_LEADER_MAX);
+          uint32_t id[VOXF_LEADER_MAX];
+          float4 pp[VOXF_LEADER_MAX];
+#pragma unroll
+          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) id[k] = (mine && k < m) ? agent_load(a.sorted_idx + start[q] + k) : 0xFFFFFFFFu;
+#pragma unroll
+          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) pp[k] = (mine && k < m) ? a.pts[id[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+          int rk[VOXF_LEADER_MAX];
+#pragma unroll
+          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) {
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < int(VOXF_LEADER_MAX); ++j) r += (id[j] < id[k]) ? 1 : 0;   // distinct indices; the padding ranks last
+            rk[k] = r;
+          }
+#pragma unroll
+          for (int r = 0; r < int(VOXF_LEADER_MAX); ++r) {   // the adds in ascending original index
+            float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) if (rk[k] == r) sel = pp[k];
+            if (mine && r < m) { ax += sel.x; ay += sel.y; az += sel.z; ai += sel.w; }
+          }
+        }
+        int wbig = (m > int(VOXF_LEADER_MAX)) ? m : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wbig = max(wbig, __shfl_xor(wbig, o, 64));
+        if (wbig > 0) {
+          const bool big = m > int(VOXF_LEADER_MAX);
           const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.ordered + start[q]);
-          for (int k0 = 0; k0 < wmax; k0 += 8) {   // wave-uniform trip count
+          for (int k0 = 0; k0 < wbig; k0 += 8) {   // wave-uniform trip count
             unsigned long long lo[8], hi[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               lo[j] = 0; hi[j] = 0;
-              if (m > 1 && k0 + j < m) { lo[j] = agent_load(src + 2 * (k0 + j)); hi[j] = agent_load(src + 2 * (k0 + j) + 1); }
+              if (big && k0 + j < m) { lo[j] = agent_load(src + 2 * (k0 + j)); hi[j] = agent_load(src + 2 * (k0 + j) + 1); }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (m > 1 && k0 + j < m) {
+              if (big && k0 + j < m) {
                 ax += __uint_as_float(uint32_t(lo[j])); ay += __uint_as_float(uint32_t(lo[j] >> 32));
                 az += __uint_as_float(uint32_t(hi[j])); ai += __uint_as_float(uint32_t(hi[j] >> 32));
               }
@@ -666,13 +714,50 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
       if (cell[q] != 0xFFFFFFFFu) a.table[cell[q] >> 2] = 0u;   // plain store: the next launch starts behind this kernel's end
     VOXF_STAMP(11);
     if (blockIdx.x == 0) {
-      if (tid < 7 * VOXF_ACC_WAYS) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 * VOXF_ACC_WAYS ? 0xFFFFFFFFu : 0u;   // the bounds' accumulators, ready for the next launch
+      __shared__ VoxParams s_true;
+      __shared__ int s_status;
+      if (tid == 0) { s_true = vp; s_status = bail ? (bail_code == 2 ? 4 : 2) : 0; }
+      __syncthreads();
+      if (a.box_given && tid < 64) {
+        // the cloud's own bounds for the host (VoxParams exactly as k_bounds_final forms it), from the accumulators every block fed
+        // in phase 0: all of them are in (five barriers ago for the slowest)
+        unsigned e[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          e[k] = lane < VOXF_ACC_WAYS ? agent_load(a.acc + (k * VOXF_ACC_WAYS + lane) * VOXF_ACC_STRIDE) : (k < 3 ? 0xFFFFFFFFu : 0u);
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) {
+            const unsigned t = __shfl_xor(e[k], o, 64);
+            e[k] = k < 3 ? min(e[k], t) : (k < 6 ? max(e[k], t) : e[k] + t);
+          }
+        }
+        if (tid == 0) {
+          VoxParams v;
+          long long dd[3];
+          const unsigned total = e[6];
+          for (int d = 0; d < 3; ++d) {
+            const float lo = total ? voxf_dec(e[d]) : FLT_MAX, hi = total ? voxf_dec(e[3 + d]) : -FLT_MAX;
+            v.mn[d] = lo; v.mx[d] = hi;
+            dd[d] = (long long)((hi - lo) * a.inv_leaf) + 1;
+            v.minb[d] = int(floorf(lo * a.inv_leaf));
+            const int maxb = int(floorf(hi * a.inv_leaf));
+            v.divb[d] = maxb - v.minb[d] + 1;
+          }
+          v.overflow = (total > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+          v.n_valid = int(total);
+          s_true = v;
+          if (total == 0 && s_status == 0) s_status = 2;   // no finite point: the sorted path writes the canonical empty result
+        }
+      }
+      __syncthreads();
       if (tid == 0) {
         *a.count = n_out;
-        *a.params = vp;
-        smail.count = n_out; smail.params = vp; smail.range_overflow = bail ? 2 : 0;
+        *a.params = s_true;
+        smail.count = n_out; smail.params = s_true; smail.range_overflow = s_status;
         if (bail) __hip_atomic_store(a.bail_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody reads it any more in this launch)
       }
+      __syncthreads();
+      if (tid < 7 * VOXF_ACC_WAYS) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 * VOXF_ACC_WAYS ? 0xFFFFFFFFu : 0u;   // the bounds' accumulators, ready for the next launch
       if (a.sig.flag) {
         __syncthreads();
         if (tid < 64) post_host_mail(a.sig, a.mail, &smail, int(sizeof(VoxMail) / 4), tid);
@@ -718,7 +803,7 @@ void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &
   int expect = 0;
   if (fused_eligible() && g_vox_fused_inflight.compare_exchange_strong(expect, 1)) {
     fused_slot_ = true;
-    try { enqueue_fused(); } catch (...) { fused_slot_ = false; g_vox_fused_inflight.store(0); throw; }
+    try { enqueue_fused(true); } catch (...) { fused_slot_ = false; g_vox_fused_inflight.store(0); throw; }
   } else {
     enqueue(false);
   }
@@ -764,7 +849,7 @@ void VoxelGridDev::reset_fused_acc(hipStream_t s) {
 }
 
 // the one-launch form (k_vox_fused); finish() falls back to enqueue(false) when the kernel reports that it could not run
-void VoxelGridDev::enqueue_fused() {
+void VoxelGridDev::enqueue_fused(bool with_box) {
   hipStream_t s = p_stream_;
   const int g = vox_fused_grid();
   if (!f_table_.p) {
@@ -776,7 +861,7 @@ void VoxelGridDev::enqueue_fused() {
     reset_fused_acc(s);
     f_bar_.reserve(5 * VOXF_BAR_LINES * 16 + 32);   // the barrier lines, then the abort flag and the bail flag (a line each)
     LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), s));
-    f_epoch_ = 0;
+    f_epoch_ = 0; f_epoch0_ = 0;
   }
   f_sorted_.reserve(p_n_); f_ordered_.reserve(p_n_);
   static const bool dbg_stamps = std::getenv("LIO_DEBUG_TIMING") != nullptr;
@@ -792,10 +877,20 @@ void VoxelGridDev::enqueue_fused() {
   }
   ++f_epoch_;
   VoxFusedArgs a{};
+  // The box of cells: the union of the boxes this filter has seen at this leaf, a few cells wider — the clouds of one caller move
+  // slowly — unless that is not known yet, does not fit the table or was just found too small (finish(): status 4).
+  a.box_given = 0;
+  if (with_box && spec_valid_ && spec_leaf_ == p_leaf_) {
+    long long cells = 1;
+    for (int d = 0; d < 3; ++d) { a.box_minb[d] = spec_lo_[d] - 4; a.box_divb[d] = spec_hi_[d] - spec_lo_[d] + 1 + 8; cells *= a.box_divb[d]; }
+    if ((cells + 1023) / 1024 * 256 <= (long long)VOXF_TABLE_WORDS) a.box_given = 1;
+  }
+  if (!a.box_given) ++f_epoch0_;
+  fused_with_box_ = a.box_given != 0;
   a.pts = p_in_; a.n = int(p_n_); a.inv_leaf = 1.0f / p_leaf_;
   a.table = f_table_.p; a.table_words = VOXF_TABLE_WORDS;
   a.prefix = f_prefix_.p; a.wtot = f_wtot_.p; a.sorted_idx = f_sorted_.p; a.ordered = f_ordered_.p; a.stamps = f_stamps_.p; a.acc = f_acc_.p;
-  a.bar = f_bar_.p; a.target = f_epoch_ * unsigned(g / VOXF_BAR_LINES);
+  a.bar = f_bar_.p; a.target = f_epoch_ * unsigned(g / VOXF_BAR_LINES); a.target0 = f_epoch0_ * unsigned(g / VOXF_BAR_LINES);
   a.abort_flag = f_bar_.p + 5 * VOXF_BAR_LINES * 16; a.bail_flag = reinterpret_cast<int *>(f_bar_.p + 5 * VOXF_BAR_LINES * 16 + 16);
   a.out = p_out_->p; a.count = count_.p; a.params = params_.p; a.mail = reinterpret_cast<VoxMail *>(h_count_);
   sig_ = HostSignal();
@@ -892,13 +987,14 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
     else LIO_HIP(hipStreamSynchronize(p_stream_));
     const int status = m->range_overflow;
     if (fused_pending_ && f_stamps_.p && status == 0) {   // LIO_DEBUG_TIMING: the phase boundaries of block 0 and of the last block
-      static int printed = 0;
-      if (printed < 6) {
+      static int seen = 0, printed = 0;
+      ++seen;
+      if ((seen <= 3 || seen % 97 == 0) && printed < 12) {   // the first launches and a sample of the steady state
         ++printed;
         long long st[32];
         LIO_HIP(hipStreamSynchronize(p_stream_));
         LIO_HIP(hipMemcpy(st, f_stamps_.p, sizeof(st), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[lio_hip timing] k_vox_fused n %zu, 10 ns ticks from the first block's start (block 0 | last block): ", p_n_);
+        std::fprintf(stderr, "[lio_hip timing] k_vox_fused n %zu%s, 10 ns ticks from the first block's start (block 0 | last block): ", p_n_, fused_with_box_ ? " (box given)" : "");
         static const char *nm[12] = {"start", "bounds", "B1", "count", "B2", "scan", "B3", "place", "B4", "order", "B5", "centroids+clean"};
         for (int k = 0; k < 12; ++k) std::fprintf(stderr, "%s %lld|%lld  ", nm[k], st[k] - st[0], st[16 + k] - st[0]);
         std::fprintf(stderr, "(box known %lld|%lld)", st[12] - st[0], st[16 + 12] - st[0]);
@@ -906,6 +1002,24 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
       }
     }
     if (fused_slot_ && status != 3) { fused_slot_ = false; g_vox_fused_inflight.store(0); }   // posted = past its last barrier
+    if (fused_pending_ && status == 4) {
+      // a point lay outside the box that came with the launch: once more, the bounds taken inside the kernel this time (the union
+      // of the boxes seen so far stays and takes this cloud's box in when that launch reports)
+      ++fused_reboxed_;
+      enqueue_fused(false);
+      redone = true;
+      continue;
+    }
+    if (fused_pending_ && status == 0) {
+      // the box for the next launch: the union with what this cloud occupied (reset when the leaf changes)
+      const VoxParams &vp = m->params;
+      if (!spec_valid_ || spec_leaf_ != p_leaf_) {
+        for (int d = 0; d < 3; ++d) { spec_lo_[d] = vp.minb[d]; spec_hi_[d] = vp.minb[d] + vp.divb[d] - 1; }
+        spec_valid_ = true; spec_leaf_ = p_leaf_;
+      } else {
+        for (int d = 0; d < 3; ++d) { spec_lo_[d] = std::min(spec_lo_[d], vp.minb[d]); spec_hi_[d] = std::max(spec_hi_[d], vp.minb[d] + vp.divb[d] - 1); }
+      }
+    }
     if (fused_pending_ && (status == 2 || status == 3)) {
       // the one-launch form could not run (2: box larger than the counter table, a crowded voxel, no finite point; 3: a grid
       // barrier timed out): the sorted path takes the filter
@@ -914,7 +1028,7 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
         LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), p_stream_));
         LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), p_stream_));
         reset_fused_acc(p_stream_);
-        f_epoch_ = 0;
+        f_epoch_ = 0; f_epoch0_ = 0;
         fused_off_ = true;
         std::fprintf(stderr, "[lio_hip] VoxelGrid: the one-launch form timed out at a grid barrier (blocks not co-resident); this filter takes the sorted path from now on\n");
       }

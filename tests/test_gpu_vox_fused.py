@@ -4,7 +4,8 @@ barriers inside one kernel) against the oracle, bit for bit, and the hand-over t
 Same voxel order (PCL's index i0 + i1 d0 + i2 d0 d1 ascending) and the same within-voxel summation order (ascending original index)
 as the sorted path, hence `assert_array_equal` against the oracle throughout.  lio_vox_fused_stats counts the filters that took the
 one-launch form and those that handed the cloud back, so every case also asserts WHICH path ran (the product must not pass on a silent
-fallback): regular clouds stay on the one-launch form; a crowded voxel (> 32 points), a box of more cells than the counter table, a
+fallback): regular clouds stay on the one-launch form (with the box of cells handed to the launch once the handle has seen a cloud, and a
+second launch with the bounds taken inside the kernel when a point falls outside it); a crowded voxel (> 32 points), a box of more cells than the counter table, a
 cloud without a finite point and a cloud above the grid's register capacity go to the sorted path; and a regular cloud right after each
 of those is filtered by the one-launch form again with a clean counter table."""
 import numpy as np
@@ -51,7 +52,10 @@ def _run(hip, oracle, pts, leaf, expect_fused, expect_fallback):
     out, ref = hip.voxel_grid(pts, leaf), oracle.voxel_grid(pts, leaf)
     a1, b1 = hip.vox_fused_stats()
     np.testing.assert_array_equal(out, ref)
-    assert (a1 - a0, b1 - b0) == (int(expect_fused), int(expect_fallback)), ("one-launch filters / hand-overs", a1 - a0, b1 - b0)
+    # launches: one, or two when a point lay outside the box that came with the first (the union of the boxes the handle has seen so far,
+    # a few cells wider: no bounds phase then) and the filter ran again with the bounds taken inside the kernel
+    launches = (1, 2) if expect_fused else (0,)
+    assert a1 - a0 in launches and b1 - b0 == int(expect_fallback), ("one-launch filters / hand-overs", a1 - a0, b1 - b0)
     return len(ref)
 
 
@@ -77,6 +81,26 @@ def test_same_handle_many_clouds_in_a_row(hip, oracle):
         kept += 0 if over else 1
         _run(hip, oracle, pts, leaf, True, over)
     assert kept >= 20, kept
+
+
+def test_box_from_the_previous_clouds(hip, oracle):
+    """the second filter of a handle gets its box of cells with the launch (no bounds phase); a cloud that leaves it is filtered again"""
+    rng = np.random.default_rng(23)
+    base = _cloud(rng, 60000, 50.0)
+    _run(hip, oracle, base, 0.4, True, False)
+    a0, _ = hip.vox_fused_stats()
+    _run(hip, oracle, base + np.array([0.3, -0.2, 0.1, 0.0], np.float32), 0.4, True, False)     # inside the margin: one launch
+    a1, _ = hip.vox_fused_stats()
+    assert a1 - a0 == 1
+    moved = base + np.array([40.0, 0.0, 0.0, 0.0], np.float32)                                   # leaves the box: two launches, same result
+    _run(hip, oracle, moved, 0.4, True, False)
+    a2, _ = hip.vox_fused_stats()
+    assert a2 - a1 == 2
+    _run(hip, oracle, base, 0.4, True, False)                                                    # the union holds both now
+    _run(hip, oracle, moved, 0.4, True, False)
+    a3, _ = hip.vox_fused_stats()
+    assert a3 - a2 == 2
+    _run(hip, oracle, base, 0.2, True, False)                                                    # another leaf: the box starts over
 
 
 def test_hand_over_to_the_sorted_path(hip, oracle):

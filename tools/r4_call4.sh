@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, fourth GPU call: k_vox_fused with the rank phase; phase stamps; suite; bench A/B.
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4f; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r4k; mkdir -p $O; cd $R
 (LIO_DEBUG_TIMING=1 timeout 300 python -m pytest tests/test_gpu_vox_fused.py -q -s -x > $O/pytest_vox.log 2>&1; echo rc=$? >> $O/pytest_vox.log)
 grep -E "timing|passed|failed|us per filter|rc=" $O/pytest_vox.log | tail -12
 B="python bench.py --no-pmc --no-cpu-baseline --windows 0 --keyframes 0"
@@ -16,7 +16,7 @@ try:
 except Exception as e: print(sys.argv[1], "ERR", e)
 PY
 done
-(hipcc --offload-arch=gfx950 -O3 -o /tmp/grid_sync tools/micro/grid_sync.hip && timeout 60 /tmp/grid_sync > $O/grid_sync.txt 2>&1; cat $O/grid_sync.txt)
+true
 if false; then
   (timeout 900 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log)
   grep -E "passed|failed|rc=" $O/pytest_gpu.log | tail -3

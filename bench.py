@@ -377,9 +377,7 @@ def main():
         dist_util.barrier(world)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r = None
-        for _ in range(args.steps):
-            r = one_step(est)
+        r = est.solve_restored(args.steps)   # --steps x (restore + SolveOptimization), looped inside the library (no interpreter between two solves)
         est.sync()                 # the last solve's deferred marginalization belongs to the timed region
         torch.cuda.synchronize()
         dist_util.barrier(world)
@@ -583,7 +581,7 @@ def main():
             "ms_per_step": round(1e3 * dt_max / args.steps, 4),
             "timing": {"blocks": n_blocks, "steps_per_block": args.steps, "timed_seconds": round(float(np.sum(block_s)), 4),
                        "ms_per_step_min": round(1e3 * float(np.min(block_s)) / args.steps, 4), "ms_per_step_max": round(1e3 * float(np.max(block_s)) / args.steps, 4),
-                       "note": "value / ms_per_step = the MEDIAN block of exactly --steps steps (barrier + synchronize on both sides, max over ranks)"},
+                       "note": "value / ms_per_step = the MEDIAN block of exactly --steps steps (barrier + synchronize on both sides, max over ranks); a step = restore + SolveOptimization, the --steps of a block looped inside the library (lio_est_solve_restored: no Python between two solves)"},
             "higher_is_better": True,
             "scaling": "strong" if args.shard_factors else "weak",
             "vs_baseline": None,

@@ -483,6 +483,10 @@ int lio_marginalize_schur(const double *A, const double *b, int m, int n, double
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);
+/* Measurement hook: `steps` times lio_est_restore + lio_est_solve_optimization, in one call (what bench.py times: a caller that
+ * is compiled code, like estimator_node, pays no interpreter between two solves).  report_or_null receives the last solve's report.
+ * Stops at the first failing step and returns its code. */
+int lio_est_solve_restored(lio_est *, int steps, lio_solve_report *report_or_null);
 
 /* Multi-GPU factor sharding (the reference's own 4-thread split of ThreadsConstructA,
  * MarginalizationFactor.cc:245-269, extended across ranks): rank r of `world` evaluates only its contiguous share of

@@ -818,6 +818,17 @@ int lio_est_restore(lio_est *h) {
   return guarded([&] { return h->e->Restore() ? LIO_OK : LIO_ERR_STATE; });
 }
 
+int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
+  if (!h || steps < 0) return LIO_ERR_ARG;
+  for (int k = 0; k < steps; ++k) {
+    int rc = lio_est_restore(h);
+    if (rc != LIO_OK) return rc;
+    rc = lio_est_solve_optimization(h, rep);
+    if (rc != LIO_OK) return rc;
+  }
+  return LIO_OK;
+}
+
 int lio_est_set_factor_sharding(lio_est *h, int rank, int world, lio_allreduce_fn fn, void *user) {
   if (!h || world < 1 || rank < 0 || rank >= world) return LIO_ERR_ARG;
   h->e->shard_rank_ = rank; h->e->shard_world_ = world; h->e->allreduce_ = fn; h->e->allreduce_user_ = user;

@@ -235,6 +235,7 @@ _SIGS = {
     "lio_marginalize_schur": (C.c_int, [c_double_p, c_double_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
+    "lio_est_solve_restored": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolveReport)]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lio_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lio_rccl_init": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
@@ -957,6 +958,12 @@ class Estimator:
 
     def restore(self):
         _chk(self.lib.dll.lio_est_restore(self.h), "lio_est_restore")
+
+    def solve_restored(self, steps):
+        """`steps` x (restore + SolveOptimization) inside the library -> the last solve's report"""
+        rep = SolveReport()
+        _chk(self.lib.dll.lio_est_solve_restored(self.h, int(steps), C.byref(rep)), "lio_est_solve_restored")
+        return rep
 
 
 def load_hip() -> LioLib:

@@ -740,6 +740,17 @@ int lio_est_restore(lio_est *h) {
   return LIO_OK;
 }
 
+int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
+  if (!h || steps < 0) return LIO_ERR_ARG;
+  for (int k = 0; k < steps; ++k) {
+    int rc = lio_est_restore(h);
+    if (rc != LIO_OK) return rc;
+    rc = lio_est_solve_optimization(h, rep);
+    if (rc != LIO_OK) return rc;
+  }
+  return LIO_OK;
+}
+
 // oracle-only probes (not part of lio_c.h): include/utils/math_utils.h:44-64, pinned by the reference's own
 // assertions at test/test_point_processor/test_point_processor.cc:57-61
 // ---- oracle-only hooks for tests/golden (second-sourcing the restated third-party semantics)

@@ -1,7 +1,8 @@
 """The PRODUCT against the reference's own Estimator.cc STEP BY STEP, at the contract tolerance (1e-4 m / 1e-4 rad), on the GPU.
 
 Whole replays of tests/ref_est_cases.py from t = 0 — the VLP-16 indoor configuration at 6 / 3 and at indoor_test_config.yaml's 12 / 7,
-BASELINE.json's headline HDL-64E window (15 / 5, every third sweep a message) and its Wo = 15 stress variant — go through the HIP library
+BASELINE.json's headline HDL-64E window (15 / 5, every third sweep a message) and its Wo = 15 stress variant, and six replays that flip
+one configuration switch each (cut-off de-skew, constant extrinsic, no marginalization, PriorFactor, IMU only, HDL-64E at 6 / 3) — go through the HIP library
 with the teacher forcing of tests/test_ref_estimator_run.py: after every laser message of an initialised estimator the window, the
 extrinsic and the marginalization prior are overwritten with what the REFERENCE's Estimator.cc produced
 (tests/golden/ref_estimator_run.npz: the reference's sources compiled where they lie, oracle/ref_estimator.cc), so every
@@ -36,7 +37,12 @@ from window_util import rot_angle
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_estimator_run.npz")
 # case -> number of sweeps replayed (None: all of the case)
-RUNS = {"indoor": None, "indoor_12_7": None, "outdoor64_15_5": None, "outdoor64_15_15": None}
+RUNS = {"indoor": None, "indoor_12_7": None, "outdoor64_15_5": None, "outdoor64_15_15": None,
+        # the configuration switches of the estimator, each against the reference run with the same switch: HDL-64E at 6 / 3, cut-off
+        # de-skew without kept features (every other laser message skipped while initialising), a constant extrinsic, no marginalization
+        # factor, the extrinsic PriorFactor, no lidar factors at all
+        "outdoor64": None, "indoor_iwf2": None, "indoor_fixed_extrinsic": None, "indoor_no_marginalization": None, "indoor_prior_factor": None,
+        "indoor_imu_only": None}
 
 
 class Pair:

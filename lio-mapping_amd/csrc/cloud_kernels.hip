@@ -1001,7 +1001,9 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
         std::fprintf(stderr, "\n");
       }
     }
-    if (fused_slot_ && status != 3) { fused_slot_ = false; g_vox_fused_inflight.store(0); }   // posted = past its last barrier
+    // posted = past its last barrier: the slot is free for other filters — unless this one is about to launch again (status 4) or
+    // has to drain first (3); the guard above releases it on the way out then
+    if (fused_slot_ && status != 3 && status != 4) { fused_slot_ = false; g_vox_fused_inflight.store(0); }
     if (fused_pending_ && status == 4) {
       // a point lay outside the box that came with the launch: once more, the bounds taken inside the kernel this time (the union
       // of the boxes seen so far stays and takes this cloud's box in when that launch reports)

@@ -337,8 +337,8 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
 #define VOXF_LEADER_MAX 8u           // voxels of up to this many points are ordered by their leader in registers (phase 5)
 struct VoxFusedArgs {
   const float4 *pts; int n; float inv_leaf;
-  uint32_t *table; unsigned table_words;      // capacity; a multiple of 256 (one wave iteration of the scan)
-  unsigned long long *prefix;                 // per segment: (points << 32 | voxels) in front of it inside its block's stretch
+  uint32_t *table; unsigned table_words;      // capacity; a multiple of 512 (one wave iteration of the scan)
+  unsigned long long *prefix;                 // per 32-cell group that holds a point: (points << 32 | voxels) in front of it inside its block's stretch
   unsigned long long *wtot;                   // per block: the stretch's totals
   uint32_t *sorted_idx;
   float4 *ordered;                            // the points of crowded voxels in voxel order, ascending original index inside a voxel
@@ -488,8 +488,8 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     v.n_valid = int(total);
     svp = v;
     const long long cells = total > 0 ? (long long)v.divb[0] * v.divb[1] * v.divb[2] : 0;
-    // the scan reads whole wave iterations (256 words = 1024 cells): the box must fit the table with that rounding
-    s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 1023) / 1024 * 256 > (long long)a.table_words) ? 1 : 0;
+    // the scan reads whole wave iterations (512 words = 2048 cells): the box must fit the table with that rounding
+    s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 2047) / 2048 * 512 > (long long)a.table_words) ? 1 : 0;
     }
   }
   }
@@ -498,25 +498,54 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
   {
     const VoxParams vp = svp;
     bool bail = s_bail != 0;   // uniform over the grid (a function of the folded bounds)
-    // ---- phase 1: counters
+    // ---- phase 1: counters.  Neighbouring lanes hold neighbouring points, and the clouds are mostly concatenations of voxel-ordered
+    // stacks: runs of lanes whose cells share a counter WORD send ONE atomic (the run's head adds the run's four byte increments at
+    // once; a run is at most 64 long, so no byte carries) and every lane takes its arrival slot from the old word plus the number
+    // of earlier lanes of the run in its own cell.  176 k single atomics on such input took 10-25 us (same-line queueing at the
+    // memory side, tools/micro/grid_sync.hip).
+    static_assert(VOXF_PPT == 1, "the aggregation pairs one point per lane with its neighbours");
     unsigned cell[VOXF_PPT], slot[VOXF_PPT];
     int over = 0;
+    {
+      cell[0] = 0xFFFFFFFFu; slot[0] = 0;
+      unsigned c = 0xFFFFFFFFu;
+      if (!bail && fin[0]) {
+        const int i0 = int(floorf(pt[0].x * a.inv_leaf) - float(vp.minb[0]));
+        const int i1 = int(floorf(pt[0].y * a.inv_leaf) - float(vp.minb[1]));
+        const int i2 = int(floorf(pt[0].z * a.inv_leaf) - float(vp.minb[2]));
+        if (a.box_given && (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= vp.divb[0] || i1 >= vp.divb[1] || i2 >= vp.divb[2])) over = 2;
+        else c = unsigned(i0 + i1 * vp.divb[0] + i2 * vp.divb[0] * vp.divb[1]);
+      }
+      const bool valid = c != 0xFFFFFFFFu;
+      cell[0] = c;
+      const unsigned w = valid ? (c >> 2) : (0xFFFFFFFFu - unsigned(lane));   // (an invalid lane matches nobody)
+      const unsigned pw = __shfl_up(w, 1, 64);
+      const bool head = valid && (lane == 0 || pw != w);
+      const unsigned long long hm = __ballot(head);
+      const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+      const int hl = (valid && (hm & le)) ? 63 - __clzll((long long)(hm & le)) : lane;     // the head of this lane's run
+      const unsigned sh = 8u * (c & 3u);
+      const unsigned inc = valid ? (1u << sh) : 0u;
+      unsigned sc = inc;   // inclusive scan of the byte increments inside the run
 #pragma unroll
-    for (int q = 0; q < VOXF_PPT; ++q) {
-      cell[q] = 0xFFFFFFFFu; slot[q] = 0;
-      if (!bail && fin[q]) {
-        const int i0 = int(floorf(pt[q].x * a.inv_leaf) - float(vp.minb[0]));
-        const int i1 = int(floorf(pt[q].y * a.inv_leaf) - float(vp.minb[1]));
-        const int i2 = int(floorf(pt[q].z * a.inv_leaf) - float(vp.minb[2]));
-        if (a.box_given && (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= vp.divb[0] || i1 >= vp.divb[1] || i2 >= vp.divb[2])) { over = 2; continue; }
-        const unsigned c = unsigned(i0 + i1 * vp.divb[0] + i2 * vp.divb[0] * vp.divb[1]);
-        cell[q] = c;
-        const unsigned sh = 8u * (c & 3u);
-        const unsigned old = __hip_atomic_fetch_add(a.table + (c >> 2), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        slot[q] = (old >> sh) & 0xFFu;
-        if (slot[q] >= VOXF_MAX_CNT) over = over ? over : 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(sc, o, 64);
+        if (lane >= o && lane - o >= hl) sc += t;
+      }
+      // the run ends in front of the next head or the next invalid lane
+      const unsigned long long bounds = __ballot(head || !valid);
+      const unsigned long long after = (lane == 63) ? 0ull : (bounds & ~((2ull << lane) - 1ull));
+      const int last = (after ? __ffsll((long long)after) - 1 : 64) - 1;
+      const unsigned total = __shfl(sc, head ? last : lane, 64);
+      unsigned old = 0;
+      if (head) old = __hip_atomic_fetch_add(a.table + w, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __shfl(old, hl, 64);
+      if (valid) {
+        slot[0] = ((old >> sh) & 0xFFu) + (((sc - inc) >> sh) & 0xFFu);
+        if (slot[0] >= VOXF_MAX_CNT) over = over ? over : 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
       }
     }
+    if (a.stamps && tid == 0) a.stamps[32 + blockIdx.x] = wall_clock64();
     if (over) __hip_atomic_fetch_max(a.bail_flag, over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 (outside the given box) wins over 1
     VOXF_STAMP(3);
     if (!voxf_grid_sync(a.bar + 1 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
@@ -525,41 +554,49 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     __syncthreads();
     const int bail_code = s_bail;
     bail = bail_code != 0;   // uniform over the grid again
-    // ---- phase 2: one pass over the counters of the box; a wave keeps its <= 8 iterations in registers until the block has
-    // scanned its waves' totals, so the segment prefixes go out relative to the BLOCK's stretch (one total per block to exchange)
+    // ---- phase 2: one pass over the counters of the box, a lane taking EIGHT words (32 cells) per iteration; a wave keeps the prefixes
+    // of its <= 8 iterations in registers until the block has scanned its waves' totals, so they go out relative to the BLOCK's
+    // stretch (one total per block to exchange) — and only for the 32-cell groups that hold a point: nobody looks the others up
     const unsigned cells = bail ? 0u : unsigned(vp.divb[0]) * unsigned(vp.divb[1]) * unsigned(vp.divb[2]);
-    const unsigned iters_total = (cells + 1023u) / 1024u;                          // wave iterations of 256 words
-    const unsigned iters_per_wave = (iters_total + unsigned(nwaves) - 1u) / unsigned(nwaves);   // <= 8 (table_words / 256 / nwaves)
+    const unsigned iters_total = (cells + 2047u) / 2048u;                          // wave iterations of 512 words
+    const unsigned iters_per_wave = (iters_total + unsigned(nwaves) - 1u) / unsigned(nwaves);   // <= 8 (table_words / 512 / nwaves)
     {
       unsigned run_p = 0, run_v = 0;
       const unsigned it0 = unsigned(gwave) * iters_per_wave;
       const unsigned it_end = min(it0 + min(iters_per_wave, 8u), iters_total);
-      unsigned long long lo[8], hi[8];
-      unsigned ep[8], ev[8];
+      unsigned ep[8], ev[8], pp[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        lo[j] = 0; hi[j] = 0;
-        if (it0 + j < it_end) {
-          const unsigned w0 = (it0 + j) * 256u + unsigned(lane) * 4u;
-          lo[j] = agent_load(reinterpret_cast<const unsigned long long *>(a.table + w0));
-          hi[j] = agent_load(reinterpret_cast<const unsigned long long *>(a.table + w0 + 2));
-        }
-      }
+      for (int jb = 0; jb < 8; jb += 4) {   // the loads of four iterations go out together
+        unsigned long long x[4][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ep[j] = 0; ev[j] = 0;
-        if (it0 + j < it_end) {   // wave-uniform
-          const uint32_t x0 = uint32_t(lo[j]), x1 = uint32_t(lo[j] >> 32), x2 = uint32_t(hi[j]), x3 = uint32_t(hi[j] >> 32);
-          const unsigned p = voxf_bytes_sum(x0) + voxf_bytes_sum(x1) + voxf_bytes_sum(x2) + voxf_bytes_sum(x3);
-          const unsigned v = voxf_bytes_nonzero(x0) + voxf_bytes_nonzero(x1) + voxf_bytes_nonzero(x2) + voxf_bytes_nonzero(x3);
-          unsigned ip = p, iv = v;   // inclusive scan over the lanes
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const unsigned tp = __shfl_up(ip, o, 64), tv = __shfl_up(iv, o, 64);
-            if (lane >= o) { ip += tp; iv += tv; }
+          for (int k = 0; k < 4; ++k) x[j][k] = 0;
+          if (it0 + jb + j < it_end) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.table + size_t(it0 + jb + j) * 512u + unsigned(lane) * 8u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[j][k] = agent_load(src + k);
           }
-          ep[j] = run_p + ip - p; ev[j] = run_v + iv - v;
-          run_p += __shfl(ip, 63, 64); run_v += __shfl(iv, 63, 64);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ep[jb + j] = 0; ev[jb + j] = 0; pp[jb + j] = 0;
+          if (it0 + jb + j < it_end) {   // wave-uniform
+            unsigned p = 0, v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              p += voxf_bytes_sum(uint32_t(x[j][k])) + voxf_bytes_sum(uint32_t(x[j][k] >> 32));
+              v += voxf_bytes_nonzero(uint32_t(x[j][k])) + voxf_bytes_nonzero(uint32_t(x[j][k] >> 32));
+            }
+            unsigned ip = p, iv = v;   // inclusive scan over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const unsigned tp = __shfl_up(ip, o, 64), tv = __shfl_up(iv, o, 64);
+              if (lane >= o) { ip += tp; iv += tv; }
+            }
+            ep[jb + j] = run_p + ip - p; ev[jb + j] = run_v + iv - v; pp[jb + j] = p;
+            run_p += __shfl(ip, 63, 64); run_v += __shfl(iv, 63, 64);
+          }
         }
       }
       if (lane == 0) swtot[wv] = (static_cast<unsigned long long>(run_p) << 32) | run_v;
@@ -569,8 +606,8 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
       const unsigned op = unsigned(woff >> 32), ov = unsigned(woff);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (it0 + j < it_end && (lane & 3) == 0)   // first lane of a segment (4 lanes x 4 words)
-          agent_store(a.prefix + (size_t(it0 + j) * 16u + unsigned(lane >> 2)), (static_cast<unsigned long long>(op + ep[j]) << 32) | (ov + ev[j]));
+        if (it0 + j < it_end && pp[j] != 0u)
+          agent_store(a.prefix + (size_t(it0 + j) * 64u + unsigned(lane)), (static_cast<unsigned long long>(op + ep[j]) << 32) | (ov + ev[j]));
       if (tid == 0) agent_store(a.wtot + blockIdx.x, btot);
     }
     VOXF_STAMP(5);
@@ -604,13 +641,13 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
     for (int q = 0; q < VOXF_PPT; ++q) {
       start[q] = 0; rank[q] = 0; ccount[q] = 0;
       if (!bail && cell[q] != 0xFFFFFFFFu) {
-        const unsigned c = cell[q], seg = c >> 6, it = c >> 10;
-        const unsigned long long pre = agent_load(a.prefix + seg) + sbase[(it / iters_per_wave) / unsigned(WPB)];
+        const unsigned c = cell[q], grp = c >> 5, it = c >> 11;
+        const unsigned long long pre = agent_load(a.prefix + grp) + sbase[(it / iters_per_wave) / unsigned(WPB)];
         unsigned p = unsigned(pre >> 32), v = unsigned(pre);
-        const unsigned wsel = (c >> 2) & 15u, bsel = c & 3u;
-        const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(a.table + size_t(seg) * VOXF_SEG_WORDS);
+        const unsigned wsel = (c >> 2) & 7u, bsel = c & 3u;
+        const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(a.table + size_t(grp) * 8u);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
           const unsigned long long x = agent_load(sp + k);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -626,6 +663,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
       }
     }
     VOXF_STAMP(7);
+    if (a.stamps && tid == 0) a.stamps[32 + 256 + blockIdx.x] = wall_clock64();
     if (!voxf_grid_sync(a.bar + 3 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
     VOXF_STAMP(8);
     // ---- phase 4: a point's position inside its voxel = the voxel's points with a smaller original index (the order the stable
@@ -644,6 +682,7 @@ __global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
       }
     }
     VOXF_STAMP(9);
+    if (a.stamps && tid == 0) a.stamps[32 + 512 + blockIdx.x] = wall_clock64();
     if (!voxf_grid_sync(a.bar + 4 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
     VOXF_STAMP(10);
     // ---- phase 5: centroids by the first arrival of every voxel, eight loads in flight at a time; counters back to zero
@@ -831,7 +870,7 @@ static int vox_fused_grid() {
   }();
   return g;
 }
-#define VOXF_TABLE_WORDS (8u << 20)   // 32 M cells (a 200 x 200 x 50 m box at a 0.4 m leaf is 15.6 M), 32 MB, zero between runs
+#define VOXF_TABLE_WORDS (16u << 20)   // 64 M cells (the headline's local map: 240 x 240 x 34 m at a 0.4 m leaf = 30 M), 64 MB, zero between runs
 
 bool VoxelGridDev::fused_eligible() const {
   if (!vox_fused_enabled() || fused_off_ || !(use_signal_ && host_signal_enabled())) return false;
@@ -855,7 +894,7 @@ void VoxelGridDev::enqueue_fused(bool with_box) {
   if (!f_table_.p) {
     f_table_.reserve(VOXF_TABLE_WORDS);
     LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), s));
-    f_prefix_.reserve(VOXF_TABLE_WORDS / VOXF_SEG_WORDS);
+    f_prefix_.reserve(VOXF_TABLE_WORDS / 8);   // one entry per 32-cell group (written only where a point is)
     f_wtot_.reserve(256);
     f_acc_.reserve(7 * VOXF_ACC_WAYS * VOXF_ACC_STRIDE);
     reset_fused_acc(s);
@@ -865,7 +904,7 @@ void VoxelGridDev::enqueue_fused(bool with_box) {
   }
   f_sorted_.reserve(p_n_); f_ordered_.reserve(p_n_);
   static const bool dbg_stamps = std::getenv("LIO_DEBUG_TIMING") != nullptr;
-  if (dbg_stamps && !f_stamps_.p) { f_stamps_.reserve(32); LIO_HIP(hipMemsetAsync(f_stamps_.p, 0, 32 * sizeof(long long), s)); }
+  if (dbg_stamps && !f_stamps_.p) { f_stamps_.reserve(32 + 768); LIO_HIP(hipMemsetAsync(f_stamps_.p, 0, (32 + 768) * sizeof(long long), s)); }
   params_.reserve(1);
   if (count_.cap < 2) { count_.reserve(2); LIO_HIP(hipMemsetAsync(count_.p, 0, count_.cap * sizeof(int), s)); }
   p_out_->reserve(p_n_);
@@ -883,7 +922,7 @@ void VoxelGridDev::enqueue_fused(bool with_box) {
   if (with_box && spec_valid_ && spec_leaf_ == p_leaf_) {
     long long cells = 1;
     for (int d = 0; d < 3; ++d) { a.box_minb[d] = spec_lo_[d] - 4; a.box_divb[d] = spec_hi_[d] - spec_lo_[d] + 1 + 8; cells *= a.box_divb[d]; }
-    if ((cells + 1023) / 1024 * 256 <= (long long)VOXF_TABLE_WORDS) a.box_given = 1;
+    if ((cells + 2047) / 2048 * 512 <= (long long)VOXF_TABLE_WORDS) a.box_given = 1;
   }
   if (!a.box_given) ++f_epoch0_;
   fused_with_box_ = a.box_given != 0;
@@ -999,6 +1038,19 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
         for (int k = 0; k < 12; ++k) std::fprintf(stderr, "%s %lld|%lld  ", nm[k], st[k] - st[0], st[16 + k] - st[0]);
         std::fprintf(stderr, "(box known %lld|%lld)", st[12] - st[0], st[16 + 12] - st[0]);
         std::fprintf(stderr, "\n");
+        {   // where the slowest block of a phase sits: end of count / place / order per block
+          static long long blk[768];
+          LIO_HIP(hipMemcpy(blk, f_stamps_.p + 32, sizeof(blk), hipMemcpyDeviceToHost));
+          const int g = vox_fused_grid();
+          const char *ph[3] = {"count", "place", "order"};
+          for (int q = 0; q < 3; ++q) {
+            int arg = 0; long long mx = -1, sum = 0;
+            for (int b = 0; b < g; ++b) { const long long v = blk[q * 256 + b] - st[0]; sum += v; if (v > mx) { mx = v; arg = b; } }
+            std::fprintf(stderr, "[lio_hip timing]   %s done: mean %lld, slowest block %d at %lld; blocks 0/32/64/96/128/160/192/224: %lld %lld %lld %lld %lld %lld %lld %lld\n", ph[q], sum / g, arg, mx,
+                         blk[q * 256 + 0] - st[0], blk[q * 256 + 32] - st[0], blk[q * 256 + 64] - st[0], blk[q * 256 + 96] - st[0], blk[q * 256 + 128] - st[0],
+                         blk[q * 256 + 160] - st[0], blk[q * 256 + 192] - st[0], blk[q * 256 + 224] - st[0]);
+          }
+        }
       }
     }
     // posted = past its last barrier: the slot is free for other filters — unless this one is about to launch again (status 4) or

@@ -33,7 +33,7 @@ def _cloud(rng, n, extent=40.0, height=6.0):
 
 def _hands_over(pts, leaf):
     """what k_vox_fused decides from the cloud: more than 32 points in a voxel, a box of more cells than the counter table
-    (32 M, counted in whole 1024-cell stretches), or no finite point"""
+    (64 M, counted in whole 2048-cell stretches), or no finite point"""
     ok = np.isfinite(pts[:, :3]).all(axis=1)
     if not ok.any():
         return True
@@ -41,7 +41,7 @@ def _hands_over(pts, leaf):
     c = np.floor(pts[ok, :3] * inv).astype(np.int64)
     lo, hi = np.floor(pts[ok, :3].min(axis=0) * inv).astype(np.int64), np.floor(pts[ok, :3].max(axis=0) * inv).astype(np.int64)
     d = hi - lo + 1
-    if (int(d[0]) * int(d[1]) * int(d[2]) + 1023) // 1024 * 256 > (8 << 20):
+    if (int(d[0]) * int(d[1]) * int(d[2]) + 2047) // 2048 * 512 > (16 << 20):
         return True
     key = (c[:, 0] - lo[0]) + d[0] * ((c[:, 1] - lo[1]) + d[1] * (c[:, 2] - lo[2]))
     return bool(np.unique(key, return_counts=True)[1].max() > 32)
@@ -119,7 +119,7 @@ def test_hand_over_to_the_sorted_path(hip, oracle):
     _run(hip, oracle, edge, 0.4, True, False)
     edge[32, :3] = edge[0, :3]
     _run(hip, oracle, edge, 0.4, True, True)
-    # a box of more cells than the counter table holds (32 M): 900 x 900 x 600 m at 0.4 m
+    # a box of more cells than the counter table holds (64 M): 900 x 900 x 600 m at 0.4 m
     wide = _cloud(rng, 20000, 450.0)
     wide[:100, 2] = rng.uniform(-300, 300, 100).astype(np.float32)
     _run(hip, oracle, wide, 0.4, True, True)

@@ -560,14 +560,19 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
       bool resident = mail && resident_rounds_ && nb + 1 <= kOdomResidentMaxBlocks;
       if (resident && g_resident_rounds.fetch_add(1) >= kMaxResidentRounds) { g_resident_rounds.fetch_sub(1); resident = false; }
       if (resident) {
+        struct Release { ~Release() { g_resident_rounds.fetch_sub(1); } } release;   // from the admission on: a launch that throws gives the slot back too
         sig.flag = h_signal_ + 128; sig.seq = ++signal_seq_[1];
+        if (odom_seq_ > 0xF0000000u) {   // 32-bit sequence numbers: start over long before they wrap (no launch is in flight here)
+          LIO_HIP(hipStreamSynchronize(stream_));
+          LIO_HIP(hipMemset(d_odom_flags_.p, 0, sizeof(unsigned) * (kOdomResidentMaxBlocks + 1)));
+          odom_seq_ = 16;   // (as a fresh handle: zeroed flags never equal a live round number)
+        }
         const unsigned seq0 = odom_seq_;
         odom_seq_ += 16;
         launch_odom_rounds_resident(fo, slot_off_[W_], keep_mult > 1 ? 1 : 0, 10, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
                                     f_score_.p, d_odom_partials_.p, d_odom_flags_.p, d_odom_flags_.p + kOdomResidentMaxBlocks, seq0, res_timeout_ticks_ / 4, stream_,
                                     h_odom_, sig, g_debug_timing ? d_odom_stamps_.p : nullptr, lpq);
-        struct Release { ~Release() { g_resident_rounds.fetch_sub(1); } } release;   // (the launch is asynchronous; the slot is held until the state is back)
-        LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+        LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));   // (the launch is asynchronous; the slot is held until the state is back)
         wait_host_signal(sig, stream_);
         st = *h_odom_;
         have_state = true;

@@ -2136,7 +2136,8 @@ void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int
   LIO_HIP(hipGetLastError());
 }
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
-                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq) {
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq,
+                       hipEvent_t after_search) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
   const int nb = odom_round_blocks(M, lpq);
@@ -2144,6 +2145,7 @@ void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, Od
     hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   else
   hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
+  if (after_search) LIO_HIP(hipEventRecord(after_search, s));   // the one-block update kernel behind it leaves the chip idle: work of another stream can start here
   hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());
 }

@@ -244,6 +244,9 @@ class Estimator {
 
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_round_[3] = {nullptr, nullptr, nullptr};   // behind the search kernel of the first three newest-frame rounds (staged features)
+  bool stage_features_ = false, stage_features_now_ = false;   // LIO_STAGE_FEATURES=1: the older frames' features in three launches behind the first rounds' search kernels (measured slower)
+  FeatArgs staged_fa_{};
   std::vector<DeviceCloud> stacks_;
   std::vector<size_t> size_surf_stack_;
   std::vector<StampedPose> imu_stamped_;

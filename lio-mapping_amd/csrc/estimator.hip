@@ -69,6 +69,8 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipStreamCreate(&stream2_));
   LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  for (hipEvent_t &e : ev_round_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char *e = std::getenv("LIO_STAGE_FEATURES")) stage_features_ = std::atoi(e) != 0;
   transform_lb_ = cfg.transform_lb;
   Ps_.assign(W_ + 1, V3d()); Vs_ = Bas_ = Bgs_ = Ps_;
   Rs_.assign(W_ + 1, M3d::identity());
@@ -150,6 +152,7 @@ Estimator::~Estimator() {
   if (h_ds_) (void)hipHostFree(h_ds_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
+  for (hipEvent_t e : ev_round_) if (e) (void)hipEventDestroy(e);
   if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -526,14 +529,24 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // The Wo-1 older frames do not depend on the newest frame's Gauss-Newton rounds: their batched launch goes to a second
     // stream and fills the CUs the serial rows/update kernels of that loop leave idle; joined before the solve.
     hipStream_t sf = cfg_.imu_factor ? stream2_ : stream_;
-    if (sf != stream_) {
-      LIO_HIP(hipEventRecord(ev_fork_, stream_));
-      LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
+    // Staged form (LIO_STAGE_FEATURES=1, NOT the default): beside the first round's search kernel the batched launch slows that round
+    // from 19 to 37 us (both are bound by vector issue; kernel trace in profiles/r4_solve_timeline.md), while the one-block update kernel
+    // behind every search leaves the chip idle for 12 us — so the older frames can go out in up to three launches, each behind the
+    // search kernel of one of the first three rounds (an event between the round's two kernels).  Measured: the event costs a 7 us
+    // bubble between the two kernels of every round and the 8-lane launches of the parts outlast their holes: feature_cost 0.157
+    // against 0.135 ms.  Same kernels, same results either way.
+    stage_features_now_ = sf != stream_ && stage_features_ && !resident_rounds_ && !timers_.on && stacks_[W_].n > 0 && fa.nframes >= 2;
+    staged_fa_ = fa;
+    if (!stage_features_now_) {
+      if (sf != stream_) {
+        LIO_HIP(hipEventRecord(ev_fork_, stream_));
+        LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
+      }
+      th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, sf);
+      launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, sf);
+      timers_.end(th, sf);
+      if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
     }
-    th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, sf);
-    launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, sf);
-    timers_.end(th, sf);
-    if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
   }
   laser_odom_iters_ = 0; laser_odom_kz_ = 0;
   if (cfg_.imu_factor) {
@@ -605,9 +618,24 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         // one round = search + plane fit + rows (k_odom_round) and fold + 6x6 step (k_odom_update_wide)
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
+        const bool stage_here = stage_features_now_ && iter < 3;
         launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq);
+                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq, stage_here ? ev_round_[iter] : nullptr);
         timers_.end(t1h, stream_);
+        if (stage_here) {
+          // the older frames' share behind this round's search: half of them, half of the rest, the rest
+          const int nf = staged_fa_.nframes;
+          const int c0 = (nf + 1) / 2, c1 = (nf - c0 + 1) / 2;
+          const int begin = iter == 0 ? 0 : (iter == 1 ? c0 : c0 + c1), end = iter == 0 ? c0 : (iter == 1 ? c0 + c1 : nf);
+          LIO_HIP(hipStreamWaitEvent(stream2_, ev_round_[iter], 0));
+          if (end > begin) {
+            FeatArgs part = staged_fa_;
+            part.nframes = 0; part.max_M = 0;
+            for (int k = begin; k < end; ++k) { part.fr[part.nframes++] = staged_fa_.fr[k]; part.max_M = std::max(part.max_M, staged_fa_.fr[k].M); }
+            launch_features(part, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, stream2_);
+          }
+          if (iter == 2) LIO_HIP(hipEventRecord(ev_join_, stream2_));
+        }
       }
       }
     }

@@ -65,8 +65,17 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   int ndev = 0;
   LIO_HIP(hipGetDeviceCount(&ndev));
   if (ndev <= 0) throw DeviceError("no HIP device: the product has no CPU path");
-  LIO_HIP(hipStreamCreate(&stream_));
-  LIO_HIP(hipStreamCreate(&stream2_));
+  // LIO_STREAM_PRIORITY=1 (A/B switch): the estimator's stream at the highest priority, the side stream (older frames' features) at the
+  // lowest, so that the newest-frame rounds — the critical path — are dispatched first where both have workgroups pending
+  static const bool prio = [] { const char *e = std::getenv("LIO_STREAM_PRIORITY"); return e && std::atoi(e) != 0; }();
+  int least = 0, greatest = 0;
+  if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+    LIO_HIP(hipStreamCreateWithPriority(&stream_, hipStreamDefault, greatest));
+    LIO_HIP(hipStreamCreateWithPriority(&stream2_, hipStreamDefault, least));
+  } else {
+    LIO_HIP(hipStreamCreate(&stream_));
+    LIO_HIP(hipStreamCreate(&stream2_));
+  }
   LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   for (hipEvent_t &e : ev_round_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -186,7 +186,8 @@ int odom_rows_blocks(int nslots);
 int odom_round_blocks(int M, int lpq);
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
                        uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail = nullptr,
-                       const HostSignal &sig = HostSignal(), int lpq = 8, hipEvent_t after_search = nullptr);
+                       const HostSignal &sig = HostSignal(), int lpq = 8, hipEvent_t after_search = nullptr, const FeatArgs *ride = nullptr,
+                       const float *transforms = nullptr);   // ride: frames whose features go out in the update block's launch (k_odom_update_with_features)
 
 // every round of the loop in ONE launch: nb search blocks + one update block that folds, steps and republishes
 // the state between rounds; block_flag (nb words) and state_seq (1 word) must hold values below seq0 (they only ever grow);

@@ -1505,26 +1505,29 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
 // (the fit used to occupy one lane in LPQ of every wave while costing all of its issue slots — these kernels are bound by
 // vector-instruction issue, not by memory).
 #define FEAT_THREADS 256
-template <bool MAPPING, int LPQ>
-__global__ void __launch_bounds__(FEAT_THREADS) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
-                                                          const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                          float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
-                                                          float4 *__restrict__ abs_coef) {
-  if (skip_flag && *skip_flag) return;
+// One (frame, block) share of CalculateFeatures by FEAT_THREADS lanes.  SUBS > 1: the calling block is SUBS x FEAT_THREADS wide and its
+// SUBS quarters take the blocks SUBS * block_x + 0 .. SUBS - 1 (the 1024-thread launch that rides behind the rounds' update block).
+template <bool MAPPING, int LPQ, int SUBS>
+__device__ __forceinline__ void features_block(const FeatArgs &a, int frame, int block_x, const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                               const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
+                                               float4 *__restrict__ coef, float *__restrict__ score, float4 *__restrict__ abs_coef) {
   constexpr int QPB = FEAT_THREADS / LPQ;
   static_assert(QPB <= 64, "the fit phase is one wave");
-  __shared__ int s_bj[QPB][5];
-  __shared__ float s_bd4[QPB];
-  __shared__ int s_bi4[QPB];
-  const FeatFrame fr = a.fr[blockIdx.y];
-  if (int(blockIdx.x) * QPB >= fr.M) return;
+  __shared__ int s_bj[SUBS][QPB][5];
+  __shared__ float s_bd4[SUBS][QPB];
+  __shared__ int s_bi4[SUBS][QPB];
+  const int sb = SUBS > 1 ? int(threadIdx.x) / FEAT_THREADS : 0, lt = SUBS > 1 ? int(threadIdx.x) % FEAT_THREADS : int(threadIdx.x);
+  const int blk = block_x * SUBS + sb;
+  const FeatFrame fr = a.fr[frame];
+  const bool blk_active = blk * QPB < fr.M;
+  if (SUBS == 1 && !blk_active) return;
   const FeatScalars fs = feat_scalars(a);
   const float *tp = transforms + 8 * fr.tf_index;
   const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   const Vec3<float> t(tp[4], tp[5], tp[6]);
-  {
-    const int ql = threadIdx.x / LPQ, sub = threadIdx.x % LPQ;
-    const int i = blockIdx.x * QPB + ql;
+  if (blk_active) {
+    const int ql = lt / LPQ, sub = lt % LPQ;
+    const int i = blk * QPB + ql;
     const bool active = i < fr.M;
     const float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
     const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
@@ -1533,23 +1536,32 @@ __global__ void __launch_bounds__(FEAT_THREADS) k_features(FeatArgs a, const flo
     knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
     if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) s_bj[ql][k] = bj[k];
-      s_bd4[ql] = bd[4]; s_bi4[ql] = bi[4];
+      for (int k = 0; k < 5; ++k) s_bj[sb][ql][k] = bj[k];
+      s_bd4[sb][ql] = bd[4]; s_bi4[sb][ql] = bi[4];
     }
   }
   __syncthreads();
-  const int ql = threadIdx.x, i = blockIdx.x * QPB + ql;
-  if (ql >= QPB || i >= fr.M) return;
+  const int ql = lt, i = blk * QPB + ql;
+  if (!blk_active || ql >= QPB || i >= fr.M) return;
   const float4 po = fr.stack[i];
   const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
   const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   int bj[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
-  const FeatResult res = features_fit<MAPPING>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
+  for (int k = 0; k < 5; ++k) bj[k] = s_bj[sb][ql][k];
+  const FeatResult res = features_fit<MAPPING>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[sb][ql], s_bi4[sb][ql], bj, map);
   valid[res.slot] = res.ok; coef[res.slot] = res.c;
   if (score) score[res.slot] = res.sc;
   if (MAPPING && abs_coef && res.ok) abs_coef[res.slot] = res.abs;
+}
+// CalculateFeatures for every frame of the launch (blockIdx.y)
+template <bool MAPPING, int LPQ>
+__global__ void __launch_bounds__(FEAT_THREADS) k_features(FeatArgs a, const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                                          const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                          float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
+                                                          float4 *__restrict__ abs_coef) {
+  if (skip_flag && *skip_flag) return;
+  features_block<MAPPING, LPQ, 1>(a, int(blockIdx.y), int(blockIdx.x), transforms, map, cells, g, valid, coef, score, abs_coef);
 }
 
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
@@ -2063,8 +2075,8 @@ __global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_rounds_resident(Fea
 // ascending), followed by the update of odom_update_body
 // mail: a copy of the state in coherent pinned host memory, posted with the round's sequence number after every round (also
 // by the no-op rounds behind convergence), so the host's look at the convergence flag is a read of its own memory.
-__global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
-                                                           int left_update, OdomState *mail, HostSignal sig) {
+__device__ __forceinline__ void odom_update_wide_block(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
+                                                      int left_update, OdomState *mail, const HostSignal &sig) {
   if (st->converged) {
     if (sig.flag && threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
     return;
@@ -2096,6 +2108,26 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
     __syncthreads();   // thread 0's update of *st is visible to wave 0
     if (threadIdx.x < 64) post_host_mail(sig, mail, st, int(sizeof(OdomState) / 4), threadIdx.x);
   }
+}
+__global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
+                                                           int left_update, OdomState *mail, HostSignal sig) {
+  odom_update_wide_block(partials, nblocks, st, iter, min_rows, left_update, mail, sig);
+}
+// The update block with a share of the older frames' features riding in the same launch (round 4).  The update is ONE block: for its
+// 12 us the chip is idle (kernel trace, profiles/r4_solve_timeline.md), while the batched k_features on a side stream used to run
+// beside round 0's search kernel and slowed it from 19 to 37 us (both are bound by vector issue).  Block 0 is the update; the blocks
+// behind it are 1024 threads wide and take four 256-lane feature blocks each (features_block<.., 4>), a frame's blocks contiguous.
+// No second stream, no fork / join events (an event between two kernels of a stream costs a 7 us bubble).  Same results: the
+// features do not depend on the split, and they finish before the launch does, i.e. before anything later on the stream.
+template <int LPQ>
+__global__ void __launch_bounds__(1024) k_odom_update_with_features(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
+                                                                    int left_update, OdomState *mail, HostSignal sig, FeatArgs af,
+                                                                    const float *__restrict__ transforms, const float4 *__restrict__ map,
+                                                                    const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
+                                                                    float4 *__restrict__ coef, float *__restrict__ score, int fblocks) {
+  if (blockIdx.x == 0) { odom_update_wide_block(partials, nblocks, st, iter, min_rows, left_update, mail, sig); return; }
+  const int fb = int(blockIdx.x) - 1;
+  features_block<false, LPQ, 4>(af, fb / fblocks, fb % fblocks, transforms, map, cells, g, valid, coef, score, nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_solve_setup(SolveSetup a, float *__restrict__ d_transforms, OdomState *__restrict__ d_odom, uint8_t *__restrict__ valid,
@@ -2137,7 +2169,7 @@ void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int
 }
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
                        uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq,
-                       hipEvent_t after_search) {
+                       hipEvent_t after_search, const FeatArgs *ride, const float *transforms) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
   const int nb = odom_round_blocks(M, lpq);
@@ -2146,6 +2178,12 @@ void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, Od
   else
   hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   if (after_search) LIO_HIP(hipEventRecord(after_search, s));   // the one-block update kernel behind it leaves the chip idle: work of another stream can start here
+  if (ride && ride->nframes > 0 && ride->max_M > 0 && !ride->mapping_mode) {
+    // the older frames' share of this round rides with the update block: four lanes per query, 64 queries per 256-lane quarter
+    const int fblocks = cdiv(cdiv((long long)ride->max_M * 4, FEAT_THREADS), 4);
+    hipLaunchKernelGGL(k_odom_update_with_features<4>, dim3(1 + fblocks * ride->nframes), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig, *ride,
+                       transforms, map_sorted, cells, g, valid, coef, score, fblocks);
+  } else
   hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());
 }

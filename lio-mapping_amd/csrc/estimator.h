@@ -246,6 +246,7 @@ class Estimator {
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   hipEvent_t ev_round_[3] = {nullptr, nullptr, nullptr};   // behind the search kernel of the first three newest-frame rounds (staged features)
   bool stage_features_ = false, stage_features_now_ = false;   // LIO_STAGE_FEATURES=1: the older frames' features in three launches behind the first rounds' search kernels (measured slower)
+  bool ride_features_ = false, ride_features_now_ = false;    // LIO_RIDE_FEATURES=1: the older frames' features in the launches of the first three rounds' update blocks (measured slower)
   FeatArgs staged_fa_{};
   std::vector<DeviceCloud> stacks_;
   std::vector<size_t> size_surf_stack_;

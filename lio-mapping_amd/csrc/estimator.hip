@@ -80,6 +80,7 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   for (hipEvent_t &e : ev_round_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char *e = std::getenv("LIO_STAGE_FEATURES")) stage_features_ = std::atoi(e) != 0;
+  if (const char *e = std::getenv("LIO_RIDE_FEATURES")) ride_features_ = std::atoi(e) != 0;
   transform_lb_ = cfg.transform_lb;
   Ps_.assign(W_ + 1, V3d()); Vs_ = Bas_ = Bgs_ = Ps_;
   Rs_.assign(W_ + 1, M3d::identity());
@@ -545,8 +546,13 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // bubble between the two kernels of every round and the 8-lane launches of the parts outlast their holes: feature_cost 0.157
     // against 0.135 ms.  Same kernels, same results either way.
     stage_features_now_ = sf != stream_ && stage_features_ && !resident_rounds_ && !timers_.on && stacks_[W_].n > 0 && fa.nframes >= 2;
+    // Ride-along form (LIO_RIDE_FEATURES=1, NOT the default): the older frames' features in the launches of the first three rounds'
+    // UPDATE blocks (k_odom_update_with_features: the chip is idle while that one block folds and steps) — no side stream, no events.
+    // Measured: a feature launch takes 29-33 us however few blocks it has (a query is a chain of dependent candidate loads), so each
+    // of the three update launches grows from 12 to ~30 us: feature_cost 0.161 against 0.138 ms.
+    ride_features_now_ = sf != stream_ && ride_features_ && !stage_features_now_ && !resident_rounds_ && !timers_.on && stacks_[W_].n > 0 && fa.nframes >= 1;
     staged_fa_ = fa;
-    if (!stage_features_now_) {
+    if (!stage_features_now_ && !ride_features_now_) {
       if (sf != stream_) {
         LIO_HIP(hipEventRecord(ev_fork_, stream_));
         LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
@@ -628,8 +634,18 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
         const bool stage_here = stage_features_now_ && iter < 3;
+        FeatArgs ride{};
+        if (ride_features_now_ && iter < 3) {   // this round's share of the older frames
+          const int nf = staged_fa_.nframes;
+          const int c0 = (nf + 1) / 2, c1 = (nf - c0 + 1) / 2;
+          const int begin = iter == 0 ? 0 : (iter == 1 ? c0 : c0 + c1), end = iter == 0 ? c0 : (iter == 1 ? c0 + c1 : nf);
+          ride = staged_fa_;
+          ride.nframes = 0; ride.max_M = 0;
+          for (int k = begin; k < end; ++k) { ride.fr[ride.nframes++] = staged_fa_.fr[k]; ride.max_M = std::max(ride.max_M, staged_fa_.fr[k].M); }
+        }
         launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq, stage_here ? ev_round_[iter] : nullptr);
+                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq, stage_here ? ev_round_[iter] : nullptr,
+                          ride.nframes > 0 ? &ride : nullptr, d_transforms_.p);
         timers_.end(t1h, stream_);
         if (stage_here) {
           // the older frames' share behind this round's search: half of them, half of the rest, the rest
@@ -650,7 +666,7 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     }
     // the older frames' features (second stream) must be complete before anything later on stream_ reads them; the host
     // itself only needs the final state, which a converged peek has already delivered
-    LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    if (!ride_features_now_) LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (!have_state) {
       if (sig.flag) {
         wait_host_signal(sig, stream_);

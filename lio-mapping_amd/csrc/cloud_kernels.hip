@@ -2086,13 +2086,30 @@ __device__ __forceinline__ void odom_update_wide_block(const double *__restrict_
   const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
   double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
   if (c < 28) {
+    // The sums are those of the four-at-a-time walk (rows b, b + 32, b + 64, b + 96 into v0 .. v3, the tail into v0, ascending b) — the
+    // order the resident form of the loop folds in too — but the LOADS go out eight, then four, then up to three at a time: the
+    // fold is a chain of memory round trips (19 rows per lane at 606 blocks: 7 trips before, 3 now), not of additions.
     int b = gq;
-    for (; b + 96 < nblocks; b += 128) {   // four loads in flight per lane, summed in ascending b
+    for (; b + 224 < nblocks; b += 256) {
+      double x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = partials[size_t(b + 32 * k) * 28 + c];
+      v0 += x[0]; v1 += x[1]; v2 += x[2]; v3 += x[3];
+      v0 += x[4]; v1 += x[5]; v2 += x[6]; v3 += x[7];
+    }
+    for (; b + 96 < nblocks; b += 128) {
       const double x0 = partials[size_t(b) * 28 + c], x1 = partials[size_t(b + 32) * 28 + c], x2 = partials[size_t(b + 64) * 28 + c],
                    x3 = partials[size_t(b + 96) * 28 + c];
       v0 += x0; v1 += x1; v2 += x2; v3 += x3;
     }
-    for (; b < nblocks; b += 32) v0 += partials[size_t(b) * 28 + c];
+    {   // at most three rows are left
+      const bool h0 = b < nblocks, h1 = b + 32 < nblocks, h2 = b + 64 < nblocks;
+      const double x0 = h0 ? partials[size_t(b) * 28 + c] : 0.0, x1 = h1 ? partials[size_t(b + 32) * 28 + c] : 0.0,
+                   x2 = h2 ? partials[size_t(b + 64) * 28 + c] : 0.0;
+      if (h0) v0 += x0;
+      if (h1) v0 += x1;
+      if (h2) v0 += x2;
+    }
   }
   part[gq][c] = (v0 + v1) + (v2 + v3);
   __syncthreads();

@@ -234,14 +234,6 @@ int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *xyzi_out, siz
  * stream, timed with HIP events; avg_ms_out = one filter (keys, sort, run heads, centroids, the count's way back to the host).
  * The oracle returns LIO_ERR_DEVICE. */
 int lio_bench_voxel_grid(const float *xyzi, size_t n, float leaf, int reps, double *avg_ms_out, size_t *n_out_or_null);
-/* Test hook (no reference counterpart): how many filters of this process took the one-launch form (a counting sort over the cloud's
- * own box of cells inside one kernel, csrc/cloud_kernels.hip: k_vox_fused) and how many of those handed the cloud back to the sorted
- * path (box larger than the counter table, a voxel with more than 32 points, no finite point, a grid barrier that timed out).  Either
- * output may be null.  The oracle reports 0 / 0. */
-void lio_vox_fused_stats(long long *launched_or_null, long long *fell_back_or_null);
-/* Test hook: 1 / 0 = the filters of this process take / do not take the one-launch form from now on, -1 = the environment decides
- * again (LIO_VOX_FUSED, off unless set to 1: DESIGN.md 5.4 has the measurement).  Returns the previous setting.  The oracle ignores it. */
-int lio_vox_fused_set(int on);
 /* pcl::KdTreeFLANN::nearestKSearch (B.2): exact K-NN, ascending squared distance, index tiebreak.
  * idx_out / sqd_out are m*k.  The product restricts the search to radius_sq (entries beyond it
  * come back as idx -1 / sqd +inf); pass radius_sq <= 0 for an unbounded search (oracle only).  */
@@ -338,7 +330,6 @@ typedef struct {
   int inline_marg;            /* 1: marginalization inside lio_est_solve_optimization instead of the worker thread (LIO_ASYNC_MARG=0) */
   int stream_sync;            /* 1: hipStreamSynchronize + D2H copies instead of completion words in host memory (LIO_HOST_SIGNAL=0) */
   int moments_form;           /* 0: by launch size, 1: fp64 MFMA form, 2: structured fp64 VALU form (LIO_MOMENTS=mfma|valu) */
-  int moments_fold_in_kernel; /* 1: fold the per-block moments inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL) */
   int resident_moments;       /* 0: by default rule (on), 1: on, 2: off, 3: its partition with launches only — the lidar moments of a solve
                                  come from ONE resident kernel that waits for each linearisation point on a doorbell in host memory
                                  (LIO_RESIDENT_MOMENTS=0|1).  "On" is a permission: a solve takes the resident form while it is the only
@@ -346,10 +337,6 @@ typedef struct {
                                  per linearisation otherwise — over the SAME partition of the factor slots, so the moments do not
                                  depend on which of the two ran (3 pins the launch pairs: what a refused solve gets).  2 is round 2's
                                  launch pair with its own partition: the same sums in a different order, last-ulp differences */
-  int resident_rounds;        /* 1: the <= 10 rounds of CalculateLaserOdom as ONE launch (search blocks + an update block that folds, steps and
-                                 republishes the state between rounds; LIO_RESIDENT_ROUNDS=1).  Measured no faster than a launch pair per
-                                 round (30 vs 32 us per round: the one-thread 6x6 step and the fold dominate the gap), and it admits one
-                                 window per process at a time, so it is opt-in */
 } lio_est_config;
 
 /* Named after the reference's TicToc stages so CPU/GPU tables line up. */

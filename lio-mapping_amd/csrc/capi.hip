@@ -410,13 +410,6 @@ static void host_bounds(const float *xyzi, size_t n, float mn[3], float mx[3]) {
     for (int d = 0; d < 3; ++d) { float v = xyzi[4 * i + d]; if (std::isfinite(v)) { mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); } }
 }
 
-void lio_vox_fused_stats(long long *launched, long long *fell_back) {
-  long long a = 0, b = 0;
-  vox_fused_stats(&a, &b);
-  if (launched) *launched = a;
-  if (fell_back) *fell_back = b;
-}
-int lio_vox_fused_set(int on) { return vox_fused_set(on); }
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
   if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
   return guarded([&] {
@@ -573,10 +566,9 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
   e.init_window_factor = c->init_window_factor > 0 ? c->init_window_factor : 1;
   e.device_solve = c->device_solve != 0; e.device_marg = c->device_marg != 0; e.inline_marg = c->inline_marg != 0;
-  e.stream_sync = c->stream_sync != 0; e.moments_fold_in_kernel = c->moments_fold_in_kernel != 0;
+  e.stream_sync = c->stream_sync != 0;
   e.moments_form = (c->moments_form == 1 || c->moments_form == 2) ? c->moments_form : 0;
   e.resident_moments = (c->resident_moments >= 1 && c->resident_moments <= 3) ? c->resident_moments : 0;
-  e.resident_rounds = c->resident_rounds == 1;
   // Estimator.cc:189-194: the estimator's filter sizes and thresholds configure its PointMapping base (created on first use)
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
   h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;

@@ -52,26 +52,6 @@ class VoxelGridDev {
   const float4 *p_in_ = nullptr; size_t p_n_ = 0; DBuf<float4> *p_out_ = nullptr; hipStream_t p_stream_ = nullptr;  // the pending launch
   float p_leaf_ = 0.f;
   void enqueue(bool exact);
-  // the filter as one launch (k_vox_fused: counting sort over the cloud's own box of cells, grid barriers inside)
-  bool fused_eligible() const;
-  void enqueue_fused(bool with_box);
-  DBuf<uint32_t> f_table_, f_sorted_;
-  DBuf<float4> f_ordered_;
-  DBuf<long long> f_stamps_;
-  DBuf<unsigned long long> f_prefix_, f_wtot_;
-  DBuf<unsigned> f_acc_;
-  void reset_fused_acc(hipStream_t s);
-  DBuf<unsigned> f_bar_;
-  unsigned f_epoch_ = 0, f_epoch0_ = 0;       // launches so far / launches that took their bounds inside the kernel (barrier 0)
-  bool spec_valid_ = false, fused_with_box_ = false;
-  float spec_leaf_ = 0.f;
-  int spec_lo_[3] = {0, 0, 0}, spec_hi_[3] = {0, 0, 0};   // union of the boxes (in cells) of the clouds filtered so far at spec_leaf_
-  int fused_reboxed_ = 0;
-  bool fused_pending_ = false, fused_off_ = false, fused_slot_ = false;
-  int fused_fallbacks_ = 0;
- public:
-  int fused_fallbacks() const { return fused_fallbacks_; }   // filters of this object that fell back to the sorted path
- private:
   int *h_count_ = nullptr;          // pinned: output count, followed by the VoxParams
   VoxParams *h_params_ = nullptr;
   DBuf<float> partial_;
@@ -84,10 +64,6 @@ class VoxelGridDev {
   HostSignal sig_{};
   bool use_signal_ = true;
 };
-// process-wide counters of the one-launch filter: launches, and those that fell back to the sorted path (lio_vox_fused_stats)
-void vox_fused_stats(long long *launched, long long *fell_back);
-// 1 / 0: filters take / do not take the one-launch form from now on, -1: back to LIO_VOX_FUSED; returns the previous setting
-int vox_fused_set(int on);
 // LIO_HOST_SIGNAL=0: every wait is a hipStreamSynchronize again
 bool host_signal_enabled();
 
@@ -186,15 +162,7 @@ int odom_rows_blocks(int nslots);
 int odom_round_blocks(int M, int lpq);
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
                        uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail = nullptr,
-                       const HostSignal &sig = HostSignal(), int lpq = 8, hipEvent_t after_search = nullptr, const FeatArgs *ride = nullptr,
-                       const float *transforms = nullptr);   // ride: frames whose features go out in the update block's launch (k_odom_update_with_features)
-
-// every round of the loop in ONE launch: nb search blocks + one update block that folds, steps and republishes
-// the state between rounds; block_flag (nb words) and state_seq (1 word) must hold values below seq0 (they only ever grow);
-// the final state reaches the host through mail / sig.  max_rounds <= 10.
-void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int max_rounds, OdomState *st, const float4 *map_sorted, const int *cells,
-                                 const GridDesc &g, uint8_t *valid, float4 *coef, float *score, double *partials, unsigned *block_flag, unsigned *state_seq,
-                                 unsigned seq0, long long timeout_ticks, hipStream_t s, OdomState *mail, const HostSignal &sig, long long *stamps = nullptr, int lpq = 8);
+                       const HostSignal &sig = HostSignal(), int lpq = 8);
 
 // ---- batched keyframe refinement (config 5: B independent OptimizeMap / OptimizeTransformTobeMapped loops, MapBuilder.cc:624-1014,
 // PointMapping.cc:325-753).  Slots of keyframe k = [slot_off, slot_off + Mc) corner, then Ms surf, in one concatenated stack.

@@ -309,512 +309,6 @@ __global__ void __launch_bounds__(VOX_TILE) k_vox_centroids(const float4 *__rest
   out[pos] = make_float4(ax / c, ay / c, az / c, ai / c);
 }
 
-// ================================================================================================
-// The filter as ONE launch (round 4).  The library sort of the (voxel, index) keys is launch latency — a block sort and seven
-// merges of ~6 us for 150 k keys — so the sort is replaced by what the voxel index allows: a COUNTING sort over the cloud's own
-// box of cells, all phases inside one kernel whose blocks are co-resident and meet at five grid barriers:
-//   0  every thread keeps its <= VOXF_PPT points in registers; bounds of the cloud (block partials, folded by every block after
-//      barrier 1) -> VoxParams exactly as k_bounds_final forms it, and with it PCL's own voxel index c = i0 + i1 d0 + i2 d0 d1
-//   1  per-cell counters, one BYTE per cell (four cells to a word), incremented by agent-scope atomics (executed at the memory
-//      side, hence coherent over the eight L2s); the old value hands the point its arrival slot in the voxel
-//   2  (after barrier 2) the counter table is read once, 64-cell segments at a time: per segment the number of points and of
-//      occupied cells in front of it inside the reading wave's stretch (a wave scan), per wave the totals
-//   3  (after barrier 3) a point looks up  points-before / voxels-before  = wave base + segment prefix + the bytes in front of its
-//      cell in its own 64-byte segment; it writes its index to sorted_idx[points-before + slot]
-//   4  (after barrier 4) a point of a voxel with company counts the voxel's indices below its own — its position in the order the
-//      stable sort gave, which is the order the oracle's sum runs in — and puts its coordinates there in `ordered`
-//   5  (after barrier 5) the point that arrived first in a voxel adds the voxel's points up in that order (contiguous, eight loads
-//      in flight) and writes the centroid at voxels-before; every point zeroes its counter word: the table is clean for the next run.
-// No fence anywhere (an agent-scope release writes back the L2's dirty lines, dev.h): everything one block reads of another is
-// written with agent-scope stores (written through) and read with agent-scope loads, behind `s_waitcnt vmcnt(0)` + the barrier.
-// Falls back to the sorted path (status 2 in the mail) when the box has more cells than the table, a voxel holds more than
-// VOXF_MAX_CNT points, or the cloud is larger than the grid's registers; status 3 = a barrier timed out (blocks not co-resident).
-#define VOXF_THREADS 1024           // one block per CU: the grid barrier sees <= 256 arrivals, the CU still runs 16 waves
-#define VOXF_PPT 1
-#define VOXF_BAR_LINES 16             // arrival counters per barrier, one cache line each (same-address atomics serialise at the memory side)
-#define VOXF_MAX_CNT 32
-#define VOXF_SEG_WORDS 16            // 64 cells
-#define VOXF_LEADER_MAX 8u           // voxels of up to this many points are ordered by their leader in registers (phase 5)
-struct VoxFusedArgs {
-  const float4 *pts; int n; float inv_leaf;
-  uint32_t *table; unsigned table_words;      // capacity; a multiple of 512 (one wave iteration of the scan)
-  unsigned long long *prefix;                 // per 32-cell group that holds a point: (points << 32 | voxels) in front of it inside its block's stretch
-  unsigned long long *wtot;                   // per block: the stretch's totals
-  uint32_t *sorted_idx;
-  float4 *ordered;                            // the points of crowded voxels in voxel order, ascending original index inside a voxel
-  long long *stamps;                          // optional (LIO_DEBUG_TIMING): wall clock of block 0 and of the last block at the phase boundaries
-  unsigned *acc;                              // the bounds of the cloud: seven accumulators, VOXF_ACC_STRIDE words apart (mn[3] and mx[3] as
-                                              // order-preserving codes, the count of finite points); reset by the kernel itself
-  unsigned *bar; unsigned target;             // 5 barriers x VOXF_BAR_LINES arrival counters (16 words apart) that only grow; a line is
-                                              // complete for this launch at `target` (the grid is a multiple of VOXF_BAR_LINES blocks)
-  unsigned target0;                           // the same for barrier 0, which only the launches WITHOUT a given box pass
-  int box_given;                              // 1: the box of cells comes with the launch (the union of the boxes this filter has seen, plus a
-  int box_minb[3], box_divb[3];               // margin): no bounds phase, no barrier 0; a point outside it ends the launch with status 4
-  unsigned *abort_flag; int *bail_flag;
-  float4 *out; int *count; VoxParams *params; VoxMail *mail; HostSignal sig;
-  long long timeout_ticks;
-};
-template <typename T> __device__ __forceinline__ void agent_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ T agent_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// all blocks of the grid; false: timed out or another block gave up (the caller leaves).  Every thread's agent-scope stores are
-// acknowledged before its block arrives.
-__device__ __forceinline__ bool voxf_grid_sync(unsigned *ctr, unsigned target, unsigned *abort_flag, long long timeout_ticks) {
-  __shared__ int s_ok;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    // block b arrives on line b mod 16; `target` = arrivals per line once every block of this launch (and of all launches before
-    // it) is in.  The 16 lines are polled by 16 lanes of the block's first wave.
-    const int lane = threadIdx.x;
-    if (lane == 0) __hip_atomic_fetch_add(ctr + (blockIdx.x % VOXF_BAR_LINES) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long t0 = wall_clock64();
-    int ok = 1;
-    for (;;) {
-      const bool in = lane >= VOXF_BAR_LINES || int(agent_load(ctr + lane * 16) - target) >= 0;
-      if (__all(in)) break;
-      if (agent_load(abort_flag) != 0u) { ok = 0; break; }
-      if (wall_clock64() - t0 > timeout_ticks) { if (lane == 0) agent_store(abort_flag, 1u); ok = 0; break; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (lane == 0) s_ok = ok;
-  }
-  __syncthreads();
-  return s_ok != 0;
-}
-__device__ __forceinline__ unsigned voxf_bytes_sum(uint32_t x) { return __builtin_amdgcn_sad_u8(x, 0u, 0u); }
-__device__ __forceinline__ unsigned voxf_bytes_nonzero(uint32_t x) { return __popc((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u); }
-#define VOXF_STAMP(k) do { if (a.stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) a.stamps[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
-// order-preserving code of a float for unsigned atomicMin / atomicMax (the bounds of the cloud are folded at the memory side: one
-// atomic per block and value instead of every block reading every block's partials — 458 k coherent loads of the same 8 KB took
-// 10-25 us in the first form of this kernel)
-__device__ __forceinline__ unsigned voxf_enc(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-__device__ __forceinline__ float voxf_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
-#define VOXF_ACC_STRIDE 16   // words between accumulators (a cache line each)
-#define VOXF_ACC_WAYS 16     // copies of each of the seven accumulators mn[3], mx[3], count: same-address atomics serialise at
-                            // ~27 ns each at the memory side (tools/micro/grid_sync.hip), 256 of them cost a barrier and a half
-
-__global__ void __launch_bounds__(VOXF_THREADS) k_vox_fused(VoxFusedArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int G = int(gridDim.x), nthreads = G * VOXF_THREADS, gid = int(blockIdx.x) * VOXF_THREADS + tid;
-  constexpr int WPB = VOXF_THREADS / 64;   // waves per block
-  const int nwaves = G * WPB, gwave = int(blockIdx.x) * WPB + wv;
-  __shared__ float sred[7][WPB];
-  __shared__ VoxParams svp;
-  __shared__ int s_bail;
-  __shared__ unsigned long long swtot[WPB], sbase[256];   // wave totals of this block; exclusive scan of the blocks' totals (G <= 256)
-  __shared__ unsigned long long s_grand;
-  __shared__ VoxMail smail;
-  VOXF_STAMP(0);
-  // ---- phase 0: the thread's points and the bounds
-  float4 pt[VOXF_PPT];
-  bool fin[VOXF_PPT];
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  float cnt = 0;
-  // (Dealing the points out so that neighbouring lanes do not hit the same 64-byte line of the counter table — the clouds are mostly
-  // concatenations of voxel-ordered stacks — was measured and lost: the count phase got shorter, the gathers and the scattered
-  // list accesses of the later phases cost more than that, profiles/r4_vox_fused_v3_stamps.txt.)
-  int pidx[VOXF_PPT];
-#pragma unroll
-  for (int q = 0; q < VOXF_PPT; ++q) pidx[q] = q * nthreads + gid;
-#pragma unroll
-  for (int q = 0; q < VOXF_PPT; ++q) {
-    const int i = pidx[q];
-    fin[q] = false;
-    pt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < a.n) {
-      pt[q] = a.pts[i];
-      fin[q] = finite3(pt[q]);
-      if (fin[q]) {
-        cnt += 1.f;
-        mn[0] = fminf(mn[0], pt[q].x); mn[1] = fminf(mn[1], pt[q].y); mn[2] = fminf(mn[2], pt[q].z);
-        mx[0] = fmaxf(mx[0], pt[q].x); mx[1] = fmaxf(mx[1], pt[q].y); mx[2] = fmaxf(mx[2], pt[q].z);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
-    cnt += __shfl_xor(cnt, o, 64);
-  }
-  if (lane == 0) { for (int d = 0; d < 3; ++d) { sred[d][wv] = mn[d]; sred[3 + d][wv] = mx[d]; } sred[6][wv] = cnt; }
-  __syncthreads();
-  if (tid < 7) {
-    float v = sred[tid][0];
-    for (int w = 1; w < WPB; ++w) v = tid < 3 ? fminf(v, sred[tid][w]) : (tid < 6 ? fmaxf(v, sred[tid][w]) : v + sred[tid][w]);
-    unsigned *acc = a.acc + (tid * VOXF_ACC_WAYS + int(blockIdx.x) % VOXF_ACC_WAYS) * VOXF_ACC_STRIDE;
-    if (tid < 3) { if (v != FLT_MAX) __hip_atomic_fetch_min(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else if (tid < 6) { if (v != -FLT_MAX) __hip_atomic_fetch_max(acc, voxf_enc(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else if (v > 0.f) __hip_atomic_fetch_add(acc, unsigned(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  VOXF_STAMP(1);
-  if (a.box_given) {
-    // The voxel ORDER does not depend on where the box starts (PCL's index orders the cells by (z, y, x) whatever its minimum), so any
-    // box that holds the cloud gives the same output; the true bounds still go to the accumulators and are read at the very end.
-    if (tid == 0) {
-      VoxParams v{};
-      for (int d = 0; d < 3; ++d) { v.minb[d] = a.box_minb[d]; v.divb[d] = a.box_divb[d]; }
-      svp = v;
-      s_bail = 0;
-    }
-  } else {
-  if (!voxf_grid_sync(a.bar + 0 * VOXF_BAR_LINES * 16, a.target0, a.abort_flag, a.timeout_ticks)) goto aborted;
-  VOXF_STAMP(2);
-  if (tid < 64) {
-    // VoxParams exactly as k_bounds_final forms it (min / max are order-free, the count is an integer): lanes 0..15 fold the copies
-    unsigned e[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      e[k] = lane < VOXF_ACC_WAYS ? agent_load(a.acc + (k * VOXF_ACC_WAYS + lane) * VOXF_ACC_STRIDE) : (k < 3 ? 0xFFFFFFFFu : 0u);
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        const unsigned t = __shfl_xor(e[k], o, 64);
-        e[k] = k < 3 ? min(e[k], t) : (k < 6 ? max(e[k], t) : e[k] + t);
-      }
-    }
-    if (tid == 0) {
-    VoxParams v;
-    long long dd[3];
-    const unsigned total = e[6];
-    for (int d = 0; d < 3; ++d) {
-      const float lo = total ? voxf_dec(e[d]) : FLT_MAX, hi = total ? voxf_dec(e[3 + d]) : -FLT_MAX;
-      v.mn[d] = lo; v.mx[d] = hi;
-      dd[d] = (long long)((hi - lo) * a.inv_leaf) + 1;
-      v.minb[d] = int(floorf(lo * a.inv_leaf));
-      const int maxb = int(floorf(hi * a.inv_leaf));
-      v.divb[d] = maxb - v.minb[d] + 1;
-    }
-    v.overflow = (total > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
-    v.n_valid = int(total);
-    svp = v;
-    const long long cells = total > 0 ? (long long)v.divb[0] * v.divb[1] * v.divb[2] : 0;
-    // the scan reads whole wave iterations (512 words = 2048 cells): the box must fit the table with that rounding
-    s_bail = (v.overflow || total == 0 || v.divb[0] <= 0 || v.divb[1] <= 0 || v.divb[2] <= 0 || (cells + 2047) / 2048 * 512 > (long long)a.table_words) ? 1 : 0;
-    }
-  }
-  }
-  __syncthreads();
-  VOXF_STAMP(12);
-  {
-    const VoxParams vp = svp;
-    bool bail = s_bail != 0;   // uniform over the grid (a function of the folded bounds)
-    // ---- phase 1: counters.  Neighbouring lanes hold neighbouring points, and the clouds are mostly concatenations of voxel-ordered
-    // stacks: runs of lanes whose cells share a counter WORD send ONE atomic (the run's head adds the run's four byte increments at
-    // once; a run is at most 64 long, so no byte carries) and every lane takes its arrival slot from the old word plus the number
-    // of earlier lanes of the run in its own cell.  176 k single atomics on such input took 10-25 us (same-line queueing at the
-    // memory side, tools/micro/grid_sync.hip).
-    static_assert(VOXF_PPT == 1, "the aggregation pairs one point per lane with its neighbours");
-    unsigned cell[VOXF_PPT], slot[VOXF_PPT];
-    int over = 0;
-    {
-      cell[0] = 0xFFFFFFFFu; slot[0] = 0;
-      unsigned c = 0xFFFFFFFFu;
-      if (!bail && fin[0]) {
-        const int i0 = int(floorf(pt[0].x * a.inv_leaf) - float(vp.minb[0]));
-        const int i1 = int(floorf(pt[0].y * a.inv_leaf) - float(vp.minb[1]));
-        const int i2 = int(floorf(pt[0].z * a.inv_leaf) - float(vp.minb[2]));
-        if (a.box_given && (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= vp.divb[0] || i1 >= vp.divb[1] || i2 >= vp.divb[2])) over = 2;
-        else c = unsigned(i0 + i1 * vp.divb[0] + i2 * vp.divb[0] * vp.divb[1]);
-      }
-      const bool valid = c != 0xFFFFFFFFu;
-      cell[0] = c;
-      const unsigned w = valid ? (c >> 2) : (0xFFFFFFFFu - unsigned(lane));   // (an invalid lane matches nobody)
-      const unsigned pw = __shfl_up(w, 1, 64);
-      const bool head = valid && (lane == 0 || pw != w);
-      const unsigned long long hm = __ballot(head);
-      const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-      const int hl = (valid && (hm & le)) ? 63 - __clzll((long long)(hm & le)) : lane;     // the head of this lane's run
-      const unsigned sh = 8u * (c & 3u);
-      const unsigned inc = valid ? (1u << sh) : 0u;
-      unsigned sc = inc;   // inclusive scan of the byte increments inside the run
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(sc, o, 64);
-        if (lane >= o && lane - o >= hl) sc += t;
-      }
-      // the run ends in front of the next head or the next invalid lane
-      const unsigned long long bounds = __ballot(head || !valid);
-      const unsigned long long after = (lane == 63) ? 0ull : (bounds & ~((2ull << lane) - 1ull));
-      const int last = (after ? __ffsll((long long)after) - 1 : 64) - 1;
-      const unsigned total = __shfl(sc, head ? last : lane, 64);
-      unsigned old = 0;
-      if (head) old = __hip_atomic_fetch_add(a.table + w, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      old = __shfl(old, hl, 64);
-      if (valid) {
-        slot[0] = ((old >> sh) & 0xFFu) + (((sc - inc) >> sh) & 0xFFu);
-        if (slot[0] >= VOXF_MAX_CNT) over = over ? over : 1;   // (a byte cannot carry into its neighbour before 255 arrivals; the run is dropped at 32)
-      }
-    }
-    if (a.stamps && tid == 0) a.stamps[32 + blockIdx.x] = wall_clock64();
-    if (over) __hip_atomic_fetch_max(a.bail_flag, over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2 (outside the given box) wins over 1
-    VOXF_STAMP(3);
-    if (!voxf_grid_sync(a.bar + 1 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
-    VOXF_STAMP(4);
-    if (tid == 0) s_bail = bail ? 1 : agent_load(a.bail_flag);   // one reader per block: written before the barrier, read behind it (0, 1 or 2)
-    __syncthreads();
-    const int bail_code = s_bail;
-    bail = bail_code != 0;   // uniform over the grid again
-    // ---- phase 2: one pass over the counters of the box, a lane taking EIGHT words (32 cells) per iteration; a wave keeps the prefixes
-    // of its <= 8 iterations in registers until the block has scanned its waves' totals, so they go out relative to the BLOCK's
-    // stretch (one total per block to exchange) — and only for the 32-cell groups that hold a point: nobody looks the others up
-    const unsigned cells = bail ? 0u : unsigned(vp.divb[0]) * unsigned(vp.divb[1]) * unsigned(vp.divb[2]);
-    const unsigned iters_total = (cells + 2047u) / 2048u;                          // wave iterations of 512 words
-    const unsigned iters_per_wave = (iters_total + unsigned(nwaves) - 1u) / unsigned(nwaves);   // <= 8 (table_words / 512 / nwaves)
-    {
-      unsigned run_p = 0, run_v = 0;
-      const unsigned it0 = unsigned(gwave) * iters_per_wave;
-      const unsigned it_end = min(it0 + min(iters_per_wave, 8u), iters_total);
-      unsigned ep[8], ev[8], pp[8];
-#pragma unroll
-      for (int jb = 0; jb < 8; jb += 4) {   // the loads of four iterations go out together
-        unsigned long long x[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) x[j][k] = 0;
-          if (it0 + jb + j < it_end) {
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.table + size_t(it0 + jb + j) * 512u + unsigned(lane) * 8u);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[j][k] = agent_load(src + k);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ep[jb + j] = 0; ev[jb + j] = 0; pp[jb + j] = 0;
-          if (it0 + jb + j < it_end) {   // wave-uniform
-            unsigned p = 0, v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              p += voxf_bytes_sum(uint32_t(x[j][k])) + voxf_bytes_sum(uint32_t(x[j][k] >> 32));
-              v += voxf_bytes_nonzero(uint32_t(x[j][k])) + voxf_bytes_nonzero(uint32_t(x[j][k] >> 32));
-            }
-            unsigned ip = p, iv = v;   // inclusive scan over the lanes
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const unsigned tp = __shfl_up(ip, o, 64), tv = __shfl_up(iv, o, 64);
-              if (lane >= o) { ip += tp; iv += tv; }
-            }
-            ep[jb + j] = run_p + ip - p; ev[jb + j] = run_v + iv - v; pp[jb + j] = p;
-            run_p += __shfl(ip, 63, 64); run_v += __shfl(iv, 63, 64);
-          }
-        }
-      }
-      if (lane == 0) swtot[wv] = (static_cast<unsigned long long>(run_p) << 32) | run_v;
-      __syncthreads();
-      unsigned long long woff = 0, btot = 0;
-      for (int w = 0; w < WPB; ++w) { if (w < wv) woff += swtot[w]; btot += swtot[w]; }
-      const unsigned op = unsigned(woff >> 32), ov = unsigned(woff);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (it0 + j < it_end && pp[j] != 0u)
-          agent_store(a.prefix + (size_t(it0 + j) * 64u + unsigned(lane)), (static_cast<unsigned long long>(op + ep[j]) << 32) | (ov + ev[j]));
-      if (tid == 0) agent_store(a.wtot + blockIdx.x, btot);
-    }
-    VOXF_STAMP(5);
-    if (!voxf_grid_sync(a.bar + 2 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
-    VOXF_STAMP(6);
-    // ---- phase 3: bases of the blocks' stretches (256 loads per block), then every point's place
-    {
-      unsigned long long v = 0;
-      if (tid < 256) v = (tid < G && !bail) ? agent_load(a.wtot + tid) : 0ull;
-      unsigned long long inc = v;
-      if (tid < 256) {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned lo_ = __shfl_up(unsigned(inc), o, 64), hi_ = __shfl_up(unsigned(inc >> 32), o, 64);
-          if (lane >= o) inc += (static_cast<unsigned long long>(hi_) << 32) | lo_;   // (no carry between the halves: both totals are < 2^32)
-        }
-        if (lane == 63) swtot[wv] = inc;   // waves 0..3
-      }
-      __syncthreads();
-      if (tid < 256) {
-        unsigned long long before = inc - v;
-        for (int w = 0; w < wv; ++w) before += swtot[w];
-        sbase[tid] = before;
-        if (tid == 255) s_grand = before + v;
-      }
-      __syncthreads();
-    }
-    const int n_out = bail ? 0 : int(unsigned(s_grand));   // occupied cells
-    unsigned start[VOXF_PPT], rank[VOXF_PPT], ccount[VOXF_PPT];
-#pragma unroll
-    for (int q = 0; q < VOXF_PPT; ++q) {
-      start[q] = 0; rank[q] = 0; ccount[q] = 0;
-      if (!bail && cell[q] != 0xFFFFFFFFu) {
-        const unsigned c = cell[q], grp = c >> 5, it = c >> 11;
-        const unsigned long long pre = agent_load(a.prefix + grp) + sbase[(it / iters_per_wave) / unsigned(WPB)];
-        unsigned p = unsigned(pre >> 32), v = unsigned(pre);
-        const unsigned wsel = (c >> 2) & 7u, bsel = c & 3u;
-        const unsigned long long *sp = reinterpret_cast<const unsigned long long *>(a.table + size_t(grp) * 8u);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned long long x = agent_load(sp + k);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t wd = h ? uint32_t(x >> 32) : uint32_t(x);
-            const unsigned wi = unsigned(2 * k + h);
-            const uint32_t below = wi < wsel ? wd : (wi == wsel ? (wd & ((1u << (8u * bsel)) - 1u)) : 0u);
-            p += voxf_bytes_sum(below); v += voxf_bytes_nonzero(below);
-            if (wi == wsel) ccount[q] = (wd >> (8u * bsel)) & 0xFFu;
-          }
-        }
-        start[q] = p; rank[q] = v;
-        if (ccount[q] > 1u) agent_store(a.sorted_idx + p + slot[q], uint32_t(pidx[q]));   // a voxel of one point needs no list
-      }
-    }
-    VOXF_STAMP(7);
-    if (a.stamps && tid == 0) a.stamps[32 + 256 + blockIdx.x] = wall_clock64();
-    if (!voxf_grid_sync(a.bar + 3 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
-    VOXF_STAMP(8);
-    // ---- phase 4: a point's position inside its voxel = the voxel's points with a smaller original index (the order the stable
-    // sort gave and the oracle's sum runs in); the points of voxels with company go to `ordered` at that position
-#pragma unroll
-    for (int q = 0; q < VOXF_PPT; ++q) {
-      if (!bail && cell[q] != 0xFFFFFFFFu && ccount[q] > VOXF_LEADER_MAX) {   // (up to VOXF_LEADER_MAX points the leader orders them itself)
-        const uint32_t me = uint32_t(pidx[q]);
-        unsigned r = 0;
-#pragma unroll
-        for (int k = 0; k < VOXF_MAX_CNT; ++k)
-          if (unsigned(k) < ccount[q]) r += (agent_load(a.sorted_idx + start[q] + k) < me) ? 1u : 0u;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.ordered + start[q] + r);
-        agent_store(dst, (static_cast<unsigned long long>(__float_as_uint(pt[q].y)) << 32) | __float_as_uint(pt[q].x));
-        agent_store(dst + 1, (static_cast<unsigned long long>(__float_as_uint(pt[q].w)) << 32) | __float_as_uint(pt[q].z));
-      }
-    }
-    VOXF_STAMP(9);
-    if (a.stamps && tid == 0) a.stamps[32 + 512 + blockIdx.x] = wall_clock64();
-    if (!voxf_grid_sync(a.bar + 4 * VOXF_BAR_LINES * 16, a.target, a.abort_flag, a.timeout_ticks)) goto aborted;
-    VOXF_STAMP(10);
-    // ---- phase 5: centroids by the first arrival of every voxel, eight loads in flight at a time; counters back to zero
-    if (!bail) {
-#pragma unroll
-      for (int q = 0; q < VOXF_PPT; ++q) {
-        const bool leader = cell[q] != 0xFFFFFFFFu && slot[q] == 0;
-        const int m = leader ? int(ccount[q]) : 0;
-        int wmax = m;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o, 64));
-        if (wmax == 0) continue;   // wave-uniform
-        float ax = 0, ay = 0, az = 0, ai = 0;
-        if (m == 1) { ax += pt[q].x; ay += pt[q].y; az += pt[q].z; ai += pt[q].w; }
-        int wsmall = (m > 1 && m <= int(VOXF_LEADER_MAX)) ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wsmall |= __shfl_xor(wsmall, o, 64);
-        if (wsmall) {   // wave-uniform: some leader of the wave has 2 .. 8 points to order itself
-          const bool mine = m > 1 && m <= int(VOXF_LEADER_MAX);
-          uint32_t id[VOXF_LEADER_MAX];
-          float4 pp[VOXF_LEADER_MAX];
-#pragma unroll
-          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) id[k] = (mine && k < m) ? agent_load(a.sorted_idx + start[q] + k) : 0xFFFFFFFFu;
-#pragma unroll
-          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) pp[k] = (mine && k < m) ? a.pts[id[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
-          int rk[VOXF_LEADER_MAX];
-#pragma unroll
-          for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) {
-            int r = 0;
-#pragma unroll
-            for (int j = 0; j < int(VOXF_LEADER_MAX); ++j) r += (id[j] < id[k]) ? 1 : 0;   // distinct indices; the padding ranks last
-            rk[k] = r;
-          }
-#pragma unroll
-          for (int r = 0; r < int(VOXF_LEADER_MAX); ++r) {   // the adds in ascending original index
-            float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < int(VOXF_LEADER_MAX); ++k) if (rk[k] == r) sel = pp[k];
-            if (mine && r < m) { ax += sel.x; ay += sel.y; az += sel.z; ai += sel.w; }
-          }
-        }
-        int wbig = (m > int(VOXF_LEADER_MAX)) ? m : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wbig = max(wbig, __shfl_xor(wbig, o, 64));
-        if (wbig > 0) {
-          const bool big = m > int(VOXF_LEADER_MAX);
-          const unsigned long long *src = reinterpret_cast<const unsigned long long *>(a.ordered + start[q]);
-          for (int k0 = 0; k0 < wbig; k0 += 8) {   // wave-uniform trip count
-            unsigned long long lo[8], hi[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              lo[j] = 0; hi[j] = 0;
-              if (big && k0 + j < m) { lo[j] = agent_load(src + 2 * (k0 + j)); hi[j] = agent_load(src + 2 * (k0 + j) + 1); }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (big && k0 + j < m) {
-                ax += __uint_as_float(uint32_t(lo[j])); ay += __uint_as_float(uint32_t(lo[j] >> 32));
-                az += __uint_as_float(uint32_t(hi[j])); ai += __uint_as_float(uint32_t(hi[j] >> 32));
-              }
-          }
-        }
-        if (leader) { const float c = float(m); a.out[rank[q]] = make_float4(ax / c, ay / c, az / c, ai / c); }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < VOXF_PPT; ++q)
-      if (cell[q] != 0xFFFFFFFFu) a.table[cell[q] >> 2] = 0u;   // plain store: the next launch starts behind this kernel's end
-    VOXF_STAMP(11);
-    if (blockIdx.x == 0) {
-      __shared__ VoxParams s_true;
-      __shared__ int s_status;
-      if (tid == 0) { s_true = vp; s_status = bail ? (bail_code == 2 ? 4 : 2) : 0; }
-      __syncthreads();
-      if (a.box_given && tid < 64) {
-        // the cloud's own bounds for the host (VoxParams exactly as k_bounds_final forms it), from the accumulators every block fed
-        // in phase 0: all of them are in (five barriers ago for the slowest)
-        unsigned e[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          e[k] = lane < VOXF_ACC_WAYS ? agent_load(a.acc + (k * VOXF_ACC_WAYS + lane) * VOXF_ACC_STRIDE) : (k < 3 ? 0xFFFFFFFFu : 0u);
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            const unsigned t = __shfl_xor(e[k], o, 64);
-            e[k] = k < 3 ? min(e[k], t) : (k < 6 ? max(e[k], t) : e[k] + t);
-          }
-        }
-        if (tid == 0) {
-          VoxParams v;
-          long long dd[3];
-          const unsigned total = e[6];
-          for (int d = 0; d < 3; ++d) {
-            const float lo = total ? voxf_dec(e[d]) : FLT_MAX, hi = total ? voxf_dec(e[3 + d]) : -FLT_MAX;
-            v.mn[d] = lo; v.mx[d] = hi;
-            dd[d] = (long long)((hi - lo) * a.inv_leaf) + 1;
-            v.minb[d] = int(floorf(lo * a.inv_leaf));
-            const int maxb = int(floorf(hi * a.inv_leaf));
-            v.divb[d] = maxb - v.minb[d] + 1;
-          }
-          v.overflow = (total > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
-          v.n_valid = int(total);
-          s_true = v;
-          if (total == 0 && s_status == 0) s_status = 2;   // no finite point: the sorted path writes the canonical empty result
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        *a.count = n_out;
-        *a.params = s_true;
-        smail.count = n_out; smail.params = s_true; smail.range_overflow = s_status;
-        if (bail) __hip_atomic_store(a.bail_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody reads it any more in this launch)
-      }
-      __syncthreads();
-      if (tid < 7 * VOXF_ACC_WAYS) a.acc[tid * VOXF_ACC_STRIDE] = tid < 3 * VOXF_ACC_WAYS ? 0xFFFFFFFFu : 0u;   // the bounds' accumulators, ready for the next launch
-      if (a.sig.flag) {
-        __syncthreads();
-        if (tid < 64) post_host_mail(a.sig, a.mail, &smail, int(sizeof(VoxMail) / 4), tid);
-      }
-    }
-    return;
-  }
-aborted:
-  // a barrier timed out: the blocks are not all resident.  Status 3 goes to the host, which clears the table and takes the sorted path.
-  if (blockIdx.x == 0) {
-    if (tid == 0) { smail.count = 0; smail.params = VoxParams(); smail.range_overflow = 3; *a.count = 0; }
-    if (a.sig.flag) {
-      __syncthreads();
-      if (tid < 64) post_host_mail(a.sig, a.mail, &smail, int(sizeof(VoxMail) / 4), tid);
-    }
-  }
-}
-
 void launch_cloud_bounds(const float4 *pts, int n, DBuf<float> &partial, VoxParams *d_out, hipStream_t s) {
   const int nb = std::max(1, std::min(cdiv(n, 256), 512));
   partial.reserve(size_t(nb) * 8);
@@ -828,127 +322,17 @@ bool host_signal_enabled() {
   return on;
 }
 
-// One k_vox_fused at a time per process: its blocks take a whole CU each, so two of them in flight on two streams could each
-// hold half the chip and wait for the other half at their first barrier.  A filter that finds the slot taken uses the sorted path.
-static std::atomic<int> g_vox_fused_inflight{0};
-static std::atomic<long long> g_vox_fused_launched{0}, g_vox_fused_fell_back{0};
-void vox_fused_stats(long long *launched, long long *fell_back) { *launched = g_vox_fused_launched.load(); *fell_back = g_vox_fused_fell_back.load(); }
-
 // launch() enqueues the whole filter on `s` (no host sync); finish() waits for it and returns the output count.  Two
 // filters launched on two streams overlap (the scan-to-map step filters its corner and surf stacks that way).
 void VoxelGridDev::launch(const float4 *in, size_t n, float leaf, DBuf<float4> &out, hipStream_t s) {
   p_in_ = in; p_n_ = n; p_out_ = &out; p_stream_ = s; p_leaf_ = leaf;
   if (n == 0) return;
-  int expect = 0;
-  if (fused_eligible() && g_vox_fused_inflight.compare_exchange_strong(expect, 1)) {
-    fused_slot_ = true;
-    try { enqueue_fused(true); } catch (...) { fused_slot_ = false; g_vox_fused_inflight.store(0); throw; }
-  } else {
-    enqueue(false);
-  }
-}
-
-// LIO_VOX_FUSED=1 turns the one-launch form on (opt-in: measured on the MI355X it takes 47-56 us for 44 k points against ~52 us for
-// the sorted path and 63 against 75 us for 150 k — every phase is one or two round trips to the memory side, where the agent-scope
-// accesses that keep the eight L2s out of the picture are served, and there are nine of them between the five barriers; the solve as
-// a whole gained 1.3-1.5 %, inside the run-to-run spread.  profiles/r4_vox_fused_*_stamps.txt, profiles/r4_grid_sync_micro.txt.)
-static std::atomic<int> g_vox_fused_override{-1};   // lio_vox_fused_set: -1 = the environment decides, 0 / 1 = off / on
-int vox_fused_set(int on) { return g_vox_fused_override.exchange(on < 0 ? -1 : (on ? 1 : 0)); }
-static bool vox_fused_enabled() {
-  static const bool env_on = [] { const char *e = std::getenv("LIO_VOX_FUSED"); return e ? std::atoi(e) != 0 : false; }();
-  const int o = g_vox_fused_override.load(std::memory_order_relaxed);
-  return o < 0 ? env_on : o != 0;
-}
-// blocks of k_vox_fused the device keeps resident at once (a multiple of VOXF_BAR_LINES, at most one per CU up to 256)
-static int vox_fused_grid() {
-  static const int g = [] {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_vox_fused, VOXF_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const int blocks = std::min(256, cus * std::min(per_cu, 1));
-    return blocks / VOXF_BAR_LINES * VOXF_BAR_LINES;
-  }();
-  return g;
-}
-#define VOXF_TABLE_WORDS (16u << 20)   // 64 M cells (the headline's local map: 240 x 240 x 34 m at a 0.4 m leaf = 30 M), 64 MB, zero between runs
-
-bool VoxelGridDev::fused_eligible() const {
-  if (!vox_fused_enabled() || fused_off_ || !(use_signal_ && host_signal_enabled())) return false;
-  const int g = vox_fused_grid();
-  return g >= VOXF_BAR_LINES && p_n_ <= size_t(g) * VOXF_THREADS * VOXF_PPT;
-}
-
-// the bounds accumulators as a launch expects them (the kernel leaves them like this; needed once, and after an aborted launch)
-void VoxelGridDev::reset_fused_acc(hipStream_t s) {
-  static unsigned init[7 * VOXF_ACC_WAYS * VOXF_ACC_STRIDE];
-  for (unsigned &v : init) v = 0u;
-  for (int k = 0; k < 3 * VOXF_ACC_WAYS; ++k) init[k * VOXF_ACC_STRIDE] = 0xFFFFFFFFu;
-  LIO_HIP(hipMemcpyAsync(f_acc_.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-  LIO_HIP(hipStreamSynchronize(s));   // `init` is on the stack
-}
-
-// the one-launch form (k_vox_fused); finish() falls back to enqueue(false) when the kernel reports that it could not run
-void VoxelGridDev::enqueue_fused(bool with_box) {
-  hipStream_t s = p_stream_;
-  const int g = vox_fused_grid();
-  if (!f_table_.p) {
-    f_table_.reserve(VOXF_TABLE_WORDS);
-    LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), s));
-    f_prefix_.reserve(VOXF_TABLE_WORDS / 8);   // one entry per 32-cell group (written only where a point is)
-    f_wtot_.reserve(256);
-    f_acc_.reserve(7 * VOXF_ACC_WAYS * VOXF_ACC_STRIDE);
-    reset_fused_acc(s);
-    f_bar_.reserve(5 * VOXF_BAR_LINES * 16 + 32);   // the barrier lines, then the abort flag and the bail flag (a line each)
-    LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), s));
-    f_epoch_ = 0; f_epoch0_ = 0;
-  }
-  f_sorted_.reserve(p_n_); f_ordered_.reserve(p_n_);
-  static const bool dbg_stamps = std::getenv("LIO_DEBUG_TIMING") != nullptr;
-  if (dbg_stamps && !f_stamps_.p) { f_stamps_.reserve(32 + 768); LIO_HIP(hipMemsetAsync(f_stamps_.p, 0, (32 + 768) * sizeof(long long), s)); }
-  params_.reserve(1);
-  if (count_.cap < 2) { count_.reserve(2); LIO_HIP(hipMemsetAsync(count_.p, 0, count_.cap * sizeof(int), s)); }
-  p_out_->reserve(p_n_);
-  if (!h_count_) {
-    LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_count_), 256, hipHostMallocCoherent));
-    std::memset(h_count_, 0, 256);
-    h_params_ = reinterpret_cast<VoxParams *>(h_count_ + 1);
-    h_flag_ = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h_count_) + 128);
-  }
-  ++f_epoch_;
-  VoxFusedArgs a{};
-  // The box of cells: the union of the boxes this filter has seen at this leaf, a few cells wider — the clouds of one caller move
-  // slowly — unless that is not known yet, does not fit the table or was just found too small (finish(): status 4).
-  a.box_given = 0;
-  if (with_box && spec_valid_ && spec_leaf_ == p_leaf_) {
-    long long cells = 1;
-    for (int d = 0; d < 3; ++d) { a.box_minb[d] = spec_lo_[d] - 4; a.box_divb[d] = spec_hi_[d] - spec_lo_[d] + 1 + 8; cells *= a.box_divb[d]; }
-    if ((cells + 2047) / 2048 * 512 <= (long long)VOXF_TABLE_WORDS) a.box_given = 1;
-  }
-  if (!a.box_given) ++f_epoch0_;
-  fused_with_box_ = a.box_given != 0;
-  a.pts = p_in_; a.n = int(p_n_); a.inv_leaf = 1.0f / p_leaf_;
-  a.table = f_table_.p; a.table_words = VOXF_TABLE_WORDS;
-  a.prefix = f_prefix_.p; a.wtot = f_wtot_.p; a.sorted_idx = f_sorted_.p; a.ordered = f_ordered_.p; a.stamps = f_stamps_.p; a.acc = f_acc_.p;
-  a.bar = f_bar_.p; a.target = f_epoch_ * unsigned(g / VOXF_BAR_LINES); a.target0 = f_epoch0_ * unsigned(g / VOXF_BAR_LINES);
-  a.abort_flag = f_bar_.p + 5 * VOXF_BAR_LINES * 16; a.bail_flag = reinterpret_cast<int *>(f_bar_.p + 5 * VOXF_BAR_LINES * 16 + 16);
-  a.out = p_out_->p; a.count = count_.p; a.params = params_.p; a.mail = reinterpret_cast<VoxMail *>(h_count_);
-  sig_ = HostSignal();
-  sig_.flag = h_flag_; sig_.seq = ++seq_;
-  a.sig = sig_;
-  int khz = 0, dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
-  a.timeout_ticks = (long long)(0.05 * 1e3 * khz);   // 50 ms at a barrier: the blocks are not all resident
-  hipLaunchKernelGGL(k_vox_fused, dim3(g), dim3(VOXF_THREADS), 0, s, a);
-  LIO_HIP(hipGetLastError());
-  fused_pending_ = true;
-  g_vox_fused_launched.fetch_add(1);
+  enqueue(false);
 }
 
 // exact == false: absolute-cell keys, bounds folded on the side (4 stages: keys, sort, tile heads, centroids);
 // exact == true: PCL's own index from the bounds (two more launches in front), used when the cloud leaves the key's range.
 void VoxelGridDev::enqueue(bool exact) {
-  fused_pending_ = false;
   const float4 *in = p_in_;
   const size_t n = p_n_;
   DBuf<float4> &out = *p_out_;
@@ -983,19 +367,9 @@ void VoxelGridDev::enqueue(bool exact) {
     npartial = nkb;
   }
   size_t tmp_bytes = 0;
-  // LIO_VOX_SORT=onesweep: the library's radix form (histograms + four 8-bit passes) instead of the block sort + merges it picks
-  // below a million keys — an A/B switch; the result is the same stable order either way
-  static const bool onesweep = [] { const char *e = std::getenv("LIO_VOX_SORT"); return e && std::string(e) == "onesweep"; }();
-  using OnesweepCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
-  if (onesweep) {
-    LIO_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-    tmp_.reserve(tmp_bytes + 256);
-    LIO_HIP(rocprim::radix_sort_pairs<OnesweepCfg>(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-  } else {
-    LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-    tmp_.reserve(tmp_bytes + 256);
-    LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
-  }
+  LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
+  tmp_.reserve(tmp_bytes + 256);
+  LIO_HIP(rocprim::radix_sort_pairs(tmp_.p, tmp_bytes, keys_.p, keys2_.p, vals_.p, vals2_.p, n, 0, 32, s));
   const int ntiles = cdiv(ni, VOX_TILE);
   tile_heads_.reserve(ntiles);
   hipLaunchKernelGGL(k_vox_tile_heads, dim3(ntiles + 1), dim3(VOX_TILE), 0, s, keys2_.p, ni, tile_heads_.p, partial_.p, npartial, inv_leaf, params_.p);
@@ -1019,82 +393,13 @@ size_t VoxelGridDev::finish(VoxParams *host_params) {
     return 0;
   }
   const VoxMail *m = reinterpret_cast<const VoxMail *>(h_count_);
-  struct SlotRelease { bool &held; ~SlotRelease() { if (held) { held = false; g_vox_fused_inflight.store(0); } } } slot_release{fused_slot_};
-  bool redone = false, exact_done = false;
+  bool redone = false;
   for (;;) {
     if (sig_.flag) wait_host_signal(sig_, p_stream_);   // the count is out; the centroids follow in stream order
     else LIO_HIP(hipStreamSynchronize(p_stream_));
-    const int status = m->range_overflow;
-    if (fused_pending_ && f_stamps_.p && status == 0) {   // LIO_DEBUG_TIMING: the phase boundaries of block 0 and of the last block
-      static int seen = 0, printed = 0;
-      ++seen;
-      if ((seen <= 3 || seen % 97 == 0) && printed < 12) {   // the first launches and a sample of the steady state
-        ++printed;
-        long long st[32];
-        LIO_HIP(hipStreamSynchronize(p_stream_));
-        LIO_HIP(hipMemcpy(st, f_stamps_.p, sizeof(st), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[lio_hip timing] k_vox_fused n %zu%s, 10 ns ticks from the first block's start (block 0 | last block): ", p_n_, fused_with_box_ ? " (box given)" : "");
-        static const char *nm[12] = {"start", "bounds", "B1", "count", "B2", "scan", "B3", "place", "B4", "order", "B5", "centroids+clean"};
-        for (int k = 0; k < 12; ++k) std::fprintf(stderr, "%s %lld|%lld  ", nm[k], st[k] - st[0], st[16 + k] - st[0]);
-        std::fprintf(stderr, "(box known %lld|%lld)", st[12] - st[0], st[16 + 12] - st[0]);
-        std::fprintf(stderr, "\n");
-        {   // where the slowest block of a phase sits: end of count / place / order per block
-          static long long blk[768];
-          LIO_HIP(hipMemcpy(blk, f_stamps_.p + 32, sizeof(blk), hipMemcpyDeviceToHost));
-          const int g = vox_fused_grid();
-          const char *ph[3] = {"count", "place", "order"};
-          for (int q = 0; q < 3; ++q) {
-            int arg = 0; long long mx = -1, sum = 0;
-            for (int b = 0; b < g; ++b) { const long long v = blk[q * 256 + b] - st[0]; sum += v; if (v > mx) { mx = v; arg = b; } }
-            std::fprintf(stderr, "[lio_hip timing]   %s done: mean %lld, slowest block %d at %lld; blocks 0/32/64/96/128/160/192/224: %lld %lld %lld %lld %lld %lld %lld %lld\n", ph[q], sum / g, arg, mx,
-                         blk[q * 256 + 0] - st[0], blk[q * 256 + 32] - st[0], blk[q * 256 + 64] - st[0], blk[q * 256 + 96] - st[0], blk[q * 256 + 128] - st[0],
-                         blk[q * 256 + 160] - st[0], blk[q * 256 + 192] - st[0], blk[q * 256 + 224] - st[0]);
-          }
-        }
-      }
-    }
-    // posted = past its last barrier: the slot is free for other filters — unless this one is about to launch again (status 4) or
-    // has to drain first (3); the guard above releases it on the way out then
-    if (fused_slot_ && status != 3 && status != 4) { fused_slot_ = false; g_vox_fused_inflight.store(0); }
-    if (fused_pending_ && status == 4) {
-      // a point lay outside the box that came with the launch: once more, the bounds taken inside the kernel this time (the union
-      // of the boxes seen so far stays and takes this cloud's box in when that launch reports)
-      ++fused_reboxed_;
-      enqueue_fused(false);
-      redone = true;
-      continue;
-    }
-    if (fused_pending_ && status == 0) {
-      // the box for the next launch: the union with what this cloud occupied (reset when the leaf changes)
-      const VoxParams &vp = m->params;
-      if (!spec_valid_ || spec_leaf_ != p_leaf_) {
-        for (int d = 0; d < 3; ++d) { spec_lo_[d] = vp.minb[d]; spec_hi_[d] = vp.minb[d] + vp.divb[d] - 1; }
-        spec_valid_ = true; spec_leaf_ = p_leaf_;
-      } else {
-        for (int d = 0; d < 3; ++d) { spec_lo_[d] = std::min(spec_lo_[d], vp.minb[d]); spec_hi_[d] = std::max(spec_hi_[d], vp.minb[d] + vp.divb[d] - 1); }
-      }
-    }
-    if (fused_pending_ && (status == 2 || status == 3)) {
-      // the one-launch form could not run (2: box larger than the counter table, a crowded voxel, no finite point; 3: a grid
-      // barrier timed out): the sorted path takes the filter
-      if (status == 3) {
-        LIO_HIP(hipStreamSynchronize(p_stream_));
-        LIO_HIP(hipMemsetAsync(f_table_.p, 0, size_t(VOXF_TABLE_WORDS) * sizeof(uint32_t), p_stream_));
-        LIO_HIP(hipMemsetAsync(f_bar_.p, 0, f_bar_.cap * sizeof(unsigned), p_stream_));
-        reset_fused_acc(p_stream_);
-        f_epoch_ = 0; f_epoch0_ = 0;
-        fused_off_ = true;
-        std::fprintf(stderr, "[lio_hip] VoxelGrid: the one-launch form timed out at a grid barrier (blocks not co-resident); this filter takes the sorted path from now on\n");
-      }
-      ++fused_fallbacks_;
-      g_vox_fused_fell_back.fetch_add(1);
-      enqueue(false);
-      redone = true;
-      continue;
-    }
-    if (status == 1 && !exact_done) {
+    if (m->range_overflow == 1 && !redone) {
       enqueue(true);   // the cloud spans more cells than the absolute key holds
-      exact_done = true; redone = true;
+      redone = true;
       continue;
     }
     // cold path: a second pass was enqueued AFTER launch() returned, i.e. after the caller may have recorded the event other
@@ -1120,7 +425,6 @@ size_t VoxelGridDev::run(const float4 *in, size_t n, float leaf, DBuf<float4> &o
 }
 
 VoxelGridDev::~VoxelGridDev() {
-  if (fused_slot_) { fused_slot_ = false; g_vox_fused_inflight.store(0); }
   if (h_count_) (void)hipHostFree(h_count_);
 }
 
@@ -1505,29 +809,24 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
 // (the fit used to occupy one lane in LPQ of every wave while costing all of its issue slots — these kernels are bound by
 // vector-instruction issue, not by memory).
 #define FEAT_THREADS 256
-// One (frame, block) share of CalculateFeatures by FEAT_THREADS lanes.  SUBS > 1: the calling block is SUBS x FEAT_THREADS wide and its
-// SUBS quarters take the blocks SUBS * block_x + 0 .. SUBS - 1 (the 1024-thread launch that rides behind the rounds' update block).
-template <bool MAPPING, int LPQ, int SUBS>
+template <bool MAPPING, int LPQ>
 __device__ __forceinline__ void features_block(const FeatArgs &a, int frame, int block_x, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
                                                float4 *__restrict__ coef, float *__restrict__ score, float4 *__restrict__ abs_coef) {
   constexpr int QPB = FEAT_THREADS / LPQ;
   static_assert(QPB <= 64, "the fit phase is one wave");
-  __shared__ int s_bj[SUBS][QPB][5];
-  __shared__ float s_bd4[SUBS][QPB];
-  __shared__ int s_bi4[SUBS][QPB];
-  const int sb = SUBS > 1 ? int(threadIdx.x) / FEAT_THREADS : 0, lt = SUBS > 1 ? int(threadIdx.x) % FEAT_THREADS : int(threadIdx.x);
-  const int blk = block_x * SUBS + sb;
+  __shared__ int s_bj[QPB][5];
+  __shared__ float s_bd4[QPB];
+  __shared__ int s_bi4[QPB];
   const FeatFrame fr = a.fr[frame];
-  const bool blk_active = blk * QPB < fr.M;
-  if (SUBS == 1 && !blk_active) return;
+  if (block_x * QPB >= fr.M) return;
   const FeatScalars fs = feat_scalars(a);
   const float *tp = transforms + 8 * fr.tf_index;
   const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   const Vec3<float> t(tp[4], tp[5], tp[6]);
-  if (blk_active) {
-    const int ql = lt / LPQ, sub = lt % LPQ;
-    const int i = blk * QPB + ql;
+  {
+    const int ql = int(threadIdx.x) / LPQ, sub = int(threadIdx.x) % LPQ;
+    const int i = block_x * QPB + ql;
     const bool active = i < fr.M;
     const float4 po = active ? fr.stack[i] : make_float4(0, 0, 0, 0);
     const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
@@ -1536,20 +835,20 @@ __device__ __forceinline__ void features_block(const FeatArgs &a, int frame, int
     knn_scan_group<5, LPQ>(sel, active, sub, map, cells, g, bd, bi, bj);
     if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) s_bj[sb][ql][k] = bj[k];
-      s_bd4[sb][ql] = bd[4]; s_bi4[sb][ql] = bi[4];
+      for (int k = 0; k < 5; ++k) s_bj[ql][k] = bj[k];
+      s_bd4[ql] = bd[4]; s_bi4[ql] = bi[4];
     }
   }
   __syncthreads();
-  const int ql = lt, i = blk * QPB + ql;
-  if (!blk_active || ql >= QPB || i >= fr.M) return;
+  const int ql = threadIdx.x, i = block_x * QPB + ql;
+  if (ql >= QPB || i >= fr.M) return;
   const float4 po = fr.stack[i];
   const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
   const Vec3<float> sel(r.x + t.x, r.y + t.y, r.z + t.z);
   int bj[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) bj[k] = s_bj[sb][ql][k];
-  const FeatResult res = features_fit<MAPPING>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[sb][ql], s_bi4[sb][ql], bj, map);
+  for (int k = 0; k < 5; ++k) bj[k] = s_bj[ql][k];
+  const FeatResult res = features_fit<MAPPING>(fs, fr.slot_off + i, q, t, po, sel, s_bd4[ql], s_bi4[ql], bj, map);
   valid[res.slot] = res.ok; coef[res.slot] = res.c;
   if (score) score[res.slot] = res.sc;
   if (MAPPING && abs_coef && res.ok) abs_coef[res.slot] = res.abs;
@@ -1561,7 +860,7 @@ __global__ void __launch_bounds__(FEAT_THREADS) k_features(FeatArgs a, const flo
                                                           float4 *__restrict__ coef, float *__restrict__ score, const int *__restrict__ skip_flag,
                                                           float4 *__restrict__ abs_coef) {
   if (skip_flag && *skip_flag) return;
-  features_block<MAPPING, LPQ, 1>(a, int(blockIdx.y), int(blockIdx.x), transforms, map, cells, g, valid, coef, score, abs_coef);
+  features_block<MAPPING, LPQ>(a, int(blockIdx.y), int(blockIdx.x), transforms, map, cells, g, valid, coef, score, abs_coef);
 }
 
 // Corner branch of the scan-to-map step: one query per FEAT_LPQ lanes, 5-NN, covariance of the 5 neighbours, line
@@ -1941,136 +1240,6 @@ __global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_round(FeatArgs a, c
   if (threadIdx.x < 28) partials[size_t(blockIdx.x) * 28 + threadIdx.x] = v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// All rounds of the newest frame's loop in ONE launch.  Grid = the search blocks of k_odom_round + one update
-// block.  A round: every search block computes its 28 sums at the current transform, parks them in HBM (agent-scope stores,
-// acknowledged) and raises its flag to the round's number; the update block waits for all flags, folds the partials in
-// k_odom_update_wide's order, takes the 6x6 step on its copy of the state, republishes the state and then the round number the
-// search blocks are waiting for.  After convergence or the last round the update block posts the state to the host's mailbox.
-// No atomics, no fences: flags and data travel as agent-scope stores / loads, the writer waits for its data to be acknowledged
-// before it raises the flag.  Every waiter gives up after `timeout_ticks` of the wall clock (a dead peer must not hang the GPU).
-struct OdomRoundsCtl {
-  double *partials;          // nb x 28
-  unsigned *block_flag;      // nb
-  unsigned *state_seq;       // 1: number of the round whose INPUT state is published
-  unsigned seq0;             // number of round 0 of this launch (monotonic over the life of the handle)
-  int max_rounds;
-  long long timeout_ticks;
-  long long *stamps;         // optional (LIO_DEBUG_TIMING): wall clock of the update block at its start, [1 + 2 r] all flags of round r in, [2 + 2 r] state republished
-};
-template <int LPQ>
-__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_odom_rounds_resident(FeatArgs a, OdomState *st, const float4 *__restrict__ map, const int *__restrict__ cells,
-                                                                            GridDesc g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
-                                                                            float *__restrict__ score, int base_slot, int keep, OdomRoundsCtl ctl, OdomState *mail,
-                                                                            HostSignal sig) {
-  const int nb = int(gridDim.x) - 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  __shared__ OdomState s_st;
-  __shared__ int s_go;
-  unsigned *su = reinterpret_cast<unsigned *>(&s_st);
-  constexpr int NW = int(sizeof(OdomState) / 4);
-  if (int(blockIdx.x) < nb) {
-    // ---------------- search block
-    for (int round = 0; round < ctl.max_rounds; ++round) {
-      const unsigned seq = ctl.seq0 + unsigned(round);
-      if (tid < 64) {
-        int ok = 1;
-        if (round > 0) {   // round 0's state was uploaded in front of the launch
-          const long long t0 = wall_clock64();
-          while (__hip_atomic_load(ctl.state_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-            if (wall_clock64() - t0 > ctl.timeout_ticks) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        if (lane < NW) su[lane] = __hip_atomic_load(reinterpret_cast<unsigned *>(st) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) s_go = ok;
-      }
-      __syncthreads();
-      if (!s_go || s_st.converged) return;
-      const Quat<float> q(s_st.T[3], s_st.T[0], s_st.T[1], s_st.T[2]);
-      const Vec3<float> t(s_st.T[4], s_st.T[5], s_st.T[6]);
-      const double v = odom_round_block<LPQ>(a, a.fr[0], q, t, map, cells, g, valid, coef, score, base_slot, round, keep, int(blockIdx.x));
-      if (tid < 64) {
-        if (tid < 28) __hip_atomic_store(ctl.partials + size_t(blockIdx.x) * 28 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) __hip_atomic_store(ctl.block_flag + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();   // the next round overwrites s_st and the LDS tables of odom_round_block
-    }
-    return;
-  }
-  // ---------------- update block
-  __shared__ double part[32][32];
-  __shared__ double ssum[28];
-  if (tid < NW) su[tid] = reinterpret_cast<const unsigned *>(st)[tid];   // uploaded in front of the launch
-  if (ctl.stamps && tid == 0) ctl.stamps[0] = wall_clock64();
-  __syncthreads();
-  int round = 0;
-  for (; round < ctl.max_rounds && !s_st.converged; ++round) {
-    const unsigned seq = ctl.seq0 + unsigned(round);
-    if (tid < 64) {
-      const long long t0 = wall_clock64();
-      int ok = 1;
-      for (;;) {
-        bool all = true;
-        for (int b0 = 0; b0 < nb; b0 += 64) {
-          const int b = b0 + lane;
-          const unsigned f = b < nb ? __hip_atomic_load(ctl.block_flag + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
-          all = all && __all(f == seq);
-        }
-        if (all) break;
-        if (wall_clock64() - t0 > ctl.timeout_ticks) { ok = 0; break; }
-      }
-      if (lane == 0) s_go = ok;
-    }
-    __syncthreads();
-    if (!s_go) break;
-    if (ctl.stamps && tid == 0) ctl.stamps[1 + 2 * round] = wall_clock64();
-    // fold in k_odom_update_wide's order: 32 groups g of rows b = g, g + 32, ..., each as four interleaved chains combined
-    // (v0 + v1) + (v2 + v3), then the group sums in ascending g.  256 threads stand in for its 1024: thread (c, g0) takes the
-    // groups g0, g0 + 8, g0 + 16, g0 + 24 one after the other.
-    {
-      const int c = tid & 31, g0 = tid >> 5;
-      for (int gq = g0; gq < 32; gq += 8) {
-        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        if (c < 28) {
-          int b = gq;
-          for (; b + 96 < nb; b += 128) {
-            const double x0 = __hip_atomic_load(ctl.partials + size_t(b) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double x1 = __hip_atomic_load(ctl.partials + size_t(b + 32) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double x2 = __hip_atomic_load(ctl.partials + size_t(b + 64) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double x3 = __hip_atomic_load(ctl.partials + size_t(b + 96) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v0 += x0; v1 += x1; v2 += x2; v3 += x3;
-          }
-          for (; b < nb; b += 32) v0 += __hip_atomic_load(ctl.partials + size_t(b) * 28 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        part[gq][c] = (v0 + v1) + (v2 + v3);
-      }
-    }
-    __syncthreads();
-    if (tid < 28) {
-      double s2 = 0;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) s2 += part[k][tid];
-      ssum[tid] = s2;
-    }
-    __syncthreads();
-    odom_update_from_sums(ssum, &s_st, round, 0, 0);   // thread 0, on the LDS copy
-    __syncthreads();
-    // republish: the state first, acknowledged, then the number of the round that may start from it
-    if (tid < 64) {
-      if (lane < NW) __hip_atomic_store(reinterpret_cast<unsigned *>(st) + lane, su[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(ctl.state_seq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ctl.stamps && lane == 0) ctl.stamps[2 + 2 * round] = wall_clock64();
-    }
-    __syncthreads();
-  }
-  // the loop ended by convergence, by the round limit or by a timeout: release waiting search blocks (a converged / final state is
-  // already published; after a timeout nothing more can be done for them: they give up on their own), then tell the host
-  if (sig.flag && tid < 64) post_host_mail(sig, mail, &s_st, NW, tid);
-}
-
 // fold of `nblocks` 28-double partials by a 1024-thread block (32 groups of rows b = g mod 32, ascending, then the group sums
 // ascending), followed by the update of odom_update_body
 // mail: a copy of the state in coherent pinned host memory, posted with the round's sequence number after every round (also
@@ -2130,23 +1299,6 @@ __global__ void __launch_bounds__(1024) k_odom_update_wide(const double *__restr
                                                            int left_update, OdomState *mail, HostSignal sig) {
   odom_update_wide_block(partials, nblocks, st, iter, min_rows, left_update, mail, sig);
 }
-// The update block with a share of the older frames' features riding in the same launch (round 4).  The update is ONE block: for its
-// 12 us the chip is idle (kernel trace, profiles/r4_solve_timeline.md), while the batched k_features on a side stream used to run
-// beside round 0's search kernel and slowed it from 19 to 37 us (both are bound by vector issue).  Block 0 is the update; the blocks
-// behind it are 1024 threads wide and take four 256-lane feature blocks each (features_block<.., 4>), a frame's blocks contiguous.
-// No second stream, no fork / join events (an event between two kernels of a stream costs a 7 us bubble).  Same results: the
-// features do not depend on the split, and they finish before the launch does, i.e. before anything later on the stream.
-template <int LPQ>
-__global__ void __launch_bounds__(1024) k_odom_update_with_features(const double *__restrict__ partials, int nblocks, OdomState *st, int iter, int min_rows,
-                                                                    int left_update, OdomState *mail, HostSignal sig, FeatArgs af,
-                                                                    const float *__restrict__ transforms, const float4 *__restrict__ map,
-                                                                    const int *__restrict__ cells, GridDesc g, uint8_t *__restrict__ valid,
-                                                                    float4 *__restrict__ coef, float *__restrict__ score, int fblocks) {
-  if (blockIdx.x == 0) { odom_update_wide_block(partials, nblocks, st, iter, min_rows, left_update, mail, sig); return; }
-  const int fb = int(blockIdx.x) - 1;
-  features_block<false, LPQ, 4>(af, fb / fblocks, fb % fblocks, transforms, map, cells, g, valid, coef, score, nullptr);
-}
-
 __global__ void __launch_bounds__(256) k_solve_setup(SolveSetup a, float *__restrict__ d_transforms, OdomState *__restrict__ d_odom, uint8_t *__restrict__ valid,
                                                      size_t n_valid) {
   const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 16;
@@ -2169,38 +1321,15 @@ void launch_solve_setup(const SolveSetup &a, float *d_transforms, OdomState *d_o
 }
 
 int odom_round_blocks(int M, int lpq) { return std::max(1, cdiv((long long)M * lpq, ODOM_ROUND_THREADS)); }
-void launch_odom_rounds_resident(const FeatArgs &a, int base_slot, int keep, int max_rounds, OdomState *st, const float4 *map_sorted, const int *cells,
-                                 const GridDesc &g, uint8_t *valid, float4 *coef, float *score, double *partials, unsigned *block_flag, unsigned *state_seq,
-                                 unsigned seq0, long long timeout_ticks, hipStream_t s, OdomState *mail, const HostSignal &sig, long long *stamps, int lpq) {
-  const int M = a.fr[0].M;
-  if (M <= 0) return;
-  const int nb = odom_round_blocks(M, lpq);
-  OdomRoundsCtl ctl{partials, block_flag, state_seq, seq0, max_rounds, timeout_ticks, stamps};
-  if (lpq == 4)
-    hipLaunchKernelGGL(k_odom_rounds_resident<4>, dim3(nb + 1), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, base_slot, keep, ctl,
-                       mail, sig);
-  else
-  hipLaunchKernelGGL(k_odom_rounds_resident<8>, dim3(nb + 1), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, base_slot, keep, ctl,
-                     mail, sig);
-  LIO_HIP(hipGetLastError());
-}
 void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, OdomState *st, const float4 *map_sorted, const int *cells, const GridDesc &g,
-                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq,
-                       hipEvent_t after_search, const FeatArgs *ride, const float *transforms) {
+                       uint8_t *valid, float4 *coef, float *score, double *partials, hipStream_t s, OdomState *mail, const HostSignal &sig, int lpq) {
   const int M = a.fr[0].M;
   if (M <= 0) return;
   const int nb = odom_round_blocks(M, lpq);
   if (lpq == 4)
     hipLaunchKernelGGL(k_odom_round<4>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   else
-  hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
-  if (after_search) LIO_HIP(hipEventRecord(after_search, s));   // the one-block update kernel behind it leaves the chip idle: work of another stream can start here
-  if (ride && ride->nframes > 0 && ride->max_M > 0 && !ride->mapping_mode) {
-    // the older frames' share of this round rides with the update block: four lanes per query, 64 queries per 256-lane quarter
-    const int fblocks = cdiv(cdiv((long long)ride->max_M * 4, FEAT_THREADS), 4);
-    hipLaunchKernelGGL(k_odom_update_with_features<4>, dim3(1 + fblocks * ride->nframes), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig, *ride,
-                       transforms, map_sorted, cells, g, valid, coef, score, fblocks);
-  } else
+    hipLaunchKernelGGL(k_odom_round<8>, dim3(nb), dim3(ODOM_ROUND_THREADS), 0, s, a, st, map_sorted, cells, g, valid, coef, score, partials, base_slot, round, keep);
   hipLaunchKernelGGL(k_odom_update_wide, dim3(1), dim3(1024), 0, s, partials, nb, st, round, 0, 0, mail, sig);
   LIO_HIP(hipGetLastError());
 }

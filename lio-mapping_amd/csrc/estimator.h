@@ -35,9 +35,8 @@ struct EstConfig {
   int extrinsic_stage = 2;
   int init_window_factor = 3;
   // execution switches (lio_est_config's trailing block; environment overrides are applied in the constructor)
-  bool device_solve = false, device_marg = false, inline_marg = false, stream_sync = false, moments_fold_in_kernel = false;
+  bool device_solve = false, device_marg = false, inline_marg = false, stream_sync = false;
   int moments_form = 0, resident_moments = 0;
-  bool resident_rounds = false;
 };
 
 struct DeviceCloud {
@@ -244,10 +243,6 @@ class Estimator {
 
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-  hipEvent_t ev_round_[3] = {nullptr, nullptr, nullptr};   // behind the search kernel of the first three newest-frame rounds (staged features)
-  bool stage_features_ = false, stage_features_now_ = false;   // LIO_STAGE_FEATURES=1: the older frames' features in three launches behind the first rounds' search kernels (measured slower)
-  bool ride_features_ = false, ride_features_now_ = false;    // LIO_RIDE_FEATURES=1: the older frames' features in the launches of the first three rounds' update blocks (measured slower)
-  FeatArgs staged_fa_{};
   std::vector<DeviceCloud> stacks_;
   std::vector<size_t> size_surf_stack_;
   std::vector<StampedPose> imu_stamped_;
@@ -263,8 +258,6 @@ class Estimator {
   DBuf<float> d_transforms_;
   DBuf<OdomState> d_odom_;
   DBuf<double> d_odom_partials_, d_moment_partials_, d_moment_out_;
-  DBuf<int> d_moment_tickets_;
-  bool fold_in_kernel_ = false;
   int moments_form_ = 0;            // 0 by launch size, 1 MFMA, 2 VALU
   // Resident moments (solve_kernels.h): one launch per solve; every linearisation is a doorbell write + a spin on
   // the blocks' completion words.  Begun lazily by the first LidarLaunch of a SolveOptimization, stopped when it returns.
@@ -285,13 +278,6 @@ class Estimator {
   double res_busy_us_ = 0, res_bytes_ = 0; int res_passes_ = 0, res_passes_total_ = 0;   // device-side busy time of the passes (doorbell copy seen -> sums posted), SURVEY 8(d) bytes
   MomentArgs res_args_{};
   DBuf<double> d_res_relay_, d_res_part_;   // HBM: the doorbell as republished by the relay block; the per-block records
-  // The newest frame's rounds as one launch (cloud_kernels.h: launch_odom_rounds_resident): lio_est_config.resident_rounds /
-  // LIO_RESIDENT_ROUNDS=1.  Opt-in: measured at 30 us per round against 32 for a launch pair per round.
-  static constexpr int kOdomResidentMaxBlocks = 512;
-  bool resident_rounds_ = false;
-  DBuf<long long> d_odom_stamps_;
-  DBuf<unsigned> d_odom_flags_;   // [0, 512) one flag per search block, [512] the state's round number
-  unsigned odom_seq_ = 16;        // round numbers grow over the life of the handle: flags never need a reset
   // lio_est_enable_kernel_timing(-1): HIP events around every launch of the resident kernel (it stays in use, unlike under
   // the per-kernel timing of on >= 1): its dispatch-to-exit span, which is what rocprofv3 reports for it
   bool res_time_launch_ = false;

@@ -65,22 +65,10 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   int ndev = 0;
   LIO_HIP(hipGetDeviceCount(&ndev));
   if (ndev <= 0) throw DeviceError("no HIP device: the product has no CPU path");
-  // LIO_STREAM_PRIORITY=1 (A/B switch): the estimator's stream at the highest priority, the side stream (older frames' features) at the
-  // lowest, so that the newest-frame rounds — the critical path — are dispatched first where both have workgroups pending
-  static const bool prio = [] { const char *e = std::getenv("LIO_STREAM_PRIORITY"); return e && std::atoi(e) != 0; }();
-  int least = 0, greatest = 0;
-  if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-    LIO_HIP(hipStreamCreateWithPriority(&stream_, hipStreamDefault, greatest));
-    LIO_HIP(hipStreamCreateWithPriority(&stream2_, hipStreamDefault, least));
-  } else {
-    LIO_HIP(hipStreamCreate(&stream_));
-    LIO_HIP(hipStreamCreate(&stream2_));
-  }
+  LIO_HIP(hipStreamCreate(&stream_));
+  LIO_HIP(hipStreamCreate(&stream2_));
   LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   LIO_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-  for (hipEvent_t &e : ev_round_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (const char *e = std::getenv("LIO_STAGE_FEATURES")) stage_features_ = std::atoi(e) != 0;
-  if (const char *e = std::getenv("LIO_RIDE_FEATURES")) ride_features_ = std::atoi(e) != 0;
   transform_lb_ = cfg.transform_lb;
   Ps_.assign(W_ + 1, V3d()); Vs_ = Bas_ = Bgs_ = Ps_;
   Rs_.assign(W_ + 1, M3d::identity());
@@ -97,19 +85,12 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   d_odom_.reserve(1);
   d_moment_out_.reserve(size_t(LIO_MAX_FRAMES) * LIO_MOMENT_OUT);
   LIO_HIP(hipMemset(d_moment_out_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));   // the two pad entries per frame stay zero under the all-reduce
-  d_moment_tickets_.reserve(LIO_MAX_FRAMES);
-  LIO_HIP(hipMemset(d_moment_tickets_.p, 0, LIO_MAX_FRAMES * sizeof(int)));
   LIO_HIP(hipDeviceSynchronize());   // the memsets above run on the null stream; the kernels that read them on streams of our own
-  // Fold inside the moments launch (LIO_MOMENTS_FOLD_IN_KERNEL=1) or as a separate k_moment_reduce launch (default).  Measured
-  // on the MI355X per linearisation: in-kernel fold with agent-scope fences 18.8 us (round 1), with the fence-free sc1
-  // store / load / relaxed-ticket protocol 18.8 us again (round 2: 39 serialised ticket adds and memory-side loads per frame
-  // cost what the fences did), two launches 12.5 us.
   // Execution switches: lio_est_config's trailing block, each overridable by its environment variable (A/B runs of a built host).
-  fold_in_kernel_ = cfg.moments_fold_in_kernel; device_solve_ = cfg.device_solve; async_marg_ = !cfg.inline_marg;
+  device_solve_ = cfg.device_solve; async_marg_ = !cfg.inline_marg;
   host_signal_ = !cfg.stream_sync; device_marg_ = cfg.device_marg; moments_form_ = cfg.moments_form;
   resident_moments_ = cfg.resident_moments != 2;
   resident_never_ = cfg.resident_moments == 3;
-  if (const char *e = std::getenv("LIO_MOMENTS_FOLD_IN_KERNEL")) fold_in_kernel_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_MOMENTS")) moments_form_ = std::string(e) == "mfma" ? 1 : (std::string(e) == "valu" ? 2 : moments_form_);
   if (const char *e = std::getenv("LIO_RESIDENT_MOMENTS")) resident_moments_ = std::atoi(e) != 0;
@@ -117,11 +98,6 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_res_relay_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR));
   d_res_part_.reserve(size_t(LIO_RES_MAX_BLOCKS) * LIO_MOMENT_OUT);
   LIO_HIP(hipMemset(d_res_part_.p, 0, sizeof(double) * LIO_RES_MAX_BLOCKS * LIO_MOMENT_OUT));   // flags: no pass has sequence number 0
-  resident_rounds_ = cfg.resident_rounds;
-  if (const char *e = std::getenv("LIO_RESIDENT_ROUNDS")) resident_rounds_ = std::atoi(e) != 0;
-  d_odom_stamps_.reserve(24);
-  d_odom_flags_.reserve(kOdomResidentMaxBlocks + 1);
-  LIO_HIP(hipMemset(d_odom_flags_.p, 0, sizeof(unsigned) * (kOdomResidentMaxBlocks + 1)));
   if (const char *e = std::getenv("LIO_RES_PER_LANE")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) res_per_lane_ = v; }
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_door_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_DOOR, hipHostMallocCoherent));
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_res_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_RES_OUT, hipHostMallocCoherent));
@@ -162,7 +138,6 @@ Estimator::~Estimator() {
   if (h_ds_) (void)hipHostFree(h_ds_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
-  for (hipEvent_t e : ev_round_) if (e) (void)hipEventDestroy(e);
   if (stream2_) (void)hipStreamDestroy(stream2_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -228,15 +203,14 @@ void Estimator::SetWindow(const double *Ps, const double *Rs, const double *Vs, 
 
 static std::atomic<uint64_t> g_content_id{1};
 // Resident kernels hold their CUs until the host (or a peer block) feeds them, so the blocks of ALL of them must be co-resident:
-// a process that drives many windows admits only as many as fit (one round kernel of ~300 blocks, four moments kernels of ~100);
+// a process that drives many windows admits only as many as fit (four moments kernels of ~100 blocks);
 // a solve that is not admitted takes the launch path, with the same results.
-static std::atomic<int> g_resident_rounds{0}, g_resident_moments{0};
+static std::atomic<int> g_resident_moments{0};
 // Solves in flight in this process.  A resident moments kernel holds ~100 CUs' worth of registers while it waits for the host,
 // which is free when the GPU has nothing else to do and expensive when other windows' feature kernels want those CUs: measured
 // on the MI355X with four windows solving on four host threads, 3290 solves/s with every solve resident, 3530 with one at a time,
 // 4230 with none (launch pairs).  So a solve takes the resident form only while it is the ONLY solve in flight.
 static std::atomic<int> g_active_solves{0};
-static constexpr int kMaxResidentRounds = 1;
 // (process-wide, hence an environment knob and not a lio_est_config field; 0 = every solve takes the launch path)
 static const int kMaxResidentMoments = [] { const char *e = std::getenv("LIO_MAX_RESIDENT_MOMENTS"); return e ? std::max(0, std::atoi(e)) : 4; }();
 
@@ -539,29 +513,14 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     // The Wo-1 older frames do not depend on the newest frame's Gauss-Newton rounds: their batched launch goes to a second
     // stream and fills the CUs the serial rows/update kernels of that loop leave idle; joined before the solve.
     hipStream_t sf = cfg_.imu_factor ? stream2_ : stream_;
-    // Staged form (LIO_STAGE_FEATURES=1, NOT the default): beside the first round's search kernel the batched launch slows that round
-    // from 19 to 37 us (both are bound by vector issue; kernel trace in profiles/r4_solve_timeline.md), while the one-block update kernel
-    // behind every search leaves the chip idle for 12 us — so the older frames can go out in up to three launches, each behind the
-    // search kernel of one of the first three rounds (an event between the round's two kernels).  Measured: the event costs a 7 us
-    // bubble between the two kernels of every round and the 8-lane launches of the parts outlast their holes: feature_cost 0.157
-    // against 0.135 ms.  Same kernels, same results either way.
-    stage_features_now_ = sf != stream_ && stage_features_ && !resident_rounds_ && !timers_.on && stacks_[W_].n > 0 && fa.nframes >= 2;
-    // Ride-along form (LIO_RIDE_FEATURES=1, NOT the default): the older frames' features in the launches of the first three rounds'
-    // UPDATE blocks (k_odom_update_with_features: the chip is idle while that one block folds and steps) — no side stream, no events.
-    // Measured: a feature launch takes 29-33 us however few blocks it has (a query is a chain of dependent candidate loads), so each
-    // of the three update launches grows from 12 to ~30 us: feature_cost 0.161 against 0.138 ms.
-    ride_features_now_ = sf != stream_ && ride_features_ && !stage_features_now_ && !resident_rounds_ && !timers_.on && stacks_[W_].n > 0 && fa.nframes >= 1;
-    staged_fa_ = fa;
-    if (!stage_features_now_ && !ride_features_now_) {
-      if (sf != stream_) {
-        LIO_HIP(hipEventRecord(ev_fork_, stream_));
-        LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
-      }
-      th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, sf);
-      launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, sf);
-      timers_.end(th, sf);
-      if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
+    if (sf != stream_) {
+      LIO_HIP(hipEventRecord(ev_fork_, stream_));
+      LIO_HIP(hipStreamWaitEvent(sf, ev_fork_, 0));
     }
+    th = timers_.begin(KT_FEATURES, 16.0 * (mq + double(local_filtered_.n)) + 40.0 * mq + 32.0 * mq, sf);
+    launch_features(fa, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, sf);
+    timers_.end(th, sf);
+    if (sf != stream_) LIO_HIP(hipEventRecord(ev_join_, sf));
   }
   laser_odom_iters_ = 0; laser_odom_kz_ = 0;
   if (cfg_.imu_factor) {
@@ -574,45 +533,13 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
     const bool mail = host_signal_ && !timers_.on;
     HostSignal sig{};
     if (M > 0) {
-      // lanes per query: eight, or four when eight would need more search blocks than can be co-resident for the one-launch form
-      // (the K-NN result does not depend on it; the row partition does, so both forms of the loop use the same value)
-      const int lpq = (!resident_rounds_ || odom_round_blocks(M, 8) + 1 <= kOdomResidentMaxBlocks) ? 8 : 4;
+      const int lpq = 8;   // lanes per query (the K-NN result does not depend on it; the row partition does)
       const int nb = odom_round_blocks(M, lpq);
       d_odom_partials_.reserve(size_t(nb) * 28);
       FeatArgs fo{};
       fo.min_match_sq_dis = cfg_.min_match_sq_dis; fo.min_plane_dis = cfg_.min_plane_dis;
       fo.nframes = 1; fo.max_M = M;
       fo.fr[0].stack = stacks_[W_].buf.p; fo.fr[0].M = M; fo.fr[0].tf_index = 0; fo.fr[0].slot_off = slot_off_[W_];
-      // All rounds in ONE launch when its blocks can be co-resident and no other window of this process holds
-      // the chip with one; otherwise round by round.
-      bool resident = mail && resident_rounds_ && nb + 1 <= kOdomResidentMaxBlocks;
-      if (resident && g_resident_rounds.fetch_add(1) >= kMaxResidentRounds) { g_resident_rounds.fetch_sub(1); resident = false; }
-      if (resident) {
-        struct Release { ~Release() { g_resident_rounds.fetch_sub(1); } } release;   // from the admission on: a launch that throws gives the slot back too
-        sig.flag = h_signal_ + 128; sig.seq = ++signal_seq_[1];
-        if (odom_seq_ > 0xF0000000u) {   // 32-bit sequence numbers: start over long before they wrap (no launch is in flight here)
-          LIO_HIP(hipStreamSynchronize(stream_));
-          LIO_HIP(hipMemset(d_odom_flags_.p, 0, sizeof(unsigned) * (kOdomResidentMaxBlocks + 1)));
-          odom_seq_ = 16;   // (as a fresh handle: zeroed flags never equal a live round number)
-        }
-        const unsigned seq0 = odom_seq_;
-        odom_seq_ += 16;
-        launch_odom_rounds_resident(fo, slot_off_[W_], keep_mult > 1 ? 1 : 0, 10, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                                    f_score_.p, d_odom_partials_.p, d_odom_flags_.p, d_odom_flags_.p + kOdomResidentMaxBlocks, seq0, res_timeout_ticks_ / 4, stream_,
-                                    h_odom_, sig, g_debug_timing ? d_odom_stamps_.p : nullptr, lpq);
-        LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));   // (the launch is asynchronous; the slot is held until the state is back)
-        wait_host_signal(sig, stream_);
-        st = *h_odom_;
-        have_state = true;
-        if (g_debug_timing) {
-          long long sp[24] = {0};
-          LIO_HIP(hipMemcpy(sp, d_odom_stamps_.p, sizeof(sp), hipMemcpyDeviceToHost));
-          std::fprintf(stderr, "[lio_hip timing] resident rounds (%d blocks), update block, us from its start:", nb);
-          for (int r = 0; r < st.iters && r < 10; ++r) std::fprintf(stderr, " round %d flags in %.1f republished %.1f |", r, (sp[1 + 2 * r] - sp[0]) * res_tick_us_, (sp[2 + 2 * r] - sp[0]) * res_tick_us_);
-          std::fprintf(stderr, "\n");
-        }
-        if (st.iters == 0 && !st.converged) throw DeviceError("newest-frame rounds: the resident kernel gave up (a block did not report)");
-      } else {
       // Launch in chunks and peek at the device-side convergence flag between them: a peek costs one small
       // D2H (~10 us) and saves the no-op launches of every skipped round.
       const int chunk_end[4] = {3, 5, 7, 10};
@@ -633,40 +560,14 @@ void Estimator::BuildLocalMap(lio_solve_report *rep) {
         // one round = search + plane fit + rows (k_odom_round) and fold + 6x6 step (k_odom_update_wide)
         const double ns = keep_mult > 1 ? double(iter + 1) * M : double(M);
         int t1h = timers_.begin(KT_ODOM_FEATURES, 16.0 * (double(M) + double(local_filtered_.n)) + 72.0 * M + 33.0 * ns, stream_);
-        const bool stage_here = stage_features_now_ && iter < 3;
-        FeatArgs ride{};
-        if (ride_features_now_ && iter < 3) {   // this round's share of the older frames
-          const int nf = staged_fa_.nframes;
-          const int c0 = (nf + 1) / 2, c1 = (nf - c0 + 1) / 2;
-          const int begin = iter == 0 ? 0 : (iter == 1 ? c0 : c0 + c1), end = iter == 0 ? c0 : (iter == 1 ? c0 + c1 : nf);
-          ride = staged_fa_;
-          ride.nframes = 0; ride.max_M = 0;
-          for (int k = begin; k < end; ++k) { ride.fr[ride.nframes++] = staged_fa_.fr[k]; ride.max_M = std::max(ride.max_M, staged_fa_.fr[k].M); }
-        }
         launch_odom_round(fo, slot_off_[W_], iter, keep_mult > 1 ? 1 : 0, d_odom_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p,
-                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq, stage_here ? ev_round_[iter] : nullptr,
-                          ride.nframes > 0 ? &ride : nullptr, d_transforms_.p);
+                          f_score_.p, d_odom_partials_.p, stream_, mail ? h_odom_ : nullptr, sig, lpq);
         timers_.end(t1h, stream_);
-        if (stage_here) {
-          // the older frames' share behind this round's search: half of them, half of the rest, the rest
-          const int nf = staged_fa_.nframes;
-          const int c0 = (nf + 1) / 2, c1 = (nf - c0 + 1) / 2;
-          const int begin = iter == 0 ? 0 : (iter == 1 ? c0 : c0 + c1), end = iter == 0 ? c0 : (iter == 1 ? c0 + c1 : nf);
-          LIO_HIP(hipStreamWaitEvent(stream2_, ev_round_[iter], 0));
-          if (end > begin) {
-            FeatArgs part = staged_fa_;
-            part.nframes = 0; part.max_M = 0;
-            for (int k = begin; k < end; ++k) { part.fr[part.nframes++] = staged_fa_.fr[k]; part.max_M = std::max(part.max_M, staged_fa_.fr[k].M); }
-            launch_features(part, d_transforms_.p, grid_.sorted(), grid_.cells(), grid_.desc(), f_valid_.p, f_coef_.p, f_score_.p, nullptr, stream2_);
-          }
-          if (iter == 2) LIO_HIP(hipEventRecord(ev_join_, stream2_));
-        }
-      }
       }
     }
     // the older frames' features (second stream) must be complete before anything later on stream_ reads them; the host
     // itself only needs the final state, which a converged peek has already delivered
-    if (!ride_features_now_) LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    LIO_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     if (!have_state) {
       if (sig.flag) {
         wait_host_signal(sig, stream_);
@@ -772,7 +673,7 @@ void Estimator::FillMomentArgs(MomentArgs &ma, int &max_slots) const {
 // counts, so the partition — and with it every bit of the result — does not depend on how a pass is executed.
 int Estimator::ResidentBpf(int max_slots, int nframes, int *per_lane) const {
   if (per_lane) *per_lane = 0;
-  if (!resident_moments_ || fold_in_kernel_ || moments_form_ == 2) return 0;
+  if (!resident_moments_ || moments_form_ == 2) return 0;
   for (int r : {1, 2, 4, 8}) {
     if (res_per_lane_ > 0 && r != res_per_lane_) continue;
     const int b = resident_blocks_per_frame(max_slots, nframes, r);
@@ -1033,18 +934,16 @@ void Estimator::LidarLaunch(const WindowParams &P) {
   if (rccl_comm_) {
     // per-shard moments -> whole-window moments without leaving HBM: fold into a device buffer, SUM all-reduce over xGMI on the
     // same stream, then the 10 KB result goes to the pinned landing zone
-    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, nullptr, d_moment_out_.p, stream_);
+    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, d_moment_out_.p, stream_);
     rccl_all_reduce_sum_f64(rccl_comm_, d_moment_out_.p, size_t(Wo_) * LIO_MOMENT_OUT, stream_);
     LIO_HIP(hipMemcpyAsync(h_moment_out_, d_moment_out_.p, sizeof(double) * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
   } else {
     moment_signal_ = HostSignal();
     if (host_signal_ && !timers_.on) {
-      // one completion word per block of the kernel that writes the result: k_moment_reduce's (frames, 3) grid, or the
-      // last-ticket block of each frame when the fold runs inside k_lidar_moments
-      moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0]; moment_signal_.nslots = (fold_in_kernel_ ? 1 : 3) * ma.nframes;
+      // one completion word per block of the kernel that writes the result: k_moment_reduce's (frames, 3) grid
+      moment_signal_.flag = h_signal_; moment_signal_.seq = ++signal_seq_[0]; moment_signal_.nslots = 3 * ma.nframes;
     }
-    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, fold_in_kernel_ ? d_moment_tickets_.p : nullptr, h_moment_out_, stream_,
-                         moment_signal_);
+    launch_lidar_moments(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, h_moment_out_, stream_, moment_signal_);
   }
   timers_.end(th, stream_);
 }

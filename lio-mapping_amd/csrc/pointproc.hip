@@ -211,78 +211,6 @@ __device__ inline float sqdiff(float ax, float ay, float az, float bx, float by,
   return dx * dx + dy * dy + dz * dz;
 }
 
-// One (subregion, phase) group of the pick loops, by ONE WAVE, 64 candidates of the sorted order at a time (lane = rank inside the
-// chunk; descending: corners from the largest curvature, else flats from the smallest).  A candidate is eligible while the ring's
-// mask does not cover it; per round every eligible candidate publishes its rank at its ring position, looks the ranks in its own
-// reach up (<= 2 nc byte reads) and joins if none is better; those that joined mark their reach, whoever is marked drops out.
-// When no candidate of the chunk is eligible any more the members are known; the best-ranked `quota - picked` of them are the
-// picks: they go to sel[] in rank order (= the order the sequential loop appends them) and mask their reach (MaskPickedInRing,
-// :624-645).  Returns the number of picks of the group.
-__device__ __forceinline__ int pick_group_rounds(const unsigned long long *wk, int region, bool descending, float th, int quota, signed char *mask,
-                                                 unsigned char *rk, unsigned char *kill, const unsigned char *snfb, int lane, int *sel) {
-  int picked = 0;
-  bool stop = false;
-  for (int pos = 0; pos < region && picked < quota && !stop; pos += 64) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int k = pos + lane;
-    const bool in = k < region;
-    const unsigned long long e = in ? wk[descending ? region - 1 - k : k] : 0ull;
-    const float cv = __uint_as_float(static_cast<unsigned int>(e >> 32));
-    const int idx = int(static_cast<unsigned int>(e));
-    const bool cand = in && (descending ? (cv > th) : (cv < th));
-    const int reach = cand ? int(snfb[idx]) : 0;
-    const int nf = reach & 15, nb = reach >> 4;
-    bool alive = cand && mask[idx] == 0;
-    bool member = false;
-    while (__ballot(alive)) {
-      if (alive) rk[idx] = static_cast<unsigned char>(lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      bool blocked = false;
-      if (alive) {
-        for (int q = 1; q <= nf; ++q) blocked = blocked || int(rk[idx + q]) < lane;
-        for (int q = 1; q <= nb; ++q) blocked = blocked || int(rk[idx - q]) < lane;
-      }
-      const bool join = alive && !blocked;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();   // every rank has been read before any is withdrawn
-      if (join) {
-        member = true; alive = false;
-        rk[idx] = 255;
-        for (int q = 1; q <= nf; ++q) kill[idx + q] = 1;
-        for (int q = 1; q <= nb; ++q) kill[idx - q] = 1;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (alive && kill[idx]) { alive = false; rk[idx] = 255; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    const unsigned long long mb = __ballot(member);
-    const int before = __popcll(mb & ((1ull << lane) - 1ull));
-    const bool keep = member && picked + before < quota;
-    if (member) {   // the marks of this chunk go (whether the member is kept or not), the kept members' reach goes into the ring's mask
-      for (int q = 1; q <= nf; ++q) kill[idx + q] = 0;
-      for (int q = 1; q <= nb; ++q) kill[idx - q] = 0;
-    }
-    if (keep) {
-      sel[picked + before] = idx;
-      mask[idx] = 1;
-      for (int q = 1; q <= nf; ++q) mask[idx + q] = 1;
-      for (int q = 1; q <= nb; ++q) mask[idx - q] = 1;
-    }
-    picked = min(quota, picked + __popcll(mb));
-    if (__ballot(in && !cand)) stop = true;   // sorted: nothing further along passes the threshold
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  return picked;
-}
-
-template <bool ROUNDS>
 __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, PickCfg c,
                                                                float *__restrict__ g_curv, int *__restrict__ g_mask, int8_t *__restrict__ g_label,
                                                                int *__restrict__ pick_idx, int *__restrict__ pick_cnt,
@@ -310,10 +238,8 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   unsigned char *snfb = reinterpret_cast<unsigned char *>(slabel + NP);  // MaskPickedInRing reach of every point: nf | nb << 4
   unsigned char *sgap = snfb + NP;
   signed char *macc = reinterpret_cast<signed char *>(sgap + NP);        // the ring's mask incl. the reach of every final pick
-  unsigned char *rkb = reinterpret_cast<unsigned char *>(macc + NP);     // pick rounds: rank of a still-eligible candidate of the chunk at hand (255: none)
-  unsigned char *killb = rkb + NP;                                       // pick rounds: 1 = in the reach of a candidate that just joined (8 * PP_WMASK >= NP bytes)
-  signed char *wmask = reinterpret_cast<signed char *>(killb);           // ROUNDS == false: 8 private masks, a subregion's range +- nc (the same bytes)
-  signed char *zfwd = reinterpret_cast<signed char *>(rkb);              // ROUNDS == false: forward reach of finished subregions beyond their end (the same bytes)
+  signed char *zfwd = macc + NP;                                         // forward reach of finished subregions beyond their end
+  signed char *wmask = zfwd + NP;                                        // 8 private masks, a subregion's range +- nc
   int *wsel = reinterpret_cast<int *>(wmask + 8 * PP_WMASK);             // 8 x (corner picks, flat picks) of the speculative pass
   int *wcnt = wsel + 8 * PP_WSEL;                                        // 8 x (number of corner picks, number of flat picks)
   volatile int *wdone = wcnt + 16;                                       // 8 flags: the wave's picks (and its zfwd entries) are final
@@ -378,7 +304,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   // smask is PrepareRing's mask from here on (read-only); macc accumulates it + the reach of every FINAL pick (the ring's mask)
   for (int i = tid; i < NP; i += PP_PICK_THREADS) {
     if (i < n) macc[i] = smask[i];
-    if (ROUNDS) { rkb[i] = 255; killb[i] = 0; } else zfwd[i] = 0;
+    zfwd[i] = 0;
   }
   __syncthreads();
   PICK_STAMP(2);
@@ -462,35 +388,6 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
     if (jg == 0) PICK_STAMP(4);
     signed char *wm = wmask + wv * PP_WMASK;
     const int off = sp - c.nc;
-    if (ROUNDS) {
-    // ---- picks (:685-725) in PARALLEL ROUNDS.  Inside one (subregion, phase) group "taking a masks b" is a symmetric relation — b = a + k
-    // is masked iff k <= nc and the k gaps between them are small, the same gaps b's backward walk checks — so the sequential picks
-    // are the lexicographically-first maximal independent set of the conflict graph in curvature order, and that set grows in
-    // parallel: every remaining candidate that out-ranks all remaining candidates in its reach joins at once (pick_group_rounds;
-    // tests/ring_pick_model.py is the numpy model of this, tests/test_ring_pick_rounds.py holds it to the sequential loops: 2.1
-    // rounds per group on average on ray-cast rings, 4 at worst, against up to 24 dependent picks).  The quota (20 corners, 4 flats)
-    // is a truncation of the set to its best-ranked members, and only the kept members leave masks behind.
-    // The mask is shared by the ring's subregions (A.4): a pick masks up to nc points across the boundary, so the subregions take
-    // their picks one after the other on the ring's mask — wave j starts when wave j - 1 has published its picks — while
-    // curvature and sort of all eight ran at the same time above.  A group is a handful of LDS round trips now, so the chain through
-    // the subregions is short; the speculative private masks of round 3 are gone.
-    int *sel = wsel + wv * PP_WSEL;
-    if (lane == 0) wdone[wv] = 0;
-    __syncthreads();
-    if (active) {
-      for (int w2 = 0; w2 < wv; ++w2)
-        while (wdone[w2] == 0) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int num_largest = pick_group_rounds(wk, region, true, c.curv_th, c.max_less_sharp, macc, rkb, killb, snfb, lane, sel);
-      if (lane < num_largest) slabel[sel[lane]] = lane < c.max_sharp ? 2 : 1;
-      const int num_smallest = pick_group_rounds(wk, region, false, c.curv_th, c.max_flat, macc, rkb, killb, snfb, lane, sel + c.max_less_sharp);
-      if (lane < num_smallest) slabel[sel[c.max_less_sharp + lane]] = -1;
-      if (lane == 0) { wcnt[2 * wv] = num_largest; wcnt[2 * wv + 1] = num_smallest; }
-    } else if (lane == 0) { wcnt[2 * wv] = 0; wcnt[2 * wv + 1] = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) wdone[wv] = 1;
-    __syncthreads();
-    } else {
     // ---- picks (:685-725).  The mask is shared by the ring's subregions (A.4): a pick masks up to nc points on either side, so a
     // subregion sees its predecessors' picks — but only through the <= nc points behind its start (its "zone").  The eight waves
     // therefore pick their subregions at the same time, each on a private copy of the mask (its range +- nc) that starts as
@@ -602,7 +499,6 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) wdone[wv] = 1;
     __syncthreads();
-    }
     if (jg == 0) PICK_STAMP(5);
     // the ring's lists in subregion order; every wave folds its private mask into the ring's mask (stores of 1 only, so the
     // overlapping margins need no ordering)
@@ -621,7 +517,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
         n_flat += nsm;
       }
     }
-    if (!ROUNDS && active)
+    if (active)
       for (int li = lane; li < region + 2 * c.nc; li += 64) { const int i = off + li; if (i >= 0 && i < n && wm[li]) macc[i] = 1; }
     __syncthreads();
   }
@@ -872,8 +768,7 @@ PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const 
   ring_offsets_.assign(rings + 1, 0);
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_out_), sizeof(HostOut)));
   // the pick kernel needs up to ~104 KB of dynamic LDS
-  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lf_ring), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
 }
 PointProcessorDev::~PointProcessorDev() {
@@ -955,15 +850,8 @@ void PointProcessorDev::ProcessLaunch(const float *xyzi, size_t n, const uint16_
                      first_valid_p_, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_p_ : nullptr);
   const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 6) + size_t(8) * PP_WMASK +
                      size_t(8) * PP_WSEL * sizeof(int) + 24 * sizeof(int) + size_t(cap_all) * sizeof(int) + 64;
-  // LIO_PICK_ROUNDS=1: the pick loops in parallel rounds (pick_group_rounds) instead of the speculative sequential form.  Bit-identical
-  // picks; measured on the MI355X (HDL-64E sweeps) the kernel takes 105 us that way against 62-67 us, so it is not the default.
-  static const bool pick_rounds = [] { const char *e = std::getenv("LIO_PICK_ROUNDS"); return e && std::atoi(e) != 0; }();
-  if (pick_rounds)
-    hipLaunchKernelGGL(k_ring_pick<true>, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
-                       pick_idx_.p, pick_cnt_.p, d_counts_p_);
-  else
-    hipLaunchKernelGGL(k_ring_pick<false>, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
-                       pick_idx_.p, pick_cnt_.p, d_counts_p_);
+  hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
+                     pick_idx_.p, pick_cnt_.p, d_counts_p_);
   // less-flat
   const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
   lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);

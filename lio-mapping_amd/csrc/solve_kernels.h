@@ -32,11 +32,9 @@ struct MomentArgs {
   int form;   // 0: MFMA or VALU form by chunks per wave, 1: MFMA, 2: VALU (lio_est_config.moments_form)
 };
 
-// partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles
-// tickets: nframes ints, zero before the first launch (the kernel re-zeroes them) -> the fold runs inside the same launch;
-// tickets == nullptr -> separate k_moment_reduce launch.
-void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
-                          hipStream_t s, const HostSignal &sig = HostSignal());
+// partials: nframes * blocks_per_frame * LIO_MOMENT_OUT doubles; out: nframes * LIO_MOMENT_OUT doubles (k_moment_reduce folds them)
+void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s,
+                          const HostSignal &sig = HostSignal());
 int moment_blocks_per_frame(int max_slots);
 
 // ---- resident form: ONE launch per solve.  The worker blocks keep their residuals in registers and wait for

@@ -64,8 +64,7 @@ __device__ __forceinline__ double ds_bcast_lane(double v, int src_lane);   // de
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
 __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                   double *__restrict__ partials, int *__restrict__ tickets, double *__restrict__ out, int nblk,
-                                                   const HostSignal &sig = HostSignal()) {
+                                                   double *__restrict__ partials, int nblk) {
   // nblk = blocks per frame (gridDim.x of the plain launches; the device-solver launch has a wider grid: k_lidar_moments_dev)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e = lane & 15, grp = lane >> 4;
@@ -151,66 +150,10 @@ __device__ __forceinline__ void lidar_moments_body(const MomentFrame &fr, const 
   if (lane == 0) { sm[wv][256] = cost; sm[wv][257] = cnt; }
   __syncthreads();
   double *dst = partials + (size_t(blockIdx.y) * nblk + blockIdx.x) * LIO_MOMENT_OUT;
-  if (!tickets) {
-    for (int k = threadIdx.x; k < 258; k += MOMENT_THREADS) {
-      double v = 0;
-      for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][k];
-      dst[k] = v;
-    }
-    return;
-  }
-  // ---- fold in the same launch: the block that draws the frame's last ticket sums the frame's partials in block order
-  // (independent of which block that is).  No fences: an agent-scope release / acquire pair writes back and invalidates the
-  // L2 of the XCD (measured in round 1: 18.8 us for this kernel against 13.6 us for moments + reduce).  Instead the partials
-  // travel as agent-scope STORES and LOADS (sc1: written through to / read from the memory side, coherent across the eight
-  // L2s), every wave waits for its stores to be acknowledged, and the ticket is a relaxed agent-scope add: a block that sees
-  // the last ticket therefore finds every other block's partial in memory.
   for (int k = threadIdx.x; k < 258; k += MOMENT_THREADS) {
     double v = 0;
     for (int w = 0; w < MOMENT_THREADS / 64; ++w) v += sm[w][k];
-    __hip_atomic_store(&dst[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __shared__ int is_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == nblk - 1);
-  }
-  __syncthreads();
-  if (!is_last) return;
-  asm volatile("" ::: "memory");
-  // the arithmetic of k_moment_reduce (four interleaved chains per value on four lanes, remainder on lane 0, xor-shuffle pair
-  // sums): the two paths give bit-identical moments
-  const double *src = partials + size_t(blockIdx.y) * nblk * LIO_MOMENT_OUT;
-  const int bpf = nblk, b4 = bpf & ~3, q = threadIdx.x & 3;
-  for (int k0 = 0; k0 < 258; k0 += MOMENT_THREADS / 4) {
-    const int k = k0 + (threadIdx.x >> 2);
-    const bool in = k < 258;
-    const double *sk = src + (in ? k : 0);
-    double v = 0;
-    int b = q;
-    for (; b + 12 < b4; b += 16) {
-      const double x0 = __hip_atomic_load(sk + size_t(b) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double x1 = __hip_atomic_load(sk + size_t(b + 4) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double x2 = __hip_atomic_load(sk + size_t(b + 8) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double x3 = __hip_atomic_load(sk + size_t(b + 12) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v += x0; v += x1; v += x2; v += x3;
-    }
-    for (; b < b4; b += 4) v += __hip_atomic_load(sk + size_t(b) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (q == 0) for (int r = b4; r < bpf; ++r) v += __hip_atomic_load(sk + size_t(r) * LIO_MOMENT_OUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    if (in && q == 0) {
-      if (sig.flag) host_store(&out[size_t(blockIdx.y) * LIO_MOMENT_OUT + k], v);   // `out` is coherent host memory then
-      else out[size_t(blockIdx.y) * LIO_MOMENT_OUT + k] = v;
-    }
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (stream order)
-  if (sig.flag) {   // this frame's moments are out: post its completion word (dev.h: HostSignal)
-    host_signal_drain();
-    __syncthreads();
-    if (threadIdx.x == 0) post_host_signal(sig, int(blockIdx.y));
+    dst[k] = v;
   }
 }
 
@@ -664,16 +607,15 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_sym_batched(co
 }
 
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments(MomentArgs a, const uint8_t *__restrict__ valid,
-                                                                  const float4 *__restrict__ coef, double *__restrict__ partials,
-                                                                  int *__restrict__ tickets, double *__restrict__ out, HostSignal sig) {
-  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials, tickets, out, gridDim.x, sig);
+                                                                  const float4 *__restrict__ coef, double *__restrict__ partials) {
+  lidar_moments_body(a.fr[blockIdx.y], valid, coef, partials, gridDim.x);
 }
 
 // Batched form for B windows in flight: the frame descriptors live in device memory (B x Wo of them), everything else is the
 // same code.  Used by the batched roofline measurement (SURVEY.md §8d ii) and by multi-window hosts.
 __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_batched(const MomentFrame *__restrict__ frames, const uint8_t *__restrict__ valid,
                                                                           const float4 *__restrict__ coef, double *__restrict__ partials) {
-  lidar_moments_body(frames[blockIdx.y], valid, coef, partials, nullptr, nullptr, gridDim.x);
+  lidar_moments_body(frames[blockIdx.y], valid, coef, partials, gridDim.x);
 }
 
 // Fold of the per-block partials: out[f][k] = sum_b partials[f][b][k].  Four lanes per value, lane q walks the blocks b = q, q + 4, ...
@@ -768,17 +710,16 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
   LIO_HIP(hipGetLastError());
 }
 
-void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, int *tickets, double *out,
-                          hipStream_t s, const HostSignal &sig) {
+void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, double *out, hipStream_t s,
+                          const HostSignal &sig) {
   if (a.nframes <= 0) return;
   int max_slots = 0;
   for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
-  if (tickets || use_mfma(max_slots, a.blocks_per_frame, a.form))
-    hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, tickets, out,
-                       tickets ? sig : HostSignal());
+  if (use_mfma(max_slots, a.blocks_per_frame, a.form))
+    hipLaunchKernelGGL(k_lidar_moments, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
   else
     hipLaunchKernelGGL(k_lidar_moments_sym, dim3(a.blocks_per_frame, a.nframes), dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials);
-  if (!tickets) hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, a.blocks_per_frame, out, sig);
+  hipLaunchKernelGGL(k_moment_reduce, dim3(a.nframes, 3), dim3(REDUCE_THREADS), 0, s, partials, a.blocks_per_frame, out, sig);
   LIO_HIP(hipGetLastError());
 }
 
@@ -930,7 +871,7 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_dev(MomentArgs
 #pragma unroll
     for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
     if (SYM) lidar_moments_sym_body(fr, valid, coef, partials, a.blocks_per_frame);
-    else lidar_moments_body(fr, valid, coef, partials, nullptr, nullptr, a.blocks_per_frame);
+    else lidar_moments_body(fr, valid, coef, partials, a.blocks_per_frame);
     return;
   }
   __shared__ double aux_lds[1024];

@@ -96,9 +96,7 @@ class EstConfig(C.Structure):
         ("inline_marg", C.c_int),
         ("stream_sync", C.c_int),
         ("moments_form", C.c_int),
-        ("moments_fold_in_kernel", C.c_int),
         ("resident_moments", C.c_int),
-        ("resident_rounds", C.c_int),
     ]
 
 
@@ -145,8 +143,6 @@ _SIGS = {
     "lio_pp_process": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
     "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
-    "lio_vox_fused_stats": (None, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
-    "lio_vox_fused_set": (C.c_int, [C.c_int]),
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
@@ -334,16 +330,6 @@ class LioLib:
         J, r, s = np.zeros((n, n)), np.zeros(n), np.zeros(n)
         _chk(self.dll.lio_marginalize_schur(_dp(A), _dp(b), m, n, _dp(J), _dp(r), _dp(s)), "lio_marginalize_schur")
         return J, r, s
-
-    def vox_fused_stats(self):
-        """(filters that took the one-launch form, of those: handed back to the sorted path) — process-wide counters"""
-        a, b = C.c_longlong(0), C.c_longlong(0)
-        self.dll.lio_vox_fused_stats(C.byref(a), C.byref(b))
-        return int(a.value), int(b.value)
-
-    def vox_fused_set(self, on):
-        """1 / 0: filters take / do not take the one-launch form; -1: LIO_VOX_FUSED decides.  Returns the previous setting."""
-        return int(self.dll.lio_vox_fused_set(int(on)))
 
     def bench_voxel_grid(self, xyzi, leaf, reps=10):
         """device time of one VoxelGrid of a resident cloud (HIP events over `reps` runs) -> (ms, output points)"""

@@ -347,8 +347,6 @@ int lio_compact_decode(const float *d, size_t n, lio_transform_f *T, size_t *nc,
 }
 
 // ---------------------------------------------------------------- stateless blocks
-int lio_vox_fused_set(int) { return -1; }
-void lio_vox_fused_stats(long long *launched, long long *fell_back) { if (launched) *launched = 0; if (fell_back) *fell_back = 0; }
 int lio_voxel_grid(const float *xyzi, size_t n, float leaf, float *out, size_t *n_out) {
   if ((!xyzi && n) || !out || !n_out || !(leaf > 0)) return LIO_ERR_ARG;
   Cloud in = toCloud(xyzi, n), o;

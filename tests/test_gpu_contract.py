@@ -160,13 +160,11 @@ def test_teacher_forced_chain_of_20_solves(hip, oracle, kind, frame_dt):
         np.testing.assert_allclose(sa[:, :3], sb[:, :3], atol=5e-4)
 
 
-@pytest.mark.parametrize("resident_rounds", [0, 1])
-def test_stream_sync_fallback_gives_the_same_bits(hip, oracle, resident_rounds):
+def test_stream_sync_fallback_gives_the_same_bits(hip, oracle):
     """lio_est_config.stream_sync = 1 (the LIO_HOST_SIGNAL=0 path: D2H copies + hipStreamSynchronize instead of completion words in
     host memory) must stay alive: same kernels, same arithmetic => the same window bit for bit over solve + slide + solve.  This
-    also pins the two resident kernels to their launch forms: with stream_sync the lidar moments come from k_lidar_moments +
-    k_moment_reduce launches instead of the resident kernel's passes, and (resident_rounds = 1, opt-in) the newest frame's rounds
-    from a launch pair per round instead of the one-launch form."""
+    also pins the resident moments kernel to its launch form: with stream_sync the lidar moments come from k_lidar_moments +
+    k_moment_reduce launches instead of the resident kernel's passes."""
     from lio_amd import capi, synth
     W, Wo = 8, 4
     ds = synth.make_dataset("indoor", W + 3, 0.2)
@@ -174,7 +172,7 @@ def test_stream_sync_fallback_gives_the_same_bits(hip, oracle, resident_rounds):
     wins = []
     for sync in (0, 1):
         cfg = pipeline.config_indoor(hip, W, Wo)
-        cfg.keep_features, cfg.cutoff_deskew, cfg.prior_factor, cfg.stream_sync, cfg.resident_rounds = 0, 1, 1, sync, resident_rounds
+        cfg.keep_features, cfg.cutoff_deskew, cfg.prior_factor, cfg.stream_sync = 0, 1, 1, sync
         pipeline.set_extrinsic(cfg, ds)
         est = capi.Estimator(hip, cfg)
         pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)

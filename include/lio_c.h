@@ -325,8 +325,9 @@ typedef struct {
   /* ---- execution switches of the product (no reference counterpart; results are the same up to the documented tolerances, the
    * oracle ignores them).  0 = the shipped default.  An environment variable (named at each field), when set, overrides the
    * field at lio_est_create — for A/B runs of a host that cannot be rebuilt. */
-  int device_solve;           /* 1: trust-region loop on the device, two launches per iteration (LIO_DEVICE_SOLVE); ignores max_solver_time */
-  int device_marg;            /* 1: marginalization's Schur complement + eigensolves on the device (LIO_DEVICE_MARG) */
+  int device_solve;           /* 1: the handle solves as a batch of ONE window (lio_est_batch below: trust-region loop and marginalization on
+                                 the device, the prior stays there between solves); LIO_DEVICE_SOLVE=1 or LIO_DEVICE_MARG=1 in the
+                                 environment select it too.  Ignores max_solver_time */
   int inline_marg;            /* 1: marginalization inside lio_est_solve_optimization instead of the worker thread (LIO_ASYNC_MARG=0) */
   int stream_sync;            /* 1: hipStreamSynchronize + D2H copies instead of completion words in host memory (LIO_HOST_SIGNAL=0) */
   int moments_form;           /* 0: by launch size, 1: fp64 MFMA form, 2: structured fp64 VALU form (LIO_MOMENTS=mfma|valu) */
@@ -470,10 +471,45 @@ int lio_marginalize_schur(const double *A, const double *b, int m, int n, double
 /* In-memory snapshot / restore of the whole estimator state (bench + parity loops). */
 int lio_est_snapshot(lio_est *);
 int lio_est_restore(lio_est *);
+/* Measurement hook: dst's snapshot becomes a copy of src's (same window sizes; the clouds are copied into buffers of dst's own), so
+ * that B windows holding the same data at distinct addresses exist without replaying the sequence B times.  lio_est_restore(dst)
+ * then puts dst into that state.  LIO_ERR_STATE when src has no snapshot or the window sizes differ. */
+int lio_est_copy_snapshot(lio_est *dst, lio_est *src);
 /* Measurement hook: `steps` times lio_est_restore + lio_est_solve_optimization, in one call (what bench.py times: a caller that
  * is compiled code, like estimator_node, pays no interpreter between two solves).  report_or_null receives the last solve's report.
  * Stops at the first failing step and returns its code. */
 int lio_est_solve_restored(lio_est *, int steps, lio_solve_report *report_or_null);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched windows (no reference counterpart: the reference solves one window per process).
+ * B independent estimators — different vehicles, logs, or the shards of an offline re-optimisation — solve together: every stage
+ * of Estimator::SolveOptimization (Estimator.cc:1648-2438: BuildLocalMap :1361-1646, CalculateFeatures :970-1097,
+ * CalculateLaserOdom :1242-1359, ceres::Solve :1909-1990, MarginalizationInfo::Marginalize MarginalizationFactor.cc:185-311)
+ * is ONE launch over all windows, the trust-region loop (ImuFactor.h:53-168 and the prior included) and the Schur-complement
+ * marginalization run on the device, one workgroup per window.  A window gives the same bits alone (a batch of one) and inside
+ * any batch.  Windows the device loop does not take (not initialised, convergence_flag_ still changing the problem, factor
+ * sharding) are solved by the single-window path inside the same call.
+ * lio_est_batch_create ADOPTS the handles: their device work moves to the batch's stream; they stay usable one at a time from the
+ * thread that drives the batch (push frames, slide, snapshot / restore, getters) and must outlive the batch.  NULL on bad arguments. */
+typedef struct lio_est_batch lio_est_batch;
+lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n_windows);
+void lio_est_batch_destroy(lio_est_batch *);
+int lio_est_batch_size(const lio_est_batch *);
+/* SolveOptimization of every window; reports_or_null: n_windows reports (the ms_* fields of a window solved on the device are the
+ * batch's stage times: ms_build_map = filter chain, ms_features = K-NN grids + features + newest-frame rounds, ms_opt = the
+ * trust-region loop, ms_marg = write-back + marginalization enqueue).  LIO_ERR_STATE when a window is not initialised. */
+int lio_est_batch_solve(lio_est_batch *, lio_solve_report *reports_or_null);
+/* Measurement hook (what bench.py times): `steps` x (lio_est_restore of every window + lio_est_batch_solve), then a wait for the
+ * last marginalizations. */
+int lio_est_batch_solve_restored(lio_est_batch *, int steps, lio_solve_report *reports_or_null);
+/* waits for everything the batch has enqueued (the marginalizations of the last solve run behind its return) */
+int lio_est_batch_sync(lio_est_batch *);
+/* host wall clock of the last lio_est_batch_solve, ms: [0] descriptors, [1] filter chain, [2] grids + features + rounds, [3] problem
+ * packing (inside [2]), [4] trust-region loop, [5] write-back + marginalization enqueue, [6] single-window fallbacks, [7] total,
+ * [8] windows solved on the device, [9] newest-frame rounds launched; DEVICE time of the stages (HIP events on the batch's stream;
+ * the call waits for the stream): [10] filter chain, [11] K-NN grids, [12] features of the older frames, [13] newest-frame rounds,
+ * [14] trust-region loop, [15] marginalization.  out: 16 doubles. */
+int lio_est_batch_get_clock(const lio_est_batch *, double *out16);
 
 /* Multi-GPU factor sharding (the reference's own 4-thread split of ThreadsConstructA,
  * MarginalizationFactor.cc:245-269, extended across ranks): rank r of `world` evaluates only its contiguous share of

@@ -1,0 +1,59 @@
+// batch_kernels.h — the map / feature stages of Estimator::SolveOptimization for B windows at once:
+// every stage of BuildLocalMap (Estimator.cc:1361-1646), CalculateFeatures (:970-1097) and CalculateLaserOdom (:1242-1359) is
+// ONE launch over all windows of the batch, indexed by blockIdx.y / .z through a per-window descriptor in device memory.
+// The per-window arithmetic is the single-window kernels' (cloud_device.h), and every partition (blocks of a round, tiles of a
+// filter) is a function of the window's own sizes: a window gives the same bits alone (B = 1) and inside any batch.
+#pragma once
+#include "cloud_kernels.h"
+
+namespace lio {
+
+#define LIO_BW_MAX_SEG 8        // segments of a local map: the pivot's cloud + the Wo - 1 frames behind it (Wo <= 7)
+#define LIO_BW_MAX_STATIC 7     // frames whose features do not depend on the newest frame's rounds
+#define LIO_BW_LPQ 4            // lanes per query of the batched search kernels (fixed: the row partition of a round depends on it)
+
+struct BwSeg { const float4 *src; int n; int dst_off; int identity; int set_intensity; float intensity; Affine3f tf; };
+
+struct BatchWin {
+  // ---- BuildLocalMap: concat into local_all[loc_off, loc_off + n_local), keys, filter
+  BwSeg seg[LIO_BW_MAX_SEG];
+  int nseg, n_local;
+  int loc_off, loc_cap;          // this window's range of the batch's point arrays (both multiples of 256)
+  float inv_leaf;
+  // ---- feature slots: this window's range of the batch's slot arrays (valid / coef / score)
+  int slot_base, n_slots;
+  FeatFrame fr[LIO_BW_MAX_STATIC];   // slot_off is an offset into the batch's arrays, tf_index an index into tf
+  int nstatic;
+  FeatFrame newest;              // the frame CalculateLaserOdom iterates on (M = 0: none)
+  int nb_round, part_off, keep;  // its search blocks per round, its first row of the batch's partials, keep_features
+  float tf[LIO_BW_MAX_STATIC + 1][8];   // local transforms (qx qy qz qw px py pz pad); the last entry is the newest frame's start
+  float min_match_sq_dis, min_plane_dis;
+};
+
+// what the filter reports per window (read by the host after the stream has drained)
+struct BwVoxOut { int count; VoxParams params; int range_overflow; };
+
+// the K-NN grid of a window (host-computed from the filter's bounds, uploaded before the cell build)
+struct BatchGrid { GridDesc g; int cell_off; int n_filtered; };
+
+int bw_round_blocks(int M);   // search blocks of one round of a window's newest frame (LIO_BW_LPQ lanes per query)
+
+// concat + voxel keys + per-block bounds.  keys64 / vals: loc-array sized; partial: 8 floats per 256-point block
+void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, unsigned long long *keys64, uint32_t *vals, float *partial,
+                           int *range_overflow, hipStream_t s);
+// sorted keys -> tile heads (+ the bounds fold) -> centroids, counts
+void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const unsigned long long *keys_sorted, const uint32_t *vals_sorted,
+                          const float *partial, int *tile_heads, float4 *filtered_all, VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s);
+// feature flags cleared, the newest frames' Gauss-Newton states started
+void launch_bw_setup(const BatchWin *win, int B, int max_slots, uint8_t *valid_all, OdomState *odom, int *n_converged, hipStream_t s);
+// K-NN grid: histogram, (scan by the caller), placement
+void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, uint32_t *slot, int *cnt_all,
+                          hipStream_t s);
+void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
+                          const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s);
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, const float4 *sorted_all, const int *cells_all,
+                        uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, int round, OdomState *odom, const float4 *sorted_all, const int *cells_all,
+                          uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials, int *n_converged, hipStream_t s);
+
+}  // namespace lio

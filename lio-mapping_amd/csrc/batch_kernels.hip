@@ -1,0 +1,353 @@
+// batch_kernels.hip — see batch_kernels.h.  gfx950 kernels; blockIdx.y (or .z) = the window, blockIdx.x = a block of that window's
+// share, blocks past a window's own size leave at once.  Clouds are float4 AoS as everywhere (cloud_kernels.hip); the batch's
+// arrays are the windows' ranges laid end to end, so a wave's 64 lanes always read one window's consecutive points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "batch_kernels.h"
+#include "cloud_device.h"
+
+namespace lio {
+
+#define BW_THREADS 256
+
+int bw_round_blocks(int M) { return std::max(1, cdiv((long long)M * LIO_BW_LPQ, ODOM_ROUND_THREADS)); }
+
+// ------------------------------------------------------------------------------------------------
+// BuildLocalMap, first half: pcl::transformPointCloud + `+=` (Estimator.cc:1480-1507) and, from the point still in registers, the
+// filter's sort key — the window above PCL's voxel index in absolute cells (cloud_kernels.hip: k_vox_keys_abs; the window in the
+// high word keeps every window's points together through ONE sort of the whole batch) — and the block's share of the bounds.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *__restrict__ win, float4 *__restrict__ local_all,
+                                                              unsigned long long *__restrict__ keys64, uint32_t *__restrict__ vals,
+                                                              float *__restrict__ partial, int *__restrict__ range_overflow) {
+  const int w = blockIdx.y;
+  const BatchWin &W = win[w];
+  const int base = int(blockIdx.x) * BW_THREADS;
+  if (base >= W.loc_cap) return;
+  const int gid = base + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float cnt = 0;
+  uint32_t key = 0xFFFFFFFFu;
+  if (gid < W.n_local) {
+    int sidx = 0;
+    for (int k = 1; k < W.nseg; ++k)
+      if (gid >= W.seg[k].dst_off) sidx = k;
+    const BwSeg &sg = W.seg[sidx];
+    const float4 p = sg.src[gid - sg.dst_off];
+    float4 o;
+    if (sg.identity) {
+      o = p;
+    } else {
+      const float *m = sg.tf.m;
+      o.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+      o.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+      o.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+      o.w = p.w;
+    }
+    if (sg.set_intensity) o.w = sg.intensity;
+    local_all[W.loc_off + gid] = o;
+    if (finite3(o)) {
+      cnt = 1.f;
+      mn[0] = mx[0] = o.x; mn[1] = mx[1] = o.y; mn[2] = mx[2] = o.z;
+      const float cx = floorf(o.x * W.inv_leaf), cy = floorf(o.y * W.inv_leaf), cz = floorf(o.z * W.inv_leaf);
+      if (fabsf(cx) < 1024.f && fabsf(cy) < 1024.f && fabsf(cz) < 511.f) key = (uint32_t(int(cz) + 512) << 22) | (uint32_t(int(cy) + 1024) << 11) | uint32_t(int(cx) + 1024);
+      else range_overflow[w] = 1;
+    }
+  }
+  keys64[W.loc_off + gid] = (static_cast<unsigned long long>(w) << 32) | key;
+  vals[W.loc_off + gid] = uint32_t(W.loc_off + gid);
+  __shared__ float sm[7][BW_THREADS / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64)); }
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) { for (int d = 0; d < 3; ++d) { sm[d][wv] = mn[d]; sm[3 + d][wv] = mx[d]; } sm[6][wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int t = threadIdx.x;
+    float v = sm[t][0];
+    for (int q = 1; q < BW_THREADS / 64; ++q) v = t < 3 ? fminf(v, sm[t][q]) : (t < 6 ? fmaxf(v, sm[t][q]) : v + sm[t][q]);
+    partial[(size_t(W.loc_off / BW_THREADS) + blockIdx.x) * 8 + t] = v;
+  }
+}
+
+void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, unsigned long long *keys64, uint32_t *vals, float *partial,
+                           int *range_overflow, hipStream_t s) {
+  if (B <= 0 || max_local <= 0) return;
+  hipLaunchKernelGGL(k_bw_concat_keys, dim3(cdiv(max_local, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, local_all, keys64, vals, partial, range_overflow);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// pcl::VoxelGrid (Estimator.cc:1518-1519), behind the sort: heads per 256-entry tile of a window's sorted range (+ one block per
+// window that folds the bounds into VoxParams exactly as the single-window filter does), then the centroids — a run is added up
+// in sorted order, i.e. in ascending original index (the sort is stable), the order the oracle fixes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bw_is_head(const unsigned long long *__restrict__ keys, int pos, unsigned long long k) {
+  return uint32_t(k) != 0xFFFFFFFFu && (pos == 0 || keys[pos - 1] != k);
+}
+__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_heads(const BatchWin *__restrict__ win, const unsigned long long *__restrict__ keys,
+                                                            const float *__restrict__ partial, int *__restrict__ tile_heads,
+                                                            VoxParams *__restrict__ params) {
+  const int w = blockIdx.y;
+  const BatchWin &W = win[w];
+  const int ntiles = W.loc_cap / BW_THREADS;
+  if (blockIdx.x == gridDim.x - 1) {
+    __shared__ float sm[7][BW_THREADS];
+    const int t = threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    float cnt = 0;
+    const float *pw = partial + size_t(W.loc_off / BW_THREADS) * 8;
+    for (int b = t; b < ntiles; b += BW_THREADS) {
+      for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], pw[size_t(b) * 8 + d]); mx[d] = fmaxf(mx[d], pw[size_t(b) * 8 + 3 + d]); }
+      cnt += pw[size_t(b) * 8 + 6];   // integers below 2^24: exact in any order
+    }
+    for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+    sm[6][t] = cnt;
+    __syncthreads();
+    for (int st = BW_THREADS / 2; st > 0; st >>= 1) {
+      if (t < st) {
+        for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+        sm[6][t] += sm[6][t + st];
+      }
+      __syncthreads();
+    }
+    if (t != 0) return;
+    VoxParams v;
+    long long dd[3];
+    for (int d = 0; d < 3; ++d) {
+      v.mn[d] = sm[d][0]; v.mx[d] = sm[3 + d][0];
+      dd[d] = (long long)((v.mx[d] - v.mn[d]) * W.inv_leaf) + 1;
+      v.minb[d] = int(floorf(v.mn[d] * W.inv_leaf));
+      const int maxb = int(floorf(v.mx[d] * W.inv_leaf));
+      v.divb[d] = maxb - v.minb[d] + 1;
+    }
+    v.overflow = (sm[6][0] > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+    v.n_valid = int(sm[6][0]);
+    params[w] = v;
+    return;
+  }
+  if (int(blockIdx.x) >= ntiles) return;
+  __shared__ int swave[BW_THREADS / 64];
+  const int pos = W.loc_off + int(blockIdx.x) * BW_THREADS + threadIdx.x;
+  const unsigned long long k = keys[pos];
+  const unsigned long long b = __ballot(bw_is_head(keys, pos, k));
+  if ((threadIdx.x & 63) == 0) swave[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_heads[W.loc_off / BW_THREADS + blockIdx.x] = (swave[0] + swave[1]) + (swave[2] + swave[3]);
+}
+
+__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_centroids(const BatchWin *__restrict__ win, const float4 *__restrict__ pts,
+                                                                const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                                const int *__restrict__ tile_heads, float4 *__restrict__ out,
+                                                                const VoxParams *__restrict__ params, int *__restrict__ range_overflow,
+                                                                BwVoxOut *__restrict__ vout) {
+  const int w = blockIdx.y;
+  const BatchWin &W = win[w];
+  const int ntiles = W.loc_cap / BW_THREADS;
+  if (int(blockIdx.x) >= ntiles) return;
+  __shared__ float4 sp[BW_THREADS];
+  __shared__ unsigned long long sk[BW_THREADS];
+  __shared__ int swave[BW_THREADS / 64], sbase[BW_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int seg_end = W.loc_off + W.loc_cap;
+  const int base_i = W.loc_off + int(blockIdx.x) * BW_THREADS, i = base_i + tid;
+  const int *th = tile_heads + W.loc_off / BW_THREADS;
+  int before = 0;
+  for (int b = tid; b < int(blockIdx.x); b += BW_THREADS) before += th[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  const unsigned long long k = keys[i];
+  const bool real = uint32_t(k) != 0xFFFFFFFFu;
+  sk[tid] = k;
+  if (real) sp[tid] = pts[vals[i]];
+  const bool head = bw_is_head(keys, i, k);
+  const unsigned long long hb = __ballot(head);
+  if (lane == 0) { swave[wv] = __popcll(hb); sbase[wv] = before; }
+  __syncthreads();
+  int pos = (sbase[0] + sbase[1]) + (sbase[2] + sbase[3]);
+  for (int q = 0; q < wv; ++q) pos += swave[q];
+  pos += __popcll(hb & ((1ull << lane) - 1ull));
+  if (int(blockIdx.x) == ntiles - 1 && tid == BW_THREADS - 1) {   // the window's last tile knows the total
+    BwVoxOut o;
+    o.count = pos + (head ? 1 : 0);
+    o.params = params[w];
+    o.range_overflow = range_overflow[w];
+    range_overflow[w] = 0;   // clear for the next solve (no fill command in front of it)
+    vout[w] = o;
+  }
+  if (!head) return;
+  float ax = 0, ay = 0, az = 0, ai = 0;
+  int e = tid;
+  while (e < BW_THREADS && sk[e] == k) { const float4 p = sp[e]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++e; }
+  int cnt = e - tid;
+  if (e == BW_THREADS) {
+    int g = base_i + BW_THREADS;
+    while (g < seg_end && keys[g] == k) { const float4 p = pts[vals[g]]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++g; ++cnt; }
+  }
+  const float c = float(cnt);
+  out[W.loc_off + pos] = make_float4(ax / c, ay / c, az / c, ai / c);
+}
+
+void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const unsigned long long *keys_sorted, const uint32_t *vals_sorted,
+                          const float *partial, int *tile_heads, float4 *filtered_all, VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s) {
+  if (B <= 0 || max_cap <= 0) return;
+  const int ntiles = max_cap / BW_THREADS;
+  hipLaunchKernelGGL(k_bw_vox_heads, dim3(ntiles + 1, B), dim3(BW_THREADS), 0, s, win, keys_sorted, partial, tile_heads, params);
+  hipLaunchKernelGGL(k_bw_vox_centroids, dim3(ntiles, B), dim3(BW_THREADS), 0, s, win, local_all, keys_sorted, vals_sorted, tile_heads, filtered_all, params,
+                     range_overflow, out);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// what a solve's feature stage starts from (cloud_kernels.hip: k_solve_setup, per window): feature flags cleared, the newest
+// frame's Gauss-Newton state = its local transform; a window without a newest frame counts as converged from the start
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BW_THREADS) k_bw_setup(const BatchWin *__restrict__ win, uint8_t *__restrict__ valid_all, OdomState *__restrict__ odom,
+                                                        int *__restrict__ n_converged) {
+  const int w = blockIdx.y;
+  const BatchWin &W = win[w];
+  const size_t i = (size_t(blockIdx.x) * BW_THREADS + threadIdx.x) * 16;
+  uint8_t *valid = valid_all + W.slot_base;   // slot_base is a multiple of 16
+  const size_t n = size_t(W.n_slots);
+  if (i + 16 <= n) *reinterpret_cast<uint4 *>(valid + i) = make_uint4(0, 0, 0, 0);
+  else for (size_t k = i; k < n; ++k) valid[k] = 0;
+  if (blockIdx.x == 0) {
+    unsigned *o = reinterpret_cast<unsigned *>(odom + w);
+    const int nw = int(sizeof(OdomState) / 4);
+    const float *T = W.tf[LIO_BW_MAX_STATIC];
+    const bool none = W.newest.M <= 0;
+    if (int(threadIdx.x) < nw) {
+      unsigned v = threadIdx.x < 8 ? __float_as_uint(T[threadIdx.x]) : 0u;
+      if (none && threadIdx.x == offsetof(OdomState, converged) / 4) v = 1u;
+      o[threadIdx.x] = v;
+    }
+    if (none && threadIdx.x == 0) atomicAdd(n_converged, 1);
+  }
+}
+void launch_bw_setup(const BatchWin *win, int B, int max_slots, uint8_t *valid_all, OdomState *odom, int *n_converged, hipStream_t s) {
+  if (B <= 0) return;
+  const int nb = std::max(1, cdiv((long long)max_slots, BW_THREADS * 16));
+  hipLaunchKernelGGL(k_bw_setup, dim3(nb, B), dim3(BW_THREADS), 0, s, win, valid_all, odom, n_converged);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-NN grid (KdTreeFLANN::setInputCloud, Estimator.cc:1544-1545): the counting sort of cloud_kernels.hip per window; the cell
+// tables of the batch are laid end to end and scanned as ONE array, so a table entry is a position in the batch's cell-sorted
+// point array and the search kernels take that array's base as their map.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_count(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                             const float4 *__restrict__ filtered_all, uint32_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ slot, int *__restrict__ cnt_all) {
+  const int w = blockIdx.y;
+  const BatchGrid &G = grid[w];
+  const int i = int(blockIdx.x) * BW_THREADS + threadIdx.x;
+  if (i >= G.n_filtered) return;
+  const int gi = win[w].loc_off + i;
+  const float4 p = filtered_all[gi];
+  const GridDesc &g = G.g;
+  int cx = cell_coord(p.x, g.inv_cell) - g.origin[0];
+  int cy = cell_coord(p.y, g.inv_cell) - g.origin[1];
+  int cz = cell_coord(p.z, g.inv_cell) - g.origin[2];
+  cx = min(max(cx, 0), g.dims[0] - 1); cy = min(max(cy, 0), g.dims[1] - 1); cz = min(max(cz, 0), g.dims[2] - 1);
+  const uint32_t c = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
+  keys[gi] = c;
+  slot[gi] = uint32_t(atomicAdd(&cnt_all[G.cell_off + int(c)], 1));
+}
+__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_place(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                             const float4 *__restrict__ filtered_all, const uint32_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ slot, const int *__restrict__ cells_all,
+                                                             float4 *__restrict__ sorted_all, int *__restrict__ cnt_all) {
+  const int w = blockIdx.y;
+  const BatchGrid &G = grid[w];
+  const int i = int(blockIdx.x) * BW_THREADS + threadIdx.x;
+  if (i >= G.n_filtered) return;
+  const int gi = win[w].loc_off + i;
+  float4 p = filtered_all[gi];
+  p.w = __int_as_float(i);
+  const int c = G.cell_off + int(keys[gi]);
+  sorted_all[cells_all[c] + int(slot[gi])] = p;
+  cnt_all[c] = 0;
+}
+void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, uint32_t *slot, int *cnt_all,
+                          hipStream_t s) {
+  if (B <= 0 || max_filtered <= 0) return;
+  hipLaunchKernelGGL(k_bw_cell_count, dim3(cdiv(max_filtered, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys, slot, cnt_all);
+  LIO_HIP(hipGetLastError());
+}
+void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
+                          const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s) {
+  if (B <= 0 || max_filtered <= 0) return;
+  hipLaunchKernelGGL(k_bw_cell_place, dim3(cdiv(max_filtered, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys, slot, cells_all, sorted_all, cnt_all);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// CalculateFeatures (Estimator.cc:1014-1097) of the frames behind the pivot: grid (blocks of the largest frame, frames, windows)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FEAT_THREADS) k_bw_features(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                             const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all,
+                                                             uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) {
+  const int w = blockIdx.z;
+  const BatchWin &W = win[w];
+  if (int(blockIdx.y) >= W.nstatic) return;
+  const BatchGrid &G = grid[w];
+  const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
+  features_block<false, LIO_BW_LPQ>(W.fr[blockIdx.y], fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
+                                    nullptr);
+}
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, const float4 *sorted_all, const int *cells_all,
+                        uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {
+  if (B <= 0 || max_M <= 0 || max_static <= 0) return;
+  hipLaunchKernelGGL(k_bw_features, dim3(cdiv((long long)max_M * LIO_BW_LPQ, FEAT_THREADS), max_static, B), dim3(FEAT_THREADS), 0, s, win, grid, sorted_all, cells_all,
+                     valid_all, coef_all, score_all);
+  LIO_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// One round of CalculateLaserOdom (Estimator.cc:1242-1359) for every window whose newest frame has not converged: the search /
+// fit / rows launch and the fold + 6x6 step launch of cloud_kernels.hip's launch_odom_round, windows in blockIdx.y / .x
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_bw_odom_round(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                                     const OdomState *__restrict__ odom, const float4 *__restrict__ sorted_all,
+                                                                     const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
+                                                                     float4 *__restrict__ coef_all, float *__restrict__ score_all,
+                                                                     double *__restrict__ partials, int round) {
+  const int w = blockIdx.y;
+  const OdomState &st = odom[w];
+  if (st.converged) return;
+  const BatchWin &W = win[w];
+  if (int(blockIdx.x) >= W.nb_round) return;
+  const BatchGrid &G = grid[w];
+  const float *tp = st.T;
+  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  const Vec3<float> t(tp[4], tp[5], tp[6]);
+  const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
+  const double v = odom_round_block<LIO_BW_LPQ>(fs, W.newest, q, t, sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all, W.newest.slot_off, round,
+                                                W.keep, int(blockIdx.x));
+  if (threadIdx.x < 28) partials[(size_t(W.part_off) + blockIdx.x) * 28 + threadIdx.x] = v;
+}
+__global__ void __launch_bounds__(1024) k_bw_odom_update(const BatchWin *__restrict__ win, OdomState *__restrict__ odom, const double *__restrict__ partials,
+                                                        int round, int *__restrict__ n_converged) {
+  const int w = blockIdx.x;
+  OdomState *st = odom + w;
+  if (st->converged) return;
+  const BatchWin &W = win[w];
+  odom_update_wide_block(partials + size_t(W.part_off) * 28, W.nb_round, st, round, 0, 0, nullptr, HostSignal());
+  if (threadIdx.x == 0 && st->converged) atomicAdd(n_converged, 1);   // (thread 0 wrote the flag itself)
+}
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, int round, OdomState *odom, const float4 *sorted_all, const int *cells_all,
+                          uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials, int *n_converged, hipStream_t s) {
+  if (B <= 0 || max_nb <= 0) return;
+  hipLaunchKernelGGL(k_bw_odom_round, dim3(max_nb, B), dim3(ODOM_ROUND_THREADS), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials,
+                     round);
+  hipLaunchKernelGGL(k_bw_odom_update, dim3(B), dim3(1024), 0, s, win, odom, partials, round, n_converged);
+  LIO_HIP(hipGetLastError());
+}
+
+}  // namespace lio

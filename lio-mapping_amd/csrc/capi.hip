@@ -6,6 +6,7 @@
 #include <new>
 
 #include "../../include/lio_c.h"
+#include "est_batch.h"
 #include "estimator.h"
 #include "rccl_comm.h"
 #include "host_init.h"
@@ -17,7 +18,9 @@
 using namespace lio;
 
 struct lio_pim { std::shared_ptr<Preintegration> p; };
-struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; };
+// (members are destroyed in reverse order: the batch of one that serves lio_est_config.device_solve goes before the estimator it adopted)
+struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; std::unique_ptr<EstimatorBatch> solo; bool adopted = false; };
+struct lio_est_batch { std::unique_ptr<EstimatorBatch> b; std::vector<lio_est *> members; };
 struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
 struct lio_map { std::unique_ptr<MappingDev> m; };
@@ -565,7 +568,8 @@ lio_est *lio_est_create(const lio_est_config *c) {
   e.pim.acc_n = c->acc_n; e.pim.gyr_n = c->gyr_n; e.pim.acc_w = c->acc_w; e.pim.gyr_w = c->gyr_w; e.pim.g_norm = c->g_norm;
   e.max_num_iterations = c->max_num_iterations; e.max_solver_time = c->max_solver_time; e.extrinsic_stage = c->extrinsic_stage;
   e.init_window_factor = c->init_window_factor > 0 ? c->init_window_factor : 1;
-  e.device_solve = c->device_solve != 0; e.device_marg = c->device_marg != 0; e.inline_marg = c->inline_marg != 0;
+  e.device_solve = c->device_solve != 0; e.inline_marg = c->inline_marg != 0;
+  for (const char *name : {"LIO_DEVICE_SOLVE", "LIO_DEVICE_MARG"}) if (const char *v = std::getenv(name)) { if (std::atoi(v) != 0) e.device_solve = true; else if (std::string(name) == "LIO_DEVICE_SOLVE") e.device_solve = false; }
   e.stream_sync = c->stream_sync != 0;
   e.moments_form = (c->moments_form == 1 || c->moments_form == 2) ? c->moments_form : 0;
   e.resident_moments = (c->resident_moments >= 1 && c->resident_moments <= 3) ? c->resident_moments : 0;
@@ -573,7 +577,15 @@ lio_est *lio_est_create(const lio_est_config *c) {
   h->map_cfg.corner_filter_size = c->corner_filter_size; h->map_cfg.surf_filter_size = c->surf_filter_size;
   h->map_cfg.min_match_sq_dis = c->min_match_sq_dis; h->map_cfg.min_plane_dis = c->min_plane_dis; h->map_cfg.num_max_iterations = 10;
   h->map_cfg.map_builder = 0; h->map_cfg.enable_4d = 1; h->map_cfg.skip_count = 2;
-  int rc = guarded([&] { h->e.reset(new Estimator(e)); return LIO_OK; });
+  int rc = guarded([&] {
+    h->e.reset(new Estimator(e));
+    if (e.device_solve) {   // a batch of one window: the device loop and the device marginalization serve this handle's solves
+      h->solo.reset(new EstimatorBatch({h->e.get()}));
+      EstimatorBatch *b = h->solo.get();
+      h->e->solve_hook_ = [b](lio_solve_report *rep) { b->Solve(rep); return true; };
+    }
+    return LIO_OK;
+  });
   if (rc != LIO_OK) { delete h; return nullptr; }
   return h;
 }
@@ -810,6 +822,11 @@ int lio_est_restore(lio_est *h) {
   return guarded([&] { return h->e->Restore() ? LIO_OK : LIO_ERR_STATE; });
 }
 
+int lio_est_copy_snapshot(lio_est *dst, lio_est *src) {
+  if (!dst || !src) return LIO_ERR_ARG;
+  return guarded([&] { return dst->e->CopySnapshotOf(*src->e) ? LIO_OK : LIO_ERR_STATE; });
+}
+
 int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
   if (!h || steps < 0) return LIO_ERR_ARG;
   for (int k = 0; k < steps; ++k) {
@@ -818,6 +835,63 @@ int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
     rc = lio_est_solve_optimization(h, rep);
     if (rc != LIO_OK) return rc;
   }
+  return LIO_OK;
+}
+
+// ---------------------------------------------------------------- batched windows
+lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
+  if (!windows || n < 1 || n > 65535) return nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (!windows[i] || windows[i]->adopted || windows[i]->solo) return nullptr;
+    for (int j = 0; j < i; ++j) if (windows[j] == windows[i]) return nullptr;
+  }
+  lio_est_batch *h = new (std::nothrow) lio_est_batch;
+  if (!h) return nullptr;
+  int rc = guarded([&] {
+    std::vector<Estimator *> es;
+    for (int i = 0; i < n; ++i) es.push_back(windows[i]->e.get());
+    h->b.reset(new EstimatorBatch(es));
+    return LIO_OK;
+  });
+  if (rc != LIO_OK) { delete h; return nullptr; }
+  for (int i = 0; i < n; ++i) { windows[i]->adopted = true; h->members.push_back(windows[i]); }
+  return h;
+}
+void lio_est_batch_destroy(lio_est_batch *h) {
+  if (!h) return;
+  h->b.reset();
+  for (lio_est *m : h->members) m->adopted = false;
+  delete h;
+}
+int lio_est_batch_size(const lio_est_batch *h) { return h ? h->b->size() : 0; }
+int lio_est_batch_solve(lio_est_batch *h, lio_solve_report *reps) {
+  if (!h) return LIO_ERR_ARG;
+  for (lio_est *m : h->members) if (!m->e->inited_) return LIO_ERR_STATE;
+  return guarded([&] { h->b->Solve(reps); return LIO_OK; });
+}
+int lio_est_batch_solve_restored(lio_est_batch *h, int steps, lio_solve_report *reps) {
+  if (!h || steps < 0) return LIO_ERR_ARG;
+  return guarded([&] {
+    for (int k = 0; k < steps; ++k) {
+      for (lio_est *m : h->members) if (!m->e->Restore()) return int(LIO_ERR_STATE);
+      h->b->Solve(reps);
+    }
+    h->b->Sync();
+    return int(LIO_OK);
+  });
+}
+int lio_est_batch_sync(lio_est_batch *h) {
+  if (!h) return LIO_ERR_ARG;
+  return guarded([&] { h->b->Sync(); return LIO_OK; });
+}
+int lio_est_batch_get_clock(const lio_est_batch *h, double *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  BatchClock c;
+  const int rc = guarded([&] { c = const_cast<lio_est_batch *>(h)->b->clock(); return LIO_OK; });
+  if (rc != LIO_OK) return rc;
+  for (int k = 0; k < 6; ++k) out[10 + k] = c.dev[k];
+  out[0] = c.describe; out[1] = c.map; out[2] = c.grid_features; out[3] = c.pack; out[4] = c.solve; out[5] = c.finish; out[6] = c.fallback; out[7] = c.total;
+  out[8] = c.n_device; out[9] = c.rounds;
   return LIO_OK;
 }
 

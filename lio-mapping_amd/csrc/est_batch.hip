@@ -1,0 +1,356 @@
+// est_batch.hip — host orchestration of the batched solve (see est_batch.h).  The kernels: batch_kernels.hip (map / feature stages),
+// solve_kernels.hip (launch A / launch B of the trust-region loop), marg_kernels.hip (marginalization).
+#include "est_batch.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace lio {
+
+static double bnow_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+template <typename T> static void pinned(T *&p, size_t n) { LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(T) * std::max<size_t>(n, 1))); std::memset(static_cast<void *>(p), 0, sizeof(T) * std::max<size_t>(n, 1)); }
+
+EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(members) {
+  if (m_.empty()) throw std::runtime_error("EstimatorBatch: no windows");
+  for (Estimator *e : m_) if (!e) throw std::runtime_error("EstimatorBatch: null window");
+  const size_t B = m_.size();
+  LIO_HIP(hipStreamCreate(&stream_));
+  for (hipEvent_t &e : ev_) LIO_HIP(hipEventCreate(&e));
+  win_.resize(B);
+  for (size_t w = 0; w < B; ++w) { win_[w].e = m_[w]; m_[w]->AdoptStream(stream_); }
+  pinned(h_win_, B); pinned(h_grid_, B); pinned(h_vout_, B); pinned(h_odom_, B); pinned(h_bs_, B); pinned(h_pb_, B); pinned(h_st_, B); pinned(h_mg_, B);
+  pinned(h_prior_, B * ds_prior_mats_size(MARG_MAX_N)); pinned(h_nconv_, 4);
+  d_win_.reserve(B); d_grid_.reserve(B); d_vout_.reserve(B); d_odom_.reserve(B); d_bs_.reserve(B); d_pb_.reserve(B); d_st_.reserve(B); d_mg_.reserve(B);
+  range_overflow_.reserve(B); vparams_.reserve(B); nconv_.reserve(4);
+  LIO_HIP(hipMemsetAsync(range_overflow_.p, 0, sizeof(int) * range_overflow_.cap, stream_));
+  LIO_HIP(hipMemsetAsync(d_mg_.p, 0, sizeof(DevMarg) * d_mg_.cap, stream_));
+  // the scratch slab of a window (doubles)
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 7) & ~size_t(7); return at; };
+  lay_.prior[0] = take(ds_prior_mats_size(MARG_MAX_N)); lay_.prior[1] = take(ds_prior_mats_size(MARG_MAX_N));
+  lay_.imu = take(size_t(DS_MAX_WO) * DS_IMU_OUT); lay_.lmap = take(size_t(DS_MAX_WO) * DS_LMAP_OUT);
+  lay_.prior_out = take(MARG_MAX_N + 8); lay_.exprior = take(DS_EXP_OUT);
+  lay_.Hcur = take(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); lay_.Sbuf = take(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT); lay_.prof = take(32);
+  lay_.marg_imu = take(DS_IMU_OUT); lay_.marg_lmap = take(size_t(DS_MAX_WO) * DS_LMAP_OUT); lay_.marg_prior_out = take(MARG_MAX_N + 8);
+  { const size_t N = MARG_MAX_M + MARG_MAX_N; lay_.marg_A = take(N * N + N); }
+  lay_.marg_info = take(MARG_MAX_N + 8);
+  lay_.total = o;
+  slab_.reserve(B * lay_.total);
+  LIO_HIP(hipMemsetAsync(slab_.p, 0, sizeof(double) * slab_.cap, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
+}
+
+EstimatorBatch::~EstimatorBatch() {
+  try {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (size_t w = 0; w < win_.size(); ++w)
+      for (int k = 0; k < 2; ++k) if (win_[w].dev_prior[k]) win_[w].dev_prior[k]->materialize();   // nobody may be left holding a shell
+    for (Estimator *e : m_) { e->solve_hook_ = nullptr; e->ReleaseAdoptedStream(); }
+  } catch (...) {}
+  for (void *p : {static_cast<void *>(h_win_), static_cast<void *>(h_grid_), static_cast<void *>(h_vout_), static_cast<void *>(h_odom_), static_cast<void *>(h_bs_),
+                  static_cast<void *>(h_pb_), static_cast<void *>(h_st_), static_cast<void *>(h_mg_), static_cast<void *>(h_prior_), static_cast<void *>(h_nconv_)})
+    if (p) (void)hipHostFree(p);
+  for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+const BatchClock &EstimatorBatch::clock() {
+  if (ev_valid_) {
+    LIO_HIP(hipStreamSynchronize(stream_));
+    for (int k = 0; k < 6; ++k) {
+      float ms = 0;
+      clk_.dev[k] = hipEventElapsedTime(&ms, ev_[k], ev_[k + 1]) == hipSuccess ? double(ms) : 0.0;
+    }
+    ev_valid_ = false;
+  }
+  return clk_;
+}
+
+void EstimatorBatch::Sync() { LIO_HIP(hipStreamSynchronize(stream_)); }
+
+// the matrices of the prior held in device buffer `buf` of window w -> pr (the fetch of a MargPrior shell)
+void EstimatorBatch::FetchPrior(int w, int buf, MargPrior &pr) {
+  const size_t n = size_t(pr.n);
+  std::vector<double> h(ds_prior_mats_size(pr.n));
+  LIO_HIP(hipStreamSynchronize(stream_));
+  LIO_HIP(hipMemcpy(h.data(), slab_.p + size_t(w) * lay_.total + lay_.prior[buf], h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  pr.JtJ = DMat(pr.n, pr.n); pr.lin_jac = DMat(pr.n, pr.n); pr.lin_res.assign(n, 0.0); pr.Jtr0.assign(n, 0.0);
+  std::memcpy(pr.JtJ.a.data(), h.data(), sizeof(double) * n * n);
+  std::memcpy(pr.lin_jac.a.data(), h.data() + n * n, sizeof(double) * n * n);
+  std::memcpy(pr.lin_res.data(), h.data() + 2 * n * n, sizeof(double) * n);
+  std::memcpy(pr.Jtr0.data(), h.data() + 2 * n * n + n, sizeof(double) * n);
+}
+// buffer `buf` of window w is about to be overwritten: whoever else still holds its prior as a shell gets the matrices first
+void EstimatorBatch::Materialize(int w, int buf) {
+  std::shared_ptr<MargPrior> &p = win_[w].dev_prior[buf];
+  if (p && p->on_device && p.use_count() > 1) p->materialize();
+  p.reset();
+}
+
+int EstimatorBatch::Solve(lio_solve_report *reps) {
+  const double t0 = bnow_ms();
+  const int B = size();
+  hipStream_t s = stream_;
+  std::vector<lio_solve_report> local;
+  if (!reps) { local.resize(B); reps = local.data(); }
+  std::memset(static_cast<void *>(reps), 0, sizeof(lio_solve_report) * B);
+  clk_ = BatchClock();
+  ev_valid_ = false;
+  // ------------------------------------------------------------------------------------------------ describe
+  int off = 0, slot = 0, part_rows = 0, max_cap = 0, max_slots = 0, max_M = 0, max_static = 0, max_nb = 0;
+  for (int w = 0; w < B; ++w) {
+    Win &Wn = win_[w];
+    Estimator *e = Wn.e;
+    BatchWin &bw = h_win_[w];
+    Wn.device = e->BatchEligible();
+    Wn.prior_used.reset();
+    if (Wn.device) {
+      e->JoinMarg(false);
+      e->BatchDescribe(bw);
+    } else {
+      std::memset(&bw, 0, sizeof(bw));
+      bw.inv_leaf = 1.f;
+    }
+    bw.loc_off = off; bw.loc_cap = round_up(std::max(bw.n_local, 1), 256); off += bw.loc_cap;
+    bw.slot_base = slot; slot += round_up(bw.n_slots, 16);
+    for (int k = 0; k < bw.nstatic; ++k) { bw.fr[k].slot_off += bw.slot_base; max_M = std::max(max_M, bw.fr[k].M); }
+    bw.newest.slot_off += bw.slot_base;
+    bw.part_off = part_rows; part_rows += bw.nb_round;
+    max_cap = std::max(max_cap, bw.loc_cap); max_slots = std::max(max_slots, bw.n_slots); max_static = std::max(max_static, bw.nstatic);
+    max_nb = std::max(max_nb, bw.nb_round);
+  }
+  const size_t N = size_t(off);
+  if (N > size_t(INT_MAX) / 2) throw std::runtime_error("EstimatorBatch: the batch's local maps exceed 2^30 points");
+  local_all_.reserve(N, s); filtered_all_.reserve(N, s); sorted_all_.reserve(N, s);
+  keys64_.reserve(N, s); keys64b_.reserve(N, s); vals_.reserve(N, s); valsb_.reserve(N, s); ckeys_.reserve(N, s); cslot_.reserve(N, s);
+  bounds_partial_.reserve(N / 256 * 8, s); tile_heads_.reserve(N / 256, s);
+  valid_all_.reserve(std::max(slot, 16), s); coef_all_.reserve(std::max(slot, 16), s); score_all_.reserve(std::max(slot, 16), s);
+  odom_partials_.reserve(size_t(std::max(part_rows, 1)) * 28, s);
+  const double t1 = bnow_ms();
+  clk_.describe = t1 - t0;
+  // ------------------------------------------------------------------------------------------------ BuildLocalMap
+  LIO_HIP(hipEventRecord(ev_[0], s));
+  LIO_HIP(hipMemcpyAsync(d_win_.p, h_win_, sizeof(BatchWin) * B, hipMemcpyHostToDevice, s));
+  LIO_HIP(hipMemsetAsync(nconv_.p, 0, sizeof(int), s));
+  launch_bw_setup(d_win_.p, B, max_slots, valid_all_.p, d_odom_.p, nconv_.p, s);
+  launch_bw_concat_keys(d_win_.p, B, max_cap, local_all_.p, keys64_.p, vals_.p, bounds_partial_.p, range_overflow_.p, s);
+  {
+    int wbits = 0;
+    while ((1 << wbits) < B) ++wbits;
+    size_t tmp_bytes = 0;
+    LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys64_.p, keys64b_.p, vals_.p, valsb_.p, N, 0, 32 + wbits, s));
+    sort_tmp_.reserve(tmp_bytes + 256, s);
+    LIO_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp_bytes, keys64_.p, keys64b_.p, vals_.p, valsb_.p, N, 0, 32 + wbits, s));
+  }
+  launch_bw_vox_finish(d_win_.p, B, max_cap, local_all_.p, keys64b_.p, valsb_.p, bounds_partial_.p, tile_heads_.p, filtered_all_.p, vparams_.p, range_overflow_.p,
+                       d_vout_.p, s);
+  LIO_HIP(hipMemcpyAsync(h_vout_, d_vout_.p, sizeof(BwVoxOut) * B, hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipEventRecord(ev_[1], s));
+  LIO_HIP(hipStreamSynchronize(s));
+  const double t2 = bnow_ms();
+  clk_.map = t2 - t1;
+  // ------------------------------------------------------------------------------------------------ K-NN grids, features, rounds
+  size_t cell_total = 0;
+  int max_filtered = 0;
+  for (int w = 0; w < B; ++w) {
+    Win &Wn = win_[w];
+    BatchGrid &G = h_grid_[w];
+    std::memset(&G, 0, sizeof(G));
+    const BwVoxOut &vo = h_vout_[w];
+    size_t ncells = 1;
+    G.g.dims[0] = G.g.dims[1] = G.g.dims[2] = 1;
+    G.g.inv_cell = 1.f;
+    if (Wn.device && (vo.params.overflow || vo.range_overflow)) Wn.device = false;   // PCL's own index / "leaf too small": the single-window path has those forms
+    if (Wn.device && vo.count > 0) {
+      const float cell = std::sqrt(Wn.e->cfg_.min_match_sq_dis) * 1.0001f + 1e-6f;
+      G.g.inv_cell = 1.0f / cell;
+      for (int d = 0; d < 3; ++d) {
+        const int lo = int(std::floor(vo.params.mn[d] * G.g.inv_cell)) - 1, hi = int(std::floor(vo.params.mx[d] * G.g.inv_cell)) + 1;
+        G.g.origin[d] = lo; G.g.dims[d] = hi - lo + 1;
+        ncells *= size_t(G.g.dims[d]);
+      }
+      if (ncells > (size_t(1) << 28)) { Wn.device = false; ncells = 1; G.g.dims[0] = G.g.dims[1] = G.g.dims[2] = 1; }
+      else { G.n_filtered = vo.count; G.g.n_points = vo.count; }
+    }
+    G.cell_off = int(cell_total);
+    cell_total += ncells + 1;
+    max_filtered = std::max(max_filtered, G.n_filtered);
+    reps[w].n_local_map = G.n_filtered;
+  }
+  if (cell_total > size_t(INT_MAX)) throw std::runtime_error("EstimatorBatch: the batch's cell tables exceed 2^31 entries");
+  cells_all_.reserve(cell_total, s);
+  if (cnt_all_.cap < cell_total || cnt_dirty_) {
+    cnt_all_.reserve(cell_total, s);
+    LIO_HIP(hipMemsetAsync(cnt_all_.p, 0, cnt_all_.cap * sizeof(int), s));
+  }
+  cnt_dirty_ = true;
+  LIO_HIP(hipMemcpyAsync(d_grid_.p, h_grid_, sizeof(BatchGrid) * B, hipMemcpyHostToDevice, s));
+  launch_bw_cell_count(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cnt_all_.p, s);
+  {
+    size_t tmp_bytes = 0;
+    LIO_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_all_.p, cells_all_.p, 0, cell_total, rocprim::plus<int>(), s));
+    scan_tmp_.reserve(tmp_bytes + 256, s);
+    LIO_HIP(rocprim::exclusive_scan(scan_tmp_.p, tmp_bytes, cnt_all_.p, cells_all_.p, 0, cell_total, rocprim::plus<int>(), s));
+  }
+  launch_bw_cell_place(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cells_all_.p, sorted_all_.p, cnt_all_.p, s);
+  cnt_dirty_ = false;
+  LIO_HIP(hipEventRecord(ev_[2], s));
+  launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
+  LIO_HIP(hipEventRecord(ev_[3], s));
+  int round = 0;
+  for (; round < 3; ++round)
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+                         nconv_.p, s);
+  // ---- while the device searches: the problems of Estimator.cc:1660-1921, packed for the device loop
+  const double t3a = bnow_ms();
+  int max_bpf = 1, max_wo = 1, max_npad = DS_NB;
+  size_t part_total = 0;
+  for (int w = 0; w < B; ++w) {
+    Win &Wn = win_[w];
+    if (!Wn.device) continue;
+    Estimator *e = Wn.e;
+    int ms = 0;
+    for (int i = e->W_ - e->Wo_ + 1; i <= e->W_; ++i) ms = std::max(ms, e->nslots_[i]);
+    Wn.max_slots = ms;
+    Wn.bpf = batch_blocks_per_frame(ms);
+    if (e->total_slots_ == 0 || !e->BatchPackProblem(Wn.bpf, h_pb_[w], h_st_[w], &Wn.prior_used)) { Wn.device = false; continue; }
+    Wn.part_off = part_total;
+    part_total += size_t(e->Wo_) * Wn.bpf * LIO_MOMENT_OUT;
+    max_bpf = std::max(max_bpf, Wn.bpf); max_wo = std::max(max_wo, e->Wo_); max_npad = std::max(max_npad, h_pb_[w].n_pad);
+    // the prior's matrices on the device: already there (the previous solve's marginalization left them, or an earlier upload), or sent now
+    if (Wn.prior_used) {
+      int k = -1;
+      for (int q = 0; q < 2; ++q) if (Wn.dev_prior[q] == Wn.prior_used) k = q;
+      if (k < 0) {
+        k = 0;
+        Materialize(w, k);
+        MargPrior &pr = *Wn.prior_used;
+        pr.materialize();
+        const size_t n = size_t(pr.n);
+        double *h = h_prior_ + size_t(w) * ds_prior_mats_size(MARG_MAX_N);
+        std::memcpy(h, pr.JtJ.a.data(), sizeof(double) * n * n);
+        std::memcpy(h + n * n, pr.lin_jac.a.data(), sizeof(double) * n * n);
+        std::memcpy(h + 2 * n * n, pr.lin_res.data(), sizeof(double) * n);
+        std::memcpy(h + 2 * n * n + n, pr.Jtr0.data(), sizeof(double) * n);
+        LIO_HIP(hipMemcpyAsync(slab_.p + size_t(w) * lay_.total + lay_.prior[k], h, sizeof(double) * ds_prior_mats_size(pr.n), hipMemcpyHostToDevice, s));
+        Wn.dev_prior[k] = Wn.prior_used;
+      }
+      Wn.cur = k;
+    } else {
+      Wn.cur = 0;
+    }
+  }
+  LIO_HIP(hipMemcpyAsync(d_pb_.p, h_pb_, sizeof(DevProblem) * B, hipMemcpyHostToDevice, s));
+  LIO_HIP(hipMemcpyAsync(d_st_.p, h_st_, sizeof(DevState) * B, hipMemcpyHostToDevice, s));
+  clk_.pack = bnow_ms() - t3a;
+  // ---- the remaining rounds, with a look at the number of converged windows every second round
+  for (; round < 10; ++round) {
+    if (round >= 3 && round % 2 == 1) {
+      LIO_HIP(hipMemcpyAsync(h_nconv_, nconv_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      LIO_HIP(hipStreamSynchronize(s));
+      if (*h_nconv_ >= B) break;
+    }
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+                         nconv_.p, s);
+  }
+  clk_.rounds = round;
+  LIO_HIP(hipEventRecord(ev_[4], s));
+  LIO_HIP(hipMemcpyAsync(h_odom_, d_odom_.p, sizeof(OdomState) * B, hipMemcpyDeviceToHost, s));
+  LIO_HIP(hipStreamSynchronize(s));
+  const double t3 = bnow_ms();
+  clk_.grid_features = t3 - t2;
+  // ------------------------------------------------------------------------------------------------ the trust-region loop
+  partials_.reserve(std::max<size_t>(part_total, 1), s);
+  int max_it = 0, n_dev = 0;
+  for (int w = 0; w < B; ++w) {
+    Win &Wn = win_[w];
+    BatchSolve &S = h_bs_[w];
+    std::memset(static_cast<void *>(&S), 0, sizeof(S));
+    S.marg = d_mg_.p + w;
+    if (!Wn.device) continue;
+    Estimator *e = Wn.e;
+    e->BatchSetOdom(h_odom_[w]);
+    const int pivot = e->W_ - e->Wo_;
+    double *slab = slab_.p + size_t(w) * lay_.total;
+    S.active = 1; S.nframes = e->Wo_; S.bpf = Wn.bpf;
+    for (int i = 1; i <= e->Wo_; ++i) {
+      MomentFrame &f = S.fr[i - 1];
+      const int idx = pivot + i;
+      f.stack = e->stacks_[idx].buf.p; f.M = std::max<int>(1, int(e->stacks_[idx].n));
+      f.slot_off = h_win_[w].slot_base + e->slot_off_[idx]; f.nslots = e->nslots_[idx]; f.slot_begin = 0; f.slot_end = f.nslots;
+    }
+    S.pb = d_pb_.p + w; S.st = d_st_.p + w;
+    S.prior_mats = slab + lay_.prior[Wn.cur]; S.next_prior_mats = slab + lay_.prior[1 - Wn.cur];
+    S.partials = partials_.p + Wn.part_off;
+    S.imu_out = slab + lay_.imu; S.lmap = slab + lay_.lmap; S.prior_out = slab + lay_.prior_out; S.exprior_out = slab + lay_.exprior;
+    S.Hcur = slab + lay_.Hcur; S.S_buf = slab + lay_.Sbuf; S.prof = nullptr;
+    S.marg_imu = slab + lay_.marg_imu; S.marg_lmap = slab + lay_.marg_lmap; S.marg_prior_out = slab + lay_.marg_prior_out;
+    S.marg_A = slab + lay_.marg_A; S.marg_info = slab + lay_.marg_info;
+    max_it = std::max(max_it, e->cfg_.max_num_iterations);
+    ++n_dev;
+  }
+  LIO_HIP(hipMemcpyAsync(d_bs_.p, h_bs_, sizeof(BatchSolve) * B, hipMemcpyHostToDevice, s));
+  if (n_dev > 0) {
+    // iteration k evaluates candidate k (k = 0: the initial point); a window that is done costs its blocks one load each
+    for (int k = 0; k <= max_it; ++k) launch_bw_solve_iteration(d_bs_.p, B, max_bpf, max_wo, max_npad, valid_all_.p, coef_all_.p, s);
+    LIO_HIP(hipEventRecord(ev_[5], s));
+    LIO_HIP(hipMemcpyAsync(h_st_, d_st_.p, sizeof(DevState) * B, hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipStreamSynchronize(s));
+  } else {
+    LIO_HIP(hipEventRecord(ev_[5], s));
+  }
+  clk_.iterations = max_it + 1;
+  const double t4 = bnow_ms();
+  clk_.solve = t4 - t3;
+  // ------------------------------------------------------------------------------------------------ write-back, marginalization
+  int max_n = 1, n_marg = 0;
+  std::vector<int> host_path;
+  for (int w = 0; w < B; ++w) {
+    Win &Wn = win_[w];
+    DevMarg &mg = h_mg_[w];
+    std::memset(&mg, 0, sizeof(mg));
+    if (!Wn.device) { host_path.push_back(w); continue; }
+    const DevState &st = h_st_[w];
+    if (st.need_host || !st.started) { Wn.device = false; host_path.push_back(w); continue; }
+    Estimator *e = Wn.e;
+    std::shared_ptr<MargPrior> shell;
+    if (e->BatchFinish(st, Wn.prior_used, reps[w], mg, &shell)) {
+      const int nb = 1 - Wn.cur;
+      Materialize(w, nb);
+      shell->on_device = true;
+      shell->fetch = [this, w, nb](MargPrior &pr) { FetchPrior(w, nb, pr); };
+      Wn.dev_prior[nb] = shell;
+      e->last_marg_ = shell;
+      max_n = std::max(max_n, mg.n);
+      ++n_marg;
+    }
+    Wn.prior_used.reset();
+  }
+  clk_.n_device = B - int(host_path.size()); clk_.n_host = int(host_path.size());
+  if (n_marg > 0) {
+    LIO_HIP(hipMemcpyAsync(d_mg_.p, h_mg_, sizeof(DevMarg) * B, hipMemcpyHostToDevice, s));
+    launch_bw_marginalize(d_bs_.p, B, max_wo, max_n, s);
+  }
+  LIO_HIP(hipEventRecord(ev_[6], s));
+  ev_valid_ = true;
+  const double t5 = bnow_ms();
+  clk_.finish = t5 - t4;
+  // ------------------------------------------------------------------------------------------------ windows the device loop did not take
+  for (int w : host_path) win_[w].e->SolveOptimizationHost(&reps[w]);
+  const double t6 = bnow_ms();
+  clk_.fallback = t6 - t5;
+  clk_.total = t6 - t0;
+  for (int w = 0; w < B; ++w) {
+    if (!win_[w].device) continue;
+    lio_solve_report &R = reps[w];
+    R.ms_build_map = clk_.map; R.ms_features = clk_.grid_features; R.ms_prepare = clk_.describe + clk_.pack; R.ms_opt = clk_.solve; R.ms_marg = clk_.finish;
+    R.ms_total = t5 - t0;
+  }
+  return B;
+}
+
+}  // namespace lio

@@ -15,7 +15,7 @@
 #include "cloud_kernels.h"
 #include "host_init.h"
 #include "host_solver.h"
-#include "marg_kernels.h"
+#include "batch_kernels.h"
 #include "solve_step.h"
 
 namespace lio {
@@ -35,7 +35,7 @@ struct EstConfig {
   int extrinsic_stage = 2;
   int init_window_factor = 3;
   // execution switches (lio_est_config's trailing block; environment overrides are applied in the constructor)
-  bool device_solve = false, device_marg = false, inline_marg = false, stream_sync = false;
+  bool device_solve = false, inline_marg = false, stream_sync = false;
   int moments_form = 0, resident_moments = 0;
 };
 
@@ -164,9 +164,27 @@ class Estimator {
                  bool surf_on_device = false);
   bool RunInitialization();
   void SetStatesFromLaser();
-  bool SolveOptimization(lio_solve_report *rep);
+  // Estimator.cc:1648-2438.  With a hook installed (lio_est_config.device_solve: a batch of one window, est_batch.h) the whole
+  // solve runs there; SolveOptimizationHost is the default path (device kernels + the trust-region loop on the host).
+  bool SolveOptimization(lio_solve_report *rep) { return solve_hook_ ? solve_hook_(rep) : SolveOptimizationHost(rep); }
+  bool SolveOptimizationHost(lio_solve_report *rep);
+  std::function<bool(lio_solve_report *)> solve_hook_;
   void SlideWindow();
   void BuildLocalMap(lio_solve_report *rep);
+
+  // ---- the per-window host halves of a BATCHED solve (est_batch.h drives them; the device work between them is one launch per
+  // stage over all windows of the batch)
+  bool BatchEligible() const;
+  // host half of BuildLocalMap (Estimator.cc:1361-1646): segments of the local map, frames, local transforms, slot layout.
+  // Offsets are the window's own (from 0); the batch shifts them to its arrays.
+  void BatchDescribe(BatchWin &bw);
+  // the problem of Estimator.cc:1660-1921 as the device loop reads it; *prior = the marginalization prior the problem uses.
+  // false: this window's problem does not fit the device loop.
+  bool BatchPackProblem(int bpf, DevProblem &pb, DevState &st, std::shared_ptr<MargPrior> *prior);
+  // after the device loop: DoubleToVector, the report, convergence_flag_.  true: the window marginalises now — mg is filled
+  // (linearisation point, layout) and *shell is the new prior without its matrices (they are computed on the device).
+  bool BatchFinish(const DevState &st, const std::shared_ptr<MargPrior> &prior_used, lio_solve_report &R, DevMarg &mg, std::shared_ptr<MargPrior> *shell);
+  void BatchSetOdom(const OdomState &st);   // CalculateLaserOdom's outcome as the rounds left it (Estimator.cc:1242-1359)
 
   // test hooks
   void SetWindow(const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs, const double g[3]);
@@ -178,6 +196,9 @@ class Estimator {
   size_t GetFeatures(int frame, double *pt, double *co, double *sc);
   void Snapshot();
   bool Restore();
+  // this handle's snapshot <- a copy of src's (same configuration; clouds copied into buffers of this handle): B windows of the
+  // same data at distinct addresses for the batched measurements, without replaying the sequence B times
+  bool CopySnapshotOf(Estimator &src);
   // B copies of the current window's lidar factors through ONE moments launch (distinct memory per copy); returns the average
   // launch-pair duration in ms and the algorithmic bytes per launch.  false when no features have been built yet.
   bool BenchBatchedMoments(int n_windows, int reps, double *avg_ms, double *bytes);
@@ -203,7 +224,9 @@ class Estimator {
   MargWorker marg_worker_;
   bool async_marg_ = true;                  // LIO_ASYNC_MARG=0 computes it inside SolveOptimization
   unsigned marg_epoch_ = 0, marg_task_epoch_ = 0;   // Restore() bumps the epoch: a result computed for a discarded state is dropped
-  void JoinMarg() {
+  // materialize: a prior that a batched solve left on the device (MargPrior::on_device) is brought to the host as well — every
+  // reader of its matrices on the host needs that; the batch itself, which feeds the next solve from the device copy, does not
+  void JoinMarg(bool materialize = true) {
     std::shared_ptr<MargPrior> r;
     const bool discard = marg_task_epoch_ != marg_epoch_;
     try {
@@ -211,6 +234,7 @@ class Estimator {
     } catch (...) {
       if (!discard) throw;  // a failure of a task whose result is dropped anyway (state restored meanwhile) is not the caller's problem
     }
+    if (materialize && last_marg_) last_marg_->materialize();
   }
   std::vector<std::shared_ptr<Preintegration>> pre_integrations_;
   std::shared_ptr<Preintegration> tmp_pre_integration_;
@@ -225,14 +249,12 @@ class Estimator {
   bool Sharded() const { return shard_world_ > 1 && (allreduce_ || rccl_comm_); }
 
  private:
+  friend class EstimatorBatch;
   struct HostState;  // snapshot payload
   Rigidd LidarPose(int i, const Rigidd &lb) const;
   Rigidf RelTransform(int i, const Rigidd &T_pivot, const Rigidd &lb) const;
   void VectorToParams(WindowParams &P) const;
   void ParamsToVector(const WindowParams &P);
-  // The whole trust-region loop on the device (solve_step.h): two launches per iteration, no host round trip.  false: the
-  // problem does not fit that path (or changed shape at the first evaluation) and the caller runs the host solver instead.
-  bool SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &sum, WindowSystem::Costs &costs0, bool &turn_off);
   void FillMomentArgs(MomentArgs &ma, int &max_slots) const;
   void LidarEval(const WindowParams &P, std::vector<FrameMoments> &m);
   void LidarLaunch(const WindowParams &P);             // asynchronous part: frame transforms + moments kernels
@@ -242,6 +264,10 @@ class Estimator {
   void PushState(int from);
 
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  bool owns_stream_ = true;   // false once a batch has adopted the handle: its work is enqueued on the batch's stream
+  void AdoptStream(hipStream_t s);
+  void ReleaseAdoptedStream();   // the batch is gone: the handle works on a stream of its own again
+  void FusePivotOnce();       // A.15: frames 0 .. pivot fused into the pivot's stack, the first time a local map is built
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::vector<DeviceCloud> stacks_;
   std::vector<size_t> size_surf_stack_;
@@ -301,17 +327,6 @@ class Estimator {
   void ResidentEnd();
   double ResidentBusyUs(int *passes, double *bytes) const { if (passes) *passes = res_passes_total_; if (bytes) *bytes = res_bytes_; return res_busy_us_; }
  private:
-  // Device-resident dogleg (solve_step.h), opt-in with LIO_DEVICE_SOLVE=1.  Measured on the MI355X at D = 96 it is SLOWER than
-  // the host loop for one window (launch B = one workgroup: 150 us per iteration against the host's 17 us of assemble +
-  // Cholesky + step), so the host loop stays the default; it exists for hosts that drive many windows per
-  // thread, where the estimator's host thread is the bottleneck.
-  bool device_solve_ = false;
-  double dev_n_lidar_ = -1;                 // valid lidar factors at the last device evaluation (-1: the host path ran)
-  struct DsHost { DevProblem pb; DevState st; double prior_mats[2 * 64 * 64 + 2 * 64]; double S_buf[2 * DS_MAX_WO * LIO_MOMENT_OUT]; };
-  DsHost *h_ds_ = nullptr;                  // pinned staging: problem + state up, state + moments back
-  DBuf<char> d_ds_;                         // device image of {DevProblem, DevState, prior_mats}
-  DBuf<double> d_ds_imu_, d_ds_lmap_, d_ds_prior_out_, d_ds_exprior_out_, d_ds_Hcur_, d_ds_Sbuf_;
-  DBuf<long long> d_ds_prof_;
   double *h_moment_out_ = nullptr;  // pinned
   OdomState *h_odom_ = nullptr;     // pinned landing zone of the laser-odom state peeks
   // Completion words (dev.h: HostSignal) in coherent pinned memory: [0, 96) one per block of k_moment_reduce, [128] the
@@ -319,11 +334,7 @@ class Estimator {
   unsigned *h_signal_ = nullptr;
   unsigned signal_seq_[2] = {0, 0};
   bool host_signal_ = true;
-  // Marginalization's dense tail on the device (marg_kernels.h), opt-in with LIO_DEVICE_MARG=1: one workgroup of Jacobi sweeps
-  // takes longer than the host's tridiagonal QL at these sizes (n = 45 .. 105), and the work is off the critical path anyway.
-  bool device_marg_ = false;
   int device_id_ = 0;
-  std::shared_ptr<MargSchurDev> marg_dev_;
   HostSignal moment_signal_{};
   std::unique_ptr<HostState> snap_;
   std::vector<DeviceCloud> snap_stacks_;

@@ -2,6 +2,7 @@
 // Reference call structure: Estimator.cc:430-774 (ProcessLaserOdom), :1361-1646 (BuildLocalMap),
 // :1648-2438 (SolveOptimization), :2440-2568 (VectorToDouble/DoubleToVector), :2570-2666 (SlideWindow).
 #include "estimator.h"
+#include "marg_kernels.h"
 #include "rccl_comm.h"
 
 #include <atomic>
@@ -87,11 +88,10 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   LIO_HIP(hipMemset(d_moment_out_.p, 0, sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT));   // the two pad entries per frame stay zero under the all-reduce
   LIO_HIP(hipDeviceSynchronize());   // the memsets above run on the null stream; the kernels that read them on streams of our own
   // Execution switches: lio_est_config's trailing block, each overridable by its environment variable (A/B runs of a built host).
-  device_solve_ = cfg.device_solve; async_marg_ = !cfg.inline_marg;
-  host_signal_ = !cfg.stream_sync; device_marg_ = cfg.device_marg; moments_form_ = cfg.moments_form;
+  async_marg_ = !cfg.inline_marg;
+  host_signal_ = !cfg.stream_sync; moments_form_ = cfg.moments_form;
   resident_moments_ = cfg.resident_moments != 2;
   resident_never_ = cfg.resident_moments == 3;
-  if (const char *e = std::getenv("LIO_DEVICE_SOLVE")) device_solve_ = std::atoi(e) != 0;
   if (const char *e = std::getenv("LIO_MOMENTS")) moments_form_ = std::string(e) == "mfma" ? 1 : (std::string(e) == "valu" ? 2 : moments_form_);
   if (const char *e = std::getenv("LIO_RESIDENT_MOMENTS")) resident_moments_ = std::atoi(e) != 0;
   d_res_relay_.reserve(size_t(LIO_MAX_FRAMES) * LIO_RES_DOOR);
@@ -112,7 +112,6 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
     res_tick_us_ = 1e3 / double(khz);
     res_timeout_ticks_ = (long long)(0.2 * 1e3 * khz);   // 200 ms without a doorbell: the block posts LIO_RES_EXPIRED and exits
   }
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_ds_), sizeof(DsHost)));
   if (const char *e = std::getenv("LIO_ASYNC_MARG")) async_marg_ = std::atoi(e) != 0;
   // coherent (fine-grained): kernels store results and completion words here and the host reads them while the stream is live
   LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_moment_out_), sizeof(double) * LIO_MAX_FRAMES * LIO_MOMENT_OUT, hipHostMallocCoherent));
@@ -122,8 +121,6 @@ Estimator::Estimator(const EstConfig &cfg) : cfg_(cfg), W_(cfg.W), Wo_(cfg.Wo) {
   if (const char *e = std::getenv("LIO_HOST_SIGNAL")) host_signal_ = std::atoi(e) != 0;
   vox_.set_host_signal(host_signal_);
   LIO_HIP(hipGetDevice(&device_id_));
-  if (const char *e = std::getenv("LIO_DEVICE_MARG")) device_marg_ = std::atoi(e) != 0;
-  if (device_marg_) marg_dev_ = std::make_shared<MargSchurDev>(device_id_);
 }
 
 Estimator::~Estimator() {
@@ -135,11 +132,26 @@ Estimator::~Estimator() {
   if (h_moment_out_) (void)hipHostFree(h_moment_out_);
   if (h_signal_) (void)hipHostFree(h_signal_);
   if (h_odom_) (void)hipHostFree(h_odom_);
-  if (h_ds_) (void)hipHostFree(h_ds_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream_ && owns_stream_) (void)hipStreamDestroy(stream_);
+}
+
+// A batch (est_batch.h) takes over the handle's stream: everything the handle enqueues from now on (Restore's copies, SlideWindow's
+// concat, PushFrame's filter) is ordered with the batch's own launches without an event per window and solve.
+void Estimator::AdoptStream(hipStream_t s) {
+  ResidentEnd();
+  LIO_HIP(hipStreamSynchronize(stream_));
+  LIO_HIP(hipStreamSynchronize(stream2_));
+  if (owns_stream_) LIO_HIP(hipStreamDestroy(stream_));
+  stream_ = s; owns_stream_ = false;
+}
+void Estimator::ReleaseAdoptedStream() {
+  if (owns_stream_) return;
+  stream_ = nullptr;
+  LIO_HIP(hipStreamCreate(&stream_));
+  owns_stream_ = true;
 }
 
 template <typename T> static void push_full(std::vector<T> &buf, T v) {
@@ -422,28 +434,34 @@ bool Estimator::PushFrame(const Rigidf &transform_in, const float *surf, size_t 
   return true;
 }
 
+void Estimator::FusePivotOnce() {
+  if (init_local_map_) return;
+  const int pivot = W_ - Wo_;
+  const Rigidd lb = toDouble(transform_lb_);
+  const Rigidd T_pivot = LidarPose(pivot, lb);
+  ConcatArgs ca{};
+  int total = 0;
+  for (int i = 0; i <= pivot; ++i) {
+    ConcatSeg &sg = ca.seg[ca.nseg++];
+    sg.src = stacks_[i].buf.p; sg.n = int(stacks_[i].n); sg.dst_off = total; sg.set_intensity = 0; sg.intensity = 0; sg.identity = 0;
+    sg.tf = affineOf(RelTransform(i, T_pivot, lb));
+    total += sg.n;
+  }
+  ca.total = total;
+  scratch_cloud_.buf.reserve(std::max(total, 1));
+  launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
+  scratch_cloud_.n = size_t(total);
+  scratch_cloud_.id = ++g_content_id;
+  std::swap(stacks_[pivot], scratch_cloud_);
+  init_local_map_ = true;
+}
+
 void Estimator::BuildLocalMap(lio_solve_report *rep) {
   const double t0 = now_ms();
   const int pivot = W_ - Wo_;
   const Rigidd lb = toDouble(transform_lb_);
   const Rigidd T_pivot = LidarPose(pivot, lb);
-  if (!init_local_map_) {  // A.15: fuse frames 0..pivot into the pivot's stack, once
-    ConcatArgs ca{};
-    int total = 0;
-    for (int i = 0; i <= pivot; ++i) {
-      ConcatSeg &sg = ca.seg[ca.nseg++];
-      sg.src = stacks_[i].buf.p; sg.n = int(stacks_[i].n); sg.dst_off = total; sg.set_intensity = 0; sg.intensity = 0; sg.identity = 0;
-      sg.tf = affineOf(RelTransform(i, T_pivot, lb));
-      total += sg.n;
-    }
-    ca.total = total;
-    scratch_cloud_.buf.reserve(std::max(total, 1));
-    launch_transform_concat(ca, scratch_cloud_.buf.p, stream_);
-    scratch_cloud_.n = size_t(total);
-    scratch_cloud_.id = ++g_content_id;
-    std::swap(stacks_[pivot], scratch_cloud_);
-    init_local_map_ = true;
-  }
+  FusePivotOnce();
   std::vector<Rigidf> local_transforms(W_ + 1);
   ConcatArgs ca{};
   int total = 0;
@@ -691,7 +709,7 @@ void Estimator::ResidentLaunchKernel(unsigned first_seq) {
 // The resident kernel of this solve: launched behind everything the feature stage enqueued on stream_; it returns when the host
 // writes LIO_RES_STOP (ResidentEnd) or after res_timeout_ticks_ without a doorbell.
 bool Estimator::ResidentBegin(const MomentArgs &ma) {
-  if (!res_allowed_ || resident_never_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_ || device_solve_) return false;
+  if (!res_allowed_ || resident_never_ || !host_signal_ || timers_.on || Sharded() || rccl_comm_) return false;
   int max_slots = 0;
   for (int k = 0; k < ma.nframes; ++k) max_slots = std::max(max_slots, ma.fr[k].nslots);
   int per_lane = 0;
@@ -834,79 +852,6 @@ void Estimator::ResidentEnd() {
   if (res_time_launch_ && !res_launch_events_.empty()) (void)hipEventRecord(res_launch_events_.back().second, stream_);
 }
 
-// Estimator.cc:1909-1990 on the device: upload the problem once, enqueue (launch A, launch B) per iteration, read back.
-bool Estimator::SolveOnDevice(WindowSystem &sys, WindowParams &P, SolveSummary &sum, WindowSystem::Costs &costs0, bool &turn_off) {
-  if (!device_solve_ || Sharded() || rccl_comm_ || !sys.use_lidar || total_slots_ == 0) return false;
-  MomentArgs ma;
-  int max_slots = 0;
-  FillMomentArgs(ma, max_slots);
-  DsHost &H = *h_ds_;
-  std::vector<double> pm;
-  if (!ds_pack_problem(sys, P, cfg_.max_num_iterations, ma.blocks_per_frame, convergence_flag_, cfg_.imu_factor, H.pb, pm)) return false;
-  if (pm.size() > sizeof(H.prior_mats) / sizeof(double)) return false;
-  if (ds_lds_doubles(H.pb.n_pad, Wo_) * sizeof(double) > 160 * 1024) return false;
-  if (!pm.empty()) std::memcpy(H.prior_mats, pm.data(), pm.size() * sizeof(double));
-  ds_init_state(P, H.st);
-  const size_t up_bytes = offsetof(DsHost, prior_mats) + std::max<size_t>(pm.size(), 4) * sizeof(double);
-  d_ds_.reserve(sizeof(DsHost));
-  d_ds_imu_.reserve(size_t(DS_MAX_WO) * DS_IMU_OUT); d_ds_lmap_.reserve(size_t(DS_MAX_WO) * DS_LMAP_OUT);
-  d_ds_prior_out_.reserve(72); d_ds_exprior_out_.reserve(DS_EXP_OUT);
-  d_ds_Hcur_.reserve(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); d_ds_Sbuf_.reserve(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT);
-  d_moment_partials_.reserve(size_t(ma.nframes) * ma.blocks_per_frame * LIO_MOMENT_OUT);
-  LIO_HIP(hipMemcpyAsync(d_ds_.p, &H, up_bytes, hipMemcpyHostToDevice, stream_));
-  const DevProblem *d_pb = reinterpret_cast<const DevProblem *>(d_ds_.p + offsetof(DsHost, pb));
-  DevState *d_st = reinterpret_cast<DevState *>(d_ds_.p + offsetof(DsHost, st));
-  const double *d_pm = reinterpret_cast<const double *>(d_ds_.p + offsetof(DsHost, prior_mats));
-  const bool dbg_prof = g_debug_timing;
-  if (dbg_prof) { d_ds_prof_.reserve(32); LIO_HIP(hipMemsetAsync(d_ds_prof_.p, 0, 32 * sizeof(long long), stream_)); }
-  StepBuffers B{d_pm, d_moment_partials_.p, d_ds_imu_.p, d_ds_lmap_.p, d_ds_prior_out_.p, d_ds_exprior_out_.p, d_ds_Hcur_.p, d_ds_Sbuf_.p,
-                dbg_prof ? d_ds_prof_.p : nullptr};
-  double nres = 0;
-  for (int k = 0; k < ma.nframes; ++k) nres += ma.fr[k].nslots;
-  // iteration k evaluates candidate k (k = 0: the initial point); at most max_num_iterations candidates follow it
-  static const int dbg_max_launch = [] { const char *e = std::getenv("LIO_DS_MAX_LAUNCH"); return e ? std::atoi(e) : 1 << 30; }();  // debug: truncate the chain
-  for (int k = 0; k <= cfg_.max_num_iterations && k < dbg_max_launch; ++k) {
-    int th = timers_.begin(KT_MOMENTS, 60.0 * nres, stream_);
-    launch_solve_iteration(ma, f_valid_.p, f_coef_.p, d_moment_partials_.p, d_pb, d_st, B, d_ds_imu_.p, d_ds_lmap_.p, d_ds_prior_out_.p,
-                           d_ds_exprior_out_.p, H.pb.n_pad, stream_);
-    timers_.end(th, stream_);
-  }
-  LIO_HIP(hipMemcpyAsync(&H.st, d_st, sizeof(DevState), hipMemcpyDeviceToHost, stream_));
-  LIO_HIP(hipMemcpyAsync(H.S_buf, d_ds_Sbuf_.p, sizeof(double) * 2 * Wo_ * LIO_MOMENT_OUT, hipMemcpyDeviceToHost, stream_));
-  LIO_HIP(hipStreamSynchronize(stream_));
-  timers_.resolve();
-  if (dbg_prof) {
-    long long pr[32];
-    LIO_HIP(hipMemcpy(pr, d_ds_prof_.p, sizeof(pr), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[lio_hip timing] launch B phases (shader clocks):");
-    for (int k = 1; k < 14; ++k) if (pr[k] && pr[k - 1]) std::fprintf(stderr, " P%d %lld", k, pr[k] - pr[k - 1]); else if (pr[k]) { int j = k - 1; while (j > 0 && !pr[j]) --j; std::fprintf(stderr, " P%d(from %d) %lld", k, j, pr[k] - pr[j]); }
-    std::fprintf(stderr, " | ldlt: panel0 %lld trsm0 %lld update0 %lld all-blocks %lld backsolve %lld | raw", pr[17] - pr[16], pr[18] - pr[17], pr[19] - pr[18], pr[20] - pr[16],
-                 pr[21] - pr[20]);
-    for (int k = 0; k < 24; ++k) std::fprintf(stderr, " %lld", pr[k] ? pr[k] - pr[0] : -1);
-    std::fprintf(stderr, "\n");
-  }
-  const DevState &st = H.st;
-  if (st.need_host || !st.started) return false;
-  costs0.marg = st.costs0[0]; costs0.pim = st.costs0[1]; costs0.ppp = st.costs0[2]; costs0.prior = st.costs0[3];
-  turn_off = st.turn_off != 0;
-  convergence_flag_ = st.conv_flag_out != 0;
-  ds_unpack_params(st.x, P);
-  sum = SolveSummary();
-  sum.iterations = st.it; sum.successful = st.successful; sum.termination = st.termination;
-  sum.trace.assign(st.trace, st.trace + std::min(st.ntrace, 40));
-  sum.initial_cost = st.ntrace > 0 ? st.trace[0] : 0.0; sum.final_cost = st.x_cost;
-  sum.initial_costs = costs0;
-  sum.final_moments.assign(Wo_ + 1, FrameMoments());
-  const double *Sc = H.S_buf + size_t(st.s_cur) * Wo_ * LIO_MOMENT_OUT;
-  for (int i = 1; i <= Wo_; ++i) {
-    const double *src = Sc + size_t(i - 1) * LIO_MOMENT_OUT;
-    std::memcpy(sum.final_moments[i].S, src, 256 * sizeof(double));
-    sum.final_moments[i].cost = src[256]; sum.final_moments[i].count = src[257];
-  }
-  dev_n_lidar_ = st.n_lidar;
-  return true;
-}
-
 void Estimator::LidarLaunch(const WindowParams &P) {
   const double t_dbg0 = now_ms();
   struct DbgAcc { Estimator *e; double t0; ~DbgAcc() { e->dbg_eval_ms_ += now_ms() - t0; } } dbg_acc{this, t_dbg0};
@@ -1028,7 +973,7 @@ void Estimator::LidarWait(std::vector<FrameMoments> &m) {
   }
 }
 
-bool Estimator::SolveOptimization(lio_solve_report *rep) {
+bool Estimator::SolveOptimizationHost(lio_solve_report *rep) {
   if (cir_buf_count_ < W_ && cfg_.imu_factor) return false;
   const double t_total0 = now_ms();
   lio_solve_report local{};
@@ -1069,25 +1014,9 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   // Group costs at the initial point (Estimator.cc:1924-1954) and the convergence_flag_ logic (:1956-1984).
   // The reference evaluates the three groups, then Ceres linearises again at the same point; here ONE device
   // pass yields both — unless the flag logic changes the problem (prior dropped / extrinsic frozen).
-  // Device-resident dogleg first (solve_step.h); it reports the group costs and applies the convergence_flag_ logic itself and
-  // hands the solve back (false) when that logic changes the shape of the problem or the problem does not fit.
   SolveSummary s;
-  bool on_device = false;
-  {
-    WindowSystem::Costs gc;
-    bool toff = true;
-    const double t_dev0 = now_ms();
-    on_device = SolveOnDevice(sys, P, s, gc, toff);
-    if (on_device) {
-      R.ms_opt = now_ms() - t_dev0;
-      R.cost_pim_before = gc.pim; R.cost_ppp_before = gc.ppp; R.cost_marg_before = gc.marg;
-      turn_off = toff;
-      if (!convergence_flag_) { last_marg_.reset(); sys.prior.reset(); }
-    }
-  }
   Linearization first;
-  if (!on_device) {
-    dev_n_lidar_ = -1;
+  {
     Layout lay = WindowSystem::solve_layout(P);
     first.costs = sys.evaluate(P, lay, 1 | 2 | 4 | 8, false, &first.H, &first.g, &first.m);
     first.valid = true;
@@ -1104,7 +1033,7 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
     }
   }
   const double t_opt0 = now_ms();
-  if (!on_device) {
+  {
   // Factor sharding: every linearisation is a collective, so every rank must take the same number of them.  A per-rank
   // wall-clock cap (Estimator.cc:1921) could stop one rank an iteration earlier than its peers and leave an unmatched
   // all-reduce behind; the sharded mode therefore terminates on the iteration / tolerance rules only.
@@ -1134,12 +1063,6 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
       if (pi && pi->sum_dt < 10.0) msys->pim[0] = pi;
     }
     msys->prior = last_marg_;
-    if (marg_dev_) {
-      std::shared_ptr<MargSchurDev> md = marg_dev_;   // the task may outlive a Restore(); the device object is shared
-      msys->marg_schur_hook = [md](const double *A, const double *b, int m, int n, double eps, double *jac, double *res) {
-        return md->Run(A, b, m, n, eps, jac, res, nullptr, nullptr);
-      };
-    }
     const bool have_moments = msys->use_lidar && !s.final_moments.empty();
     if (async_marg_ && (have_moments || !msys->use_lidar)) {
       // host-only from here (the lidar moments at the final point come from the solve): hand it to the worker
@@ -1162,7 +1085,6 @@ bool Estimator::SolveOptimization(lio_solve_report *rep) {
   {
     double cnt = 0;
     for (int i = 1; i <= Wo_; ++i) cnt += h_moment_out_[size_t(i - 1) * LIO_MOMENT_OUT + 257];
-    if (dev_n_lidar_ >= 0) cnt = dev_n_lidar_;
     R.n_lidar_residuals = cfg_.point_distance_factor ? int(cnt) : 0;
   }
   R.ms_total = now_ms() - t_total0;
@@ -1229,6 +1151,22 @@ void Estimator::Snapshot() {
   LIO_HIP(hipStreamSynchronize(stream_));
 }
 
+bool Estimator::CopySnapshotOf(Estimator &src) {
+  if (!src.snap_ || src.W_ != W_ || src.Wo_ != Wo_ || &src == this) return false;
+  JoinMarg();
+  snap_.reset(new HostState(*src.snap_));   // pre-integrations and the prior are immutable once pushed: shared
+  snap_stacks_.resize(src.snap_stacks_.size());
+  for (size_t i = 0; i < src.snap_stacks_.size(); ++i) {
+    const DeviceCloud &c = src.snap_stacks_[i];
+    snap_stacks_[i].buf.reserve(std::max<size_t>(c.n, 1), stream_);
+    if (c.n) LIO_HIP(hipMemcpyAsync(snap_stacks_[i].buf.p, c.buf.p, c.n * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    snap_stacks_[i].n = c.n;
+    snap_stacks_[i].id = ++g_content_id;
+  }
+  LIO_HIP(hipStreamSynchronize(stream_));
+  return true;
+}
+
 bool Estimator::Restore() {
   if (!snap_) return false;
   ++marg_epoch_;  // a marginalization still in flight belongs to the state being discarded: its result is dropped at the next join
@@ -1249,6 +1187,150 @@ bool Estimator::Restore() {
     stacks_[i].n = snap_stacks_[i].n;
   }
   // no host wait: every consumer of the stacks is ordered behind these copies on stream_ (or behind an event recorded on it)
+  return true;
+}
+
+// ================================================================================================
+// Batched solve: the per-window host halves (est_batch.hip drives them)
+// ================================================================================================
+bool Estimator::BatchEligible() const {
+  if (!inited_ || cir_buf_count_ < W_ || false) return false;
+  if (!cfg_.imu_factor || !cfg_.point_distance_factor || Sharded() || rccl_comm_) return false;
+  if (Wo_ < 1 || Wo_ > DS_MAX_WO || Wo_ > LIO_BW_MAX_STATIC + 1 || Wo_ > LIO_BW_MAX_SEG) return false;
+  const int dim = 15 * (Wo_ + 1) + 6;
+  if ((dim + DS_NB - 1) / DS_NB * DS_NB > DS_MAX_NPAD || 6 * Wo_ + 15 > MARG_MAX_N) return false;
+  return true;
+}
+
+void Estimator::BatchDescribe(BatchWin &bw) {
+  FusePivotOnce();
+  const int pivot = W_ - Wo_;
+  const Rigidd lb = toDouble(transform_lb_);
+  const Rigidd T_pivot = LidarPose(pivot, lb);
+  std::memset(&bw, 0, sizeof(bw));
+  bw.inv_leaf = 1.0f / cfg_.surf_filter_size;
+  bw.min_match_sq_dis = cfg_.min_match_sq_dis; bw.min_plane_dis = cfg_.min_plane_dis;
+  const int keep_mult = cfg_.keep_features ? 10 : 1;
+  bw.keep = cfg_.keep_features ? 1 : 0;
+  int total = 0;
+  total_slots_ = 0;
+  for (int i = 0; i <= W_; ++i) { slot_off_[i] = 0; nslots_[i] = 0; }
+  for (int i = pivot; i <= W_; ++i) {
+    const Rigidf tf = RelTransform(i, T_pivot, lb);
+    const Rigidf lt = fromAffine(linearOf(tf), tf.pos);
+    if (i < W_) {   // a segment of the local map (Estimator.cc:1480-1507)
+      BwSeg &sg = bw.seg[bw.nseg++];
+      sg.src = stacks_[i].buf.p; sg.n = int(stacks_[i].n); sg.dst_off = total;
+      if (i == pivot) { sg.identity = 1; sg.set_intensity = 0; sg.intensity = 0; }
+      else { sg.identity = 0; sg.set_intensity = 1; sg.intensity = float(i); sg.tf = affineOf(tf); }
+      total += sg.n;
+    }
+    if (i == pivot) continue;
+    const int k = (i == W_) ? LIO_BW_MAX_STATIC : bw.nstatic;
+    float *o = bw.tf[k];
+    o[0] = lt.rot.x; o[1] = lt.rot.y; o[2] = lt.rot.z; o[3] = lt.rot.w; o[4] = lt.pos.x; o[5] = lt.pos.y; o[6] = lt.pos.z; o[7] = 0.f;
+    slot_off_[i] = int(total_slots_);
+    nslots_[i] = int(stacks_[i].n) * ((i == W_) ? keep_mult : 1);
+    total_slots_ += size_t(nslots_[i]);
+    FeatFrame &f = (i == W_) ? bw.newest : bw.fr[bw.nstatic];
+    f.stack = stacks_[i].buf.p; f.M = int(stacks_[i].n); f.slot_off = slot_off_[i]; f.tf_index = k;
+    if (i < W_) ++bw.nstatic;
+  }
+  bw.n_local = total;
+  bw.n_slots = int(total_slots_);
+  bw.nb_round = bw.newest.M > 0 ? bw_round_blocks(bw.newest.M) : 0;
+}
+
+void Estimator::BatchSetOdom(const OdomState &st) {
+  laser_odom_iters_ = st.iters;
+  laser_odom_kz_ = st.degenerate ? st.kz : 0;
+  laser_odom_transform_ = Rigidf(Quat<float>(st.T[3], st.T[0], st.T[1], st.T[2]), Vec3<float>(st.T[4], st.T[5], st.T[6]));
+  if (cfg_.keep_features) nslots_[W_] = int(stacks_[W_].n) * std::max(1, st.iters);
+}
+
+bool Estimator::BatchPackProblem(int bpf, DevProblem &pb, DevState &st, std::shared_ptr<MargPrior> *prior) {
+  const int pivot = W_ - Wo_;
+  WindowParams P;
+  VectorToParams(P);
+  P.ex_constant = (cfg_.extrinsic_stage == 0 || !cfg_.opt_extrinsic);
+  WindowSystem sys;
+  sys.Wo = Wo_;
+  sys.use_lidar = cfg_.point_distance_factor;
+  sys.pim.assign(Wo_, nullptr);
+  for (int i = 0; i < Wo_; ++i) {
+    auto &pi = pre_integrations_[pivot + i + 1];
+    if (pi && pi->sum_dt <= 10.0) sys.pim[i] = pi;
+  }
+  if (cfg_.marginalization_factor && last_marg_) sys.prior = last_marg_;
+  if (cfg_.prior_factor) {
+    sys.use_prior_factor = true;
+    Rigidd t = toDouble(transform_lb_);
+    sys.prior_pos = t.pos; sys.prior_rot = t.rot;
+  }
+  if (prior) *prior = sys.prior;
+  if (!ds_pack_problem(sys, P, cfg_.max_num_iterations, bpf, convergence_flag_, cfg_.imu_factor, pb, nullptr)) return false;
+  if (ds_lds_doubles(pb.n_pad, Wo_) * sizeof(double) > 160 * 1024) return false;
+  ds_init_state(P, st);
+  return true;
+}
+
+bool Estimator::BatchFinish(const DevState &st, const std::shared_ptr<MargPrior> &prior_used, lio_solve_report &R, DevMarg &mg,
+                            std::shared_ptr<MargPrior> *shell) {
+  const int pivot = W_ - Wo_;
+  R.cost_marg_before = st.costs0[0]; R.cost_pim_before = st.costs0[1]; R.cost_ppp_before = st.costs0[2];
+  const bool turn_off = st.turn_off != 0;
+  convergence_flag_ = st.conv_flag_out != 0;
+  std::shared_ptr<MargPrior> prior = prior_used;
+  if (!convergence_flag_) { last_marg_.reset(); prior.reset(); }   // Estimator.cc:1962-1975 (the device loop only runs when that changes nothing)
+  WindowParams P;
+  VectorToParams(P);   // sizes; every entry is overwritten
+  ds_unpack_params(st.x, P);
+  R.iterations = st.it; R.successful_steps = st.successful; R.termination = st.termination;
+  R.initial_cost = st.ntrace > 0 ? st.trace[0] : 0.0; R.final_cost = st.x_cost;
+  for (int k = 0; k < st.ntrace && k < 32; ++k) R.cost_trace[k] = st.trace[k];
+  ParamsToVector(P);
+  R.turn_off = turn_off; R.convergence_flag = convergence_flag_;
+  R.n_lidar_residuals = int(st.n_lidar);
+  R.laser_odom_iterations = laser_odom_iters_; R.laser_odom_kz = laser_odom_kz_;
+  std::memset(&mg, 0, sizeof(mg));
+  if (!cfg_.marginalization_factor || turn_off) return false;
+  // MarginalizationInfo::{AddResidualBlockInfo, PreMarginalize, Marginalize} (host_solver.h: marginalize): the layout
+  WindowParams M;
+  VectorToParams(M);
+  ds_pack_params(M, mg.x);
+  auto &pi = pre_integrations_[pivot + 1];
+  const bool has_imu = pi && pi->sum_dt < 10.0 && pi->sqrt_info() != nullptr;
+  const bool sb0_present = has_imu || prior != nullptr;
+  mg.active = 1; mg.Wo = Wo_; mg.has_imu = has_imu ? 1 : 0; mg.have_prior = prior ? 1 : 0;
+  for (int i = 0; i <= DS_MAX_WO; ++i) mg.pose_col[i] = -1;
+  mg.sb_col[0] = mg.sb_col[1] = -1;
+  int pos = 0;
+  mg.pose_col[0] = pos; pos += 6;
+  if (sb0_present) { mg.sb_col[0] = pos; pos += 9; }
+  const int m = pos;
+  std::vector<KeepBlock> keep;
+  mg.pose_col[1] = pos; keep.push_back({0, 0, 7, pos - m}); pos += 6;
+  if (has_imu) { mg.sb_col[1] = pos; keep.push_back({1, 0, 9, pos - m}); pos += 9; }
+  for (int i = 2; i <= Wo_; ++i) { mg.pose_col[i] = pos; keep.push_back({0, i - 1, 7, pos - m}); pos += 6; }
+  mg.ex_col = pos; keep.push_back({2, 0, 7, pos - m}); pos += 6;
+  mg.m = m; mg.n = pos - m;
+  for (int i = 0; i < DS_MAX_NPAD; ++i) mg.prior_col[i] = -1;
+  if (prior) {
+    for (const KeepBlock &kb : prior->keep) {
+      const int col = kb.kind == 0 ? mg.pose_col[kb.index] : (kb.kind == 1 ? (kb.index < 2 ? mg.sb_col[kb.index] : -1) : mg.ex_col);
+      if (col < 0) continue;
+      const int la = kb.size == 7 ? 6 : kb.size;
+      for (int i = 0; i < la; ++i) mg.prior_col[col + i] = kb.idx + i;
+    }
+  }
+  auto pr = std::make_shared<MargPrior>();
+  pr->n = mg.n; pr->keep = keep;
+  for (const KeepBlock &kb : keep) {
+    const double *src = kb.kind == 0 ? M.pose[kb.index + 1].data() : (kb.kind == 1 ? M.sb[kb.index + 1].data() : M.ex.data());
+    pr->x0.emplace_back(src, src + kb.size);
+  }
+  if (shell) *shell = pr;
+  R.marginalized = 1;
   return true;
 }
 

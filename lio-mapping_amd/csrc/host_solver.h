@@ -31,6 +31,14 @@ struct MargPrior {
   std::vector<double> lin_res;  // n
   DMat JtJ;                     // cached lin_jac^T lin_jac
   std::vector<double> Jtr0;     // cached lin_jac^T lin_res
+  // A prior computed by a batched solve (est_batch.h) lives on the device — where the next batched solve reads it — until a
+  // host-side reader asks for it: materialize() downloads lin_jac / lin_res / JtJ / Jtr0 through `fetch`, once.
+  bool on_device = false;
+  std::function<void(MargPrior &)> fetch;
+  void materialize() {
+    if (on_device && fetch) fetch(*this);
+    on_device = false; fetch = nullptr;
+  }
   void finalize() {
     JtJ = DMat(n, n); Jtr0.assign(n, 0.0);
     // sum of n outer products of the rows of lin_jac: contiguous inner loops

@@ -29,4 +29,8 @@ class MargSchurDev {
   double last_ms_ = 0;
 };
 
+// Marginalization of every window of a batch on `s` (two launches; BatchSolve: solve_step.h); the new priors stay on the device
+struct BatchSolve;
+void launch_bw_marginalize(const BatchSolve *bs, int B, int max_wo, int max_n, hipStream_t s);
+
 }  // namespace lio

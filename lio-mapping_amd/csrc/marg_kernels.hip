@@ -21,11 +21,11 @@
 
 #include "dev.h"
 #include "marg_kernels.h"
+#include "solve_device.h"
 
 namespace lio {
 
 #define MARG_THREADS 256
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // cyclic Jacobi on the symmetric np x np matrix S (leading dimension ld, np even; a padding row / column must be zero),
 // eigenvectors accumulated in the columns of V (identity on entry).  cs: np doubles of scratch, flag: one int.
@@ -108,10 +108,10 @@ struct MargLds {
   int *ord, *flag;
 };
 
-__global__ void __launch_bounds__(MARG_THREADS) k_marg_schur(const double *__restrict__ A, const double *__restrict__ b, int m, int n, double eps,
-                                                            double *__restrict__ lin_jac, double *__restrict__ lin_res, double *__restrict__ evals,
-                                                            double *__restrict__ info) {
-  extern __shared__ double lds[];
+// The dense tail for one system by one workgroup of MARG_THREADS threads.  A: (m + n)^2 row-major, b: m + n (global memory, written
+// before a block barrier when the caller assembled them itself); lds: marg_lds_doubles(n) doubles.
+__device__ void marg_schur_body(const double *__restrict__ A, const double *__restrict__ b, int m, int n, double eps, double *__restrict__ lin_jac,
+                                double *__restrict__ lin_res, double *__restrict__ evals, double *__restrict__ info, double *lds) {
   const int tid = threadIdx.x, N = m + n;
   const int np2 = (n + 1) & ~1, ld2 = np2 + 1;
   MargLds L;
@@ -223,13 +223,139 @@ __global__ void __launch_bounds__(MARG_THREADS) k_marg_schur(const double *__res
     const int k = e / n, i = e - k * n;
     lin_jac[e] = L.w[k] * L.V[i * ld2 + L.ord[k]];
   }
-  if (tid == 0) { info[0] = double(sweeps1); info[1] = double(sweeps2); }
+  if (tid == 0 && info) { info[0] = double(sweeps1); info[1] = double(sweeps2); }
 }
 
-static size_t marg_lds_bytes(int n) {
+__global__ void __launch_bounds__(MARG_THREADS) k_marg_schur(const double *__restrict__ A, const double *__restrict__ b, int m, int n, double eps,
+                                                            double *__restrict__ lin_jac, double *__restrict__ lin_res, double *__restrict__ evals,
+                                                            double *__restrict__ info) {
+  extern __shared__ double lds[];
+  marg_schur_body(A, b, m, n, eps, lin_jac, lin_res, evals, info, lds);
+}
+
+static size_t marg_lds_doubles(int n) {
   const int np2 = (n + 1) & ~1, ld2 = np2 + 1;
-  const size_t doubles = size_t(2) * np2 * ld2 + 2 * 16 * 17 + 16 * 16 + size_t(n) * 16 + 3 * np2 + np2 + 16 + (np2 + 1) / 2 + 1 + 2;
-  return doubles * sizeof(double);
+  return size_t(2) * np2 * ld2 + 2 * 16 * 17 + 16 * 16 + size_t(n) * 16 + 3 * np2 + np2 + 16 + (np2 + 1) / 2 + 1 + 2;
+}
+static size_t marg_lds_bytes(int n) { return marg_lds_doubles(n) * sizeof(double); }
+
+// ------------------------------------------------------------------------------------------------
+// MarginalizationInfo::Marginalize for every window of a batch (MarginalizationFactor.cc:185-311), all of it on the device:
+//   launch 1  k_bw_marg_aux     what the factors that touch the dropped blocks contribute at the linearisation point x (the window
+//                               after DoubleToVector): block i < Wo the 18 x 13 lidar map of frame i + 1 (extrinsic free), block Wo
+//                               the first ImuFactor (ImuFactor.h:53-168), block Wo + 1 the old prior's gradient and cost;
+//   launch 2  k_bw_marg_schur   one workgroup per window: frame blocks L S L^T from the solve's final moments (they depend on the
+//                               relative poses only, which the yaw re-anchoring leaves unchanged), A and b in the layout
+//                               [pose 0, speed-bias 0 | pose 1, speed-bias 1, pose 2 .. Wo, extrinsic] in the summation order of
+//                               WindowSystem::evaluate, then the dense tail above, then J^T J and J^T r of the new prior — which
+//                               stays on the device as the next solve's prior_mats.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_aux(const BatchSolve *__restrict__ bs) {
+  const BatchSolve &S = bs[blockIdx.y];
+  const DevMarg *mg = S.marg;
+  if (!mg || !mg->active) return;
+  __shared__ double aux_lds[1024];
+  const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
+  const int Wo = mg->Wo, i = blockIdx.x;
+  const DevParams &P = mg->x;
+  if (i < Wo) {
+    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.marg_lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+  } else if (i == Wo) {
+    if (mg->has_imu) aux_imu(x, S.pb->pim[0], P.pose[0], P.sb[0], P.pose[1], P.sb[1], S.marg_imu, aux_lds);
+    else for (int k = threadIdx.x; k < DS_IMU_OUT; k += blockDim.x) S.marg_imu[k] = 0.0;
+  } else if (i == Wo + 1) {
+    if (mg->have_prior) aux_prior(x, *S.pb, S.prior_mats, P, S.marg_prior_out, aux_lds);
+  }
+}
+
+__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve *__restrict__ bs, double eps) {
+  extern __shared__ double lds[];
+  const BatchSolve &S = bs[blockIdx.x];
+  const DevMarg *mgp = S.marg;
+  if (!mgp || !mgp->active) return;
+  const DevMarg &mg = *mgp;
+  const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
+  const int Wo = mg.Wo, m = mg.m, n = mg.n, N = m + n;
+  const DevState &st = *S.st;
+  const double *Sm = S.S_buf + size_t(st.s_cur) * Wo * LIO_MOMENT_OUT;   // the moments at the point the solver stopped at
+  // ---- frame blocks (LDS: zb Wo x 344, LS Wo x 234)
+  double *zb = lds, *LS = lds + size_t(Wo) * 344;
+  ds_lidar_blocks(x, Wo, S.marg_lmap, Sm, LS, zb);
+  // ---- A, b: prior, ImuFactor 0, lidar frames 1 .. Wo — one thread per entry, the contributions in that order
+  const int np = S.pb->n_prior;
+  const double *JtJ = S.prior_mats;
+  double *A = S.marg_A, *bv = S.marg_A + size_t(N) * N;
+  const int c_p0 = mg.pose_col[0], c_ex = mg.ex_col;
+  for (int e = x.tid; e < N * (N + 1); e += x.nthr) {
+    const int r = e / (N + 1), cc = e % (N + 1);
+    const bool is_g = cc == N;
+    const int c = is_g ? 0 : cc;
+    double v = 0.0;
+    if (mg.have_prior && mg.prior_col[r] >= 0) {
+      if (is_g) v += S.marg_prior_out[mg.prior_col[r]];
+      else if (mg.prior_col[c] >= 0) v += JtJ[size_t(mg.prior_col[r]) * np + mg.prior_col[c]];
+    }
+    // ImuFactor 0 spans [pose 0 | sb 0 | pose 1 | sb 1]: local index of a column (-1: not in the factor)
+    auto imu_local = [&](int col) {
+      if (col >= mg.pose_col[0] && col < mg.pose_col[0] + 6) return col - mg.pose_col[0];
+      if (mg.sb_col[0] >= 0 && col >= mg.sb_col[0] && col < mg.sb_col[0] + 9) return 6 + col - mg.sb_col[0];
+      if (col >= mg.pose_col[1] && col < mg.pose_col[1] + 6) return 15 + col - mg.pose_col[1];
+      if (mg.sb_col[1] >= 0 && col >= mg.sb_col[1] && col < mg.sb_col[1] + 9) return 21 + col - mg.sb_col[1];
+      return -1;
+    };
+    if (mg.has_imu && S.marg_imu[931] != 0.0) {
+      const int lr = imu_local(r);
+      if (lr >= 0) {
+        if (is_g) v += S.marg_imu[900 + lr];
+        else { const int lc = imu_local(c); if (lc >= 0) v += S.marg_imu[lr * 30 + lc]; }
+      }
+    }
+    // lidar frame i touches (pose 0, pose i, extrinsic): local rows 0..5, 6..11, 12..17
+    auto lidar_kind = [&](int col, int &frame, int &loc) {   // 0 pivot, 1 frame `frame`, 2 extrinsic, -1 none
+      if (col >= c_p0 && col < c_p0 + 6) { loc = col - c_p0; return 0; }
+      if (col >= c_ex && col < c_ex + 6) { loc = 12 + col - c_ex; return 2; }
+      for (int i = 1; i <= Wo; ++i)
+        if (col >= mg.pose_col[i] && col < mg.pose_col[i] + 6) { frame = i; loc = 6 + col - mg.pose_col[i]; return 1; }
+      return -1;
+    };
+    int fr_r = 0, lr = 0, fr_c = 0, lc = 0;
+    const int kr = lidar_kind(r, fr_r, lr);
+    const int kc = is_g ? 0 : lidar_kind(c, fr_c, lc);
+    if (kr >= 0 && kc >= 0) {
+      for (int i = 1; i <= Wo; ++i) {
+        if (Sm[(i - 1) * LIO_MOMENT_OUT + 257] == 0.0) continue;
+        if ((kr == 1 && fr_r != i) || (!is_g && kc == 1 && fr_c != i)) continue;
+        v += is_g ? zb[(i - 1) * 344 + 324 + lr] : zb[(i - 1) * 344 + lr * 18 + lc];
+      }
+    }
+    if (is_g) bv[r] = v; else A[size_t(r) * N + c] = v;
+  }
+  __syncthreads();   // (global writes of this block are visible to it behind the barrier)
+  // ---- dense tail: the new prior's square-root factors go straight into the next solve's prior_mats
+  double *out = S.next_prior_mats;
+  double *o_JtJ = out, *o_jac = out + size_t(n) * n, *o_res = o_jac + size_t(n) * n, *o_Jtr = o_res + n;
+  marg_schur_body(A, bv, m, n, eps, o_jac, o_res, S.marg_info + 2, S.marg_info, lds);
+  __syncthreads();
+  // J^T J and J^T r of the new prior (MargPrior::finalize): ascending k
+  for (int e = x.tid; e < n * (n + 1); e += x.nthr) {
+    const int i = e / (n + 1), j = e % (n + 1);
+    double sacc = 0.0;
+    if (j < n) { for (int k = 0; k < n; ++k) sacc += o_jac[size_t(k) * n + i] * o_jac[size_t(k) * n + j]; o_JtJ[size_t(i) * n + j] = sacc; }
+    else { for (int k = 0; k < n; ++k) sacc += o_jac[size_t(k) * n + i] * o_res[k]; o_Jtr[i] = sacc; }
+  }
+}
+
+void launch_bw_marginalize(const BatchSolve *bs, int B, int max_wo, int max_n, hipStream_t s) {
+  if (B <= 0) return;
+  static const bool attr_set = [] {
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, int(marg_lds_bytes(MARG_MAX_N))));
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_THREADS), 0, s, bs);
+  const size_t lds = std::max(marg_lds_doubles(max_n), size_t(max_wo) * (344 + 234)) * sizeof(double);
+  hipLaunchKernelGGL(k_bw_marg_schur, dim3(B), dim3(MARG_THREADS), lds, s, bs, 1e-8);
+  LIO_HIP(hipGetLastError());
 }
 
 MargSchurDev::MargSchurDev(int device) : device_(device) {

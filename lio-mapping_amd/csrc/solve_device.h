@@ -1,0 +1,138 @@
+// solve_device.h — the kernel-side executor of solve_step.h's templates (512- or 256-thread workgroup, LDS, wave shuffles, fp64 MFMA
+// tiles), shared by the solve kernels (solve_kernels.hip) and the marginalization kernels (marg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "solve_step.h"
+
+#if defined(__HIPCC__)
+namespace lio {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double ds_bcast_lane(double v, int src_lane) {   // src_lane: wave-uniform (a constant after unrolling)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+struct DevExec {
+  static constexpr bool kDevice = true;
+  static constexpr int WT = 64;
+  int tid, nthr, lane, wave, nwave;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ double wsum(double v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
+  __device__ __forceinline__ double wmax(double v) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
+    return v;
+  }
+  // 1 / d from the hardware estimate and two Newton steps (<= 1 ulp): a correctly rounded fp64 divide is ~40 instructions on
+  // the pivot chain of the factorisation
+  __device__ __forceinline__ double rcp(double d) const {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+  }
+  // lanes 4m .. 4m+3 hold v0..v3: every one of them gets (v0 + v1) + (v2 + v3)
+  __device__ __forceinline__ void stamp(long long *prof, int k) const { if (prof && tid == 0) prof[k] = clock64(); }
+  __device__ __forceinline__ double pair_sum4(double v) const {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+  }
+
+  // L D L^T of the 16x16 diagonal block at p: lane r (mod 16) keeps row r in registers, pivots and columns travel by
+  // v_readlane; the arithmetic and its order are those of the reference loop in ds_panel_factor.
+  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd) const {
+    const int r = lane & 15;
+    double a[DS_NB];
+    const double *row = A + size_t(p + r) * ld + p;
+#pragma unroll
+    for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
+    int ok = 1;
+    double myinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < DS_NB; ++j) {
+      const double d = ds_bcast_lane(a[j], j);
+      ok &= (d > 0.0) ? 1 : 0;
+      const double inv = rcp(d);
+      const double t = a[j];
+      const double l = t * inv;
+#pragma unroll
+      for (int c = j + 1; c < DS_NB; ++c) {
+        const double tc = ds_bcast_lane(t, c);
+        a[c] -= l * tc;
+      }
+      a[j] = (r > j) ? l : a[j];
+      myinv = (r == j) ? inv : myinv;
+    }
+    if (lane < DS_NB) {
+      double *orow = A + size_t(p + r) * ld + p;
+#pragma unroll
+      for (int c = 0; c < DS_NB; ++c)
+        if (c <= r) orow[c] = a[c];
+      invd[p + r] = myinv;
+    }
+    return ok;
+  }
+
+  // A22 -= L21 D L21^T on the fp64 matrix cores, one 16x16 tile of the lower triangle per wave at a time.
+  // v_mfma_f64_16x16x4: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D row = (l >> 4) + 4 reg, col = l & 15.
+  __device__ __forceinline__ void trailing_update_mfma(double *A, int ld, int npad, int p) const {
+    const int q0 = p + DS_NB, nb = (npad - q0) / DS_NB;
+    const int i = lane & 15, kq = lane >> 4;
+    double dk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) dk[kk] = A[size_t(p + 4 * kk + kq) * ld + p + 4 * kk + kq];
+    int t = 0;
+    for (int I = 0; I < nb; ++I)
+      for (int J = 0; J <= I; ++J, ++t) {
+        if (t % nwave != wave) continue;
+        const int rb = q0 + DS_NB * I, cb = q0 + DS_NB * J;
+        v4f64 acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = A[size_t(rb + kq + 4 * rr) * ld + cb + i];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = 4 * kk + kq;
+          const double aop = -A[size_t(rb + i) * ld + p + k];
+          const double bop = A[size_t(cb + i) * ld + p + k] * dk[kk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = kq + 4 * rr;
+          if (I != J || row >= i) A[size_t(rb + row) * ld + cb + i] = acc[rr];   // a diagonal tile keeps its strict upper triangle
+        }
+      }
+  }
+
+  // x_blk of L^T x = z for the 16 unknowns at p: lane j keeps y_j and column j of the unit-lower block
+  __device__ __forceinline__ void panel_backsolve_regs(double *A, int ld, int p, double *gz, const double *part) const {
+    const int j = lane & 15;
+    double s2 = 0.0;
+    for (int sl = 0; sl < 32; ++sl) s2 += part[sl * 16 + j];
+    double y = gz[p + j] - s2;
+    double col[DS_NB];
+#pragma unroll
+    for (int k = 0; k < DS_NB; ++k) col[k] = (k > j) ? A[size_t(p + k) * ld + p + j] : 0.0;
+#pragma unroll
+    for (int k = DS_NB - 1; k >= 1; --k) {
+      const double yk = ds_bcast_lane(y, k);
+      y -= col[k] * yk;
+    }
+    if (lane < DS_NB) gz[p + j] = y;
+  }
+};
+
+}  // namespace lio
+#endif

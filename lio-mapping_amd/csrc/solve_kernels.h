@@ -77,13 +77,12 @@ int moment_blocks_per_frame_batched(int max_slots, int nframes);
 void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int blocks_per_frame, int max_slots, const uint8_t *valid,
                                   const float4 *coef, double *partials, double *out, hipStream_t s, int form = 0);
 
-// One iteration of the device-resident dogleg (solve_step.h): launch A (moments at the candidate + aux row) and launch B
-// (k_solve_step), both on `s`, no host interaction.  The StepBuffers' partials must be `partials`.
-struct DevProblem;
-struct DevState;
-struct StepBuffers;
-void launch_solve_iteration(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, const DevProblem *pb, DevState *st,
-                            const StepBuffers &B, double *imu_out, double *lmap, double *prior_out, double *exprior_out, int n_pad, hipStream_t s);
+// One iteration of the device-resident dogleg (solve_step.h) for every window of a batch: launch A (moments at the candidate + aux
+// row) and launch B (one workgroup per window), both on `s`, no host interaction.  BatchSolve is declared in solve_step.h.
+struct BatchSolve;
+void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s);
+// blocks per frame of a window's moments pass inside a batch: a function of the window's own slot counts only
+int batch_blocks_per_frame(int max_slots);
 
 // test hook: x = A^-1 b through the blocked LDS L D L^T of launch B (A symmetric positive definite, n <= 128, row-major).
 // 1 ok, 0 a pivot was not positive, -1 the upper triangle was disturbed, -2 does not fit.

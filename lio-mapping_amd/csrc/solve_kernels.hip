@@ -14,10 +14,9 @@
 
 #include "solve_kernels.h"
 #include "solve_step.h"
+#include "solve_device.h"
 
 namespace lio {
-
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 #define MOMENT_THREADS 256
 
@@ -59,7 +58,6 @@ struct LogProduct {
   __device__ __forceinline__ double log_value() const { return log(prod) + exp2 * 0.69314718055994530942; }
 };
 
-__device__ __forceinline__ double ds_bcast_lane(double v, int src_lane);   // defined below (v_readlane of both halves)
 
 #define ZROW 17  // 16 doubles per residual + 1 pad: conflict-free ds_write_b64 (lane stride 136 B)
 
@@ -692,6 +690,11 @@ void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, 
   LIO_HIP(hipGetLastError());
 }
 
+// Inside a batch the partition of a window's factor slots must not depend on the batch (a window gives the same bits alone and in
+// any company): 2048 slots per block — eight 64-slot chunks per wave, enough for the chunk loop's three-deep prefetch to fill the
+// MFMA issue slots — and never more than 64 blocks per frame.
+int batch_blocks_per_frame(int max_slots) { return std::max(1, std::min(cdiv(max_slots, MOMENT_THREADS * 8), 64)); }
+
 int moment_blocks_per_frame_batched(int max_slots, int nframes) {
   // enough waves to fill the chip about four times over, each with as many chunks as possible (the chunk loop is software
   // pipelined: more chunks per wave = more MFMA issue slots filled with the next chunk's setup)
@@ -724,175 +727,54 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
 }
 
 // ================================================================================================
-// Device-resident dogleg (solve_step.h): the kernel-side executor and the two launches of one iteration
+// Device-resident dogleg (solve_step.h): the two launches of one iteration (the kernel-side executor DevExec: solve_device.h)
 // ================================================================================================
-__device__ __forceinline__ double ds_bcast_lane(double v, int src_lane) {   // src_lane: wave-uniform (a constant after unrolling)
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, src_lane);
-  hi = __builtin_amdgcn_readlane(hi, src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-struct DevExec {
-  static constexpr bool kDevice = true;
-  static constexpr int WT = 64;
-  int tid, nthr, lane, wave, nwave;
-  __device__ __forceinline__ void sync() const { __syncthreads(); }
-  __device__ __forceinline__ double wsum(double v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-  }
-  __device__ __forceinline__ double wmax(double v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = u > v ? u : v; }
-    return v;
-  }
-  // 1 / d from the hardware estimate and two Newton steps (<= 1 ulp): a correctly rounded fp64 divide is ~40 instructions on
-  // the pivot chain of the factorisation
-  __device__ __forceinline__ double rcp(double d) const {
-    double y = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    return y;
-  }
-  // lanes 4m .. 4m+3 hold v0..v3: every one of them gets (v0 + v1) + (v2 + v3)
-  __device__ __forceinline__ void stamp(long long *prof, int k) const { if (prof && tid == 0) prof[k] = clock64(); }
-  __device__ __forceinline__ double pair_sum4(double v) const {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    return v;
-  }
-
-  // L D L^T of the 16x16 diagonal block at p: lane r (mod 16) keeps row r in registers, pivots and columns travel by
-  // v_readlane; the arithmetic and its order are those of the reference loop in ds_panel_factor.
-  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd) const {
-    const int r = lane & 15;
-    double a[DS_NB];
-    const double *row = A + size_t(p + r) * ld + p;
-#pragma unroll
-    for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
-    int ok = 1;
-    double myinv = 0.0;
-#pragma unroll
-    for (int j = 0; j < DS_NB; ++j) {
-      const double d = ds_bcast_lane(a[j], j);
-      ok &= (d > 0.0) ? 1 : 0;
-      const double inv = rcp(d);
-      const double t = a[j];
-      const double l = t * inv;
-#pragma unroll
-      for (int c = j + 1; c < DS_NB; ++c) {
-        const double tc = ds_bcast_lane(t, c);
-        a[c] -= l * tc;
-      }
-      a[j] = (r > j) ? l : a[j];
-      myinv = (r == j) ? inv : myinv;
-    }
-    if (lane < DS_NB) {
-      double *orow = A + size_t(p + r) * ld + p;
-#pragma unroll
-      for (int c = 0; c < DS_NB; ++c)
-        if (c <= r) orow[c] = a[c];
-      invd[p + r] = myinv;
-    }
-    return ok;
-  }
-
-  // A22 -= L21 D L21^T on the fp64 matrix cores, one 16x16 tile of the lower triangle per wave at a time.
-  // v_mfma_f64_16x16x4: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D row = (l >> 4) + 4 reg, col = l & 15.
-  __device__ __forceinline__ void trailing_update_mfma(double *A, int ld, int npad, int p) const {
-    const int q0 = p + DS_NB, nb = (npad - q0) / DS_NB;
-    const int i = lane & 15, kq = lane >> 4;
-    double dk[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) dk[kk] = A[size_t(p + 4 * kk + kq) * ld + p + 4 * kk + kq];
-    int t = 0;
-    for (int I = 0; I < nb; ++I)
-      for (int J = 0; J <= I; ++J, ++t) {
-        if (t % nwave != wave) continue;
-        const int rb = q0 + DS_NB * I, cb = q0 + DS_NB * J;
-        v4f64 acc;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = A[size_t(rb + kq + 4 * rr) * ld + cb + i];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int k = 4 * kk + kq;
-          const double aop = -A[size_t(rb + i) * ld + p + k];
-          const double bop = A[size_t(cb + i) * ld + p + k] * dk[kk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = kq + 4 * rr;
-          if (I != J || row >= i) A[size_t(rb + row) * ld + cb + i] = acc[rr];   // a diagonal tile keeps its strict upper triangle
-        }
-      }
-  }
-
-  // x_blk of L^T x = z for the 16 unknowns at p: lane j keeps y_j and column j of the unit-lower block
-  __device__ __forceinline__ void panel_backsolve_regs(double *A, int ld, int p, double *gz, const double *part) const {
-    const int j = lane & 15;
-    double s2 = 0.0;
-    for (int sl = 0; sl < 32; ++sl) s2 += part[sl * 16 + j];
-    double y = gz[p + j] - s2;
-    double col[DS_NB];
-#pragma unroll
-    for (int k = 0; k < DS_NB; ++k) col[k] = (k > j) ? A[size_t(p + k) * ld + p + j] : 0.0;
-#pragma unroll
-    for (int k = DS_NB - 1; k >= 1; --k) {
-      const double yk = ds_bcast_lane(y, k);
-      y -= col[k] * yk;
-    }
-    if (lane < DS_NB) gz[p + j] = y;
-  }
-};
-
-// Launch A of an iteration.  Grid (max(bpf, Wo + 1), Wo + 1): rows 0 .. Wo-1 are the moments of frames 1 .. Wo at the candidate's
-// T_{pivot<-i} (read from the device-resident state, not from the launch arguments); row Wo is the aux row: block i < Wo the
-// ImuFactor between optimised frames i and i + 1 and the lidar linear map of frame i + 1, block Wo the marginalization prior
-// and the extrinsic prior — all of it at the candidate, all of it hidden under the moments pass.
-template <bool SYM>
-__global__ void __launch_bounds__(MOMENT_THREADS) k_lidar_moments_dev(MomentArgs a, const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
-                                                                      double *__restrict__ partials, const DevProblem *__restrict__ pb,
-                                                                      const DevState *__restrict__ st, const double *__restrict__ prior_mats,
-                                                                      double *__restrict__ imu_out, double *__restrict__ lmap,
-                                                                      double *__restrict__ prior_out, double *__restrict__ exprior_out) {
-  if (st->done) return;
-  const int Wo = a.nframes;
+// Launch A of an iteration, for every window of a batch.  Grid (max(bpf, Wo + 1), Wo + 1, windows): rows 0 .. Wo-1 of a window are
+// the moments of its frames 1 .. Wo at the candidate's T_{pivot<-i} (read from the device-resident state, not from the launch
+// arguments); row Wo is the aux row: block i < Wo the ImuFactor between optimised frames i and i + 1 and the lidar linear map of
+// frame i + 1, block Wo the marginalization prior and the extrinsic prior — all of it at the candidate, all of it hidden under
+// the moments pass.  A window that is done (converged, or handed back to the host) costs its blocks one load.
+__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_moments_dev(const BatchSolve *__restrict__ bs, const uint8_t *__restrict__ valid,
+                                                                   const float4 *__restrict__ coef) {
+  const BatchSolve &S = bs[blockIdx.z];
+  const DevState *st = S.st;
+  if (!S.active || st->done) return;
+  const int Wo = S.nframes;
   if (int(blockIdx.y) < Wo) {
-    if (int(blockIdx.x) >= a.blocks_per_frame) return;
-    MomentFrame fr = a.fr[blockIdx.y];
+    if (int(blockIdx.x) >= S.bpf) return;
+    MomentFrame fr = S.fr[blockIdx.y];
     const double *Rt = st->cand_Rt[blockIdx.y];
 #pragma unroll
     for (int k = 0; k < 9; ++k) fr.R[k] = Rt[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
-    if (SYM) lidar_moments_sym_body(fr, valid, coef, partials, a.blocks_per_frame);
-    else lidar_moments_body(fr, valid, coef, partials, a.blocks_per_frame);
+    lidar_moments_body(fr, valid, coef, S.partials, S.bpf);
     return;
   }
+  if (int(blockIdx.y) != Wo) return;
   __shared__ double aux_lds[1024];
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int i = blockIdx.x;
   const DevParams &P = st->cand;
+  const DevProblem *pb = S.pb;
   if (i < Wo) {
-    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], imu_out + size_t(i) * DS_IMU_OUT, aux_lds);
+    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], S.imu_out + size_t(i) * DS_IMU_OUT, aux_lds);
     __syncthreads();
-    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
   } else if (i == Wo) {
-    if (pb->have_prior) aux_prior(x, *pb, prior_mats, P, prior_out, aux_lds);
-    if (pb->use_ex_prior) aux_exprior(x, *pb, P, exprior_out);
+    if (pb->have_prior) aux_prior(x, *pb, S.prior_mats, P, S.prior_out, aux_lds);
+    if (pb->use_ex_prior) aux_exprior(x, *pb, P, S.exprior_out);
   }
 }
 
-// Launch B: one workgroup (solve_step.h)
-__global__ void __launch_bounds__(DS_THREADS) k_solve_step(const DevProblem *__restrict__ pb, DevState *st, StepBuffers B) {
+// Launch B: one workgroup per window (solve_step.h)
+__global__ void __launch_bounds__(DS_THREADS) k_bw_solve_step(const BatchSolve *__restrict__ bs) {
   extern __shared__ __attribute__((aligned(16))) double ds_lds[];
+  const BatchSolve &S = bs[blockIdx.x];
+  if (!S.active) return;
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
-  solve_step(x, *pb, *st, B, ds_lds);
+  StepBuffers B{S.prior_mats, S.partials, S.imu_out, S.lmap, S.prior_out, S.exprior_out, S.Hcur, S.S_buf, S.prof};
+  solve_step(x, *S.pb, *S.st, B, ds_lds);
 }
 
 // Test hook (lio_ldlt_solve): the LDS-resident blocked L D L^T + back-substitution of launch B on its own
@@ -937,24 +819,16 @@ int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipSt
   return ok;
 }
 
-void launch_solve_iteration(const MomentArgs &a, const uint8_t *valid, const float4 *coef, double *partials, const DevProblem *pb, DevState *st,
-                            const StepBuffers &B, double *imu_out, double *lmap, double *prior_out, double *exprior_out, int n_pad, hipStream_t s) {
+void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+  if (B <= 0) return;
   static const bool attr_set = [] {
-    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return true;
   }();
   (void)attr_set;
-  int max_slots = 0;
-  for (int k = 0; k < a.nframes; ++k) max_slots = std::max(max_slots, a.fr[k].slot_end - a.fr[k].slot_begin);
-  const dim3 grid(std::max(a.blocks_per_frame, a.nframes + 1), a.nframes + 1);
-  if (use_mfma(max_slots, a.blocks_per_frame, a.form))
-    hipLaunchKernelGGL(k_lidar_moments_dev<false>, grid, dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, pb, st, B.prior_mats, imu_out, lmap, prior_out,
-                       exprior_out);
-  else
-    hipLaunchKernelGGL(k_lidar_moments_dev<true>, grid, dim3(MOMENT_THREADS), 0, s, a, valid, coef, partials, pb, st, B.prior_mats, imu_out, lmap, prior_out,
-                       exprior_out);
-  const size_t lds = ds_lds_doubles(n_pad, a.nframes) * sizeof(double);
-  hipLaunchKernelGGL(k_solve_step, dim3(1), dim3(DS_THREADS), lds, s, pb, st, B);
+  hipLaunchKernelGGL(k_bw_moments_dev, dim3(std::max(max_bpf, max_wo + 1), max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
+  const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);
+  hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs);
   LIO_HIP(hipGetLastError());
 }
 

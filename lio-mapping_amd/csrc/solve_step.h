@@ -265,6 +265,31 @@ struct StepBuffers {
   long long *prof;             // optional: 32 shader-clock stamps of the last launch B (LIO_DEBUG_TIMING)
 };
 
+// ---- one window of a batch (device array; est_batch.hip fills it): everything the two launches of an iteration and the
+// marginalization launches read for that window
+struct DevMarg {
+  DevParams x;                       // the parameters after DoubleToVector / VectorToDouble: the point the prior is linearised at
+  int active;                        // 0: this window does not marginalise this time (turn_off, no marginalization_factor, host fallback)
+  int Wo, m, n;                      // dropped (pose 0 [+ speed-bias 0]) and kept tangent sizes (MarginalizationFactor.cc:185-311)
+  int has_imu, have_prior;
+  int pose_col[DS_MAX_WO + 1], sb_col[2], ex_col;   // columns of the marginalization's layout (-1: block absent)
+  int prior_col[DS_MAX_NPAD];        // column of [dropped | kept] -> column of the OLD prior (-1: none)
+};
+struct BatchSolve {
+  int active;                        // 0: the window is not solved on the device this time
+  int nframes, bpf;
+  MomentFrame fr[DS_MAX_WO];         // slot_off: offset into the batch's slot arrays; R, t are overwritten from the state
+  const DevProblem *pb;
+  DevState *st;
+  const double *prior_mats;          // the window's prior on the device (ds_prior_mats_size(np) doubles)
+  double *partials, *imu_out, *lmap, *prior_out, *exprior_out, *Hcur, *S_buf;
+  long long *prof;
+  // marginalization (launch_bw_marginalize, marg_kernels.hip)
+  const DevMarg *marg;
+  double *marg_imu, *marg_lmap, *marg_prior_out, *marg_A, *marg_info;
+  double *next_prior_mats;           // where the new prior goes (same layout as prior_mats)
+};
+
 struct StepLds {
   double *A, *hdiag, *gz, *invd, *scale, *diag, *grad, *gn, *g, *step, *tmp, *zb, *part, *red;
   int *ctl;
@@ -412,6 +437,37 @@ LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, do
   return 1;
 }
 
+// Frame blocks of the normal equations from the folded moments: LS = L S (18 x 13), then H_i = (L S) L^T (18 x 18) and
+// g_i = (L S) l into zb[f * 344 + ..] (324 + 18 used).  S: Wo x LIO_MOMENT_OUT (row-major 16 x 16 tiles), lmap: Wo x DS_LMAP_OUT,
+// LS: Wo x 234 doubles of scratch.  Shared by the step kernel and the marginalization's assembly.
+template <class X>
+LIO_HD void ds_lidar_blocks(const X &x, int Wo, const double *lmap, const double *S, double *LS, double *zb, long long *prof = nullptr) {
+  for (int e = x.tid; e < Wo * 234; e += x.nthr) {
+    const int f = e / 234, a = (e % 234) / 13, b = e % 13;
+    const double *Lm = lmap + size_t(f) * DS_LMAP_OUT, *Sf = S + f * LIO_MOMENT_OUT;
+    double o = 0.0;
+    for (int k = 0; k < 13; ++k) o += Lm[a * 13 + k] * Sf[k * 16 + b];
+    LS[e] = o;
+  }
+  x.sync();
+  x.stamp(prof, 2);
+  for (int e = x.tid; e < Wo * 342; e += x.nthr) {
+    const int f = e / 342, r = e % 342;
+    const double *Lm = lmap + size_t(f) * DS_LMAP_OUT, *ls = LS + f * 234;
+    double o = 0.0;
+    if (r < 324) {
+      const int a = r / 18, b = r % 18;
+      for (int k = 0; k < 13; ++k) o += ls[a * 13 + k] * Lm[b * 13 + k];
+    } else {
+      const int a = r - 324;
+      for (int k = 0; k < 13; ++k) o += ls[a * 13 + k] * Lm[234 + k];
+    }
+    zb[f * 344 + r] = o;
+  }
+  x.sync();
+  x.stamp(prof, 3);
+}
+
 // ------------------------------------------------------------------------------------------------ launch B
 template <class X>
 LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const StepBuffers &B, double *lds_base) {
@@ -455,32 +511,8 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   }
   x.sync();
   x.stamp(B.prof, 1);
-  // ---- P2: LS = L S (18 x 13 per frame)
-  for (int e = x.tid; e < Wo * 234; e += x.nthr) {
-    const int f = e / 234, a = (e % 234) / 13, b = e % 13;
-    const double *Lm = B.lmap + size_t(f) * DS_LMAP_OUT, *Sf = Sx + f * LIO_MOMENT_OUT;
-    double o = 0.0;
-    for (int k = 0; k < 13; ++k) o += Lm[a * 13 + k] * Sf[k * 16 + b];
-    LS[e] = o;
-  }
-  x.sync();
-  x.stamp(B.prof, 2);
-  // ---- P3: H_i = (L S) L^T (18 x 18), g_i = (L S) l
-  for (int e = x.tid; e < Wo * 342; e += x.nthr) {
-    const int f = e / 342, r = e % 342;
-    const double *Lm = B.lmap + size_t(f) * DS_LMAP_OUT, *ls = LS + f * 234;
-    double o = 0.0;
-    if (r < 324) {
-      const int a = r / 18, b = r % 18;
-      for (int k = 0; k < 13; ++k) o += ls[a * 13 + k] * Lm[b * 13 + k];
-    } else {
-      const int a = r - 324;
-      for (int k = 0; k < 13; ++k) o += ls[a * 13 + k] * Lm[234 + k];
-    }
-    L.zb[f * 344 + r] = o;
-  }
-  x.sync();
-  x.stamp(B.prof, 3);
+  // ---- P2, P3: H_i = (L S) L^T (18 x 18), g_i = (L S) l per frame
+  ds_lidar_blocks(x, Wo, B.lmap, Sx, LS, L.zb, B.prof);
   // ---- P4: assemble the candidate's H (full, unscaled) and g in the order of WindowSystem::evaluate:
   // prior, ImuFactor 0..Wo-1, lidar frames 1..Wo, extrinsic prior
   const double *JtJ = B.prior_mats;
@@ -841,8 +873,9 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
 // ------------------------------------------------------------------------------------------------ host side: packing
 // WindowSystem / WindowParams (host_solver.h) -> the POD problem the kernels read.  false: the problem does not fit the
 // device-resident path (too many optimised frames for the LDS-resident factorisation, no lidar factors) -> host solver.
+// prior_mats == nullptr: the caller already holds the prior's matrices on the device
 inline bool ds_pack_problem(const WindowSystem &sys, const WindowParams &P, int max_iterations, int bpf, bool conv_flag_in, bool imu_on,
-                            DevProblem &pb, std::vector<double> &prior_mats) {
+                            DevProblem &pb, std::vector<double> *prior_mats) {
   const Layout lay = WindowSystem::solve_layout(P);
   if (P.Wo < 1 || P.Wo > DS_MAX_WO || !sys.use_lidar) return false;
   const int npad = (lay.dim + DS_NB - 1) / DS_NB * DS_NB;
@@ -851,7 +884,7 @@ inline bool ds_pack_problem(const WindowSystem &sys, const WindowParams &P, int 
   pb.Wo = P.Wo; pb.n = lay.dim; pb.n_pad = npad; pb.ld = npad + 1; pb.ex_col = lay.ex;
   pb.max_iterations = max_iterations; pb.bpf = bpf; pb.conv_flag_in = conv_flag_in ? 1 : 0; pb.imu_on = imu_on ? 1 : 0;
   for (int i = 0; i < DS_MAX_NPAD + 8; ++i) pb.prior_col[i] = -1;
-  prior_mats.clear();
+  if (prior_mats) prior_mats->clear();
   if (sys.prior) {
     const MargPrior &pr = *sys.prior;
     if (int(pr.keep.size()) > DS_MAX_KEEP) return false;
@@ -867,12 +900,14 @@ inline bool ds_pack_problem(const WindowSystem &sys, const WindowParams &P, int 
       const int la = kb.size == 7 ? 6 : kb.size;
       for (int i = 0; i < la; ++i) pb.prior_col[col + i] = kb.idx + i;
     }
-    const size_t np = size_t(pr.n);
-    prior_mats.resize(ds_prior_mats_size(pr.n));
-    std::memcpy(prior_mats.data(), pr.JtJ.a.data(), sizeof(double) * np * np);
-    std::memcpy(prior_mats.data() + np * np, pr.lin_jac.a.data(), sizeof(double) * np * np);
-    std::memcpy(prior_mats.data() + 2 * np * np, pr.lin_res.data(), sizeof(double) * np);
-    std::memcpy(prior_mats.data() + 2 * np * np + np, pr.Jtr0.data(), sizeof(double) * np);
+    if (prior_mats) {
+      const size_t np = size_t(pr.n);
+      prior_mats->resize(ds_prior_mats_size(pr.n));
+      std::memcpy(prior_mats->data(), pr.JtJ.a.data(), sizeof(double) * np * np);
+      std::memcpy(prior_mats->data() + np * np, pr.lin_jac.a.data(), sizeof(double) * np * np);
+      std::memcpy(prior_mats->data() + 2 * np * np, pr.lin_res.data(), sizeof(double) * np);
+      std::memcpy(prior_mats->data() + 2 * np * np + np, pr.Jtr0.data(), sizeof(double) * np);
+    }
   }
   pb.use_ex_prior = sys.use_prior_factor ? 1 : 0;
   pb.ex_prior_pos[0] = sys.prior_pos.x; pb.ex_prior_pos[1] = sys.prior_pos.y; pb.ex_prior_pos[2] = sys.prior_pos.z;

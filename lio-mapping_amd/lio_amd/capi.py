@@ -92,7 +92,6 @@ class EstConfig(C.Structure):
         ("extrinsic_stage", C.c_int),
         ("init_window_factor", C.c_int),
         ("device_solve", C.c_int),
-        ("device_marg", C.c_int),
         ("inline_marg", C.c_int),
         ("stream_sync", C.c_int),
         ("moments_form", C.c_int),
@@ -232,6 +231,14 @@ _SIGS = {
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_solve_restored": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolveReport)]),
+    "lio_est_copy_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lio_est_batch_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
+    "lio_est_batch_destroy": (None, [C.c_void_p]),
+    "lio_est_batch_size": (C.c_int, [C.c_void_p]),
+    "lio_est_batch_solve": (C.c_int, [C.c_void_p, C.POINTER(SolveReport)]),
+    "lio_est_batch_solve_restored": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolveReport)]),
+    "lio_est_batch_sync": (C.c_int, [C.c_void_p]),
+    "lio_est_batch_get_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lio_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lio_rccl_init": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
@@ -945,11 +952,59 @@ class Estimator:
     def restore(self):
         _chk(self.lib.dll.lio_est_restore(self.h), "lio_est_restore")
 
+    def copy_snapshot_of(self, src):
+        """this handle's snapshot <- a copy of src's (lio_est_copy_snapshot)"""
+        _chk(self.lib.dll.lio_est_copy_snapshot(self.h, src.h), "lio_est_copy_snapshot")
+
     def solve_restored(self, steps):
         """`steps` x (restore + SolveOptimization) inside the library -> the last solve's report"""
         rep = SolveReport()
         _chk(self.lib.dll.lio_est_solve_restored(self.h, int(steps), C.byref(rep)), "lio_est_solve_restored")
         return rep
+
+
+class EstimatorBatch:
+    """lio_est_batch: B estimators solved together, every stage one launch over all windows (include/lio_c.h).  The batch adopts
+    the estimators; they must outlive it (this object keeps them referenced)."""
+
+    def __init__(self, lib: LioLib, estimators):
+        self.lib = lib
+        self.members = list(estimators)
+        arr = (C.c_void_p * len(self.members))(*[e.h for e in self.members])
+        self.h = lib.dll.lio_est_batch_create(arr, len(self.members))
+        if not self.h:
+            raise LioError("lio_est_batch_create failed (null / duplicate / already adopted window, or no device)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dll.lio_est_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __len__(self):
+        return int(self.lib.dll.lio_est_batch_size(self.h))
+
+    def solve(self):
+        reps = (SolveReport * len(self.members))()
+        _chk(self.lib.dll.lio_est_batch_solve(self.h, reps), "lio_est_batch_solve")
+        return list(reps)
+
+    def solve_restored(self, steps):
+        reps = (SolveReport * len(self.members))()
+        _chk(self.lib.dll.lio_est_batch_solve_restored(self.h, int(steps), reps), "lio_est_batch_solve_restored")
+        return list(reps)
+
+    def sync(self):
+        _chk(self.lib.dll.lio_est_batch_sync(self.h), "lio_est_batch_sync")
+
+    def clock(self):
+        out = (C.c_double * 16)()
+        _chk(self.lib.dll.lio_est_batch_get_clock(self.h, out), "lio_est_batch_get_clock")
+        names = ["describe", "filter", "grid_features_rounds", "pack", "solve", "finish", "fallback", "total", "n_device", "rounds",
+                 "dev_filter", "dev_grid", "dev_features", "dev_rounds", "dev_loop", "dev_marg"]
+        return dict(zip(names, [float(v) for v in out]))
 
 
 def load_hip() -> LioLib:

@@ -738,6 +738,14 @@ int lio_est_restore(lio_est *h) {
   return LIO_OK;
 }
 
+int lio_est_copy_snapshot(lio_est *dst, lio_est *src) {
+  if (!dst || !src) return LIO_ERR_ARG;
+  if (!src->snap) return LIO_ERR_STATE;
+  dst->snap.reset(new Estimator(*src->snap));
+  if (src->snap->tmp_pre_integration) dst->snap->tmp_pre_integration = std::make_shared<IntegrationBase>(*src->snap->tmp_pre_integration);
+  return LIO_OK;
+}
+
 int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
   if (!h || steps < 0) return LIO_ERR_ARG;
   for (int k = 0; k < steps; ++k) {
@@ -748,6 +756,42 @@ int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
   }
   return LIO_OK;
 }
+
+// lio_est_batch (include/lio_c.h): the oracle has one way to solve a window; a batch is a loop over its members
+struct lio_est_batch { std::vector<lio_est *> members; };
+lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
+  if (!windows || n < 1) return nullptr;
+  for (int i = 0; i < n; ++i) if (!windows[i]) return nullptr;
+  lio_est_batch *b = new lio_est_batch;
+  b->members.assign(windows, windows + n);
+  return b;
+}
+void lio_est_batch_destroy(lio_est_batch *b) { delete b; }
+int lio_est_batch_size(const lio_est_batch *b) { return b ? int(b->members.size()) : 0; }
+int lio_est_batch_solve(lio_est_batch *b, lio_solve_report *reps) {
+  if (!b) return LIO_ERR_ARG;
+  for (size_t w = 0; w < b->members.size(); ++w) {
+    const int rc = lio_est_solve_optimization(b->members[w], reps ? reps + w : nullptr);
+    if (rc != LIO_OK) return rc;
+  }
+  return LIO_OK;
+}
+int lio_est_batch_solve_restored(lio_est_batch *b, int steps, lio_solve_report *reps) {
+  if (!b || steps < 0) return LIO_ERR_ARG;
+  for (int k = 0; k < steps; ++k) {
+    for (lio_est *m : b->members) { const int rc = lio_est_restore(m); if (rc != LIO_OK) return rc; }
+    const int rc = lio_est_batch_solve(b, reps);
+    if (rc != LIO_OK) return rc;
+  }
+  return LIO_OK;
+}
+int lio_est_batch_sync(lio_est_batch *b) { return b ? LIO_OK : LIO_ERR_ARG; }
+int lio_est_batch_get_clock(const lio_est_batch *b, double *out) {
+  if (!b || !out) return LIO_ERR_ARG;
+  for (int k = 0; k < 16; ++k) out[k] = 0.0;
+  return LIO_OK;
+}
+
 
 // oracle-only probes (not part of lio_c.h): include/utils/math_utils.h:44-64, pinned by the reference's own
 // assertions at test/test_point_processor/test_point_processor.cc:57-61

@@ -66,7 +66,7 @@ bool run_device_emulated(Window &w, int max_iterations, bool conv_flag_in, DevRu
   const int Wo = w.Wo, bpf = 7;
   DevProblem pb;
   std::vector<double> prior_mats;
-  if (!ds_pack_problem(w.sys, w.P, max_iterations, bpf, conv_flag_in, true, pb, prior_mats)) return false;
+  if (!ds_pack_problem(w.sys, w.P, max_iterations, bpf, conv_flag_in, true, pb, &prior_mats)) return false;
   if (prior_mats.empty()) prior_mats.resize(4);
   DevState &st = out.st;
   ds_init_state(w.P, st);

@@ -13,8 +13,9 @@ moments per linearisation; strong scaling).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (HIP events on the
 estimator's stream), `cpu_baseline` = the CPU oracle timed on this box's host cores on the same window,
-`batched` = throughput with several independent windows in flight on the one GPU (the single-window path
-is latency-bound; this shows how far the same kernels go when the GPU is given more to do),
+`batched` = lio_est_batch: B in {8, 64, 512} copies of the window solved per launch chain — solves/s and the
+device time, algorithmic bytes and roofline fraction of every stage (the single-window path is latency-bound; this is the path's
+throughput mode),
 `keyframe_batch` = BASELINE.json configs[4] at --keyframes keyframes (N = 1 only).
 
 `--workload keyframes` makes configs[4] the bench line itself: a step = one refinement of all --keyframes keyframes,
@@ -65,16 +66,23 @@ def feature_clouds(lib, ds):
     return clouds, ms
 
 
+def est_config(lib, ds, kind, W, Wo):
+    from lio_amd import pipeline
+
+    cfg = pipeline.config_outdoor64(lib, W, Wo) if kind == "outdoor" else pipeline.config_indoor(lib, W, Wo)
+    if kind != "outdoor":
+        cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
+    pipeline.set_extrinsic(cfg, ds)
+    return cfg
+
+
 def make_estimator(lib, ds, clouds, kind, W, Wo):
     """Window initialised from ground truth + noise, EXTRA_FRAMES-1 frames fed through ProcessLaserOdom so a
     marginalization prior exists, then the last frame pushed (upload + VoxelGrid + window push) — the state right
     before the SolveOptimization under test — and snapshotted."""
     from lio_amd import capi, pipeline
 
-    cfg = pipeline.config_outdoor64(lib, W, Wo) if kind == "outdoor" else pipeline.config_indoor(lib, W, Wo)
-    if kind != "outdoor":
-        cfg.cutoff_deskew, cfg.keep_features, cfg.prior_factor = 1, 0, 1
-    pipeline.set_extrinsic(cfg, ds)
+    cfg = est_config(lib, ds, kind, W, Wo)
     est = capi.Estimator(lib, cfg)
     pipeline.init_window(est, lib, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01)
     est.solve()
@@ -300,7 +308,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes that measure roofline.traffic live")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)   # internal: a few solves on the pickled workload, run under rocprofv3
     ap.add_argument("--cpu-steps", type=int, default=8)
-    ap.add_argument("--windows", type=int, default=4, help="independent windows in flight for the `batched` extra (0 = skip)")
+    ap.add_argument("--windows", default="8,64,512", help="batch sizes of the `batched` extra (lio_est_batch: B windows per launch chain); 0 = skip")
     ap.add_argument("--keyframes", type=int, default=1000, help="keyframes of the batched-refinement extra (configs[4]); 0 = skip")
     ap.add_argument("--shard-factors", action="store_true",
                     help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
@@ -522,8 +530,9 @@ def main():
                                        "actual_GBps_at_33B_per_slot": round(gbps * 33.0 / 60.0, 1), "frac_actual": round(gbps * 33.0 / 60.0 / 8000.0, 4),
                                        "mfma_f64_GFLOPs": round(bytes_b / 60.0 * 684.0 / (ms_b * 1e-3) / 1e9, 1)})
         batched = None
-        if args.windows > 1 and not args.shard_factors and world == 1:
-            batched = batched_throughput(hip, ds, clouds, kind, W, Wo, est, args.windows, max(10, args.steps // 2))
+        if args.windows and not args.shard_factors and world == 1:
+            sizes = sorted({int(v) for v in str(args.windows).split(",") if int(v) > 0})
+            batched = batched_windows(hip, ds, kind, W, Wo, est, sizes, rep)
 
         # the rest of the estimator step a sweep triggers (Estimator::ProcessLaserOdom = push + solve + slide, Estimator.cc:430-774):
         # IMU samples of the interval, PushFrame (upload + VoxelGrid of the new surf stack + window push), SlideWindow
@@ -761,35 +770,78 @@ def fed_gpu_points(hip, ds, est, captured, W, Wo):
     return out
 
 
-def batched_throughput(hip, ds, clouds, kind, W, Wo, est0, n_windows, steps):
-    """B independent windows (same data, separate estimators / HIP streams / host threads) in flight on ONE GPU."""
-    import torch
+def batched_windows(hip, ds, kind, W, Wo, est0, sizes, rep0, min_seconds=0.4):
+    """B windows per launch chain through lio_est_batch (every stage ONE launch over all windows, trust-region
+    loop and marginalization on the device).  The windows are copies of the headline window at distinct addresses
+    (lio_est_copy_snapshot); a step = restore every window + lio_est_batch_solve, looped inside the library; the last step's
+    marginalizations are inside the timed region (lio_est_batch_solve_restored ends with a wait for the batch's stream).
+    Per stage: device time (HIP events on the batch's stream, last step), SURVEY.md 8(d) algorithmic bytes of B windows, fraction of
+    the 8 TB/s HBM roofline; the trust-region loop also against the 78.6 TFLOP/s fp64 matrix pipe (684 flop per residual and pass)."""
+    from lio_amd import capi
 
-    dev = torch.cuda.current_device()
-    ests = [est0] + [make_estimator(hip, ds, clouds, kind, W, Wo) for _ in range(n_windows - 1)]
-    for e in ests:
-        one_step(e)
-    bar = threading.Barrier(n_windows + 1)
+    pivot = W - Wo
+    n_stack = [est0.get_surf_stack(i).shape[0] for i in range(W + 1)]
+    n_local = sum(n_stack[pivot:W])
+    m_static = sum(n_stack[pivot + 1:W])
+    m_new = n_stack[W]
+    n_map = int(rep0.n_local_map)
+    n_res = int(rep0.n_lidar_residuals)
+    n_slots = m_static + m_new
+    cfg = est_config(hip, ds, kind, W, Wo)
+    clones = []
+    points = []
+    for B in sizes:
+        while len(clones) < B:
+            e = capi.Estimator(hip, cfg)
+            e.copy_snapshot_of(est0)
+            e.restore()
+            clones.append(e)
+        batch = capi.EstimatorBatch(hip, clones[:B])
+        batch.solve_restored(2)            # warm-up: buffers, the sort's and the scan's scratch, the priors' upload
+        steps, dt = 2, 0.0
+        while True:
+            t0 = time.perf_counter()
+            reps = batch.solve_restored(steps)
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds or steps >= 256:
+                break
+            steps = min(256, max(steps * 2, int(steps * 1.3 * min_seconds / max(dt, 1e-6)) + 1))
+        clk = batch.clock()
+        passes = reps[0].iterations + 1
+        it_same = all(r.iterations == reps[0].iterations and r.n_lidar_residuals == reps[0].n_lidar_residuals for r in reps)
 
-    def run(e):
-        torch.cuda.set_device(dev)  # a new host thread starts on device 0
-        bar.wait()
-        for _ in range(steps):
-            one_step(e)
-        e.sync()
-        bar.wait()
+        def stage(ms, nbytes, flops=None):
+            d = {"device_ms": round(ms, 4), "algorithmic_MB": round(nbytes * B / 1e6, 2)}
+            if ms > 0:
+                gbps = nbytes * B / (ms * 1e-3) / 1e9
+                d["achieved_GBps"] = round(gbps, 1)
+                d["frac_of_8TBps"] = round(gbps / 8000.0, 4)
+                if flops is not None:
+                    d["mfma_f64_TFLOPs"] = round(flops * B / (ms * 1e-3) / 1e12, 3)
+                    d["frac_of_78p6_TFLOPs"] = round(flops * B / (ms * 1e-3) / 78.6e12, 4)
+            return d
 
-    ts = [threading.Thread(target=run, args=(e,)) for e in ests]
-    for t in ts:
-        t.start()
-    bar.wait()
-    t0 = time.perf_counter()
-    bar.wait()
-    dt = time.perf_counter() - t0
-    for t in ts:
-        t.join()
-    return {"windows": n_windows, "steps_per_window": steps, "value": round(n_windows * steps / dt, 3), "unit": "solves/s",
-            "note": "independent windows, one HIP stream + host thread each, same GPU"}
+        rounds = int(clk["rounds"])
+        points.append({
+            "windows": B, "steps": steps, "value": round(B * steps / dt, 1), "unit": "solves/s", "ms_per_batch_step": round(1e3 * dt / steps, 3),
+            "windows_on_device_loop": int(clk["n_device"]), "all_windows_same_decisions": bool(it_same),
+            "solver_iterations": int(reps[0].iterations), "n_lidar_residuals": int(reps[0].n_lidar_residuals), "newest_frame_rounds": rounds,
+            "host_ms": {k: round(clk[k], 3) for k in ("describe", "filter", "grid_features_rounds", "pack", "solve", "finish", "total")},
+            "stages": {
+                "filter (concat + keys, sort, heads, centroids)": stage(clk["dev_filter"], 32.0 * n_local),
+                "knn_grid (histogram, scan, placement)": stage(clk["dev_grid"], 32.0 * n_map),
+                "features (older frames)": stage(clk["dev_features"], 16.0 * (m_static + n_map) + 72.0 * m_static),
+                "newest_frame_rounds": stage(clk["dev_rounds"], rounds * (16.0 * (m_new + n_map) + 72.0 * m_new + 33.0 * m_new)),
+                "trust_region_loop (moments + aux row, step)": stage(clk["dev_loop"], 60.0 * n_slots * passes, 684.0 * n_res * passes),
+                "marginalization (aux row, Schur + eigensolves)": {"device_ms": round(clk["dev_marg"], 4)},
+            },
+        })
+        batch.close()
+    return {"note": "lio_est_batch: B copies of the headline window at distinct addresses, one launch per stage over all windows; value = B x steps / wall time "
+                    "of lio_est_batch_solve_restored (restore + solve per step, the last marginalizations inside); stage device times = HIP events of the last step",
+            "per_window": {"local_map_points_before_filter": int(n_local), "local_map_points": n_map, "older_frames_queries": int(m_static), "newest_frame_queries": int(m_new),
+                           "residual_slots": int(n_slots)},
+            "points": points}
 
 
 def odometry_ms_per_scan(hip, ds):

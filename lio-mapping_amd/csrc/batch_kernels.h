@@ -10,7 +10,6 @@ namespace lio {
 
 #define LIO_BW_MAX_SEG 8        // segments of a local map: the pivot's cloud + the Wo - 1 frames behind it (Wo <= 7)
 #define LIO_BW_MAX_STATIC 7     // frames whose features do not depend on the newest frame's rounds
-#define LIO_BW_LPQ 4            // lanes per query of the batched search kernels (fixed: the row partition of a round depends on it)
 
 struct BwSeg { const float4 *src; int n; int dst_off; int identity; int set_intensity; float intensity; Affine3f tf; };
 
@@ -36,7 +35,7 @@ struct BwVoxOut { int count; VoxParams params; int range_overflow; };
 // the K-NN grid of a window (host-computed from the filter's bounds, uploaded before the cell build)
 struct BatchGrid { GridDesc g; int cell_off; int n_filtered; };
 
-int bw_round_blocks(int M);   // search blocks of one round of a window's newest frame (LIO_BW_LPQ lanes per query)
+int bw_round_blocks(int M);   // search blocks of one round of a window's newest frame: 64 queries each, whatever the lanes per query
 
 // concat + voxel keys + per-block bounds.  keys64 / vals: loc-array sized; partial: 8 floats per 256-point block
 void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, unsigned long long *keys64, uint32_t *vals, float *partial,
@@ -51,9 +50,11 @@ void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int
                           hipStream_t s);
 void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
                           const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s);
-void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, const float4 *sorted_all, const int *cells_all,
-                        uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);
-void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, int round, OdomState *odom, const float4 *sorted_all, const int *cells_all,
-                          uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials, int *n_converged, hipStream_t s);
+// total_queries: stack points of the launch over all windows — picks the lanes per query (the results do not depend on it)
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const float4 *sorted_all,
+                        const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, int round, OdomState *odom,
+                          const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials,
+                          int *n_converged, hipStream_t s);
 
 }  // namespace lio

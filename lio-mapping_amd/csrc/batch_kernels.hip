@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "batch_kernels.h"
 #include "cloud_device.h"
@@ -12,7 +13,7 @@ namespace lio {
 
 #define BW_THREADS 256
 
-int bw_round_blocks(int M) { return std::max(1, cdiv((long long)M * LIO_BW_LPQ, ODOM_ROUND_THREADS)); }
+int bw_round_blocks(int M) { return std::max(1, cdiv(M, 64)); }
 
 // ------------------------------------------------------------------------------------------------
 // BuildLocalMap, first half: pcl::transformPointCloud + `+=` (Estimator.cc:1480-1507) and, from the point still in registers, the
@@ -288,36 +289,54 @@ void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// CalculateFeatures (Estimator.cc:1014-1097) of the frames behind the pivot: grid (blocks of the largest frame, frames, windows)
+// CalculateFeatures (Estimator.cc:1014-1097) of the frames behind the pivot: grid (64-query blocks of the largest frame, frames,
+// windows).  A block always owns 64 queries; LPQ lanes work on each, so the block is 64 LPQ threads wide.  The result does not
+// depend on LPQ (the candidate set and the total order (distance, index) do not: cloud_device.h), which therefore follows the
+// size of the launch: eight lanes shorten a query's dependent candidate walk when the launch is small, one lane per query wins
+// once the launch fills the chip many times over (no merge shuffles, no idle lanes in the fit; DESIGN.md: keyframe batch).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FEAT_THREADS) k_bw_features(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
-                                                             const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all,
-                                                             uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) {
+template <int LPQ>
+__global__ void __launch_bounds__(64 * LPQ) k_bw_features(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                         const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all,
+                                                         uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) {
   const int w = blockIdx.z;
   const BatchWin &W = win[w];
   if (int(blockIdx.y) >= W.nstatic) return;
   const BatchGrid &G = grid[w];
   const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
-  features_block<false, LIO_BW_LPQ>(W.fr[blockIdx.y], fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
-                                    nullptr);
+  features_block<false, LPQ, 64 * LPQ>(W.fr[blockIdx.y], fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
+                                       nullptr);
 }
-void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, const float4 *sorted_all, const int *cells_all,
-                        uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {
+int bw_lanes_per_query(long long total_queries) {
+  static const int forced = [] { const char *e = std::getenv("LIO_BW_LPQ"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }();
+  if (forced) return forced;
+  return total_queries >= 400000 ? 1 : (total_queries >= 60000 ? 4 : 8);
+}
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const float4 *sorted_all,
+                        const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {
   if (B <= 0 || max_M <= 0 || max_static <= 0) return;
-  hipLaunchKernelGGL(k_bw_features, dim3(cdiv((long long)max_M * LIO_BW_LPQ, FEAT_THREADS), max_static, B), dim3(FEAT_THREADS), 0, s, win, grid, sorted_all, cells_all,
-                     valid_all, coef_all, score_all);
+  const dim3 g(cdiv(max_M, 64), max_static, B);
+  switch (bw_lanes_per_query(total_queries)) {
+    case 1: hipLaunchKernelGGL(k_bw_features<1>, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
+    case 2: hipLaunchKernelGGL(k_bw_features<2>, g, dim3(128), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
+    case 4: hipLaunchKernelGGL(k_bw_features<4>, g, dim3(256), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
+    default: hipLaunchKernelGGL(k_bw_features<8>, g, dim3(512), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
+  }
   LIO_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
 // One round of CalculateLaserOdom (Estimator.cc:1242-1359) for every window whose newest frame has not converged: the search /
-// fit / rows launch and the fold + 6x6 step launch of cloud_kernels.hip's launch_odom_round, windows in blockIdx.y / .x
+// fit / rows launch and the fold + 6x6 step launch of cloud_kernels.hip's launch_odom_round, windows in blockIdx.y / .x.
+// A search block owns 64 queries whatever the lanes per query, and leaves ONE row of partial sums: the fold — and with it
+// every bit of the step — does not depend on how wide the launch made its blocks.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_bw_odom_round(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
-                                                                     const OdomState *__restrict__ odom, const float4 *__restrict__ sorted_all,
-                                                                     const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
-                                                                     float4 *__restrict__ coef_all, float *__restrict__ score_all,
-                                                                     double *__restrict__ partials, int round) {
+template <int LPQ>
+__global__ void __launch_bounds__(64 * LPQ) k_bw_odom_round(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                           const OdomState *__restrict__ odom, const float4 *__restrict__ sorted_all,
+                                                           const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
+                                                           float4 *__restrict__ coef_all, float *__restrict__ score_all,
+                                                           double *__restrict__ partials, int round) {
   const int w = blockIdx.y;
   const OdomState &st = odom[w];
   if (st.converged) return;
@@ -328,8 +347,8 @@ __global__ void __launch_bounds__(ODOM_ROUND_THREADS) k_bw_odom_round(const Batc
   const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   const Vec3<float> t(tp[4], tp[5], tp[6]);
   const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
-  const double v = odom_round_block<LIO_BW_LPQ>(fs, W.newest, q, t, sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all, W.newest.slot_off, round,
-                                                W.keep, int(blockIdx.x));
+  const double v = odom_round_block<LPQ, 64 * LPQ>(fs, W.newest, q, t, sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all, W.newest.slot_off,
+                                                   round, W.keep, int(blockIdx.x));
   if (threadIdx.x < 28) partials[(size_t(W.part_off) + blockIdx.x) * 28 + threadIdx.x] = v;
 }
 __global__ void __launch_bounds__(1024) k_bw_odom_update(const BatchWin *__restrict__ win, OdomState *__restrict__ odom, const double *__restrict__ partials,
@@ -341,11 +360,17 @@ __global__ void __launch_bounds__(1024) k_bw_odom_update(const BatchWin *__restr
   odom_update_wide_block(partials + size_t(W.part_off) * 28, W.nb_round, st, round, 0, 0, nullptr, HostSignal());
   if (threadIdx.x == 0 && st->converged) atomicAdd(n_converged, 1);   // (thread 0 wrote the flag itself)
 }
-void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, int round, OdomState *odom, const float4 *sorted_all, const int *cells_all,
-                          uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials, int *n_converged, hipStream_t s) {
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, int round, OdomState *odom,
+                          const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials,
+                          int *n_converged, hipStream_t s) {
   if (B <= 0 || max_nb <= 0) return;
-  hipLaunchKernelGGL(k_bw_odom_round, dim3(max_nb, B), dim3(ODOM_ROUND_THREADS), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials,
-                     round);
+  const dim3 g(max_nb, B);
+  switch (bw_lanes_per_query(total_queries)) {
+    case 1: hipLaunchKernelGGL(k_bw_odom_round<1>, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
+    case 2: hipLaunchKernelGGL(k_bw_odom_round<2>, g, dim3(128), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
+    case 4: hipLaunchKernelGGL(k_bw_odom_round<4>, g, dim3(256), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
+    default: hipLaunchKernelGGL(k_bw_odom_round<8>, g, dim3(512), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
+  }
   hipLaunchKernelGGL(k_bw_odom_update, dim3(B), dim3(1024), 0, s, win, odom, partials, round, n_converged);
   LIO_HIP(hipGetLastError());
 }

@@ -262,11 +262,11 @@ __device__ __forceinline__ void features_body(const FeatFrame fr, const FeatScal
 // (the fit used to occupy one lane in LPQ of every wave while costing all of its issue slots — these kernels are bound by
 // vector-instruction issue, not by memory).
 #define FEAT_THREADS 256
-template <bool MAPPING, int LPQ>
+template <bool MAPPING, int LPQ, int THREADS = FEAT_THREADS>
 __device__ __forceinline__ void features_block(const FeatFrame fr, const FeatScalars fs, int block_x, const float *__restrict__ transforms, const float4 *__restrict__ map,
                                                const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
                                                float4 *__restrict__ coef, float *__restrict__ score, float4 *__restrict__ abs_coef) {
-  constexpr int QPB = FEAT_THREADS / LPQ;
+  constexpr int QPB = THREADS / LPQ;
   static_assert(QPB <= 64, "the fit phase is one wave");
   __shared__ int s_bj[QPB][5];
   __shared__ float s_bd4[QPB];
@@ -393,16 +393,15 @@ __device__ __forceinline__ void odom_update_from_sums(const double *ssum, OdomSt
 #define ODOM_ROUND_THREADS 256
 // one block's share of a round at the transform (q, t): phase 1 on all lanes, phase 2 on wave 0, which leaves the block's 28 sums
 // in `out28` (lanes 0..27 of wave 0 return them; the other waves return 0 and must not use the value)
-template <int LPQ>
+template <int LPQ, int THREADS = ODOM_ROUND_THREADS>
 __device__ __forceinline__ double odom_round_block(const FeatScalars fs, FeatFrame fr, const Quat<float> q, const Vec3<float> t, const float4 *__restrict__ map,
                                                    const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid, float4 *__restrict__ coef,
                                                    float *__restrict__ score, int base_slot, int round, int keep, int block) {
-  constexpr int QPB = ODOM_ROUND_THREADS / LPQ;   // queries per block
+  constexpr int QPB = THREADS / LPQ;   // queries per block
   static_assert(QPB <= 64, "the fit phase is one wave");
   __shared__ int s_bj[QPB][5];
   __shared__ float s_bd4[QPB];
   __shared__ int s_bi4[QPB];
-  __shared__ double rows[QPB][29];
   const int M = fr.M;
   fr.slot_off = base_slot + (keep ? round * M : 0);
   {   // ---- phase 1: search, LPQ lanes per query
@@ -447,16 +446,15 @@ __device__ __forceinline__ double odom_round_block(const FeatScalars fs, FeatFra
         }
       if (res.ok) odom_row_accumulate(res.po, res.c, q, t, Rm, Rinv, 0, acc);
     }
-    if (ql < QPB) {
+    // the block's 28 sums: an xor butterfly over the wave's 64 lanes (lanes without a query hold zeros) — a fixed tree, so the
+    // sums do not depend on how many lanes worked on a query, and no LDS (the first form parked 64 x 28 doubles there, which
+    // capped the one-lane-per-query launch at ten waves per CU)
 #pragma unroll
-      for (int k = 0; k < 28; ++k) rows[ql][k] = acc[k];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (threadIdx.x < 28) {
+    for (int k = 0; k < 28; ++k) {
+      double sres = acc[k];
 #pragma unroll
-      for (int qq = 0; qq < QPB; ++qq) v += rows[qq][threadIdx.x];
+      for (int o = 32; o > 0; o >>= 1) sres += __shfl_xor(sres, o, 64);
+      if (int(threadIdx.x) == k) v = sres;
     }
   }
   return v;

@@ -69,6 +69,14 @@ class EstimatorBatch {
   std::vector<Estimator *> m_;
   std::vector<Win> win_;
   hipStream_t stream_ = nullptr;
+  // The trust-region loop runs in up to kGroups groups of windows, each a launch chain on a stream of its own: a group's step
+  // kernel (one workgroup per window: a quarter of the chip at 64 windows) overlaps the other groups' moments passes.  The
+  // marginalization runs on a stream of its own behind the loop and is joined before the next solve's problems go up: it
+  // overlaps the next solve's filter, features and rounds.
+  static constexpr int kGroups = 4;
+  hipStream_t stream_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_marg_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_marg_ = nullptr;
+  bool marg_in_flight_ = false;
   hipEvent_t ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid_ = false;
   Slab lay_{};

@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace lio {
@@ -20,6 +21,11 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   const size_t B = m_.size();
   LIO_HIP(hipStreamCreate(&stream_));
   for (hipEvent_t &e : ev_) LIO_HIP(hipEventCreate(&e));
+  for (hipStream_t &g : stream_grp_) LIO_HIP(hipStreamCreate(&g));
+  LIO_HIP(hipStreamCreate(&stream_marg_));
+  LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  LIO_HIP(hipEventCreateWithFlags(&ev_marg_, hipEventDisableTiming));
+  for (hipEvent_t &e : ev_grp_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   win_.resize(B);
   for (size_t w = 0; w < B; ++w) { win_[w].e = m_[w]; m_[w]->AdoptStream(stream_); }
   pinned(h_win_, B); pinned(h_grid_, B); pinned(h_vout_, B); pinned(h_odom_, B); pinned(h_bs_, B); pinned(h_pb_, B); pinned(h_st_, B); pinned(h_mg_, B);
@@ -47,6 +53,7 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
 EstimatorBatch::~EstimatorBatch() {
   try {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (stream_marg_) (void)hipStreamSynchronize(stream_marg_);
     for (size_t w = 0; w < win_.size(); ++w)
       for (int k = 0; k < 2; ++k) if (win_[w].dev_prior[k]) win_[w].dev_prior[k]->materialize();   // nobody may be left holding a shell
     for (Estimator *e : m_) { e->solve_hook_ = nullptr; e->ReleaseAdoptedStream(); }
@@ -55,12 +62,18 @@ EstimatorBatch::~EstimatorBatch() {
                   static_cast<void *>(h_pb_), static_cast<void *>(h_st_), static_cast<void *>(h_mg_), static_cast<void *>(h_prior_), static_cast<void *>(h_nconv_)})
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_grp_) if (e) (void)hipEventDestroy(e);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_marg_) (void)hipEventDestroy(ev_marg_);
+  for (hipStream_t g : stream_grp_) if (g) (void)hipStreamDestroy(g);
+  if (stream_marg_) (void)hipStreamDestroy(stream_marg_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 const BatchClock &EstimatorBatch::clock() {
   if (ev_valid_) {
     LIO_HIP(hipStreamSynchronize(stream_));
+    LIO_HIP(hipStreamSynchronize(stream_marg_));
     for (int k = 0; k < 6; ++k) {
       float ms = 0;
       clk_.dev[k] = hipEventElapsedTime(&ms, ev_[k], ev_[k + 1]) == hipSuccess ? double(ms) : 0.0;
@@ -70,13 +83,16 @@ const BatchClock &EstimatorBatch::clock() {
   return clk_;
 }
 
-void EstimatorBatch::Sync() { LIO_HIP(hipStreamSynchronize(stream_)); }
+void EstimatorBatch::Sync() {
+  LIO_HIP(hipStreamSynchronize(stream_));
+  LIO_HIP(hipStreamSynchronize(stream_marg_));
+}
 
 // the matrices of the prior held in device buffer `buf` of window w -> pr (the fetch of a MargPrior shell)
 void EstimatorBatch::FetchPrior(int w, int buf, MargPrior &pr) {
   const size_t n = size_t(pr.n);
   std::vector<double> h(ds_prior_mats_size(pr.n));
-  LIO_HIP(hipStreamSynchronize(stream_));
+  Sync();
   LIO_HIP(hipMemcpy(h.data(), slab_.p + size_t(w) * lay_.total + lay_.prior[buf], h.size() * sizeof(double), hipMemcpyDeviceToHost));
   pr.JtJ = DMat(pr.n, pr.n); pr.lin_jac = DMat(pr.n, pr.n); pr.lin_res.assign(n, 0.0); pr.Jtr0.assign(n, 0.0);
   std::memcpy(pr.JtJ.a.data(), h.data(), sizeof(double) * n * n);
@@ -102,6 +118,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   ev_valid_ = false;
   // ------------------------------------------------------------------------------------------------ describe
   int off = 0, slot = 0, part_rows = 0, max_cap = 0, max_slots = 0, max_M = 0, max_static = 0, max_nb = 0;
+  long long q_static = 0, q_newest = 0;
   for (int w = 0; w < B; ++w) {
     Win &Wn = win_[w];
     Estimator *e = Wn.e;
@@ -117,8 +134,8 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     }
     bw.loc_off = off; bw.loc_cap = round_up(std::max(bw.n_local, 1), 256); off += bw.loc_cap;
     bw.slot_base = slot; slot += round_up(bw.n_slots, 16);
-    for (int k = 0; k < bw.nstatic; ++k) { bw.fr[k].slot_off += bw.slot_base; max_M = std::max(max_M, bw.fr[k].M); }
-    bw.newest.slot_off += bw.slot_base;
+    for (int k = 0; k < bw.nstatic; ++k) { bw.fr[k].slot_off += bw.slot_base; max_M = std::max(max_M, bw.fr[k].M); q_static += bw.fr[k].M; }
+    bw.newest.slot_off += bw.slot_base; q_newest += bw.newest.M;
     bw.part_off = part_rows; part_rows += bw.nb_round;
     max_cap = std::max(max_cap, bw.loc_cap); max_slots = std::max(max_slots, bw.n_slots); max_static = std::max(max_static, bw.nstatic);
     max_nb = std::max(max_nb, bw.nb_round);
@@ -199,14 +216,17 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   launch_bw_cell_place(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cells_all_.p, sorted_all_.p, cnt_all_.p, s);
   cnt_dirty_ = false;
   LIO_HIP(hipEventRecord(ev_[2], s));
-  launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
+  launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, q_static, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
   LIO_HIP(hipEventRecord(ev_[3], s));
   int round = 0;
   for (; round < 3; ++round)
-    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
                          nconv_.p, s);
-  // ---- while the device searches: the problems of Estimator.cc:1660-1921, packed for the device loop
+  // ---- while the device searches: the problems of Estimator.cc:1660-1921, packed for the device loop.  Their uploads overwrite
+  // what the previous solve's marginalization (on its own stream) still reads: everything enqueued from here on waits for it —
+  // it has had this solve's filter, grids, features and first rounds to finish.
   const double t3a = bnow_ms();
+  if (marg_in_flight_) { LIO_HIP(hipStreamWaitEvent(s, ev_marg_, 0)); marg_in_flight_ = false; }
   int max_bpf = 1, max_wo = 1, max_npad = DS_NB;
   size_t part_total = 0;
   for (int w = 0; w < B; ++w) {
@@ -254,7 +274,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
       LIO_HIP(hipStreamSynchronize(s));
       if (*h_nconv_ >= B) break;
     }
-    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
                          nconv_.p, s);
   }
   clk_.rounds = round;
@@ -287,7 +307,8 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     S.prior_mats = slab + lay_.prior[Wn.cur]; S.next_prior_mats = slab + lay_.prior[1 - Wn.cur];
     S.partials = partials_.p + Wn.part_off;
     S.imu_out = slab + lay_.imu; S.lmap = slab + lay_.lmap; S.prior_out = slab + lay_.prior_out; S.exprior_out = slab + lay_.exprior;
-    S.Hcur = slab + lay_.Hcur; S.S_buf = slab + lay_.Sbuf; S.prof = nullptr;
+    static const bool dbg_prof = std::getenv("LIO_DEBUG_TIMING") != nullptr;
+    S.Hcur = slab + lay_.Hcur; S.S_buf = slab + lay_.Sbuf; S.prof = (dbg_prof && w == 0) ? reinterpret_cast<long long *>(slab + lay_.prof) : nullptr;
     S.marg_imu = slab + lay_.marg_imu; S.marg_lmap = slab + lay_.marg_lmap; S.marg_prior_out = slab + lay_.marg_prior_out;
     S.marg_A = slab + lay_.marg_A; S.marg_info = slab + lay_.marg_info;
     max_it = std::max(max_it, e->cfg_.max_num_iterations);
@@ -295,13 +316,38 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   }
   LIO_HIP(hipMemcpyAsync(d_bs_.p, h_bs_, sizeof(BatchSolve) * B, hipMemcpyHostToDevice, s));
   if (n_dev > 0) {
-    // iteration k evaluates candidate k (k = 0: the initial point); a window that is done costs its blocks one load each
-    for (int k = 0; k <= max_it; ++k) launch_bw_solve_iteration(d_bs_.p, B, max_bpf, max_wo, max_npad, valid_all_.p, coef_all_.p, s);
+    // iteration k evaluates candidate k (k = 0: the initial point); a window that is done costs its blocks one load each.
+    // Groups of windows run their chains side by side (see est_batch.h); one group below 32 windows.
+    static const int g_env = [] { const char *e = std::getenv("LIO_BW_GROUPS"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= kGroups) ? v : 0; }();
+    const int G = g_env ? std::min(g_env, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
+    if (G > 1) LIO_HIP(hipEventRecord(ev_fork_, s));
+    for (int g = 0; g < G; ++g) {
+      const int w0 = int((long long)B * g / G), w1 = int((long long)B * (g + 1) / G);
+      hipStream_t sg = G > 1 ? stream_grp_[g] : s;
+      if (G > 1) LIO_HIP(hipStreamWaitEvent(sg, ev_fork_, 0));
+      int g_bpf = 1, g_wo = 1, g_npad = DS_NB, g_it = 0, g_n = 0;
+      for (int w = w0; w < w1; ++w) {
+        if (!win_[w].device) continue;
+        const Estimator *e = win_[w].e;
+        g_bpf = std::max(g_bpf, win_[w].bpf); g_wo = std::max(g_wo, e->Wo_); g_npad = std::max(g_npad, h_pb_[w].n_pad);
+        g_it = std::max(g_it, e->cfg_.max_num_iterations); ++g_n;
+      }
+      if (g_n > 0)
+        for (int k = 0; k <= g_it; ++k) launch_bw_solve_iteration(d_bs_.p + w0, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
+      if (G > 1) { LIO_HIP(hipEventRecord(ev_grp_[g], sg)); LIO_HIP(hipStreamWaitEvent(s, ev_grp_[g], 0)); }
+    }
     LIO_HIP(hipEventRecord(ev_[5], s));
     LIO_HIP(hipMemcpyAsync(h_st_, d_st_.p, sizeof(DevState) * B, hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));
   } else {
     LIO_HIP(hipEventRecord(ev_[5], s));
+  }
+  if (h_bs_[0].prof) {   // LIO_DEBUG_TIMING: the phase stamps of window 0's last launch B (shader clock, 100 MHz wall clock is not used here)
+    long long pr[32];
+    LIO_HIP(hipMemcpy(pr, h_bs_[0].prof, sizeof(pr), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[lio_hip timing] launch B of window 0, last launch, clock64 ticks from its start:");
+    for (int k = 0; k < 24; ++k) std::fprintf(stderr, " P%d %lld", k, pr[k] ? pr[k] - pr[0] : -1);
+    std::fprintf(stderr, "\n");
   }
   clk_.iterations = max_it + 1;
   const double t4 = bnow_ms();
@@ -332,10 +378,13 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   }
   clk_.n_device = B - int(host_path.size()); clk_.n_host = int(host_path.size());
   if (n_marg > 0) {
-    LIO_HIP(hipMemcpyAsync(d_mg_.p, h_mg_, sizeof(DevMarg) * B, hipMemcpyHostToDevice, s));
-    launch_bw_marginalize(d_bs_.p, B, max_wo, max_n, s);
+    // (the host has waited for the loop; the marginalization's inputs — final moments, states, problems — are complete)
+    LIO_HIP(hipMemcpyAsync(d_mg_.p, h_mg_, sizeof(DevMarg) * B, hipMemcpyHostToDevice, stream_marg_));
+    launch_bw_marginalize(d_bs_.p, B, max_wo, max_n, stream_marg_);
+    LIO_HIP(hipEventRecord(ev_marg_, stream_marg_));
+    marg_in_flight_ = true;
   }
-  LIO_HIP(hipEventRecord(ev_[6], s));
+  LIO_HIP(hipEventRecord(ev_[6], stream_marg_));
   ev_valid_ = true;
   const double t5 = bnow_ms();
   clk_.finish = t5 - t4;

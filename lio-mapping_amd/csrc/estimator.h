@@ -190,7 +190,7 @@ class Estimator {
   void SetWindow(const double *Ps, const double *Rs, const double *Vs, const double *Bas, const double *Bgs, const double g[3]);
   void SetSurfStack(int frame, const float *xyzi, size_t n);
   size_t GetSurfStack(int frame, float *out);
-  void SetPreintegration(int frame, std::shared_ptr<Preintegration> p) { pre_integrations_[frame] = std::move(p); }
+  void SetPreintegration(int frame, std::shared_ptr<Preintegration> p) { pre_integrations_[frame] = std::move(p); frames_dirty_ = true; }
   void BeginFrame(const V3d &acc, const V3d &gyr);
   size_t GetLocalMap(float *out);
   size_t GetFeatures(int frame, double *pt, double *co, double *sc);
@@ -336,6 +336,10 @@ class Estimator {
   bool host_signal_ = true;
   int device_id_ = 0;
   HostSignal moment_signal_{};
+  // Restore() re-copies the per-frame containers (pre-integrations, laser transforms, stamped poses, the running pre-integration)
+  // only if something touched them since they last equalled the snapshot's: a solve does not, and at hundreds of windows per
+  // batch step their copies were the host's largest share of a restore + solve step
+  bool frames_dirty_ = true;
   std::unique_ptr<HostState> snap_;
   std::vector<DeviceCloud> snap_stacks_;
 };

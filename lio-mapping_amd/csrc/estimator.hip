@@ -171,6 +171,7 @@ void Estimator::PushState(int from) {  // Ps_.push(Ps_[from]) ... (Estimator.cc:
 }
 
 void Estimator::ProcessImu(double dt, const V3d &acc, const V3d &gyr, double stamp) {
+  frames_dirty_ = true;
   if (!first_imu_) {
     first_imu_ = true; acc_last_ = acc; gyr_last_ = gyr;
     if (n_state_ == 0) n_state_ = 1;  // the zero state pushed at :347-354 (the buffers already hold it)
@@ -198,6 +199,7 @@ void Estimator::ProcessImu(double dt, const V3d &acc, const V3d &gyr, double sta
 }
 
 void Estimator::BeginFrame(const V3d &acc, const V3d &gyr) {
+  frames_dirty_ = true;
   acc_last_ = acc; gyr_last_ = gyr; first_imu_ = true;
   tmp_pre_integration_ = std::make_shared<Preintegration>(acc_last_, gyr_last_, Bas_[cir_buf_count_], Bgs_[cir_buf_count_], cfg_.pim);
 }
@@ -234,6 +236,7 @@ void Estimator::SetSurfStack(int frame, const float *xyzi, size_t n) {
   LIO_HIP(hipStreamSynchronize(stream_));
   c.n = n;
   size_surf_stack_[frame] = n;
+  frames_dirty_ = true;
 }
 size_t Estimator::GetSurfStack(int frame, float *out) {
   const DeviceCloud &c = stacks_[frame];
@@ -345,6 +348,7 @@ void Estimator::SetStatesFromLaser() {  // :507-513, :892-906
 
 // Estimator.cc:858-958
 bool Estimator::RunInitialization() {
+  frames_dirty_ = true;
   {
     V3d sum_g;
     for (int i = 0; i < W_; ++i) {
@@ -376,6 +380,7 @@ bool Estimator::RunInitialization() {
 
 bool Estimator::PushFrame(const Rigidf &transform_in, const float *surf, size_t n_surf, const float * /*corner*/, size_t /*n_corner*/,
                           double stamp, bool surf_on_device) {
+  frames_dirty_ = true;
   // every precondition is checked BEFORE the window is touched: a refused frame leaves the estimator as it was
   if (inited_ && (cfg_.enable_deskew || cfg_.cutoff_deskew) && !cfg_.cutoff_deskew && imu_stamped_.empty()) return false;
   LaserFrame lf;
@@ -1135,6 +1140,7 @@ void Estimator::SlideWindow() {
 
 void Estimator::Snapshot() {
   JoinMarg();
+  frames_dirty_ = true;   // (the next Restore copies everything once, then the containers equal the snapshot's)
   snap_.reset(new HostState{Ps_, Vs_, Bas_, Bgs_, Rs_, g_vec_, acc_last_, gyr_last_, transform_lb_, inited_, first_imu_, init_local_map_,
                             convergence_flag_, cir_buf_count_, all_laser_transforms_, n_state_, n_frames_, laser_odom_recv_count_,
                             extrinsic_stage_, last_event_, initial_time_, R_WI_, last_marg_, pre_integrations_,
@@ -1154,6 +1160,7 @@ void Estimator::Snapshot() {
 bool Estimator::CopySnapshotOf(Estimator &src) {
   if (!src.snap_ || src.W_ != W_ || src.Wo_ != Wo_ || &src == this) return false;
   JoinMarg();
+  frames_dirty_ = true;
   snap_.reset(new HostState(*src.snap_));   // pre-integrations and the prior are immutable once pushed: shared
   snap_stacks_.resize(src.snap_stacks_.size());
   for (size_t i = 0; i < src.snap_stacks_.size(); ++i) {
@@ -1173,11 +1180,15 @@ bool Estimator::Restore() {
   const HostState &h = *snap_;
   Ps_ = h.Ps; Vs_ = h.Vs; Bas_ = h.Bas; Bgs_ = h.Bgs; Rs_ = h.Rs; g_vec_ = h.g_vec; acc_last_ = h.acc_last; gyr_last_ = h.gyr_last;
   transform_lb_ = h.transform_lb; inited_ = h.inited; first_imu_ = h.first_imu; init_local_map_ = h.init_local_map;
-  convergence_flag_ = h.convergence_flag; cir_buf_count_ = h.cir_buf_count; last_marg_ = h.last_marg; pre_integrations_ = h.pre_integrations;
-  all_laser_transforms_ = h.all_laser_transforms; n_state_ = h.n_state; n_frames_ = h.n_frames; laser_odom_recv_count_ = h.laser_odom_recv_count;
+  convergence_flag_ = h.convergence_flag; cir_buf_count_ = h.cir_buf_count; last_marg_ = h.last_marg;
+  n_state_ = h.n_state; n_frames_ = h.n_frames; laser_odom_recv_count_ = h.laser_odom_recv_count;
   extrinsic_stage_ = h.extrinsic_stage; last_event_ = h.last_event; initial_time_ = h.initial_time; R_WI_ = h.R_WI;
-  tmp_pre_integration_ = h.tmp_pre_integration ? std::make_shared<Preintegration>(*h.tmp_pre_integration) : nullptr;
-  size_surf_stack_ = h.size_surf_stack; imu_stamped_ = h.imu_stamped;
+  if (frames_dirty_) {
+    pre_integrations_ = h.pre_integrations; all_laser_transforms_ = h.all_laser_transforms;
+    tmp_pre_integration_ = h.tmp_pre_integration ? std::make_shared<Preintegration>(*h.tmp_pre_integration) : nullptr;
+    size_surf_stack_ = h.size_surf_stack; imu_stamped_ = h.imu_stamped;
+    frames_dirty_ = false;
+  }
   for (size_t i = 0; i < stacks_.size(); ++i) {
     if (stacks_[i].id == snap_stacks_[i].id && stacks_[i].n == snap_stacks_[i].n) continue;  // untouched since the snapshot
     stacks_[i].id = snap_stacks_[i].id;

@@ -50,9 +50,17 @@ struct DevExec {
     return v;
   }
 
-  // L D L^T of the 16x16 diagonal block at p: lane r (mod 16) keeps row r in registers, pivots and columns travel by
-  // v_readlane; the arithmetic and its order are those of the reference loop in ds_panel_factor.
-  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd) const {
+  // L D L^T of the 16x16 diagonal block at p by ONE wave: lane r (mod 16) keeps row r in registers; per pivot the block's column j
+  // goes through 16 doubles of LDS and comes back to every lane as broadcast reads (the first form moved it with 2 x 15 v_readlane
+  // per pivot: 10.6 us per block, profiles/r5_c_step_phases.txt).  Then X = L11^-1 (lane c: column c by forward substitution, L11
+  // read back from the block as broadcast LDS reads) is left row-major in scr[64 .. 320): the rows below the block are solved
+  // against it on the matrix cores (panel_trsm_mfma).  scr: >= 320 doubles of LDS.
+  __device__ __forceinline__ void wave_lds_sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd, double *scr) const {
     const int r = lane & 15;
     double a[DS_NB];
     const double *row = A + size_t(p + r) * ld + p;
@@ -60,18 +68,21 @@ struct DevExec {
     for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
     int ok = 1;
     double myinv = 0.0;
+    // Measured on the MI355X (tools/micro/pivot_chain.hip, profiles/r5_pivot_chain.txt): a dependent fp64 FMA 14 cycles, rcp + two
+    // Newton steps 64, an LDS write -> wave barrier -> read 92, a v_readlane broadcast + use 76.  A pivot is one LDS round trip (the
+    // block's column j out, every lane reads what it needs back as broadcast reads) + the reciprocal + two multiplies on the chain.
+    // (Building X inside this loop — a second LDS exchange per pivot — was measured slower: 20.4 k cycles against 12.4 k.)
 #pragma unroll
     for (int j = 0; j < DS_NB; ++j) {
-      const double d = ds_bcast_lane(a[j], j);
+      double *bc = scr + (j & 1) * DS_NB;
+      if (lane < DS_NB) bc[lane] = a[j];
+      wave_lds_sync();
+      const double d = bc[j];
       ok &= (d > 0.0) ? 1 : 0;
       const double inv = rcp(d);
-      const double t = a[j];
-      const double l = t * inv;
+      const double l = a[j] * inv;
 #pragma unroll
-      for (int c = j + 1; c < DS_NB; ++c) {
-        const double tc = ds_bcast_lane(t, c);
-        a[c] -= l * tc;
-      }
+      for (int c = j + 1; c < DS_NB; ++c) a[c] -= l * bc[c];
       a[j] = (r > j) ? l : a[j];
       myinv = (r == j) ? inv : myinv;
     }
@@ -82,7 +93,60 @@ struct DevExec {
         if (c <= r) orow[c] = a[c];
       invd[p + r] = myinv;
     }
+    wave_lds_sync();
+    // X = L11^-1: lane c solves L11 x = e_c by forward substitution (two interleaved partial sums per row)
+    {
+      const int c = lane & 15;
+      double xcol[DS_NB];
+#pragma unroll
+      for (int k = 0; k < DS_NB; ++k) xcol[k] = (k == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int rr = 1; rr < DS_NB; ++rr) {
+        const double *lr = A + size_t(p + rr) * ld + p;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) { if (k & 1) acc1 += lr[k] * xcol[k]; else acc0 += lr[k] * xcol[k]; }
+        xcol[rr] = (rr > c) ? -(acc0 + acc1) : xcol[rr];
+      }
+      double *Xs = scr + 4 * DS_NB;
+      if (lane < DS_NB) {
+#pragma unroll
+        for (int rr = 0; rr < DS_NB; ++rr) Xs[rr * DS_NB + c] = xcol[rr];
+      }
+    }
     return ok;
+  }
+
+  // rows below the block: L21 = (A21 L11^-T) D^-1 on the fp64 matrix cores, one 16-row tile per wave at a time; the right-hand
+  // side (one more row) by the wave after the last tile.  v_mfma_f64_16x16x4: lane l supplies A[i = l & 15][k = l >> 4] and
+  // B[k = l >> 4][j = l & 15]; D row = (l >> 4) + 4 reg, col = l & 15.
+  __device__ __forceinline__ void panel_trsm_mfma(double *A, int ld, int npad, int p, double *gz, const double *invd, const double *scr) const {
+    const int q0 = p + DS_NB, nt = (npad - q0) / DS_NB;
+    const int i = lane & 15, kq = lane >> 4;
+    const double *Xs = scr + 4 * DS_NB;
+    for (int t = wave; t <= nt; t += nwave) {
+      if (t == nt) {
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < DS_NB; ++k) z += gz[p + k] * Xs[i * DS_NB + k];
+        wave_lds_sync();   // (every lane has read the sixteen inputs before any is overwritten)
+        if (lane < DS_NB) gz[p + i] = z * invd[p + i];
+        continue;
+      }
+      const int rb = q0 + DS_NB * t;
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kk + kq;
+        const double aop = A[size_t(rb + i) * ld + p + k];
+        const double bop = Xs[i * DS_NB + k];   // B[k][j = i] = X[j][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+      }
+      wave_lds_sync();   // (the tile's inputs have been read: they are overwritten below)
+      const double dinv = invd[p + i];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) A[size_t(rb + kq + 4 * rr) * ld + p + i] = acc[rr] * dinv;
+    }
   }
 
   // A22 -= L21 D L21^T on the fp64 matrix cores, one 16x16 tile of the lower triangle per wave at a time.

@@ -729,39 +729,44 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
 // ================================================================================================
 // Device-resident dogleg (solve_step.h): the two launches of one iteration (the kernel-side executor DevExec: solve_device.h)
 // ================================================================================================
-// Launch A of an iteration, for every window of a batch.  Grid (max(bpf, Wo + 1), Wo + 1, windows): rows 0 .. Wo-1 of a window are
-// the moments of its frames 1 .. Wo at the candidate's T_{pivot<-i} (read from the device-resident state, not from the launch
-// arguments); row Wo is the aux row: block i < Wo the ImuFactor between optimised frames i and i + 1 and the lidar linear map of
-// frame i + 1, block Wo the marginalization prior and the extrinsic prior — all of it at the candidate, all of it hidden under
-// the moments pass.  A window that is done (converged, or handed back to the host) costs its blocks one load.
-__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_moments_dev(const BatchSolve *__restrict__ bs, const uint8_t *__restrict__ valid,
-                                                                   const float4 *__restrict__ coef) {
+// Launch A of an iteration, for every window of a batch, is two kernels (one kernel holding both bodies takes the register count of
+// the larger — 256 VGPRs for the factor code against 107 for the moments — and the moments pass then runs at a quarter of its
+// occupancy: 252 us against 90 at 64 windows, profiles/r5_a_batch64_first_kernel_stats.md):
+//   k_bw_aux       grid (Wo + 1, windows): everything that depends on the candidate but not on the points — block i < Wo the ImuFactor
+//                  between optimised frames i and i + 1 and the lidar linear map of frame i + 1, block Wo the marginalization
+//                  prior and the extrinsic prior;
+//   k_bw_moments   grid (bpf, Wo, windows): the moments of frames 1 .. Wo at the candidate's T_{pivot<-i}, read from the
+//                  device-resident state.
+// A window that is done (converged, or handed back to the host) costs its blocks one load.
+__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_moments(const BatchSolve *__restrict__ bs, const uint8_t *__restrict__ valid,
+                                                               const float4 *__restrict__ coef) {
   const BatchSolve &S = bs[blockIdx.z];
   const DevState *st = S.st;
   if (!S.active || st->done) return;
-  const int Wo = S.nframes;
-  if (int(blockIdx.y) < Wo) {
-    if (int(blockIdx.x) >= S.bpf) return;
-    MomentFrame fr = S.fr[blockIdx.y];
-    const double *Rt = st->cand_Rt[blockIdx.y];
+  if (int(blockIdx.y) >= S.nframes || int(blockIdx.x) >= S.bpf) return;
+  MomentFrame fr = S.fr[blockIdx.y];
+  const double *Rt = st->cand_Rt[blockIdx.y];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) fr.R[k] = Rt[k];
+  for (int k = 0; k < 9; ++k) fr.R[k] = Rt[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
-    lidar_moments_body(fr, valid, coef, S.partials, S.bpf);
-    return;
-  }
-  if (int(blockIdx.y) != Wo) return;
+  for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
+  lidar_moments_body(fr, valid, coef, S.partials, S.bpf);
+}
+__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_aux(const BatchSolve *__restrict__ bs) {
+  const BatchSolve &S = bs[blockIdx.y];
+  const DevState *st = S.st;
+  if (!S.active || st->done) return;
+  const int Wo = S.nframes, i = blockIdx.x;
+  if (i > Wo) return;
   __shared__ double aux_lds[1024];
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
-  const int i = blockIdx.x;
   const DevParams &P = st->cand;
   const DevProblem *pb = S.pb;
   if (i < Wo) {
     aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], S.imu_out + size_t(i) * DS_IMU_OUT, aux_lds);
     __syncthreads();
     aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
-  } else if (i == Wo) {
+  } else {
     if (pb->have_prior) aux_prior(x, *pb, S.prior_mats, P, S.prior_out, aux_lds);
     if (pb->use_ex_prior) aux_exprior(x, *pb, P, S.exprior_out);
   }
@@ -826,7 +831,8 @@ void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(k_bw_moments_dev, dim3(std::max(max_bpf, max_wo + 1), max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
+  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs);
+  hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
   const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);
   hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs);
   LIO_HIP(hipGetLastError());

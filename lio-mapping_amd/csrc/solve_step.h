@@ -326,10 +326,10 @@ LIO_HD double ds_hsym(const double *Hm, int ld, const double *hd, int i, int j) 
 // 16x16 diagonal block at p.  Reference form: one lane walks the block; the device executor keeps row r of the block in the
 // registers of lane r and broadcasts pivots / columns with v_readlane (same arithmetic, same order).
 template <class X>
-LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd) {
+LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd, double *scratch) {
   if (x.wave != 0) return 1;
   if constexpr (X::kDevice) {
-    return x.panel_factor_regs(A, ld, p, invd);
+    return x.panel_factor_regs(A, ld, p, invd, scratch);
   } else {
     for (int j = 0; j < DS_NB; ++j) {
       const double d = A[(p + j) * ld + p + j];
@@ -346,14 +346,21 @@ LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd) {
   }
 }
 
+// (not inlined into the step kernel: inside that one function — 256 VGPRs and spills — the factorisation's unrolled panel code
+// shared its registers with everything else that is live across it)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LIO_DS_LDLT_NOINLINE)
+#define LIO_DS_NOINLINE __attribute__((noinline))
+#else
+#define LIO_DS_NOINLINE
+#endif
 template <class X>
-LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, int *flag, long long *prof = nullptr) {
+LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, int *flag, long long *prof = nullptr) {
   const int nblk = npad / DS_NB;
   for (int kb = 0; kb < nblk; ++kb) {
     const int p = kb * DS_NB, q = p + DS_NB;
     // ---- phase 1: diagonal block (wave 0)
     if (kb == 0) x.stamp(prof, 16);
-    const int ok = ds_panel_factor(x, A, ld, p, invd);
+    const int ok = ds_panel_factor(x, A, ld, p, invd, part);
     if (x.tid == 0) *flag = ok;
     x.sync();
     if (kb == 0) x.stamp(prof, 17);
@@ -361,20 +368,20 @@ LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, do
     // ---- phase 2: rows below the block and the right-hand side: T = A21 L11^-T (forward substitution along the columns),
     // stored as L = T D^-1
     const int nrows = npad - q;
-    for (int t = x.tid; t <= nrows; t += x.nthr) {
-      const bool rhs = (t == nrows);
-      double *row = rhs ? (gz + p) : (A + size_t(q + t) * ld + p);
-      double tr[DS_NB];
-#pragma unroll
-      for (int j = 0; j < DS_NB; ++j) tr[j] = row[j];
-#pragma unroll
-      for (int j = 1; j < DS_NB; ++j) {
-        const double *l11 = A + size_t(p + j) * ld + p;
-#pragma unroll
-        for (int k = 0; k < j; ++k) tr[j] -= tr[k] * l11[k];
+    if constexpr (X::kDevice) {
+      x.panel_trsm_mfma(A, ld, npad, p, gz, invd, part);   // against L11^-1, which the panel wave left in `part`
+    } else {
+      for (int t = x.tid; t <= nrows; t += x.nthr) {
+        const bool rhs = (t == nrows);
+        double *row = rhs ? (gz + p) : (A + size_t(q + t) * ld + p);
+        double tr[DS_NB];
+        for (int j = 0; j < DS_NB; ++j) tr[j] = row[j];
+        for (int j = 1; j < DS_NB; ++j) {
+          const double *l11 = A + size_t(p + j) * ld + p;
+          for (int k = 0; k < j; ++k) tr[j] -= tr[k] * l11[k];
+        }
+        for (int j = 0; j < DS_NB; ++j) row[j] = tr[j] * invd[p + j];
       }
-#pragma unroll
-      for (int j = 0; j < DS_NB; ++j) row[j] = tr[j] * invd[p + j];
     }
     x.sync();
     if (kb == 0) x.stamp(prof, 18);
@@ -487,83 +494,97 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   {
     const int bpf = pb.bpf, b4 = bpf & ~3;
     const int items = Wo * 258;
-    if constexpr (X::kDevice) {
-      for (int it4 = x.tid; it4 < items * 4; it4 += x.nthr) {
-        const int item = it4 >> 2, qq = it4 & 3, f = item / 258, k = item % 258;
-        const double *src = B.partials + size_t(f) * bpf * LIO_MOMENT_OUT + k;
-        double v = 0;
-        for (int b = qq; b < b4; b += 4) v += src[size_t(b) * LIO_MOMENT_OUT];
-        if (qq == 0) for (int b = b4; b < bpf; ++b) v += src[size_t(b) * LIO_MOMENT_OUT];
-        v = x.pair_sum4(v);
-        if (qq == 0) { Sx[f * LIO_MOMENT_OUT + k] = v; S_cand[f * LIO_MOMENT_OUT + k] = v; }
+    // one lane per value, eight blocks' loads in flight at a time (the first device form — four lanes per value, one load at a time —
+    // was a chain of memory round trips: 14 us of the step at ten blocks per frame); the sums and their order are the four chains above
+    for (int item = x.tid; item < items; item += x.nthr) {
+      const int f = item / 258, k = item % 258;
+      const double *src = B.partials + size_t(f) * bpf * LIO_MOMENT_OUT + k;
+      double v[4] = {0, 0, 0, 0};
+      int b = 0;
+      for (; b + 8 <= b4; b += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = src[size_t(b + q) * LIO_MOMENT_OUT];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q & 3] += t[q];
       }
-    } else {
-      for (int item = x.tid; item < items; item += x.nthr) {
-        const int f = item / 258, k = item % 258;
-        const double *src = B.partials + size_t(f) * bpf * LIO_MOMENT_OUT + k;
-        double v[4] = {0, 0, 0, 0};
-        for (int b = 0; b < b4; ++b) v[b & 3] += src[size_t(b) * LIO_MOMENT_OUT];
-        for (int b = b4; b < bpf; ++b) v[0] += src[size_t(b) * LIO_MOMENT_OUT];
-        const double o = (v[0] + v[1]) + (v[2] + v[3]);
-        Sx[f * LIO_MOMENT_OUT + k] = o; S_cand[f * LIO_MOMENT_OUT + k] = o;
+      if (b < b4) {   // (b4 is a multiple of four: one more group of four)
+        double t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = src[size_t(b + q) * LIO_MOMENT_OUT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += t[q];
       }
+      for (b = b4; b < bpf; ++b) v[0] += src[size_t(b) * LIO_MOMENT_OUT];
+      const double o = (v[0] + v[1]) + (v[2] + v[3]);
+      Sx[f * LIO_MOMENT_OUT + k] = o; S_cand[f * LIO_MOMENT_OUT + k] = o;
     }
   }
   x.sync();
   x.stamp(B.prof, 1);
   // ---- P2, P3: H_i = (L S) L^T (18 x 18), g_i = (L S) l per frame
   ds_lidar_blocks(x, Wo, B.lmap, Sx, LS, L.zb, B.prof);
-  // ---- P4: assemble the candidate's H (full, unscaled) and g in the order of WindowSystem::evaluate:
-  // prior, ImuFactor 0..Wo-1, lidar frames 1..Wo, extrinsic prior
+  // ---- P4: assemble the candidate's H (full, unscaled) and g in the order of WindowSystem::evaluate — prior, ImuFactor 0..Wo-1,
+  // lidar frames 1..Wo, extrinsic prior — as BLOCK passes with a barrier between them: every entry still receives its
+  // contributions in that order, but a pass is a plain coalesced add of one factor's block (the first form visited every entry
+  // once and walked all factors from there: 18 entries per thread, each a chain of dependent global loads — 50 of the step's
+  // 155 us, profiles/r5_c_step_phases.txt).  Thread layout of the dense passes: 128 columns x (threads / 128) rows, no division.
   const double *JtJ = B.prior_mats;
-  for (int e = x.tid; e < npad * (npad + 1); e += x.nthr) {
-    const int r = e / (npad + 1), cc = e % (npad + 1);
-    const bool is_g = (cc == npad);
-    const int c = is_g ? 0 : cc;
-    double v = 0.0;
-    if (r >= n || (!is_g && c >= n)) { v = (!is_g && r == c) ? 1.0 : 0.0; }
-    else {
-      const int fr = r / 15, ro = r % 15;          // frame block of the row (the extrinsic block has fr = Wo + 1)
-      const bool r_ex = exc >= 0 && r >= exc;
-      if (is_g) {
-        if (pb.have_prior && pb.prior_col[r] >= 0) v += B.prior_out[pb.prior_col[r]];
-        if (!r_ex) {
-          if (fr >= 1 && B.imu_out[size_t(fr - 1) * DS_IMU_OUT + 931] != 0.0) v += B.imu_out[size_t(fr - 1) * DS_IMU_OUT + 900 + 15 + ro];
-          if (fr < Wo && B.imu_out[size_t(fr) * DS_IMU_OUT + 931] != 0.0) v += B.imu_out[size_t(fr) * DS_IMU_OUT + 900 + ro];
-          if (ro < 6) {
-            if (fr == 0) { for (int i = 0; i < Wo; ++i) if (S_cand[i * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[i * 344 + 324 + ro]; }
-            else if (S_cand[(fr - 1) * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[(fr - 1) * 344 + 324 + 6 + ro];
-          }
-        } else {
-          for (int i = 0; i < Wo; ++i) if (S_cand[i * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[i * 344 + 324 + 12 + (r - exc)];
-          if (pb.use_ex_prior) v += B.exprior_out[36 + (r - exc)];
+  constexpr int CW = X::kDevice ? 128 : 1;
+  const int tcol = x.tid % CW, trow = x.tid / CW, rstep = x.nthr >= CW ? x.nthr / CW : 1;
+  int *pcol = reinterpret_cast<int *>(L.part);   // the prior's column of every tangent column (LDS copy; `part` is idle until the back-substitution)
+  for (int i = x.tid; i < npad; i += x.nthr) pcol[i] = (pb.have_prior && i < n) ? pb.prior_col[i] : -1;
+  x.sync();
+  for (int r = trow; r < npad; r += rstep)
+    for (int c = tcol; c <= npad; c += CW) {
+      const bool is_g = (c == npad);
+      double v = 0.0;
+      if (r >= n || (!is_g && c >= n)) v = (!is_g && r == c) ? 1.0 : 0.0;
+      else {
+        const int pr = pcol[r];
+        if (pr >= 0) {
+          if (is_g) v = B.prior_out[pr];
+          else { const int pc = pcol[c]; if (pc >= 0) v = JtJ[size_t(pr) * np + pc]; }
         }
-      } else {
-        const int fc = c / 15, co = c % 15;
-        const bool c_ex = exc >= 0 && c >= exc;
-        if (pb.have_prior && pb.prior_col[r] >= 0 && pb.prior_col[c] >= 0) v += JtJ[size_t(pb.prior_col[r]) * np + pb.prior_col[c]];
-        if (!r_ex && !c_ex) {
-          // ImuFactor i spans tangent columns [15 i, 15 i + 30)
-          for (int i = (fr > 0 ? fr - 1 : 0); i <= fr && i < Wo; ++i) {
-            if (B.imu_out[size_t(i) * DS_IMU_OUT + 931] == 0.0) continue;
-            const int lr = r - 15 * i, lc = c - 15 * i;
-            if (lc >= 0 && lc < 30) v += B.imu_out[size_t(i) * DS_IMU_OUT + lr * 30 + lc];
-          }
-        }
-        // lidar frame i touches (pose_0, pose_i, extrinsic): local rows 0..5, 6..11, 12..17
-        const int kr = r_ex ? 2 : (ro < 6 ? (fr == 0 ? 0 : 1) : -1), kc = c_ex ? 2 : (co < 6 ? (fc == 0 ? 0 : 1) : -1);
-        if (kr >= 0 && kc >= 0) {
-          const int lr = kr == 2 ? 12 + (r - exc) : (kr == 0 ? ro : 6 + ro), lc = kc == 2 ? 12 + (c - exc) : (kc == 0 ? co : 6 + co);
-          if (kr == 1 && kc == 1) { if (fr == fc && S_cand[(fr - 1) * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[(fr - 1) * 344 + lr * 18 + lc]; }
-          else if (kr == 1 || kc == 1) { const int i = (kr == 1 ? fr : fc); if (S_cand[(i - 1) * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[(i - 1) * 344 + lr * 18 + lc]; }
-          else { for (int i = 0; i < Wo; ++i) if (S_cand[i * LIO_MOMENT_OUT + 257] != 0.0) v += L.zb[i * 344 + lr * 18 + lc]; }
-        }
-        if (r_ex && c_ex && pb.use_ex_prior) v += B.exprior_out[(r - exc) * 6 + (c - exc)];
+      }
+      if (is_g) L.gz[r] = v; else A[size_t(r) * ld + c] = v;
+    }
+  x.sync();
+  for (int i = 0; i < Wo; ++i) {   // ImuFactor i spans tangent columns [15 i, 15 i + 30)
+    const double *im = B.imu_out + size_t(i) * DS_IMU_OUT;
+    if (im[931] != 0.0) {
+      for (int e = x.tid; e < 930; e += x.nthr) {
+        if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += im[e]; }
+        else L.gz[15 * i + (e - 900)] += im[e];
       }
     }
-    if (is_g) L.gz[r] = v; else A[size_t(r) * ld + c] = v;
+    x.sync();
   }
-  x.sync();
+  for (int f = 0; f < Wo; ++f) {   // lidar frame f + 1 touches (pose_0, pose_{f+1}, extrinsic): local rows 0..5, 6..11, 12..17
+    if (S_cand[f * LIO_MOMENT_OUT + 257] != 0.0) {
+      const double *zf = L.zb + f * 344;
+      for (int e = x.tid; e < 342; e += x.nthr) {
+        if (e < 324) {
+          const int a = e / 18, b = e % 18;
+          const int ra = a < 6 ? a : (a < 12 ? 15 * (f + 1) + (a - 6) : (exc >= 0 ? exc + (a - 12) : -1));
+          const int cb = b < 6 ? b : (b < 12 ? 15 * (f + 1) + (b - 6) : (exc >= 0 ? exc + (b - 12) : -1));
+          if (ra >= 0 && cb >= 0) A[size_t(ra) * ld + cb] += zf[e];
+        } else {
+          const int a = e - 324;
+          const int ra = a < 6 ? a : (a < 12 ? 15 * (f + 1) + (a - 6) : (exc >= 0 ? exc + (a - 12) : -1));
+          if (ra >= 0) L.gz[ra] += zf[e];
+        }
+      }
+    }
+    x.sync();
+  }
+  if (pb.use_ex_prior && exc >= 0) {
+    for (int e = x.tid; e < 42; e += x.nthr) {
+      if (e < 36) A[size_t(exc + e / 6) * ld + exc + e % 6] += B.exprior_out[e];
+      else L.gz[exc + (e - 36)] += B.exprior_out[e];
+    }
+    x.sync();
+  }
   // NOTE: Sx / LS aliased A and are gone now; S_cand (global) keeps the moments.
   x.stamp(B.prof, 4);
   // ---- P5: decide on the pending candidate (thread 0)
@@ -667,13 +688,13 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       if (mode == DS_MODE_INIT && i < n) st.scale[i] = sc;
     }
     x.sync();
-    for (int e = x.tid; e < n * n; e += x.nthr) {
-      const int r = e / n, c = e % n;
-      const double v = A[size_t(r) * ld + c] * (L.scale[r] * L.scale[c]);
-      A[size_t(r) * ld + c] = v;
-      B.Hcur[size_t(r) * ld + c] = v;
-      if (r == c) L.hdiag[r] = v;
-    }
+    for (int r = trow; r < n; r += rstep)
+      for (int c = tcol; c < n; c += CW) {
+        const double v = A[size_t(r) * ld + c] * (L.scale[r] * L.scale[c]);
+        A[size_t(r) * ld + c] = v;
+        B.Hcur[size_t(r) * ld + c] = v;
+        if (r == c) L.hdiag[r] = v;
+      }
     for (int i = x.tid; i < npad; i += x.nthr) {
       const double gs = i < n ? L.gz[i] * L.scale[i] : 0.0;
       L.g[i] = gs;
@@ -704,10 +725,8 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     if (!C.reuse) {
       if (x.tid == 0) { C.reuse = 1; C.lin_ok = 0; }
       if (!C.a_valid) {   // a linearisation is needed at the accepted point but LDS holds a rejected candidate: reload
-        for (int e = x.tid; e < npad * npad; e += x.nthr) {
-          const int r = e / npad, c = e % npad;
-          A[size_t(r) * ld + c] = (r < n && c < n) ? B.Hcur[size_t(r) * ld + c] : (r == c ? 1.0 : 0.0);
-        }
+        for (int r = trow; r < npad; r += rstep)
+          for (int c = tcol; c < npad; c += CW) A[size_t(r) * ld + c] = (r < n && c < n) ? B.Hcur[size_t(r) * ld + c] : (r == c ? 1.0 : 0.0);
         if (x.tid == 0) C.a_valid = 1;
         x.sync();
         Hm = A;
@@ -739,11 +758,11 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         x.sync();
         if (!(C.mu < 1.0) || C.lin_ok) break;
         // lower triangle <- upper triangle, regularised diagonal, right-hand side
-        for (int e = x.tid; e < npad * npad; e += x.nthr) {
-          const int r = e / npad, c = e % npad;
-          if (c < r) A[size_t(r) * ld + c] = A[size_t(c) * ld + r];
-          else if (c == r) A[size_t(r) * ld + r] = (r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0;
-        }
+        for (int r = trow; r < npad; r += rstep)
+          for (int c = tcol; c <= r; c += CW) {
+            if (c < r) A[size_t(r) * ld + c] = A[size_t(c) * ld + r];
+            else A[size_t(r) * ld + r] = (r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0;
+          }
         for (int i = x.tid; i < npad; i += x.nthr) L.gz[i] = L.g[i];
         x.sync();
         int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, &C.fact_ok, B.prof);

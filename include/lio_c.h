@@ -71,6 +71,10 @@ void lio_pp_default_config(lio_pp_config *cfg);
  * constructor argument here: it only selects which PointToRing overload runs, i.e. which of the two process calls
  * below the caller uses (PointProcessor.cc:185-190). */
 lio_pp *lio_pp_create(float lower_deg, float upper_deg, int rings, const lio_pp_config *cfg_or_null);
+/* Why lio_pp_create would refuse these arguments: LIO_OK, LIO_ERR_ARG (out-of-range value), or LIO_ERR_CAPACITY — the product's
+ * k_ring_pick keeps a subregion's picks one per lane of a wave, so max_corner_less_sharp + max_surf_flat <= 64 (the reference,
+ * PointProcessor.cc:685-732, accepts any quota; its defaults are 20 + 4).  The oracle has no such limit.  No device work. */
+int lio_pp_check_config(float lower_deg, float upper_deg, int rings, const lio_pp_config *config_or_null);
 void lio_pp_destroy(lio_pp *);
 /* SetInputCloud + PointToRing + ExtractFeaturePoints (PointProcessor.cc:96-100, test_point_processor.cc:103-106) */
 int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
@@ -94,6 +98,9 @@ int lio_pp_get_indices(const lio_pp *, int which, int32_t *ring_out, int32_t *id
 int lio_pp_get_ring_offsets(const lio_pp *, int32_t *offsets_out);
 /* per-point curvature of the LIO_PP_RINGS cloud (0 outside [5, n-5) of a ring) and final pick mask */
 int lio_pp_get_curvature(const lio_pp *, float *curv_out, int32_t *mask_out);
+/* the intensity channel of the reference's public intensity_scans, concatenated in ring order (one float per LIO_PP_RINGS point):
+ * int(input intensity) + rel_time (PointProcessor.cc:413, :524; the coordinates are those of the LIO_PP_RINGS cloud) */
+int lio_pp_get_ring_intensity(const lio_pp *, float *intensity_out);
 
 /* ------------------------------------------------------------------------------------------------
  * PointOdometry (include/point_processor/PointOdometry.h:102-147; §8a a6-a7): LOAM scan-to-scan step

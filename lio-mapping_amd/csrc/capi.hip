@@ -57,24 +57,34 @@ void lio_pp_default_config(lio_pp_config *c) {
   c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
   c->infer_start_ori = 0; c->rad_diff = 0.2;
 }
-lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
-  if (rings <= 0 || rings > LIO_PP_MAX_RINGS || !(up > lo)) return nullptr;
+int lio_pp_check_config(float lo, float up, int rings, const lio_pp_config *c) {
+  if (rings <= 0 || rings > LIO_PP_MAX_RINGS || !(up > lo)) return LIO_ERR_ARG;
   lio_pp_config cfg;
   if (c) cfg = *c; else lio_pp_default_config(&cfg);
-  if (cfg.num_scan_subregions < 1 || cfg.num_scan_subregions > 16 || cfg.num_curvature_regions < 1 || cfg.num_curvature_regions > 8) return nullptr;
+  if (cfg.num_scan_subregions < 1 || cfg.num_scan_subregions > 16 || cfg.num_curvature_regions < 1 || cfg.num_curvature_regions > 8) return LIO_ERR_ARG;
   // pick caps size LDS tables and device reserves; the leaf is inverted: keep them in sane ranges
   const int caps[3] = {cfg.max_corner_sharp, cfg.max_corner_less_sharp, cfg.max_surf_flat};
   for (int v : caps)
-    if (v < 0 || v > 4096) return nullptr;
-  // k_ring_pick keeps the picks of a subregion one per lane of a wave (corner picks + flat picks in 64 slots)
-  if (cfg.max_corner_less_sharp + cfg.max_surf_flat > 64 || cfg.max_corner_sharp > cfg.max_corner_less_sharp) {
-    std::fprintf(stderr, "lio_pp_create: max_corner_less_sharp + max_surf_flat = %d > 64 picks per subregion (or max_corner_sharp > max_corner_less_sharp): "
-                         "not supported by k_ring_pick (the reference's defaults are 20 + 4)\n", cfg.max_corner_less_sharp + cfg.max_surf_flat);
+    if (v < 0 || v > 4096) return LIO_ERR_ARG;
+  if (cfg.max_corner_sharp > cfg.max_corner_less_sharp) return LIO_ERR_ARG;
+  if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return LIO_ERR_ARG;
+  if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return LIO_ERR_ARG;
+  if (cfg.infer_start_ori && !(cfg.rad_diff >= 0.0)) return LIO_ERR_ARG;
+  // k_ring_pick keeps the picks of a subregion one per lane of a wave (corner picks + flat picks in 64 slots): a fixed capacity of
+  // the device path, reported as such (the reference accepts any quota; its defaults are 20 + 4)
+  if (cfg.max_corner_less_sharp + cfg.max_surf_flat > 64) return LIO_ERR_CAPACITY;
+  return LIO_OK;
+}
+lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
+  const int chk = lio_pp_check_config(lo, up, rings, c);
+  if (chk != LIO_OK) {
+    if (chk == LIO_ERR_CAPACITY)
+      std::fprintf(stderr, "lio_pp_create: LIO_ERR_CAPACITY — max_corner_less_sharp + max_surf_flat > 64 picks per subregion is beyond k_ring_pick's per-wave pick table "
+                           "(lio_pp_check_config reports the code)\n");
     return nullptr;
   }
-  if (!(cfg.less_flat_filter_size > 1e-4f && cfg.less_flat_filter_size < 1e4f)) return nullptr;
-  if (!(cfg.scan_period > 0.0f) || !std::isfinite(cfg.scan_period)) return nullptr;
-  if (cfg.infer_start_ori && !(cfg.rad_diff >= 0.0)) return nullptr;
+  lio_pp_config cfg;
+  if (c) cfg = *c; else lio_pp_default_config(&cfg);
   lio_pp *h = new (std::nothrow) lio_pp;
   if (!h) return nullptr;
   int rc = guarded([&] { h->pp.reset(new PointProcessorDev(lo, up, rings, cfg)); return LIO_OK; });
@@ -125,6 +135,11 @@ int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
 int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->pp->ProcessFinish(); h->pp->GetCurvature(curv, mask); return LIO_OK; });
+}
+
+int lio_pp_get_ring_intensity(const lio_pp *h, float *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetRingIntensity(out); return LIO_OK; });
 }
 
 // ---------------------------------------------------------------- PointOdometry

@@ -285,7 +285,12 @@ class WindowSystem {
   static constexpr int LMAP_STRIDE = 18 * 13 + 13 * LIO_LT_LD;
   std::vector<double> lmaps_;                    // per frame: L (18 x 13) and [L^T | l] (13 x LIO_LT_LD) of the current evaluate() call
   std::vector<double> prior_scratch_;            // the prior's residual and gradient (no allocation per linearisation)
-  DMat prior_base_;                              // the prior's J^T J in the solve's layout (evaluate())
+  // the prior's J^T J in the solve's layout (evaluate()).  The cache is keyed by the MargPrior's address, the layout's dimension and
+  // its extrinsic column: valid because a WindowSystem lives for ONE solve (Estimator::SolveOptimizationHost builds it on the
+  // stack, the marginalization builds its own), holds `prior` as a shared_ptr for that whole time (no other prior can take its
+  // address meanwhile) and a MargPrior is immutable once built (lio_est_set_prior_factor installs a copy, never edits in place).
+  // A WindowSystem that outlived its solve would have to clear prior_base_for_ whenever `prior` is assigned.
+  DMat prior_base_;
   const MargPrior *prior_base_for_ = nullptr;
   int prior_base_ex_ = -2;
   std::vector<FrameMoments> moments_scratch_;    // landing zone of the device pass (no allocation per linearisation)

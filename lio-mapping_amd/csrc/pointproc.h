@@ -59,6 +59,7 @@ class PointProcessorDev {
   void ProcessFinish();
   void GetIndices(int which, int32_t *ring, int32_t *idx);
   void GetRingOffsets(int32_t *out);
+  void GetRingIntensity(float *out);
   void GetCurvature(float *curv, int32_t *mask);
   // device-resident results (valid until the next Process)
   const float4 *d_less_flat() const { return less_flat_.p; }
@@ -75,6 +76,7 @@ class PointProcessorDev {
   HostOut *h_out_ = nullptr;   // pinned landing zone of the per-sweep results
   std::vector<int> ring_offsets_;
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
+  DBuf<float> ring_intensity_;   // intensity_scans' intensity channel, ring order
   DBuf<float> azi_, curv_, start_ori_dev_;
   StartOriFilter start_ori_filter_;
   bool processed_ = false, start_ori_known_ = false, in_flight_ = false;

@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *_
                                                                  const float *__restrict__ azi, const int *__restrict__ table, int nblocks, int n,
                                                                  const int *__restrict__ ring_total, int *__restrict__ offsets,
                                                                  const int *__restrict__ first_valid, const float *__restrict__ start_ori_override, int rings, double scan_period,
-                                                                 float4 *__restrict__ ring_cloud, const int *__restrict__ end_ori_bits) {
+                                                                 float4 *__restrict__ ring_cloud, float *__restrict__ ring_intensity,
+                                                                 const int *__restrict__ end_ori_bits) {
   __shared__ int wave_cnt[PP_BIN_THREADS / 64][LIO_PP_MAX_RINGS];
   __shared__ int ring_base[LIO_PP_MAX_RINGS + 1];
   for (int k = threadIdx.x; k < (PP_BIN_THREADS / 64) * LIO_PP_MAX_RINGS; k += PP_BIN_THREADS) (&wave_cnt[0][0])[k] = 0;
@@ -176,6 +177,7 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *_
     rel_time = float(scan_period * double(rel_u) / double(range_ori));
   }
   float4 p = in[i];
+  ring_intensity[dst] = float(int(p.w)) + rel_time;   // intensity_scans (:413, :524): int(input intensity) + rel_time
   p.w = float(int(key)) + rel_time;
   ring_cloud[dst] = p;
 }
@@ -791,7 +793,7 @@ void PointProcessorDev::ProcessLaunch(const float *xyzi, size_t n, const uint16_
   in_flight_ = true;
   const int ni = int(n);
   hipStream_t s = stream_;
-  in_.reserve(n); ring_cloud_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
+  in_.reserve(n); ring_cloud_.reserve(n); ring_intensity_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
   keys_.reserve(n); less_flat_.reserve(n);
   const int nblocks = cdiv(ni, PP_BIN_THREADS);
   ring_table_.reserve(size_t(rings_) * nblocks); ring_total_.reserve(rings_);
@@ -847,7 +849,7 @@ void PointProcessorDev::ProcessLaunch(const float *xyzi, size_t n, const uint16_
     start_ori_known_ = true;
   }
   hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_p_,
-                     first_valid_p_, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring ? end_ori_p_ : nullptr);
+                     first_valid_p_, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring_intensity_.p, ring ? end_ori_p_ : nullptr);
   const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 6) + size_t(8) * PP_WMASK +
                      size_t(8) * PP_WSEL * sizeof(int) + 24 * sizeof(int) + size_t(cap_all) * sizeof(int) + 64;
   hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
@@ -910,6 +912,12 @@ void PointProcessorDev::GetIndices(int which, int32_t *ring, int32_t *idx) {
 }
 void PointProcessorDev::GetRingOffsets(int32_t *out) {
   for (int r = 0; r <= rings_; ++r) out[r] = ring_offsets_[r];
+}
+void PointProcessorDev::GetRingIntensity(float *out) {
+  const size_t n = size_t(counts_.n_ring_points);
+  if (!n || !out) return;
+  LIO_HIP(hipMemcpyAsync(out, ring_intensity_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipStreamSynchronize(stream_));
 }
 void PointProcessorDev::GetCurvature(float *curv, int32_t *mask) {
   size_t n = size_t(counts_.n_ring_points);

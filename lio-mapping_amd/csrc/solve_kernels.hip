@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <mutex>
 #include <cstdlib>
 #include <string>
 
@@ -653,12 +655,25 @@ __global__ void __launch_bounds__(REDUCE_THREADS) k_moment_reduce(const double *
 // the resident form is then never chosen.  A partitioned (CPX) or smaller part gets a smaller figure and with it the launch path
 // for windows that do not fit; nothing is assumed about "256 CUs".
 int resident_max_blocks(int per_lane) {
-  static int cache[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  // cached per (device, residuals per lane): a process may drive devices of different sizes or partition modes, and several
+  // estimators may ask at once (-1 = not asked yet; racing first calls compute the same value)
+  static std::atomic<int> cache[16][9];
+  static std::atomic<bool> init{false};
   if (per_lane < 1 || per_lane > 8) return 0;
-  if (cache[per_lane] >= 0) return cache[per_lane];
+  if (!init.load(std::memory_order_acquire)) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!init.load(std::memory_order_relaxed)) {
+      for (auto &row : cache) for (auto &v : row) v.store(-1, std::memory_order_relaxed);
+      init.store(true, std::memory_order_release);
+    }
+  }
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
-  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const bool cached = dev >= 0 && dev < 16;
+  if (cached) { const int v = cache[dev][per_lane].load(std::memory_order_relaxed); if (v >= 0) return v; }
+  e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
     switch (per_lane) {
       case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lidar_moments_resident<1>, MOMENT_THREADS, 0); break;
@@ -668,8 +683,11 @@ int resident_max_blocks(int per_lane) {
       default: per_cu = 0; break;
     }
   }
-  if (e != hipSuccess) { (void)hipGetLastError(); return cache[per_lane] = 0; }
-  return cache[per_lane] = std::max(0, std::min(LIO_RES_MAX_BLOCKS, cus * per_cu - 1));
+  int v = 0;
+  if (e != hipSuccess) (void)hipGetLastError();
+  else v = std::max(0, std::min(LIO_RES_MAX_BLOCKS, cus * per_cu - 1));
+  if (cached) cache[dev][per_lane].store(v, std::memory_order_relaxed);
+  return v;
 }
 
 int resident_blocks_per_frame(int max_slots, int nframes, int per_lane) {

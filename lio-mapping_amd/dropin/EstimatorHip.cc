@@ -143,7 +143,8 @@ void EstimatorHip::ProcessImu(double dt, const Vector3d &linear_acceleration, co
   const double a[3] = {linear_acceleration.x(), linear_acceleration.y(), linear_acceleration.z()};
   const double w[3] = {angular_velocity.x(), angular_velocity.y(), angular_velocity.z()};
   if (!Check(lio_est_process_imu(est_, dt, a, w, header.stamp.toSec()), "lio_est_process_imu")) return;
-  if (stage_flag_ == INITED) {
+  if (stage_flag_ != INITED) { Refresh(); return; }   // the reference propagates Ps_ / Rs_ / Vs_[cir_buf_count_] per sample (:387-394): keep the mirrors current
+  {
     const int n = int(estimator_config_.window_size) + 1;
     std::vector<double> P(3 * n), Rm(9 * n), V(3 * n), Ba(3 * n);
     if (!Check(lio_est_get_window(est_, n, P.data(), Rm.data(), V.data(), Ba.data(), nullptr, nullptr), "lio_est_get_window")) return;
@@ -168,10 +169,13 @@ void EstimatorHip::Pack(const PointCloud &cloud, std::vector<float> &xyzi) {
   }
 }
 
-// /local_laser_odom, /predict_laser_odom (Estimator.cc:728-758) and /extrinsic_lb (:2343-2353) from the window after the slide
-void EstimatorHip::PublishAfterSolve(const std_msgs::Header &header) {
+// /extrinsic_lb (published by SolveOptimization itself, Estimator.cc:2343-2353: on every solve, the initialising one included) and —
+// in the INITED branch only (:728-758; the initialisation branch :541-600 runs SolveOptimization + SlideWindow and nothing else) —
+// /local_laser_odom and /predict_laser_odom from the window after the slide
+void EstimatorHip::PublishAfterSolve(const std_msgs::Header &header, bool odometry_topics) {
   const int pivot_idx = int(estimator_config_.window_size) - int(estimator_config_.opt_window_size);
   const Twist<double> transform_lb = transform_lb_.cast<double>();
+  if (odometry_topics) {
   if (size_t(pivot_idx + 1) < stamps_.size()) local_odom_.header.stamp = ros::Time(stamps_[pivot_idx + 1]);
   local_odom_.header.seq += 1;
   {
@@ -185,6 +189,7 @@ void EstimatorHip::PublishAfterSolve(const std_msgs::Header &header) {
     const Eigen::Quaterniond rot(Rs_.last() * transform_lb.rot.inverse());
     PutPose(rot, Ps_.last() - rot * transform_lb.pos, laser_odom_);
     pub_laser_odom_.publish(laser_odom_);
+  }
   }
   geometry_msgs::PoseStamped ex;
   ex.header = header;
@@ -222,7 +227,7 @@ void EstimatorHip::ProcessCompactData(const sensor_msgs::PointCloud2ConstPtr &co
   if (stage_flag_ == INITED && (last_event_ == 4 || (last_event_ == 3 && !was_inited))) {
     if (last_event_ == 3) stamps_.push_back(header.stamp.toSec());   // after the first slide Headers_ holds the newest stamp twice (:2646-2655)
     if (stamps_.size() > estimator_config_.window_size + 1) stamps_.erase(stamps_.begin());
-    PublishAfterSolve(header);
+    PublishAfterSolve(header, last_event_ == 4);
   }
 }
 
@@ -236,7 +241,7 @@ void EstimatorHip::ProcessLaserOdom(const Transform &transform_in, const std_msg
   if (!Check(lio_est_process_laser_odom(est_, &t, scratch_.data(), laser_cloud_surf_last_->size(), scratch2_.data(), laser_cloud_corner_last_->size(),
                                         header.stamp.toSec(), &last_report_), "lio_est_process_laser_odom")) return;
   Refresh();
-  if (stage_flag_ == INITED && last_event_ >= 3) PublishAfterSolve(header);
+  if (stage_flag_ == INITED && last_event_ >= 3) PublishAfterSolve(header, last_event_ == 4);
 }
 
 void EstimatorHip::SolveOptimization() {

@@ -80,7 +80,7 @@ class EstimatorHip : public MeasurementManager {
  private:
   void CreateHandle();
   void Refresh();                                                // library -> the state members above
-  void PublishAfterSolve(const std_msgs::Header &header);
+  void PublishAfterSolve(const std_msgs::Header &header, bool odometry_topics);
   bool Check(int rc, const char *what);
   static void Pack(const PointCloud &cloud, std::vector<float> &xyzi);
 

@@ -231,6 +231,8 @@ _SIGS = {
     "lio_est_snapshot": (C.c_int, [C.c_void_p]),
     "lio_est_restore": (C.c_int, [C.c_void_p]),
     "lio_est_solve_restored": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolveReport)]),
+    "lio_pp_get_ring_intensity": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "lio_pp_check_config": (C.c_int, [C.c_float, C.c_float, C.c_int, C.POINTER(PPConfig)]),
     "lio_est_copy_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lio_est_batch_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
     "lio_est_batch_destroy": (None, [C.c_void_p]),
@@ -522,6 +524,12 @@ class PointProcessor:
     def ring_offsets(self):
         out = np.zeros(self.rings + 1, dtype=np.int32)
         _chk(self.lib.dll.lio_pp_get_ring_offsets(self.h, out.ctypes.data_as(c_int32_p)), "lio_pp_get_ring_offsets")
+        return out
+
+    def ring_intensity(self):
+        """intensity channel of the reference's intensity_scans, ring order: int(input intensity) + rel_time"""
+        out = np.zeros(int(self.lib.dll.lio_pp_count(self.h, self.RINGS)), np.float32)
+        _chk(self.lib.dll.lio_pp_get_ring_intensity(self.h, _fp(out)), "lio_pp_get_ring_intensity")
         return out
 
     def curvature(self):

@@ -41,6 +41,7 @@ void lio_pp_default_config(lio_pp_config *c) {
   c->max_corner_sharp = 2; c->max_corner_less_sharp = 20; c->max_surf_flat = 4; c->less_flat_filter_size = 0.2f;
   c->infer_start_ori = 0; c->rad_diff = 0.2;
 }
+int lio_pp_check_config(float lo, float up, int rings, const lio_pp_config *) { return (rings <= 0 || !(up > lo)) ? LIO_ERR_ARG : LIO_OK; }
 lio_pp *lio_pp_create(float lo, float up, int rings, const lio_pp_config *c) {
   if (rings <= 0 || !(up > lo)) return nullptr;
   lio_pp *h = new (std::nothrow) lio_pp(lo, up, rings);
@@ -98,6 +99,12 @@ int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (!h) return LIO_ERR_ARG;
   if (curv) std::memcpy(curv, h->pp.curvature.data(), h->pp.curvature.size() * sizeof(float));
   if (mask) for (size_t k = 0; k < h->pp.mask.size(); ++k) mask[k] = h->pp.mask[k];
+  return LIO_OK;
+}
+
+int lio_pp_get_ring_intensity(const lio_pp *h, float *out) {
+  if (!h || !out) return LIO_ERR_ARG;
+  std::memcpy(out, h->pp.intensity_rings.data(), h->pp.intensity_rings.size() * sizeof(float));
   return LIO_OK;
 }
 

@@ -49,6 +49,8 @@ struct PointProcessor {
   Ring10 start_ori_buf1_, start_ori_buf2_;   // PointProcessor.h: CircularBuffer<float>{10} each
 
   std::vector<Cloud> laser_scans;   // intensity = ring + rel_time
+  std::vector<std::vector<float>> intensity_scans;   // the intensity channel of the reference's intensity_scans: int(input intensity) + rel_time (:413)
+  std::vector<float> intensity_rings;                // ... concatenated in ring order (= cloud_in_rings_'s intensities, :195)
   std::vector<int> ring_offsets;    // rings+1
   Cloud cloud_rings;                // laser_scans concatenated
   std::vector<float> curvature;     // per cloud_rings point
@@ -66,6 +68,7 @@ struct PointProcessor {
   // ring != nullptr selects the PointIR overload of PointToRing (uneven_ == true, PointProcessor.cc:185-190)
   void Process(const float *xyzi, size_t n, const uint16_t *ring = nullptr) {
     laser_scans.assign(num_rings_, Cloud());
+    intensity_scans.assign(num_rings_, std::vector<float>());
     sharp.clear(); less_sharp.clear(); flat.clear(); less_flat.clear();
     for (int k = 0; k < 4; ++k) { pick_ring[k].clear(); pick_idx[k].clear(); }
     if (ring) PointToRingIR(xyzi, ring, n); else PointToRing(xyzi, n);
@@ -90,15 +93,18 @@ struct PointProcessor {
       float azi_rad_rel = azi_rad - start_ori_;
       if (azi_rad_rel < 0) azi_rad = float(azi_rad + 2 * M_PI);                           // :486-489 (half_passed stays false)
       if (end_ori < azi_rad) end_ori = azi_rad;                                           // :495-497
+      intensity_scans[scan_id].push_back(p.i);
       p.i = azi_rad;
       laser_scans[scan_id].push_back(p);
     }
     const float range_ori = end_ori - start_ori_;                                         // :507
     for (int ring = 0; ring < num_rings_; ++ring)
-      for (P4 &p : laser_scans[ring]) {
+      for (size_t k = 0; k < laser_scans[ring].size(); ++k) {
+        P4 &p = laser_scans[ring][k];
         float azi_rad_rel = p.i - start_ori_;
         float rel_time = float(config_.scan_period * azi_rad_rel / range_ori);            // :521 (double * float / float)
         p.i = ring + rel_time;
+        intensity_scans[ring][k] = int(intensity_scans[ring][k]) + rel_time;              // :524
       }
     FinishRings();
   }
@@ -115,6 +121,7 @@ struct PointProcessor {
       int scan_id = ElevationToRing(ele_rad);
       if (scan_id >= num_rings_ || scan_id < 0) continue;  // :257-259
       if (!start_flag) { start_ori_ = azi_rad; start_flag = true; }  // :261-264
+      intensity_scans[scan_id].push_back(p.i);
       p.i = azi_rad;  // :268
       laser_scans[scan_id].push_back(p);
     }
@@ -139,11 +146,13 @@ struct PointProcessor {
     }
     // :393-423 second pass: intensity = ring + rel_time
     for (int ring = 0; ring < num_rings_; ++ring)
-      for (P4 &p : laser_scans[ring]) {
+      for (size_t k = 0; k < laser_scans[ring].size(); ++k) {
+        P4 &p = laser_scans[ring][k];
         float azi_rad_rel = p.i - start_ori_;
         if (azi_rad_rel < 0) azi_rad_rel = float(azi_rad_rel + 2 * M_PI);
         float rel_time = float(config_.scan_period * azi_rad_rel / (2 * M_PI));
         p.i = ring + rel_time;
+        intensity_scans[ring][k] = int(intensity_scans[ring][k]) + rel_time;   // :413
       }
     FinishRings();
   }
@@ -151,8 +160,10 @@ struct PointProcessor {
   void FinishRings() {  // :191-201
     ring_offsets.assign(num_rings_ + 1, 0);
     cloud_rings.clear();
+    intensity_rings.clear();
     for (int r = 0; r < num_rings_; ++r) {
       cloud_rings.insert(cloud_rings.end(), laser_scans[r].begin(), laser_scans[r].end());
+      intensity_rings.insert(intensity_rings.end(), intensity_scans[r].begin(), intensity_scans[r].end());
       ring_offsets[r + 1] = int(cloud_rings.size());
     }
     curvature.assign(cloud_rings.size(), 0.f);

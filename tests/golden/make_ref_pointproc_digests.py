@@ -47,6 +47,11 @@ def main():
                 a = np.zeros((n, 4), np.float32)
                 ref.ref_pp_get(h, w, a.ctypes.data_as(fp))
                 row[cname] = digest(a)
+            # intensity_scans (public member, PointProcessor.h:171) = cloud_in_rings_ (:195): the intensity channel, ring order
+            n = ref.ref_pp_count(h, 0)
+            a = np.zeros((n, 4), np.float32)
+            ref.ref_pp_get(h, 0, a.ctypes.data_as(fp))
+            row["intensity_scans"] = digest(a[:, 3])
             rows.append(row)
         ref.ref_pp_destroy(h)
         out[name] = rows

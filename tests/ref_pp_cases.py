@@ -26,6 +26,14 @@ def cases():
     ds = synth.make_dataset("indoor", 1, 0.1)
     scan = ds.frames[0].scan
     out.append(("indoor_ring_field", ds.lidar, {"uneven": 1}, [(scan, ring_field(scan, ds.lidar))]))
+    # the other two sensor presets of processor_node.cc:66-74: sensor_type 32 = PointProcessor(-30.67, 10.67, 32) (elevation formula),
+    # sensor_type 320 = PointProcessor(-25, 15, 32, uneven = true) (ring field + swept range)
+    lid32 = synth.Lidar(32, -30.67, 10.67, 1800)
+    ds32 = synth.make_dataset("indoor", 1, 0.1, lidar=lid32)
+    out.append(("preset32_elevation", lid32, {}, [(ds32.frames[0].scan, None)]))
+    lid320 = synth.Lidar(32, -25.0, 15.0, 1800)
+    ds320 = synth.make_dataset("indoor", 1, 0.1, lidar=lid320)
+    out.append(("preset320_ring_field", lid320, {"uneven": 1}, [(ds320.frames[0].scan, ring_field(ds320.frames[0].scan, lid320))]))
     # other thresholds / quotas / subregion counts than the defaults
     out.append(("indoor_other_config", ds.lidar, {"num_scan_subregions": 6, "max_corner_sharp": 3, "max_corner_less_sharp": 12, "max_surf_flat": 5,
                                                    "surf_curv_th": 0.25, "less_flat_filter_size": 0.3}, [(scan, None)]))

@@ -207,6 +207,23 @@ def test_error_codes_of_the_init_and_mapping_entry_points(hip, oracle):
         assert est.stage()["cir_buf_count"] == 0 and est.stage()["event"] == "skipped"
 
 
+def test_point_processor_capacity_is_reported_as_such(hip, oracle):
+    """k_ring_pick keeps a subregion's picks one per lane of a wave: quotas above 64 picks are LIO_ERR_CAPACITY (-4), not a silent
+    NULL; bad values are LIO_ERR_ARG; the reference's presets and defaults are accepted.  The oracle has no such limit."""
+    cfg = capi.PPConfig()
+    hip.dll.lio_pp_default_config(cfg)
+    for lo, up, rings in ((-15.0, 15.0, 16), (-30.67, 10.67, 32), (-24.9, 2.0, 64), (-25.0, 15.0, 32)):     # processor_node.cc:66-74
+        assert hip.dll.lio_pp_check_config(lo, up, rings, cfg) == 0
+    cfg.max_corner_less_sharp, cfg.max_surf_flat = 60, 4
+    assert hip.dll.lio_pp_check_config(-15.0, 15.0, 16, cfg) == 0
+    cfg.max_surf_flat = 5
+    assert hip.dll.lio_pp_check_config(-15.0, 15.0, 16, cfg) == -4
+    assert oracle.dll.lio_pp_check_config(-15.0, 15.0, 16, cfg) == 0
+    cfg.max_surf_flat, cfg.max_corner_sharp = 4, 61
+    assert hip.dll.lio_pp_check_config(-15.0, 15.0, 16, cfg) == -1
+    assert hip.dll.lio_pp_check_config(15.0, -15.0, 16, None) == -1
+
+
 def test_process_imu_batch_equals_the_loop(oracle, hip):
     """lio_est_process_imu_batch = n calls of lio_est_process_imu (host-only in both libraries; the product's handle needs
     a device to exist, so without one only the oracle is exercised)."""

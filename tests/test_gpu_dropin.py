@@ -107,7 +107,14 @@ def test_dropin_class_replays_like_the_c_abi_and_the_reference(hip, oracle):
             laser, local, rep3 = np.zeros(9), np.zeros(9), np.zeros(3)
             lib.dropin_get_published(h, _p(laser), _p(local), _p(rep3))
             assert int(rep3[0]) == e["report"].iterations and int(rep3[1]) == e["report"].n_lidar_residuals and rep3[2] == e["report"].final_cost
-            assert laser[0] == e["stamp"] and int(laser[1]) == state["solved"]
+            # /extrinsic_lb goes out with every solve; the two odometry topics only from the INITED branch (Estimator.cc:728-758), i.e.
+            # not on the initialising step (:541-600 runs SolveOptimization + SlideWindow and publishes nothing else)
+            if e["event"] != "initialised":
+                state["published"] = state.get("published", 0) + 1
+                assert laser[0] == e["stamp"]
+            assert int(laser[1]) == state.get("published", 0)
+            if e["event"] == "initialised":
+                return
             # /predict_laser_odom = the newest frame's LIDAR pose (Estimator.cc:744-758): R_last * R_lb^-1, P_last - that * t_lb
             qlb, tlb = w["q_lb"].astype(float), w["t_lb"].astype(float)
             x, y, z, s = qlb

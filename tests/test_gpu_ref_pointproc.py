@@ -38,3 +38,7 @@ def test_product_point_processor_follows_the_reference(hip, oracle, case):
             assert a.shape == b.shape
             np.testing.assert_array_equal(a[:, :3], b[:, :3])         # same points, same order
             np.testing.assert_allclose(a[:, 3], b[:, 3], atol=8e-6)   # ring / intensity part equal, rel. time within atan2f's ulp
+        ia, ib = pps[0].ring_intensity(), pps[1].ring_intensity()        # intensity_scans: int(input intensity) + rel. time
+        assert digest(ib) == GOLD[name][k]["intensity_scans"]
+        assert ia.shape == ib.shape
+        np.testing.assert_allclose(ia, ib, atol=8e-6)

@@ -33,7 +33,9 @@ def replay(lib, name, lid, cfg_over, sweeps):
     rows = []
     for scan, ring in sweeps:
         pp.process(scan, ring)
-        rows.append({c: digest(pp.cloud(w)) for c, w in zip(CLOUDS, ORDER)})
+        row = {c: digest(pp.cloud(w)) for c, w in zip(CLOUDS, ORDER)}
+        row["intensity_scans"] = digest(pp.ring_intensity())   # the public intensity_scans' intensity channel (coordinates = laser_scans')
+        rows.append(row)
     return rows
 
 
@@ -46,7 +48,7 @@ def test_oracle_point_processor_equals_the_reference(oracle, case):
     rows = replay(oracle, name, lid, cfg_over, sweeps)
     assert len(rows) == len(GOLD[name])
     for k, (got, want) in enumerate(zip(rows, GOLD[name])):
-        assert got == want, (name, k, {c: (got[c], want[c]) for c in CLOUDS if got[c] != want[c]})
+        assert got == want, (name, k, {c: (got[c], want[c]) for c in list(CLOUDS) + ["intensity_scans"] if got[c] != want[c]})
     assert all(int(r["sharp"].split(":")[0]) > 0 and int(r["less_flat"].split(":")[0]) > 1000 for r in rows)
 
 

@@ -280,3 +280,35 @@ def test_dropin_class_is_compiled_and_fails_loudly_without_a_gpu():
         fp = np.array([0.2, 0.4, 1.0, 0.2, 0, 0, 0, 1, 0, 0, -0.08], np.float32)
         dp = np.array([0.1, 0.01, 0.0002, 2e-5, 9.805])
         assert lib.dropin_create(ip.ctypes.data, fp.ctypes.data, dp.ctypes.data, 0.0, 0.1) is None
+
+
+def test_front_end_dropin_classes_are_compiled_and_fail_loudly_without_a_gpu():
+    """SURVEY.md 8(b)'s other two classes: PointProcessorHip / PointOdometryHip (lio-mapping_amd/dropin, oracle/dropin_frontend.cc) compile against
+    the reference's headers into oracle/_ref/libdropin_frontend.so, export the harness entry points, and without a GPU their constructors
+    report the failure (no handle) instead of computing anything on the host."""
+    import ctypes as C
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "oracle", "_ref", "libdropin_frontend.so")
+    if os.path.isdir("/root/reference/src/point_processor"):
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "lio-mapping_amd", "csrc")], check=True)
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref/libdropin_frontend.so"], check=True)
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdropin_frontend.so not built (needs the reference tree)")
+    lib = C.CDLL(so)
+    for pre, names in (("dropin_pp_", ("create", "destroy", "process", "count", "get", "ranges", "last_error")),
+                       ("dropin_odom_", ("create", "destroy", "enable", "process", "get", "count", "get_cloud", "last_error"))):
+        for n in names:
+            assert hasattr(lib, pre + n), pre + n
+    import torch
+
+    if not torch.cuda.is_available():
+        lib.dropin_pp_create.restype = C.c_void_p
+        lib.dropin_pp_create.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        ic = np.array([8, 5, 2, 20, 4, 0], np.int32)
+        dc = np.array([0.1, 0.2, 0.1, 0.2])
+        assert lib.dropin_pp_create(-15.0, 15.0, 16, 0, ic.ctypes.data, dc.ctypes.data) is None
+        lib.dropin_odom_create.restype = C.c_void_p
+        lib.dropin_odom_create.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int]
+        assert lib.dropin_odom_create(0.1, 2, 25, 0) is None

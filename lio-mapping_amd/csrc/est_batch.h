@@ -74,8 +74,10 @@ class EstimatorBatch {
   // marginalization runs on a stream of its own behind the loop and is joined before the next solve's problems go up: it
   // overlaps the next solve's filter, features and rounds.
   static constexpr int kGroups = 4;
-  hipStream_t stream_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_marg_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_marg_ = nullptr;
+  // (LIO_BW_AUX_STREAM=1, an experiment kept for re-measurement: the aux row of an iteration on a side stream beside the moments pass.)
+  hipStream_t stream_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_aux_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_marg_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[kGroups] = {nullptr, nullptr, nullptr, nullptr},
+             ev_step_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_marg_ = nullptr;
   bool marg_in_flight_ = false;
   hipEvent_t ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid_ = false;

@@ -22,10 +22,13 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   LIO_HIP(hipStreamCreate(&stream_));
   for (hipEvent_t &e : ev_) LIO_HIP(hipEventCreate(&e));
   for (hipStream_t &g : stream_grp_) LIO_HIP(hipStreamCreate(&g));
+  for (hipStream_t &g : stream_aux_) LIO_HIP(hipStreamCreate(&g));
   LIO_HIP(hipStreamCreate(&stream_marg_));
   LIO_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   LIO_HIP(hipEventCreateWithFlags(&ev_marg_, hipEventDisableTiming));
   for (hipEvent_t &e : ev_grp_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t &e : ev_aux_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t &e : ev_step_) LIO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   win_.resize(B);
   for (size_t w = 0; w < B; ++w) { win_[w].e = m_[w]; m_[w]->AdoptStream(stream_); }
   pinned(h_win_, B); pinned(h_grid_, B); pinned(h_vout_, B); pinned(h_odom_, B); pinned(h_bs_, B); pinned(h_pb_, B); pinned(h_st_, B); pinned(h_mg_, B);
@@ -40,7 +43,7 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   lay_.prior[0] = take(ds_prior_mats_size(MARG_MAX_N)); lay_.prior[1] = take(ds_prior_mats_size(MARG_MAX_N));
   lay_.imu = take(size_t(DS_MAX_WO) * DS_IMU_OUT); lay_.lmap = take(size_t(DS_MAX_WO) * DS_LMAP_OUT);
   lay_.prior_out = take(MARG_MAX_N + 8); lay_.exprior = take(DS_EXP_OUT);
-  lay_.Hcur = take(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); lay_.Sbuf = take(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT); lay_.prof = take(32);
+  lay_.Hcur = take(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); lay_.Sbuf = take(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT); lay_.prof = take(96);
   lay_.marg_imu = take(DS_IMU_OUT); lay_.marg_lmap = take(size_t(DS_MAX_WO) * DS_LMAP_OUT); lay_.marg_prior_out = take(MARG_MAX_N + 8);
   { const size_t N = MARG_MAX_M + MARG_MAX_N; lay_.marg_A = take(N * N + N); }
   lay_.marg_info = take(MARG_MAX_N + 8);
@@ -63,9 +66,12 @@ EstimatorBatch::~EstimatorBatch() {
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_grp_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_aux_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_step_) if (e) (void)hipEventDestroy(e);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_marg_) (void)hipEventDestroy(ev_marg_);
   for (hipStream_t g : stream_grp_) if (g) (void)hipStreamDestroy(g);
+  for (hipStream_t g : stream_aux_) if (g) (void)hipStreamDestroy(g);
   if (stream_marg_) (void)hipStreamDestroy(stream_marg_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -320,10 +326,15 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     // Groups of windows run their chains side by side (see est_batch.h); one group below 32 windows.
     static const int g_env = [] { const char *e = std::getenv("LIO_BW_GROUPS"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= kGroups) ? v : 0; }();
     const int G = g_env ? std::min(g_env, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
-    if (G > 1) LIO_HIP(hipEventRecord(ev_fork_, s));
+    // LIO_BW_AUX_STREAM=1: the aux row on a side stream beside the moments.  Measured slower on the MI355X (two events per iteration cost
+    // more than the 41 us they hide: loop 2.92 ms against 2.68 at 64 windows, profiles/r5_e_aux_stream_ab_and_step_phases.txt): off.
+    static const int aux_env = [] { const char *e = std::getenv("LIO_BW_AUX_STREAM"); return e ? std::atoi(e) : 0; }();
+    const bool side_aux = aux_env != 0;
+    static const int prof_it = [] { const char *e = std::getenv("LIO_DEBUG_TIMING_IT"); return e ? std::atoi(e) : 3; }();
+    if (G > 1 || side_aux) LIO_HIP(hipEventRecord(ev_fork_, s));
     for (int g = 0; g < G; ++g) {
       const int w0 = int((long long)B * g / G), w1 = int((long long)B * (g + 1) / G);
-      hipStream_t sg = G > 1 ? stream_grp_[g] : s;
+      hipStream_t sg = G > 1 ? stream_grp_[g] : s, sa = stream_aux_[g];
       if (G > 1) LIO_HIP(hipStreamWaitEvent(sg, ev_fork_, 0));
       int g_bpf = 1, g_wo = 1, g_npad = DS_NB, g_it = 0, g_n = 0;
       for (int w = w0; w < w1; ++w) {
@@ -333,7 +344,22 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
         g_it = std::max(g_it, e->cfg_.max_num_iterations); ++g_n;
       }
       if (g_n > 0)
-        for (int k = 0; k <= g_it; ++k) launch_bw_solve_iteration(d_bs_.p + w0, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
+        for (int k = 0; k <= g_it; ++k) {
+          const BatchSolve *gb = d_bs_.p + w0;
+          if (side_aux) {   // aux row beside the moments; the step kernel joins the two
+            LIO_HIP(hipStreamWaitEvent(sa, k == 0 ? ev_fork_ : ev_step_[g], 0));
+            launch_bw_aux(gb, w1 - w0, g_wo, sa);
+            LIO_HIP(hipEventRecord(ev_aux_[g], sa));
+            launch_bw_moments(gb, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
+            LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
+            launch_bw_step(gb, w1 - w0, g_wo, g_npad, sg);
+            if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
+          } else {
+            launch_bw_solve_iteration(gb, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
+          }
+          if (h_bs_[0].prof && w0 == 0 && k == prof_it)   // LIO_DEBUG_TIMING: keep the stamps of this iteration's launch B beside the last one's
+            LIO_HIP(hipMemcpyAsync(h_bs_[0].prof + 32, h_bs_[0].prof, 32 * sizeof(long long), hipMemcpyDeviceToDevice, sg));
+        }
       if (G > 1) { LIO_HIP(hipEventRecord(ev_grp_[g], sg)); LIO_HIP(hipStreamWaitEvent(s, ev_grp_[g], 0)); }
     }
     LIO_HIP(hipEventRecord(ev_[5], s));
@@ -343,11 +369,15 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     LIO_HIP(hipEventRecord(ev_[5], s));
   }
   if (h_bs_[0].prof) {   // LIO_DEBUG_TIMING: the phase stamps of window 0's last launch B (shader clock, 100 MHz wall clock is not used here)
-    long long pr[32];
+    long long pr[96];
     LIO_HIP(hipMemcpy(pr, h_bs_[0].prof, sizeof(pr), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[lio_hip timing] launch B of window 0, last launch, clock64 ticks from its start:");
-    for (int k = 0; k < 24; ++k) std::fprintf(stderr, " P%d %lld", k, pr[k] ? pr[k] - pr[0] : -1);
-    std::fprintf(stderr, "\n");
+    for (int half = 1; half >= 0; --half) {
+      std::fprintf(stderr, "[lio_hip timing] launch B of window 0, %s, clock64 ticks from its start:", half ? "iteration LIO_DEBUG_TIMING_IT (default 3)" : "last launch");
+      for (int k = 0; k < 32; ++k) std::fprintf(stderr, " P%d %lld", k, pr[32 * half + k] ? pr[32 * half + k] - pr[32 * half] : -1);
+      std::fprintf(stderr, "\n");
+    }
+    std::fprintf(stderr, "[lio_hip timing] aux row of window 0, block 0 (ImuFactor 0 + lidar map 1), last launch, clock64 ticks: raw Jacobians + residual %lld, whitening %lld, J^T J %lld, lidar map %lld\n",
+                 pr[65] - pr[64], pr[66] - pr[65], pr[67] - pr[66], pr[68] - pr[67]);
   }
   clk_.iterations = max_it + 1;
   const double t4 = bnow_ms();

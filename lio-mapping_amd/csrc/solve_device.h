@@ -22,6 +22,10 @@ struct DevExec {
   static constexpr int WT = 64;
   int tid, nthr, lane, wave, nwave;
   __device__ __forceinline__ void sync() const { __syncthreads(); }
+  // barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its global stores (__syncthreads() drains
+  // vmcnt too — one HBM write round trip, 1-2 us, at every barrier that follows a burst of global stores; the step kernel has eight
+  // such bursts per launch and no reader of them inside the launch)
+  __device__ __forceinline__ void sync_lds() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   __device__ __forceinline__ double wsum(double v) const {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -44,9 +48,17 @@ struct DevExec {
   }
   // lanes 4m .. 4m+3 hold v0..v3: every one of them gets (v0 + v1) + (v2 + v3)
   __device__ __forceinline__ void stamp(long long *prof, int k) const { if (prof && tid == 0) prof[k] = clock64(); }
+  // quad permutes on the data-parallel-primitives path (no LDS crossbar: __shfl_xor is a ds_bpermute, ~100 clocks per 32-bit half)
+  template <int CTRL>
+  __device__ __forceinline__ static double dpp_quad(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+  }
   __device__ __forceinline__ double pair_sum4(double v) const {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
+    v += dpp_quad<0xB1>(v);   // quad_perm [1, 0, 3, 2]: lane ^ 1
+    v += dpp_quad<0x4E>(v);   // quad_perm [2, 3, 0, 1]: lane ^ 2
     return v;
   }
 
@@ -54,7 +66,7 @@ struct DevExec {
   // goes through 16 doubles of LDS and comes back to every lane as broadcast reads (the first form moved it with 2 x 15 v_readlane
   // per pivot: 10.6 us per block, profiles/r5_c_step_phases.txt).  Then X = L11^-1 (lane c: column c by forward substitution, L11
   // read back from the block as broadcast LDS reads) is left row-major in scr[64 .. 320): the rows below the block are solved
-  // against it on the matrix cores (panel_trsm_mfma).  scr: >= 320 doubles of LDS.
+  // against it on the matrix cores (panel_trsm_mfma).  scr: >= DS_PART = 576 doubles of LDS (exchange 64 | X 256 | staging 256).
   __device__ __forceinline__ void wave_lds_sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -68,10 +80,11 @@ struct DevExec {
     for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
     int ok = 1;
     double myinv = 0.0;
-    // Measured on the MI355X (tools/micro/pivot_chain.hip, profiles/r5_pivot_chain.txt): a dependent fp64 FMA 14 cycles, rcp + two
-    // Newton steps 64, an LDS write -> wave barrier -> read 92, a v_readlane broadcast + use 76.  A pivot is one LDS round trip (the
-    // block's column j out, every lane reads what it needs back as broadcast reads) + the reciprocal + two multiplies on the chain.
-    // (Building X inside this loop — a second LDS exchange per pivot — was measured slower: 20.4 k cycles against 12.4 k.)
+    // Measured on the MI355X (tools/micro/pivot_chain.hip, diag_block.hip; profiles/r5_pivot_chain.txt, r5_f_*): a dependent fp64 FMA 14
+    // clocks, rcp + two Newton steps 64, an LDS write -> wave barrier -> read 92.  A pivot is one LDS round trip (column j of the block
+    // out, every lane reads what it needs back as broadcast reads) + the reciprocal + a multiply and a fused multiply-add on the chain:
+    // 3.5 k clocks for the sixteen.  (With separate multiplies and adds the block cost 11.6 k, with the inverse built inside this loop
+    // 16-20 k.)
 #pragma unroll
     for (int j = 0; j < DS_NB; ++j) {
       double *bc = scr + (j & 1) * DS_NB;
@@ -82,34 +95,50 @@ struct DevExec {
       const double inv = rcp(d);
       const double l = a[j] * inv;
 #pragma unroll
-      for (int c = j + 1; c < DS_NB; ++c) a[c] -= l * bc[c];
+      for (int c = j + 1; c < DS_NB; ++c) a[c] = __builtin_fma(-l, bc[c], a[c]);
       a[j] = (r > j) ? l : a[j];
       myinv = (r == j) ? inv : myinv;
     }
+    // the factored rows go to a dense 16 x 16 staging block (unconditional wide stores); from there the lower triangle is copied into
+    // A by all 64 lanes (A's strict upper triangle must survive) and the inverse reads L11 with a leading dimension of 16
+    double *Ls = scr + 4 * DS_NB + DS_NB * DS_NB;
     if (lane < DS_NB) {
-      double *orow = A + size_t(p + r) * ld + p;
 #pragma unroll
-      for (int c = 0; c < DS_NB; ++c)
-        if (c <= r) orow[c] = a[c];
+      for (int c = 0; c < DS_NB; ++c) Ls[r * DS_NB + c] = a[c];
       invd[p + r] = myinv;
     }
     wave_lds_sync();
-    // X = L11^-1: lane c solves L11 x = e_c by forward substitution (two interleaved partial sums per row)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q, rr = e >> 4, cc = e & 15;
+      if (cc <= rr) A[size_t(p + rr) * ld + p + cc] = Ls[e];
+    }
+    // X = L11^-1 by forward substitution, FOUR lanes per column (column c = lane >> 2; lane part g = lane & 3 sums the terms
+    // k = g, g + 4, ...; the four partial sums meet through two quad permutes): 30 multiply-adds per lane instead of 120
     {
-      const int c = lane & 15;
+      const int c = lane >> 2, g = lane & 3;
       double xcol[DS_NB];
 #pragma unroll
       for (int k = 0; k < DS_NB; ++k) xcol[k] = (k == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int rr = 1; rr < DS_NB; ++rr) {
-        const double *lr = A + size_t(p + rr) * ld + p;
-        double acc0 = 0.0, acc1 = 0.0;
+        double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < rr; ++k) { if (k & 1) acc1 += lr[k] * xcol[k]; else acc0 += lr[k] * xcol[k]; }
-        xcol[rr] = (rr > c) ? -(acc0 + acc1) : xcol[rr];
+        for (int k4 = 0; k4 < rr; k4 += 4) {
+          // term k = k4 + g of this lane (k < rr): the select below keeps the register index static
+          double xk = xcol[k4];
+          if (k4 + 1 < DS_NB) xk = (g == 1) ? xcol[k4 + 1] : xk;
+          if (k4 + 2 < DS_NB) xk = (g == 2) ? xcol[k4 + 2] : xk;
+          if (k4 + 3 < DS_NB) xk = (g == 3) ? xcol[k4 + 3] : xk;
+          const int k = k4 + g;
+          const double lv = (k < rr) ? Ls[rr * DS_NB + k] : 0.0;
+          acc = __builtin_fma(lv, xk, acc);
+        }
+        acc = pair_sum4(acc);
+        xcol[rr] = (rr > c) ? -acc : xcol[rr];
       }
       double *Xs = scr + 4 * DS_NB;
-      if (lane < DS_NB) {
+      if (g == 0) {
 #pragma unroll
         for (int rr = 0; rr < DS_NB; ++rr) Xs[rr * DS_NB + c] = xcol[rr];
       }
@@ -192,7 +221,7 @@ struct DevExec {
 #pragma unroll
     for (int k = DS_NB - 1; k >= 1; --k) {
       const double yk = ds_bcast_lane(y, k);
-      y -= col[k] * yk;
+      y = __builtin_fma(-col[k], yk, y);
     }
     if (lane < DS_NB) gz[p + j] = y;
   }

@@ -781,9 +781,14 @@ __global__ void __launch_bounds__(MOMENT_THREADS) k_bw_aux(const BatchSolve *__r
   const DevParams &P = st->cand;
   const DevProblem *pb = S.pb;
   if (i < Wo) {
-    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], S.imu_out + size_t(i) * DS_IMU_OUT, aux_lds);
+    long long *prof = i == 0 ? S.prof : nullptr;
+    x.stamp(prof, 64);
+    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], S.imu_out + size_t(i) * DS_IMU_OUT, aux_lds, prof);
     __syncthreads();
+    x.stamp(prof, 67);
     aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+    __syncthreads();
+    x.stamp(prof, 68);
   } else {
     if (pb->have_prior) aux_prior(x, *pb, S.prior_mats, P, S.prior_out, aux_lds);
     if (pb->use_ex_prior) aux_exprior(x, *pb, P, S.exprior_out);
@@ -807,7 +812,7 @@ __global__ void __launch_bounds__(DS_THREADS) k_ldlt_test(const double *__restri
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int ld = npad + 1;
   double *A = ds_lds, *gz = A + size_t(npad) * ld, *invd = gz + npad, *part = invd + npad;
-  int *flag = reinterpret_cast<int *>(part + 512);
+  int *flag = reinterpret_cast<int *>(part + DS_PART);
   for (int e = x.tid; e < npad * npad; e += x.nthr) {
     const int r = e / npad, c = e % npad;
     A[size_t(r) * ld + c] = (r < n && c < n) ? Ain[size_t(r) * n + c] : (r == c ? 1.0 : 0.0);
@@ -822,7 +827,7 @@ __global__ void __launch_bounds__(DS_THREADS) k_ldlt_test(const double *__restri
 }
 int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipStream_t s) {
   const int npad = (n + DS_NB - 1) / DS_NB * DS_NB;
-  const size_t lds = (size_t(npad) * (npad + 1) + 2 * size_t(npad) + 512 + 8) * sizeof(double);
+  const size_t lds = (size_t(npad) * (npad + 1) + 2 * size_t(npad) + DS_PART + 8) * sizeof(double);
   if (n < 1 || lds > 160 * 1024) return -2;
   static const bool attr_set = [] {
     LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldlt_test), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -842,18 +847,29 @@ int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipSt
   return ok;
 }
 
-void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+void launch_bw_aux(const BatchSolve *bs, int B, int max_wo, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs);
+}
+void launch_bw_moments(const BatchSolve *bs, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
+}
+void launch_bw_step(const BatchSolve *bs, int B, int max_wo, int max_npad, hipStream_t s) {
   if (B <= 0) return;
   static const bool attr_set = [] {
     LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs);
-  hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
   const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);
   hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs);
   LIO_HIP(hipGetLastError());
+}
+void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+  launch_bw_aux(bs, B, max_wo, s);
+  launch_bw_moments(bs, B, max_bpf, max_wo, valid, coef, s);
+  launch_bw_step(bs, B, max_wo, max_npad, s);
 }
 
 }  // namespace lio

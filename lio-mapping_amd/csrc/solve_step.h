@@ -31,7 +31,10 @@ namespace lio {
 #define DS_MAX_WO 7
 #define DS_MAX_NPAD 128      // padded tangent dimension the LDS-resident factorisation takes (15 (Wo + 1) + 6, rounded up to 16)
 #define DS_NB 16
-#define DS_THREADS 512
+#define DS_PART 576    // doubles of the factorisation's scratch: pivot exchange 64 | L11^-1 256 | staging block 256 (>= the 32 x 16 slices of the back-substitution)
+#ifndef DS_THREADS
+#define DS_THREADS 256     // threads of the step kernel's workgroup: one wave per SIMD, 512 registers per lane (at 512 threads the kernel spilled 230 VGPRs to scratch: 118 -> 153 us per step, profiles/r5_g_*; tools/r5/build_variant.sh builds the other form)
+#endif
 #define DS_MAX_KEEP (DS_MAX_WO + 3)
 #define DS_IMU_OUT 932       // 900 J^T J + 30 J^T r + cost + present
 #define DS_LMAP_OUT 248      // 234 L + 13 l + pad
@@ -76,7 +79,7 @@ struct DevState {
 LIO_HD size_t ds_prior_mats_size(int np) { return size_t(2) * np * np + 2 * np; }
 // LDS doubles the step kernel needs for (n_pad, Wo)
 LIO_HD size_t ds_lds_doubles(int n_pad, int Wo) {
-  return size_t(n_pad) * (n_pad + 1) + 10 * size_t(n_pad) + size_t(Wo) * 344 + 32 * 16 + 64 + 32;
+  return size_t(n_pad) * (n_pad + 1) + 10 * size_t(n_pad) + size_t(Wo) * 344 + DS_PART + 64 + 32;
 }
 
 // ------------------------------------------------------------------------------------------------ executors
@@ -85,6 +88,7 @@ struct HostExec {
   static constexpr int WT = 1;   // lanes per "wave"
   int tid = 0, nthr = 1, lane = 0, wave = 0, nwave = 1;
   void sync() const {}
+  void sync_lds() const {}
   void wsync() const {}
   double wsum(double v) const { return v; }
   double wmax(double v) const { return v; }
@@ -100,19 +104,19 @@ LIO_HD void block_sum(const X &x, double *red, double (&v)[K]) {
   if (x.lane == 0)
 #pragma unroll
     for (int k = 0; k < K; ++k) red[x.wave * K + k] = v[k];
-  x.sync();
+  x.sync_lds();
 #pragma unroll
   for (int k = 0; k < K; ++k) { double s = 0; for (int w = 0; w < x.nwave; ++w) s += red[w * K + k]; v[k] = s; }
-  x.sync();
+  x.sync_lds();
 }
 template <class X>
 LIO_HD double block_max(const X &x, double *red, double v) {
   v = x.wmax(v);
   if (x.lane == 0) red[x.wave] = v;
-  x.sync();
+  x.sync_lds();
   double s = red[0];
   for (int w = 1; w < x.nwave; ++w) s = s > red[w] ? s : red[w];
-  x.sync();
+  x.sync_lds();
   return s;
 }
 
@@ -122,7 +126,7 @@ LIO_HD double block_max(const X &x, double *red, double v) {
 // WindowSystem::evaluate (host_solver.h) so both paths produce the same blocks.
 template <class X>
 LIO_HD void aux_imu(const X &x, const DevPim &pm, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j,
-                    double *out, double *lds) {
+                    double *out, double *lds, long long *prof = nullptr) {
   if (!pm.present) {
     for (int k = x.tid; k < DS_IMU_OUT; k += x.nthr) out[k] = 0.0;
     return;
@@ -147,6 +151,7 @@ LIO_HD void aux_imu(const X &x, const DevPim &pm, const double *pose_i, const do
     }
   }
   x.sync();
+  x.stamp(prof, 65);
   const double *S = pm.sqrt_info;
   for (int e = x.tid; e < 465; e += x.nthr) {
     if (e < 450) {
@@ -162,6 +167,7 @@ LIO_HD void aux_imu(const X &x, const DevPim &pm, const double *pose_i, const do
     }
   }
   x.sync();
+  x.stamp(prof, 66);
   for (int e = x.tid; e < 931; e += x.nthr) {
     if (e < 900) {
       const int a = e / 30, b = e % 30;
@@ -301,7 +307,7 @@ LIO_HD StepLds carve_lds(double *base, int n_pad, int Wo) {
   l.hdiag = p; p += n_pad; l.gz = p; p += n_pad; l.invd = p; p += n_pad; l.scale = p; p += n_pad; l.diag = p; p += n_pad;
   l.grad = p; p += n_pad; l.gn = p; p += n_pad; l.g = p; p += n_pad; l.step = p; p += n_pad; l.tmp = p; p += n_pad;
   l.zb = p; p += size_t(Wo) * 344;
-  l.part = p; p += 32 * 16;
+  l.part = p; p += DS_PART;
   l.red = p; p += 64;
   l.ctl = reinterpret_cast<int *>(p);
   return l;
@@ -316,6 +322,31 @@ enum { DS_MODE_INIT = 0, DS_MODE_ACCEPT = 1, DS_MODE_REJECT = 2 };
 
 // H(i, j) of a symmetric matrix whose UPPER triangle (row-major, leading dimension ld) and diagonal vector are intact
 LIO_HD double ds_hsym(const double *Hm, int ld, const double *hd, int i, int j) { return i == j ? hd[i] : (i < j ? Hm[i * ld + j] : Hm[j * ld + i]); }
+
+// sum_i v_i (H v)_i for the symmetric H of ds_hsym, rows >= n excluded.  Device: four lanes per row (columns q, q + 4, ...; the
+// four partial sums combined as (p0 + p1) + (p2 + p3)) — one lane per row was a chain of n dependent multiply-adds on 96 of the
+// block's 512 threads, 12 us of the step twice per iteration (profiles/r5_e_step_phases.txt).  The thread's contribution is
+// ADDED to acc (the caller block-sums it).
+template <class X>
+LIO_HD void ds_vHv(const X &x, const double *Hm, int ld, const double *hd, int n, const double *v, double &acc) {
+  if constexpr (X::kDevice) {
+    const int q = x.tid & 3;
+    for (int i0 = 0; i0 < n; i0 += x.nthr / 4) {   // (uniform trip count: the shuffles below need every lane of the wave)
+      const int i = i0 + (x.tid >> 2);
+      double sres = 0.0;
+      if (i < n)
+        for (int j = q; j < n; j += 4) sres += ds_hsym(Hm, ld, hd, i, j) * v[j];
+      sres = x.pair_sum4(sres);
+      if (i < n && q == 0) acc += v[i] * sres;
+    }
+  } else {
+    for (int i = x.tid; i < n; i += x.nthr) {
+      double sres = 0;
+      for (int j = 0; j < n; ++j) sres += ds_hsym(Hm, ld, hd, i, j) * v[j];
+      acc += v[i] * sres;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ blocked L D L^T in LDS
 // Lower triangle of A (n_pad x n_pad, leading dimension ld; rows/cols >= n are an identity pad) is replaced by unit L with D
@@ -362,7 +393,7 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
     if (kb == 0) x.stamp(prof, 16);
     const int ok = ds_panel_factor(x, A, ld, p, invd, part);
     if (x.tid == 0) *flag = ok;
-    x.sync();
+    x.sync_lds();
     if (kb == 0) x.stamp(prof, 17);
     if (!*flag) return 0;   // uniform: every thread reads the same LDS word after the barrier
     // ---- phase 2: rows below the block and the right-hand side: T = A21 L11^-T (forward substitution along the columns),
@@ -383,7 +414,7 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
         for (int j = 0; j < DS_NB; ++j) row[j] = tr[j] * invd[p + j];
       }
     }
-    x.sync();
+    x.sync_lds();
     if (kb == 0) x.stamp(prof, 18);
     if (q >= npad) break;
     // ---- phase 3: trailing update  A22 -= L21 D L21^T  (lower triangle), rhs -= L21 D z
@@ -404,7 +435,7 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
           A[size_t(r) * ld + c] -= sres;
         }
     }
-    x.sync();
+    x.sync_lds();
     if (kb == 0) x.stamp(prof, 19);
   }
   x.stamp(prof, 20);
@@ -427,7 +458,7 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
         }
       }
     }
-    x.sync();
+    x.sync_lds();
     if (x.wave == 0) {
       if constexpr (X::kDevice) {
         x.panel_backsolve_regs(A, ld, p, gz, part);
@@ -439,7 +470,7 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
         for (int j = 0; j < DS_NB; ++j) gz[p + j] = y[j];
       }
     }
-    x.sync();
+    x.sync_lds();
   }
   return 1;
 }
@@ -456,7 +487,7 @@ LIO_HD void ds_lidar_blocks(const X &x, int Wo, const double *lmap, const double
     for (int k = 0; k < 13; ++k) o += Lm[a * 13 + k] * Sf[k * 16 + b];
     LS[e] = o;
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(prof, 2);
   for (int e = x.tid; e < Wo * 342; e += x.nthr) {
     const int f = e / 342, r = e % 342;
@@ -471,7 +502,7 @@ LIO_HD void ds_lidar_blocks(const X &x, int Wo, const double *lmap, const double
     }
     zb[f * 344 + r] = o;
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(prof, 3);
 }
 
@@ -482,7 +513,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   StepLds L = carve_lds(lds_base, npad, Wo);
   StepCtl &C = *reinterpret_cast<StepCtl *>(L.ctl);
   if (x.tid == 0) C.done = st.done;
-  x.sync();
+  x.sync_lds();
   if (C.done) return;
   double *A = L.A;
   x.stamp(B.prof, 0);
@@ -494,33 +525,59 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   {
     const int bpf = pb.bpf, b4 = bpf & ~3;
     const int items = Wo * 258;
-    // one lane per value, eight blocks' loads in flight at a time (the first device form — four lanes per value, one load at a time —
-    // was a chain of memory round trips: 14 us of the step at ten blocks per frame); the sums and their order are the four chains above
-    for (int item = x.tid; item < items; item += x.nthr) {
-      const int f = item / 258, k = item % 258;
-      const double *src = B.partials + size_t(f) * bpf * LIO_MOMENT_OUT + k;
-      double v[4] = {0, 0, 0, 0};
+    // one lane per value, eight blocks' loads in flight per value and a thread's (up to three) values together (the first device form —
+    // four lanes per value, one load at a time — was a chain of memory round trips: 14 us of the step at ten blocks per frame; one value
+    // at a time still cost three round trips: 5 us); the sums and their order are the four chains above
+    constexpr int IT = X::kDevice ? 3 : 1;
+    for (int item0 = x.tid; item0 < items; item0 += IT * x.nthr) {
+      const double *src[IT];
+      double v[IT][4];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int item = item0 + u * x.nthr;
+        const int it2 = item < items ? item : item0;
+        src[u] = B.partials + size_t(it2 / 258) * bpf * LIO_MOMENT_OUT + it2 % 258;
+        v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.0;
+      }
       int b = 0;
       for (; b + 8 <= b4; b += 8) {
-        double t[8];
+        double t[IT][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = src[size_t(b + q) * LIO_MOMENT_OUT];
+        for (int u = 0; u < IT; ++u)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q & 3] += t[q];
+          for (int q = 0; q < 8; ++q) t[u][q] = src[u][size_t(b + q) * LIO_MOMENT_OUT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[u][q & 3] += t[u][q];
       }
       if (b < b4) {   // (b4 is a multiple of four: one more group of four)
-        double t[4];
+        double t[IT][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = src[size_t(b + q) * LIO_MOMENT_OUT];
+        for (int u = 0; u < IT; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += t[q];
+          for (int q = 0; q < 4; ++q) t[u][q] = src[u][size_t(b + q) * LIO_MOMENT_OUT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[u][q] += t[u][q];
       }
-      for (b = b4; b < bpf; ++b) v[0] += src[size_t(b) * LIO_MOMENT_OUT];
-      const double o = (v[0] + v[1]) + (v[2] + v[3]);
-      Sx[f * LIO_MOMENT_OUT + k] = o; S_cand[f * LIO_MOMENT_OUT + k] = o;
+      for (b = b4; b < bpf; ++b)
+#pragma unroll
+        for (int u = 0; u < IT; ++u) v[u][0] += src[u][size_t(b) * LIO_MOMENT_OUT];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int item = item0 + u * x.nthr;
+        if (item < items) {
+          const int f = item / 258, k = item % 258;
+          const double o = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+          Sx[f * LIO_MOMENT_OUT + k] = o; S_cand[f * LIO_MOMENT_OUT + k] = o;
+          if (k >= 256) L.tmp[2 * f + (k - 256)] = o;   // cost and count of frame f, for the passes and the decision below (Sx is gone by then)
+        }
+      }
     }
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(B.prof, 1);
   // ---- P2, P3: H_i = (L S) L^T (18 x 18), g_i = (L S) l per frame
   ds_lidar_blocks(x, Wo, B.lmap, Sx, LS, L.zb, B.prof);
@@ -534,34 +591,80 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   const int tcol = x.tid % CW, trow = x.tid / CW, rstep = x.nthr >= CW ? x.nthr / CW : 1;
   int *pcol = reinterpret_cast<int *>(L.part);   // the prior's column of every tangent column (LDS copy; `part` is idle until the back-substitution)
   for (int i = x.tid; i < npad; i += x.nthr) pcol[i] = (pb.have_prior && i < n) ? pb.prior_col[i] : -1;
-  x.sync();
-  for (int r = trow; r < npad; r += rstep)
+  x.sync_lds();
+  // the ImuFactor blocks of this thread's entries, requested now (one memory round trip under the prior pass instead of one per block)
+  constexpr int IMU_Q = X::kDevice ? (930 + DS_THREADS - 1) / DS_THREADS : 1;
+  double imv[X::kDevice ? DS_MAX_WO : 1][IMU_Q];
+  double imflag[X::kDevice ? DS_MAX_WO : 1];
+  if (X::kDevice) {
+#pragma unroll
+    for (int i = 0; i < DS_MAX_WO; ++i) {
+      const double *im = B.imu_out + size_t(i < Wo ? i : 0) * DS_IMU_OUT;
+      imflag[i] = im[931];
+#pragma unroll
+      for (int q = 0; q < IMU_Q; ++q) { const int e = x.tid + q * DS_THREADS; imv[i][q] = im[e < 930 ? e : 0]; }
+    }
+  }
+  {  // prior pass: column tcol of rows trow, trow + rstep, ...; 24 rows' loads in flight at a time (all of them at 96 unknowns)
     for (int c = tcol; c <= npad; c += CW) {
       const bool is_g = (c == npad);
-      double v = 0.0;
-      if (r >= n || (!is_g && c >= n)) v = (!is_g && r == c) ? 1.0 : 0.0;
-      else {
-        const int pr = pcol[r];
-        if (pr >= 0) {
-          if (is_g) v = B.prior_out[pr];
-          else { const int pc = pcol[c]; if (pc >= 0) v = JtJ[size_t(pr) * np + pc]; }
+      const int pc = is_g ? -1 : pcol[c < npad ? c : 0];
+      constexpr int PQ = X::kDevice ? 24 : 8;
+      for (int r0 = trow; r0 < npad; r0 += PQ * rstep) {
+        double v[PQ];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+          const int r = r0 + q * rstep;
+          const int pr = r < npad ? pcol[r] : -1;
+          double t = 0.0;
+          if (pr >= 0) {
+            if (is_g) t = B.prior_out[pr];
+            else if (pc >= 0) t = JtJ[size_t(pr) * np + pc];
+          }
+          v[q] = t;
+        }
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+          const int r = r0 + q * rstep;
+          if (r < npad) {
+            double t = v[q];
+            if (r >= n || (!is_g && c >= n)) t = (!is_g && r == c) ? 1.0 : 0.0;
+            if (is_g) L.gz[r] = t; else A[size_t(r) * ld + c] = t;
+          }
         }
       }
-      if (is_g) L.gz[r] = v; else A[size_t(r) * ld + c] = v;
     }
-  x.sync();
+  }
+  x.sync_lds();
+  x.stamp(B.prof, 11);
   for (int i = 0; i < Wo; ++i) {   // ImuFactor i spans tangent columns [15 i, 15 i + 30)
-    const double *im = B.imu_out + size_t(i) * DS_IMU_OUT;
-    if (im[931] != 0.0) {
-      for (int e = x.tid; e < 930; e += x.nthr) {
-        if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += im[e]; }
-        else L.gz[15 * i + (e - 900)] += im[e];
+    if (X::kDevice) {
+      // (static register indices: the loop over the frames is unrolled to its bound, a frame beyond Wo never passes the outer test)
+#pragma unroll
+      for (int ii = 0; ii < DS_MAX_WO; ++ii) {
+        if (ii == i && imflag[ii] != 0.0) {
+#pragma unroll
+          for (int q = 0; q < IMU_Q; ++q) {
+            const int e = x.tid + q * DS_THREADS;
+            if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += imv[ii][q]; }
+            else if (e < 930) L.gz[15 * i + (e - 900)] += imv[ii][q];
+          }
+        }
+      }
+    } else {
+      const double *im = B.imu_out + size_t(i) * DS_IMU_OUT;
+      if (im[931] != 0.0) {
+        for (int e = x.tid; e < 930; e += x.nthr) {
+          if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += im[e]; }
+          else L.gz[15 * i + (e - 900)] += im[e];
+        }
       }
     }
-    x.sync();
+    x.sync_lds();
   }
+  x.stamp(B.prof, 14);
   for (int f = 0; f < Wo; ++f) {   // lidar frame f + 1 touches (pose_0, pose_{f+1}, extrinsic): local rows 0..5, 6..11, 12..17
-    if (S_cand[f * LIO_MOMENT_OUT + 257] != 0.0) {
+    if (L.tmp[2 * f + 1] != 0.0) {
       const double *zf = L.zb + f * 344;
       for (int e = x.tid; e < 342; e += x.nthr) {
         if (e < 324) {
@@ -576,14 +679,14 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
       }
     }
-    x.sync();
+    x.sync_lds();
   }
   if (pb.use_ex_prior && exc >= 0) {
     for (int e = x.tid; e < 42; e += x.nthr) {
       if (e < 36) A[size_t(exc + e / 6) * ld + exc + e % 6] += B.exprior_out[e];
       else L.gz[exc + (e - 36)] += B.exprior_out[e];
     }
-    x.sync();
+    x.sync_lds();
   }
   // NOTE: Sx / LS aliased A and are gone now; S_cand (global) keeps the moments.
   x.stamp(B.prof, 4);
@@ -591,7 +694,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   if (x.tid == 0) {
     double marg = pb.have_prior ? B.prior_out[np] : 0.0, pim = 0.0, ppp = 0.0, cnt = 0.0;
     for (int i = 0; i < Wo; ++i) if (B.imu_out[size_t(i) * DS_IMU_OUT + 931] != 0.0) pim += B.imu_out[size_t(i) * DS_IMU_OUT + 930];
-    for (int i = 0; i < Wo; ++i) { ppp += S_cand[i * LIO_MOMENT_OUT + 256]; cnt += S_cand[i * LIO_MOMENT_OUT + 257]; }
+    for (int i = 0; i < Wo; ++i) { ppp += L.tmp[2 * i]; cnt += L.tmp[2 * i + 1]; }
     const double exprior = pb.use_ex_prior ? B.exprior_out[42] : 0.0;
     const double total = marg + pim + ppp + exprior;
     C.radius = st.radius; C.mu = st.mu; C.alpha = st.alpha; C.dogleg_norm = st.dogleg_norm; C.gmax = st.gmax; C.x_cost = st.x_cost;
@@ -640,7 +743,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       }
     }
   }
-  x.sync();
+  x.sync_lds();
   if (C.done) { if (x.tid == 0) { st.it = C.it; st.successful = C.successful; } return; }
   const int mode = C.mode;
   x.stamp(B.prof, 5);
@@ -650,7 +753,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     const double *src = reinterpret_cast<const double *>(&st.cand);
     double *dst = reinterpret_cast<double *>(&st.x);
     for (int k = x.tid; k < int(sizeof(DevParams) / sizeof(double)); k += x.nthr) dst[k] = src[k];
-    x.sync();
+    x.sync();   // (st.x is read back from global memory by other threads)
   }
   if (mode != DS_MODE_REJECT) {
     // gradient max-norm through the ambient Plus (TrustRegionMinimizer: || Plus(x, -g) - x ||_inf) and |x|
@@ -680,6 +783,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     double sv[1] = {sq};
     block_sum<X, 1>(x, L.red, sv);
     if (x.tid == 0) { C.gmax = gmax; C.x_norm = sqrt(sv[0]); }
+    x.stamp(B.prof, 22);
     // Jacobi scaling: fixed at the first linearisation (scale = 1 / (1 + sqrt(H_ii)))
     for (int i = x.tid; i < npad; i += x.nthr) {
       double sc = 1.0;
@@ -687,14 +791,25 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       L.scale[i] = sc;
       if (mode == DS_MODE_INIT && i < n) st.scale[i] = sc;
     }
-    x.sync();
-    for (int r = trow; r < n; r += rstep)
-      for (int c = tcol; c < n; c += CW) {
-        const double v = A[size_t(r) * ld + c] * (L.scale[r] * L.scale[c]);
-        A[size_t(r) * ld + c] = v;
-        B.Hcur[size_t(r) * ld + c] = v;
-        if (r == c) L.hdiag[r] = v;
+    x.sync_lds();
+    x.stamp(B.prof, 23);
+    for (int c = tcol; c < n; c += CW) {
+      const double sc_c = L.scale[c];
+      for (int r0 = trow; r0 < n; r0 += 8 * rstep) {   // eight entries in flight; only the upper triangle goes to global memory (ds_hsym reads nothing else)
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int r = r0 + q * rstep; v[q] = r < n ? A[size_t(r) * ld + c] * (L.scale[r] * sc_c) : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = r0 + q * rstep;
+          if (r < n) {
+            A[size_t(r) * ld + c] = v[q];
+            if (c >= r) B.Hcur[size_t(r) * ld + c] = v[q];
+            if (r == c) L.hdiag[r] = v[q];
+          }
+        }
       }
+    }
     for (int i = x.tid; i < npad; i += x.nthr) {
       const double gs = i < n ? L.gz[i] * L.scale[i] : 0.0;
       L.g[i] = gs;
@@ -709,7 +824,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       L.hdiag[i] = in ? B.Hcur[size_t(i) * ld + i] : 1.0;
     }
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(B.prof, 6);
   // ---- P7: the minimizer loop up to the next candidate (TrustRegionMinimizer::Minimize + DoglegStrategy::ComputeStep)
   for (int guard = 0; guard < 64; ++guard) {
@@ -719,17 +834,20 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       else if (C.radius <= 1e-32) { C.termination = 1; C.done = 1; }
       else ++C.it;
     }
-    x.sync();
+    x.sync_lds();
     if (C.done) break;
-    const double *Hm = C.a_valid ? A : B.Hcur;
+    bool h_in_lds = C.a_valid != 0;   // H of the current point: in LDS, or only in global memory (LDS holds a rejected candidate's)
     if (!C.reuse) {
       if (x.tid == 0) { C.reuse = 1; C.lin_ok = 0; }
-      if (!C.a_valid) {   // a linearisation is needed at the accepted point but LDS holds a rejected candidate: reload
+      if (!h_in_lds) {   // a linearisation is needed at the accepted point but LDS holds a rejected candidate: reload
         for (int r = trow; r < npad; r += rstep)
-          for (int c = tcol; c < npad; c += CW) A[size_t(r) * ld + c] = (r < n && c < n) ? B.Hcur[size_t(r) * ld + c] : (r == c ? 1.0 : 0.0);
+          for (int c = tcol; c < npad; c += CW) {
+            if (r < n && c < n) { if (c >= r) A[size_t(r) * ld + c] = B.Hcur[size_t(r) * ld + c]; }   // (the lower triangle is rebuilt from the upper before the factorisation)
+            else A[size_t(r) * ld + c] = (r == c) ? 1.0 : 0.0;
+          }
+        x.sync_lds();   // (every thread has read a_valid above before it changes)
         if (x.tid == 0) C.a_valid = 1;
-        x.sync();
-        Hm = A;
+        h_in_lds = true;
       }
       // diag, gradient in the scaled space, Cauchy step length alpha = |g|^2 / |J g|^2
       double gq[2] = {0.0, 0.0};
@@ -744,27 +862,32 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
         L.diag[i] = dg; L.grad[i] = gr; L.tmp[i] = tt;
       }
-      x.sync();
-      for (int i = x.tid; i < n; i += x.nthr) {
-        double sres = 0;
-        for (int j = 0; j < n; ++j) sres += ds_hsym(Hm, ld, L.hdiag, i, j) * L.tmp[j];
-        gq[1] += L.tmp[i] * sres;
-      }
+      x.sync_lds();
+      if (h_in_lds) ds_vHv(x, A, ld, L.hdiag, n, L.tmp, gq[1]); else ds_vHv(x, B.Hcur, ld, L.hdiag, n, L.tmp, gq[1]);   // (two calls: an LDS pointer and a global one, never a flat access)
       block_sum<X, 2>(x, L.red, gq);
       if (x.tid == 0) C.alpha = gq[0] / gq[1];
       x.stamp(B.prof, 7);
       // Gauss-Newton step of the regularised system; mu grows until the factorisation succeeds (DoglegStrategy::ComputeGaussNewtonStep)
       for (int attempt = 0; attempt < 12; ++attempt) {
-        x.sync();
+        x.sync_lds();
         if (!(C.mu < 1.0) || C.lin_ok) break;
         // lower triangle <- upper triangle, regularised diagonal, right-hand side
-        for (int r = trow; r < npad; r += rstep)
-          for (int c = tcol; c <= r; c += CW) {
-            if (c < r) A[size_t(r) * ld + c] = A[size_t(c) * ld + r];
-            else A[size_t(r) * ld + r] = (r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0;
+        for (int c = tcol; c < npad; c += CW)
+          for (int r0 = trow; r0 < npad; r0 += 8 * rstep) {   // eight LDS reads in flight, then the eight writes
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = r0 + q * rstep;
+              v[q] = (r < npad && c < r) ? A[size_t(c) * ld + r] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int r = r0 + q * rstep;
+              if (r < npad && c <= r) A[size_t(r) * ld + c] = (c < r) ? v[q] : ((r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0);
+            }
           }
         for (int i = x.tid; i < npad; i += x.nthr) L.gz[i] = L.g[i];
-        x.sync();
+        x.sync_lds();
         int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, &C.fact_ok, B.prof);
         x.stamp(B.prof, 21);
         int fin = 1;
@@ -775,7 +898,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
           if (ok && fv[0] == double(x.nthr)) C.lin_ok = 1; else C.mu *= 10.0;
         }
       }
-      x.sync();
+      x.sync_lds();
       x.stamp(B.prof, 8);
       if (C.lin_ok) {
         for (int i = x.tid; i < npad; i += x.nthr) {
@@ -784,9 +907,9 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
           if (i < n) st.gn[i] = v;
         }
       }
-      x.sync();
+      x.sync_lds();
     } else if (x.tid == 0) C.lin_ok = 1;
-    x.sync();
+    x.sync_lds();
     if (C.lin_ok) {
       double nq[3] = {0.0, 0.0, 0.0};
       for (int i = x.tid; i < n; i += x.nthr) { nq[0] += L.grad[i] * L.grad[i]; nq[1] += L.gn[i] * L.gn[i]; nq[2] += L.grad[i] * L.gn[i]; }
@@ -816,33 +939,31 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
         L.step[i] = sv;
       }
-      if (kind == 2) { block_sum<X, 1>(x, L.red, sn); dnorm = sqrt(sn[0]); } else x.sync();
+      if (kind == 2) { block_sum<X, 1>(x, L.red, sn); dnorm = sqrt(sn[0]); } else x.sync_lds();
       for (int i = x.tid; i < n; i += x.nthr) L.step[i] = L.step[i] / L.diag[i];
-      x.sync();
+      x.sync_lds();
       x.stamp(B.prof, 9);
       double mq[2] = {0.0, 0.0};
-      for (int i = x.tid; i < n; i += x.nthr) {
-        double sres = 0;
-        for (int j = 0; j < n; ++j) sres += ds_hsym(Hm, ld, L.hdiag, i, j) * L.step[j];
-        mq[1] += L.step[i] * sres; mq[0] += L.step[i] * L.g[i];
-      }
+      if (h_in_lds) ds_vHv(x, A, ld, L.hdiag, n, L.step, mq[1]); else ds_vHv(x, B.Hcur, ld, L.hdiag, n, L.step, mq[1]);
+      for (int i = x.tid; i < n; i += x.nthr) mq[0] += L.step[i] * L.g[i];
       block_sum<X, 2>(x, L.red, mq);
+      x.stamp(B.prof, 10);
       if (x.tid == 0) {
         C.dogleg_norm = dnorm;
         C.model_change = -(mq[0] + 0.5 * mq[1]);
         C.valid_step = (C.model_change > 0) ? 1 : 0;
       }
     } else if (x.tid == 0) C.valid_step = 0;
-    x.sync();
+    x.sync_lds();
     if (C.valid_step) break;
     if (x.tid == 0) {
       if (++C.invalid >= 5) { C.termination = 5; C.done = 1; }
       else { C.mu *= 10.0; C.reuse = 0; if (st.ntrace < 40) st.trace[st.ntrace++] = C.x_cost; }
     }
-    x.sync();
+    x.sync_lds();
     if (C.done) break;
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(B.prof, 12);
   // ---- P8: write the candidate (Plus), its ambient step norm and the relative lidar poses launch A will read
   if (!C.done) {
@@ -867,7 +988,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         }
       }
     }
-    x.sync();
+    x.sync();   // (st.cand is read back from global memory by other threads)
     double sq[1] = {0.0};
     for (int t = x.tid; t < (Wo + 1) * 16 + 7; t += x.nthr) {
       double d = 0;
@@ -879,7 +1000,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     for (int i = x.tid; i < Wo; i += x.nthr) relative_lidar_pose(st.cand.pose[0], st.cand.pose[i + 1], st.cand.ex, st.cand_Rt[i], st.cand_Rt[i] + 9);
     if (x.tid == 0) { C.step_norm = sqrt(sq[0]); C.invalid = 0; }
   }
-  x.sync();
+  x.sync_lds();
   x.stamp(B.prof, 13);
   if (x.tid == 0) {
     st.radius = C.radius; st.mu = C.mu; st.alpha = C.alpha; st.dogleg_norm = C.dogleg_norm; st.gmax = C.gmax; st.x_cost = C.x_cost;

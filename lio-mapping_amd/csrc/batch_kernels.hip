@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *_
     for (int k = 1; k < W.nseg; ++k)
       if (gid >= W.seg[k].dst_off) sidx = k;
     const BwSeg &sg = W.seg[sidx];
-    const float4 p = sg.src[gid - sg.dst_off];
+    const float4 p = rebase(local_all, sg.src)[gid - sg.dst_off];
     float4 o;
     if (sg.identity) {
       o = p;
@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(64 * LPQ) k_bw_features(const BatchWin *__rest
   if (int(blockIdx.y) >= W.nstatic) return;
   const BatchGrid &G = grid[w];
   const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
-  features_block<false, LPQ, 64 * LPQ>(W.fr[blockIdx.y], fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
+  FeatFrame frm = W.fr[blockIdx.y];
+  frm.stack = rebase(sorted_all, frm.stack);   // (dev.h: a pointer read from a descriptor is generic until it is tied to a kernel argument)
+  features_block<false, LPQ, 64 * LPQ>(frm, fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
                                        nullptr);
 }
 int bw_lanes_per_query(long long total_queries) {
@@ -347,7 +349,9 @@ __global__ void __launch_bounds__(64 * LPQ) k_bw_odom_round(const BatchWin *__re
   const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   const Vec3<float> t(tp[4], tp[5], tp[6]);
   const FeatScalars fs{W.min_match_sq_dis, W.min_plane_dis, 0, {0.f, 0.f, 0.f}};
-  const double v = odom_round_block<LPQ, 64 * LPQ>(fs, W.newest, q, t, sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all, W.newest.slot_off,
+  FeatFrame frm = W.newest;
+  frm.stack = rebase(sorted_all, frm.stack);
+  const double v = odom_round_block<LPQ, 64 * LPQ>(fs, frm, q, t, sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all, W.newest.slot_off,
                                                    round, W.keep, int(blockIdx.x));
   if (threadIdx.x < 28) partials[(size_t(W.part_off) + blockIdx.x) * 28 + threadIdx.x] = v;
 }

@@ -843,14 +843,15 @@ __device__ __forceinline__ void kf_round_body(const KfDesc *__restrict__ kd, con
   if (blockIdx.y == 0) {
     if (int(blockIdx.x) * 128 >= d.Mc * LPQ) return;
     const KfMapDesc &m = md[d.map];
-    line_features_body<LPQ>(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis, m.corner_sorted,
-                       m.corner_cells, m.corner_grid, valid, coef);
+    // (the maps' pointers come from a descriptor: tied to a kernel argument they are global to the compiler, dev.h: rebase)
+    line_features_body<LPQ>(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis,
+                       rebase(stack_all, m.corner_sorted), rebase(stack_all, m.corner_cells), m.corner_grid, valid, coef);
   } else {
     if (int(blockIdx.x) * 128 >= d.Ms * LPQ) return;
     const KfMapDesc &m = md[d.map];
     const FeatFrame fr{stack_all + d.slot_off + d.Mc, d.Ms, d.slot_off + d.Mc, 0};
     const FeatScalars fs{min_match_sq_dis, min_plane_dis, mapping_mode, {d.pz[0], d.pz[1], d.pz[2]}};
-    features_body<true, LPQ>(fr, fs, blockIdx.x, tp, m.surf_sorted, m.surf_cells, m.surf_grid, valid, coef, nullptr, nullptr);
+    features_body<true, LPQ>(fr, fs, blockIdx.x, tp, rebase(stack_all, m.surf_sorted), rebase(stack_all, m.surf_cells), m.surf_grid, valid, coef, nullptr, nullptr);
   }
 }
 

@@ -1,6 +1,7 @@
 // dev.h — HIP runtime plumbing for the product: error propagation, growable device buffers, timers.
 // No CPU fallback anywhere: a failed HIP call surfaces as LIO_ERR_DEVICE through the C-ABI.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -10,6 +11,23 @@
 #include <vector>
 
 namespace lio {
+
+// A pointer READ FROM MEMORY (a field of a descriptor in device memory) is generic to the compiler: every access through it becomes a
+// FLAT instruction, which counts in lgkmcnt as well as vmcnt — so each wait for an LDS operation also waits for every such load in
+// flight, and a phase that mixes LDS work with descriptor-addressed global loads runs one memory round trip at a time (the prior pass
+// of the batched step kernel: 28 k clocks for 36 loads per thread, profiles/r5_i_*).  Neither an assumption (is_shared / is_private
+// false) nor a cast through address space 1 and back survives to the pass that decides; what does is arithmetic on a pointer that
+// arrived as a KERNEL ARGUMENT (those are global): base + (p - base), with `base` the start of the allocation p points into.
+#if defined(__HIPCC__)
+template <class T, class U>
+__device__ __forceinline__ U *rebase(T *base, U *p) {
+  // (null stays null explicitly: base + offset is never null to the compiler, which would drop the callers' null checks)
+  if (!p) return nullptr;
+  return reinterpret_cast<U *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(base)) +
+                               (reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(base)));
+}
+#endif
+
 
 struct DeviceError : std::runtime_error {
   using std::runtime_error::runtime_error;

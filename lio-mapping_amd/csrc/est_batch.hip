@@ -328,6 +328,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     const int G = g_env ? std::min(g_env, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
     // LIO_BW_AUX_STREAM=1: the aux row on a side stream beside the moments.  Measured slower on the MI355X (two events per iteration cost
     // more than the 41 us they hide: loop 2.92 ms against 2.68 at 64 windows, profiles/r5_e_aux_stream_ab_and_step_phases.txt): off.
+    const BatchBases bases{slab_.p, partials_.p, d_st_.p, d_pb_.p, d_mg_.p};
     static const int aux_env = [] { const char *e = std::getenv("LIO_BW_AUX_STREAM"); return e ? std::atoi(e) : 0; }();
     const bool side_aux = aux_env != 0;
     static const int prof_it = [] { const char *e = std::getenv("LIO_DEBUG_TIMING_IT"); return e ? std::atoi(e) : 3; }();
@@ -348,14 +349,14 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
           const BatchSolve *gb = d_bs_.p + w0;
           if (side_aux) {   // aux row beside the moments; the step kernel joins the two
             LIO_HIP(hipStreamWaitEvent(sa, k == 0 ? ev_fork_ : ev_step_[g], 0));
-            launch_bw_aux(gb, w1 - w0, g_wo, sa);
+            launch_bw_aux(gb, bases, w1 - w0, g_wo, sa);
             LIO_HIP(hipEventRecord(ev_aux_[g], sa));
-            launch_bw_moments(gb, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
+            launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
             LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
-            launch_bw_step(gb, w1 - w0, g_wo, g_npad, sg);
+            launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
             if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
           } else {
-            launch_bw_solve_iteration(gb, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
+            launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
           }
           if (h_bs_[0].prof && w0 == 0 && k == prof_it)   // LIO_DEBUG_TIMING: keep the stamps of this iteration's launch B beside the last one's
             LIO_HIP(hipMemcpyAsync(h_bs_[0].prof + 32, h_bs_[0].prof, 32 * sizeof(long long), hipMemcpyDeviceToDevice, sg));
@@ -410,7 +411,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   if (n_marg > 0) {
     // (the host has waited for the loop; the marginalization's inputs — final moments, states, problems — are complete)
     LIO_HIP(hipMemcpyAsync(d_mg_.p, h_mg_, sizeof(DevMarg) * B, hipMemcpyHostToDevice, stream_marg_));
-    launch_bw_marginalize(d_bs_.p, B, max_wo, max_n, stream_marg_);
+    launch_bw_marginalize(d_bs_.p, BatchBases{slab_.p, partials_.p, d_st_.p, d_pb_.p, d_mg_.p}, B, max_wo, max_n, stream_marg_);
     LIO_HIP(hipEventRecord(ev_marg_, stream_marg_));
     marg_in_flight_ = true;
   }

@@ -250,41 +250,43 @@ static size_t marg_lds_bytes(int n) { return marg_lds_doubles(n) * sizeof(double
 //                               WindowSystem::evaluate, then the dense tail above, then J^T J and J^T r of the new prior — which
 //                               stays on the device as the next solve's prior_mats.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_aux(const BatchSolve *__restrict__ bs) {
+__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_aux(const BatchSolve *__restrict__ bs, BatchBases bb) {
   const BatchSolve &S = bs[blockIdx.y];
-  const DevMarg *mg = S.marg;
+  const DevMarg *mg = S.marg ? rebase(bb.mg, S.marg) : nullptr;
   if (!mg || !mg->active) return;
-  __shared__ double aux_lds[1024];
+  __shared__ double aux_lds[1536];
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int Wo = mg->Wo, i = blockIdx.x;
   const DevParams &P = mg->x;
   if (i < Wo) {
-    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.marg_lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, rebase(bb.slab, S.marg_lmap) + size_t(i) * DS_LMAP_OUT, aux_lds);
   } else if (i == Wo) {
-    if (mg->has_imu) aux_imu(x, S.pb->pim[0], P.pose[0], P.sb[0], P.pose[1], P.sb[1], S.marg_imu, aux_lds);
-    else for (int k = threadIdx.x; k < DS_IMU_OUT; k += blockDim.x) S.marg_imu[k] = 0.0;
+    double *marg_imu = rebase(bb.slab, S.marg_imu);
+    if (mg->has_imu) aux_imu(x, rebase(bb.pb, S.pb)->pim[0], P.pose[0], P.sb[0], P.pose[1], P.sb[1], marg_imu, aux_lds);
+    else for (int k = threadIdx.x; k < DS_IMU_OUT; k += blockDim.x) marg_imu[k] = 0.0;
   } else if (i == Wo + 1) {
-    if (mg->have_prior) aux_prior(x, *S.pb, S.prior_mats, P, S.marg_prior_out, aux_lds);
+    if (mg->have_prior) aux_prior(x, *rebase(bb.pb, S.pb), rebase(bb.slab, S.prior_mats), P, rebase(bb.slab, S.marg_prior_out), aux_lds);
   }
 }
 
-__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve *__restrict__ bs, double eps) {
+__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve *__restrict__ bs, BatchBases bb, double eps) {
   extern __shared__ double lds[];
   const BatchSolve &S = bs[blockIdx.x];
-  const DevMarg *mgp = S.marg;
+  const DevMarg *mgp = S.marg ? rebase(bb.mg, S.marg) : nullptr;
   if (!mgp || !mgp->active) return;
   const DevMarg &mg = *mgp;
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int Wo = mg.Wo, m = mg.m, n = mg.n, N = m + n;
-  const DevState &st = *S.st;
-  const double *Sm = S.S_buf + size_t(st.s_cur) * Wo * LIO_MOMENT_OUT;   // the moments at the point the solver stopped at
+  const DevState &st = *rebase(bb.st, S.st);
+  const double *Sm = rebase(bb.slab, S.S_buf) + size_t(st.s_cur) * Wo * LIO_MOMENT_OUT;   // the moments at the point the solver stopped at
   // ---- frame blocks (LDS: zb Wo x 344, LS Wo x 234)
   double *zb = lds, *LS = lds + size_t(Wo) * 344;
-  ds_lidar_blocks(x, Wo, S.marg_lmap, Sm, LS, zb);
+  const double *marg_imu = rebase(bb.slab, S.marg_imu), *marg_prior_out = rebase(bb.slab, S.marg_prior_out);
+  ds_lidar_blocks(x, Wo, rebase(bb.slab, S.marg_lmap), Sm, LS, zb);
   // ---- A, b: prior, ImuFactor 0, lidar frames 1 .. Wo — one thread per entry, the contributions in that order
-  const int np = S.pb->n_prior;
-  const double *JtJ = S.prior_mats;
-  double *A = S.marg_A, *bv = S.marg_A + size_t(N) * N;
+  const int np = rebase(bb.pb, S.pb)->n_prior;
+  const double *JtJ = rebase(bb.slab, S.prior_mats);
+  double *A = rebase(bb.slab, S.marg_A), *bv = A + size_t(N) * N;
   const int c_p0 = mg.pose_col[0], c_ex = mg.ex_col;
   for (int e = x.tid; e < N * (N + 1); e += x.nthr) {
     const int r = e / (N + 1), cc = e % (N + 1);
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
     const int c = is_g ? 0 : cc;
     double v = 0.0;
     if (mg.have_prior && mg.prior_col[r] >= 0) {
-      if (is_g) v += S.marg_prior_out[mg.prior_col[r]];
+      if (is_g) v += marg_prior_out[mg.prior_col[r]];
       else if (mg.prior_col[c] >= 0) v += JtJ[size_t(mg.prior_col[r]) * np + mg.prior_col[c]];
     }
     // ImuFactor 0 spans [pose 0 | sb 0 | pose 1 | sb 1]: local index of a column (-1: not in the factor)
@@ -303,11 +305,11 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
       if (mg.sb_col[1] >= 0 && col >= mg.sb_col[1] && col < mg.sb_col[1] + 9) return 21 + col - mg.sb_col[1];
       return -1;
     };
-    if (mg.has_imu && S.marg_imu[931] != 0.0) {
+    if (mg.has_imu && marg_imu[931] != 0.0) {
       const int lr = imu_local(r);
       if (lr >= 0) {
-        if (is_g) v += S.marg_imu[900 + lr];
-        else { const int lc = imu_local(c); if (lc >= 0) v += S.marg_imu[lr * 30 + lc]; }
+        if (is_g) v += marg_imu[900 + lr];
+        else { const int lc = imu_local(c); if (lc >= 0) v += marg_imu[lr * 30 + lc]; }
       }
     }
     // lidar frame i touches (pose 0, pose i, extrinsic): local rows 0..5, 6..11, 12..17
@@ -332,9 +334,9 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
   }
   __syncthreads();   // (global writes of this block are visible to it behind the barrier)
   // ---- dense tail: the new prior's square-root factors go straight into the next solve's prior_mats
-  double *out = S.next_prior_mats;
+  double *out = rebase(bb.slab, S.next_prior_mats);
   double *o_JtJ = out, *o_jac = out + size_t(n) * n, *o_res = o_jac + size_t(n) * n, *o_Jtr = o_res + n;
-  marg_schur_body(A, bv, m, n, eps, o_jac, o_res, S.marg_info + 2, S.marg_info, lds);
+  marg_schur_body(A, bv, m, n, eps, o_jac, o_res, rebase(bb.slab, S.marg_info) + 2, rebase(bb.slab, S.marg_info), lds);
   __syncthreads();
   // J^T J and J^T r of the new prior (MargPrior::finalize): ascending k
   for (int e = x.tid; e < n * (n + 1); e += x.nthr) {
@@ -345,16 +347,16 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
   }
 }
 
-void launch_bw_marginalize(const BatchSolve *bs, int B, int max_wo, int max_n, hipStream_t s) {
+void launch_bw_marginalize(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_n, hipStream_t s) {
   if (B <= 0) return;
   static const bool attr_set = [] {
     LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, int(marg_lds_bytes(MARG_MAX_N))));
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_THREADS), 0, s, bs);
+  hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_THREADS), 0, s, bs, bb);
   const size_t lds = std::max(marg_lds_doubles(max_n), size_t(max_wo) * (344 + 234)) * sizeof(double);
-  hipLaunchKernelGGL(k_bw_marg_schur, dim3(B), dim3(MARG_THREADS), lds, s, bs, 1e-8);
+  hipLaunchKernelGGL(k_bw_marg_schur, dim3(B), dim3(MARG_THREADS), lds, s, bs, bb, 1e-8);
   LIO_HIP(hipGetLastError());
 }
 

@@ -65,17 +65,17 @@ struct DevExec {
   // L D L^T of the 16x16 diagonal block at p by ONE wave: lane r (mod 16) keeps row r in registers; per pivot the block's column j
   // goes through 16 doubles of LDS and comes back to every lane as broadcast reads (the first form moved it with 2 x 15 v_readlane
   // per pivot: 10.6 us per block, profiles/r5_c_step_phases.txt).  Then X = L11^-1 (lane c: column c by forward substitution, L11
-  // read back from the block as broadcast LDS reads) is left row-major in scr[64 .. 320): the rows below the block are solved
-  // against it on the matrix cores (panel_trsm_mfma).  scr: >= DS_PART = 576 doubles of LDS (exchange 64 | X 256 | staging 256).
+  // read back from the block as broadcast LDS reads) is left row-major in Xs (one 256-double slot per panel: the back-substitution uses it again): the rows below the block are solved
+  // against it on the matrix cores (panel_trsm_mfma).  scr: >= 320 doubles of LDS (exchange 64 | staging 256).
   __device__ __forceinline__ void wave_lds_sync() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd, double *scr) const {
+  __device__ __forceinline__ int panel_factor_regs(double *A, int ld, int p, double *invd, double *scr, double *Xs) const {
     const int r = lane & 15;
     double a[DS_NB];
-    const double *row = A + size_t(p + r) * ld + p;
+    const double *row = A + (p + r) * ld + p;
 #pragma unroll
     for (int c = 0; c < DS_NB; ++c) a[c] = row[c];
     int ok = 1;
@@ -101,7 +101,7 @@ struct DevExec {
     }
     // the factored rows go to a dense 16 x 16 staging block (unconditional wide stores); from there the lower triangle is copied into
     // A by all 64 lanes (A's strict upper triangle must survive) and the inverse reads L11 with a leading dimension of 16
-    double *Ls = scr + 4 * DS_NB + DS_NB * DS_NB;
+    double *Ls = scr + 4 * DS_NB;
     if (lane < DS_NB) {
 #pragma unroll
       for (int c = 0; c < DS_NB; ++c) Ls[r * DS_NB + c] = a[c];
@@ -111,7 +111,7 @@ struct DevExec {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = lane + 64 * q, rr = e >> 4, cc = e & 15;
-      if (cc <= rr) A[size_t(p + rr) * ld + p + cc] = Ls[e];
+      if (cc <= rr) A[(p + rr) * ld + p + cc] = Ls[e];
     }
     // X = L11^-1 by forward substitution, FOUR lanes per column (column c = lane >> 2; lane part g = lane & 3 sums the terms
     // k = g, g + 4, ...; the four partial sums meet through two quad permutes): 30 multiply-adds per lane instead of 120
@@ -137,7 +137,6 @@ struct DevExec {
         acc = pair_sum4(acc);
         xcol[rr] = (rr > c) ? -acc : xcol[rr];
       }
-      double *Xs = scr + 4 * DS_NB;
       if (g == 0) {
 #pragma unroll
         for (int rr = 0; rr < DS_NB; ++rr) Xs[rr * DS_NB + c] = xcol[rr];
@@ -149,10 +148,9 @@ struct DevExec {
   // rows below the block: L21 = (A21 L11^-T) D^-1 on the fp64 matrix cores, one 16-row tile per wave at a time; the right-hand
   // side (one more row) by the wave after the last tile.  v_mfma_f64_16x16x4: lane l supplies A[i = l & 15][k = l >> 4] and
   // B[k = l >> 4][j = l & 15]; D row = (l >> 4) + 4 reg, col = l & 15.
-  __device__ __forceinline__ void panel_trsm_mfma(double *A, int ld, int npad, int p, double *gz, const double *invd, const double *scr) const {
+  __device__ __forceinline__ void panel_trsm_mfma(double *A, int ld, int npad, int p, double *gz, const double *invd, const double *Xs) const {
     const int q0 = p + DS_NB, nt = (npad - q0) / DS_NB;
     const int i = lane & 15, kq = lane >> 4;
-    const double *Xs = scr + 4 * DS_NB;
     for (int t = wave; t <= nt; t += nwave) {
       if (t == nt) {
         double z = 0.0;
@@ -167,14 +165,14 @@ struct DevExec {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int k = 4 * kk + kq;
-        const double aop = A[size_t(rb + i) * ld + p + k];
+        const double aop = A[(rb + i) * ld + p + k];
         const double bop = Xs[i * DS_NB + k];   // B[k][j = i] = X[j][k]
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
       }
       wave_lds_sync();   // (the tile's inputs have been read: they are overwritten below)
       const double dinv = invd[p + i];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) A[size_t(rb + kq + 4 * rr) * ld + p + i] = acc[rr] * dinv;
+      for (int rr = 0; rr < 4; ++rr) A[(rb + kq + 4 * rr) * ld + p + i] = acc[rr] * dinv;
     }
   }
 
@@ -185,7 +183,7 @@ struct DevExec {
     const int i = lane & 15, kq = lane >> 4;
     double dk[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) dk[kk] = A[size_t(p + 4 * kk + kq) * ld + p + 4 * kk + kq];
+    for (int kk = 0; kk < 4; ++kk) dk[kk] = A[(p + 4 * kk + kq) * ld + p + 4 * kk + kq];
     int t = 0;
     for (int I = 0; I < nb; ++I)
       for (int J = 0; J <= I; ++J, ++t) {
@@ -193,37 +191,38 @@ struct DevExec {
         const int rb = q0 + DS_NB * I, cb = q0 + DS_NB * J;
         v4f64 acc;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = A[size_t(rb + kq + 4 * rr) * ld + cb + i];
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = A[(rb + kq + 4 * rr) * ld + cb + i];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int k = 4 * kk + kq;
-          const double aop = -A[size_t(rb + i) * ld + p + k];
-          const double bop = A[size_t(cb + i) * ld + p + k] * dk[kk];
+          const double aop = -A[(rb + i) * ld + p + k];
+          const double bop = A[(cb + i) * ld + p + k] * dk[kk];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = kq + 4 * rr;
-          if (I != J || row >= i) A[size_t(rb + row) * ld + cb + i] = acc[rr];   // a diagonal tile keeps its strict upper triangle
+          if (I != J || row >= i) A[(rb + row) * ld + cb + i] = acc[rr];   // a diagonal tile keeps its strict upper triangle
         }
       }
   }
 
-  // x_blk of L^T x = z for the 16 unknowns at p: lane j keeps y_j and column j of the unit-lower block
-  __device__ __forceinline__ void panel_backsolve_regs(double *A, int ld, int p, double *gz, const double *part) const {
+  // x_blk of L11^T x = y for the 16 unknowns at p, y = z - (the rows below): with X = L11^-1 kept from the factorisation x = X^T y is
+  // one LDS exchange and sixteen multiply-adds (the substitution it replaces was a chain of fifteen broadcast + multiply-add steps:
+  // 1.4 k clocks per block).  Lane j: y_j from the 32 slices (four interleaved sums), then column j of X against y.
+  __device__ __forceinline__ void panel_backsolve_regs(double *A, int ld, int p, double *gz, double *part, const double *Xs) const {
     const int j = lane & 15;
-    double s2 = 0.0;
-    for (int sl = 0; sl < 32; ++sl) s2 += part[sl * 16 + j];
-    double y = gz[p + j] - s2;
-    double col[DS_NB];
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < DS_NB; ++k) col[k] = (k > j) ? A[size_t(p + k) * ld + p + j] : 0.0;
+    for (int sl = 0; sl < 32; ++sl) s4[sl & 3] += part[sl * 16 + j];
+    const double y = gz[p + j] - ((s4[0] + s4[1]) + (s4[2] + s4[3]));
+    wave_lds_sync();   // (every lane has read the slices before the first sixteen words are reused)
+    if (lane < DS_NB) part[j] = y;
+    wave_lds_sync();
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = DS_NB - 1; k >= 1; --k) {
-      const double yk = ds_bcast_lane(y, k);
-      y = __builtin_fma(-col[k], yk, y);
-    }
-    if (lane < DS_NB) gz[p + j] = y;
+    for (int k = 0; k < DS_NB; ++k) a4[k & 3] = __builtin_fma(Xs[k * DS_NB + j], part[k], a4[k & 3]);   // X is lower triangular with zeros above
+    if (lane < DS_NB) gz[p + j] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
 };
 

@@ -80,11 +80,12 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
 // One iteration of the device-resident dogleg (solve_step.h) for every window of a batch: launch A (moments at the candidate + aux
 // row) and launch B (one workgroup per window), both on `s`, no host interaction.  BatchSolve is declared in solve_step.h.
 struct BatchSolve;
+struct BatchBases;
 // the three launches of an iteration one by one (the aux row depends on the candidate only: it can run beside the moments on a stream of its own)
-void launch_bw_aux(const BatchSolve *bs, int B, int max_wo, hipStream_t s);
-void launch_bw_moments(const BatchSolve *bs, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s);
-void launch_bw_step(const BatchSolve *bs, int B, int max_wo, int max_npad, hipStream_t s);
-void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s);
+void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, hipStream_t s);
+void launch_bw_moments(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s);
+void launch_bw_step(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_npad, hipStream_t s);
+void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s);
 // blocks per frame of a window's moments pass inside a batch: a function of the window's own slot counts only
 int batch_blocks_per_frame(int max_slots);
 

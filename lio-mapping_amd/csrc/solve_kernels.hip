@@ -756,53 +756,55 @@ void launch_lidar_moments(const MomentArgs &a, const uint8_t *valid, const float
 //   k_bw_moments   grid (bpf, Wo, windows): the moments of frames 1 .. Wo at the candidate's T_{pivot<-i}, read from the
 //                  device-resident state.
 // A window that is done (converged, or handed back to the host) costs its blocks one load.
-__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_moments(const BatchSolve *__restrict__ bs, const uint8_t *__restrict__ valid,
+__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_moments(const BatchSolve *__restrict__ bs, BatchBases bb, const uint8_t *__restrict__ valid,
                                                                const float4 *__restrict__ coef) {
   const BatchSolve &S = bs[blockIdx.z];
-  const DevState *st = S.st;
+  const DevState *st = rebase(bb.st, S.st);
   if (!S.active || st->done) return;
   if (int(blockIdx.y) >= S.nframes || int(blockIdx.x) >= S.bpf) return;
   MomentFrame fr = S.fr[blockIdx.y];
+  fr.stack = rebase(coef, fr.stack);
   const double *Rt = st->cand_Rt[blockIdx.y];
 #pragma unroll
   for (int k = 0; k < 9; ++k) fr.R[k] = Rt[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) fr.t[k] = Rt[9 + k];
-  lidar_moments_body(fr, valid, coef, S.partials, S.bpf);
+  lidar_moments_body(fr, valid, coef, rebase(bb.partials, S.partials), S.bpf);
 }
-__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_aux(const BatchSolve *__restrict__ bs) {
+__global__ void __launch_bounds__(MOMENT_THREADS) k_bw_aux(const BatchSolve *__restrict__ bs, BatchBases bb) {
   const BatchSolve &S = bs[blockIdx.y];
-  const DevState *st = S.st;
+  const DevState *st = rebase(bb.st, S.st);
   if (!S.active || st->done) return;
   const int Wo = S.nframes, i = blockIdx.x;
   if (i > Wo) return;
-  __shared__ double aux_lds[1024];
+  __shared__ double aux_lds[1536];
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const DevParams &P = st->cand;
-  const DevProblem *pb = S.pb;
+  const DevProblem *pb = rebase(bb.pb, S.pb);
   if (i < Wo) {
-    long long *prof = i == 0 ? S.prof : nullptr;
+    long long *prof = i == 0 ? rebase(bb.slab, S.prof) : nullptr;
     x.stamp(prof, 64);
-    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], S.imu_out + size_t(i) * DS_IMU_OUT, aux_lds, prof);
+    aux_imu(x, pb->pim[i], P.pose[i], P.sb[i], P.pose[i + 1], P.sb[i + 1], rebase(bb.slab, S.imu_out) + size_t(i) * DS_IMU_OUT, aux_lds, prof);
     __syncthreads();
     x.stamp(prof, 67);
-    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, S.lmap + size_t(i) * DS_LMAP_OUT, aux_lds);
+    aux_lmap(x, P.pose[0], P.pose[i + 1], P.ex, rebase(bb.slab, S.lmap) + size_t(i) * DS_LMAP_OUT, aux_lds);
     __syncthreads();
     x.stamp(prof, 68);
   } else {
-    if (pb->have_prior) aux_prior(x, *pb, S.prior_mats, P, S.prior_out, aux_lds);
-    if (pb->use_ex_prior) aux_exprior(x, *pb, P, S.exprior_out);
+    if (pb->have_prior) aux_prior(x, *pb, rebase(bb.slab, S.prior_mats), P, rebase(bb.slab, S.prior_out), aux_lds);
+    if (pb->use_ex_prior) aux_exprior(x, *pb, P, rebase(bb.slab, S.exprior_out));
   }
 }
 
 // Launch B: one workgroup per window (solve_step.h)
-__global__ void __launch_bounds__(DS_THREADS) k_bw_solve_step(const BatchSolve *__restrict__ bs) {
+__global__ void __launch_bounds__(DS_THREADS) k_bw_solve_step(const BatchSolve *__restrict__ bs, BatchBases bb) {
   extern __shared__ __attribute__((aligned(16))) double ds_lds[];
   const BatchSolve &S = bs[blockIdx.x];
   if (!S.active) return;
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
-  StepBuffers B{S.prior_mats, S.partials, S.imu_out, S.lmap, S.prior_out, S.exprior_out, S.Hcur, S.S_buf, S.prof};
-  solve_step(x, *S.pb, *S.st, B, ds_lds);
+  StepBuffers B{rebase(bb.slab, S.prior_mats), rebase(bb.partials, S.partials), rebase(bb.slab, S.imu_out), rebase(bb.slab, S.lmap), rebase(bb.slab, S.prior_out), rebase(bb.slab, S.exprior_out),
+                rebase(bb.slab, S.Hcur), rebase(bb.slab, S.S_buf), rebase(bb.slab, S.prof)};
+  solve_step(x, *rebase(bb.pb, S.pb), *rebase(bb.st, S.st), B, ds_lds);
 }
 
 // Test hook (lio_ldlt_solve): the LDS-resident blocked L D L^T + back-substitution of launch B on its own
@@ -812,14 +814,15 @@ __global__ void __launch_bounds__(DS_THREADS) k_ldlt_test(const double *__restri
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int ld = npad + 1;
   double *A = ds_lds, *gz = A + size_t(npad) * ld, *invd = gz + npad, *part = invd + npad;
-  int *flag = reinterpret_cast<int *>(part + DS_PART);
+  double *xinv = part + DS_PART;
+  int *flag = reinterpret_cast<int *>(xinv + size_t(npad) * DS_NB);
   for (int e = x.tid; e < npad * npad; e += x.nthr) {
     const int r = e / npad, c = e % npad;
     A[size_t(r) * ld + c] = (r < n && c < n) ? Ain[size_t(r) * n + c] : (r == c ? 1.0 : 0.0);
   }
   for (int i = x.tid; i < npad; i += x.nthr) gz[i] = i < n ? b[i] : 0.0;
   x.sync();
-  const int ok = ds_ldlt_solve(x, A, ld, npad, gz, invd, part, flag);
+  const int ok = ds_ldlt_solve(x, A, ld, npad, gz, invd, part, xinv, flag);
   if (x.tid == 0) *ok_out = ok;
   if (ok) for (int i = x.tid; i < n; i += x.nthr) xout[i] = gz[i];
   // the strict upper triangle must have survived (launch B reads H from it after the factorisation)
@@ -827,7 +830,7 @@ __global__ void __launch_bounds__(DS_THREADS) k_ldlt_test(const double *__restri
 }
 int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipStream_t s) {
   const int npad = (n + DS_NB - 1) / DS_NB * DS_NB;
-  const size_t lds = (size_t(npad) * (npad + 1) + 2 * size_t(npad) + DS_PART + 8) * sizeof(double);
+  const size_t lds = (size_t(npad) * (npad + 1) + 2 * size_t(npad) + DS_PART + size_t(npad) * DS_NB + 8) * sizeof(double);
   if (n < 1 || lds > 160 * 1024) return -2;
   static const bool attr_set = [] {
     LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ldlt_test), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -847,15 +850,15 @@ int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipSt
   return ok;
 }
 
-void launch_bw_aux(const BatchSolve *bs, int B, int max_wo, hipStream_t s) {
+void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs);
+  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs, bb);
 }
-void launch_bw_moments(const BatchSolve *bs, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s) {
+void launch_bw_moments(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, valid, coef);
+  hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, bb, valid, coef);
 }
-void launch_bw_step(const BatchSolve *bs, int B, int max_wo, int max_npad, hipStream_t s) {
+void launch_bw_step(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_npad, hipStream_t s) {
   if (B <= 0) return;
   static const bool attr_set = [] {
     LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -863,13 +866,14 @@ void launch_bw_step(const BatchSolve *bs, int B, int max_wo, int max_npad, hipSt
   }();
   (void)attr_set;
   const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);
-  hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs);
+  hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs, bb);
   LIO_HIP(hipGetLastError());
 }
-void launch_bw_solve_iteration(const BatchSolve *bs, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s) {
-  launch_bw_aux(bs, B, max_wo, s);
-  launch_bw_moments(bs, B, max_bpf, max_wo, valid, coef, s);
-  launch_bw_step(bs, B, max_wo, max_npad, s);
+void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef,
+                               hipStream_t s) {
+  launch_bw_aux(bs, bb, B, max_wo, s);
+  launch_bw_moments(bs, bb, B, max_bpf, max_wo, valid, coef, s);
+  launch_bw_step(bs, bb, B, max_wo, max_npad, s);
 }
 
 }  // namespace lio

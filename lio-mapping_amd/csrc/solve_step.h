@@ -31,7 +31,7 @@ namespace lio {
 #define DS_MAX_WO 7
 #define DS_MAX_NPAD 128      // padded tangent dimension the LDS-resident factorisation takes (15 (Wo + 1) + 6, rounded up to 16)
 #define DS_NB 16
-#define DS_PART 576    // doubles of the factorisation's scratch: pivot exchange 64 | L11^-1 256 | staging block 256 (>= the 32 x 16 slices of the back-substitution)
+#define DS_PART 512    // doubles of the factorisation's scratch: pivot exchange 64 | staging block 256; the 32 x 16 slices of the back-substitution
 #ifndef DS_THREADS
 #define DS_THREADS 256     // threads of the step kernel's workgroup: one wave per SIMD, 512 registers per lane (at 512 threads the kernel spilled 230 VGPRs to scratch: 118 -> 153 us per step, profiles/r5_g_*; tools/r5/build_variant.sh builds the other form)
 #endif
@@ -79,7 +79,7 @@ struct DevState {
 LIO_HD size_t ds_prior_mats_size(int np) { return size_t(2) * np * np + 2 * np; }
 // LDS doubles the step kernel needs for (n_pad, Wo)
 LIO_HD size_t ds_lds_doubles(int n_pad, int Wo) {
-  return size_t(n_pad) * (n_pad + 1) + 10 * size_t(n_pad) + size_t(Wo) * 344 + DS_PART + 64 + 32;
+  return size_t(n_pad) * (n_pad + 1) + 10 * size_t(n_pad) + size_t(Wo) * 344 + DS_PART + size_t(n_pad) * DS_NB + 64 + 32;   // (n_pad * 16: L11^-1 of every panel)
 }
 
 // ------------------------------------------------------------------------------------------------ executors
@@ -122,7 +122,7 @@ LIO_HD double block_max(const X &x, double *red, double v) {
 
 // ------------------------------------------------------------------------------------------------ aux row of launch A
 // ImuFactor i at (pose_i, sb_i, pose_j, sb_j): whitened J (15 x 30, tangent columns [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]),
-// J^T J, J^T r, 0.5 |r|^2  -> out[DS_IMU_OUT].  lds: >= 15*30*2 + 32 doubles.  The summation orders are those of
+// J^T J, J^T r, 0.5 |r|^2  -> out[DS_IMU_OUT].  lds: >= 15*30*2 + 32 + 4*136 = 1476 doubles.  The summation orders are those of
 // WindowSystem::evaluate (host_solver.h) so both paths produce the same blocks.
 template <class X>
 LIO_HD void aux_imu(const X &x, const DevPim &pm, const double *pose_i, const double *sb_i, const double *pose_j, const double *sb_j,
@@ -136,9 +136,17 @@ LIO_HD void aux_imu(const X &x, const DevPim &pm, const double *pose_i, const do
   for (int k = 0; k < 3; ++k) { c.dp[k] = pm.dp[k]; c.dv[k] = pm.dv[k]; c.ba[k] = pm.ba[k]; c.bg[k] = pm.bg[k]; c.g[k] = pm.g[k]; }
   for (int k = 0; k < 4; ++k) c.dq[k] = pm.dq[k];
   c.sum_dt = pm.sum_dt; c.jac = pm.jac;
-  for (int job = x.tid; job < 5; job += x.nthr) {
+  // five serial jobs (four raw Jacobian blocks, the residual).  Device: one job per WAVE — on neighbouring lanes of one wave the five
+  // different code paths ran one after the other (the wave executes every divergent branch); the residual shares a wave with the
+  // lightest block.  Host emulation: one thread walks them.
+  for (int job = 0; job < 5; ++job) {
+    const int owner = X::kDevice ? (job < 4 ? (x.WT * job) % x.nthr : (x.WT * 3 + x.WT / 2) % x.nthr) : job % x.nthr;
+    if (x.tid != owner) continue;
     if (job < 4) {
-      double J[135];
+      // the raw block goes through LDS (x.kDevice: as a thread-private array it is indexed at run time and lives in scratch memory —
+      // 56 k of the aux row's 73 k clocks were this phase, profiles/r5_i_*)
+      double Jpriv[X::kDevice ? 1 : 135];
+      double *J = X::kDevice ? lds + 932 + job * 136 : Jpriv;
       imu_raw_jacobian(c, job, pose_i, sb_i, pose_j, sb_j, J);
       const int cols = (job & 1) ? 9 : 7, use = (job & 1) ? 9 : 6, off = job == 0 ? 0 : (job == 1 ? 6 : (job == 2 ? 15 : 21));
       for (int k = 0; k < 15; ++k)
@@ -296,8 +304,12 @@ struct BatchSolve {
   double *next_prior_mats;           // where the new prior goes (same layout as prior_mats)
 };
 
+// The batch's allocations, handed to the batched kernels BY VALUE next to the descriptors: pointers that arrive as kernel arguments are
+// global to the compiler, pointers read from a descriptor are not (dev.h: rebase).
+struct BatchBases { double *slab; double *partials; DevState *st; DevProblem *pb; DevMarg *mg; };
+
 struct StepLds {
-  double *A, *hdiag, *gz, *invd, *scale, *diag, *grad, *gn, *g, *step, *tmp, *zb, *part, *red;
+  double *A, *hdiag, *gz, *invd, *scale, *diag, *grad, *gn, *g, *step, *tmp, *zb, *part, *xinv, *red;
   int *ctl;
 };
 LIO_HD StepLds carve_lds(double *base, int n_pad, int Wo) {
@@ -308,6 +320,7 @@ LIO_HD StepLds carve_lds(double *base, int n_pad, int Wo) {
   l.grad = p; p += n_pad; l.gn = p; p += n_pad; l.g = p; p += n_pad; l.step = p; p += n_pad; l.tmp = p; p += n_pad;
   l.zb = p; p += size_t(Wo) * 344;
   l.part = p; p += DS_PART;
+  l.xinv = p; p += size_t(n_pad) * DS_NB;
   l.red = p; p += 64;
   l.ctl = reinterpret_cast<int *>(p);
   return l;
@@ -331,11 +344,26 @@ template <class X>
 LIO_HD void ds_vHv(const X &x, const double *Hm, int ld, const double *hd, int n, const double *v, double &acc) {
   if constexpr (X::kDevice) {
     const int q = x.tid & 3;
-    for (int i0 = 0; i0 < n; i0 += x.nthr / 4) {   // (uniform trip count: the shuffles below need every lane of the wave)
+    for (int i0 = 0; i0 < n; i0 += x.nthr / 4) {   // (uniform trip count: the quad permutes below need every lane of the wave)
       const int i = i0 + (x.tid >> 2);
+      const int ic = i < n ? i : 0;
+      const double hii = hd[ic];
       double sres = 0.0;
-      if (i < n)
-        for (int j = q; j < n; j += 4) sres += ds_hsym(Hm, ld, hd, i, j) * v[j];
+      for (int j0 = q; j0 < n; j0 += 32) {          // eight terms' loads in flight (unconditional, clamped), then the eight multiply-adds in order
+        double hv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + 4 * u, jc = j < n ? j : ic;
+          hv[u] = Hm[ic < jc ? ic * ld + jc : jc * ld + ic];
+          vv[u] = v[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + 4 * u;
+          const double h = (j == ic) ? hii : hv[u];
+          sres += (j < n) ? h * vv[u] : 0.0;
+        }
+      }
       sres = x.pair_sum4(sres);
       if (i < n && q == 0) acc += v[i] * sres;
     }
@@ -357,10 +385,10 @@ LIO_HD void ds_vHv(const X &x, const double *Hm, int ld, const double *hd, int n
 // 16x16 diagonal block at p.  Reference form: one lane walks the block; the device executor keeps row r of the block in the
 // registers of lane r and broadcasts pivots / columns with v_readlane (same arithmetic, same order).
 template <class X>
-LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd, double *scratch) {
+LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd, double *scratch, double *xinv) {
   if (x.wave != 0) return 1;
   if constexpr (X::kDevice) {
-    return x.panel_factor_regs(A, ld, p, invd, scratch);
+    return x.panel_factor_regs(A, ld, p, invd, scratch, xinv + size_t(p) * DS_NB);
   } else {
     for (int j = 0; j < DS_NB; ++j) {
       const double d = A[(p + j) * ld + p + j];
@@ -385,13 +413,13 @@ LIO_HD int ds_panel_factor(const X &x, double *A, int ld, int p, double *invd, d
 #define LIO_DS_NOINLINE
 #endif
 template <class X>
-LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, int *flag, long long *prof = nullptr) {
+LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad, double *gz, double *invd, double *part, double *xinv, int *flag, long long *prof = nullptr) {
   const int nblk = npad / DS_NB;
   for (int kb = 0; kb < nblk; ++kb) {
     const int p = kb * DS_NB, q = p + DS_NB;
     // ---- phase 1: diagonal block (wave 0)
     if (kb == 0) x.stamp(prof, 16);
-    const int ok = ds_panel_factor(x, A, ld, p, invd, part);
+    const int ok = ds_panel_factor(x, A, ld, p, invd, part, xinv);
     if (x.tid == 0) *flag = ok;
     x.sync_lds();
     if (kb == 0) x.stamp(prof, 17);
@@ -400,15 +428,15 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
     // stored as L = T D^-1
     const int nrows = npad - q;
     if constexpr (X::kDevice) {
-      x.panel_trsm_mfma(A, ld, npad, p, gz, invd, part);   // against L11^-1, which the panel wave left in `part`
+      x.panel_trsm_mfma(A, ld, npad, p, gz, invd, xinv + size_t(p) * DS_NB);   // against L11^-1, which the panel wave left in its slot of xinv
     } else {
       for (int t = x.tid; t <= nrows; t += x.nthr) {
         const bool rhs = (t == nrows);
-        double *row = rhs ? (gz + p) : (A + size_t(q + t) * ld + p);
+        double *row = rhs ? (gz + p) : (A + (q + t) * ld + p);
         double tr[DS_NB];
         for (int j = 0; j < DS_NB; ++j) tr[j] = row[j];
         for (int j = 1; j < DS_NB; ++j) {
-          const double *l11 = A + size_t(p + j) * ld + p;
+          const double *l11 = A + (p + j) * ld + p;
           for (int k = 0; k < j; ++k) tr[j] -= tr[k] * l11[k];
         }
         for (int j = 0; j < DS_NB; ++j) row[j] = tr[j] * invd[p + j];
@@ -420,9 +448,9 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
     // ---- phase 3: trailing update  A22 -= L21 D L21^T  (lower triangle), rhs -= L21 D z
     for (int c = q + x.tid; c < npad; c += x.nthr) {
       double sres = 0;
-      const double *lc = A + size_t(c) * ld + p;
+      const double *lc = A + (c) * ld + p;
 #pragma unroll
-      for (int j = 0; j < DS_NB; ++j) sres += gz[p + j] * (lc[j] * A[size_t(p + j) * ld + p + j]);
+      for (int j = 0; j < DS_NB; ++j) sres += gz[p + j] * (lc[j] * A[(p + j) * ld + p + j]);
       gz[c] -= sres;
     }
     if constexpr (X::kDevice) {
@@ -431,8 +459,8 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
       for (int r = q; r < npad; ++r)
         for (int c = q; c <= r; ++c) {
           double sres = 0;
-          for (int j = 0; j < DS_NB; ++j) sres += A[size_t(r) * ld + p + j] * (A[size_t(c) * ld + p + j] * A[size_t(p + j) * ld + p + j]);
-          A[size_t(r) * ld + c] -= sres;
+          for (int j = 0; j < DS_NB; ++j) sres += A[(r) * ld + p + j] * (A[(c) * ld + p + j] * A[(p + j) * ld + p + j]);
+          A[(r) * ld + c] -= sres;
         }
     }
     x.sync_lds();
@@ -447,12 +475,12 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
       const int j = x.tid & 15;
       for (int sl = x.tid >> 4; sl < 32; sl += (x.nthr + 15) / 16) {
         double acc = 0;
-        for (int r = q + sl; r < npad; r += 32) acc += A[size_t(r) * ld + p + j] * gz[r];
+        for (int r = q + sl; r < npad; r += 32) acc += A[(r) * ld + p + j] * gz[r];
         part[sl * 16 + j] = acc;
         if (x.nthr < 16) {   // host emulation: one thread walks every column
           for (int jj = 1; jj < 16; ++jj) {
             double a2 = 0;
-            for (int r = q + sl; r < npad; r += 32) a2 += A[size_t(r) * ld + p + jj] * gz[r];
+            for (int r = q + sl; r < npad; r += 32) a2 += A[(r) * ld + p + jj] * gz[r];
             part[sl * 16 + jj] = a2;
           }
         }
@@ -461,12 +489,12 @@ LIO_DS_NOINLINE LIO_HD int ds_ldlt_solve(const X &x, double *A, int ld, int npad
     x.sync_lds();
     if (x.wave == 0) {
       if constexpr (X::kDevice) {
-        x.panel_backsolve_regs(A, ld, p, gz, part);
+        x.panel_backsolve_regs(A, ld, p, gz, part, xinv + size_t(p) * DS_NB);
       } else {
         double y[DS_NB];
         for (int j = 0; j < DS_NB; ++j) { double s2 = 0; for (int sl = 0; sl < 32; ++sl) s2 += part[sl * 16 + j]; y[j] = gz[p + j] - s2; }
         for (int k = DS_NB - 1; k >= 1; --k)
-          for (int j = 0; j < k; ++j) y[j] -= A[size_t(p + k) * ld + p + j] * y[k];
+          for (int j = 0; j < k; ++j) y[j] -= A[(p + k) * ld + p + j] * y[k];
         for (int j = 0; j < DS_NB; ++j) gz[p + j] = y[j];
       }
     }
@@ -592,6 +620,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   int *pcol = reinterpret_cast<int *>(L.part);   // the prior's column of every tangent column (LDS copy; `part` is idle until the back-substitution)
   for (int i = x.tid; i < npad; i += x.nthr) pcol[i] = (pb.have_prior && i < n) ? pb.prior_col[i] : -1;
   x.sync_lds();
+  x.stamp(B.prof, 15);
   // the ImuFactor blocks of this thread's entries, requested now (one memory round trip under the prior pass instead of one per block)
   constexpr int IMU_Q = X::kDevice ? (930 + DS_THREADS - 1) / DS_THREADS : 1;
   double imv[X::kDevice ? DS_MAX_WO : 1][IMU_Q];
@@ -605,57 +634,58 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       for (int q = 0; q < IMU_Q; ++q) { const int e = x.tid + q * DS_THREADS; imv[i][q] = im[e < 930 ? e : 0]; }
     }
   }
-  {  // prior pass: column tcol of rows trow, trow + rstep, ...; 24 rows' loads in flight at a time (all of them at 96 unknowns)
-    for (int c = tcol; c <= npad; c += CW) {
-      const bool is_g = (c == npad);
-      const int pc = is_g ? -1 : pcol[c < npad ? c : 0];
-      constexpr int PQ = X::kDevice ? 24 : 8;
+  x.stamp(B.prof, 24);
+  {  // prior pass: column tcol of rows trow, trow + rstep, ...: the rows' prior columns first (one batch of LDS reads), then 24 rows' loads
+     // in flight, unconditional from clamped 32-bit indices (profiles/r5_i_*, r5_j_*: with a branch and an LDS read in front of every
+     // load the pass cost 28 k clocks)
+    constexpr int PQ = X::kDevice ? 24 : 8;
+    for (int c = tcol; c < npad; c += CW) {
+      const int pc = pcol[c];
       for (int r0 = trow; r0 < npad; r0 += PQ * rstep) {
+        int pr[PQ];
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) { const int r = r0 + q * rstep; pr[q] = pcol[r < npad ? r : 0]; }
         double v[PQ];
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-          const int r = r0 + q * rstep;
-          const int pr = r < npad ? pcol[r] : -1;
-          double t = 0.0;
-          if (pr >= 0) {
-            if (is_g) t = B.prior_out[pr];
-            else if (pc >= 0) t = JtJ[size_t(pr) * np + pc];
-          }
-          v[q] = t;
+          const bool on = (pr[q] >= 0) & (pc >= 0) & (r0 + q * rstep < npad);
+          const double t = JtJ[on ? pr[q] * np + pc : 0];
+          v[q] = on ? t : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
           const int r = r0 + q * rstep;
-          if (r < npad) {
-            double t = v[q];
-            if (r >= n || (!is_g && c >= n)) t = (!is_g && r == c) ? 1.0 : 0.0;
-            if (is_g) L.gz[r] = t; else A[size_t(r) * ld + c] = t;
-          }
+          if (r < npad) A[r * ld + c] = (r == c && r >= n) ? 1.0 : v[q];   // (rows / columns of the pad have no prior column: zero, identity on the diagonal)
         }
       }
     }
+    for (int r = x.tid; r < npad; r += x.nthr) { const int pr = pcol[r]; const double t = B.prior_out[pr >= 0 ? pr : 0]; L.gz[r] = pr >= 0 ? t : 0.0; }
   }
+  x.stamp(B.prof, 25);
   x.sync_lds();
   x.stamp(B.prof, 11);
-  for (int i = 0; i < Wo; ++i) {   // ImuFactor i spans tangent columns [15 i, 15 i + 30)
+  // ImuFactor i spans tangent columns [15 i, 15 i + 30): the even factors touch disjoint entries, and so do the odd ones — two passes
+  // (an entry shared by factors i and i + 1 receives the even one first)
+  for (int parity = 0; parity < 2; ++parity) {
     if (X::kDevice) {
-      // (static register indices: the loop over the frames is unrolled to its bound, a frame beyond Wo never passes the outer test)
+      // (static register indices: the loop over the frames is unrolled to its bound)
 #pragma unroll
       for (int ii = 0; ii < DS_MAX_WO; ++ii) {
-        if (ii == i && imflag[ii] != 0.0) {
+        if ((ii & 1) == parity && ii < Wo && imflag[ii] != 0.0) {
 #pragma unroll
           for (int q = 0; q < IMU_Q; ++q) {
             const int e = x.tid + q * DS_THREADS;
-            if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += imv[ii][q]; }
-            else if (e < 930) L.gz[15 * i + (e - 900)] += imv[ii][q];
+            if (e < 900) { const int lr = e / 30, lc = e % 30; A[(15 * ii + lr) * ld + 15 * ii + lc] += imv[ii][q]; }
+            else if (e < 930) L.gz[15 * ii + (e - 900)] += imv[ii][q];
           }
         }
       }
     } else {
-      const double *im = B.imu_out + size_t(i) * DS_IMU_OUT;
-      if (im[931] != 0.0) {
+      for (int i = parity; i < Wo; i += 2) {
+        const double *im = B.imu_out + size_t(i) * DS_IMU_OUT;
+        if (im[931] == 0.0) continue;
         for (int e = x.tid; e < 930; e += x.nthr) {
-          if (e < 900) { const int lr = e / 30, lc = e % 30; A[size_t(15 * i + lr) * ld + 15 * i + lc] += im[e]; }
+          if (e < 900) { const int lr = e / 30, lc = e % 30; A[(15 * i + lr) * ld + 15 * i + lc] += im[e]; }
           else L.gz[15 * i + (e - 900)] += im[e];
         }
       }
@@ -663,28 +693,38 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     x.sync_lds();
   }
   x.stamp(B.prof, 14);
-  for (int f = 0; f < Wo; ++f) {   // lidar frame f + 1 touches (pose_0, pose_{f+1}, extrinsic): local rows 0..5, 6..11, 12..17
-    if (L.tmp[2 * f + 1] != 0.0) {
-      const double *zf = L.zb + f * 344;
-      for (int e = x.tid; e < 342; e += x.nthr) {
-        if (e < 324) {
-          const int a = e / 18, b = e % 18;
-          const int ra = a < 6 ? a : (a < 12 ? 15 * (f + 1) + (a - 6) : (exc >= 0 ? exc + (a - 12) : -1));
-          const int cb = b < 6 ? b : (b < 12 ? 15 * (f + 1) + (b - 6) : (exc >= 0 ? exc + (b - 12) : -1));
-          if (ra >= 0 && cb >= 0) A[size_t(ra) * ld + cb] += zf[e];
-        } else {
-          const int a = e - 324;
-          const int ra = a < 6 ? a : (a < 12 ? 15 * (f + 1) + (a - 6) : (exc >= 0 ? exc + (a - 12) : -1));
-          if (ra >= 0) L.gz[ra] += zf[e];
-        }
+  // lidar frame f + 1 touches (pose_0, pose_{f+1}, extrinsic): local rows 0..5, 6..11, 12..17.  ONE pass: the entries that involve
+  // pose_{f+1} belong to that frame alone; the 12 x 12 (+ 12 of g) entries among pose_0 and the extrinsic are shared by all frames —
+  // one thread each walks the frames in order and adds the extrinsic PriorFactor behind them.
+  {
+    auto glob = [&](int f, int a) { return a < 6 ? a : (a < 12 ? 15 * (f + 1) + (a - 6) : (exc >= 0 ? exc + (a - 12) : -1)); };
+    for (int item = x.tid; item < Wo * 342; item += x.nthr) {
+      const int f = item / 342, e = item % 342;
+      if (L.tmp[2 * f + 1] == 0.0) continue;
+      const double val = L.zb[f * 344 + e];
+      if (e < 324) {
+        const int a = e / 18, b = e % 18;
+        if ((a < 6 || a >= 12) && (b < 6 || b >= 12)) continue;          // shared: below
+        const int ra = glob(f, a), cb = glob(f, b);
+        if (ra >= 0 && cb >= 0) A[ra * ld + cb] += val;
+      } else {
+        const int a = e - 324;
+        if (a < 6 || a >= 12) continue;
+        L.gz[glob(f, a)] += val;
       }
     }
-    x.sync_lds();
-  }
-  if (pb.use_ex_prior && exc >= 0) {
-    for (int e = x.tid; e < 42; e += x.nthr) {
-      if (e < 36) A[size_t(exc + e / 6) * ld + exc + e % 6] += B.exprior_out[e];
-      else L.gz[exc + (e - 36)] += B.exprior_out[e];
+    const bool exp_on = pb.use_ex_prior && exc >= 0;
+    for (int item = x.tid; item < 156; item += x.nthr) {
+      const bool is_g = item >= 144;
+      const int sa = is_g ? item - 144 : item / 12, sb = is_g ? 0 : item % 12;       // indices among (pose_0 | extrinsic)
+      const int a = sa < 6 ? sa : sa + 6, b = sb < 6 ? sb : sb + 6;                   // local indices of the 18
+      const int ra = glob(0, a), cb = glob(0, b);
+      if (ra < 0 || cb < 0) continue;
+      double acc = is_g ? L.gz[ra] : A[ra * ld + cb];
+      for (int f = 0; f < Wo; ++f)
+        if (L.tmp[2 * f + 1] != 0.0) acc += L.zb[f * 344 + (is_g ? 324 + a : a * 18 + b)];
+      if (exp_on && sa >= 6 && (is_g || sb >= 6)) acc += B.exprior_out[is_g ? 36 + (sa - 6) : (sa - 6) * 6 + (sb - 6)];
+      if (is_g) L.gz[ra] = acc; else A[ra * ld + cb] = acc;
     }
     x.sync_lds();
   }
@@ -787,7 +827,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     // Jacobi scaling: fixed at the first linearisation (scale = 1 / (1 + sqrt(H_ii)))
     for (int i = x.tid; i < npad; i += x.nthr) {
       double sc = 1.0;
-      if (i < n) sc = (mode == DS_MODE_INIT) ? 1.0 / (1.0 + sqrt(A[size_t(i) * ld + i])) : st.scale[i];
+      if (i < n) sc = (mode == DS_MODE_INIT) ? 1.0 / (1.0 + sqrt(A[(i) * ld + i])) : st.scale[i];
       L.scale[i] = sc;
       if (mode == DS_MODE_INIT && i < n) st.scale[i] = sc;
     }
@@ -798,13 +838,13 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       for (int r0 = trow; r0 < n; r0 += 8 * rstep) {   // eight entries in flight; only the upper triangle goes to global memory (ds_hsym reads nothing else)
         double v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int r = r0 + q * rstep; v[q] = r < n ? A[size_t(r) * ld + c] * (L.scale[r] * sc_c) : 0.0; }
+        for (int q = 0; q < 8; ++q) { const int r = r0 + q * rstep, rc = r < n ? r : 0; v[q] = A[(rc) * ld + c] * (L.scale[rc] * sc_c); }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q * rstep;
           if (r < n) {
-            A[size_t(r) * ld + c] = v[q];
-            if (c >= r) B.Hcur[size_t(r) * ld + c] = v[q];
+            A[(r) * ld + c] = v[q];
+            if (c >= r) B.Hcur[(r) * ld + c] = v[q];
             if (r == c) L.hdiag[r] = v[q];
           }
         }
@@ -821,7 +861,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       const bool in = i < n;
       L.scale[i] = in ? st.scale[i] : 1.0; L.g[i] = in ? st.g[i] : 0.0; L.diag[i] = in ? st.diag[i] : 1.0;
       L.grad[i] = in ? st.grad[i] : 0.0; L.gn[i] = in ? st.gn[i] : 0.0;
-      L.hdiag[i] = in ? B.Hcur[size_t(i) * ld + i] : 1.0;
+      L.hdiag[i] = in ? B.Hcur[(i) * ld + i] : 1.0;
     }
   }
   x.sync_lds();
@@ -842,8 +882,8 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       if (!h_in_lds) {   // a linearisation is needed at the accepted point but LDS holds a rejected candidate: reload
         for (int r = trow; r < npad; r += rstep)
           for (int c = tcol; c < npad; c += CW) {
-            if (r < n && c < n) { if (c >= r) A[size_t(r) * ld + c] = B.Hcur[size_t(r) * ld + c]; }   // (the lower triangle is rebuilt from the upper before the factorisation)
-            else A[size_t(r) * ld + c] = (r == c) ? 1.0 : 0.0;
+            if (r < n && c < n) { if (c >= r) A[(r) * ld + c] = B.Hcur[(r) * ld + c]; }   // (the lower triangle is rebuilt from the upper before the factorisation)
+            else A[(r) * ld + c] = (r == c) ? 1.0 : 0.0;
           }
         x.sync_lds();   // (every thread has read a_valid above before it changes)
         if (x.tid == 0) C.a_valid = 1;
@@ -878,17 +918,17 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const int r = r0 + q * rstep;
-              v[q] = (r < npad && c < r) ? A[size_t(c) * ld + r] : 0.0;
+              v[q] = A[(c) * ld + (r < npad ? r : c)];   // (unconditional: a load under a branch waits for the one before it)
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const int r = r0 + q * rstep;
-              if (r < npad && c <= r) A[size_t(r) * ld + c] = (c < r) ? v[q] : ((r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0);
+              if (r < npad && c <= r) A[(r) * ld + c] = (c < r) ? v[q] : ((r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0);
             }
           }
         for (int i = x.tid; i < npad; i += x.nthr) L.gz[i] = L.g[i];
         x.sync_lds();
-        int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, &C.fact_ok, B.prof);
+        int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, L.xinv, &C.fact_ok, B.prof);
         x.stamp(B.prof, 21);
         int fin = 1;
         if (ok) for (int i = x.tid; i < n; i += x.nthr) if (!(fabs(L.gz[i]) <= 1.7e308)) fin = 0;

@@ -711,7 +711,11 @@ void launch_lidar_moments_resident(const MomentArgs &a, const ResidentArgs &ra, 
 // Inside a batch the partition of a window's factor slots must not depend on the batch (a window gives the same bits alone and in
 // any company): 2048 slots per block — eight 64-slot chunks per wave, enough for the chunk loop's three-deep prefetch to fill the
 // MFMA issue slots — and never more than 64 blocks per frame.
-int batch_blocks_per_frame(int max_slots) { return std::max(1, std::min(cdiv(max_slots, MOMENT_THREADS * 8), 64)); }
+int batch_blocks_per_frame(int max_slots) {
+  // slots per block: a function of the window's own size only (bit-identity of a window alone and in a batch); LIO_BW_SLOTS_PER_BLOCK for A/B runs
+  static const int per_block = [] { const char *e = std::getenv("LIO_BW_SLOTS_PER_BLOCK"); const int v = e ? std::atoi(e) : 0; return v >= 256 ? v : MOMENT_THREADS * 16; }();   // 4096: measured against 1024 / 2048 / 8192 / 16384 at 64 and 512 windows (profiles/r5_l_*): fewer partials for the step kernel's fold, still 640 blocks per 32 windows
+  return std::max(1, std::min(cdiv(max_slots, per_block), 64));
+}
 
 int moment_blocks_per_frame_batched(int max_slots, int nframes) {
   // enough waves to fill the chip about four times over, each with as many chunks as possible (the chunk loop is software

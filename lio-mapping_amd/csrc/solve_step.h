@@ -329,7 +329,7 @@ LIO_HD StepLds carve_lds(double *base, int n_pad, int Wo) {
 // ---- control block shared through LDS (thread 0 writes, everybody reads after a barrier)
 struct StepCtl {
   double radius, mu, alpha, dogleg_norm, gmax, x_cost, x_norm, model_change, step_norm, cand_total;
-  int mode, done, a_valid, fact_ok, reuse, invalid, it, successful, termination, valid_step, lin_ok, pad;
+  int mode, done, a_valid, fact_ok, reuse, invalid, it, successful, termination, valid_step, lin_ok, lower_fresh;   // lower_fresh: A's lower triangle mirrors the upper
 };
 enum { DS_MODE_INIT = 0, DS_MODE_ACCEPT = 1, DS_MODE_REJECT = 2 };
 
@@ -740,7 +740,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     C.radius = st.radius; C.mu = st.mu; C.alpha = st.alpha; C.dogleg_norm = st.dogleg_norm; C.gmax = st.gmax; C.x_cost = st.x_cost;
     C.x_norm = st.x_norm; C.model_change = st.model_change; C.step_norm = st.step_norm; C.cand_total = total;
     C.reuse = st.reuse; C.invalid = st.invalid; C.it = st.it; C.successful = st.successful; C.termination = st.termination;
-    C.a_valid = 0; C.fact_ok = 1; C.valid_step = 0; C.lin_ok = 1;
+    C.a_valid = 0; C.fact_ok = 1; C.valid_step = 0; C.lin_ok = 1; C.lower_fresh = 0;
     if (!st.started) {
       st.costs0[0] = marg; st.costs0[1] = pim; st.costs0[2] = ppp; st.costs0[3] = exprior;
       st.n_lidar = cnt;
@@ -833,18 +833,21 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     }
     x.sync_lds();
     x.stamp(B.prof, 23);
+    // the UPPER triangle is scaled and mirrored into the lower one in the same pass (the factorisation below then only has to set the
+    // diagonal); eight entries in flight; only the upper triangle goes to global memory (ds_hsym reads nothing else)
     for (int c = tcol; c < n; c += CW) {
       const double sc_c = L.scale[c];
-      for (int r0 = trow; r0 < n; r0 += 8 * rstep) {   // eight entries in flight; only the upper triangle goes to global memory (ds_hsym reads nothing else)
+      for (int r0 = trow; r0 <= c; r0 += 8 * rstep) {
         double v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int r = r0 + q * rstep, rc = r < n ? r : 0; v[q] = A[(rc) * ld + c] * (L.scale[rc] * sc_c); }
+        for (int q = 0; q < 8; ++q) { const int r = r0 + q * rstep, rc = r <= c ? r : c; v[q] = A[rc * ld + c] * (L.scale[rc] * sc_c); }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q * rstep;
-          if (r < n) {
-            A[(r) * ld + c] = v[q];
-            if (c >= r) B.Hcur[(r) * ld + c] = v[q];
+          if (r <= c) {
+            A[r * ld + c] = v[q];
+            A[c * ld + r] = v[q];
+            B.Hcur[r * ld + c] = v[q];
             if (r == c) L.hdiag[r] = v[q];
           }
         }
@@ -855,7 +858,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       L.g[i] = gs;
       if (i < n) st.g[i] = gs; else L.hdiag[i] = 1.0;
     }
-    if (x.tid == 0) C.a_valid = 1;
+    if (x.tid == 0) { C.a_valid = 1; C.lower_fresh = 1; }
   } else {
     for (int i = x.tid; i < npad; i += x.nthr) {
       const bool in = i < n;
@@ -911,24 +914,29 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
       for (int attempt = 0; attempt < 12; ++attempt) {
         x.sync_lds();
         if (!(C.mu < 1.0) || C.lin_ok) break;
-        // lower triangle <- upper triangle, regularised diagonal, right-hand side
-        for (int c = tcol; c < npad; c += CW)
-          for (int r0 = trow; r0 < npad; r0 += 8 * rstep) {   // eight LDS reads in flight, then the eight writes
-            double v[8];
+        // lower triangle <- upper triangle (unless the scaling pass has just mirrored it), regularised diagonal, right-hand side
+        if (C.lower_fresh) {
+          for (int r = x.tid; r < npad; r += x.nthr) A[r * ld + r] = (r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0;
+        } else {
+          for (int c = tcol; c < npad; c += CW)
+            for (int r0 = trow; r0 < npad; r0 += 8 * rstep) {   // eight LDS reads in flight, then the eight writes
+              double v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int r = r0 + q * rstep;
-              v[q] = A[(c) * ld + (r < npad ? r : c)];   // (unconditional: a load under a branch waits for the one before it)
-            }
+              for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q * rstep;
+                v[q] = A[(c) * ld + (r < npad ? r : c)];   // (unconditional: a load under a branch waits for the one before it)
+              }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int r = r0 + q * rstep;
-              if (r < npad && c <= r) A[(r) * ld + c] = (c < r) ? v[q] : ((r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0);
+              for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q * rstep;
+                if (r < npad && c <= r) A[(r) * ld + c] = (c < r) ? v[q] : ((r < n) ? L.hdiag[r] + L.diag[r] * L.diag[r] * C.mu : 1.0);
+              }
             }
-          }
+        }
         for (int i = x.tid; i < npad; i += x.nthr) L.gz[i] = L.g[i];
         x.sync_lds();
         int ok = ds_ldlt_solve(x, A, ld, npad, L.gz, L.invd, L.part, L.xinv, &C.fact_ok, B.prof);
+        if (x.tid == 0) C.lower_fresh = 0;   // (the lower triangle now holds L; every thread read the flag before the factorisation's barriers)
         x.stamp(B.prof, 21);
         int fin = 1;
         if (ok) for (int i = x.tid; i < n; i += x.nthr) if (!(fabs(L.gz[i]) <= 1.7e308)) fin = 0;

@@ -84,6 +84,11 @@ int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
  * (The oracle processes inside _async; its _wait is a no-op.) */
 int lio_pp_process_async(lio_pp *, const float *xyzi, size_t n);
 int lio_pp_wait(lio_pp *);
+/* B sweeps (B sensors of a fleet node, or the sweeps of a log) through B handles in one call: every sweep is enqueued before the
+ * first is waited for, so the GPU sees B x rings workgroups of work at once (a single HDL-64 sweep fills 64 of the 256 compute
+ * units in the pick stage).  = lio_pp_process_async on every handle, then lio_pp_wait on every handle; the first failing code is
+ * returned after all handles have been waited for.  A handle may appear once. */
+int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps);
 /* The same with the PointIR overload of PointToRing (uneven = true, sensor_type 320 of processor_node.cc:73;
  * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
  * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */

@@ -110,6 +110,18 @@ int lio_pp_wait(lio_pp *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->pp->ProcessFinish(); return LIO_OK; });
 }
+int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
+  if (n_sweeps < 0 || (n_sweeps > 0 && (!handles || !xyzi || !n))) return LIO_ERR_ARG;
+  for (int k = 0; k < n_sweeps; ++k) {
+    if (!handles[k] || (!xyzi[k] && n[k])) return LIO_ERR_ARG;
+    for (int j = 0; j < k; ++j) if (handles[j] == handles[k]) return LIO_ERR_ARG;
+  }
+  int rc = LIO_OK, launched = 0;
+  for (; launched < n_sweeps && rc == LIO_OK; ++launched) rc = lio_pp_process_async(handles[launched], xyzi[launched], n[launched]);
+  if (rc != LIO_OK) --launched;   // (the failing handle has nothing in flight)
+  for (int k = 0; k < launched; ++k) { const int r = lio_pp_wait(handles[k]); if (rc == LIO_OK) rc = r; }
+  return rc;
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   return guarded([&] { h->pp->Process(xyzi, n, n ? ring : nullptr); return LIO_OK; });

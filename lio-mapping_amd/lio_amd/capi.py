@@ -143,6 +143,7 @@ _SIGS = {
     "lio_pp_process_rings": (C.c_int, [C.c_void_p, c_float_p, c_uint16_p, C.c_size_t]),
     "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
+    "lio_pp_process_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_float_p), C.POINTER(C.c_size_t), C.c_int]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
@@ -491,6 +492,19 @@ class PointProcessor:
     def wait(self):
         _chk(self.lib.dll.lio_pp_wait(self.h), "lio_pp_wait")
         self._pending = None
+
+    @staticmethod
+    def process_batch(processors, sweeps):
+        """lio_pp_process_batch: one sweep per handle, all enqueued before the first is waited for."""
+        assert len(processors) == len(sweeps)
+        B = len(processors)
+        if B == 0:
+            return
+        arrs = [_f32(x).reshape(-1, 4) for x in sweeps]
+        hs = (C.c_void_p * B)(*[p.h for p in processors])
+        ptrs = (c_float_p * B)(*[_fp(a) for a in arrs])
+        ns = (C.c_size_t * B)(*[a.shape[0] for a in arrs])
+        _chk(processors[0].lib.dll.lio_pp_process_batch(hs, ptrs, ns, B), "lio_pp_process_batch")
 
     def process(self, xyzi, ring=None):
         """ring (uint16 per point) selects the PointIR overload of PointToRing (uneven sensors, PointProcessor.cc:428-536)."""

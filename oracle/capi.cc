@@ -63,6 +63,16 @@ int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
 }
 int lio_pp_process_async(lio_pp *h, const float *xyzi, size_t n) { return lio_pp_process(h, xyzi, n); }
 int lio_pp_wait(lio_pp *h) { return h ? LIO_OK : LIO_ERR_ARG; }
+int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
+  if (n_sweeps < 0 || (n_sweeps > 0 && (!handles || !xyzi || !n))) return LIO_ERR_ARG;
+  for (int k = 0; k < n_sweeps; ++k) {
+    if (!handles[k] || (!xyzi[k] && n[k])) return LIO_ERR_ARG;
+    for (int j = 0; j < k; ++j) if (handles[j] == handles[k]) return LIO_ERR_ARG;
+  }
+  int rc = LIO_OK;
+  for (int k = 0; k < n_sweeps && rc == LIO_OK; ++k) rc = lio_pp_process(handles[k], xyzi[k], n[k]);
+  return rc;
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   h->pp.Process(xyzi, n, ring);

@@ -598,3 +598,31 @@ def test_factor_sharding_two_ranks_on_one_gpu(hip):
     assert results[0][2] == r_ref.n_lidar_residuals  # the all-reduced count covers every factor exactly once
     np.testing.assert_allclose(results[0][0], ref.get_window()["Ps"], atol=1e-7)
     np.testing.assert_allclose(results[0][1], r_ref.final_cost, rtol=1e-7)
+
+
+def test_point_processor_batch_equals_one_by_one(hip):
+    """lio_pp_process_batch: four sweeps (two HDL-64E, two VLP-16) through four handles in one call — every sweep enqueued before the
+    first wait — against the same sweeps through four other handles one call at a time: clouds, pick lists and ring offsets bit for bit.
+    A handle twice in one batch is an argument error."""
+    sweeps, lids = [], []
+    for kind, n in (("outdoor", 2), ("indoor", 2)):
+        ds = synth.make_dataset(kind, n, 0.1)
+        for f in ds.frames:
+            sweeps.append(f.scan)
+            lids.append(ds.lidar)
+    batch = [capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings) for lid in lids]
+    single = [capi.PointProcessor(hip, lid.lower_deg, lid.upper_deg, lid.rings) for lid in lids]
+    for rep in range(2):                                    # twice: the second call reuses every buffer, with the sweeps of a sensor swapped
+        pick = [0, 1, 2, 3] if rep == 0 else [1, 0, 3, 2]
+        order = [0, 1, 2, 3] if rep == 0 else [2, 0, 3, 1]
+        capi.PointProcessor.process_batch([batch[i] for i in order], [sweeps[pick[i]] for i in order])
+        for i in range(4):
+            single[i].process(sweeps[pick[i]])
+        for a, b in zip(batch, single):
+            for which in range(5):
+                np.testing.assert_array_equal(a.cloud(which), b.cloud(which))
+            for which in (1, 2, 3):
+                np.testing.assert_array_equal(a.indices(which)[1], b.indices(which)[1])
+            np.testing.assert_array_equal(a.ring_offsets(), b.ring_offsets())
+    with pytest.raises(capi.LioError):
+        capi.PointProcessor.process_batch([batch[0], batch[0]], [sweeps[0], sweeps[0]])

@@ -296,9 +296,9 @@ void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int
 // once the launch fills the chip many times over (no merge shuffles, no idle lanes in the fit; DESIGN.md: keyframe batch).
 // ------------------------------------------------------------------------------------------------
 template <int LPQ>
-__global__ void __launch_bounds__(64 * LPQ) k_bw_features(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
-                                                         const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all,
-                                                         uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) {
+__device__ __forceinline__ void bw_features_body(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid, const float4 *__restrict__ sorted_all,
+                                                 const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all,
+                                                 float *__restrict__ score_all) {
   const int w = blockIdx.z;
   const BatchWin &W = win[w];
   if (int(blockIdx.y) >= W.nstatic) return;
@@ -308,6 +308,29 @@ __global__ void __launch_bounds__(64 * LPQ) k_bw_features(const BatchWin *__rest
   frm.stack = rebase(sorted_all, frm.stack);   // (dev.h: a pointer read from a descriptor is generic until it is tied to a kernel argument)
   features_block<false, LPQ, 64 * LPQ>(frm, fs, int(blockIdx.x), &W.tf[0][0], sorted_all, cells_all + G.cell_off, G.g, valid_all, coef_all, score_all,
                                        nullptr);
+}
+template <int LPQ>
+__global__ void __launch_bounds__(64 * LPQ) k_bw_features(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                         const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all,
+                                                         uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) {
+  bw_features_body<LPQ>(win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+}
+// the one-lane-per-query form at a fixed occupancy (the keyframe batch's k_kf_round1_w8 gained 15 % from eight waves per SIMD at 64
+// VGPRs): LIO_BW_OCC = 6 / 8 selects these for A/B runs
+#define BW_FEAT_OCC(W)                                                                                                                            \
+  __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))                                                                \
+  k_bw_features1_w##W(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid, const float4 *__restrict__ sorted_all,                \
+                      const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all, float4 *__restrict__ coef_all, float *__restrict__ score_all) { \
+    bw_features_body<1>(win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);                                                        \
+  }
+BW_FEAT_OCC(6)
+BW_FEAT_OCC(8)
+// Measured at 64 / 512 windows (profiles/r5_m_occupancy.txt): features 0.747 / 5.69 ms by the compiler's choice (84 VGPRs, 5 waves),
+// 0.709 / 5.25 at 6 waves, 0.699 / 5.02 at 8 (64 VGPRs, 84 B of spills); the rounds lose at both (0.835 / 5.98 -> 0.897 / 6.72 ->
+// 1.137 / 8.68: their fit + row phase spills 176 - 240 B).  Default: features at 8, rounds as compiled; LIO_BW_OCC = 0 / 6 / 8 forces both.
+static int bw_occ(bool features) {
+  static const int v = [] { const char *e = std::getenv("LIO_BW_OCC"); const int o = e ? std::atoi(e) : -1; return (o == 0 || o == 6 || o == 8) ? o : -1; }();
+  return v >= 0 ? v : (features ? 8 : 0);
 }
 int bw_lanes_per_query(long long total_queries) {
   static const int forced = [] { const char *e = std::getenv("LIO_BW_LPQ"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }();
@@ -319,7 +342,11 @@ void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int m
   if (B <= 0 || max_M <= 0 || max_static <= 0) return;
   const dim3 g(cdiv(max_M, 64), max_static, B);
   switch (bw_lanes_per_query(total_queries)) {
-    case 1: hipLaunchKernelGGL(k_bw_features<1>, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
+    case 1:
+      if (bw_occ(true) == 8) hipLaunchKernelGGL(k_bw_features1_w8, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+      else if (bw_occ(true) == 6) hipLaunchKernelGGL(k_bw_features1_w6, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+      else hipLaunchKernelGGL(k_bw_features<1>, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+      break;
     case 2: hipLaunchKernelGGL(k_bw_features<2>, g, dim3(128), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
     case 4: hipLaunchKernelGGL(k_bw_features<4>, g, dim3(256), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
     default: hipLaunchKernelGGL(k_bw_features<8>, g, dim3(512), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
@@ -334,11 +361,9 @@ void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int m
 // every bit of the step — does not depend on how wide the launch made its blocks.
 // ------------------------------------------------------------------------------------------------
 template <int LPQ>
-__global__ void __launch_bounds__(64 * LPQ) k_bw_odom_round(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
-                                                           const OdomState *__restrict__ odom, const float4 *__restrict__ sorted_all,
-                                                           const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
-                                                           float4 *__restrict__ coef_all, float *__restrict__ score_all,
-                                                           double *__restrict__ partials, int round) {
+__device__ __forceinline__ void bw_odom_round_body(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid, const OdomState *__restrict__ odom,
+                                                   const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
+                                                   float4 *__restrict__ coef_all, float *__restrict__ score_all, double *__restrict__ partials, int round) {
   const int w = blockIdx.y;
   const OdomState &st = odom[w];
   if (st.converged) return;
@@ -355,6 +380,23 @@ __global__ void __launch_bounds__(64 * LPQ) k_bw_odom_round(const BatchWin *__re
                                                    round, W.keep, int(blockIdx.x));
   if (threadIdx.x < 28) partials[(size_t(W.part_off) + blockIdx.x) * 28 + threadIdx.x] = v;
 }
+template <int LPQ>
+__global__ void __launch_bounds__(64 * LPQ) k_bw_odom_round(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                           const OdomState *__restrict__ odom, const float4 *__restrict__ sorted_all,
+                                                           const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,
+                                                           float4 *__restrict__ coef_all, float *__restrict__ score_all,
+                                                           double *__restrict__ partials, int round) {
+  bw_odom_round_body<LPQ>(win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+}
+#define BW_ROUND_OCC(W)                                                                                                                           \
+  __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))                                                                \
+  k_bw_odom_round1_w##W(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid, const OdomState *__restrict__ odom,                 \
+                        const float4 *__restrict__ sorted_all, const int *__restrict__ cells_all, uint8_t *__restrict__ valid_all,                \
+                        float4 *__restrict__ coef_all, float *__restrict__ score_all, double *__restrict__ partials, int round) {                 \
+    bw_odom_round_body<1>(win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);                               \
+  }
+BW_ROUND_OCC(6)
+BW_ROUND_OCC(8)
 __global__ void __launch_bounds__(1024) k_bw_odom_update(const BatchWin *__restrict__ win, OdomState *__restrict__ odom, const double *__restrict__ partials,
                                                         int round, int *__restrict__ n_converged) {
   const int w = blockIdx.x;
@@ -370,7 +412,11 @@ void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int
   if (B <= 0 || max_nb <= 0) return;
   const dim3 g(max_nb, B);
   switch (bw_lanes_per_query(total_queries)) {
-    case 1: hipLaunchKernelGGL(k_bw_odom_round<1>, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
+    case 1:
+      if (bw_occ(false) == 8) hipLaunchKernelGGL(k_bw_odom_round1_w8, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+      else if (bw_occ(false) == 6) hipLaunchKernelGGL(k_bw_odom_round1_w6, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+      else hipLaunchKernelGGL(k_bw_odom_round<1>, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+      break;
     case 2: hipLaunchKernelGGL(k_bw_odom_round<2>, g, dim3(128), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
     case 4: hipLaunchKernelGGL(k_bw_odom_round<4>, g, dim3(256), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;
     default: hipLaunchKernelGGL(k_bw_odom_round<8>, g, dim3(512), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;

@@ -9,6 +9,8 @@
 namespace lio {
 
 #define LIO_BW_MAX_SEG 8        // segments of a local map: the pivot's cloud + the Wo - 1 frames behind it (Wo <= 7)
+#define BW_KEY_BITS 31          // voxel key of the batched filter: window << 31 | key; all ones = no point
+#define BW_KEY_NONE 0x7FFFFFFFu
 #define LIO_BW_MAX_STATIC 7     // frames whose features do not depend on the newest frame's rounds
 
 struct BwSeg { const float4 *src; int n; int dst_off; int identity; int set_intensity; float intensity; Affine3f tf; };

@@ -856,7 +856,14 @@ int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipSt
 
 void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(MOMENT_THREADS), 0, s, bs, bb);
+  // Threads per block follow the size of the launch (the results do not depend on it: every sum of the aux row has a fixed order).
+  // The kernel holds 256 VGPRs, so a CU runs two 256-thread blocks or eight one-wave blocks: at 256 windows per launch the 1536
+  // blocks took 334 us in six rounds (profiles/r5_final3_batch512_kernel_stats.md); one wave per block keeps them all resident.
+  // A small launch is a latency chain and wants the four serial jobs of an IMU factor on four waves.
+  const char *e = std::getenv("LIO_BW_AUX_THREADS");   // (read per launch: tests/test_gpu_batch.py switches it between two solves)
+  const int forced = e ? std::atoi(e) : 0;
+  const int threads = (forced == 64 || forced == 128 || forced == 256) ? forced : (B >= 128 ? 64 : MOMENT_THREADS);
+  hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(threads), 0, s, bs, bb);
 }
 void launch_bw_moments(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s) {
   if (B <= 0) return;

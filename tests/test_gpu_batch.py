@@ -204,3 +204,39 @@ def test_batch_arguments(hip):
         batch.solve()                             # not initialised
     batch.close()
     capi.EstimatorBatch(hip, [a]).close()         # released by the batch that is gone: adoptable again
+
+
+def test_aux_row_does_not_depend_on_its_block_size(hip):
+    """launch A's aux row (IMU factors, priors) runs 256 threads per block in small launches and one wave per block from 128 windows
+    per launch on: the same window solved with either (LIO_BW_AUX_THREADS is read per launch) gives the same bits — what makes a
+    window in a batch of 512 equal to the window alone."""
+    import os
+    kind, W, Wo = "indoor", 5, 2
+    ds = synth.make_dataset(kind, W + 4, 0.2)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+    cfg = _cfg(hip, kind, W, Wo, 0, 0, device_solve=1)
+    pipeline.set_extrinsic(cfg, ds)
+    est = capi.Estimator(hip, cfg)
+    pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01, seed=5)
+    est.solve(); est.slide()
+    _push(est, ds, W + 1, clouds[W + 1][0], clouds[W + 1][1])
+    est.solve(); est.slide()                                     # (the device loop has a prior from here on)
+    _push(est, ds, W + 2, clouds[W + 2][0], clouds[W + 2][1])
+    est.snapshot()
+    got = []
+    try:
+        for threads in ("256", "64", "128"):
+            os.environ["LIO_BW_AUX_THREADS"] = threads
+            est.restore()
+            rep = est.solve()
+            got.append((_rep_key(rep), est.get_window(), est.prior()))
+    finally:
+        os.environ.pop("LIO_BW_AUX_THREADS", None)
+    assert got[0][0][0] >= 1
+    for other in got[1:]:
+        assert other[0] == got[0][0]
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "q_lb", "t_lb"):
+            np.testing.assert_array_equal(other[1][key], got[0][1][key])
+        assert (other[2] is None) == (got[0][2] is None)
+        if other[2] is not None:
+            np.testing.assert_array_equal(other[2]["JtJ"], got[0][2]["JtJ"])

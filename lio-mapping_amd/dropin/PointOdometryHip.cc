@@ -1,4 +1,4 @@
-// PointOdometryHip.cc — see PointOdometryHip.h.  Host glue: message handling, pairing, publishing; the step itself is lio_odom_process.
+// PointOdometryHip.cc — see PointOdometryHip.h.  Host glue only (inboxes, pairing, publishing); the step itself is lio_odom_process.
 #include "PointOdometryHip.h"
 
 #include <cmath>
@@ -6,202 +6,209 @@
 
 namespace lio {
 
+namespace {
+const char *const kTopics[5] = {"/laser_cloud_sharp", "/laser_cloud_less_sharp", "/laser_cloud_flat", "/laser_cloud_less_flat", "/full_cloud"};
+
+Transform FromC(const lio_transform_f &t) {
+  Transform out;
+  out.rot = Eigen::Quaternionf(t.q[3], t.q[0], t.q[1], t.q[2]);   // lio_c.h: q = x y z w
+  out.pos = Eigen::Vector3f(t.p[0], t.p[1], t.p[2]);
+  return out;
+}
+void FillPose(const Transform &t, geometry_msgs::Pose &pose) {
+  pose.orientation.x = t.rot.x(); pose.orientation.y = t.rot.y(); pose.orientation.z = t.rot.z(); pose.orientation.w = t.rot.w();
+  pose.position.x = t.pos.x(); pose.position.y = t.pos.y(); pose.position.z = t.pos.z();
+}
+PointT HeaderPoint(float x, float y, float z, float i) {
+  PointT p;
+  p.x = x; p.y = y; p.z = z; p.intensity = i;
+  return p;
+}
+}  // namespace
+
 PointOdometryHip::PointOdometryHip(float scan_period, int io_ratio, size_t num_max_iterations)
-    : scan_period_(scan_period), time_factor_(1 / scan_period), io_ratio_(io_ratio), num_max_iterations_(num_max_iterations),
-      corner_points_sharp_(new PointCloud()), corner_points_less_sharp_(new PointCloud()), surf_points_flat_(new PointCloud()),
-      surf_points_less_flat_(new PointCloud()), full_cloud_(new PointCloud()), last_corner_cloud_(new PointCloud()), last_surf_cloud_(new PointCloud()) {
-  laser_odometry_msg_.header.frame_id = "/camera_init";
-  laser_odometry_msg_.child_frame_id = "/laser_odom";
-  laser_odometry_trans_.frame_id_ = "/camera_init";
-  laser_odometry_trans_.child_frame_id_ = "/camera";
-  Recreate();
+    : period_(scan_period), io_ratio_(io_ratio), max_iterations_(num_max_iterations), kept_corner_(new PointCloud()), kept_surf_(new PointCloud()) {
+  for (Inbox &b : in_) b.cloud.reset(new PointCloud());
+  odom_msg_.header.frame_id = "/camera_init";      // PointOdometry.cc:86-90
+  odom_msg_.child_frame_id = "/laser_odom";
+  odom_tf_.frame_id_ = "/camera_init";
+  odom_tf_.child_frame_id_ = "/camera";
+  OpenHandle();
 }
 
-PointOdometryHip::~PointOdometryHip() { if (odom_) lio_odom_destroy(odom_); }
-
-bool PointOdometryHip::Check(int rc, const char *what) {
-  last_error_ = rc;
-  if (rc == LIO_OK) return true;
-  std::fprintf(stderr, "PointOdometryHip: %s failed with code %d\n", what, rc);
-  return false;
-}
-
-void PointOdometryHip::Recreate() {
+PointOdometryHip::~PointOdometryHip() {
   if (odom_) lio_odom_destroy(odom_);
-  odom_ = lio_odom_create(scan_period_, io_ratio_, int(num_max_iterations_), no_deskew_ ? 1 : 0);
-  if (!odom_) Check(LIO_ERR_DEVICE, "lio_odom_create");
-  else if (!enable_odom_) Check(lio_odom_enable(odom_, 0), "lio_odom_enable");
 }
 
-void PointOdometryHip::SetupRos(ros::NodeHandle &nh) {
-  is_ros_setup_ = true;
-  const bool had = no_deskew_;
-  nh.param("compact_data", compact_data_, true);
-  nh.param("no_deskew", no_deskew_, false);
-  if (no_deskew_ != had) Recreate();   // the library takes no_deskew at creation (PointOdometry.cc:109)
-  enable_odom_service_ = nh.advertiseService("/enable_odom", &PointOdometryHip::EnableOdom, this);
-  if (compact_data_) {
-    pub_compact_data_ = nh.advertise<sensor_msgs::PointCloud2>("/compact_data", 2);
+bool PointOdometryHip::Ok(int rc, const char *what) {
+  last_error_ = rc;
+  if (rc != LIO_OK) std::fprintf(stderr, "PointOdometryHip: %s failed with code %d\n", what, rc);
+  return rc == LIO_OK;
+}
+
+void PointOdometryHip::OpenHandle() {
+  if (odom_) lio_odom_destroy(odom_);
+  odom_ = lio_odom_create(period_, io_ratio_, int(max_iterations_), no_deskew_ ? 1 : 0);   // (no_deskew is fixed at creation)
+  if (!odom_) { Ok(LIO_ERR_DEVICE, "lio_odom_create"); return; }
+  if (!running_) Ok(lio_odom_enable(odom_, 0), "lio_odom_enable");
+}
+
+void PointOdometryHip::set_no_deskew(bool on) {
+  if (on == no_deskew_) return;
+  no_deskew_ = on;
+  OpenHandle();
+}
+
+void PointOdometryHip::SetupRos(ros::NodeHandle &nh) {   // PointOdometry.cc:105-150: same parameters, topics and queue sizes
+  ros_ready_ = true;
+  bool no_deskew = false;
+  nh.param("compact_data", compact_, true);
+  nh.param("no_deskew", no_deskew, false);
+  set_no_deskew(no_deskew);
+  enable_service_ = nh.advertiseService("/enable_odom", &PointOdometryHip::EnableOdom, this);
+  if (compact_) {
+    pub_compact_ = nh.advertise<sensor_msgs::PointCloud2>("/compact_data", 2);
   } else {
-    pub_laser_cloud_corner_last_ = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_corner_last", 2);
-    pub_laser_cloud_surf_last_ = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_surf_last", 2);
-    pub_full_cloud_ = nh.advertise<sensor_msgs::PointCloud2>("/full_odom_cloud", 2);
+    pub_corner_ = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_corner_last", 2);
+    pub_surf_ = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_surf_last", 2);
+    pub_full_ = nh.advertise<sensor_msgs::PointCloud2>("/full_odom_cloud", 2);
   }
-  pub_laser_odometry_ = nh.advertise<nav_msgs::Odometry>("/laser_odom_to_init", 5);
-  pub_diff_odometry_ = nh.advertise<nav_msgs::Odometry>("/laser_odom_to_last", 5);
-  sub_corner_points_sharp_ = nh.subscribe<sensor_msgs::PointCloud2>("/laser_cloud_sharp", 2, &PointOdometryHip::LaserCloudSharpHandler, this);
-  sub_corner_points_less_sharp_ = nh.subscribe<sensor_msgs::PointCloud2>("/laser_cloud_less_sharp", 2, &PointOdometryHip::LaserCloudLessSharpHandler, this);
-  sub_surf_points_flat_ = nh.subscribe<sensor_msgs::PointCloud2>("/laser_cloud_flat", 2, &PointOdometryHip::LaserCloudFlatHandler, this);
-  sub_surf_points_less_flat_ = nh.subscribe<sensor_msgs::PointCloud2>("/laser_cloud_less_flat", 2, &PointOdometryHip::LaserCloudLessFlatHandler, this);
-  sub_full_cloud_ = nh.subscribe<sensor_msgs::PointCloud2>("/full_cloud", 2, &PointOdometryHip::LaserFullCloudHandler, this);
+  pub_to_init_ = nh.advertise<nav_msgs::Odometry>("/laser_odom_to_init", 5);
+  pub_to_last_ = nh.advertise<nav_msgs::Odometry>("/laser_odom_to_last", 5);
+  typedef void (PointOdometryHip::*Handler)(const sensor_msgs::PointCloud2ConstPtr &);
+  const Handler handlers[kChannels] = {&PointOdometryHip::LaserCloudSharpHandler, &PointOdometryHip::LaserCloudLessSharpHandler,
+                                       &PointOdometryHip::LaserCloudFlatHandler, &PointOdometryHip::LaserCloudLessFlatHandler,
+                                       &PointOdometryHip::LaserFullCloudHandler};
+  for (int c = 0; c < kChannels; ++c) sub_[c] = nh.subscribe<sensor_msgs::PointCloud2>(kTopics[c], 2, handlers[c], this);
 }
 
-bool PointOdometryHip::EnableOdom(std_srvs::SetBoolRequest &req, std_srvs::SetBoolResponse &res) {
-  enable_odom_ = req.data > 0;
-  if (odom_) Check(lio_odom_enable(odom_, enable_odom_ ? 1 : 0), "lio_odom_enable");
+bool PointOdometryHip::EnableOdom(std_srvs::SetBoolRequest &req, std_srvs::SetBoolResponse &res) {   // PointOdometry.h:126-131
+  running_ = req.data > 0;
+  if (odom_) Ok(lio_odom_enable(odom_, running_ ? 1 : 0), "lio_odom_enable");
   res.success = true;
   return true;
 }
 
-static void take(const sensor_msgs::PointCloud2ConstPtr &msg, PointCloudPtr &cloud, ros::Time &stamp, bool &flag) {
-  stamp = msg->header.stamp;
-  cloud->clear();
-  pcl::fromROSMsg(*msg, *cloud);
-  std::vector<int> indices;
-  pcl::removeNaNFromPointCloud(*cloud, *cloud, indices);
-  flag = true;
+// PointOdometry.cc:152-206: the five handlers differ in the member they fill
+void PointOdometryHip::Receive(Channel c, const sensor_msgs::PointCloud2ConstPtr &msg) {
+  Inbox &box = in_[c];
+  box.stamp = msg->header.stamp;
+  box.cloud->clear();
+  pcl::fromROSMsg(*msg, *box.cloud);
+  std::vector<int> kept;
+  pcl::removeNaNFromPointCloud(*box.cloud, *box.cloud, kept);
+  box.fresh = true;
 }
-void PointOdometryHip::LaserCloudSharpHandler(const sensor_msgs::PointCloud2ConstPtr &m) { take(m, corner_points_sharp_, time_corner_points_sharp_, new_corner_points_sharp_); }
-void PointOdometryHip::LaserCloudLessSharpHandler(const sensor_msgs::PointCloud2ConstPtr &m) { take(m, corner_points_less_sharp_, time_corner_points_less_sharp_, new_corner_points_less_sharp_); }
-void PointOdometryHip::LaserCloudFlatHandler(const sensor_msgs::PointCloud2ConstPtr &m) { take(m, surf_points_flat_, time_surf_points_flat_, new_surf_points_flat_); }
-void PointOdometryHip::LaserCloudLessFlatHandler(const sensor_msgs::PointCloud2ConstPtr &m) { take(m, surf_points_less_flat_, time_surf_points_less_flat_, new_surf_points_less_flat_); }
-void PointOdometryHip::LaserFullCloudHandler(const sensor_msgs::PointCloud2ConstPtr &m) { take(m, full_cloud_, time_full_cloud_, new_full_cloud_); }
 
 void PointOdometryHip::Reset() {
-  new_corner_points_sharp_ = new_corner_points_less_sharp_ = new_surf_points_flat_ = new_surf_points_less_flat_ = new_full_cloud_ = false;
+  for (Inbox &b : in_) b.fresh = false;
 }
 
-bool PointOdometryHip::HasNewData() {
-  return new_corner_points_sharp_ && new_corner_points_less_sharp_ && new_surf_points_flat_ && new_surf_points_less_flat_ && new_full_cloud_ &&
-         std::fabs((time_corner_points_less_sharp_ - time_corner_points_sharp_).toSec()) < 0.005 &&
-         std::fabs((time_surf_points_flat_ - time_corner_points_sharp_).toSec()) < 0.005 &&
-         std::fabs((time_surf_points_less_flat_ - time_corner_points_sharp_).toSec()) < 0.005 &&
-         std::fabs((time_full_cloud_ - time_corner_points_sharp_).toSec()) < 0.005;
+bool PointOdometryHip::HasNewData() {   // every topic fresh and within 5 ms of the sharp corners' stamp
+  for (const Inbox &b : in_) {
+    if (!b.fresh) return false;
+    if (std::fabs((b.stamp - in_[kSharp].stamp).toSec()) >= 0.005) return false;
+  }
+  return true;
 }
 
-// PointOdometry.cc:260-292, for the pass-through full-resolution cloud
+// PointOdometry.cc:260-292 for one cloud: a point measured at fraction s of the sweep is taken back to the sweep's start by the
+// partial motion (translation s p, rotation slerp(identity, q, s)) and forward to its end by the whole motion; the intensity loses
+// its time part
 size_t PointOdometryHip::TransformToEnd(PointCloudPtr &cloud) {
-  const size_t cloud_size = cloud->points.size();
-  for (size_t i = 0; i < cloud_size; i++) {
-    PointT &point = cloud->points[i];
-    float s = time_factor_ * (point.intensity - int(point.intensity));
-    if (no_deskew_) s = 0;
-    point.x -= s * transform_es_.pos.x();
-    point.y -= s * transform_es_.pos.y();
-    point.z -= s * transform_es_.pos.z();
-    point.intensity = int(point.intensity);
-    Eigen::Quaternionf q_id, q_s, q_e;
-    q_e = transform_es_.rot;
-    q_id.setIdentity();
-    q_s = q_id.slerp(s, q_e);
-    RotatePoint(q_s.conjugate(), point);
-    RotatePoint(q_e, point);
-    point.x += transform_es_.pos.x();
-    point.y += transform_es_.pos.y();
-    point.z += transform_es_.pos.z();
+  const Eigen::Quaternionf whole = sweep_motion_.rot;
+  const Eigen::Vector3f shift = sweep_motion_.pos;
+  const float per_second = 1.0f / period_;
+  Eigen::Quaternionf identity;
+  identity.setIdentity();
+  for (PointT &pt : cloud->points) {
+    const int ring = int(pt.intensity);
+    const float s = no_deskew_ ? 0.0f : per_second * (pt.intensity - ring);
+    pt.x -= s * shift.x(); pt.y -= s * shift.y(); pt.z -= s * shift.z();
+    pt.intensity = ring;
+    const Eigen::Quaternionf partial = identity.slerp(s, whole);
+    RotatePoint(partial.conjugate(), pt);
+    RotatePoint(whole, pt);
+    pt.x += shift.x(); pt.y += shift.y(); pt.z += shift.z();
   }
-  return cloud_size;
+  return cloud->points.size();
 }
 
-void PointOdometryHip::Pack(const PointCloud &c, std::vector<float> &xyzi) {
-  xyzi.resize(4 * c.size());
-  for (size_t i = 0; i < c.size(); ++i) { xyzi[4 * i] = c[i].x; xyzi[4 * i + 1] = c[i].y; xyzi[4 * i + 2] = c[i].z; xyzi[4 * i + 3] = c[i].intensity; }
-}
-void PointOdometryHip::Fetch(int which, PointCloud &dst) {
+void PointOdometryHip::Download(int which, PointCloud &into) {
   const size_t n = lio_odom_get_last_cloud(odom_, which, nullptr);
-  std::vector<float> buf(4 * n);
-  if (n) lio_odom_get_last_cloud(odom_, which, buf.data());
-  dst.clear();
-  for (size_t k = 0; k < n; ++k) {
-    PointT p;
-    p.x = buf[4 * k]; p.y = buf[4 * k + 1]; p.z = buf[4 * k + 2]; p.intensity = buf[4 * k + 3];
-    dst.push_back(p);
-  }
+  std::vector<float> xyzi(4 * n);
+  if (n) lio_odom_get_last_cloud(odom_, which, xyzi.data());
+  into.clear();
+  for (size_t k = 0; k < n; ++k) into.push_back(HeaderPoint(xyzi[4 * k], xyzi[4 * k + 1], xyzi[4 * k + 2], xyzi[4 * k + 3]));
 }
 
 void PointOdometryHip::Process() {
-  if (!HasNewData() || !odom_) return;
+  if (!odom_ || !HasNewData()) return;
   Reset();
-  const bool first = !system_inited_;
-  Pack(*corner_points_sharp_, b_sharp_); Pack(*corner_points_less_sharp_, b_less_sharp_);
-  Pack(*surf_points_flat_, b_flat_); Pack(*surf_points_less_flat_, b_less_flat_);
-  lio_transform_f t_sum, t_es;
-  if (!Check(lio_odom_process(odom_, b_sharp_.data(), corner_points_sharp_->size(), b_less_sharp_.data(), corner_points_less_sharp_->size(), b_flat_.data(),
-                              surf_points_flat_->size(), b_less_flat_.data(), surf_points_less_flat_->size(), &t_sum, &t_es, nullptr, nullptr), "lio_odom_process")) return;
-  Fetch(0, *last_corner_cloud_);
-  Fetch(1, *last_surf_cloud_);
-  system_inited_ = true;
-  if (first) return;   // :302-310: the first sweep only becomes "last"
-  ++frame_count_;
-  transform_sum_.rot = Eigen::Quaternionf(t_sum.q[3], t_sum.q[0], t_sum.q[1], t_sum.q[2]);
-  transform_sum_.pos = Eigen::Vector3f(t_sum.p[0], t_sum.p[1], t_sum.p[2]);
-  transform_es_.rot = Eigen::Quaternionf(t_es.q[3], t_es.q[0], t_es.q[1], t_es.q[2]);
-  transform_es_.pos = Eigen::Vector3f(t_es.p[0], t_es.p[1], t_es.p[2]);
+  size_t counts[4];
+  for (int c = 0; c < 4; ++c) {
+    const PointCloud &src = *in_[c].cloud;
+    counts[c] = src.size();
+    stage_[c].resize(4 * counts[c]);
+    for (size_t i = 0; i < counts[c]; ++i) {
+      stage_[c][4 * i] = src[i].x; stage_[c][4 * i + 1] = src[i].y; stage_[c][4 * i + 2] = src[i].z; stage_[c][4 * i + 3] = src[i].intensity;
+    }
+  }
+  lio_transform_f in_init, over_sweep;
+  const int rc = lio_odom_process(odom_, stage_[kSharp].data(), counts[kSharp], stage_[kLessSharp].data(), counts[kLessSharp], stage_[kFlat].data(), counts[kFlat],
+                                  stage_[kLessFlat].data(), counts[kLessFlat], &in_init, &over_sweep, nullptr, nullptr);
+  if (!Ok(rc, "lio_odom_process")) return;
+  Download(0, *kept_corner_);
+  Download(1, *kept_surf_);
+  if (!have_previous_) {   // PointOdometry.cc:302-310: the first sweep only becomes "last"; nothing is published
+    have_previous_ = true;
+    return;
+  }
+  ++sweeps_done_;
+  pose_in_init_ = FromC(in_init);
+  sweep_motion_ = FromC(over_sweep);
   PublishResults();
 }
 
-void PointOdometryHip::PublishResults() {
-  if (!is_ros_setup_) return;
-  geometry_msgs::Quaternion geo_quat;
-  geo_quat.x = transform_sum_.rot.x(); geo_quat.y = transform_sum_.rot.y(); geo_quat.z = transform_sum_.rot.z(); geo_quat.w = transform_sum_.rot.w();
-  laser_odometry_msg_.header.stamp = time_corner_points_sharp_;
-  laser_odometry_msg_.pose.pose.orientation = geo_quat;
-  laser_odometry_msg_.pose.pose.position.x = transform_sum_.pos.x();
-  laser_odometry_msg_.pose.pose.position.y = transform_sum_.pos.y();
-  laser_odometry_msg_.pose.pose.position.z = transform_sum_.pos.z();
-  pub_laser_odometry_.publish(laser_odometry_msg_);
-  laser_odometry_trans_.stamp_ = time_corner_points_sharp_;
-  laser_odometry_trans_.setRotation(tf::Quaternion(geo_quat.x, geo_quat.y, geo_quat.z, geo_quat.w));
-  laser_odometry_trans_.setOrigin(tf::Vector3(transform_sum_.pos.x(), transform_sum_.pos.y(), transform_sum_.pos.z()));
-  tf_broadcaster_.sendTransform(laser_odometry_trans_);
-  geo_quat.x = transform_es_.rot.x(); geo_quat.y = transform_es_.rot.y(); geo_quat.z = transform_es_.rot.z(); geo_quat.w = transform_es_.rot.w();
-  laser_odometry_msg_.pose.pose.orientation = geo_quat;
-  laser_odometry_msg_.pose.pose.position.x = transform_es_.pos.x();
-  laser_odometry_msg_.pose.pose.position.y = transform_es_.pos.y();
-  laser_odometry_msg_.pose.pose.position.z = transform_es_.pos.z();
-  pub_diff_odometry_.publish(laser_odometry_msg_);
-  if (io_ratio_ < 2 || frame_count_ % io_ratio_ == 1) {
-    const ros::Time sweepTime = time_corner_points_sharp_;
-    if (enable_odom_) TransformToEnd(full_cloud_);
-    if (compact_data_) {
-      PointCloud compact_data;
-      PointT compact_point;
-      compact_point.x = transform_sum_.pos.x(); compact_point.y = transform_sum_.pos.y(); compact_point.z = transform_sum_.pos.z();
-      compact_data.push_back(compact_point);
-      compact_point.x = transform_sum_.rot.x(); compact_point.y = transform_sum_.rot.y(); compact_point.z = transform_sum_.rot.z();
-      compact_point.intensity = transform_sum_.rot.w();
-      compact_data.push_back(compact_point);
-      compact_point.x = last_corner_cloud_->size(); compact_point.y = last_surf_cloud_->size(); compact_point.z = full_cloud_->size();
-      compact_data.push_back(compact_point);
-      compact_data += (*last_corner_cloud_);
-      compact_data += (*last_surf_cloud_);
-      compact_data += (*full_cloud_);
-      PublishCloudMsg(pub_compact_data_, compact_data, sweepTime, "/camera");
-    } else {
-      PublishCloudMsg(pub_laser_cloud_corner_last_, *last_corner_cloud_, sweepTime, "/camera");
-      PublishCloudMsg(pub_laser_cloud_surf_last_, *last_surf_cloud_, sweepTime, "/camera");
-      PublishCloudMsg(pub_full_cloud_, *full_cloud_, sweepTime, "/camera");
-    }
+void PointOdometryHip::PublishResults() {   // PointOdometry.cc:685-790
+  if (!ros_ready_) return;
+  const ros::Time stamp = in_[kSharp].stamp;
+  odom_msg_.header.stamp = stamp;
+  FillPose(pose_in_init_, odom_msg_.pose.pose);
+  pub_to_init_.publish(odom_msg_);
+  odom_tf_.stamp_ = stamp;
+  odom_tf_.setRotation(tf::Quaternion(pose_in_init_.rot.x(), pose_in_init_.rot.y(), pose_in_init_.rot.z(), pose_in_init_.rot.w()));
+  odom_tf_.setOrigin(tf::Vector3(pose_in_init_.pos.x(), pose_in_init_.pos.y(), pose_in_init_.pos.z()));
+  tf_out_.sendTransform(odom_tf_);
+  FillPose(sweep_motion_, odom_msg_.pose.pose);
+  pub_to_last_.publish(odom_msg_);
+
+  const bool clouds_due = io_ratio_ < 2 || sweeps_done_ % io_ratio_ == 1;   // the input / output ratio of the cloud topics
+  if (!clouds_due) return;
+  PointCloudPtr &full = in_[kFull].cloud;
+  if (running_) TransformToEnd(full);
+  if (!compact_) {
+    PublishCloudMsg(pub_corner_, *kept_corner_, stamp, "/camera");
+    PublishCloudMsg(pub_surf_, *kept_surf_, stamp, "/camera");
+    PublishCloudMsg(pub_full_, *full, stamp, "/camera");
+    return;
   }
+  // /compact_data: position | rotation (x y z, w in the intensity) | the three sizes | corner, surf, full clouds (:732-764)
+  PointCloud packed;
+  packed.push_back(HeaderPoint(pose_in_init_.pos.x(), pose_in_init_.pos.y(), pose_in_init_.pos.z(), 0.f));
+  packed.push_back(HeaderPoint(pose_in_init_.rot.x(), pose_in_init_.rot.y(), pose_in_init_.rot.z(), pose_in_init_.rot.w()));
+  packed.push_back(HeaderPoint(float(kept_corner_->size()), float(kept_surf_->size()), float(full->size()), pose_in_init_.rot.w()));   // (the reference reuses one point: w stays in the intensity)
+  packed += *kept_corner_;
+  packed += *kept_surf_;
+  packed += *full;
+  PublishCloudMsg(pub_compact_, packed, stamp, "/camera");
 }
 
-void PointOdometryHip::Spin() {
+void PointOdometryHip::Spin() {   // PointOdometry.h:133-147
   ros::Rate rate(200);
-  bool status = ros::ok();
-  while (status) {
+  for (bool alive = ros::ok(); alive; alive = ros::ok()) {
     ros::spinOnce();
     Process();
-    status = ros::ok();
     rate.sleep();
   }
 }

@@ -1,5 +1,5 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r5final3
+O=$R/gpurun_out/r5final5
 mkdir -p $O
 cd $R
 (timeout 1200 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log)

@@ -502,7 +502,9 @@ int lio_est_solve_restored(lio_est *, int steps, lio_solve_report *report_or_nul
  * any batch.  Windows the device loop does not take (not initialised, convergence_flag_ still changing the problem, factor
  * sharding) are solved by the single-window path inside the same call.
  * lio_est_batch_create ADOPTS the handles: their device work moves to the batch's stream; they stay usable one at a time from the
- * thread that drives the batch (push frames, slide, snapshot / restore, getters) and must outlive the batch.  NULL on bad arguments. */
+ * thread that drives the batch (push frames, slide, snapshot / restore, getters) and must outlive the batch.  NULL on bad arguments:
+ * no window, more than 65535, a null handle, a handle twice, a handle that already belongs to a batch (lio_est_batch_destroy
+ * releases its members). */
 typedef struct lio_est_batch lio_est_batch;
 lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n_windows);
 void lio_est_batch_destroy(lio_est_batch *);

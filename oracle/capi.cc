@@ -22,6 +22,7 @@ struct lio_est {
   Estimator est;
   std::unique_ptr<Estimator> snap;
   PointMapping map;  // the PointMapping base of the reference's Estimator (Estimator.h:110)
+  bool adopted = false;   // member of a lio_est_batch (a handle is in at most one)
   explicit lio_est(const EstimatorConfig &c, const MappingConfig &m) : est(c), map(m) {}
 };
 
@@ -777,13 +778,21 @@ int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
 // lio_est_batch (include/lio_c.h): the oracle has one way to solve a window; a batch is a loop over its members
 struct lio_est_batch { std::vector<lio_est *> members; };
 lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
-  if (!windows || n < 1) return nullptr;
-  for (int i = 0; i < n; ++i) if (!windows[i]) return nullptr;
+  if (!windows || n < 1 || n > 65535) return nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (!windows[i] || windows[i]->adopted) return nullptr;
+    for (int j = 0; j < i; ++j) if (windows[j] == windows[i]) return nullptr;
+  }
   lio_est_batch *b = new lio_est_batch;
   b->members.assign(windows, windows + n);
+  for (lio_est *m : b->members) m->adopted = true;
   return b;
 }
-void lio_est_batch_destroy(lio_est_batch *b) { delete b; }
+void lio_est_batch_destroy(lio_est_batch *b) {
+  if (!b) return;
+  for (lio_est *m : b->members) m->adopted = false;
+  delete b;
+}
 int lio_est_batch_size(const lio_est_batch *b) { return b ? int(b->members.size()) : 0; }
 int lio_est_batch_solve(lio_est_batch *b, lio_solve_report *reps) {
   if (!b) return LIO_ERR_ARG;

@@ -240,3 +240,44 @@ def test_aux_row_does_not_depend_on_its_block_size(hip):
         assert (other[2] is None) == (got[0][2] is None)
         if other[2] is not None:
             np.testing.assert_array_equal(other[2]["JtJ"], got[0][2]["JtJ"])
+
+
+def test_window_beyond_the_filter_s_key_range_takes_the_single_window_path(hip, oracle):
+    """The batched VoxelGrid keys a point by 31 bits of absolute cell coordinates (z: +-255 cells); a window with a return far above
+    that (a stray point 300 m up) is handed to the single-window path inside the same call: the batch reports it as solved on the
+    host side, its neighbour in the batch stays on the device loop, and both equal what the oracle computes for them."""
+    kind, W, Wo = "indoor", 4, 2
+    ds = synth.make_dataset(kind, W + 3, 0.2)
+    clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
+    prod, orc = [], []
+    for lib, dst in ((hip, prod), (oracle, orc)):
+        for seed in (3, 5):
+            cfg = _cfg(lib, kind, W, Wo, 0, 0)
+            pipeline.set_extrinsic(cfg, ds)
+            e = capi.Estimator(lib, cfg)
+            pipeline.init_window(e, lib, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01, seed=seed)
+            dst.append(e)
+    batch = capi.EstimatorBatch(hip, prod)
+    for step in range(3):
+        if step > 0:
+            k = W + step
+            for ea, eb in zip(prod, orc):
+                force_all(ea, eb, ds)
+                _push(ea, ds, k, clouds[k][0], clouds[k][1])
+                _push(eb, ds, k, clouds[k][0], clouds[k][1])
+        if step == 2:                                        # the stray return goes into the pivot frame's stack of window 0, on both sides
+            pivot = W - Wo
+            stack = prod[0].get_surf_stack(pivot)
+            stray = np.vstack([stack, np.array([[0.5, 0.5, 300.0, stack[0, 3]]], np.float32)])
+            prod[0].set_surf_stack(pivot, stray)
+            orc[0].set_surf_stack(pivot, stray)
+        ra = batch.solve()
+        rb = [e.solve() for e in orc]
+        clk = batch.clock()
+        if step == 2:
+            assert int(clk["n_device"]) == 1, clk            # window 1 on the device loop, window 0 handed over
+        for ea, eb, a, b in zip(prod, orc, ra, rb):
+            assert a.iterations == b.iterations and a.termination == b.termination, (step, a.iterations, b.iterations)
+            assert_windows_close(ea.get_window(), eb.get_window())
+            ea.slide(); eb.slide()
+    batch.close()

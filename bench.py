@@ -532,7 +532,10 @@ def main():
         batched = None
         if args.windows and not args.shard_factors and world == 1:
             sizes = sorted({int(v) for v in str(args.windows).split(",") if int(v) > 0})
-            batched = batched_windows(hip, ds, kind, W, Wo, est, sizes, rep)
+            try:
+                batched = batched_windows(hip, ds, kind, W, Wo, est, sizes, rep)
+            except Exception as e:  # noqa: BLE001 -- an extra must not take the bench line down
+                batched = {"error": f"{type(e).__name__}: {e}"}
 
         # the rest of the estimator step a sweep triggers (Estimator::ProcessLaserOdom = push + solve + slide, Estimator.cc:430-774):
         # IMU samples of the interval, PushFrame (upload + VoxelGrid of the new surf stack + window push), SlideWindow

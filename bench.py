@@ -811,7 +811,22 @@ def batched_windows(hip, ds, kind, W, Wo, est0, sizes, rep0, min_seconds=0.4):
             steps = min(256, max(steps * 2, int(steps * 1.3 * min_seconds / max(dt, 1e-6)) + 1))
         clk = batch.clock()
         passes = reps[0].iterations + 1
-        it_same = all(r.iterations == reps[0].iterations and r.n_lidar_residuals == reps[0].n_lidar_residuals for r in reps)
+        # parity gate of the figure: the B windows are identical inputs, so every stage of every window must have left identical bits
+        # on the device (lio_est_batch_stage_digest) and identical reports; rep0 is the same window through the single-window handle
+        it_same = all((r.iterations, r.successful_steps, r.termination, r.n_lidar_residuals, r.final_cost) ==
+                      (reps[0].iterations, reps[0].successful_steps, reps[0].termination, reps[0].n_lidar_residuals, reps[0].final_cost) for r in reps)
+        differing = []
+        for s_idx, s_name in enumerate(capi.EstimatorBatch.STAGES):
+            d = batch.stage_digest(s_idx)
+            if bool((d != d[0]).any()):
+                differing.append(s_name)
+        same_as_single = (reps[0].iterations == rep0.iterations and reps[0].n_lidar_residuals == rep0.n_lidar_residuals)
+        if not it_same or differing:
+            points.append({"windows": B, "parity": "broken", "value": None, "all_windows_same_decisions": bool(it_same), "stages_that_differ_between_windows": differing,
+                           "same_decisions_as_the_single_window_handle": bool(same_as_single),
+                           "note": "identical windows disagreed: no throughput is reported for this size (tests/test_gpu_batch_scale.py pins this)"})
+            batch.close()
+            continue
 
         def stage(ms, nbytes, flops=None):
             d = {"device_ms": round(ms, 4), "algorithmic_MB": round(nbytes * B / 1e6, 2)}
@@ -827,7 +842,7 @@ def batched_windows(hip, ds, kind, W, Wo, est0, sizes, rep0, min_seconds=0.4):
         rounds = int(clk["rounds"])
         points.append({
             "windows": B, "steps": steps, "value": round(B * steps / dt, 1), "unit": "solves/s", "ms_per_batch_step": round(1e3 * dt / steps, 3),
-            "windows_on_device_loop": int(clk["n_device"]), "all_windows_same_decisions": bool(it_same),
+            "windows_on_device_loop": int(clk["n_device"]), "parity": "ok", "all_windows_same_decisions": True, "all_stage_digests_equal": True, "same_decisions_as_the_single_window_handle": bool(same_as_single),
             "solver_iterations": int(reps[0].iterations), "n_lidar_residuals": int(reps[0].n_lidar_residuals), "newest_frame_rounds": rounds,
             "host_ms": {k: round(clk[k], 3) for k in ("describe", "filter", "grid_features_rounds", "pack", "solve", "finish", "total")},
             "stages": {

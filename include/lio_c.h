@@ -499,12 +499,15 @@ int lio_est_solve_restored(lio_est *, int steps, lio_solve_report *report_or_nul
  * CalculateLaserOdom :1242-1359, ceres::Solve :1909-1990, MarginalizationInfo::Marginalize MarginalizationFactor.cc:185-311)
  * is ONE launch over all windows, the trust-region loop (ImuFactor.h:53-168 and the prior included) and the Schur-complement
  * marginalization run on the device, one workgroup per window.  A window gives the same bits alone (a batch of one) and inside
- * any batch.  Windows the device loop does not take (not initialised, convergence_flag_ still changing the problem, factor
- * sharding) are solved by the single-window path inside the same call.
+ * any batch.  Windows the device loop does not take (convergence_flag_ still changing the problem, factor sharding, a local map
+ * beyond the batched filter's key range) are solved by the single-window path inside the same call.  Every window must be
+ * initialised: lio_est_batch_solve checks all of them first and returns LIO_ERR_STATE without solving any otherwise.
  * lio_est_batch_create ADOPTS the handles: their device work moves to the batch's stream; they stay usable one at a time from the
- * thread that drives the batch (push frames, slide, snapshot / restore, getters) and must outlive the batch.  NULL on bad arguments:
- * no window, more than 65535, a null handle, a handle twice, a handle that already belongs to a batch (lio_est_batch_destroy
- * releases its members). */
+ * thread that drives the batch (push frames, slide, snapshot / restore, getters) and should outlive the batch — lio_est_destroy of
+ * an adopted handle first dissolves its batch (the other members are released; the batch handle stays valid for
+ * lio_est_batch_destroy only and every other call on it returns LIO_ERR_STATE).  NULL on bad arguments: no window, more than
+ * 65535, a null handle, a handle twice, a handle that already belongs to a batch (lio_est_batch_destroy releases its members),
+ * windows created on different devices. */
 typedef struct lio_est_batch lio_est_batch;
 lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n_windows);
 void lio_est_batch_destroy(lio_est_batch *);
@@ -524,6 +527,21 @@ int lio_est_batch_sync(lio_est_batch *);
  * the call waits for the stream): [10] filter chain, [11] K-NN grids, [12] features of the older frames, [13] newest-frame rounds,
  * [14] trust-region loop, [15] marginalization.  out: 16 doubles. */
 int lio_est_batch_get_clock(const lio_est_batch *, double *out16);
+/* Execution choices of a batch that its results do not depend on (bit for bit: tests/test_gpu_batch_scale.py), by name; value 0
+ * (occupancy: -1) = chosen by the size of the launch, the default.  "lanes_per_query" 1 | 2 | 4 | 8 (search kernels of
+ * CalculateFeatures / CalculateLaserOdom), "occupancy" 0 | 6 | 8 waves per SIMD of their one-lane-per-query forms, "loop_groups"
+ * 1 .. 4 launch chains of the trust-region loop side by side, "aux_threads" 64 | 128 | 256 threads per block of the IMU / prior
+ * row, "aux_stream" 0 | 1, "finish_threads" 1 .. 8 host threads of the write-back.  The environment variables LIO_BW_LPQ,
+ * LIO_BW_OCC, LIO_BW_GROUPS, LIO_BW_AUX_THREADS, LIO_BW_AUX_STREAM, LIO_BW_FINISH_THREADS set a new batch's defaults (read once
+ * at lio_est_batch_create).  LIO_ERR_ARG: unknown name or value.  The oracle accepts and ignores them. */
+int lio_est_batch_set_option(lio_est_batch *, const char *name, int value);
+/* Test hook: one 64-bit digest per window of what a stage of the LAST lio_est_batch_solve left on the device — stage 0 the filtered
+ * local map (Estimator.cc:1518-1519), 1 the K-NN grid (:1544-1545; points of a cell as a multiset), 2 the feature flags and
+ * 3 the plane coefficients of CalculateFeatures / CalculateLaserOdom (:970-1097, :1242-1359), 4 the newest frame's Gauss-Newton state,
+ * 5 the trust-region loop's final state (:1909-1990), 6 the final normal-equation moments, 7 the Jacobi scaling fixed at the first
+ * linearisation, 8 the scaled Hessian at the accepted point.  Equal inputs must give equal digests
+ * whatever the batch size (tests/test_gpu_batch_scale.py).  Waits for the batch.  The oracle returns zeros. */
+int lio_est_batch_stage_digest(lio_est_batch *, int stage, unsigned long long *out_n_windows);
 
 /* Multi-GPU factor sharding (the reference's own 4-thread split of ThreadsConstructA,
  * MarginalizationFactor.cc:245-269, extended across ranks): rank r of `world` evaluates only its contiguous share of

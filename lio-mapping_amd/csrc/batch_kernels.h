@@ -37,6 +37,19 @@ struct BwVoxOut { int count; VoxParams params; int range_overflow; };
 // the K-NN grid of a window (host-computed from the filter's bounds, uploaded before the cell build)
 struct BatchGrid { GridDesc g; int cell_off; int n_filtered; };
 
+// Execution choices of a batch that the results do NOT depend on (every one of them keeps the sums' orders): 0 (occupancy: -1) = by the
+// size of the launch.  They live in the batch handle (lio_est_batch_set_option); the environment variables named here only set the
+// defaults of a new batch, read once at lio_est_batch_create.
+struct BatchKnobs {
+  int lanes_per_query = 0;   // 1 / 2 / 4 / 8 lanes per query of the search kernels (LIO_BW_LPQ); by size: 1 from 400 k queries, 4 from 60 k, else 8
+  int occupancy = -1;        // 0 / 6 / 8 waves per SIMD of the one-lane-per-query kernels (LIO_BW_OCC); by default features 8, rounds as compiled
+  int loop_groups = 0;       // 1 .. 4 launch chains of the trust-region loop side by side (LIO_BW_GROUPS); by size: 2 from 32 windows
+  int aux_threads = 0;       // 64 / 128 / 256 threads per block of the aux row (LIO_BW_AUX_THREADS); by size: 64 from 128 windows per launch
+  int aux_stream = 0;        // 1: the aux row on a side stream (LIO_BW_AUX_STREAM; measured slower)
+  int finish_threads = 0;    // 1 .. 8 host threads of the write-back; by size: 4 from 128 windows
+};
+BatchKnobs batch_knobs_from_env();
+
 int bw_round_blocks(int M);   // search blocks of one round of a window's newest frame: 64 queries each, whatever the lanes per query
 
 // concat + voxel keys + per-block bounds.  keys64 / vals: loc-array sized; partial: 8 floats per 256-point block
@@ -53,9 +66,9 @@ void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int
 void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
                           const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s);
 // total_queries: stack points of the launch over all windows — picks the lanes per query (the results do not depend on it)
-void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const float4 *sorted_all,
-                        const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);
-void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, int round, OdomState *odom,
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const BatchKnobs &knobs,
+                        const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, const BatchKnobs &knobs, int round, OdomState *odom,
                           const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials,
                           int *n_converged, hipStream_t s);
 

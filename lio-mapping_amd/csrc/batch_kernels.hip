@@ -329,24 +329,31 @@ BW_FEAT_OCC(6)
 BW_FEAT_OCC(8)
 // Measured at 64 / 512 windows (profiles/r5_m_occupancy.txt): features 0.747 / 5.69 ms by the compiler's choice (84 VGPRs, 5 waves),
 // 0.709 / 5.25 at 6 waves, 0.699 / 5.02 at 8 (64 VGPRs, 84 B of spills); the rounds lose at both (0.835 / 5.98 -> 0.897 / 6.72 ->
-// 1.137 / 8.68: their fit + row phase spills 176 - 240 B).  Default: features at 8, rounds as compiled; LIO_BW_OCC = 0 / 6 / 8 forces both.
-static int bw_occ(bool features) {
-  static const int v = [] { const char *e = std::getenv("LIO_BW_OCC"); const int o = e ? std::atoi(e) : -1; return (o == 0 || o == 6 || o == 8) ? o : -1; }();
-  return v >= 0 ? v : (features ? 8 : 0);
+// 1.137 / 8.68: their fit + row phase spills 176 - 240 B).  Default: features at 8, rounds as compiled; BatchKnobs::occupancy = 0 / 6 / 8 forces both.
+static int env_int(const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+BatchKnobs batch_knobs_from_env() {
+  BatchKnobs k;
+  { const int v = env_int("LIO_BW_LPQ", 0); if (v == 1 || v == 2 || v == 4 || v == 8) k.lanes_per_query = v; }
+  { const int v = env_int("LIO_BW_OCC", -1); if (v == 0 || v == 6 || v == 8) k.occupancy = v; }
+  { const int v = env_int("LIO_BW_GROUPS", 0); if (v >= 1 && v <= 4) k.loop_groups = v; }
+  { const int v = env_int("LIO_BW_AUX_THREADS", 0); if (v == 64 || v == 128 || v == 256) k.aux_threads = v; }
+  k.aux_stream = env_int("LIO_BW_AUX_STREAM", 0) != 0 ? 1 : 0;
+  { const int v = env_int("LIO_BW_FINISH_THREADS", 0); if (v >= 1 && v <= 8) k.finish_threads = v; }
+  return k;
 }
-int bw_lanes_per_query(long long total_queries) {
-  static const int forced = [] { const char *e = std::getenv("LIO_BW_LPQ"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }();
-  if (forced) return forced;
+static int bw_occ(const BatchKnobs &k, bool features) { return k.occupancy >= 0 ? k.occupancy : (features ? 8 : 0); }
+static int bw_lanes_per_query(const BatchKnobs &k, long long total_queries) {
+  if (k.lanes_per_query) return k.lanes_per_query;
   return total_queries >= 400000 ? 1 : (total_queries >= 60000 ? 4 : 8);
 }
-void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const float4 *sorted_all,
-                        const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {
+void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const BatchKnobs &knobs,
+                        const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {
   if (B <= 0 || max_M <= 0 || max_static <= 0) return;
   const dim3 g(cdiv(max_M, 64), max_static, B);
-  switch (bw_lanes_per_query(total_queries)) {
+  switch (bw_lanes_per_query(knobs, total_queries)) {
     case 1:
-      if (bw_occ(true) == 8) hipLaunchKernelGGL(k_bw_features1_w8, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
-      else if (bw_occ(true) == 6) hipLaunchKernelGGL(k_bw_features1_w6, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+      if (bw_occ(knobs, true) == 8) hipLaunchKernelGGL(k_bw_features1_w8, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
+      else if (bw_occ(knobs, true) == 6) hipLaunchKernelGGL(k_bw_features1_w6, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
       else hipLaunchKernelGGL(k_bw_features<1>, g, dim3(64), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all);
       break;
     case 2: hipLaunchKernelGGL(k_bw_features<2>, g, dim3(128), 0, s, win, grid, sorted_all, cells_all, valid_all, coef_all, score_all); break;
@@ -408,15 +415,15 @@ __global__ void __launch_bounds__(1024) k_bw_odom_update(const BatchWin *__restr
   odom_update_wide_block(partials + size_t(W.part_off) * 28, W.nb_round, st, round, 0, 0, nullptr, HostSignal());
   if (threadIdx.x == 0 && st->converged) atomicAdd(n_converged, 1);   // (thread 0 wrote the flag itself)
 }
-void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, int round, OdomState *odom,
+void launch_bw_odom_round(const BatchWin *win, const BatchGrid *grid, int B, int max_nb, long long total_queries, const BatchKnobs &knobs, int round, OdomState *odom,
                           const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, double *partials,
                           int *n_converged, hipStream_t s) {
   if (B <= 0 || max_nb <= 0) return;
   const dim3 g(max_nb, B);
-  switch (bw_lanes_per_query(total_queries)) {
+  switch (bw_lanes_per_query(knobs, total_queries)) {
     case 1:
-      if (bw_occ(false) == 8) hipLaunchKernelGGL(k_bw_odom_round1_w8, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
-      else if (bw_occ(false) == 6) hipLaunchKernelGGL(k_bw_odom_round1_w6, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+      if (bw_occ(knobs, false) == 8) hipLaunchKernelGGL(k_bw_odom_round1_w8, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
+      else if (bw_occ(knobs, false) == 6) hipLaunchKernelGGL(k_bw_odom_round1_w6, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
       else hipLaunchKernelGGL(k_bw_odom_round<1>, g, dim3(64), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round);
       break;
     case 2: hipLaunchKernelGGL(k_bw_odom_round<2>, g, dim3(128), 0, s, win, grid, odom, sorted_all, cells_all, valid_all, coef_all, score_all, partials, round); break;

@@ -19,7 +19,7 @@ using namespace lio;
 
 struct lio_pim { std::shared_ptr<Preintegration> p; };
 // (members are destroyed in reverse order: the batch of one that serves lio_est_config.device_solve goes before the estimator it adopted)
-struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; std::unique_ptr<EstimatorBatch> solo; bool adopted = false; };
+struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; std::unique_ptr<EstimatorBatch> solo; bool adopted = false; struct lio_est_batch *owner = nullptr; };
 struct lio_est_batch { std::unique_ptr<EstimatorBatch> b; std::vector<lio_est *> members; };
 struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
@@ -609,14 +609,22 @@ lio_est *lio_est_create(const lio_est_config *c) {
     if (e.device_solve) {   // a batch of one window: the device loop and the device marginalization serve this handle's solves
       h->solo.reset(new EstimatorBatch({h->e.get()}));
       EstimatorBatch *b = h->solo.get();
-      h->e->solve_hook_ = [b](lio_solve_report *rep) { b->Solve(rep); return true; };
+      h->e->solve_hook_ = [b](lio_solve_report *rep) { b->Solve(rep); return b->window_ok(0); };
     }
     return LIO_OK;
   });
   if (rc != LIO_OK) { delete h; return nullptr; }
   return h;
 }
-void lio_est_destroy(lio_est *h) { delete h; }
+static void dissolve_batch(lio_est_batch *B);
+void lio_est_destroy(lio_est *h) {
+  if (!h) return;
+  if (h->owner) {   // destroyed before its batch: the batch goes first (it holds pointers into every member)
+    std::fprintf(stderr, "[lio_hip] lio_est_destroy: the handle is a member of a batch; the batch is dissolved\n");
+    dissolve_batch(h->owner);
+  }
+  delete h;
+}
 
 int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double gyr[3], double stamp) {
   if (!h || !acc || !gyr) return LIO_ERR_ARG;
@@ -881,26 +889,38 @@ lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
     return LIO_OK;
   });
   if (rc != LIO_OK) { delete h; return nullptr; }
-  for (int i = 0; i < n; ++i) { windows[i]->adopted = true; h->members.push_back(windows[i]); }
+  for (int i = 0; i < n; ++i) { windows[i]->adopted = true; windows[i]->owner = h; h->members.push_back(windows[i]); }
   return h;
+}
+static void dissolve_batch(lio_est_batch *B) {
+  (void)guarded([&] { B->b.reset(); return LIO_OK; });
+  for (lio_est *m : B->members) { m->adopted = false; m->owner = nullptr; }
+  B->members.clear();
 }
 void lio_est_batch_destroy(lio_est_batch *h) {
   if (!h) return;
-  h->b.reset();
-  for (lio_est *m : h->members) m->adopted = false;
+  dissolve_batch(h);
   delete h;
 }
-int lio_est_batch_size(const lio_est_batch *h) { return h ? h->b->size() : 0; }
+int lio_est_batch_size(const lio_est_batch *h) { return (h && h->b) ? h->b->size() : 0; }
 int lio_est_batch_solve(lio_est_batch *h, lio_solve_report *reps) {
   if (!h) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
   for (lio_est *m : h->members) if (!m->e->inited_) return LIO_ERR_STATE;
   return guarded([&] { h->b->Solve(reps); return LIO_OK; });
 }
+int lio_est_batch_set_option(lio_est_batch *h, const char *name, int value) {
+  if (!h || !name) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
+  return h->b->SetOption(name, value) ? LIO_OK : LIO_ERR_ARG;
+}
 int lio_est_batch_solve_restored(lio_est_batch *h, int steps, lio_solve_report *reps) {
   if (!h || steps < 0) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
   return guarded([&] {
     for (int k = 0; k < steps; ++k) {
       for (lio_est *m : h->members) if (!m->e->Restore()) return int(LIO_ERR_STATE);
+      for (lio_est *m : h->members) if (!m->e->inited_) return int(LIO_ERR_STATE);
       h->b->Solve(reps);
     }
     h->b->Sync();
@@ -909,10 +929,17 @@ int lio_est_batch_solve_restored(lio_est_batch *h, int steps, lio_solve_report *
 }
 int lio_est_batch_sync(lio_est_batch *h) {
   if (!h) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
   return guarded([&] { h->b->Sync(); return LIO_OK; });
+}
+int lio_est_batch_stage_digest(lio_est_batch *h, int stage, unsigned long long *out) {
+  if (!h || !out || stage < 0 || stage > 8) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
+  return guarded([&] { h->b->StageDigest(stage, out); return LIO_OK; });
 }
 int lio_est_batch_get_clock(const lio_est_batch *h, double *out) {
   if (!h || !out) return LIO_ERR_ARG;
+  if (!h->b) return LIO_ERR_STATE;
   BatchClock c;
   const int rc = guarded([&] { c = const_cast<lio_est_batch *>(h)->b->clock(); return LIO_OK; });
   if (rc != LIO_OK) return rc;

@@ -49,7 +49,17 @@ class EstimatorBatch {
   // waits for everything the batch has enqueued (the marginalizations of the last Solve)
   void Sync();
   const BatchClock &clock();   // waits for the batch's stream (the device stage times come from events on it)
+  // Test hook (lio_est_batch_stage_digest): a 64-bit digest per window of what stage `stage` of the LAST Solve() left on the device —
+  // 0 filtered local map (in order), 1 K-NN grid (cell table relative to the window's base + the cell-sorted points as a multiset per
+  // cell run: the placement order inside a cell is not defined), 2 feature flags, 3 plane coefficients of the set flags, 4 the newest
+  // frame's Gauss-Newton state, 5 the trust-region loop's final state, 6 the final moments partials.  Waits for the batch.
+  void StageDigest(int stage, unsigned long long *out);
   hipStream_t stream() const { return stream_; }
+  // execution choices (batch_kernels.h: BatchKnobs) by name: lanes_per_query, occupancy, loop_groups, aux_threads, aux_stream, finish_threads;
+  // false: unknown name or a value the knob does not take
+  bool SetOption(const char *name, int value);
+  const BatchKnobs &knobs() const { return knobs_; }
+  bool window_ok(int w) const { return w >= 0 && w < int(ok_.size()) && ok_[size_t(w)] != 0; }   // the last Solve() solved window w
 
  private:
   struct Slab {   // offsets (doubles) into a window's scratch slab
@@ -79,6 +89,9 @@ class EstimatorBatch {
   hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[kGroups] = {nullptr, nullptr, nullptr, nullptr},
              ev_step_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_marg_ = nullptr;
   bool marg_in_flight_ = false;
+  BatchKnobs knobs_;
+  std::vector<char> ok_;
+  int device_id_ = 0;
   hipEvent_t ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid_ = false;
   Slab lay_{};

@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <exception>
+#include <string>
 #include <thread>
 #include <cmath>
 #include <cstdlib>
@@ -17,10 +18,18 @@ static double bnow_ms() { return std::chrono::duration<double, std::milli>(std::
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 template <typename T> static void pinned(T *&p, size_t n) { LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(T) * std::max<size_t>(n, 1))); std::memset(static_cast<void *>(p), 0, sizeof(T) * std::max<size_t>(n, 1)); }
 
-EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(members) {
+EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(members), knobs_(batch_knobs_from_env()) {
   if (m_.empty()) throw std::runtime_error("EstimatorBatch: no windows");
   for (Estimator *e : m_) if (!e) throw std::runtime_error("EstimatorBatch: null window");
   const size_t B = m_.size();
+  // one device per batch: the members' buffers, this batch's streams and the kernels' per-device attributes (hipFuncSetAttribute
+  // applies to the current device only) all belong to the device the windows were created on
+  device_id_ = m_[0]->device_id_;
+  for (Estimator *e : m_) if (e->device_id_ != device_id_) throw std::runtime_error("EstimatorBatch: windows of different devices");
+  LIO_HIP(hipSetDevice(device_id_));
+  prepare_bw_step_kernel();
+  prepare_bw_marg_kernel();
+  ok_.assign(B, 0);
   LIO_HIP(hipStreamCreate(&stream_));
   for (hipEvent_t &e : ev_) LIO_HIP(hipEventCreate(&e));
   for (hipStream_t &g : stream_grp_) LIO_HIP(hipStreamCreate(&g));
@@ -78,6 +87,19 @@ EstimatorBatch::~EstimatorBatch() {
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+bool EstimatorBatch::SetOption(const char *name, int v) {
+  if (!name) return false;
+  const std::string n(name);
+  if (n == "lanes_per_query") { if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) return false; knobs_.lanes_per_query = v; }
+  else if (n == "occupancy") { if (v != -1 && v != 0 && v != 6 && v != 8) return false; knobs_.occupancy = v; }
+  else if (n == "loop_groups") { if (v < 0 || v > kGroups) return false; knobs_.loop_groups = v; }
+  else if (n == "aux_threads") { if (v != 0 && v != 64 && v != 128 && v != 256) return false; knobs_.aux_threads = v; }
+  else if (n == "aux_stream") { if (v != 0 && v != 1) return false; knobs_.aux_stream = v; }
+  else if (n == "finish_threads") { if (v < 0 || v > 8) return false; knobs_.finish_threads = v; }
+  else return false;
+  return true;
+}
+
 const BatchClock &EstimatorBatch::clock() {
   if (ev_valid_) {
     LIO_HIP(hipStreamSynchronize(stream_));
@@ -113,6 +135,100 @@ void EstimatorBatch::Materialize(int w, int buf) {
   std::shared_ptr<MargPrior> &p = win_[w].dev_prior[buf];
   if (p && p->on_device && p.use_count() > 1) p->materialize();
   p.reset();
+}
+
+// ---- test hook: per-window digests of a stage's device arrays (est_batch.h)
+static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h = 1469598103934665603ull) {
+  const unsigned char *b = static_cast<const unsigned char *>(p);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+static unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+template <typename T> static std::vector<T> fetch(const T *d, size_t n) {
+  std::vector<T> h(std::max<size_t>(n, 1));
+  if (n) LIO_HIP(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+  return h;
+}
+void EstimatorBatch::StageDigest(int stage, unsigned long long *out) {
+  Sync();
+  for (hipStream_t g : stream_grp_) LIO_HIP(hipStreamSynchronize(g));
+  const int B = size();
+  for (int w = 0; w < B; ++w) {
+    const BatchWin &bw = h_win_[w];
+    const BatchGrid &G = h_grid_[w];
+    unsigned long long h = 0;
+    switch (stage) {
+      case 0: {
+        const std::vector<float4> p = fetch(filtered_all_.p + bw.loc_off, size_t(G.n_filtered));
+        h = fnv1a(p.data(), size_t(G.n_filtered) * sizeof(float4), mix64(G.n_filtered));
+        break;
+      }
+      case 1: {
+        size_t ncells = size_t(G.g.dims[0]) * G.g.dims[1] * G.g.dims[2];
+        const std::vector<int> c = fetch(cells_all_.p + G.cell_off, ncells + 1);
+        const std::vector<float4> p = fetch(sorted_all_.p + c[0], size_t(G.n_filtered));
+        h = mix64(ncells);
+        for (size_t k = 0; k < ncells; ++k) {
+          unsigned long long run = 0;   // a cell's points as a multiset
+          for (int j = c[k] - c[0]; j < c[k + 1] - c[0]; ++j) run += mix64(fnv1a(&p[size_t(j)], sizeof(float4)));
+          const int rel[2] = {c[k] - c[0], c[k + 1] - c[0]};
+          if (rel[1] != rel[0]) h = mix64(h ^ fnv1a(rel, sizeof(rel)) ^ run ^ mix64(k));
+        }
+        break;
+      }
+      case 2: {
+        const std::vector<uint8_t> v = fetch(valid_all_.p + bw.slot_base, size_t(bw.n_slots));
+        h = fnv1a(v.data(), size_t(bw.n_slots), mix64(bw.n_slots));
+        break;
+      }
+      case 3: {
+        const std::vector<uint8_t> v = fetch(valid_all_.p + bw.slot_base, size_t(bw.n_slots));
+        const std::vector<float4> c = fetch(coef_all_.p + bw.slot_base, size_t(bw.n_slots));
+        h = mix64(bw.n_slots);
+        for (int k = 0; k < bw.n_slots; ++k) if (v[size_t(k)]) h = fnv1a(&c[size_t(k)], sizeof(float4), h ^ mix64(k));
+        break;
+      }
+      case 4: { const std::vector<OdomState> o = fetch(d_odom_.p + w, 1); h = fnv1a(o.data(), sizeof(OdomState)); break; }
+      case 5: { const std::vector<DevState> o = fetch(d_st_.p + w, 1); h = fnv1a(o.data(), sizeof(DevState)); break; }
+      case 8: {   // scaled H at the accepted point (upper triangle), + on stderr whether it is positive definite
+        const DevProblem &pb = h_pb_[w];
+        const int n = pb.n, ld = pb.ld;
+        const std::vector<double> Hc = fetch(slab_.p + size_t(w) * lay_.total + lay_.Hcur, size_t(pb.n_pad) * ld);
+        h = mix64(n);
+        std::vector<double> M(size_t(n) * n);
+        for (int r = 0; r < n; ++r) { h = fnv1a(&Hc[size_t(r) * ld + r], sizeof(double) * (n - r), h); for (int c = r; c < n; ++c) M[size_t(r) * n + c] = M[size_t(c) * n + r] = Hc[size_t(r) * ld + c]; }
+        if (std::getenv("LIO_DEBUG_DIGEST")) {
+          int bad = -1; double dmin = 1e300, dmax = 0; bool finite = true;
+          for (double v : M) if (!std::isfinite(v)) finite = false;
+          for (int j = 0; j < n && bad < 0; ++j) {   // plain Cholesky of H + 1e-8 diag(H)
+            double d = M[size_t(j) * n + j] * (1.0 + 1e-8);
+            for (int k = 0; k < j; ++k) d -= M[size_t(j) * n + k] * M[size_t(j) * n + k];
+            if (!(d > 0)) { bad = j; break; }
+            dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+            const double l = std::sqrt(d);
+            M[size_t(j) * n + j] = l;
+            for (int r = j + 1; r < n; ++r) { double v = M[size_t(r) * n + j]; for (int k = 0; k < j; ++k) v -= M[size_t(r) * n + k] * M[size_t(j) * n + k]; M[size_t(r) * n + j] = v / l; }
+          }
+          std::fprintf(stderr, "[digest] window %d: H_cur %016llx finite %d cholesky %s (pivot %d) pivots in [%.3e, %.3e]\n", w, h, int(finite), bad < 0 ? "ok" : "FAILS", bad, dmin, dmax);
+        }
+        break;
+      }
+      case 7: { const std::vector<DevState> o = fetch(d_st_.p + w, 1); h = fnv1a(o[0].scale, sizeof(o[0].scale)); break; }
+      case 6: {
+        const Win &Wn = win_[w];
+        const size_t n = Wn.device ? size_t(Wn.e->Wo_) * Wn.bpf * LIO_MOMENT_OUT : 0;
+        const std::vector<double> o = fetch(partials_.p + Wn.part_off, n);
+        h = mix64(n);
+        for (size_t r = 0; r + LIO_MOMENT_OUT <= n; r += LIO_MOMENT_OUT) h = fnv1a(o.data() + r, 258 * sizeof(double), h);   // (the last two words of a row are never written)
+        break;
+      }
+      default: throw std::runtime_error("EstimatorBatch::StageDigest: unknown stage");
+    }
+    out[w] = h;
+  }
 }
 
 int EstimatorBatch::Solve(lio_solve_report *reps) {
@@ -224,11 +340,11 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   launch_bw_cell_place(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cells_all_.p, sorted_all_.p, cnt_all_.p, s);
   cnt_dirty_ = false;
   LIO_HIP(hipEventRecord(ev_[2], s));
-  launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, q_static, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
+  launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, q_static, knobs_, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
   LIO_HIP(hipEventRecord(ev_[3], s));
   int round = 0;
   for (; round < 3; ++round)
-    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, knobs_, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
                          nconv_.p, s);
   // ---- while the device searches: the problems of Estimator.cc:1660-1921, packed for the device loop.  Their uploads overwrite
   // what the previous solve's marginalization (on its own stream) still reads: everything enqueued from here on waits for it —
@@ -282,7 +398,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
       LIO_HIP(hipStreamSynchronize(s));
       if (*h_nconv_ >= B) break;
     }
-    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
+    launch_bw_odom_round(d_win_.p, d_grid_.p, B, max_nb, q_newest, knobs_, round, d_odom_.p, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, odom_partials_.p,
                          nconv_.p, s);
   }
   clk_.rounds = round;
@@ -326,13 +442,11 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   if (n_dev > 0) {
     // iteration k evaluates candidate k (k = 0: the initial point); a window that is done costs its blocks one load each.
     // Groups of windows run their chains side by side (see est_batch.h); one group below 32 windows.
-    static const int g_env = [] { const char *e = std::getenv("LIO_BW_GROUPS"); const int v = e ? std::atoi(e) : 0; return (v >= 1 && v <= kGroups) ? v : 0; }();
-    const int G = g_env ? std::min(g_env, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
-    // LIO_BW_AUX_STREAM=1: the aux row on a side stream beside the moments.  Measured slower on the MI355X (two events per iteration cost
+    const int G = knobs_.loop_groups ? std::min(knobs_.loop_groups, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
+    // knobs_.aux_stream: the aux row on a side stream beside the moments.  Measured slower on the MI355X (two events per iteration cost
     // more than the 41 us they hide: loop 2.92 ms against 2.68 at 64 windows, profiles/r5_e_aux_stream_ab_and_step_phases.txt): off.
     const BatchBases bases{slab_.p, partials_.p, d_st_.p, d_pb_.p, d_mg_.p};
-    static const int aux_env = [] { const char *e = std::getenv("LIO_BW_AUX_STREAM"); return e ? std::atoi(e) : 0; }();
-    const bool side_aux = aux_env != 0;
+    const bool side_aux = knobs_.aux_stream != 0;
     static const int prof_it = [] { const char *e = std::getenv("LIO_DEBUG_TIMING_IT"); return e ? std::atoi(e) : 3; }();
     if (G > 1 || side_aux) LIO_HIP(hipEventRecord(ev_fork_, s));
     for (int g = 0; g < G; ++g) {
@@ -351,14 +465,14 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
           const BatchSolve *gb = d_bs_.p + w0;
           if (side_aux) {   // aux row beside the moments; the step kernel joins the two
             LIO_HIP(hipStreamWaitEvent(sa, k == 0 ? ev_fork_ : ev_step_[g], 0));
-            launch_bw_aux(gb, bases, w1 - w0, g_wo, sa);
+            launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sa);
             LIO_HIP(hipEventRecord(ev_aux_[g], sa));
             launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
             LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
             launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
             if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
           } else {
-            launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, valid_all_.p, coef_all_.p, sg);
+            launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, knobs_.aux_threads, valid_all_.p, coef_all_.p, sg);
           }
           if (h_bs_[0].prof && w0 == 0 && k == prof_it)   // LIO_DEBUG_TIMING: keep the stamps of this iteration's launch B beside the last one's
             LIO_HIP(hipMemcpyAsync(h_bs_[0].prof + 32, h_bs_[0].prof, 32 * sizeof(long long), hipMemcpyDeviceToDevice, sg));
@@ -404,7 +518,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     }
   };
   {
-    const int T = B >= 128 ? 4 : 1;
+    const int T = knobs_.finish_threads ? std::min(knobs_.finish_threads, B) : (B >= 128 ? 4 : 1);
     if (T == 1) {
       finish_range(0, B);
     } else {
@@ -449,7 +563,8 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   const double t5 = bnow_ms();
   clk_.finish = t5 - t4;
   // ------------------------------------------------------------------------------------------------ windows the device loop did not take
-  for (int w : host_path) win_[w].e->SolveOptimizationHost(&reps[w]);
+  for (int w = 0; w < B; ++w) ok_[size_t(w)] = 1;
+  for (int w : host_path) ok_[size_t(w)] = win_[w].e->SolveOptimizationHost(&reps[w]) ? 1 : 0;
   const double t6 = bnow_ms();
   clk_.fallback = t6 - t5;
   clk_.total = t6 - t0;

@@ -32,6 +32,7 @@ class MargSchurDev {
 // Marginalization of every window of a batch on `s` (two launches; BatchSolve: solve_step.h); the new priors stay on the device
 struct BatchSolve;
 struct BatchBases;
+void prepare_bw_marg_kernel();   // per device, before the first launch_bw_marginalize on it
 void launch_bw_marginalize(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_n, hipStream_t s);
 
 }  // namespace lio

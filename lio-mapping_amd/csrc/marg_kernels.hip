@@ -347,13 +347,11 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
   }
 }
 
+void prepare_bw_marg_kernel() {   // per device (EstimatorBatch's constructor)
+  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, int(marg_lds_bytes(MARG_MAX_N))));
+}
 void launch_bw_marginalize(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_n, hipStream_t s) {
   if (B <= 0) return;
-  static const bool attr_set = [] {
-    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_marg_schur), hipFuncAttributeMaxDynamicSharedMemorySize, int(marg_lds_bytes(MARG_MAX_N))));
-    return true;
-  }();
-  (void)attr_set;
   hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_THREADS), 0, s, bs, bb);
   const size_t lds = std::max(marg_lds_doubles(max_n), size_t(max_wo) * (344 + 234)) * sizeof(double);
   hipLaunchKernelGGL(k_bw_marg_schur, dim3(B), dim3(MARG_THREADS), lds, s, bs, bb, 1e-8);

@@ -82,10 +82,12 @@ void launch_lidar_moments_batched(const MomentFrame *d_frames, int nframes, int 
 struct BatchSolve;
 struct BatchBases;
 // the three launches of an iteration one by one (the aux row depends on the candidate only: it can run beside the moments on a stream of its own)
-void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, hipStream_t s);
+void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int threads_or_0, hipStream_t s);
 void launch_bw_moments(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, const uint8_t *valid, const float4 *coef, hipStream_t s);
+void prepare_bw_step_kernel();   // per device, before the first launch_bw_step on it
 void launch_bw_step(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_npad, hipStream_t s);
-void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef, hipStream_t s);
+void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, int aux_threads_or_0, const uint8_t *valid, const float4 *coef,
+                               hipStream_t s);
 // blocks per frame of a window's moments pass inside a batch: a function of the window's own slot counts only
 int batch_blocks_per_frame(int max_slots);
 

@@ -854,14 +854,12 @@ int ldlt_solve_device(const double *A, const double *b, int n, double *xh, hipSt
   return ok;
 }
 
-void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, hipStream_t s) {
+void launch_bw_aux(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int forced, hipStream_t s) {
   if (B <= 0) return;
   // Threads per block follow the size of the launch (the results do not depend on it: every sum of the aux row has a fixed order).
   // The kernel holds 256 VGPRs, so a CU runs two 256-thread blocks or eight one-wave blocks: at 256 windows per launch the 1536
   // blocks took 334 us in six rounds (profiles/r5_final3_batch512_kernel_stats.md); one wave per block keeps them all resident.
   // A small launch is a latency chain and wants the four serial jobs of an IMU factor on four waves.
-  const char *e = std::getenv("LIO_BW_AUX_THREADS");   // (read per launch: tests/test_gpu_batch.py switches it between two solves)
-  const int forced = e ? std::atoi(e) : 0;
   const int threads = (forced == 64 || forced == 128 || forced == 256) ? forced : (B >= 128 ? 64 : MOMENT_THREADS);
   hipLaunchKernelGGL(k_bw_aux, dim3(max_wo + 1, B), dim3(threads), 0, s, bs, bb);
 }
@@ -869,20 +867,19 @@ void launch_bw_moments(const BatchSolve *bs, const BatchBases &bb, int B, int ma
   if (B <= 0) return;
   hipLaunchKernelGGL(k_bw_moments, dim3(max_bpf, max_wo, B), dim3(MOMENT_THREADS), 0, s, bs, bb, valid, coef);
 }
+// the step kernel's dynamic-LDS limit on the CURRENT device (hipFuncSetAttribute is per device): every EstimatorBatch calls it for its own
+void prepare_bw_step_kernel() {
+  LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
 void launch_bw_step(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_npad, hipStream_t s) {
   if (B <= 0) return;
-  static const bool attr_set = [] {
-    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bw_solve_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    return true;
-  }();
-  (void)attr_set;
-  const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);
+  const size_t lds = ds_lds_doubles(max_npad, max_wo) * sizeof(double);   // (above 64 KB: prepare_bw_step_kernel on this device, EstimatorBatch's constructor)
   hipLaunchKernelGGL(k_bw_solve_step, dim3(B), dim3(DS_THREADS), lds, s, bs, bb);
   LIO_HIP(hipGetLastError());
 }
-void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, const uint8_t *valid, const float4 *coef,
+void launch_bw_solve_iteration(const BatchSolve *bs, const BatchBases &bb, int B, int max_bpf, int max_wo, int max_npad, int aux_threads, const uint8_t *valid, const float4 *coef,
                                hipStream_t s) {
-  launch_bw_aux(bs, bb, B, max_wo, s);
+  launch_bw_aux(bs, bb, B, max_wo, aux_threads, s);
   launch_bw_moments(bs, bb, B, max_bpf, max_wo, valid, coef, s);
   launch_bw_step(bs, bb, B, max_wo, max_npad, s);
 }

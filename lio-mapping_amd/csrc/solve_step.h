@@ -871,7 +871,11 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
   x.stamp(B.prof, 6);
   // ---- P7: the minimizer loop up to the next candidate (TrustRegionMinimizer::Minimize + DoglegStrategy::ComputeStep)
   for (int guard = 0; guard < 64; ++guard) {
-    if (x.tid == 0) {
+    // Thread 0 owns the control block; every other thread only reads it, and between such a read and thread 0's next write of the
+    // same word lies a barrier.  (Round 6: two places broke that rule — C.reuse was set right behind the test below, C.done behind the
+    // test at the loop's end — and a wave delayed by blocks of another stream sharing its SIMD read the NEW value, took the other branch
+    // and met the workgroup's barriers out of step: windows diverged at random once two loop groups ran side by side.)
+    if (x.tid == 0 && !C.done) {   // (done: five invalid steps in a row, set at the end of the previous pass)
       if (C.it >= pb.max_iterations) { C.termination = 0; C.done = 1; }
       else if (C.gmax <= 1e-10) { C.termination = 3; C.done = 1; }
       else if (C.radius <= 1e-32) { C.termination = 1; C.done = 1; }
@@ -881,7 +885,6 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     if (C.done) break;
     bool h_in_lds = C.a_valid != 0;   // H of the current point: in LDS, or only in global memory (LDS holds a rejected candidate's)
     if (!C.reuse) {
-      if (x.tid == 0) { C.reuse = 1; C.lin_ok = 0; }
       if (!h_in_lds) {   // a linearisation is needed at the accepted point but LDS holds a rejected candidate: reload
         for (int r = trow; r < npad; r += rstep)
           for (int c = tcol; c < npad; c += CW) {
@@ -906,6 +909,7 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
         L.diag[i] = dg; L.grad[i] = gr; L.tmp[i] = tt;
       }
       x.sync_lds();
+      if (x.tid == 0) { C.reuse = 1; C.lin_ok = 0; }   // (behind the barrier: every thread has tested C.reuse; lin_ok is read behind the next one)
       if (h_in_lds) ds_vHv(x, A, ld, L.hdiag, n, L.tmp, gq[1]); else ds_vHv(x, B.Hcur, ld, L.hdiag, n, L.tmp, gq[1]);   // (two calls: an LDS pointer and a global one, never a flat access)
       block_sum<X, 2>(x, L.red, gq);
       if (x.tid == 0) C.alpha = gq[0] / gq[1];
@@ -1004,12 +1008,10 @@ LIO_HD void solve_step(const X &x, const DevProblem &pb, DevState &st, const Ste
     } else if (x.tid == 0) C.valid_step = 0;
     x.sync_lds();
     if (C.valid_step) break;
-    if (x.tid == 0) {
+    if (x.tid == 0) {   // (the others read nothing of this before the barrier at the top of the next pass, which also ends the loop when done)
       if (++C.invalid >= 5) { C.termination = 5; C.done = 1; }
       else { C.mu *= 10.0; C.reuse = 0; if (st.ntrace < 40) st.trace[st.ntrace++] = C.x_cost; }
     }
-    x.sync_lds();
-    if (C.done) break;
   }
   x.sync_lds();
   x.stamp(B.prof, 12);

@@ -242,6 +242,8 @@ _SIGS = {
     "lio_est_batch_solve_restored": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SolveReport)]),
     "lio_est_batch_sync": (C.c_int, [C.c_void_p]),
     "lio_est_batch_get_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "lio_est_batch_stage_digest": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "lio_est_batch_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lio_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lio_rccl_init": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
@@ -1020,6 +1022,18 @@ class EstimatorBatch:
 
     def sync(self):
         _chk(self.lib.dll.lio_est_batch_sync(self.h), "lio_est_batch_sync")
+
+    STAGES = ("filtered_map", "knn_grid", "feature_flags", "plane_coefficients", "newest_frame_state", "solver_state", "moments", "jacobi_scaling", "scaled_hessian")
+
+    def set_option(self, name, value):
+        """an execution choice of the batch (lio_est_batch_set_option): results do not depend on it"""
+        _chk(self.lib.dll.lio_est_batch_set_option(self.h, name.encode(), int(value)), f"lio_est_batch_set_option({name}, {value})")
+
+    def stage_digest(self, stage):
+        """one 64-bit digest per window of what stage `stage` (index into STAGES) of the last solve left on the device"""
+        out = (C.c_ulonglong * len(self.members))()
+        _chk(self.lib.dll.lio_est_batch_stage_digest(self.h, int(stage), out), "lio_est_batch_stage_digest")
+        return np.array(list(out), dtype=np.uint64)
 
     def clock(self):
         out = (C.c_double * 16)()

@@ -23,6 +23,7 @@ struct lio_est {
   std::unique_ptr<Estimator> snap;
   PointMapping map;  // the PointMapping base of the reference's Estimator (Estimator.h:110)
   bool adopted = false;   // member of a lio_est_batch (a handle is in at most one)
+  struct lio_est_batch *owner = nullptr;
   explicit lio_est(const EstimatorConfig &c, const MappingConfig &m) : est(c), map(m) {}
 };
 
@@ -500,7 +501,11 @@ lio_est *lio_est_create(const lio_est_config *c) {
   m.min_match_sq_dis = c->min_match_sq_dis; m.min_plane_dis = c->min_plane_dis;
   return new (std::nothrow) lio_est(e, m);
 }
-void lio_est_destroy(lio_est *h) { delete h; }
+static void dissolve_batch(struct lio_est_batch *b);
+void lio_est_destroy(lio_est *h) {
+  if (h && h->owner) dissolve_batch(h->owner);   // (include/lio_c.h: an adopted handle's batch is dissolved first)
+  delete h;
+}
 
 int lio_est_process_imu(lio_est *h, double dt, const double acc[3], const double gyr[3], double stamp) {
   if (!h || !acc || !gyr) return LIO_ERR_ARG;
@@ -776,7 +781,7 @@ int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
 }
 
 // lio_est_batch (include/lio_c.h): the oracle has one way to solve a window; a batch is a loop over its members
-struct lio_est_batch { std::vector<lio_est *> members; };
+struct lio_est_batch { std::vector<lio_est *> members; bool dissolved = false; };
 lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
   if (!windows || n < 1 || n > 65535) return nullptr;
   for (int i = 0; i < n; ++i) {
@@ -785,17 +790,24 @@ lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
   }
   lio_est_batch *b = new lio_est_batch;
   b->members.assign(windows, windows + n);
-  for (lio_est *m : b->members) m->adopted = true;
+  for (lio_est *m : b->members) { m->adopted = true; m->owner = b; }
   return b;
+}
+static void dissolve_batch(lio_est_batch *b) {
+  for (lio_est *m : b->members) { m->adopted = false; m->owner = nullptr; }
+  b->members.clear();
+  b->dissolved = true;
 }
 void lio_est_batch_destroy(lio_est_batch *b) {
   if (!b) return;
-  for (lio_est *m : b->members) m->adopted = false;
+  dissolve_batch(b);
   delete b;
 }
 int lio_est_batch_size(const lio_est_batch *b) { return b ? int(b->members.size()) : 0; }
 int lio_est_batch_solve(lio_est_batch *b, lio_solve_report *reps) {
   if (!b) return LIO_ERR_ARG;
+  if (b->dissolved) return LIO_ERR_STATE;
+  for (lio_est *m : b->members) if (!m->est.inited) return LIO_ERR_STATE;   // (checked up front, as the product does: nothing is solved then)
   for (size_t w = 0; w < b->members.size(); ++w) {
     const int rc = lio_est_solve_optimization(b->members[w], reps ? reps + w : nullptr);
     if (rc != LIO_OK) return rc;
@@ -804,6 +816,7 @@ int lio_est_batch_solve(lio_est_batch *b, lio_solve_report *reps) {
 }
 int lio_est_batch_solve_restored(lio_est_batch *b, int steps, lio_solve_report *reps) {
   if (!b || steps < 0) return LIO_ERR_ARG;
+  if (b->dissolved) return LIO_ERR_STATE;
   for (int k = 0; k < steps; ++k) {
     for (lio_est *m : b->members) { const int rc = lio_est_restore(m); if (rc != LIO_OK) return rc; }
     const int rc = lio_est_batch_solve(b, reps);
@@ -811,9 +824,24 @@ int lio_est_batch_solve_restored(lio_est_batch *b, int steps, lio_solve_report *
   }
   return LIO_OK;
 }
-int lio_est_batch_sync(lio_est_batch *b) { return b ? LIO_OK : LIO_ERR_ARG; }
+int lio_est_batch_sync(lio_est_batch *b) { return b ? (b->dissolved ? LIO_ERR_STATE : LIO_OK) : LIO_ERR_ARG; }
+int lio_est_batch_set_option(lio_est_batch *b, const char *name, int value) {   // execution choices of the product: accepted, ignored
+  if (!b || !name) return LIO_ERR_ARG;
+  if (b->dissolved) return LIO_ERR_STATE;
+  (void)value;
+  for (const char *k : {"lanes_per_query", "occupancy", "loop_groups", "aux_threads", "aux_stream", "finish_threads"})
+    if (std::strcmp(name, k) == 0) return LIO_OK;
+  return LIO_ERR_ARG;
+}
+int lio_est_batch_stage_digest(lio_est_batch *b, int stage, unsigned long long *out) {
+  if (!b || !out || stage < 0 || stage > 8) return LIO_ERR_ARG;
+  if (b->dissolved) return LIO_ERR_STATE;
+  for (size_t w = 0; w < b->members.size(); ++w) out[w] = 0;
+  return LIO_OK;
+}
 int lio_est_batch_get_clock(const lio_est_batch *b, double *out) {
   if (!b || !out) return LIO_ERR_ARG;
+  if (b->dissolved) return LIO_ERR_STATE;
   for (int k = 0; k < 16; ++k) out[k] = 0.0;
   return LIO_OK;
 }

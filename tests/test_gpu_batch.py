@@ -202,36 +202,46 @@ def test_batch_arguments(hip):
         capi.EstimatorBatch(hip, [b])             # already adopted
     with pytest.raises(capi.LioError):
         batch.solve()                             # not initialised
+    batch.set_option("loop_groups", 2)
+    with pytest.raises(capi.LioError):
+        batch.set_option("no_such_option", 1)
+    with pytest.raises(capi.LioError):
+        batch.set_option("aux_threads", 100)
     batch.close()
     capi.EstimatorBatch(hip, [a]).close()         # released by the batch that is gone: adoptable again
+    # a member destroyed before its batch: the batch is dissolved (no dangling pointer), the other member is free again
+    batch = capi.EstimatorBatch(hip, [a, b])
+    hip.dll.lio_est_destroy(b.h)
+    b.h = None
+    assert len(batch) == 0
+    with pytest.raises(capi.LioError):
+        batch.solve()
+    capi.EstimatorBatch(hip, [a]).close()
+    batch.close()
 
 
 def test_aux_row_does_not_depend_on_its_block_size(hip):
     """launch A's aux row (IMU factors, priors) runs 256 threads per block in small launches and one wave per block from 128 windows
-    per launch on: the same window solved with either (LIO_BW_AUX_THREADS is read per launch) gives the same bits — what makes a
-    window in a batch of 512 equal to the window alone."""
-    import os
+    per launch on: the same window solved with either (lio_est_batch_set_option "aux_threads") gives the same bits — what makes a
+    window in a batch of 512 equal to the window alone.  (All execution choices together: tests/test_gpu_batch_scale.py.)"""
     kind, W, Wo = "indoor", 5, 2
     ds = synth.make_dataset(kind, W + 4, 0.2)
     clouds = [pipeline.feature_clouds(hip, ds.lidar, f.scan) for f in ds.frames]
-    cfg = _cfg(hip, kind, W, Wo, 0, 0, device_solve=1)
+    cfg = _cfg(hip, kind, W, Wo, 0, 0)
     pipeline.set_extrinsic(cfg, ds)
     est = capi.Estimator(hip, cfg)
     pipeline.init_window(est, hip, ds, [c[0] for c in clouds], pos_sigma=0.01, rot_sigma=0.001, vel_sigma=0.01, seed=5)
-    est.solve(); est.slide()
+    batch = capi.EstimatorBatch(hip, [est])
+    batch.solve(); est.slide()
     _push(est, ds, W + 1, clouds[W + 1][0], clouds[W + 1][1])
-    est.solve(); est.slide()                                     # (the device loop has a prior from here on)
+    batch.solve(); est.slide()                                   # (the device loop has a prior from here on)
     _push(est, ds, W + 2, clouds[W + 2][0], clouds[W + 2][1])
     est.snapshot()
     got = []
-    try:
-        for threads in ("256", "64", "128"):
-            os.environ["LIO_BW_AUX_THREADS"] = threads
-            est.restore()
-            rep = est.solve()
-            got.append((_rep_key(rep), est.get_window(), est.prior()))
-    finally:
-        os.environ.pop("LIO_BW_AUX_THREADS", None)
+    for threads in (256, 64, 128):
+        batch.set_option("aux_threads", threads)
+        rep = batch.solve_restored(1)[0]
+        got.append((_rep_key(rep), est.get_window(), est.prior()))
     assert got[0][0][0] >= 1
     for other in got[1:]:
         assert other[0] == got[0][0]
@@ -240,6 +250,7 @@ def test_aux_row_does_not_depend_on_its_block_size(hip):
         assert (other[2] is None) == (got[0][2] is None)
         if other[2] is not None:
             np.testing.assert_array_equal(other[2]["JtJ"], got[0][2]["JtJ"])
+    batch.close()
 
 
 def test_window_beyond_the_filter_s_key_range_takes_the_single_window_path(hip, oracle):

@@ -50,6 +50,37 @@ def test_batch_arguments(oracle):
     capi.EstimatorBatch(oracle, [a]).close()           # released by the batch that is gone: adoptable again
 
 
+def test_batch_contract_shared_with_the_product(oracle):
+    """What include/lio_c.h promises on the error paths, identically in both libraries (the product's side: tests/test_gpu_batch.py::
+    test_batch_arguments): an uninitialised member -> LIO_ERR_STATE before ANY window is solved; options by name; a member destroyed
+    before its batch dissolves the batch instead of leaving it with a dangling pointer."""
+    a, b = _estimators(oracle, (1, 2))
+    ds = synth.make_dataset("indoor", 7, 0.2)
+    cfg = pipeline.config_indoor(oracle, 4, 2)
+    pipeline.set_extrinsic(cfg, ds)
+    fresh = capi.Estimator(oracle, cfg)                # never initialised
+    before = a.get_window()
+    batch = capi.EstimatorBatch(oracle, [a, fresh, b])
+    with pytest.raises(capi.LioError):
+        batch.solve()
+    for key in ("Ps", "Rs", "Vs"):
+        np.testing.assert_array_equal(a.get_window()[key], before[key])   # member 0 was NOT solved
+    batch.set_option("lanes_per_query", 1)
+    batch.set_option("loop_groups", 2)
+    with pytest.raises(capi.LioError):
+        batch.set_option("no_such_option", 1)
+    # destroying a member first: the batch is dissolved, its other members are free again, the batch handle only accepts destroy
+    oracle.dll.lio_est_destroy(fresh.h)
+    fresh.h = None
+    with pytest.raises(capi.LioError):
+        batch.solve()
+    assert len(batch) == 0
+    other = capi.EstimatorBatch(oracle, [a, b])        # released
+    assert len(other.solve()) == 2
+    other.close()
+    batch.close()
+
+
 def test_point_processor_batch_equals_one_by_one(oracle):
     ds = synth.make_dataset("indoor", 3, 0.1)
     lid = ds.lidar

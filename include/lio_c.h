@@ -539,7 +539,8 @@ int lio_est_batch_set_option(lio_est_batch *, const char *name, int value);
  * local map (Estimator.cc:1518-1519), 1 the K-NN grid (:1544-1545; points of a cell as a multiset), 2 the feature flags and
  * 3 the plane coefficients of CalculateFeatures / CalculateLaserOdom (:970-1097, :1242-1359), 4 the newest frame's Gauss-Newton state,
  * 5 the trust-region loop's final state (:1909-1990), 6 the final normal-equation moments, 7 the Jacobi scaling fixed at the first
- * linearisation, 8 the scaled Hessian at the accepted point.  Equal inputs must give equal digests
+ * linearisation, 8 the scaled Hessian at the accepted point, 9 the prior the
+ * marginalization left on the device (MarginalizationFactor.cc:185-311).  Equal inputs must give equal digests
  * whatever the batch size (tests/test_gpu_batch_scale.py).  Waits for the batch.  The oracle returns zeros. */
 int lio_est_batch_stage_digest(lio_est_batch *, int stage, unsigned long long *out_n_windows);
 

@@ -933,7 +933,7 @@ int lio_est_batch_sync(lio_est_batch *h) {
   return guarded([&] { h->b->Sync(); return LIO_OK; });
 }
 int lio_est_batch_stage_digest(lio_est_batch *h, int stage, unsigned long long *out) {
-  if (!h || !out || stage < 0 || stage > 8) return LIO_ERR_ARG;
+  if (!h || !out || stage < 0 || stage > 9) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
   return guarded([&] { h->b->StageDigest(stage, out); return LIO_OK; });
 }

@@ -57,7 +57,7 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   lay_.Hcur = take(size_t(DS_MAX_NPAD) * (DS_MAX_NPAD + 1)); lay_.Sbuf = take(size_t(2) * DS_MAX_WO * LIO_MOMENT_OUT); lay_.prof = take(96);
   lay_.marg_imu = take(DS_IMU_OUT); lay_.marg_lmap = take(size_t(DS_MAX_WO) * DS_LMAP_OUT); lay_.marg_prior_out = take(MARG_MAX_N + 8);
   { const size_t N = MARG_MAX_M + MARG_MAX_N; lay_.marg_A = take(N * N + N); }
-  lay_.marg_info = take(MARG_MAX_N + 8);
+  lay_.marg_info = take(MARG_MAX_N + 8 + 16);   // sweeps (2) | eigenvalues | 8 phase stamps | 4 per-phase sums of the eigensolver (LIO_MARG_PROF builds)
   lay_.total = o;
   slab_.reserve(B * lay_.total);
   LIO_HIP(hipMemsetAsync(slab_.p, 0, sizeof(double) * slab_.cap, stream_));
@@ -214,6 +214,18 @@ void EstimatorBatch::StageDigest(int stage, unsigned long long *out) {
           }
           std::fprintf(stderr, "[digest] window %d: H_cur %016llx finite %d cholesky %s (pivot %d) pivots in [%.3e, %.3e]\n", w, h, int(finite), bad < 0 ? "ok" : "FAILS", bad, dmin, dmax);
         }
+        break;
+      }
+      case 9: {   // marginalization: sweeps and phase stamps of the last launch (stderr under LIO_DEBUG_DIGEST); digest of the new prior
+        const std::vector<double> mi = fetch(slab_.p + size_t(w) * lay_.total + lay_.marg_info, MARG_MAX_N + 24);
+        const std::vector<double> pm = fetch(slab_.p + size_t(w) * lay_.total + lay_.prior[1 - win_[w].cur], ds_prior_mats_size(h_mg_[w].n));
+        h = fnv1a(pm.data(), pm.size() * sizeof(double), mix64(h_mg_[w].n));
+        if (std::getenv("LIO_DEBUG_DIGEST") && (w == 0 || w == B - 1))
+          std::fprintf(stderr, "[digest] window %d marginalization: m %d n %d sweeps %g / %g; shader clocks: assembly %.0f, Amm eig %.0f, pinv + T + S %.0f, S eig %.0f, factors out %.0f, J^T J %.0f\n",
+                       w, h_mg_[w].m, h_mg_[w].n, mi[0], mi[1], mi[MARG_MAX_N + 9] - mi[MARG_MAX_N + 8], mi[MARG_MAX_N + 10] - mi[MARG_MAX_N + 9], mi[MARG_MAX_N + 11] - mi[MARG_MAX_N + 10], mi[MARG_MAX_N + 12] - mi[MARG_MAX_N + 11],
+                       mi[MARG_MAX_N + 13] - mi[MARG_MAX_N + 12], mi[MARG_MAX_N + 14] - mi[MARG_MAX_N + 13]);
+        if (std::getenv("LIO_DEBUG_DIGEST") && w == 0 && mi[MARG_MAX_N + 16] != 0.0)
+          std::fprintf(stderr, "[digest] S eig, thread 0, summed over the steps: angles %.0f, barrier %.0f, blocks %.0f, barrier %.0f\n", mi[MARG_MAX_N + 16], mi[MARG_MAX_N + 17], mi[MARG_MAX_N + 18], mi[MARG_MAX_N + 19]);
         break;
       }
       case 7: { const std::vector<DevState> o = fetch(d_st_.p + w, 1); h = fnv1a(o[0].scale, sizeof(o[0].scale)); break; }

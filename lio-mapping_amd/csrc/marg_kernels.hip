@@ -25,77 +25,144 @@
 
 namespace lio {
 
-#define MARG_THREADS 256
+#ifndef MARG_THREADS
+#define MARG_THREADS 512       // the Schur / eigen kernels: latency chains through LDS, two waves per SIMD to hide them
+#endif
+#define MARG_AUX_THREADS 256   // the aux row (256 VGPRs per lane: one wave per SIMD)
 
 // cyclic Jacobi on the symmetric np x np matrix S (leading dimension ld, np even; a padding row / column must be zero),
-// eigenvectors accumulated in the columns of V (identity on entry).  cs: np doubles of scratch, flag: one int.
-__device__ int jacobi_eig_lds(double *S, double *V, int np, int ld, double *cs, int *flag) {
-  const int tid = threadIdx.x, half = np / 2;
+// eigenvectors accumulated in the columns of V (identity on entry).  cs: np doubles of scratch (16-byte aligned), flag: two ints.
+//
+// A step applies np / 2 disjoint rotations J (round-robin pairing): S <- J^T S J, V <- V J.  The pairs partition the indices, so
+// S falls into (np / 2)^2 blocks of 2 x 2 — rows of pair P, columns of pair Q — and a block's new value depends on its old value and
+// the two angles only: one thread rotates a block's rows and then its columns in registers and stores it and its transpose (S stays
+// exactly symmetric; only one block of every unordered pair {P, Q} is computed).  Two barriers per step: angles | blocks and
+// eigenvector rows.  Where the time went (n = 45, 12 sweeps x 45 steps, shader clocks per step, profiles/r6_b_marg_phases.txt):
+// round 5's form — a row pass and a column pass over the whole matrix, four barriers — 9.3 k; the fused block form with correctly
+// rounded divides / square roots in the angles and a division per item 6.1 k; hardware reciprocal / rsqrt + Newton, division-free
+// item map, 512 threads 3.3 k, of which 2.5 k were vector-instruction ISSUE (selects, address products, the identity row rotation of
+// the eigenvector items) — not LDS latency and not arithmetic (a step is 8.6 k fp64 operations per workgroup).  This form: triangle of
+// blocks, eigenvector rows on their own, fused multiply-adds.
+__device__ __forceinline__ double jac_rcp(double d) {   // 1 / d: hardware estimate + two Newton steps (<= 1 ulp)
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double jac_rsqrt(double d) {  // 1 / sqrt(d) likewise
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y * __builtin_fma(-h * y, y, 1.5);
+}
+__device__ int jacobi_eig_lds(double *S, double *V, int np, int ld, double *cs, int *flag, double *jprof = nullptr) {
+  const int tid = threadIdx.x, half = np / 2, nm1 = np - 1;
+#if defined(LIO_MARG_PROF)
+  long long tA = 0, tB1 = 0, tB = 0, tB2 = 0;
+#endif
+  // round-robin pairing of step r: index np - 1 stays, the others rotate; pair t = (r + t, r - t) mod (np - 1), pair 0 = (np - 1, r)
+  // (both sums lie in [0, 2 (np - 1)): no division; every thread derives the pairs it needs — a pair table in LDS cost a round trip)
+  auto pair_of = [&](int r, int t, int &p, int &q) {
+    p = r + t; q = r - t + nm1;
+    p = p >= nm1 ? p - nm1 : p; q = q >= nm1 ? q - nm1 : q;
+    if (t == 0) { p = nm1; q = r; }
+    if (p > q) { const int x = p; p = q; q = x; }
+  };
+  // A thread keeps ONE pair index cq = tid mod half and a row offset rp0 = tid / half:
+  //   blocks of S: pair P = cq against pair Q = cq + j (mod half), j = rp0, rp0 + rstep, ... <= half / 2 — every unordered {P, Q} once
+  //                (for even half the distance half / 2 would come twice: only P < half / 2 takes it);
+  //   eigenvectors: column pair cq of rows k = rp0, rp0 + rstep, ...
+  const int cq = tid % half, rp0 = tid / half, rstep = MARG_THREADS / half;
+  const bool worker = rp0 < rstep;
+  const int jmax = half / 2;
+  const bool even_half = (half & 1) == 0;
+  const double2 *cs2 = reinterpret_cast<const double2 *>(cs);   // (c, s) of pair t
   int sweeps = 0;
   for (; sweeps < 40; ++sweeps) {
-    if (tid == 0) *flag = 0;
+    if (tid == 0) flag[0] = 0;
     __syncthreads();
-    for (int r = 0; r < np - 1; ++r) {
-      // round-robin pairing: index np - 1 stays, the others rotate
-      auto pair_of = [&](int t, int &p, int &q) {
-        if (t == 0) { p = np - 1; q = r; }
-        else { p = (r + t) % (np - 1); q = (r - t + (np - 1)) % (np - 1); }
-        if (p > q) { const int x = p; p = q; q = x; }
-      };
-      if (tid < half) {
+    for (int r = 0; r < nm1; ++r) {
+#if defined(LIO_MARG_PROF)
+      const long long c0 = clock64();
+#endif
+      if (tid < half) {   // (one wave: its stores to the step's flag are ordered)
+        if (tid == 0) flag[1] = 0;
         int p, q;
-        pair_of(tid, p, q);
+        pair_of(r, tid, p, q);
         const double app = S[p * ld + p], aqq = S[q * ld + q], apq = S[p * ld + q];
         double c = 1.0, s = 0.0;
-        if (fabs(apq) > 2.3e-16 * sqrt(fabs(app) * fabs(aqq)) && fabs(apq) > 1e-300) {
-          const double tau = (aqq - app) / (2.0 * apq);
-          const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
+        // |apq| > 2.3e-16 sqrt(|app aqq|), compared in squares (an apq whose square underflows counts as zero)
+        if (fabs(apq) > 1e-300 && apq * apq > 5.29e-32 * fabs(app * aqq)) {
+          const double tau = (aqq - app) * jac_rcp(2.0 * apq);
+          const double w = __builtin_fma(tau, tau, 1.0);
+          const double t = (tau >= 0 ? 1.0 : -1.0) * jac_rcp(fabs(tau) + w * jac_rsqrt(w));
+          c = jac_rsqrt(__builtin_fma(t, t, 1.0));
           s = t * c;
-          *flag = 1;
+          flag[0] = 1; flag[1] = 1;
         }
         cs[2 * tid] = c; cs[2 * tid + 1] = s;
       }
+#if defined(LIO_MARG_PROF)
+      const long long c1_ = clock64();
+#endif
       __syncthreads();
-      // rows: S <- J^T S
-      for (int item = tid; item < half * np; item += MARG_THREADS) {
-        const int t = item / np, k = item - t * np;
-        const double c = cs[2 * t], s = cs[2 * t + 1];
-        if (s == 0.0) continue;
-        int p, q;
-        pair_of(t, p, q);
-        const double x = S[p * ld + k], y = S[q * ld + k];
-        S[p * ld + k] = c * x - s * y;
-        S[q * ld + k] = s * x + c * y;
+#if defined(LIO_MARG_PROF)
+      const long long c2_ = clock64();
+#endif
+      if (worker && flag[1]) {   // (a step without a rotation — the last sweep is made of them — leaves everything as it is)
+        const double2 aq = cs2[cq];
+        int pc, qc;
+        pair_of(r, cq, pc, qc);
+        // ---- blocks of S: rows of pair P = cq, columns of pair Q
+        for (int j = rp0; j <= jmax; j += rstep) {
+          if (even_half && j == jmax && cq >= jmax) break;
+          int tq = cq + j;
+          tq = tq >= half ? tq - half : tq;
+          const double2 bq = cs2[tq];
+          int p2, q2;
+          pair_of(r, tq, p2, q2);
+          const double c1 = aq.x, s1 = aq.y, c2 = bq.x, s2 = bq.y;
+          const int ra = pc * ld, rb = qc * ld;
+          const double a = S[ra + p2], b = S[ra + q2], c = S[rb + p2], d = S[rb + q2];
+          // rows pc, qc <- J_P^T (rows), then columns p2, q2 <- (columns) J_Q
+          const double a1 = __builtin_fma(c1, a, -(s1 * c)), c1r = __builtin_fma(s1, a, c1 * c), b1 = __builtin_fma(c1, b, -(s1 * d)), d1 = __builtin_fma(s1, b, c1 * d);
+          double ao = __builtin_fma(c2, a1, -(s2 * b1)), bo = __builtin_fma(s2, a1, c2 * b1), co = __builtin_fma(c2, c1r, -(s2 * d1)), dd = __builtin_fma(s2, c1r, c2 * d1);
+          if (j == 0 && s1 != 0.0) { bo = 0.0; co = 0.0; }   // the rotated pair is exactly decoupled
+          S[ra + p2] = ao; S[ra + q2] = bo; S[rb + p2] = co; S[rb + q2] = dd;
+          if (j != 0) { S[p2 * ld + pc] = ao; S[q2 * ld + pc] = bo; S[p2 * ld + qc] = co; S[q2 * ld + qc] = dd; }   // the transposed block
+        }
+        // ---- eigenvectors: V <- V J, columns of pair cq
+        if (aq.y != 0.0) {
+          const double c2 = aq.x, s2 = aq.y;
+          for (int k0 = rp0; k0 < np; k0 += 4 * rstep) {
+            double u[4], w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int k = k0 + e * rstep, kc = k < np ? k : rp0; u[e] = V[kc * ld + pc]; w[e] = V[kc * ld + qc]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = k0 + e * rstep;
+              if (k < np) { V[k * ld + pc] = __builtin_fma(c2, u[e], -(s2 * w[e])); V[k * ld + qc] = __builtin_fma(s2, u[e], c2 * w[e]); }
+            }
+          }
+        }
       }
+#if defined(LIO_MARG_PROF)
+      const long long c3_ = clock64();
+#endif
       __syncthreads();
-      // columns: S <- S J, V <- V J
-      for (int item = tid; item < half * np; item += MARG_THREADS) {
-        const int t = item / np, k = item - t * np;
-        const double c = cs[2 * t], s = cs[2 * t + 1];
-        if (s == 0.0) continue;
-        int p, q;
-        pair_of(t, p, q);
-        const double x = S[k * ld + p], y = S[k * ld + q];
-        S[k * ld + p] = c * x - s * y;
-        S[k * ld + q] = s * x + c * y;
-        const double u = V[k * ld + p], w = V[k * ld + q];
-        V[k * ld + p] = c * u - s * w;
-        V[k * ld + q] = s * u + c * w;
-      }
-      __syncthreads();
-      if (tid < half && cs[2 * tid + 1] != 0.0) {   // the rotated pair is exactly decoupled
-        int p, q;
-        pair_of(tid, p, q);
-        S[p * ld + q] = 0.0; S[q * ld + p] = 0.0;
-      }
-      // (the next step's angle phase reads only after its own barrier below; entries written here belong to this thread's pair)
-      __syncthreads();
+#if defined(LIO_MARG_PROF)
+      const long long c4_ = clock64();
+      tA += c1_ - c0; tB1 += c2_ - c1_; tB += c3_ - c2_; tB2 += c4_ - c3_;
+#endif
     }
-    const int any = *flag;
+    const int any = flag[0];
     __syncthreads();
     if (!any) break;
   }
+#if defined(LIO_MARG_PROF)
+  if (jprof && tid == 0) { jprof[0] = double(tA); jprof[1] = double(tB1); jprof[2] = double(tB); jprof[3] = double(tB2); }
+#endif
   return sweeps;
 }
 
@@ -111,7 +178,7 @@ struct MargLds {
 // The dense tail for one system by one workgroup of MARG_THREADS threads.  A: (m + n)^2 row-major, b: m + n (global memory, written
 // before a block barrier when the caller assembled them itself); lds: marg_lds_doubles(n) doubles.
 __device__ void marg_schur_body(const double *__restrict__ A, const double *__restrict__ b, int m, int n, double eps, double *__restrict__ lin_jac,
-                                double *__restrict__ lin_res, double *__restrict__ evals, double *__restrict__ info, double *lds) {
+                                double *__restrict__ lin_res, double *__restrict__ evals, double *__restrict__ info, double *lds, double *__restrict__ stamps = nullptr) {
   const int tid = threadIdx.x, N = m + n;
   const int np2 = (n + 1) & ~1, ld2 = np2 + 1;
   MargLds L;
@@ -125,10 +192,13 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
   L.bs = ptr; ptr += np2;
   L.ev = ptr; ptr += np2;
   L.w = ptr; ptr += np2;
-  L.cs = ptr; ptr += np2 + 16;
+  L.cs = ptr; ptr += np2 + 16;        // (c, s) of the step's np2 / 2 rotations, 16-byte aligned
   L.ord = reinterpret_cast<int *>(ptr); ptr += (np2 + 1) / 2 + 1;
   L.flag = reinterpret_cast<int *>(ptr);
 
+  // (stamps: shader-clock stamps of the phases for the batch's test hook — a handful of stores by thread 0)
+  auto stamp = [&](int k) { if (tid == 0 && stamps) stamps[k] = double(clock64()); };
+  stamp(1);
   // ---- Amm (symmetrised) and its eigendecomposition
   for (int e = tid; e < 16 * 17; e += MARG_THREADS) { L.a1[e] = 0.0; L.v1[e] = 0.0; }
   __syncthreads();
@@ -139,6 +209,7 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
   }
   __syncthreads();
   const int sweeps1 = jacobi_eig_lds(L.a1, L.v1, 16, 17, L.cs, L.flag);
+  stamp(2);
   for (int e = tid; e < 16 * 16; e += MARG_THREADS) {
     const int i = e >> 4, j = e & 15;
     double s = 0.0;
@@ -198,7 +269,9 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
       }
   }
   __syncthreads();
-  const int sweeps2 = jacobi_eig_lds(L.S, L.V, np2, ld2, L.cs, L.flag);
+  stamp(3);
+  const int sweeps2 = jacobi_eig_lds(L.S, L.V, np2, ld2, L.cs, L.flag, stamps ? stamps + 8 : nullptr);
+  stamp(4);
   // ---- ascending eigenvalues (rank sort; ties by index), then the square-root factors
   for (int i = tid; i < n; i += MARG_THREADS) L.ev[i] = L.S[i * ld2 + i];
   __syncthreads();
@@ -214,16 +287,26 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
     const double s = L.ev[col];
     double vb = 0.0;
     for (int i = 0; i < n; ++i) vb += L.V[i * ld2 + col] * L.bs[i];
-    lin_res[k] = s > eps ? vb / sqrt(s) : 0.0;
+    const double res = s > eps ? vb / sqrt(s) : 0.0;
+    lin_res[k] = res;
+    L.T[k] = res;          // (T is dead: the caller's J^T r reads the residuals from here)
     evals[k] = s;
     L.w[k] = s > eps ? sqrt(s) : 0.0;
   }
   __syncthreads();
-  for (int e = tid; e < n * n; e += MARG_THREADS) {
-    const int k = e / n, i = e - k * n;
-    lin_jac[e] = L.w[k] * L.V[i * ld2 + L.ord[k]];
+  // the factor J (row k = sqrt(s_k) v_k^T) goes to global memory and, densely (leading dimension n), over S — dead since its diagonal
+  // was read — for the caller's J^T J
+  for (int k = tid / 64; k < n; k += MARG_THREADS / 64) {
+    const double wk = L.w[k];
+    const int col = L.ord[k];
+    for (int i = tid & 63; i < n; i += 64) {
+      const double v = wk * L.V[i * ld2 + col];
+      lin_jac[k * n + i] = v;
+      L.S[k * n + i] = v;
+    }
   }
   if (tid == 0 && info) { info[0] = double(sweeps1); info[1] = double(sweeps2); }
+  stamp(5);
 }
 
 __global__ void __launch_bounds__(MARG_THREADS) k_marg_schur(const double *__restrict__ A, const double *__restrict__ b, int m, int n, double eps,
@@ -250,7 +333,7 @@ static size_t marg_lds_bytes(int n) { return marg_lds_doubles(n) * sizeof(double
 //                               WindowSystem::evaluate, then the dense tail above, then J^T J and J^T r of the new prior — which
 //                               stays on the device as the next solve's prior_mats.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_aux(const BatchSolve *__restrict__ bs, BatchBases bb) {
+__global__ void __launch_bounds__(MARG_AUX_THREADS) k_bw_marg_aux(const BatchSolve *__restrict__ bs, BatchBases bb) {
   const BatchSolve &S = bs[blockIdx.y];
   const DevMarg *mg = S.marg ? rebase(bb.mg, S.marg) : nullptr;
   if (!mg || !mg->active) return;
@@ -277,6 +360,8 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
   const DevMarg &mg = *mgp;
   const DevExec x{int(threadIdx.x), int(blockDim.x), int(threadIdx.x & 63), int(threadIdx.x >> 6), int(blockDim.x >> 6)};
   const int Wo = mg.Wo, m = mg.m, n = mg.n, N = m + n;
+  double *mstamps = rebase(bb.slab, S.marg_info) + MARG_MAX_N + 8;
+  if (x.tid == 0) mstamps[0] = double(clock64());
   const DevState &st = *rebase(bb.st, S.st);
   const double *Sm = rebase(bb.slab, S.S_buf) + size_t(st.s_cur) * Wo * LIO_MOMENT_OUT;   // the moments at the point the solver stopped at
   // ---- frame blocks (LDS: zb Wo x 344, LS Wo x 234)
@@ -336,15 +421,29 @@ __global__ void __launch_bounds__(MARG_THREADS) k_bw_marg_schur(const BatchSolve
   // ---- dense tail: the new prior's square-root factors go straight into the next solve's prior_mats
   double *out = rebase(bb.slab, S.next_prior_mats);
   double *o_JtJ = out, *o_jac = out + size_t(n) * n, *o_res = o_jac + size_t(n) * n, *o_Jtr = o_res + n;
-  marg_schur_body(A, bv, m, n, eps, o_jac, o_res, rebase(bb.slab, S.marg_info) + 2, rebase(bb.slab, S.marg_info), lds);
+  marg_schur_body(A, bv, m, n, eps, o_jac, o_res, rebase(bb.slab, S.marg_info) + 2, rebase(bb.slab, S.marg_info), lds, mstamps);
   __syncthreads();
-  // J^T J and J^T r of the new prior (MargPrior::finalize): ascending k
-  for (int e = x.tid; e < n * (n + 1); e += x.nthr) {
-    const int i = e / (n + 1), j = e % (n + 1);
-    double sacc = 0.0;
-    if (j < n) { for (int k = 0; k < n; ++k) sacc += o_jac[size_t(k) * n + i] * o_jac[size_t(k) * n + j]; o_JtJ[size_t(i) * n + j] = sacc; }
-    else { for (int k = 0; k < n; ++k) sacc += o_jac[size_t(k) * n + i] * o_res[k]; o_Jtr[i] = sacc; }
+  // J^T J and J^T r of the new prior (MargPrior::finalize): ascending k; J and the residuals are still in LDS (marg_schur_body left them
+  // over S and T — the first form re-read them from global memory, 72 of the kernel's 720 us)
+  {
+    const int np2 = (n + 1) & ~1, ld2 = np2 + 1;
+    const double *Jl = lds, *rl = lds + 2 * np2 * ld2 + 2 * 16 * 17 + 16 * 16;
+    for (int i = x.tid / 64; i < n; i += x.nthr / 64)
+      for (int j = x.tid & 63; j <= n; j += 64) {
+        double sacc = 0.0;
+        const double *rhs = j < n ? Jl + j : rl;   // column j of J, or the residuals
+        const int rstr = j < n ? n : 1;
+        for (int k0 = 0; k0 < n; k0 += 8) {        // eight terms' loads in flight, added in ascending k
+          double u8[8], v8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const int k = k0 + q < n ? k0 + q : n - 1; u8[q] = Jl[k * n + i]; v8[q] = rhs[k * rstr]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (k0 + q < n) sacc += u8[q] * v8[q];
+        }
+        if (j < n) o_JtJ[size_t(i) * n + j] = sacc; else o_Jtr[i] = sacc;
+      }
   }
+  if (x.tid == 0) mstamps[6] = double(clock64());
 }
 
 void prepare_bw_marg_kernel() {   // per device (EstimatorBatch's constructor)
@@ -352,7 +451,7 @@ void prepare_bw_marg_kernel() {   // per device (EstimatorBatch's constructor)
 }
 void launch_bw_marginalize(const BatchSolve *bs, const BatchBases &bb, int B, int max_wo, int max_n, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_THREADS), 0, s, bs, bb);
+  hipLaunchKernelGGL(k_bw_marg_aux, dim3(max_wo + 2, B), dim3(MARG_AUX_THREADS), 0, s, bs, bb);
   const size_t lds = std::max(marg_lds_doubles(max_n), size_t(max_wo) * (344 + 234)) * sizeof(double);
   hipLaunchKernelGGL(k_bw_marg_schur, dim3(B), dim3(MARG_THREADS), lds, s, bs, bb, 1e-8);
   LIO_HIP(hipGetLastError());

@@ -1023,7 +1023,7 @@ class EstimatorBatch:
     def sync(self):
         _chk(self.lib.dll.lio_est_batch_sync(self.h), "lio_est_batch_sync")
 
-    STAGES = ("filtered_map", "knn_grid", "feature_flags", "plane_coefficients", "newest_frame_state", "solver_state", "moments", "jacobi_scaling", "scaled_hessian")
+    STAGES = ("filtered_map", "knn_grid", "feature_flags", "plane_coefficients", "newest_frame_state", "solver_state", "moments", "jacobi_scaling", "scaled_hessian", "new_prior")
 
     def set_option(self, name, value):
         """an execution choice of the batch (lio_est_batch_set_option): results do not depend on it"""

@@ -834,7 +834,7 @@ int lio_est_batch_set_option(lio_est_batch *b, const char *name, int value) {   
   return LIO_ERR_ARG;
 }
 int lio_est_batch_stage_digest(lio_est_batch *b, int stage, unsigned long long *out) {
-  if (!b || !out || stage < 0 || stage > 8) return LIO_ERR_ARG;
+  if (!b || !out || stage < 0 || stage > 9) return LIO_ERR_ARG;
   if (b->dissolved) return LIO_ERR_STATE;
   for (size_t w = 0; w < b->members.size(); ++w) out[w] = 0;
   return LIO_OK;

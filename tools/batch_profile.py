@@ -35,4 +35,6 @@ dt = time.perf_counter() - t0
 clk = batch.clock()
 print(f"B {B}: {B * steps / dt:.0f} solves/s, {1e3 * dt / steps:.3f} ms per batch step; iterations {reps[0].iterations}, residuals {reps[0].n_lidar_residuals}")
 print({k: round(v, 3) for k, v in clk.items()})
+if os.environ.get("LIO_DEBUG_DIGEST"):   # phase stamps of the last marginalization (window 0 and the last one) on stderr
+    batch.stage_digest(9)
 batch.close()

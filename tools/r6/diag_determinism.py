@@ -49,4 +49,5 @@ for t in range(trials):
     print(" | ".join(line), flush=True)
 if os.environ.get("LIO_DEBUG_DIGEST"):
     batch.stage_digest(8)
+    batch.stage_digest(9)
 print("RESULT", "deterministic" if bad_total == 0 else f"{bad_total} stage mismatches")

@@ -251,6 +251,50 @@ def keyframes_measure(lib, rank, world, n_kf, steps, sync, device, rccl=None, us
     }
 
 
+def throughput_measure(lib, cfg, est0, B, steps, warmup, rank, world, sync, device):
+    """The throughput mode of the metric: every rank solves B windows per step through lio_est_batch (copies of ITS window at distinct
+    addresses, one launch per stage over all of them; no data-path collective — the windows are independent), EXACTLY `steps` steps
+    between barrier + synchronize on both sides, max over ranks -> world x B x steps / time.  Parity gate: the B windows of a rank are
+    identical inputs, so every stage of every window must have left identical bits (lio_est_batch_stage_digest) and identical reports;
+    a rank where they differ voids the number (returned as parity "broken", value None)."""
+    from lio_amd import capi, dist_util
+
+    clones = []
+    for _ in range(B):
+        e = capi.Estimator(lib, cfg)
+        e.copy_snapshot_of(est0)
+        e.restore()
+        clones.append(e)
+    batch = capi.EstimatorBatch(lib, clones)
+    batch.solve_restored(max(1, warmup))
+    dist_util.barrier(world)
+    sync()
+    t0 = time.perf_counter()
+    reps = batch.solve_restored(steps)       # (ends with a wait for the last step's marginalizations)
+    sync()
+    dist_util.barrier(world)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, device=device)
+    same = all((r.iterations, r.successful_steps, r.termination, r.n_lidar_residuals, r.final_cost) ==
+               (reps[0].iterations, reps[0].successful_steps, reps[0].termination, reps[0].n_lidar_residuals, reps[0].final_cost) for r in reps)
+    differing = []
+    for s_idx, s_name in enumerate(capi.EstimatorBatch.STAGES):
+        d = batch.stage_digest(s_idx)
+        if bool((d != d[0]).any()):
+            differing.append(s_name)
+    broken = dist_util.max_over_ranks(0.0 if (same and not differing) else 1.0, world, device=device) > 0.0
+    clk = batch.clock()
+    batch.close()
+    out = {"windows_per_rank": B, "ranks": world, "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+           "parity": "broken" if broken else "ok", "stages_that_differ_between_windows_on_rank_0": differing,
+           "value": None if broken else round(world * B * steps / dt, 1), "unit": "solves/s",
+           "solver_iterations": int(reps[0].iterations), "n_lidar_residuals": int(reps[0].n_lidar_residuals),
+           "windows_on_device_loop_rank_0": int(clk["n_device"]),
+           "rank_0_stage_device_ms": {k: round(clk[k], 4) for k in ("dev_filter", "dev_grid", "dev_features", "dev_rounds", "dev_loop", "dev_marg", "dev_marg_wait")},
+           "note": "lio_est_batch: every rank solves `windows_per_rank` copies of its own window per step, one launch per stage over all of them, trust-region loop and "
+                   "marginalization on the device; a step = restore every window + lio_est_batch_solve, looped inside the library; no collective on the data path"}
+    return out
+
+
 def dry_run(args, rank, world, torch, dist):
     """CPU rehearsal of the multi-rank run (no GPU, nothing measured): gloo process group, the CPU oracle behind the same C-ABI
     as the worker, a small VLP-16 window.  Exercises exactly the control flow of the real run: per-rank windows between
@@ -275,6 +319,7 @@ def dry_run(args, rank, world, torch, dist):
     dist_util.barrier(world)
     dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, device="cpu")
     sharded = keyframes = None
+    thr = throughput_measure(lib, est_config(lib, ds, kind, W, Wo), est, 2, steps, 1, rank, world, sync=lambda: None, device="cpu")   # the N > 1 headline's control flow
     if world > 1:
         sharded = sharded_solve_stats(lib, kind, W, Wo, rank, world, steps, sync=lambda: None, device="cpu", allreduce_numpy=dist_util.make_allreduce("cpu"))
         km = keyframes_measure(lib, rank, world, 2 * world, 1, sync=lambda: None, device="cpu", use_library_gather=False, kind="indoor")
@@ -282,8 +327,10 @@ def dry_run(args, rank, world, torch, dist):
     if rank == 0:
         print(json.dumps({
             "dry_launch": True, "backend": lib.backend, "process_group": "gloo" if world > 1 else None,
-            "metric": "CPU rehearsal of the multi-rank control flow (NOT a measurement)", "value": round(world * steps / dt, 3), "unit": "solves/s",
-            "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": "CPU rehearsal of the multi-rank control flow (NOT a measurement)",
+            "value": thr["value"] if world > 1 else round(world * steps / dt, 3), "unit": "solves/s",
+            "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": thr["ms_per_step"] if world > 1 else round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak",
+            "throughput_mode": thr, "single_window": {"value": round(world * steps / dt, 3), "ms_per_step": round(1e3 * dt / steps, 3)},
             "vs_baseline": None, "dtype": "f64 (solve) / f32 (features)", "data": "synthetic",
             "config": {"workload": f"VLP-16 indoor, window_size={W} opt_window_size={Wo}, CPU oracle", "n_lidar_residuals": int(rep.n_lidar_residuals),
                        "parallelism": f"{world} independent windows" if world > 1 else "1 window"},
@@ -309,6 +356,7 @@ def main():
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)   # internal: a few solves on the pickled workload, run under rocprofv3
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--windows", default="8,64,512", help="batch sizes of the `batched` extra (lio_est_batch: B windows per launch chain); 0 = skip")
+    ap.add_argument("--rank-windows", type=int, default=512, help="N > 1: windows per rank and step of the throughput mode (lio_est_batch) the line's value is measured in; 0 = one window per rank")
     ap.add_argument("--keyframes", type=int, default=1000, help="keyframes of the batched-refinement extra (configs[4]); 0 = skip")
     ap.add_argument("--shard-factors", action="store_true",
                     help="strong-scaling mode: ONE window, its lidar factors sharded over the ranks, RCCL all-reduce of the normal-"
@@ -405,6 +453,12 @@ def main():
     value = world * args.steps / dt_max
     if args.shard_factors:
         value = args.steps / dt_max  # one window solved cooperatively: total work is fixed
+    # N > 1 (one rank per GPU, independent windows): the line's value is the THROUGHPUT mode — every rank solves --rank-windows windows per
+    # step through lio_est_batch — because that is what a node full of GPUs is for; N ranks x one latency-bound window each is carried as
+    # `single_window`.  At N = 1 the headline stays the single window and the same mode is the `batched` extra.
+    thr = None
+    if world > 1 and not args.shard_factors and args.rank_windows > 0:
+        thr = throughput_measure(hip, est_config(hip, ds, kind, W, Wo), est, args.rank_windows, args.steps, args.warmup, rank, world, sync=torch.cuda.synchronize, device="cuda")
 
     resident = est.kernel_timing("moments_resident")   # passes served by the resident moments kernel so far (the timed blocks above)
     est.enable_kernel_timing(-1)                       # untimed block: HIP events around the resident kernel's launches (dispatch -> exit)
@@ -645,6 +699,20 @@ def main():
     # N > 1: the two modes with a real exchange step, measured in the same run on every rank (collective), reported by rank 0 in
     # the same line.  They come LAST and under a watchdog: if a rank fails or a collective never completes, rank 0 still prints the
     # line it has (the weak-scaling measurement) with the failure noted, instead of hanging the whole run.
+    if rank == 0 and thr is not None:
+        # N > 1: the throughput mode leads the line; the N one-window-per-rank figure measured above stays beside it
+        out["single_window"] = {"value": out["value"], "unit": "solves/s", "ms_per_step": out["ms_per_step"], "timing": out["timing"],
+                                "note": f"{world} ranks x ONE window each (latency-bound: SURVEY.md 8(d)(i)); its roofline is `roofline` below"}
+        out["throughput_mode"] = thr
+        if thr["value"] is not None:
+            out["value"] = thr["value"]
+            out["ms_per_step"] = thr["ms_per_step"]
+            out["config"]["parallelism"] = f"{world} ranks x {thr['windows_per_rank']} independent windows per step (lio_est_batch), no collective on the data path"
+            out["config"]["workload"] += f"; throughput mode: {thr['windows_per_rank']} windows per rank and step"
+            out["timing"] = {"blocks": 1, "steps_per_block": args.steps, "note": "value = ranks x windows_per_rank x --steps / the time of exactly --steps batch steps (barrier + synchronize on both sides, max over ranks); "
+                             "compare with the N = 1 line's batched.points[windows = windows_per_rank].value, not with its single-window value"}
+        else:
+            out["throughput_mode_note"] = "identical windows disagreed on a rank: the line falls back to the single-window figure"
     if world > 1 and not args.shard_factors:
         done = threading.Event()
 
@@ -852,6 +920,7 @@ def batched_windows(hip, ds, kind, W, Wo, est0, sizes, rep0, min_seconds=0.4):
                 "newest_frame_rounds": stage(clk["dev_rounds"], rounds * (16.0 * (m_new + n_map) + 72.0 * m_new + 33.0 * m_new)),
                 "trust_region_loop (moments + aux row, step)": stage(clk["dev_loop"], 60.0 * n_slots * passes, 684.0 * n_res * passes),
                 "marginalization (aux row, Schur + eigensolves)": {"device_ms": round(clk["dev_marg"], 4)},
+                "wait_for_the_previous_marginalization (own stream; joined before the problems' upload, not part of the rounds above)": {"device_ms": round(clk["dev_marg_wait"], 4)},
             },
         })
         batch.close()

@@ -524,14 +524,18 @@ int lio_est_batch_sync(lio_est_batch *);
 /* host wall clock of the last lio_est_batch_solve, ms: [0] descriptors, [1] filter chain, [2] grids + features + rounds, [3] problem
  * packing (inside [2]), [4] trust-region loop, [5] write-back + marginalization enqueue, [6] single-window fallbacks, [7] total,
  * [8] windows solved on the device, [9] newest-frame rounds launched; DEVICE time of the stages (HIP events on the batch's stream;
- * the call waits for the stream): [10] filter chain, [11] K-NN grids, [12] features of the older frames, [13] newest-frame rounds,
- * [14] trust-region loop, [15] marginalization.  out: 16 doubles. */
-int lio_est_batch_get_clock(const lio_est_batch *, double *out16);
+ * the call waits for the stream): [10] filter chain, [11] K-NN grids, [12] features of the older frames, [13] newest-frame rounds
+ * (without [16]), [14] trust-region loop, [15] marginalization, [16] the stream's wait for the PREVIOUS solve's marginalization
+ * (it runs on a stream of its own beside this solve's first stages and is joined in front of the problems' upload); with the
+ * option "time_kernels" (measurement runs: HIP events around every launch of the trust-region loop, on the stream it runs on)
+ * [17..19] summed duration (ms) and [20..22] number of the last solve's launches of the aux row, the moments pass and the step
+ * kernel, else 0; [23] reserved.  out: 24 doubles. */
+int lio_est_batch_get_clock(const lio_est_batch *, double *out24);
 /* Execution choices of a batch that its results do not depend on (bit for bit: tests/test_gpu_batch_scale.py), by name; value 0
  * (occupancy: -1) = chosen by the size of the launch, the default.  "lanes_per_query" 1 | 2 | 4 | 8 (search kernels of
  * CalculateFeatures / CalculateLaserOdom), "occupancy" 0 | 6 | 8 waves per SIMD of their one-lane-per-query forms, "loop_groups"
  * 1 .. 4 launch chains of the trust-region loop side by side, "aux_threads" 64 | 128 | 256 threads per block of the IMU / prior
- * row, "aux_stream" 0 | 1, "finish_threads" 1 .. 8 host threads of the write-back.  The environment variables LIO_BW_LPQ,
+ * row, "aux_stream" 0 | 1, "finish_threads" 1 .. 8 host threads of the write-back, "time_kernels" 0 | 1 (lio_est_batch_get_clock).  The environment variables LIO_BW_LPQ,
  * LIO_BW_OCC, LIO_BW_GROUPS, LIO_BW_AUX_THREADS, LIO_BW_AUX_STREAM, LIO_BW_FINISH_THREADS set a new batch's defaults (read once
  * at lio_est_batch_create).  LIO_ERR_ARG: unknown name or value.  The oracle accepts and ignores them. */
 int lio_est_batch_set_option(lio_est_batch *, const char *name, int value);

@@ -47,6 +47,8 @@ struct BatchKnobs {
   int aux_threads = 0;       // 64 / 128 / 256 threads per block of the aux row (LIO_BW_AUX_THREADS); by size: 64 from 128 windows per launch
   int aux_stream = 0;        // 1: the aux row on a side stream (LIO_BW_AUX_STREAM; measured slower)
   int finish_threads = 0;    // 1 .. 8 host threads of the write-back; by size: 4 from 128 windows
+  int time_kernels = 0;      // 1: HIP events around every launch of the trust-region loop's three kernels on the stream they run on (measurement
+                             //    runs only: the events serialise the host's enqueue; BatchClock::kernel_ms / kernel_launches)
 };
 BatchKnobs batch_knobs_from_env();
 

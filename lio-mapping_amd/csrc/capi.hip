@@ -946,6 +946,8 @@ int lio_est_batch_get_clock(const lio_est_batch *h, double *out) {
   for (int k = 0; k < 6; ++k) out[10 + k] = c.dev[k];
   out[0] = c.describe; out[1] = c.map; out[2] = c.grid_features; out[3] = c.pack; out[4] = c.solve; out[5] = c.finish; out[6] = c.fallback; out[7] = c.total;
   out[8] = c.n_device; out[9] = c.rounds;
+  out[16] = c.dev_marg_wait;
+  for (int k = 0; k < 3; ++k) { out[17 + k] = c.kernel_ms[k]; out[20 + k] = double(c.kernel_launches[k]); }
   return LIO_OK;
 }
 

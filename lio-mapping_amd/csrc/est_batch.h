@@ -35,6 +35,10 @@ struct BatchClock {   // host wall clock of the last Solve(), ms
   // device time of the last Solve()'s stages (HIP events on the batch's stream), ms: filter chain (concat, keys, sort, heads,
   // centroids), K-NN grids, features of the older frames, newest-frame rounds, trust-region loop, marginalization
   double dev[6] = {0, 0, 0, 0, 0, 0};
+  // with the option time_kernels: summed duration and count of the last Solve()'s launches of k_bw_aux, k_bw_moments, k_bw_solve_step
+  double kernel_ms[3] = {0, 0, 0};
+  int kernel_launches[3] = {0, 0, 0};
+  double dev_marg_wait = 0;   // of dev[3]: the stream's wait for the PREVIOUS solve's marginalization (it sits in front of the problems' upload)
 };
 
 class EstimatorBatch {
@@ -93,6 +97,10 @@ class EstimatorBatch {
   std::vector<char> ok_;
   int device_id_ = 0;
   hipEvent_t ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_k_;        // time_kernels: 4 events per iteration and group (aux | moments | step boundaries)
+  int ev_k_used_ = 0;
+  hipEvent_t ev_wait_[2] = {nullptr, nullptr};   // around the wait for the previous marginalization
+  bool ev_wait_valid_ = false;
   bool ev_valid_ = false;
   Slab lay_{};
   BatchClock clk_;

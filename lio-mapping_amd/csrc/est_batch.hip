@@ -32,6 +32,7 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   ok_.assign(B, 0);
   LIO_HIP(hipStreamCreate(&stream_));
   for (hipEvent_t &e : ev_) LIO_HIP(hipEventCreate(&e));
+  for (hipEvent_t &e : ev_wait_) LIO_HIP(hipEventCreate(&e));
   for (hipStream_t &g : stream_grp_) LIO_HIP(hipStreamCreate(&g));
   for (hipStream_t &g : stream_aux_) LIO_HIP(hipStreamCreate(&g));
   LIO_HIP(hipStreamCreate(&stream_marg_));
@@ -76,6 +77,8 @@ EstimatorBatch::~EstimatorBatch() {
                   static_cast<void *>(h_pb_), static_cast<void *>(h_st_), static_cast<void *>(h_mg_), static_cast<void *>(h_prior_), static_cast<void *>(h_nconv_)})
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_wait_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_k_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_grp_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_aux_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_step_) if (e) (void)hipEventDestroy(e);
@@ -96,6 +99,7 @@ bool EstimatorBatch::SetOption(const char *name, int v) {
   else if (n == "aux_threads") { if (v != 0 && v != 64 && v != 128 && v != 256) return false; knobs_.aux_threads = v; }
   else if (n == "aux_stream") { if (v != 0 && v != 1) return false; knobs_.aux_stream = v; }
   else if (n == "finish_threads") { if (v < 0 || v > 8) return false; knobs_.finish_threads = v; }
+  else if (n == "time_kernels") { if (v != 0 && v != 1) return false; knobs_.time_kernels = v; }
   else return false;
   return true;
 }
@@ -108,7 +112,20 @@ const BatchClock &EstimatorBatch::clock() {
       float ms = 0;
       clk_.dev[k] = hipEventElapsedTime(&ms, ev_[k], ev_[k + 1]) == hipSuccess ? double(ms) : 0.0;
     }
-    ev_valid_ = false;
+    clk_.dev_marg_wait = 0;
+    if (ev_wait_valid_) {   // the rounds' stage minus the wait for the previous marginalization: what the rounds themselves took
+      float ms = 0;
+      clk_.dev_marg_wait = hipEventElapsedTime(&ms, ev_wait_[0], ev_wait_[1]) == hipSuccess ? double(ms) : 0.0;
+      clk_.dev[3] = std::max(0.0, clk_.dev[3] - clk_.dev_marg_wait);
+    }
+    for (int k = 0; k < 3; ++k) { clk_.kernel_ms[k] = 0; clk_.kernel_launches[k] = 0; }
+    for (int q = 0; q + 3 < ev_k_used_; q += 4)
+      for (int k = 0; k < 3; ++k) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev_k_[size_t(q + k)], ev_k_[size_t(q + k + 1)]) == hipSuccess) { clk_.kernel_ms[k] += double(ms); ++clk_.kernel_launches[k]; }
+      }
+    ev_k_used_ = 0;
+    ev_valid_ = false; ev_wait_valid_ = false;
   }
   return clk_;
 }
@@ -252,6 +269,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   std::memset(static_cast<void *>(reps), 0, sizeof(lio_solve_report) * B);
   clk_ = BatchClock();
   ev_valid_ = false;
+  ev_k_used_ = 0;
   // ------------------------------------------------------------------------------------------------ describe
   int off = 0, slot = 0, part_rows = 0, max_cap = 0, max_slots = 0, max_M = 0, max_static = 0, max_nb = 0;
   long long q_static = 0, q_newest = 0;
@@ -362,7 +380,14 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   // what the previous solve's marginalization (on its own stream) still reads: everything enqueued from here on waits for it —
   // it has had this solve's filter, grids, features and first rounds to finish.
   const double t3a = bnow_ms();
-  if (marg_in_flight_) { LIO_HIP(hipStreamWaitEvent(s, ev_marg_, 0)); marg_in_flight_ = false; }
+  ev_wait_valid_ = false;
+  if (marg_in_flight_) {
+    LIO_HIP(hipEventRecord(ev_wait_[0], s));
+    LIO_HIP(hipStreamWaitEvent(s, ev_marg_, 0));
+    LIO_HIP(hipEventRecord(ev_wait_[1], s));   // (reached when the first three rounds are done AND the marginalization is: the difference is rounds + wait;
+    ev_wait_valid_ = true;                     //  the rounds in front of it end at ev_wait_[0], so [0] -> [1] is the wait alone)
+    marg_in_flight_ = false;
+  }
   int max_bpf = 1, max_wo = 1, max_npad = DS_NB;
   size_t part_total = 0;
   for (int w = 0; w < B; ++w) {
@@ -483,6 +508,17 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
             LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
             launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
             if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
+          } else if (knobs_.time_kernels) {   // measurement run: the three launches bracketed by events on their stream
+            while (ev_k_.size() < size_t(ev_k_used_ + 4)) { hipEvent_t e = nullptr; LIO_HIP(hipEventCreate(&e)); ev_k_.push_back(e); }
+            hipEvent_t *ek = ev_k_.data() + ev_k_used_;
+            ev_k_used_ += 4;
+            LIO_HIP(hipEventRecord(ek[0], sg));
+            launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sg);
+            LIO_HIP(hipEventRecord(ek[1], sg));
+            launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
+            LIO_HIP(hipEventRecord(ek[2], sg));
+            launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
+            LIO_HIP(hipEventRecord(ek[3], sg));
           } else {
             launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, knobs_.aux_threads, valid_all_.p, coef_all_.p, sg);
           }

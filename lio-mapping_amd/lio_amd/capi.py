@@ -1036,10 +1036,10 @@ class EstimatorBatch:
         return np.array(list(out), dtype=np.uint64)
 
     def clock(self):
-        out = (C.c_double * 16)()
+        out = (C.c_double * 24)()
         _chk(self.lib.dll.lio_est_batch_get_clock(self.h, out), "lio_est_batch_get_clock")
         names = ["describe", "filter", "grid_features_rounds", "pack", "solve", "finish", "fallback", "total", "n_device", "rounds",
-                 "dev_filter", "dev_grid", "dev_features", "dev_rounds", "dev_loop", "dev_marg"]
+                 "dev_filter", "dev_grid", "dev_features", "dev_rounds", "dev_loop", "dev_marg", "dev_marg_wait", "aux_ms", "moments_ms", "step_ms", "aux_launches", "moments_launches", "step_launches"]
         return dict(zip(names, [float(v) for v in out]))
 
 

@@ -829,7 +829,7 @@ int lio_est_batch_set_option(lio_est_batch *b, const char *name, int value) {   
   if (!b || !name) return LIO_ERR_ARG;
   if (b->dissolved) return LIO_ERR_STATE;
   (void)value;
-  for (const char *k : {"lanes_per_query", "occupancy", "loop_groups", "aux_threads", "aux_stream", "finish_threads"})
+  for (const char *k : {"lanes_per_query", "occupancy", "loop_groups", "aux_threads", "aux_stream", "finish_threads", "time_kernels"})
     if (std::strcmp(name, k) == 0) return LIO_OK;
   return LIO_ERR_ARG;
 }
@@ -842,7 +842,7 @@ int lio_est_batch_stage_digest(lio_est_batch *b, int stage, unsigned long long *
 int lio_est_batch_get_clock(const lio_est_batch *b, double *out) {
   if (!b || !out) return LIO_ERR_ARG;
   if (b->dissolved) return LIO_ERR_STATE;
-  for (int k = 0; k < 16; ++k) out[k] = 0.0;
+  for (int k = 0; k < 24; ++k) out[k] = 0.0;
   return LIO_OK;
 }
 

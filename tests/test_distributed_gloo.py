@@ -170,6 +170,10 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["dry_launch"] and out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "2 independent windows"
+    # N > 1: the line's value is the throughput mode (every rank solves a batch of windows per step through lio_est_batch, parity-gated)
+    thr = out["throughput_mode"]
+    assert thr["parity"] == "ok" and thr["ranks"] == 2 and thr["windows_per_rank"] == 2 and thr["value"] > 0
+    assert out["value"] == thr["value"] and out["ms_per_step"] == thr["ms_per_step"] and out["single_window"]["value"] > 0
     sh, kf = out["sharded"], out["keyframes"]
     assert sh["scaling"] == "strong" and sh["value"] > 0 and sh["linearisations_per_solve"] == sh["solver_iterations"] + 1
     assert sh["solver_iterations"] == sh["solver_iterations_unsharded"] and sh["final_cost_rel_gap_to_unsharded"] < 1e-9

@@ -145,11 +145,17 @@ def test_bench_with_two_gpus_runs_over_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU visible: the N > 1 control flow is covered by the gloo tests, RCCL at world 1 above")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-fed",
-                        "--keyframes", "40", "--windows", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--keyframes", "40", "--windows", "0", "--rank-windows", "40"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # the line's value is the throughput mode: 2 ranks x 40 windows per step through lio_est_batch, parity-gated; the one-window-per-rank
+    # figure stays beside it
+    thr = d["throughput_mode"]
+    assert thr["parity"] == "ok" and thr["ranks"] == 2 and thr["windows_per_rank"] == 40
+    assert d["value"] == thr["value"] and d["ms_per_step"] == thr["ms_per_step"]
+    assert d["single_window"]["value"] > 0 and d["value"] > d["single_window"]["value"]
     assert d["sharded"] and d["sharded"]["rccl_world"] == 2, d["sharded"]
     assert d["keyframes"] and d["keyframes"]["rccl_world"] == 2, d["keyframes"]

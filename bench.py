@@ -1197,6 +1197,7 @@ def cpu_baseline(kind, W, Wo, steps, ds):
         "stages_ms": {"t_build_map": round(rep.ms_build_map, 3), "feature_cost": round(rep.ms_features, 3), "t_opt": round(rep.ms_opt, 3), "whole_marginalization": round(rep.ms_marg, 3)},
         "point_processor_ms_per_scan": round(float(np.median(pp_ms[1:])), 3),
         "point_mapping": mapping_ms_per_scan(orc, ds, clouds, n_frames=5),
+        "point_odometry_ms_per_scan": odometry_ms_per_scan(orc, ds)[0] if kind == "outdoor" else None,   # PointOdometry::Process on the same four sweeps (oracle/odometry.h)
         "as_shipped_with_0p1s_solver_cap": capped,
         "note": "the oracle has none of the reference's ROS/PCL/Ceres/heap overheads: a faster-than-reference, conservative baseline; the reference itself cannot be built here (Eigen/PCL/Ceres/ROS absent)",
     }

@@ -539,6 +539,12 @@ int lio_est_batch_get_clock(const lio_est_batch *, double *out24);
  * LIO_BW_OCC, LIO_BW_GROUPS, LIO_BW_AUX_THREADS, LIO_BW_AUX_STREAM, LIO_BW_FINISH_THREADS set a new batch's defaults (read once
  * at lio_est_batch_create).  LIO_ERR_ARG: unknown name or value.  The oracle accepts and ignores them. */
 int lio_est_batch_set_option(lio_est_batch *, const char *name, int value);
+/* Test hook: the segmented stable radix sort of the batched BuildLocalMap (csrc/seg_sort.h; it orders a window's points by PCL's voxel
+ * index, Estimator.cc:1518-1519, and by K-NN cell, :1544-1545): `passes` passes of `bits` (1 .. 9) bits from bit 0 over
+ * (key, value) pairs inside n_segments ranges [seg_off[k], seg_off[k] + seg_n[k]) of arrays of n_total elements; values_or_null:
+ * the values are the elements' positions.  Elements outside every segment are copied through.  LIO_ERR_ARG on bad arguments. */
+int lio_seg_sort_pairs(const unsigned *keys, const unsigned *values_or_null, size_t n_total, const int *seg_off, const int *seg_n, int n_segments, int bits, int passes,
+                       unsigned *keys_out, unsigned *values_out);
 /* Test hook: one 64-bit digest per window of what a stage of the LAST lio_est_batch_solve left on the device — stage 0 the filtered
  * local map (Estimator.cc:1518-1519), 1 the K-NN grid (:1544-1545; points of a cell as a multiset), 2 the feature flags and
  * 3 the plane coefficients of CalculateFeatures / CalculateLaserOdom (:970-1097, :1242-1359), 4 the newest frame's Gauss-Newton state,

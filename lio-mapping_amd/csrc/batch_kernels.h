@@ -5,12 +5,12 @@
 // filter) is a function of the window's own sizes: a window gives the same bits alone (B = 1) and inside any batch.
 #pragma once
 #include "cloud_kernels.h"
+#include "seg_sort.h"
 
 namespace lio {
 
 #define LIO_BW_MAX_SEG 8        // segments of a local map: the pivot's cloud + the Wo - 1 frames behind it (Wo <= 7)
-#define BW_KEY_BITS 31          // voxel key of the batched filter: window << 31 | key; all ones = no point
-#define BW_KEY_NONE 0x7FFFFFFFu
+#define BW_KEY_NONE 0x7FFFFFFFu  // stored voxel key of the batched filter (absolute cells, 31 bits): all ones = no point
 #define LIO_BW_MAX_STATIC 7     // frames whose features do not depend on the newest frame's rounds
 
 struct BwSeg { const float4 *src; int n; int dst_off; int identity; int set_intensity; float intensity; Affine3f tf; };
@@ -54,19 +54,20 @@ BatchKnobs batch_knobs_from_env();
 
 int bw_round_blocks(int M);   // search blocks of one round of a window's newest frame: 64 queries each, whatever the lanes per query
 
-// concat + voxel keys + per-block bounds.  keys64 / vals: loc-array sized; partial: 8 floats per 256-point block
-void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, unsigned long long *keys64, uint32_t *vals, float *partial,
-                           int *range_overflow, hipStream_t s);
-// sorted keys -> tile heads (+ the bounds fold) -> centroids, counts
-void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const unsigned long long *keys_sorted, const uint32_t *vals_sorted,
-                          const float *partial, int *tile_heads, float4 *filtered_all, VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s);
+// concat + voxel keys (absolute cells) + per-block bounds; then, one block per window, the bounds folded into VoxParams and the key layout
+// the segmented sort runs on (seg_sort.h).  keys: loc-array sized; partial: 8 floats per 256-point block
+// max_bits: what the passes the caller is going to run can order, minus one (a window that needs more is flagged in range_overflow)
+void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, uint32_t *keys, float *partial, VoxParams *params, KeyLayout *layout,
+                           int *range_overflow, int max_bits, hipStream_t s);
+// sorted (relative) keys -> tile heads -> centroids, counts
+void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const uint32_t *keys_sorted, const uint32_t *vals_sorted, int *tile_heads,
+                          float4 *filtered_all, const VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s);
 // feature flags cleared, the newest frames' Gauss-Newton states started
 void launch_bw_setup(const BatchWin *win, int B, int max_slots, uint8_t *valid_all, OdomState *odom, int *n_converged, hipStream_t s);
-// K-NN grid: histogram, (scan by the caller), placement
-void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, uint32_t *slot, int *cnt_all,
-                          hipStream_t s);
-void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
-                          const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s);
+// K-NN grid: cell keys of the filtered points; (segmented sort by the caller); cell-sorted points + the dense table of run starts
+void launch_bw_cell_keys(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, hipStream_t s);
+void launch_bw_cell_table(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys_sorted,
+                          const uint32_t *vals_sorted, int *cells_all, float4 *sorted_all, hipStream_t s);
 // total_queries: stack points of the launch over all windows — picks the lanes per query (the results do not depend on it)
 void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const BatchKnobs &knobs,
                         const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "batch_kernels.h"
+#include "seg_sort.h"
 #include "cloud_device.h"
 
 namespace lio {
@@ -20,8 +21,7 @@ int bw_round_blocks(int M) { return std::max(1, cdiv(M, 64)); }
 // filter's sort key — the window above PCL's voxel index in absolute cells (cloud_kernels.hip: k_vox_keys_abs; the window in the
 // high word keeps every window's points together through ONE sort of the whole batch) — and the block's share of the bounds.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *__restrict__ win, float4 *__restrict__ local_all,
-                                                              unsigned long long *__restrict__ keys64, uint32_t *__restrict__ vals,
+__global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *__restrict__ win, float4 *__restrict__ local_all, uint32_t *__restrict__ keys,
                                                               float *__restrict__ partial, int *__restrict__ range_overflow) {
   const int w = blockIdx.y;
   const BatchWin &W = win[w];
@@ -53,14 +53,13 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *_
       cnt = 1.f;
       mn[0] = mx[0] = o.x; mn[1] = mx[1] = o.y; mn[2] = mx[2] = o.z;
       const float cx = floorf(o.x * W.inv_leaf), cy = floorf(o.y * W.inv_leaf), cz = floorf(o.z * W.inv_leaf);
-      // 31 bits (z 9, y 11, x 11: +-102 m of height at a 0.4 m leaf; a window beyond that takes the single-window path) — with nine bits of
-      // window index the sort's key is 40 bits: five 8-bit passes instead of six at 512 windows
+      // PCL's voxel index in ABSOLUTE cells, z 9 bits | y 11 | x 11 (+-102 m of height at a 0.4 m leaf; a window beyond that takes the
+      // single-window path); the sort runs on the key relative to the window's bounds (seg_sort.h: KeyLayout)
       if (fabsf(cx) < 1024.f && fabsf(cy) < 1024.f && fabsf(cz) < 255.f) key = (uint32_t(int(cz) + 256) << 22) | (uint32_t(int(cy) + 1024) << 11) | uint32_t(int(cx) + 1024);
       else range_overflow[w] = 1;
     }
+    keys[W.loc_off + gid] = key;
   }
-  keys64[W.loc_off + gid] = (static_cast<unsigned long long>(w) << BW_KEY_BITS) | key;
-  vals[W.loc_off + gid] = uint32_t(W.loc_off + gid);
   __shared__ float sm[7][BW_THREADS / 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -78,75 +77,91 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_concat_keys(const BatchWin *_
   }
 }
 
-void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, unsigned long long *keys64, uint32_t *vals, float *partial,
-                           int *range_overflow, hipStream_t s) {
+// the window's bounds folded into VoxParams exactly as the single-window filter does, and from them how the sort sees the keys: one block
+// per window
+__device__ __forceinline__ int bits_for(int extent) { int b = 0; while ((1 << b) < extent) ++b; return b; }
+__global__ void __launch_bounds__(BW_THREADS) k_bw_key_layout(const BatchWin *__restrict__ win, const float *__restrict__ partial, VoxParams *__restrict__ params,
+                                                             KeyLayout *__restrict__ layout, int *__restrict__ range_overflow, int max_bits) {
+  const int w = blockIdx.x;
+  const BatchWin &W = win[w];
+  const int ntiles = W.loc_cap / BW_THREADS;
+  __shared__ float sm[7][BW_THREADS];
+  const int t = threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  float cnt = 0;
+  const float *pw = partial + size_t(W.loc_off / BW_THREADS) * 8;
+  for (int b = t; b < ntiles; b += BW_THREADS) {
+    for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], pw[size_t(b) * 8 + d]); mx[d] = fmaxf(mx[d], pw[size_t(b) * 8 + 3 + d]); }
+    cnt += pw[size_t(b) * 8 + 6];   // integers below 2^24: exact in any order
+  }
+  for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
+  sm[6][t] = cnt;
+  __syncthreads();
+  for (int st = BW_THREADS / 2; st > 0; st >>= 1) {
+    if (t < st) {
+      for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
+      sm[6][t] += sm[6][t + st];
+    }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  VoxParams v;
+  long long dd[3];
+  for (int d = 0; d < 3; ++d) {
+    v.mn[d] = sm[d][0]; v.mx[d] = sm[3 + d][0];
+    dd[d] = (long long)((v.mx[d] - v.mn[d]) * W.inv_leaf) + 1;
+    v.minb[d] = int(floorf(v.mn[d] * W.inv_leaf));
+    const int maxb = int(floorf(v.mx[d] * W.inv_leaf));
+    v.divb[d] = maxb - v.minb[d] + 1;
+  }
+  v.overflow = (sm[6][0] > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
+  v.n_valid = int(sm[6][0]);
+  params[w] = v;
+  KeyLayout L{0, 0, 0, 0, 0, 0};
+  if (v.n_valid > 0 && !range_overflow[w]) {
+    // floor(x inv_leaf) is monotone in x: the smallest stored cell coordinate of the window is the bound's
+    L.mx = v.minb[0] + 1024; L.my = v.minb[1] + 1024; L.mz = v.minb[2] + 256;
+    const int bx = bits_for(v.divb[0]), by = bits_for(v.divb[1]), bz = bits_for(v.divb[2]);
+    L.bx = bx; L.by = bx + by; L.bits = bx + by + bz;
+    if (L.bits > max_bits) range_overflow[w] = 1;   // the launch's passes order max_bits + 1 bits ("no point" sits one above the real keys): single-window path
+  }
+  layout[w] = L;
+}
+
+void launch_bw_concat_keys(const BatchWin *win, int B, int max_local, float4 *local_all, uint32_t *keys, float *partial, VoxParams *params, KeyLayout *layout,
+                           int *range_overflow, int max_bits, hipStream_t s) {
   if (B <= 0 || max_local <= 0) return;
-  hipLaunchKernelGGL(k_bw_concat_keys, dim3(cdiv(max_local, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, local_all, keys64, vals, partial, range_overflow);
+  hipLaunchKernelGGL(k_bw_concat_keys, dim3(cdiv(max_local, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, local_all, keys, partial, range_overflow);
+  hipLaunchKernelGGL(k_bw_key_layout, dim3(B), dim3(BW_THREADS), 0, s, win, partial, params, layout, range_overflow, max_bits);
   LIO_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
-// pcl::VoxelGrid (Estimator.cc:1518-1519), behind the sort: heads per 256-entry tile of a window's sorted range (+ one block per
-// window that folds the bounds into VoxParams exactly as the single-window filter does), then the centroids — a run is added up
-// in sorted order, i.e. in ascending original index (the sort is stable), the order the oracle fixes.
+// pcl::VoxelGrid (Estimator.cc:1518-1519), behind the sort: heads per 256-entry tile of a window's sorted range, then the centroids — a
+// run is added up in sorted order, i.e. in ascending original index (the sort is stable), the order the oracle fixes.  Keys: the sort's
+// relative keys, all ones = no point (sorted last); positions from n_local on hold nothing.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bw_is_head(const unsigned long long *__restrict__ keys, int pos, unsigned long long k) {
-  return (uint32_t(k) & BW_KEY_NONE) != BW_KEY_NONE && (pos == 0 || keys[pos - 1] != k);
+#define BW_SORTED_NONE 0xFFFFFFFFu
+__device__ __forceinline__ bool bw_is_head(const uint32_t *__restrict__ wkeys, int i, uint32_t k) {   // wkeys: the window's sorted keys, i < n_local
+  return k != BW_SORTED_NONE && (i == 0 || wkeys[i - 1] != k);
 }
-__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_heads(const BatchWin *__restrict__ win, const unsigned long long *__restrict__ keys,
-                                                            const float *__restrict__ partial, int *__restrict__ tile_heads,
-                                                            VoxParams *__restrict__ params) {
+__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_heads(const BatchWin *__restrict__ win, const uint32_t *__restrict__ keys, int *__restrict__ tile_heads) {
   const int w = blockIdx.y;
   const BatchWin &W = win[w];
   const int ntiles = W.loc_cap / BW_THREADS;
-  if (blockIdx.x == gridDim.x - 1) {
-    __shared__ float sm[7][BW_THREADS];
-    const int t = threadIdx.x;
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    float cnt = 0;
-    const float *pw = partial + size_t(W.loc_off / BW_THREADS) * 8;
-    for (int b = t; b < ntiles; b += BW_THREADS) {
-      for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], pw[size_t(b) * 8 + d]); mx[d] = fmaxf(mx[d], pw[size_t(b) * 8 + 3 + d]); }
-      cnt += pw[size_t(b) * 8 + 6];   // integers below 2^24: exact in any order
-    }
-    for (int d = 0; d < 3; ++d) { sm[d][t] = mn[d]; sm[3 + d][t] = mx[d]; }
-    sm[6][t] = cnt;
-    __syncthreads();
-    for (int st = BW_THREADS / 2; st > 0; st >>= 1) {
-      if (t < st) {
-        for (int d = 0; d < 3; ++d) { sm[d][t] = fminf(sm[d][t], sm[d][t + st]); sm[3 + d][t] = fmaxf(sm[3 + d][t], sm[3 + d][t + st]); }
-        sm[6][t] += sm[6][t + st];
-      }
-      __syncthreads();
-    }
-    if (t != 0) return;
-    VoxParams v;
-    long long dd[3];
-    for (int d = 0; d < 3; ++d) {
-      v.mn[d] = sm[d][0]; v.mx[d] = sm[3 + d][0];
-      dd[d] = (long long)((v.mx[d] - v.mn[d]) * W.inv_leaf) + 1;
-      v.minb[d] = int(floorf(v.mn[d] * W.inv_leaf));
-      const int maxb = int(floorf(v.mx[d] * W.inv_leaf));
-      v.divb[d] = maxb - v.minb[d] + 1;
-    }
-    v.overflow = (sm[6][0] > 0 && dd[0] * dd[1] * dd[2] > (long long)INT_MAX) ? 1 : 0;
-    v.n_valid = int(sm[6][0]);
-    params[w] = v;
-    return;
-  }
   if (int(blockIdx.x) >= ntiles) return;
   __shared__ int swave[BW_THREADS / 64];
-  const int pos = W.loc_off + int(blockIdx.x) * BW_THREADS + threadIdx.x;
-  const unsigned long long k = keys[pos];
-  const unsigned long long b = __ballot(bw_is_head(keys, pos, k));
+  const int i = int(blockIdx.x) * BW_THREADS + threadIdx.x;
+  const uint32_t *wk = keys + W.loc_off;
+  const uint32_t k = i < W.n_local ? wk[i] : BW_SORTED_NONE;
+  const unsigned long long b = __ballot(bw_is_head(wk, i, k));
   if ((threadIdx.x & 63) == 0) swave[threadIdx.x >> 6] = __popcll(b);
   __syncthreads();
   if (threadIdx.x == 0) tile_heads[W.loc_off / BW_THREADS + blockIdx.x] = (swave[0] + swave[1]) + (swave[2] + swave[3]);
 }
 
-__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_centroids(const BatchWin *__restrict__ win, const float4 *__restrict__ pts,
-                                                                const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                                const int *__restrict__ tile_heads, float4 *__restrict__ out,
+__global__ void __launch_bounds__(BW_THREADS) k_bw_vox_centroids(const BatchWin *__restrict__ win, const float4 *__restrict__ pts, const uint32_t *__restrict__ keys,
+                                                                const uint32_t *__restrict__ vals, const int *__restrict__ tile_heads, float4 *__restrict__ out,
                                                                 const VoxParams *__restrict__ params, int *__restrict__ range_overflow,
                                                                 BwVoxOut *__restrict__ vout) {
   const int w = blockIdx.y;
@@ -154,21 +169,22 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_vox_centroids(const BatchWin 
   const int ntiles = W.loc_cap / BW_THREADS;
   if (int(blockIdx.x) >= ntiles) return;
   __shared__ float4 sp[BW_THREADS];
-  __shared__ unsigned long long sk[BW_THREADS];
+  __shared__ uint32_t sk[BW_THREADS];
   __shared__ int swave[BW_THREADS / 64], sbase[BW_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int seg_end = W.loc_off + W.loc_cap;
-  const int base_i = W.loc_off + int(blockIdx.x) * BW_THREADS, i = base_i + tid;
+  const int base_i = int(blockIdx.x) * BW_THREADS, i = base_i + tid;
+  const uint32_t *wk = keys + W.loc_off;
+  const uint32_t *wvals = vals + W.loc_off;
   const int *th = tile_heads + W.loc_off / BW_THREADS;
   int before = 0;
   for (int b = tid; b < int(blockIdx.x); b += BW_THREADS) before += th[b];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
-  const unsigned long long k = keys[i];
-  const bool real = (uint32_t(k) & BW_KEY_NONE) != BW_KEY_NONE;
+  const uint32_t k = i < W.n_local ? wk[i] : BW_SORTED_NONE;
+  const bool real = k != BW_SORTED_NONE;
   sk[tid] = k;
-  if (real) sp[tid] = pts[vals[i]];
-  const bool head = bw_is_head(keys, i, k);
+  if (real) sp[tid] = pts[wvals[i]];
+  const bool head = bw_is_head(wk, i, k);
   const unsigned long long hb = __ballot(head);
   if (lane == 0) { swave[wv] = __popcll(hb); sbase[wv] = before; }
   __syncthreads();
@@ -190,17 +206,17 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_vox_centroids(const BatchWin 
   int cnt = e - tid;
   if (e == BW_THREADS) {
     int g = base_i + BW_THREADS;
-    while (g < seg_end && keys[g] == k) { const float4 p = pts[vals[g]]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++g; ++cnt; }
+    while (g < W.n_local && wk[g] == k) { const float4 p = pts[wvals[g]]; ax += p.x; ay += p.y; az += p.z; ai += p.w; ++g; ++cnt; }
   }
   const float c = float(cnt);
   out[W.loc_off + pos] = make_float4(ax / c, ay / c, az / c, ai / c);
 }
 
-void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const unsigned long long *keys_sorted, const uint32_t *vals_sorted,
-                          const float *partial, int *tile_heads, float4 *filtered_all, VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s) {
+void launch_bw_vox_finish(const BatchWin *win, int B, int max_cap, const float4 *local_all, const uint32_t *keys_sorted, const uint32_t *vals_sorted, int *tile_heads,
+                          float4 *filtered_all, const VoxParams *params, int *range_overflow, BwVoxOut *out, hipStream_t s) {
   if (B <= 0 || max_cap <= 0) return;
   const int ntiles = max_cap / BW_THREADS;
-  hipLaunchKernelGGL(k_bw_vox_heads, dim3(ntiles + 1, B), dim3(BW_THREADS), 0, s, win, keys_sorted, partial, tile_heads, params);
+  hipLaunchKernelGGL(k_bw_vox_heads, dim3(ntiles, B), dim3(BW_THREADS), 0, s, win, keys_sorted, tile_heads);
   hipLaunchKernelGGL(k_bw_vox_centroids, dim3(ntiles, B), dim3(BW_THREADS), 0, s, win, local_all, keys_sorted, vals_sorted, tile_heads, filtered_all, params,
                      range_overflow, out);
   LIO_HIP(hipGetLastError());
@@ -240,13 +256,13 @@ void launch_bw_setup(const BatchWin *win, int B, int max_slots, uint8_t *valid_a
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-NN grid (KdTreeFLANN::setInputCloud, Estimator.cc:1544-1545): the counting sort of cloud_kernels.hip per window; the cell
-// tables of the batch are laid end to end and scanned as ONE array, so a table entry is a position in the batch's cell-sorted
-// point array and the search kernels take that array's base as their map.
+// K-NN grid (KdTreeFLANN::setInputCloud, Estimator.cc:1544-1545): a window's filtered points ordered by cell (seg_sort.h: the same
+// segmented sort as the filter's, so the order inside a cell is the filtered cloud's — defined, unlike a histogram's atomics) and a
+// dense table of run starts per window; the tables of the batch are laid end to end, an entry is a position in the batch's
+// cell-sorted point array and the search kernels take that array's base as their map.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_count(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
-                                                             const float4 *__restrict__ filtered_all, uint32_t *__restrict__ keys,
-                                                             uint32_t *__restrict__ slot, int *__restrict__ cnt_all) {
+__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_keys(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+                                                            const float4 *__restrict__ filtered_all, uint32_t *__restrict__ keys) {
   const int w = blockIdx.y;
   const BatchGrid &G = grid[w];
   const int i = int(blockIdx.x) * BW_THREADS + threadIdx.x;
@@ -258,35 +274,67 @@ __global__ void __launch_bounds__(BW_THREADS) k_bw_cell_count(const BatchWin *__
   int cy = cell_coord(p.y, g.inv_cell) - g.origin[1];
   int cz = cell_coord(p.z, g.inv_cell) - g.origin[2];
   cx = min(max(cx, 0), g.dims[0] - 1); cy = min(max(cy, 0), g.dims[1] - 1); cz = min(max(cz, 0), g.dims[2] - 1);
-  const uint32_t c = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
-  keys[gi] = c;
-  slot[gi] = uint32_t(atomicAdd(&cnt_all[G.cell_off + int(c)], 1));
+  keys[gi] = uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz));
 }
-__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_place(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
+// behind the sort by cell: the cell-sorted points, and the table — entry c = position of the first point whose cell is >= c (an empty cell
+// holds the start of the next occupied one, entry n_cells the end), every entry written here: no histogram, no scan, no clearing.
+// A point whose cell differs from its predecessor's owns the entries (predecessor's cell, its own]; the wave writes those ranges one
+// after the other, 64 entries per store.
+__global__ void __launch_bounds__(BW_THREADS) k_bw_cell_table(const BatchWin *__restrict__ win, const BatchGrid *__restrict__ grid,
                                                              const float4 *__restrict__ filtered_all, const uint32_t *__restrict__ keys,
-                                                             const uint32_t *__restrict__ slot, const int *__restrict__ cells_all,
-                                                             float4 *__restrict__ sorted_all, int *__restrict__ cnt_all) {
+                                                             const uint32_t *__restrict__ vals, int *__restrict__ cells_all, float4 *__restrict__ sorted_all) {
   const int w = blockIdx.y;
   const BatchGrid &G = grid[w];
-  const int i = int(blockIdx.x) * BW_THREADS + threadIdx.x;
-  if (i >= G.n_filtered) return;
-  const int gi = win[w].loc_off + i;
-  float4 p = filtered_all[gi];
-  p.w = __int_as_float(i);
-  const int c = G.cell_off + int(keys[gi]);
-  sorted_all[cells_all[c] + int(slot[gi])] = p;
-  cnt_all[c] = 0;
+  const int n = G.n_filtered;
+  const int i0 = int(blockIdx.x) * BW_THREADS;
+  if (i0 >= max(n, 1)) return;
+  const int off = win[w].loc_off, i = i0 + threadIdx.x, lane = threadIdx.x & 63;
+  const int ncells = G.g.dims[0] * G.g.dims[1] * G.g.dims[2];
+  int *cells = cells_all + G.cell_off;
+  if (n == 0) {   // (block 0 only)
+    for (int c = threadIdx.x; c <= ncells; c += BW_THREADS) cells[c] = off;
+    return;
+  }
+  int lo = 0, hi = -1;   // entries [lo, hi] get the value off + i
+  if (i < n) {
+    const uint32_t gsrc = vals[off + i];
+    float4 p = filtered_all[gsrc];
+    p.w = __int_as_float(int(gsrc) - off);   // the point's index in the window's filtered cloud: what the search orders ties by
+    sorted_all[off + i] = p;
+    const int k = int(keys[off + i]), prev = i ? int(keys[off + i - 1]) : -1;
+    lo = prev + 1; hi = k;
+  }
+  // most ranges are one to a few entries (neighbouring occupied cells): the owning lane writes up to four itself; only what is left of the
+  // long ones (a jump to the next row or layer) goes through the wave, 64 entries per store
+#pragma unroll
+  for (int q = 0; q < 4; ++q) if (lo + q <= hi) cells[lo + q] = off + i;
+  lo += 4;
+  unsigned long long heads = __ballot(hi >= lo);
+  while (heads) {
+    const int src = __ffsll((long long)heads) - 1;
+    heads &= heads - 1;
+    const int a = __shfl(lo, src, 64), b = __shfl(hi, src, 64), v = off + (i - lane) + src;
+    for (int c = a + lane; c <= b; c += 64) cells[c] = v;
+  }
+  // entries behind the last occupied cell: the end (the whole block of the last point writes them)
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = -2;
+  __syncthreads();
+  if (i == n - 1) s_last = int(keys[off + i]);
+  __syncthreads();
+  if (s_last != -2)
+    for (int c = s_last + 1 + int(threadIdx.x); c <= ncells; c += BW_THREADS) cells[c] = off + n;
 }
-void launch_bw_cell_count(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, uint32_t *slot, int *cnt_all,
-                          hipStream_t s) {
+void launch_bw_cell_keys(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, uint32_t *keys, hipStream_t s) {
   if (B <= 0 || max_filtered <= 0) return;
-  hipLaunchKernelGGL(k_bw_cell_count, dim3(cdiv(max_filtered, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys, slot, cnt_all);
+  hipLaunchKernelGGL(k_bw_cell_keys, dim3(cdiv(max_filtered, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys);
   LIO_HIP(hipGetLastError());
 }
-void launch_bw_cell_place(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys, const uint32_t *slot,
-                          const int *cells_all, float4 *sorted_all, int *cnt_all, hipStream_t s) {
-  if (B <= 0 || max_filtered <= 0) return;
-  hipLaunchKernelGGL(k_bw_cell_place, dim3(cdiv(max_filtered, BW_THREADS), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys, slot, cells_all, sorted_all, cnt_all);
+void launch_bw_cell_table(const BatchWin *win, const BatchGrid *grid, int B, int max_filtered, const float4 *filtered_all, const uint32_t *keys_sorted,
+                          const uint32_t *vals_sorted, int *cells_all, float4 *sorted_all, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_bw_cell_table, dim3(std::max(1, cdiv(max_filtered, BW_THREADS)), B), dim3(BW_THREADS), 0, s, win, grid, filtered_all, keys_sorted, vals_sorted,
+                     cells_all, sorted_all);
   LIO_HIP(hipGetLastError());
 }
 

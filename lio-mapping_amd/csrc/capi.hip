@@ -7,6 +7,7 @@
 
 #include "../../include/lio_c.h"
 #include "est_batch.h"
+#include "seg_sort.h"
 #include "estimator.h"
 #include "rccl_comm.h"
 #include "host_init.h"
@@ -931,6 +932,10 @@ int lio_est_batch_sync(lio_est_batch *h) {
   if (!h) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
   return guarded([&] { h->b->Sync(); return LIO_OK; });
+}
+int lio_seg_sort_pairs(const unsigned *keys, const unsigned *vals, size_t n_total, const int *seg_off, const int *seg_n, int nseg, int bits, int passes, unsigned *keys_out,
+                       unsigned *vals_out) {
+  return guarded([&] { return seg_sort_host_test(keys, vals, n_total, seg_off, seg_n, nseg, bits, passes, keys_out, vals_out) ? LIO_OK : LIO_ERR_ARG; });
 }
 int lio_est_batch_stage_digest(lio_est_batch *h, int stage, unsigned long long *out) {
   if (!h || !out || stage < 0 || stage > 9) return LIO_ERR_ARG;

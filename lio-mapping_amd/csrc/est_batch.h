@@ -3,8 +3,8 @@
 // A batch adopts B estimator handles (independent windows: different vehicles, different logs, or the shards of an offline
 // re-optimisation).  One call solves all of them, every stage ONE launch over all windows:
 //
-//   concat + voxel keys | ONE sort | tile heads | centroids          BuildLocalMap        Estimator.cc:1480-1519
-//   cell histogram | ONE scan | placement                             KdTreeFLANN build    :1544-1545
+//   concat + voxel keys | segmented sort | tile heads | centroids     BuildLocalMap        Estimator.cc:1480-1519
+//   cell keys | segmented sort | cell-sorted points + run starts      KdTreeFLANN build    :1544-1545
 //   features of the frames behind the pivot                           CalculateFeatures    :970-1097
 //   <= 10 x (search + fit + rows | fold + 6x6 step)                   CalculateLaserOdom   :1242-1359
 //   <= max_iterations + 1 x (moments + IMU / prior / lidar-map aux row | trust-region step, one workgroup per window)
@@ -76,6 +76,7 @@ class EstimatorBatch {
     std::shared_ptr<MargPrior> dev_prior[2];   // which host object each of the two device prior buffers holds
     int cur = 0;                               // buffer holding prior_used
     int bpf = 1, max_slots = 0;
+    int key_bits = 0;                          // bits the window's relative voxel keys took in its last solve (0: not known yet)
     size_t part_off = 0;                       // doubles into partials_
   };
   void FetchPrior(int w, int buf, MargPrior &pr);
@@ -104,7 +105,6 @@ class EstimatorBatch {
   bool ev_valid_ = false;
   Slab lay_{};
   BatchClock clk_;
-  bool cnt_dirty_ = false;   // the cell histogram holds counts of a build that did not finish
   // pinned staging (one entry per window)
   BatchWin *h_win_ = nullptr; BatchGrid *h_grid_ = nullptr; BwVoxOut *h_vout_ = nullptr; OdomState *h_odom_ = nullptr;
   BatchSolve *h_bs_ = nullptr; DevProblem *h_pb_ = nullptr; DevState *h_st_ = nullptr; DevMarg *h_mg_ = nullptr;
@@ -115,13 +115,14 @@ class EstimatorBatch {
   DBuf<BatchSolve> d_bs_; DBuf<DevProblem> d_pb_; DBuf<DevState> d_st_; DBuf<DevMarg> d_mg_;
   DBuf<double> slab_, partials_, odom_partials_;
   DBuf<float4> local_all_, filtered_all_, sorted_all_, coef_all_;
-  DBuf<unsigned long long> keys64_, keys64b_;
-  DBuf<uint32_t> vals_, valsb_, ckeys_, cslot_;
+  DBuf<uint32_t> keys_, keysb_, vals_, valsb_, ckeys_, sort_hist_;   // the segmented sort's ping-pong pairs (filter, then K-NN grid) and its histograms
+  DBuf<SegDesc> d_seg_;
+  DBuf<KeyLayout> d_layout_;
+  SegDesc *h_seg_ = nullptr;
   DBuf<float> bounds_partial_, score_all_;
-  DBuf<int> tile_heads_, range_overflow_, cells_all_, cnt_all_, nconv_;
+  DBuf<int> tile_heads_, range_overflow_, cells_all_, nconv_;
   DBuf<VoxParams> vparams_;
   DBuf<uint8_t> valid_all_;
-  DBuf<char> sort_tmp_, scan_tmp_;
 };
 
 }  // namespace lio

@@ -2,8 +2,6 @@
 // solve_kernels.hip (launch A / launch B of the trust-region loop), marg_kernels.hip (marginalization).
 #include "est_batch.h"
 
-#include <rocprim/rocprim.hpp>
-
 #include <chrono>
 #include <exception>
 #include <string>
@@ -44,9 +42,9 @@ EstimatorBatch::EstimatorBatch(const std::vector<Estimator *> &members) : m_(mem
   win_.resize(B);
   for (size_t w = 0; w < B; ++w) { win_[w].e = m_[w]; m_[w]->AdoptStream(stream_); }
   pinned(h_win_, B); pinned(h_grid_, B); pinned(h_vout_, B); pinned(h_odom_, B); pinned(h_bs_, B); pinned(h_pb_, B); pinned(h_st_, B); pinned(h_mg_, B);
-  pinned(h_prior_, B * ds_prior_mats_size(MARG_MAX_N)); pinned(h_nconv_, 4);
+  pinned(h_prior_, B * ds_prior_mats_size(MARG_MAX_N)); pinned(h_nconv_, 4); pinned(h_seg_, 2 * B);
   d_win_.reserve(B); d_grid_.reserve(B); d_vout_.reserve(B); d_odom_.reserve(B); d_bs_.reserve(B); d_pb_.reserve(B); d_st_.reserve(B); d_mg_.reserve(B);
-  range_overflow_.reserve(B); vparams_.reserve(B); nconv_.reserve(4);
+  range_overflow_.reserve(B); vparams_.reserve(B); nconv_.reserve(4); d_seg_.reserve(2 * B); d_layout_.reserve(B);
   LIO_HIP(hipMemsetAsync(range_overflow_.p, 0, sizeof(int) * range_overflow_.cap, stream_));
   LIO_HIP(hipMemsetAsync(d_mg_.p, 0, sizeof(DevMarg) * d_mg_.cap, stream_));
   // the scratch slab of a window (doubles)
@@ -74,7 +72,8 @@ EstimatorBatch::~EstimatorBatch() {
     for (Estimator *e : m_) { e->solve_hook_ = nullptr; e->ReleaseAdoptedStream(); }
   } catch (...) {}
   for (void *p : {static_cast<void *>(h_win_), static_cast<void *>(h_grid_), static_cast<void *>(h_vout_), static_cast<void *>(h_odom_), static_cast<void *>(h_bs_),
-                  static_cast<void *>(h_pb_), static_cast<void *>(h_st_), static_cast<void *>(h_mg_), static_cast<void *>(h_prior_), static_cast<void *>(h_nconv_)})
+                  static_cast<void *>(h_pb_), static_cast<void *>(h_st_), static_cast<void *>(h_mg_), static_cast<void *>(h_prior_), static_cast<void *>(h_nconv_),
+                  static_cast<void *>(h_seg_)})
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_wait_) if (e) (void)hipEventDestroy(e);
@@ -297,7 +296,7 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   const size_t N = size_t(off);
   if (N > size_t(INT_MAX) / 2) throw std::runtime_error("EstimatorBatch: the batch's local maps exceed 2^30 points");
   local_all_.reserve(N, s); filtered_all_.reserve(N, s); sorted_all_.reserve(N, s);
-  keys64_.reserve(N, s); keys64b_.reserve(N, s); vals_.reserve(N, s); valsb_.reserve(N, s); ckeys_.reserve(N, s); cslot_.reserve(N, s);
+  keys_.reserve(N, s); keysb_.reserve(N, s); vals_.reserve(N, s); valsb_.reserve(N, s); ckeys_.reserve(N, s);
   bounds_partial_.reserve(N / 256 * 8, s); tile_heads_.reserve(N / 256, s);
   valid_all_.reserve(std::max(slot, 16), s); coef_all_.reserve(std::max(slot, 16), s); score_all_.reserve(std::max(slot, 16), s);
   odom_partials_.reserve(size_t(std::max(part_rows, 1)) * 28, s);
@@ -308,17 +307,33 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   LIO_HIP(hipMemcpyAsync(d_win_.p, h_win_, sizeof(BatchWin) * B, hipMemcpyHostToDevice, s));
   LIO_HIP(hipMemsetAsync(nconv_.p, 0, sizeof(int), s));
   launch_bw_setup(d_win_.p, B, max_slots, valid_all_.p, d_odom_.p, nconv_.p, s);
-  launch_bw_concat_keys(d_win_.p, B, max_cap, local_all_.p, keys64_.p, vals_.p, bounds_partial_.p, range_overflow_.p, s);
+  // The filter's order: 9-bit passes over the keys relative to each window's bounds (pass 0 converts the stored absolute keys on the fly
+  // and numbers the values); every window sorts its own range.  Three passes order 27 bits — 26 of key and "no point" above them — which
+  // is what a 200 m x 200 m x 25 m map at a 0.4 m leaf takes; the bounds are only known on the device, so the host goes by what each
+  // window's keys took in its previous solve (4 passes while unknown).  A window that outgrows the guess is flagged by
+  // the layout kernel and re-done by the single-window path.
+  int vox_passes = 3;
+  for (int w = 0; w < B; ++w) if (win_[w].device && (win_[w].key_bits == 0 || win_[w].key_bits > 26)) vox_passes = 4;
+  launch_bw_concat_keys(d_win_.p, B, max_cap, local_all_.p, ckeys_.p, bounds_partial_.p, vparams_.p, d_layout_.p, range_overflow_.p,
+                        std::min(31, SS_MAX_BITS * vox_passes - 1), s);
+  const uint32_t *keys_sorted = nullptr, *vals_sorted = nullptr;
   {
-    int wbits = 0;
-    while ((1 << wbits) < B) ++wbits;
-    size_t tmp_bytes = 0;
-    LIO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys64_.p, keys64b_.p, vals_.p, valsb_.p, N, 0, BW_KEY_BITS + wbits, s));
-    sort_tmp_.reserve(tmp_bytes + 256, s);
-    LIO_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp_bytes, keys64_.p, keys64b_.p, vals_.p, valsb_.p, N, 0, BW_KEY_BITS + wbits, s));
+    SegDesc *seg = h_seg_;
+    for (int w = 0; w < B; ++w) seg[w] = SegDesc{h_win_[w].loc_off, h_win_[w].n_local, 0};
+    const SegSortPlan plan = seg_sort_plan(seg, B, SS_MAX_BITS);
+    sort_hist_.reserve(std::max<size_t>(plan.hist_entries, 1), s);
+    LIO_HIP(hipMemcpyAsync(d_seg_.p, seg, sizeof(SegDesc) * B, hipMemcpyHostToDevice, s));
+    const uint32_t *ki = ckeys_.p, *vi = nullptr;
+    uint32_t *ko = keys_.p, *vo = vals_.p, *ko2 = keysb_.p, *vo2 = valsb_.p;
+    for (int p = 0; p < vox_passes; ++p) {
+      const int shift = p * SS_MAX_BITS, bits = std::min(SS_MAX_BITS, 32 - shift);
+      seg_sort_pass(d_seg_.p, B, plan, ki, vi, ko, vo, sort_hist_.p, shift, bits, p == 0 ? d_layout_.p : nullptr, s);
+      ki = ko; vi = vo;
+      std::swap(ko, ko2); std::swap(vo, vo2);
+    }
+    keys_sorted = ki; vals_sorted = vi;
   }
-  launch_bw_vox_finish(d_win_.p, B, max_cap, local_all_.p, keys64b_.p, valsb_.p, bounds_partial_.p, tile_heads_.p, filtered_all_.p, vparams_.p, range_overflow_.p,
-                       d_vout_.p, s);
+  launch_bw_vox_finish(d_win_.p, B, max_cap, local_all_.p, keys_sorted, vals_sorted, tile_heads_.p, filtered_all_.p, vparams_.p, range_overflow_.p, d_vout_.p, s);
   LIO_HIP(hipMemcpyAsync(h_vout_, d_vout_.p, sizeof(BwVoxOut) * B, hipMemcpyDeviceToHost, s));
   LIO_HIP(hipEventRecord(ev_[1], s));
   LIO_HIP(hipStreamSynchronize(s));
@@ -335,7 +350,12 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
     size_t ncells = 1;
     G.g.dims[0] = G.g.dims[1] = G.g.dims[2] = 1;
     G.g.inv_cell = 1.f;
-    if (Wn.device && (vo.params.overflow || vo.range_overflow)) Wn.device = false;   // PCL's own index / "leaf too small": the single-window path has those forms
+    {   // what the window's relative keys took: the next solve's guess for the number of sort passes
+      int kb = 0;
+      for (int d = 0; d < 3; ++d) { int b = 0; while ((1 << b) < vo.params.divb[d]) ++b; kb += b; }
+      Wn.key_bits = vo.params.n_valid > 0 ? std::max(kb, 1) : Wn.key_bits;
+    }
+    if (Wn.device && (vo.params.overflow || vo.range_overflow)) Wn.device = false;   // PCL's own index / "leaf too small" / keys beyond the passes: the single-window path has those forms
     if (Wn.device && vo.count > 0) {
       const float cell = std::sqrt(Wn.e->cfg_.min_match_sq_dis) * 1.0001f + 1e-6f;
       G.g.inv_cell = 1.0f / cell;
@@ -354,21 +374,30 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   }
   if (cell_total > size_t(INT_MAX)) throw std::runtime_error("EstimatorBatch: the batch's cell tables exceed 2^31 entries");
   cells_all_.reserve(cell_total, s);
-  if (cnt_all_.cap < cell_total || cnt_dirty_) {
-    cnt_all_.reserve(cell_total, s);
-    LIO_HIP(hipMemsetAsync(cnt_all_.p, 0, cnt_all_.cap * sizeof(int), s));
-  }
-  cnt_dirty_ = true;
   LIO_HIP(hipMemcpyAsync(d_grid_.p, h_grid_, sizeof(BatchGrid) * B, hipMemcpyHostToDevice, s));
-  launch_bw_cell_count(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cnt_all_.p, s);
+  launch_bw_cell_keys(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, s);
   {
-    size_t tmp_bytes = 0;
-    LIO_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt_all_.p, cells_all_.p, 0, cell_total, rocprim::plus<int>(), s));
-    scan_tmp_.reserve(tmp_bytes + 256, s);
-    LIO_HIP(rocprim::exclusive_scan(scan_tmp_.p, tmp_bytes, cnt_all_.p, cells_all_.p, 0, cell_total, rocprim::plus<int>(), s));
+    // a window's filtered points ordered by cell: as many 9-bit passes as the largest table's index needs
+    SegDesc *seg = h_seg_ + B;
+    int bits = 1;
+    for (int w = 0; w < B; ++w) {
+      seg[w] = SegDesc{h_win_[w].loc_off, h_grid_[w].n_filtered, 0};
+      const long long nc = (long long)h_grid_[w].g.dims[0] * h_grid_[w].g.dims[1] * h_grid_[w].g.dims[2];
+      while ((1ll << bits) < nc) ++bits;
+    }
+    const int passes = std::max(1, (bits + SS_MAX_BITS - 1) / SS_MAX_BITS);
+    const SegSortPlan plan = seg_sort_plan(seg, B, SS_MAX_BITS);
+    sort_hist_.reserve(std::max<size_t>(plan.hist_entries, 1), s);
+    LIO_HIP(hipMemcpyAsync(d_seg_.p + B, seg, sizeof(SegDesc) * B, hipMemcpyHostToDevice, s));
+    const uint32_t *ki = ckeys_.p, *vi = nullptr;
+    uint32_t *ko = keys_.p, *vo = vals_.p, *ko2 = keysb_.p, *vo2 = valsb_.p;
+    for (int p = 0; p < passes; ++p) {
+      seg_sort_pass(d_seg_.p + B, B, plan, ki, vi, ko, vo, sort_hist_.p, p * SS_MAX_BITS, SS_MAX_BITS, nullptr, s);
+      ki = ko; vi = vo;
+      std::swap(ko, ko2); std::swap(vo, vo2);
+    }
+    launch_bw_cell_table(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ki, vi, cells_all_.p, sorted_all_.p, s);
   }
-  launch_bw_cell_place(d_win_.p, d_grid_.p, B, max_filtered, filtered_all_.p, ckeys_.p, cslot_.p, cells_all_.p, sorted_all_.p, cnt_all_.p, s);
-  cnt_dirty_ = false;
   LIO_HIP(hipEventRecord(ev_[2], s));
   launch_bw_features(d_win_.p, d_grid_.p, B, max_M, max_static, q_static, knobs_, sorted_all_.p, cells_all_.p, valid_all_.p, coef_all_.p, score_all_.p, s);
   LIO_HIP(hipEventRecord(ev_[3], s));

@@ -244,6 +244,8 @@ _SIGS = {
     "lio_est_batch_get_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "lio_est_batch_stage_digest": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]),
     "lio_est_batch_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "lio_seg_sort_pairs": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lio_est_set_factor_sharding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lio_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "lio_rccl_init": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int]),
@@ -349,6 +351,18 @@ class LioLib:
         ms, n_out = C.c_double(0), C.c_size_t(0)
         _chk(self.dll.lio_bench_voxel_grid(_fp(xyzi), xyzi.shape[0], float(leaf), int(reps), C.byref(ms), C.byref(n_out)), "lio_bench_voxel_grid")
         return ms.value, int(n_out.value)
+
+    def seg_sort_pairs(self, keys, values, seg_off, seg_n, bits, passes):
+        """stable radix sort of (key, value) pairs inside segments (lio_seg_sort_pairs); values None: the elements' positions"""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        vals = None if values is None else np.ascontiguousarray(values, dtype=np.uint32)
+        so, sn = np.ascontiguousarray(seg_off, dtype=np.int32), np.ascontiguousarray(seg_n, dtype=np.int32)
+        ko, vo = np.zeros_like(keys), np.zeros_like(keys)
+        u32 = C.POINTER(C.c_uint32)
+        _chk(self.dll.lio_seg_sort_pairs(keys.ctypes.data_as(u32), vals.ctypes.data_as(u32) if vals is not None else None, keys.shape[0],
+                                         so.ctypes.data_as(c_int32_p), sn.ctypes.data_as(c_int32_p), so.shape[0], int(bits), int(passes),
+                                         ko.ctypes.data_as(u32), vo.ctypes.data_as(u32)), "lio_seg_sort_pairs")
+        return ko, vo
 
     def voxel_grid(self, xyzi, leaf):
         xyzi = _f32(xyzi).reshape(-1, 4)

@@ -833,6 +833,21 @@ int lio_est_batch_set_option(lio_est_batch *b, const char *name, int value) {   
     if (std::strcmp(name, k) == 0) return LIO_OK;
   return LIO_ERR_ARG;
 }
+int lio_seg_sort_pairs(const unsigned *keys, const unsigned *vals, size_t n_total, const int *seg_off, const int *seg_n, int nseg, int bits, int passes, unsigned *keys_out,
+                       unsigned *vals_out) {
+  // the CPU statement of what the hook sorts: a stable sort of every segment on the low passes * bits bits of the key
+  if (!keys || !seg_off || !seg_n || nseg < 1 || bits < 1 || bits > 9 || passes < 1 || passes * bits > 32 || !keys_out || !vals_out) return LIO_ERR_ARG;
+  for (size_t i = 0; i < n_total; ++i) { keys_out[i] = keys[i]; vals_out[i] = vals ? vals[i] : 0u; }
+  const unsigned long long mask = (passes * bits >= 32) ? 0xFFFFFFFFull : ((1ull << (passes * bits)) - 1ull);
+  for (int k = 0; k < nseg; ++k) {
+    if (seg_off[k] < 0 || seg_n[k] < 0 || size_t(seg_off[k]) + size_t(seg_n[k]) > n_total) return LIO_ERR_ARG;
+    std::vector<unsigned> idx(size_t(seg_n[k]));
+    for (int i = 0; i < seg_n[k]; ++i) idx[size_t(i)] = unsigned(seg_off[k] + i);
+    std::stable_sort(idx.begin(), idx.end(), [&](unsigned a, unsigned b) { return (keys[a] & mask) < (keys[b] & mask); });
+    for (int i = 0; i < seg_n[k]; ++i) { keys_out[seg_off[k] + i] = keys[idx[size_t(i)]]; vals_out[seg_off[k] + i] = vals ? vals[idx[size_t(i)]] : idx[size_t(i)]; }
+  }
+  return LIO_OK;
+}
 int lio_est_batch_stage_digest(lio_est_batch *b, int stage, unsigned long long *out) {
   if (!b || !out || stage < 0 || stage > 9) return LIO_ERR_ARG;
   if (b->dissolved) return LIO_ERR_STATE;

@@ -20,11 +20,11 @@ out = {}
 rows = []
 for key in sorted(set(f) | set(w), key=lambda kg: -(f.get(kg, (0, 0))[0] * f.get(kg, (0, 0))[1])):
     k, g = key
-    if not k.startswith("lio::"):
+    if "lio::" not in k.split("(")[0]:
         continue
     nf, vf = f.get(key, (0, 0.0))
     nw, vw = w.get(key, (0, 0.0))
-    short = k.split("(")[0]
+    short = k.split("(")[0].replace("void ", "")
     hbm = (2 * vf + vw) * 1024
     out.setdefault(short, []).append({"grid_size": g, "launches": nf, "fetch_kb": vf, "write_kb": vw, "hbm_bytes_corrected": hbm})
     rows.append((short, g, nf, vf, vw, hbm))

@@ -232,8 +232,9 @@ __device__ __forceinline__ FeatResult features_eval(const FeatFrame fr, const Fe
   FeatResult res;
   res.owner = false; res.ok = 0; res.c = make_float4(0, 0, 0, 0); res.sc = 0; res.abs = make_float4(0, 0, 0, 0); res.po = make_float4(0, 0, 0, 0); res.slot = 0;
   const int gt = block_x * blockDim.x + threadIdx.x;
-  const int i = gt / LPQ, sub = gt % LPQ;
-  const bool active = i < fr.M;
+  const int it = gt / LPQ, sub = gt % LPQ;
+  const bool active = it < fr.M;
+  const int i = (active && fr.order) ? int(fr.order[it]) - fr.slot_off : it;   // (FeatFrame::order: which query this lane group works on)
   const float *tp = transforms + 8 * fr.tf_index;
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   Vec3<float> t(tp[4], tp[5], tp[6]);

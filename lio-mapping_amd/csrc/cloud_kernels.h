@@ -92,7 +92,10 @@ class KnnGrid {
   DBuf<char> tmp_;
 };
 
-struct FeatFrame { const float4 *stack; int M; int slot_off; int tf_index; };
+// order (optional): the queries are PROCESSED in this order — order[t] = slot (slot_off + index into stack) of the t-th query — so that the lanes
+// of a wave search neighbouring map cells and their gathers fall into the same cache lines; results go to the queries' own slots, so nothing
+// downstream sees the order
+struct FeatFrame { const float4 *stack; int M; int slot_off; int tf_index; const uint32_t *order = nullptr; };
 struct FeatArgs {
   FeatFrame fr[LIO_MAX_FRAMES];
   int nframes;
@@ -178,8 +181,13 @@ struct KfMapDesc {
   const float4 *surf_sorted; const int *surf_cells; GridDesc surf_grid;
 };
 // grid z limit: n_keyframes <= 65535 per launch
+// order_or_null: processing order of every keyframe's queries (global slots; a keyframe's corner queries at [slot_off, slot_off + Mc), its surf
+// queries behind them), e.g. sorted by map cell (launch_kf_query_keys + the segmented sort)
+void launch_kf_query_keys(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all, uint32_t *keys,
+                          hipStream_t s);
 void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, long long total_queries,
-                     const float4 *stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s);
+                     const float4 *stack_all, const uint32_t *order_or_null, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef,
+                     hipStream_t s);
 void launch_kf_rows(const KfDesc *kd, const OdomState *st, int n_keyframes, int max_nb, const float4 *stack_all, const uint8_t *valid, const float4 *coef,
                     double *partials, int b_from_coef, hipStream_t s);
 // n_converged (device int) is incremented once per keyframe when it converges

@@ -576,10 +576,11 @@ template <int LPQ = FEAT_LPQ>
 __device__ __forceinline__ void line_features_body(int block_x, const float4 *__restrict__ stack, int M, int slot_off, const float *__restrict__ tp,
                                                    const Vec3<float> &pz, float min_match_sq_dis, const float4 *__restrict__ map,
                                                    const int *__restrict__ cells, const GridDesc &g, uint8_t *__restrict__ valid,
-                                                   float4 *__restrict__ coef) {
+                                                   float4 *__restrict__ coef, const uint32_t *__restrict__ order = nullptr) {
   const int gt = block_x * blockDim.x + threadIdx.x;
-  const int i = gt / LPQ, sub = gt % LPQ;
-  const bool active = i < M;
+  const int it = gt / LPQ, sub = gt % LPQ;
+  const bool active = it < M;
+  const int i = (active && order) ? int(order[it]) - slot_off : it;   // (processing order: FeatFrame::order)
   Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
   Vec3<float> t(tp[4], tp[5], tp[6]);
   float4 po = active ? stack[i] : make_float4(0, 0, 0, 0);
@@ -834,8 +835,8 @@ void launch_odom_round(const FeatArgs &a, int base_slot, int round, int keep, Od
 // ------------------------------------------------------------------------------------------------
 template <int LPQ>
 __device__ __forceinline__ void kf_round_body(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,
-                                                 const float4 *__restrict__ stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode,
-                                                 uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
+                                                 const float4 *__restrict__ stack_all, const uint32_t *__restrict__ order, float min_match_sq_dis, float min_plane_dis,
+                                                 int mapping_mode, uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
   const int k = blockIdx.z;
   if (st[k].converged) return;
   const KfDesc d = kd[k];
@@ -845,11 +846,11 @@ __device__ __forceinline__ void kf_round_body(const KfDesc *__restrict__ kd, con
     const KfMapDesc &m = md[d.map];
     // (the maps' pointers come from a descriptor: tied to a kernel argument they are global to the compiler, dev.h: rebase)
     line_features_body<LPQ>(blockIdx.x, stack_all + d.slot_off, d.Mc, d.slot_off, tp, Vec3<float>(d.pz[0], d.pz[1], d.pz[2]), min_match_sq_dis,
-                       rebase(stack_all, m.corner_sorted), rebase(stack_all, m.corner_cells), m.corner_grid, valid, coef);
+                       rebase(stack_all, m.corner_sorted), rebase(stack_all, m.corner_cells), m.corner_grid, valid, coef, order ? order + d.slot_off : nullptr);
   } else {
     if (int(blockIdx.x) * 128 >= d.Ms * LPQ) return;
     const KfMapDesc &m = md[d.map];
-    const FeatFrame fr{stack_all + d.slot_off + d.Mc, d.Ms, d.slot_off + d.Mc, 0};
+    const FeatFrame fr{stack_all + d.slot_off + d.Mc, d.Ms, d.slot_off + d.Mc, 0, order ? order + d.slot_off + d.Mc : nullptr};
     const FeatScalars fs{min_match_sq_dis, min_plane_dis, mapping_mode, {d.pz[0], d.pz[1], d.pz[2]}};
     features_body<true, LPQ>(fr, fs, blockIdx.x, tp, rebase(stack_all, m.surf_sorted), rebase(stack_all, m.surf_cells), m.surf_grid, valid, coef, nullptr, nullptr);
   }
@@ -857,16 +858,16 @@ __device__ __forceinline__ void kf_round_body(const KfDesc *__restrict__ kd, con
 
 template <int LPQ>
 __global__ void __launch_bounds__(128) k_kf_round(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,
-                                                 const float4 *__restrict__ stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode,
-                                                 uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
-  kf_round_body<LPQ>(kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
+                                                 const float4 *__restrict__ stack_all, const uint32_t *__restrict__ order, float min_match_sq_dis, float min_plane_dis,
+                                                 int mapping_mode, uint8_t *__restrict__ valid, float4 *__restrict__ coef) {
+  kf_round_body<LPQ>(kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
 }
 #define KF_OCC_VARIANT(W)                                                                                                                      \
   __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(W, W)))                                                            \
   k_kf_round1_w##W(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,                          \
-                   const float4 *__restrict__ stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode,                        \
-                   uint8_t *__restrict__ valid, float4 *__restrict__ coef) {                                                                   \
-    kf_round_body<1>(kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);                                       \
+                   const float4 *__restrict__ stack_all, const uint32_t *__restrict__ order, float min_match_sq_dis, float min_plane_dis,      \
+                   int mapping_mode, uint8_t *__restrict__ valid, float4 *__restrict__ coef) {                                                 \
+    kf_round_body<1>(kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);                                \
   }
 // the one-lane-per-query form is bound by gather latency: 8 waves per SIMD (64 VGPRs, the fit phase spills a little) beats
 // the 5 waves the default allocation gives by 15% (54.4 -> 46.1 ms at 1000 HDL-64 keyframes)
@@ -893,8 +894,37 @@ __global__ void k_kf_update(const KfDesc *__restrict__ kd, OdomState *st, const 
   if (threadIdx.x == 0 && st[k].converged) atomicAdd(n_converged, 1);
 }
 
+// the map cell of every query under its keyframe's current transform: the key the queries' processing order is sorted by (all ones: outside
+// the map's grid — such a query finds nothing and costs nothing wherever it sits)
+__global__ void __launch_bounds__(256) k_kf_query_keys(const KfDesc *__restrict__ kd, const KfMapDesc *__restrict__ md, const OdomState *__restrict__ st,
+                                                      const float4 *__restrict__ stack_all, uint32_t *__restrict__ keys) {
+  const int k = blockIdx.z;
+  const KfDesc d = kd[k];
+  const bool surf = blockIdx.y == 1;
+  const int M = surf ? d.Ms : d.Mc, i = int(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int slot = d.slot_off + (surf ? d.Mc : 0) + i;
+  const KfMapDesc &m = md[d.map];
+  const GridDesc &g = surf ? m.surf_grid : m.corner_grid;
+  const float *tp = st[k].T;
+  const Quat<float> q(tp[3], tp[0], tp[1], tp[2]);
+  const float4 po = stack_all[slot];
+  const Vec3<float> r = rotate(q, Vec3<float>(po.x, po.y, po.z));
+  const int cx = cell_coord(r.x + tp[4], g.inv_cell) - g.origin[0], cy = cell_coord(r.y + tp[5], g.inv_cell) - g.origin[1],
+            cz = cell_coord(r.z + tp[6], g.inv_cell) - g.origin[2];
+  const bool in = cx >= 0 && cy >= 0 && cz >= 0 && cx < g.dims[0] && cy < g.dims[1] && cz < g.dims[2];
+  keys[slot] = in ? uint32_t(cx + g.dims[0] * (cy + g.dims[1] * cz)) : 0xFFFFFFFFu;
+}
+void launch_kf_query_keys(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, const float4 *stack_all, uint32_t *keys,
+                          hipStream_t s) {
+  if (n_keyframes <= 0) return;
+  hipLaunchKernelGGL(k_kf_query_keys, dim3(std::max(1, cdiv(std::max(max_Mc, max_Ms), 256)), 2, n_keyframes), dim3(256), 0, s, kd, md, st, stack_all, keys);
+  LIO_HIP(hipGetLastError());
+}
+
 void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st, int n_keyframes, int max_Mc, int max_Ms, long long total_queries,
-                     const float4 *stack_all, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef, hipStream_t s) {
+                     const float4 *stack_all, const uint32_t *order, float min_match_sq_dis, float min_plane_dis, int mapping_mode, uint8_t *valid, float4 *coef,
+                     hipStream_t s) {
   // lanes per query: a small batch is latency-bound (8 lanes shorten each query's dependent candidate walk); once the batch
   // fills the GPU many times over, one lane per query wins 1.8x (no merge rounds, no idle lanes in the fit): measured
   // 96 / 69 / 59 / 55 ms for 8 / 4 / 2 / 1 lanes at 1000 HDL-64 keyframes.  The result does not depend on the split.
@@ -902,8 +932,8 @@ void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st,
   const int lpq = lpq_env ? lpq_env : (total_queries >= 400000 ? 1 : total_queries >= 60000 ? 4 : 8);
   const int bx = std::max(1, cdiv((long long)std::max(max_Mc, max_Ms) * lpq, 128));
   const dim3 grid(bx, 2, n_keyframes);
-#define KF_ROUND(L) hipLaunchKernelGGL(k_kf_round<L>, grid, dim3(128), 0, s, kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef)
-  if (lpq == 1) hipLaunchKernelGGL(k_kf_round1_w8, grid, dim3(128), 0, s, kd, md, st, stack_all, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
+#define KF_ROUND(L) hipLaunchKernelGGL(k_kf_round<L>, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef)
+  if (lpq == 1) hipLaunchKernelGGL(k_kf_round1_w8, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
   else if (lpq == 2) KF_ROUND(2); else if (lpq == 4) KF_ROUND(4); else KF_ROUND(8);
 #undef KF_ROUND
   LIO_HIP(hipGetLastError());

@@ -8,6 +8,7 @@
 
 #include "../../include/lio_c.h"
 #include "cloud_kernels.h"
+#include "seg_sort.h"
 #include "hmath.h"
 
 namespace lio {
@@ -20,6 +21,7 @@ class KfBatchDev {
   int AddKeyframe(int map, const float *corner, size_t nc, const float *surf, size_t ns, const Rigid<float> &T_init);
   void ClearKeyframes();
   void Refine();
+  void BuildQueryOrder(hipStream_t s);
   // Refine + all-gather of the packed results (9 floats per keyframe: q, p, iterations, rows) over an RCCL communicator, straight
   // from the device pose buffer; packed_all (host) receives world * slots_per_rank * 9 floats
   void RefineGather(void *nccl_comm, int world, int slots_per_rank, float *packed_all);
@@ -52,6 +54,11 @@ class KfBatchDev {
   DBuf<double> partials_;
   DBuf<int> d_nconv_;
   DBuf<float> d_pack_, d_gather_;
+  // the queries' processing order (sorted by map cell under the keyframes' starting poses; rebuilt when the keyframe set changes) and the
+  // segmented sort's scratch
+  DBuf<uint32_t> order_, qkeys_, qkeys2_, qvals2_, qhist_;
+  DBuf<SegDesc> d_qseg_;
+  bool order_valid_ = false;
   int *h_nconv_ = nullptr;  // pinned
   bool md_dirty_ = true, kf_dirty_ = true;
   int max_Mc_ = 0, max_Ms_ = 0, max_nb_ = 1, total_nb_ = 0, n_gated_ = 0;

@@ -89,14 +89,52 @@ int KfBatchDev::AddKeyframe(int map, const float *corner, size_t nc, const float
   h_kd_.push_back(d);
   max_Mc_ = std::max(max_Mc_, d.Mc); max_Ms_ = std::max(max_Ms_, d.Ms); max_nb_ = std::max(max_nb_, d.nb);
   n_queries_ += (long long)(nc + ns);
-  kf_dirty_ = true;
+  kf_dirty_ = true; order_valid_ = false;
   return int(h_kd_.size()) - 1;
 }
 
 void KfBatchDev::ClearKeyframes() {
   h_stack_.clear(); h_kd_.clear(); h_st0_.clear(); h_st_.clear();
   max_Mc_ = max_Ms_ = 0; max_nb_ = 1; total_nb_ = 0; n_gated_ = 0; n_queries_ = 0;
-  kf_dirty_ = true;
+  kf_dirty_ = true; order_valid_ = false;
+}
+
+// The order the round kernels take the queries in: every keyframe's corner and surf queries sorted by the map cell they fall into under the
+// keyframe's starting pose (they move by centimetres over the rounds).  A wave's 64 queries then walk the same few rows of cells, and the
+// 16-byte gathers of its lanes fall into shared cache lines instead of 64 different ones (the walk is bound by those gathers: with every
+// lane of a wave on ONE query the batched features kernel ran 2.1x faster, profiles/r6_d_query_order.txt).  Results stay in the queries'
+// own slots: rows, updates and poses do not see the order.
+void KfBatchDev::BuildQueryOrder(hipStream_t s) {
+  const int B = int(h_kd_.size());
+  const size_t n = std::max<size_t>(h_stack_.size(), 1);
+  order_.reserve(n); qkeys_.reserve(n); qkeys2_.reserve(n); qvals2_.reserve(n);
+  std::vector<SegDesc> seg(size_t(2) * B);
+  for (int k = 0; k < B; ++k) {
+    seg[size_t(2) * k] = SegDesc{h_kd_[size_t(k)].slot_off, h_kd_[size_t(k)].Mc, 0};
+    seg[size_t(2) * k + 1] = SegDesc{h_kd_[size_t(k)].slot_off + h_kd_[size_t(k)].Mc, h_kd_[size_t(k)].Ms, 0};
+  }
+  int bits = 1;
+  for (const KfMapDesc &m : h_md_)
+    for (const GridDesc *g : {&m.corner_grid, &m.surf_grid}) {
+      const long long nc = (long long)g->dims[0] * g->dims[1] * g->dims[2];
+      while ((1ll << bits) < nc) ++bits;
+    }
+  const int passes = std::max(1, (bits + SS_MAX_BITS - 1) / SS_MAX_BITS);
+  const SegSortPlan plan = seg_sort_plan(seg.data(), 2 * B, SS_MAX_BITS);
+  qhist_.reserve(std::max<size_t>(plan.hist_entries, 1));
+  d_qseg_.reserve(seg.size());
+  LIO_HIP(hipMemcpyAsync(d_qseg_.p, seg.data(), seg.size() * sizeof(SegDesc), hipMemcpyHostToDevice, s));
+  for (int off = 0; off < B; off += kChunk)
+    launch_kf_query_keys(d_kd_.p + off, d_md_.p, d_st_.p + off, std::min(kChunk, B - off), max_Mc_, max_Ms_, d_stack_.p, qkeys_.p, s);
+  // ping-pong so that the last pass lands in order_ (queries outside the grid sort last: their keys keep the bits above the passes)
+  const uint32_t *ki = qkeys_.p, *vi = nullptr;
+  uint32_t *kb[2] = {qkeys2_.p, qkeys_.p}, *vb[2] = {(passes & 1) ? order_.p : qvals2_.p, (passes & 1) ? qvals2_.p : order_.p};
+  for (int p = 0; p < passes; ++p) {
+    seg_sort_pass(d_qseg_.p, 2 * B, plan, ki, vi, kb[p & 1], vb[p & 1], qhist_.p, p * SS_MAX_BITS, SS_MAX_BITS, nullptr, s);
+    ki = kb[p & 1]; vi = vb[p & 1];
+  }
+  LIO_HIP(hipStreamSynchronize(s));   // (seg is a local)
+  order_valid_ = true;
 }
 
 void KfBatchDev::Refine() {
@@ -120,6 +158,7 @@ void KfBatchDev::Refine() {
   }
   LIO_HIP(hipMemcpyAsync(d_st_.p, h_st0_.data(), size_t(B) * sizeof(OdomState), hipMemcpyHostToDevice, s));
   LIO_HIP(hipMemsetAsync(d_nconv_.p, 0, sizeof(int), s));
+  if (!order_valid_) BuildQueryOrder(s);
   const bool four_dof = cfg_.map_builder && cfg_.enable_4d;
   const int mode = four_dof ? 2 : 1;
   const int max_it = cfg_.num_max_iterations;
@@ -127,7 +166,7 @@ void KfBatchDev::Refine() {
   for (int iter = 0; iter < max_it; ++iter) {
     for (int off = 0; off < B; off += kChunk) {
       const int nk = std::min(kChunk, B - off);
-      launch_kf_round(d_kd_.p + off, d_md_.p, d_st_.p + off, nk, max_Mc_, max_Ms_, n_queries_, d_stack_.p, cfg_.min_match_sq_dis, cfg_.min_plane_dis, mode, valid_.p,
+      launch_kf_round(d_kd_.p + off, d_md_.p, d_st_.p + off, nk, max_Mc_, max_Ms_, n_queries_, d_stack_.p, order_.p, cfg_.min_match_sq_dis, cfg_.min_plane_dis, mode, valid_.p,
                       coef_.p, s);
       launch_kf_rows(d_kd_.p + off, d_st_.p + off, nk, max_nb_, d_stack_.p, valid_.p, coef_.p, partials_.p, mode, s);
       launch_kf_update(d_kd_.p + off, d_st_.p + off, nk, partials_.p, iter, 50, four_dof ? 1 : 0, d_nconv_.p, s);

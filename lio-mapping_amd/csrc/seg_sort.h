@@ -34,7 +34,7 @@ struct SegDesc {
 struct KeyLayout { int mx, my, mz; int bx, by; int bits; };   // mins in the stored key's offset space; shifts; total bits (> 27: not sortable in three 9-bit passes)
 
 struct SegSortPlan {
-  int threads;          // 256 or 1024 per block: tile = threads * SS_ITEMS
+  int threads;          // 256, 512 (or 1024) per block: tile = threads * SS_ITEMS
   int max_tiles;        // tiles of the largest segment
   size_t hist_entries;  // total (digit, tile) entries of one pass: sum over segments of tiles << bits
 };

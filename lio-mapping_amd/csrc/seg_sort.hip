@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dev.h"
@@ -83,17 +85,26 @@ __global__ void __launch_bounds__(SS_SCAN_THREADS) k_ss_scan(const SegDesc *__re
   for (int i = b0; i < b1; ++i) { const uint32_t t = h[i]; h[i] = run; run += t; }
 }
 
-template <int THREADS>
+// LDS of the scatter kernel: the waves' digit counts (NW x bins), the tile's digit starts (bins) and — the staging form — the tile's pairs
+// in sorted order.  Staged: the tile is first ordered inside LDS, then written out digit run by digit run with consecutive lanes on
+// consecutive addresses; unstaged (1024-thread tiles do not leave room): every lane writes its own element to its final position — 64
+// different lines per store.
+template <int THREADS, bool STAGED>
 __global__ void __launch_bounds__(THREADS) k_ss_scatter(const SegDesc *__restrict__ desc, const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                         uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ hist, int shift,
                                                         int bits, const KeyLayout *__restrict__ layout) {
   const SegDesc sg = desc[blockIdx.y];
-  constexpr int TILE = THREADS * SS_ITEMS, NW = THREADS / 64;
+  constexpr int TILE = THREADS * SS_ITEMS, NW = THREADS / 64, NB = 1 << SS_MAX_BITS;
   const int ntiles = (sg.n + TILE - 1) / TILE, tile = blockIdx.x;
   if (tile >= ntiles) return;
-  __shared__ uint32_t wh[NW][1 << SS_MAX_BITS];   // per wave: elements of each digit seen so far; later the wave's first output position of the digit
+  extern __shared__ uint32_t ss_lds[];
+  // per wave: elements of each digit seen so far; later the wave's first position of the digit (inside the tile when staged: 16 bits do)
+  using WH = typename std::conditional<STAGED, uint16_t, uint32_t>::type;
+  WH (*wh)[NB] = reinterpret_cast<WH (*)[NB]>(ss_lds);
+  uint32_t *delta = ss_lds + NW * NB * sizeof(WH) / 4;               // STAGED: digit's first output position for this tile minus its first position inside the tile
+  uint32_t *sk = delta + NB, *sv = sk + TILE;                        // STAGED: the tile's pairs in sorted order
   const int nb = 1 << bits;
-  for (int e = threadIdx.x; e < NW * (1 << SS_MAX_BITS); e += THREADS) (&wh[0][0])[e] = 0;
+  for (int e = threadIdx.x; e < int(NW * NB * sizeof(WH) / 4); e += THREADS) ss_lds[e] = 0;
   const KeyLayout *L = layout ? layout + blockIdx.y : nullptr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t key[SS_ITEMS], val[SS_ITEMS];
@@ -105,7 +116,7 @@ __global__ void __launch_bounds__(THREADS) k_ss_scatter(const SegDesc *__restric
     val[r] = in ? (vals_in ? vals_in[sg.off + i] : uint32_t(sg.off + i)) : 0u;
   }
   __syncthreads();
-  uint32_t *mine = wh[wave];
+  WH *mine = wh[wave];
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t loc[SS_ITEMS];
 #pragma unroll
@@ -122,26 +133,77 @@ __global__ void __launch_bounds__(THREADS) k_ss_scatter(const SegDesc *__restric
     }
     const uint32_t old = in ? mine[d] : 0u;
     ss_wave_lds_sync();                                      // (every lane has read the digit's count before its first lane moves it on)
-    if (in && (m & lt) == 0ull) mine[d] = old + uint32_t(__popcll(m));
+    if (in && (m & lt) == 0ull) mine[d] = WH(old + uint32_t(__popcll(m)));
     ss_wave_lds_sync();
     loc[r] = old + uint32_t(__popcll(m & lt));
   }
   __syncthreads();
-  // a digit's positions: the tile's first (scanned histogram), then wave after wave
-  for (int d = threadIdx.x; d < nb; d += THREADS) {
-    uint32_t g = hist[size_t(sg.hist_off) + size_t(d) * ntiles + tile];
+  if constexpr (!STAGED) {
+    // a digit's positions: the tile's first (scanned histogram), then wave after wave
+    for (int d = threadIdx.x; d < nb; d += THREADS) {
+      uint32_t g = hist[size_t(sg.hist_off) + size_t(d) * ntiles + tile];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { const uint32_t t = wh[w][d]; wh[w][d] = g; g += t; }
-  }
-  __syncthreads();
+      for (int w = 0; w < NW; ++w) { const uint32_t t = wh[w][d]; wh[w][d] = WH(g); g += t; }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int r = 0; r < SS_ITEMS; ++r) {
-    const int i = ss_index<THREADS>(tile, wave, r, lane);
-    if (i < sg.n) {
-      const uint32_t d = (key[r] >> shift) & uint32_t(nb - 1);
-      const size_t pos = size_t(sg.off) + mine[d] + loc[r];
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
+    for (int r = 0; r < SS_ITEMS; ++r) {
+      const int i = ss_index<THREADS>(tile, wave, r, lane);
+      if (i < sg.n) {
+        const uint32_t d = (key[r] >> shift) & uint32_t(nb - 1);
+        const size_t pos = size_t(sg.off) + mine[d] + loc[r];
+        keys_out[pos] = key[r];
+        vals_out[pos] = val[r];
+      }
+    }
+  } else {
+    // the tile's digit totals -> exclusive scan over the digits (thread d owns digit d: THREADS >= nb is not required, two per thread at 256)
+    constexpr int DPT = (NB + THREADS - 1) / THREADS;
+    uint32_t tot[DPT], pre[DPT];
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      const int d = threadIdx.x * DPT + q;
+      uint32_t t = 0;
+      if (d < nb) for (int w = 0; w < NW; ++w) t += wh[w][d];
+      tot[q] = t; pre[q] = tsum; tsum += t;
+    }
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __shared__ uint32_t wsum[NW];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - tsum;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      const int d = threadIdx.x * DPT + q;
+      if (d < nb) {
+        uint32_t l = base + pre[q];
+        delta[d] = hist[size_t(sg.hist_off) + size_t(d) * ntiles + tile] - l;   // (modulo 2^32: position = delta + place inside the tile)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const uint32_t t = wh[w][d]; wh[w][d] = WH(l); l += t; }   // the wave's first position of the digit inside the tile
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+      const int i = ss_index<THREADS>(tile, wave, r, lane);
+      if (i < sg.n) {
+        const uint32_t d = (key[r] >> shift) & uint32_t(nb - 1);
+        const uint32_t lp = mine[d] + loc[r];
+        sk[lp] = key[r]; sv[lp] = val[r];
+      }
+    }
+    __syncthreads();
+    const int tile_n = min(TILE, sg.n - tile * TILE);
+    for (int j = threadIdx.x; j < tile_n; j += THREADS) {
+      const uint32_t k = sk[j];
+      const uint32_t d = (k >> shift) & uint32_t(nb - 1);
+      const size_t pos = size_t(sg.off) + uint32_t(delta[d] + uint32_t(j));
+      keys_out[pos] = k;
+      vals_out[pos] = sv[j];
     }
   }
 }
@@ -151,8 +213,9 @@ SegSortPlan seg_sort_plan(SegDesc *desc, int nseg, int bits) {
   long long total = 0;
   int max_n = 0;
   for (int k = 0; k < nseg; ++k) { total += desc[k].n; max_n = std::max(max_n, desc[k].n); }
-  // big tiles (longer runs per digit in the scatter) once the launch fills the chip with them
-  p.threads = (total >= (long long)(1024 * SS_ITEMS) * 512) ? 1024 : 256;
+  // bigger tiles (longer runs per digit in the scatter) once the launch fills the chip with them; LIO_SS_THREADS for A/B runs
+  p.threads = (total >= (long long)(512 * SS_ITEMS) * 1024) ? 512 : 256;
+  { static const int forced = [] { const char *e = std::getenv("LIO_SS_THREADS"); const int v = e ? std::atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }(); if (forced) p.threads = forced; }
   const int tile = p.threads * SS_ITEMS;
   size_t h = 0;
   for (int k = 0; k < nseg; ++k) {
@@ -170,14 +233,29 @@ void seg_sort_pass(const SegDesc *d_desc, int nseg, const SegSortPlan &plan, con
   if (nseg <= 0 || plan.max_tiles <= 0) return;
   if (bits < 1 || bits > SS_MAX_BITS) throw DeviceError("seg_sort_pass: digit width out of range");
   const dim3 grid(plan.max_tiles, nseg);
+  constexpr int NB = 1 << SS_MAX_BITS;
+  auto lds_bytes = [&](int threads, bool staged) { return size_t(threads / 64) * NB * (staged ? 2 : 4) + (staged ? size_t(NB) * 4 + size_t(2) * threads * SS_ITEMS * 4 : 0); };
+  static const bool attrs = [&] {   // (more than 64 KB of dynamic LDS needs the attribute; per device — one device per process here)
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_scatter<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes(512, true))));
+    LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_scatter<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes(1024, false))));
+    return true;
+  }();
+  (void)attrs;
+  static const bool unstaged = std::getenv("LIO_SS_UNSTAGED") != nullptr;   // A/B: every lane writes its element to its final position
   if (plan.threads == 1024) {
     hipLaunchKernelGGL(k_ss_hist<1024>, grid, dim3(1024), 0, s, d_desc, keys_in, hist, shift, bits, layout);
     hipLaunchKernelGGL(k_ss_scan, dim3(nseg), dim3(SS_SCAN_THREADS), 0, s, d_desc, hist, bits, 1024 * SS_ITEMS);
-    hipLaunchKernelGGL(k_ss_scatter<1024>, grid, dim3(1024), 0, s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
+    hipLaunchKernelGGL((k_ss_scatter<1024, false>), grid, dim3(1024), lds_bytes(1024, false), s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
+  } else if (plan.threads == 512) {
+    hipLaunchKernelGGL(k_ss_hist<512>, grid, dim3(512), 0, s, d_desc, keys_in, hist, shift, bits, layout);
+    hipLaunchKernelGGL(k_ss_scan, dim3(nseg), dim3(SS_SCAN_THREADS), 0, s, d_desc, hist, bits, 512 * SS_ITEMS);
+    if (unstaged) hipLaunchKernelGGL((k_ss_scatter<512, false>), grid, dim3(512), lds_bytes(512, false), s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
+    else hipLaunchKernelGGL((k_ss_scatter<512, true>), grid, dim3(512), lds_bytes(512, true), s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
   } else {
     hipLaunchKernelGGL(k_ss_hist<256>, grid, dim3(256), 0, s, d_desc, keys_in, hist, shift, bits, layout);
     hipLaunchKernelGGL(k_ss_scan, dim3(nseg), dim3(SS_SCAN_THREADS), 0, s, d_desc, hist, bits, 256 * SS_ITEMS);
-    hipLaunchKernelGGL(k_ss_scatter<256>, grid, dim3(256), 0, s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
+    if (unstaged) hipLaunchKernelGGL((k_ss_scatter<256, false>), grid, dim3(256), lds_bytes(256, false), s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
+    else hipLaunchKernelGGL((k_ss_scatter<256, true>), grid, dim3(256), lds_bytes(256, true), s, d_desc, keys_in, vals_in, keys_out, vals_out, hist, shift, bits, layout);
   }
   LIO_HIP(hipGetLastError());
 }

@@ -914,8 +914,8 @@ def batched_windows(hip, ds, kind, W, Wo, est0, sizes, rep0, min_seconds=0.4):
             "solver_iterations": int(reps[0].iterations), "n_lidar_residuals": int(reps[0].n_lidar_residuals), "newest_frame_rounds": rounds,
             "host_ms": {k: round(clk[k], 3) for k in ("describe", "filter", "grid_features_rounds", "pack", "solve", "finish", "total")},
             "stages": {
-                "filter (concat + keys, sort, heads, centroids)": stage(clk["dev_filter"], 32.0 * n_local),
-                "knn_grid (histogram, scan, placement)": stage(clk["dev_grid"], 32.0 * n_map),
+                "filter (concat + keys, segmented sort, heads, centroids)": stage(clk["dev_filter"], 32.0 * n_local),
+                "knn_grid (cell keys, segmented sort, run-start table + cell-sorted points)": stage(clk["dev_grid"], 32.0 * n_map),
                 "features (older frames)": stage(clk["dev_features"], 16.0 * (m_static + n_map) + 72.0 * m_static),
                 "newest_frame_rounds": stage(clk["dev_rounds"], rounds * (16.0 * (m_new + n_map) + 72.0 * m_new + 33.0 * m_new)),
                 "trust_region_loop (moments + aux row, step)": stage(clk["dev_loop"], 60.0 * n_slots * passes, 684.0 * n_res * passes),

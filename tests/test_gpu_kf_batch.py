@@ -28,8 +28,14 @@ def _assert_batches_agree(rh, ro, noisy_fraction=0.0):
     # leaves some 6x6 systems numerically singular in fp32; Eigen's colPivHouseholderQr().solve keeps a pivot unless it is essentially
     # exactly zero ((max norm * eps)^2 (rows - k) / rows, tests/golden/README.md), so the weak unknown of such a system is rounding
     # noise over a tiny pivot in ANY implementation.  Those keyframes are counted and bounded instead (measured: 2 of 12 at 1.8e-4 m).
+    print(f"keyframe batch vs oracle: {int(np.count_nonzero(same))} of {len(same)} keyframes with equal iteration counts, worst |dp| {dp[same].max():.2e} m, |dq| {dq[same].max():.2e}; "
+          f"{int(np.count_nonzero(same & ~tight))} beyond 1e-4 (allowed {int(noisy_fraction * len(same))}); others: " +
+          (f"|dp| {dp[~same].max():.2e} |dq| {dq[~same].max():.2e}" if np.any(~same) else "none"))
     assert np.count_nonzero(same & ~tight) <= int(noisy_fraction * len(same)), (dp, dq)
-    assert dp[same].max() < 1e-3 and dq[same].max() < 1e-3
+    # caps at ~2x what the MI355X measures (round 6): 6-DoF 8.6e-6 m / 1.2e-7; 4-DoF 1.76e-4 m / 1.8e-6 on the two keyframes whose
+    # 6 x 6 system is numerically singular in fp32 (see above) — that class cannot be held to 1e-4 by any fp32 implementation
+    cap_p, cap_q = (3e-4, 1e-5) if noisy_fraction > 0 else (2e-5, 1e-6)
+    assert dp[same].max() < cap_p and dq[same].max() < cap_q, (dp[same].max(), dq[same].max())
     if np.any(~same):
         assert dp[~same].max() < 1e-3 and dq[~same].max() < 1e-3
 

@@ -389,10 +389,12 @@ BatchKnobs batch_knobs_from_env() {
   { const int v = env_int("LIO_BW_FINISH_THREADS", 0); if (v >= 1 && v <= 8) k.finish_threads = v; }
   return k;
 }
-static int bw_occ(const BatchKnobs &k, bool features) { return k.occupancy >= 0 ? k.occupancy : (features ? 8 : 0); }
+static int bw_occ(const BatchKnobs &k, bool features) { return k.occupancy >= 0 ? k.occupancy : (features ? 6 : 0); }   // (round 6, flat candidate lists: features 4.09 ms at 6 waves, 4.29 at 8, 4.31 as compiled; rounds 4.84 as compiled, 6.39 at 6 — 512 windows)
 static int bw_lanes_per_query(const BatchKnobs &k, long long total_queries) {
   if (k.lanes_per_query) return k.lanes_per_query;
-  return total_queries >= 400000 ? 1 : (total_queries >= 60000 ? 4 : 8);
+  // measured with the flat candidate lists (round 6, tools/r6 logs): one lane per query wins from ~100 k queries per launch (8 windows' newest
+  // frames: rounds 0.27 -> 0.21 ms), four lanes from ~15 k (one window's newest frame: 0.148 -> 0.127 ms)
+  return total_queries >= 100000 ? 1 : (total_queries >= 15000 ? 4 : 8);
 }
 void launch_bw_features(const BatchWin *win, const BatchGrid *grid, int B, int max_M, int max_static, long long total_queries, const BatchKnobs &knobs,
                         const float4 *sorted_all, const int *cells_all, uint8_t *valid_all, float4 *coef_all, float *score_all, hipStream_t s) {

@@ -929,7 +929,7 @@ void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st,
   // fills the GPU many times over, one lane per query wins 1.8x (no merge rounds, no idle lanes in the fit): measured
   // 96 / 69 / 59 / 55 ms for 8 / 4 / 2 / 1 lanes at 1000 HDL-64 keyframes.  The result does not depend on the split.
   static const int lpq_env = [] { const char *e = std::getenv("LIO_KF_LPQ"); return e ? std::atoi(e) : 0; }();
-  const int lpq = lpq_env ? lpq_env : (total_queries >= 400000 ? 1 : total_queries >= 60000 ? 4 : 8);
+  const int lpq = lpq_env ? lpq_env : (total_queries >= 250000 ? 1 : total_queries >= 60000 ? 4 : 8);   // (round 6, flat candidate lists: 16 keyframes = 377 k queries 0.89 ms at one lane against 0.96 at four; 8 keyframes 0.62 against 0.55)
   const int bx = std::max(1, cdiv((long long)std::max(max_Mc, max_Ms) * lpq, 128));
   const dim3 grid(bx, 2, n_keyframes);
 #define KF_ROUND(L) hipLaunchKernelGGL(k_kf_round<L>, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef)

@@ -709,7 +709,9 @@ void launch_features(const FeatArgs &a, const float *transforms, const float4 *m
 // CalculateLaserOdom: rows of (mat_A | mat_B), reduced; then the 6x6 step
 // ------------------------------------------------------------------------------------------------
 #define ODOM_ROW_THREADS 256
-int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM_ROW_THREADS * 2), 256)); }
+// eight slots per thread: the 28 running sums of a wave meet through 28 x 6 shuffle steps of doubles, which at two slots per thread cost more
+// than the rows themselves (k_kf_rows: 467 us per round of 1000 keyframes; round 6)
+int odom_rows_blocks(int nslots) { return std::max(1, std::min(cdiv(nslots, ODOM_ROW_THREADS * 8), 256)); }
 
 __device__ __forceinline__ void odom_rows_body(int block_x, int nblocks, const float4 *__restrict__ stack, int M, int nslots,
                                                const uint8_t *__restrict__ valid, const float4 *__restrict__ coef,
@@ -872,6 +874,7 @@ __global__ void __launch_bounds__(128) k_kf_round(const KfDesc *__restrict__ kd,
 // the one-lane-per-query form is bound by gather latency: 8 waves per SIMD (64 VGPRs, the fit phase spills a little) beats
 // the 5 waves the default allocation gives by 15% (54.4 -> 46.1 ms at 1000 HDL-64 keyframes)
 KF_OCC_VARIANT(8)
+KF_OCC_VARIANT(6)
 
 __global__ void __launch_bounds__(ODOM_ROW_THREADS) k_kf_rows(const KfDesc *__restrict__ kd, const OdomState *__restrict__ st,
                                                               const float4 *__restrict__ stack_all, const uint8_t *__restrict__ valid,
@@ -933,7 +936,10 @@ void launch_kf_round(const KfDesc *kd, const KfMapDesc *md, const OdomState *st,
   const int bx = std::max(1, cdiv((long long)std::max(max_Mc, max_Ms) * lpq, 128));
   const dim3 grid(bx, 2, n_keyframes);
 #define KF_ROUND(L) hipLaunchKernelGGL(k_kf_round<L>, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef)
-  if (lpq == 1) hipLaunchKernelGGL(k_kf_round1_w8, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
+  static const int occ_env = [] { const char *e = std::getenv("LIO_KF_OCC"); return e ? std::atoi(e) : 8; }();   // A/B: 0 as compiled, 6, 8 waves per SIMD
+  if (lpq == 1 && occ_env == 8) hipLaunchKernelGGL(k_kf_round1_w8, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
+  else if (lpq == 1 && occ_env == 6) hipLaunchKernelGGL(k_kf_round1_w6, grid, dim3(128), 0, s, kd, md, st, stack_all, order, min_match_sq_dis, min_plane_dis, mapping_mode, valid, coef);
+  else if (lpq == 1) KF_ROUND(1);
   else if (lpq == 2) KF_ROUND(2); else if (lpq == 4) KF_ROUND(4); else KF_ROUND(8);
 #undef KF_ROUND
   LIO_HIP(hipGetLastError());

@@ -84,11 +84,20 @@ int lio_pp_process(lio_pp *, const float *xyzi, size_t n);
  * (The oracle processes inside _async; its _wait is a no-op.) */
 int lio_pp_process_async(lio_pp *, const float *xyzi, size_t n);
 int lio_pp_wait(lio_pp *);
-/* B sweeps (B sensors of a fleet node, or the sweeps of a log) through B handles in one call: every sweep is enqueued before the
- * first is waited for, so the GPU sees B x rings workgroups of work at once (a single HDL-64 sweep fills 64 of the 256 compute
- * units in the pick stage).  = lio_pp_process_async on every handle, then lio_pp_wait on every handle; the first failing code is
- * returned after all handles have been waited for.  A handle may appear once. */
+/* B sweeps (B sensors of a fleet node, or the sweeps of a log) through B handles in one call.  Handles created with the same
+ * arguments share ONE launch chain: one upload per sweep, then every kernel of the chain (ring split, PrepareRing / PrepareSubregion /
+ * picks, per-ring VoxelGrid, packing — PointProcessor.cc:207-783) runs ONCE over all B sweeps (the sweep is a grid dimension; a single
+ * HDL-64 sweep fills 64 of the 256 compute units in the pick stage), and one copy brings all counts back.  Every handle then answers
+ * the accessors below for ITS sweep, bit for bit what lio_pp_process gives (the same kernels: one sweep is the B = 1 case); with
+ * infer_start_ori a sweep's start azimuth goes through its own handle's ten-sweep history.  The results live in storage the handles of
+ * the call share until a handle's next process call: read them from one thread at a time.  Handles that differ in their arguments (or
+ * B = 1) run lio_pp_process_async on every handle, then lio_pp_wait on every handle; the first failing code is returned after all
+ * handles have been waited for.  A handle may appear once. */
 int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps);
+/* lio_pp_process_batch with the sweeps already in DEVICE memory (a decoder or a replay buffer on the GPU; d_xyzi[k]: n[k] x 4 floats in
+ * HBM of the handles' device): no transfer over PCIe, the sweeps are copied device to device into the chain's segments.  (The oracle
+ * has no device: it reads the pointers as host memory.) */
+int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *d_xyzi, const size_t *n, int n_sweeps);
 /* The same with the PointIR overload of PointToRing (uneven = true, sensor_type 320 of processor_node.cc:73;
  * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
  * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */

@@ -12,6 +12,8 @@
 #include "rccl_comm.h"
 #include "host_init.h"
 #include "kf_batch.h"
+#include <mutex>
+
 #include "mapping.h"
 #include "odometry.h"
 #include "pointproc.h"
@@ -22,7 +24,10 @@ struct lio_pim { std::shared_ptr<Preintegration> p; };
 // (members are destroyed in reverse order: the batch of one that serves lio_est_config.device_solve goes before the estimator it adopted)
 struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; std::unique_ptr<EstimatorBatch> solo; bool adopted = false; struct lio_est_batch *owner = nullptr; };
 struct lio_est_batch { std::unique_ptr<EstimatorBatch> b; std::vector<lio_est *> members; };
-struct lio_pp { std::unique_ptr<PointProcessorDev> pp; };
+// lio_pp_process_batch runs its sweeps through ONE multi-sweep processor shared by the handles of the call (`pool`); a handle whose last
+// sweep went that way reads its results from sweep `pool_sweep` of it.  The pool is shared state: its users take `mu`.
+struct lio_pp_pool { PointProcessorDev pp; std::mutex mu; lio_pp_pool(float lo, float up, int r, const lio_pp_config &c) : pp(lo, up, r, c) {} };
+struct lio_pp { std::unique_ptr<PointProcessorDev> pp; std::shared_ptr<lio_pp_pool> pool; int pool_sweep = -1; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
 struct lio_map { std::unique_ptr<MappingDev> m; };
 
@@ -45,6 +50,22 @@ template <typename F> static int guarded(F &&f) {
     std::fprintf(stderr, "[lio_hip] %s\n", e.what());
     return LIO_ERR_STATE;
   }
+}
+
+// the processor that holds the handle's last sweep, ready to be read: f(processor) under the pool's lock when that is the shared one
+template <typename F> static int pp_read(const lio_pp *h, F &&f) {
+  return guarded([&] {
+    if (h->pool && h->pool_sweep >= 0) {
+      std::lock_guard<std::mutex> lk(h->pool->mu);
+      h->pool->pp.ProcessFinish();
+      h->pool->pp.SelectSweep(h->pool_sweep);
+      f(h->pool->pp);
+    } else {
+      h->pp->ProcessFinish();   // a sweep still in flight (lio_pp_process_async) is waited for
+      f(*h->pp);
+    }
+    return LIO_OK;
+  });
 }
 
 extern "C" {
@@ -96,63 +117,105 @@ void lio_pp_destroy(lio_pp *h) { delete h; }
 float lio_pp_start_ori(const lio_pp *h) {
   if (!h) return std::nanf("");
   float v = std::nanf("");
-  guarded([&] { h->pp->ProcessFinish(); v = h->pp->StartOri(); return LIO_OK; });
+  pp_read(h, [&](PointProcessorDev &p) { v = p.StartOri(); });
   return v;
 }
 int lio_pp_process(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
+  h->pool_sweep = -1;
   return guarded([&] { h->pp->Process(xyzi, n); return LIO_OK; });
 }
 int lio_pp_process_async(lio_pp *h, const float *xyzi, size_t n) {
   if (!h || (!xyzi && n)) return LIO_ERR_ARG;
+  h->pool_sweep = -1;
   return guarded([&] { h->pp->ProcessLaunch(xyzi, n); return LIO_OK; });
 }
 int lio_pp_wait(lio_pp *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->pp->ProcessFinish(); return LIO_OK; });
 }
-int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
+static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps, bool on_device) {
   if (n_sweeps < 0 || (n_sweeps > 0 && (!handles || !xyzi || !n))) return LIO_ERR_ARG;
+  bool same = true;
   for (int k = 0; k < n_sweeps; ++k) {
     if (!handles[k] || (!xyzi[k] && n[k])) return LIO_ERR_ARG;
     for (int j = 0; j < k; ++j) if (handles[j] == handles[k]) return LIO_ERR_ARG;
+    same = same && handles[k]->pp->SameSensor(*handles[0]->pp);
   }
+  if (n_sweeps == 0) return LIO_OK;
+  if (n_sweeps >= 2 && same) {
+    // ONE launch chain over all sweeps: the handles share a multi-sweep processor (kept for the next call), every handle reads its own
+    // sweep of it; a sweep's start azimuth still goes through ITS handle's ten-sweep history (infer_start_ori)
+    return guarded([&] {
+      std::shared_ptr<lio_pp_pool> pool = handles[0]->pool;
+      if (!pool || !pool->pp.SameSensor(*handles[0]->pp)) {
+        const PointProcessorDev &a = *handles[0]->pp;
+        pool = std::make_shared<lio_pp_pool>(a.lower(), a.upper(), a.rings(), a.config());
+      }
+      std::vector<StartOriFilter *> filters(static_cast<size_t>(n_sweeps));
+      for (int k = 0; k < n_sweeps; ++k) {
+        handles[k]->pp->ProcessFinish();
+        handles[k]->pool = pool; handles[k]->pool_sweep = k;
+        filters[size_t(k)] = &handles[k]->pp->start_ori_filter();
+      }
+      std::lock_guard<std::mutex> lk(pool->mu);
+      pool->pp.ProcessLaunchBatch(xyzi, nullptr, n, n_sweeps, on_device, filters.data());
+      pool->pp.ProcessFinish();
+      return LIO_OK;
+    });
+  }
+  // different sensors (or one sweep): every handle's own chain, all enqueued before the first is waited for
   int rc = LIO_OK, launched = 0;
-  for (; launched < n_sweeps && rc == LIO_OK; ++launched) rc = lio_pp_process_async(handles[launched], xyzi[launched], n[launched]);
+  for (; launched < n_sweeps && rc == LIO_OK; ++launched) {
+    lio_pp *h = handles[launched];
+    h->pool_sweep = -1;
+    rc = guarded([&] {
+      StartOriFilter *f = &h->pp->start_ori_filter();
+      h->pp->ProcessLaunchBatch(&xyzi[launched], nullptr, &n[launched], 1, on_device, &f);
+      return LIO_OK;
+    });
+  }
   if (rc != LIO_OK) --launched;   // (the failing handle has nothing in flight)
   for (int k = 0; k < launched; ++k) { const int r = lio_pp_wait(handles[k]); if (rc == LIO_OK) rc = r; }
   return rc;
 }
+int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
+  return pp_process_batch(handles, xyzi, n, n_sweeps, false);
+}
+int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *d_xyzi, const size_t *n, int n_sweeps) {
+  return pp_process_batch(handles, d_xyzi, n, n_sweeps, true);
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
+  h->pool_sweep = -1;
   return guarded([&] { h->pp->Process(xyzi, n, n ? ring : nullptr); return LIO_OK; });
 }
 size_t lio_pp_count(const lio_pp *h, int which) {
   if (!h || which < 0 || which > 4) return 0;
   size_t n = 0;
-  guarded([&] { h->pp->ProcessFinish(); n = h->pp->Count(which); return LIO_OK; });   // a sweep still in flight (lio_pp_process_async) is waited for
+  pp_read(h, [&](PointProcessorDev &p) { n = p.Count(which); });
   return n;
 }
 int lio_pp_get_cloud(const lio_pp *h, int which, float *out) {
   if (!h || which < 0 || which > 4 || !out) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetCloud(which, out); return LIO_OK; });
+  return pp_read(h, [&](PointProcessorDev &p) { p.GetCloud(which, out); });
 }
 int lio_pp_get_indices(const lio_pp *h, int which, int32_t *ring, int32_t *idx) {
   if (!h || which < 1 || which > 3 || !ring || !idx) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetIndices(which, ring, idx); return LIO_OK; });
+  return pp_read(h, [&](PointProcessorDev &p) { p.GetIndices(which, ring, idx); });
 }
 int lio_pp_get_ring_offsets(const lio_pp *h, int32_t *out) {
   if (!h || !out) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetRingOffsets(out); return LIO_OK; });
+  return pp_read(h, [&](PointProcessorDev &p) { p.GetRingOffsets(out); });
 }
 int lio_pp_get_curvature(const lio_pp *h, float *curv, int32_t *mask) {
   if (!h) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetCurvature(curv, mask); return LIO_OK; });
+  return pp_read(h, [&](PointProcessorDev &p) { p.GetCurvature(curv, mask); });
 }
 
 int lio_pp_get_ring_intensity(const lio_pp *h, float *out) {
   if (!h || !out) return LIO_ERR_ARG;
-  return guarded([&] { h->pp->ProcessFinish(); h->pp->GetRingIntensity(out); return LIO_OK; });
+  return pp_read(h, [&](PointProcessorDev &p) { p.GetRingIntensity(out); });
 }
 
 // ---------------------------------------------------------------- PointOdometry

@@ -57,27 +57,51 @@ class PointProcessorDev {
   // handles launched one after the other keep that many sweeps in flight on one GPU (lio_pp_process_async / lio_pp_wait).
   void ProcessLaunch(const float *xyzi, size_t n, const uint16_t *ring = nullptr);
   void ProcessFinish();
+  // B sweeps through ONE launch chain (lio_pp_process_batch): every kernel of the chain runs once over all sweeps (the sweep in
+  // blockIdx.z), one copy brings every sweep's counts back.  xyzi[k]: host memory, or device memory when `on_device` (copied device
+  // to device into the handle's segments).  filters[k] (may be null): the ten-sweep start-azimuth history sweep k belongs to
+  // (infer_start_ori) — the handle's own when null and B = 1.  The accessors read the sweep SelectSweep() chose (0 after a launch).
+  void ProcessLaunchBatch(const float *const *xyzi, const uint16_t *const *ring, const size_t *n, int B, bool on_device, StartOriFilter *const *filters);
+  int sweeps() const { return nsw_; }
+  void SelectSweep(int k);
+  StartOriFilter &start_ori_filter() { return start_ori_filter_; }
+  bool SameSensor(const PointProcessorDev &o) const;   // same constructor arguments: the two can share a launch chain
+  float lower() const { return lower_; }
+  float upper() const { return upper_; }
+  int rings() const { return rings_; }
+  const lio_pp_config &config() const { return cfg_; }
   void GetIndices(int which, int32_t *ring, int32_t *idx);
   void GetRingOffsets(int32_t *out);
   void GetRingIntensity(float *out);
   void GetCurvature(float *curv, int32_t *mask);
   // device-resident results (valid until the next Process)
-  const float4 *d_less_flat() const { return less_flat_.p; }
+  const float4 *d_less_flat() const { return less_flat_.p + size_t(sel_) * pts_stride_; }
   size_t n_less_flat() const { return size_t(counts_.n_less_flat); }
-  float StartOri();   // start_ori_ of the last Process (one small D2H unless infer_start_ori already fetched it)
+  float StartOri();   // start_ori_ of the selected sweep of the last Process (one small D2H unless infer_start_ori already fetched it)
 
  private:
   float lower_, upper_, factor_;
   int rings_;
   lio_pp_config cfg_;
   hipStream_t stream_ = nullptr;
-  PPDeviceCounts counts_{};
-  struct HostOut { PPDeviceCounts counts; int ring_offsets[LIO_PP_MAX_RINGS + 1]; float start_ori_probe[3]; };
-  HostOut *h_out_ = nullptr;   // pinned landing zone of the per-sweep results
-  std::vector<int> ring_offsets_;
+  // sweeps of the last launch; the sweep the accessors read; elements per sweep of the point-indexed arrays, of one packed class list
+  int nsw_ = 0, sel_ = 0;
+  bool last_empty_ = false;            // the last launch had no point at all: nothing ran, every count reads zero
+  std::vector<size_t> n_sw_;           // input points of the last launch's sweeps
+  size_t pts_stride_ = 0, cls_stride_ = 0;
+  int state_stride_ = 0;   // ints per sweep of the state record: PPDeviceCounts | ring offsets [LIO_PP_MAX_RINGS + 1] | first_valid [2] | end_ori | pad
+  PPDeviceCounts counts_{};            // of the selected sweep
+  std::vector<int> ring_offsets_;      // of the selected sweep
+  // pinned landing zone: the state records of all sweeps, then three floats per sweep (start-azimuth probe x 2, the value used)
+  int *h_state_ = nullptr;
+  float *h_ori_ = nullptr;
+  const float4 **h_ptr_ = nullptr;     // staging of the table of input pointers (sweeps already in device memory)
+  int h_cap_sweeps_ = 0;
+  void ReserveHost(int B);
+  const int *h_record(int k) const { return h_state_ + size_t(k) * state_stride_; }
   DBuf<float4> in_, ring_cloud_, less_flat_, lf_tmp_, class_cloud_[4];
   DBuf<float> ring_intensity_;   // intensity_scans' intensity channel, ring order
-  DBuf<float> azi_, curv_, start_ori_dev_;
+  DBuf<float> azi_, curv_, start_ori_dev_;   // start_ori_dev_: 2 probes per sweep, then one override per sweep
   StartOriFilter start_ori_filter_;
   bool processed_ = false, start_ori_known_ = false, in_flight_ = false;
   std::chrono::steady_clock::time_point t_begin_{};
@@ -85,11 +109,9 @@ class PointProcessorDev {
   DBuf<int> ring_total_;
   DBuf<int> ring_table_;   // [ring][block] counts -> exclusive offsets (the stable ring split)
   DBuf<int> mask_;
-  // the small per-sweep device state in ONE allocation, laid out like HostOut (counts, ring offsets) followed by first_valid[2]
-  // and end_ori: one init kernel instead of three fills in front of a sweep, one copy instead of two behind it
-  DBuf<int> d_state_;
-  PPDeviceCounts *d_counts_p_ = nullptr;
-  int *d_ring_offsets_p_ = nullptr, *first_valid_p_ = nullptr, *end_ori_p_ = nullptr;
+  DBuf<int> d_state_;      // the sweeps' state records
+  DBuf<int> d_n_;          // points per sweep
+  DBuf<const float4 *> d_in_table_;   // where every sweep's input lies (lio_pp_process_batch_device)
   DBuf<uint16_t> ring_in_;
   DBuf<int8_t> label_;
   DBuf<int> pick_idx_, pick_cnt_, class_ring_, class_idx_;

@@ -26,6 +26,19 @@ namespace lio {
 #define PP_STAMP_RING 20   // the ring whose block stamps its phases (an HDL-64 ring that looks at the scene, not the sky)
 #define PP_WSEL 64       // ints per wave for its speculative picks: max_corner_less_sharp + max_surf_flat <= 64
 
+// B sweeps per launch chain (lio_pp_process_batch): every per-sweep array of the handle is B segments of a fixed stride laid end to
+// end, and every kernel of the chain takes the sweep from blockIdx.z and shifts its (kernel-argument, hence global) pointers by
+// sweep x stride before doing what it does for one sweep.  A single sweep is the B = 1 case of the same kernels: same code, same bits.
+struct PPStrides {
+  int pts;      // elements per sweep of the point-indexed arrays (input, keys, azimuths, ring cloud, curvature, mask, labels, staging)
+  int table;    // ints per sweep of the (ring, block) count table
+  int state;    // ints per sweep of the small state record (counts | ring offsets | first_valid[2] | end_ori)
+  int picks;    // ints per sweep of the per-ring pick lists
+  int cls;      // elements per sweep of one packed class list / class cloud
+};
+#define PP_SWEEP(ptr, stride) ptr += size_t(blockIdx.z) * size_t(stride)
+#define PP_SWEEP_OPT(ptr, stride) do { if (ptr) ptr += size_t(blockIdx.z) * size_t(stride); } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // ring binning
 // ------------------------------------------------------------------------------------------------
@@ -42,7 +55,11 @@ __device__ inline float azimuth_of(float x, float y) {
 #define PP_BIN_THREADS 256
 __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_bin(const float4 *__restrict__ in, const uint16_t *__restrict__ ring_in, int n, float lower,
                                                              float factor, int rings, uint32_t *__restrict__ keys, float *__restrict__ azi,
-                                                             int *__restrict__ block_hist, int nblocks, int *first_valid) {
+                                                             int *__restrict__ block_hist, int nblocks, int *first_valid, PPStrides st,
+                                                             const int *__restrict__ n_arr, const float4 *const *__restrict__ in_table) {
+  if (n_arr) n = n_arr[blockIdx.z];
+  if (in_table) in = in_table[blockIdx.z]; else   // (sweeps that already live in device memory are read where they are)
+  PP_SWEEP(in, st.pts); PP_SWEEP_OPT(ring_in, st.pts); PP_SWEEP(keys, st.pts); PP_SWEEP(azi, st.pts); PP_SWEEP(block_hist, st.table); PP_SWEEP(first_valid, st.state);
   __shared__ int hist[LIO_PP_MAX_RINGS];
   __shared__ int s_first, s_first0;   // first kept point; first kept point of ring 0 (ring_out[0]->front(), :383)
   for (int r = threadIdx.x; r < rings; r += PP_BIN_THREADS) hist[r] = 0;
@@ -81,13 +98,15 @@ __device__ __forceinline__ float sweep_start_ori(const float *__restrict__ azi, 
   return start_ori_override ? *start_ori_override : azi[*first_valid];
 }
 // infer_start_ori only: the two azimuths the host filter needs
-__global__ void k_start_ori_probe(const float *__restrict__ azi, const int *__restrict__ first_valid, float *__restrict__ out) {
+__global__ void k_start_ori_probe(const float *__restrict__ azi, const int *__restrict__ first_valid, float *__restrict__ out, PPStrides st) {
+  PP_SWEEP(azi, st.pts); PP_SWEEP(first_valid, st.state); PP_SWEEP(out, 2);
   out[0] = first_valid[0] != INT_MAX ? azi[first_valid[0]] : 0.f;
   out[1] = first_valid[1] != INT_MAX ? azi[first_valid[1]] : __int_as_float(0x7fc00000);
 }
 
 // per-ring exclusive scan of the count table in place (block r owns ring r's nblocks counts) + the ring totals
-__global__ void __launch_bounds__(256) k_ring_scan(int *__restrict__ table, int nblocks, int *__restrict__ ring_total) {
+__global__ void __launch_bounds__(256) k_ring_scan(int *__restrict__ table, int nblocks, int *__restrict__ ring_total, PPStrides st) {
+  PP_SWEEP(table, st.table); PP_SWEEP(ring_total, LIO_PP_MAX_RINGS);
   __shared__ int swave[4];
   __shared__ int s_carry;
   int *row = table + size_t(blockIdx.x) * nblocks;
@@ -118,7 +137,9 @@ __device__ __forceinline__ float unwrap_azimuth(float az, float start_ori) {
   return rel < 0 ? float(double(az) + 2 * M_PI) : az;
 }
 __global__ void k_ring_end_ori(const uint32_t *__restrict__ keys, const float *__restrict__ azi, int n, int rings, const int *__restrict__ first_valid,
-                               int *end_ori_bits) {
+                               int *end_ori_bits, PPStrides st, const int *__restrict__ n_arr) {
+  if (n_arr) n = n_arr[blockIdx.z];
+  PP_SWEEP(keys, st.pts); PP_SWEEP(azi, st.pts); PP_SWEEP(first_valid, st.state); PP_SWEEP(end_ori_bits, st.state);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float v = 0.f;
   if (i < n && int(keys[i]) < rings) v = unwrap_azimuth(azi[i], azi[*first_valid]);
@@ -131,7 +152,13 @@ __global__ void __launch_bounds__(PP_BIN_THREADS) k_ring_scatter(const float4 *_
                                                                  const int *__restrict__ ring_total, int *__restrict__ offsets,
                                                                  const int *__restrict__ first_valid, const float *__restrict__ start_ori_override, int rings, double scan_period,
                                                                  float4 *__restrict__ ring_cloud, float *__restrict__ ring_intensity,
-                                                                 const int *__restrict__ end_ori_bits) {
+                                                                 const int *__restrict__ end_ori_bits, PPStrides st, const int *__restrict__ n_arr,
+                                                                 const float4 *const *__restrict__ in_table) {
+  if (n_arr) n = n_arr[blockIdx.z];
+  if (in_table) in = in_table[blockIdx.z]; else
+  PP_SWEEP(in, st.pts); PP_SWEEP(keys, st.pts); PP_SWEEP(azi, st.pts); PP_SWEEP(table, st.table); PP_SWEEP(ring_total, LIO_PP_MAX_RINGS);
+  PP_SWEEP(offsets, st.state); PP_SWEEP(first_valid, st.state); PP_SWEEP_OPT(start_ori_override, 1); PP_SWEEP(ring_cloud, st.pts);
+  PP_SWEEP(ring_intensity, st.pts); PP_SWEEP_OPT(end_ori_bits, st.state);
   __shared__ int wave_cnt[PP_BIN_THREADS / 64][LIO_PP_MAX_RINGS];
   __shared__ int ring_base[LIO_PP_MAX_RINGS + 1];
   for (int k = threadIdx.x; k < (PP_BIN_THREADS / 64) * LIO_PP_MAX_RINGS; k += PP_BIN_THREADS) (&wave_cnt[0][0])[k] = 0;
@@ -194,7 +221,8 @@ __device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long v,
 }
 
 // counts <- 0, first_valid <- INT_MAX (the atomicMin targets of k_ring_bin), end_ori <- 0: the state a sweep starts from
-__global__ void k_pp_init(int *__restrict__ state, int n_count_ints, int *__restrict__ first_valid, int *__restrict__ end_ori) {
+__global__ void k_pp_init(int *__restrict__ state, int n_count_ints, int *__restrict__ first_valid, int *__restrict__ end_ori, PPStrides st) {
+  PP_SWEEP(state, st.state); PP_SWEEP(first_valid, st.state); PP_SWEEP(end_ori, st.state);
   for (int k = threadIdx.x; k < n_count_ints; k += blockDim.x) state[k] = 0;
   if (threadIdx.x < 2) first_valid[threadIdx.x] = INT_MAX;
   if (threadIdx.x == 2) *end_ori = 0;
@@ -216,7 +244,10 @@ __device__ inline float sqdiff(float ax, float ay, float az, float bx, float by,
 __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets, PickCfg c,
                                                                float *__restrict__ g_curv, int *__restrict__ g_mask, int8_t *__restrict__ g_label,
                                                                int *__restrict__ pick_idx, int *__restrict__ pick_cnt,
-                                                               PPDeviceCounts *counts) {
+                                                               PPDeviceCounts *counts, PPStrides st, int ring_cap) {
+  PP_SWEEP(ring_cloud, st.pts); PP_SWEEP(offsets, st.state); PP_SWEEP(g_curv, st.pts); PP_SWEEP(g_mask, st.pts); PP_SWEEP(g_label, st.pts);
+  PP_SWEEP(pick_idx, st.picks); PP_SWEEP(pick_cnt, 3 * LIO_PP_MAX_RINGS);
+  counts = reinterpret_cast<PPDeviceCounts *>(reinterpret_cast<int *>(counts) + size_t(blockIdx.z) * size_t(st.state));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int r = blockIdx.x;
   const int base = offsets[r];
@@ -229,13 +260,14 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   // every ring point gets defaults in the global arrays
   for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = 0.f; g_mask[base + i] = 0; g_label[base + i] = 127; }
   if (n <= 2 * c.nc + 1) return;                         // PointProcessor.cc:660-662
-  if (n > LIO_PP_MAX_RING_POINTS) { if (tid == 0) atomicExch(&counts->overflow, 1); return; }
-  // LDS carve (all offsets multiples of 16)
+  if (n > ring_cap) { if (tid == 0) atomicExch(&counts->overflow, 1); return; }   // ring_cap: the points per ring this launch's LDS holds (<= LIO_PP_MAX_RING_POINTS)
+  // LDS carve (all offsets multiples of 16).  The curvature is NOT kept here: it is written once per point, straight to global memory
+  // (18 instead of 22 bytes per point: two workgroups per compute unit at HDL-64E ring lengths)
   const int NP = (n + 63) & ~63;
   unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem);               // 8 * 512 * 8 B
   float *sx = reinterpret_cast<float *>(smem + 8 * PP_SORT_SLOTS * 8);
-  float *sy = sx + NP, *sz = sy + NP, *scurv = sz + NP;
-  signed char *smask = reinterpret_cast<signed char *>(scurv + NP);
+  float *sy = sx + NP, *sz = sy + NP;
+  signed char *smask = reinterpret_cast<signed char *>(sz + NP);
   signed char *slabel = smask + NP;
   unsigned char *snfb = reinterpret_cast<unsigned char *>(slabel + NP);  // MaskPickedInRing reach of every point: nf | nb << 4
   unsigned char *sgap = snfb + NP;
@@ -250,7 +282,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   PICK_STAMP(0);
   for (int i = tid; i < n; i += PP_PICK_THREADS) {
     float4 p = ring_cloud[base + i];
-    sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; scurv[i] = 0.f; smask[i] = 0; slabel[i] = 127;
+    sx[i] = p.x; sy[i] = p.y; sz[i] = p.z; smask[i] = 0; slabel[i] = 127;
   }
   __syncthreads();
   PICK_STAMP(1);
@@ -341,7 +373,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
           dz += sz[i + t] + sz[i - t];
         }
         float cv = dx * dx + dy * dy + dz * dz;
-        scurv[i] = cv;
+        g_curv[base + i] = cv;   // (the zero of the defaults loop above lies behind several block barriers)
         slabel[i] = 0;
         key[q] = (static_cast<unsigned long long>(__float_as_uint(cv)) << 32) | static_cast<unsigned int>(i);
       }
@@ -526,7 +558,7 @@ __global__ void __launch_bounds__(PP_PICK_THREADS) k_ring_pick(const float4 *__r
   PICK_STAMP(6);
   if (tid == 0) { pick_cnt[r * 3 + 0] = n_sharp; pick_cnt[r * 3 + 1] = n_less; pick_cnt[r * 3 + 2] = n_flat; }
   for (int k = tid; k < cap_all; k += PP_PICK_THREADS) my_pick[k] = lpick[k];
-  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_curv[base + i] = scurv[i]; g_mask[base + i] = int(macc[i]); g_label[base + i] = slabel[i]; }
+  for (int i = tid; i < n; i += PP_PICK_THREADS) { g_mask[base + i] = int(macc[i]); g_label[base + i] = slabel[i]; }
   __syncthreads();
   PICK_STAMP(7);
 }
@@ -539,7 +571,11 @@ __global__ void __launch_bounds__(256) k_pp_pack(const float4 *__restrict__ ring
                                                  const int *__restrict__ pick_cnt, PickCfg c, int *__restrict__ class_ring, int *__restrict__ class_idx,
                                                  float4 *__restrict__ cloud1, float4 *__restrict__ cloud2, float4 *__restrict__ cloud3, int cap_total,
                                                  const float4 *__restrict__ lf_staged, const int *__restrict__ lf_ring_count,
-                                                 float4 *__restrict__ less_flat, PPDeviceCounts *counts) {
+                                                 float4 *__restrict__ less_flat, PPDeviceCounts *counts, PPStrides st) {
+  PP_SWEEP(ring_cloud, st.pts); PP_SWEEP(offsets, st.state); PP_SWEEP(pick_idx, st.picks); PP_SWEEP(pick_cnt, 3 * LIO_PP_MAX_RINGS);
+  PP_SWEEP(class_ring, 3 * size_t(st.cls)); PP_SWEEP(class_idx, 3 * size_t(st.cls)); PP_SWEEP(cloud1, st.cls); PP_SWEEP(cloud2, st.cls); PP_SWEEP(cloud3, st.cls);
+  PP_SWEEP(lf_staged, st.pts); PP_SWEEP(lf_ring_count, LIO_PP_MAX_RINGS); PP_SWEEP(less_flat, st.pts);
+  counts = reinterpret_cast<PPDeviceCounts *>(reinterpret_cast<int *>(counts) + size_t(blockIdx.z) * size_t(st.state));
   __shared__ int s_dst[4];
   const int r = blockIdx.x, rings = c.rings, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (blockIdx.y == 0) {
@@ -587,14 +623,17 @@ __global__ void __launch_bounds__(256) k_pp_pack(const float4 *__restrict__ ring
 __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restrict__ ring_cloud, const int *__restrict__ offsets,
                                                            const int8_t *__restrict__ label, float inv_leaf, const float *__restrict__ azi,
                                                            const int *__restrict__ first_valid, const float *__restrict__ start_ori_override, double scan_period, float4 *__restrict__ staged,
-                                                           int *__restrict__ ring_count) {
+                                                           int *__restrict__ ring_count, PPStrides st, int pts_cap, int sort_cap) {
+  PP_SWEEP(ring_cloud, st.pts); PP_SWEEP(offsets, st.state); PP_SWEEP(label, st.pts); PP_SWEEP(azi, st.pts); PP_SWEEP(first_valid, st.state);
+  PP_SWEEP_OPT(start_ori_override, 1); PP_SWEEP(staged, st.pts); PP_SWEEP(ring_count, LIO_PP_MAX_RINGS);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int base = offsets[r], n = offsets[r + 1] - base;
-  if (n <= 0 || n > LIO_PP_MAX_RING_POINTS) { if (tid == 0) ring_count[r] = 0; return; }
-  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem);            // up to 4096 keys
-  float4 *spt = reinterpret_cast<float4 *>(smem + size_t(4096) * 8);                   // n points
-  int *spos = reinterpret_cast<int *>(smem + size_t(4096) * 8 + size_t(4096) * 16);     // flags -> positions
+  // pts_cap points and sort_cap (a power of two >= pts_cap) sort slots fit this launch's LDS; a longer ring was flagged by k_ring_pick
+  if (n <= 0 || n > pts_cap) { if (tid == 0) ring_count[r] = 0; return; }
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem);                          // sort_cap keys
+  float4 *spt = reinterpret_cast<float4 *>(smem + size_t(sort_cap) * 8);                             // n points
+  short *spos = reinterpret_cast<short *>(smem + size_t(sort_cap) * 8 + size_t(pts_cap) * 16);       // flags -> positions (< 4096: 16-bit words)
   __shared__ float sb[PP_LF_THREADS / 64][6];
   __shared__ int swave[PP_LF_THREADS / 64];
   __shared__ int s_members;
@@ -671,7 +710,7 @@ __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restr
     if (i < NS) {
       const unsigned long long k = skey[i];
       const bool head = k != ~0ull && (i == 0 || (skey[i - 1] >> 32) != (k >> 32));
-      spos[i] = head ? 1 : 0;
+      spos[i] = short(head ? 1 : 0);
       local += head ? 1 : 0;
     }
   }
@@ -687,13 +726,13 @@ __global__ void __launch_bounds__(PP_LF_THREADS) k_lf_ring(const float4 *__restr
   for (int w = 0; w < PP_LF_THREADS / 64; ++w) total += swave[w];
   for (int q = 0; q < per; ++q) {
     const int i = tid * per + q;
-    if (i < NS) { const int f = spos[i]; spos[i] = f ? run : -1; run += f; }
+    if (i < NS) { const int f = spos[i]; spos[i] = short(f ? run : -1); run += f; }
   }
   __syncthreads();
   // ---- centroids
   const float start_ori = sweep_start_ori(azi, first_valid, start_ori_override);
   for (int i = tid; i < NS; i += PP_LF_THREADS) {
-    const int pos = spos[i];
+    const int pos = int(spos[i]);
     if (pos < 0) continue;
     const unsigned int vk = static_cast<unsigned int>(skey[i] >> 32);
     float ax = 0, ay = 0, az = 0, ai = 0;
@@ -747,17 +786,23 @@ float StartOriFilter::Update(float measured, float ring0_front, double rad_diff)
   return s;
 }
 
+// ints of a sweep's state record in front of first_valid: PPDeviceCounts, then the ring offsets
+static constexpr int kCountInts = int(sizeof(PPDeviceCounts) / sizeof(int));
+static constexpr int kOffFirstValid = kCountInts + LIO_PP_MAX_RINGS + 1;
+static constexpr int kSizedLdsFromSweeps = 4;   // batches of at least this many sweeps size the per-ring kernels' LDS by the rings they hold
+static_assert(sizeof(PPDeviceCounts) % sizeof(int) == 0 && sizeof(PPDeviceCounts) % 8 == 0, "the state record starts with the counts");
+
 float PointProcessorDev::StartOri() {
-  if (!processed_) return std::nanf("");
+  if (!processed_ || sel_ >= nsw_ || n_sw_[size_t(sel_)] == 0) return std::nanf("");   // (an empty sweep of a batch has no first point)
   if (!start_ori_known_) {
-    start_ori_dev_.reserve(3);
-    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, stream_, azi_.p, first_valid_p_, start_ori_dev_.p);
-    LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    const PPStrides st{int(pts_stride_), 0, state_stride_, 0, 0};
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1, 1, nsw_), dim3(1), 0, stream_, azi_.p, d_state_.p + kOffFirstValid, start_ori_dev_.p, st);
+    LIO_HIP(hipMemcpyAsync(h_ori_, start_ori_dev_.p, size_t(2) * nsw_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
     LIO_HIP(hipStreamSynchronize(stream_));
-    h_out_->start_ori_probe[2] = h_out_->start_ori_probe[0];
+    for (int k = nsw_ - 1; k >= 0; --k) { const float v = h_ori_[2 * k]; h_ori_[3 * k + 2] = v; }   // (probe pairs -> triples: the last first)
     start_ori_known_ = true;
   }
-  return h_out_->start_ori_probe[2];
+  return h_ori_[3 * sel_ + 2];
 }
 
 PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const lio_pp_config &cfg)
@@ -768,103 +813,178 @@ PointProcessorDev::PointProcessorDev(float lower, float upper, int rings, const 
   if (nd <= 0) throw DeviceError("no HIP device: the product has no CPU path");
   LIO_HIP(hipStreamCreate(&stream_));
   ring_offsets_.assign(rings + 1, 0);
-  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_out_), sizeof(HostOut)));
+  state_stride_ = (kOffFirstValid + 4 + 3) & ~3;
+  ReserveHost(1);
   // the pick kernel needs up to ~104 KB of dynamic LDS
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ring_pick), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   LIO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lf_ring), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28));
 }
 PointProcessorDev::~PointProcessorDev() {
-  if (h_out_) (void)hipHostFree(h_out_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (h_state_) (void)hipHostFree(h_state_);
   if (stream_) (void)hipStreamDestroy(stream_);
+}
+void PointProcessorDev::ReserveHost(int B) {
+  if (B <= h_cap_sweeps_) return;
+  if (h_state_) { LIO_HIP(hipStreamSynchronize(stream_)); (void)hipHostFree(h_state_); h_state_ = nullptr; }
+  const size_t ints = size_t(B) * state_stride_;
+  LIO_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_state_), ints * sizeof(int) + size_t(4) * B * sizeof(float) + size_t(B) * sizeof(const float4 *)));
+  h_ori_ = reinterpret_cast<float *>(h_state_ + ints);
+  h_ptr_ = reinterpret_cast<const float4 **>(h_ori_ + size_t(4) * B);   // (4 B floats behind a multiple-of-4 int count: 8-byte aligned)
+  h_cap_sweeps_ = B;
+}
+bool PointProcessorDev::SameSensor(const PointProcessorDev &o) const {
+  return lower_ == o.lower_ && upper_ == o.upper_ && rings_ == o.rings_ && std::memcmp(&cfg_, &o.cfg_, sizeof(cfg_)) == 0;
 }
 
 void PointProcessorDev::Process(const float *xyzi, size_t n, const uint16_t *ring) {
   ProcessLaunch(xyzi, n, ring);
   ProcessFinish();
 }
-
-// Everything a sweep needs, enqueued on the handle's stream: upload, ring split, picks, less-flat filter, packing, and the copy
-// of the counts into pinned memory.  The caller's buffer is read by the upload: it must stay untouched until ProcessFinish().
 void PointProcessorDev::ProcessLaunch(const float *xyzi, size_t n, const uint16_t *ring) {
+  StartOriFilter *f = &start_ori_filter_;
+  ProcessLaunchBatch(&xyzi, ring ? &ring : nullptr, &n, 1, false, &f);
+}
+
+// Everything B sweeps need, enqueued on the handle's stream: uploads, ring split, picks, less-flat filter, packing, and ONE copy of the
+// sweeps' state records into pinned memory.  Host buffers are read by the uploads: they must stay untouched until ProcessFinish().
+void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint16_t *const *ring, const size_t *n, int B, bool on_device,
+                                           StartOriFilter *const *filters) {
   if (in_flight_) ProcessFinish();
   std::memset(&counts_, 0, sizeof(counts_));
   std::fill(ring_offsets_.begin(), ring_offsets_.end(), 0);
-  if (n == 0) return;
+  size_t n_max = 0;
+  for (int k = 0; k < B; ++k) n_max = std::max(n_max, n[k]);
+  // nothing to do: every count reads zero; the start azimuth stays the last sweep's, as the reference's member does (PointProcessor.cc:261-264)
+  last_empty_ = (B <= 0 || n_max == 0);
+  if (last_empty_) return;
   in_flight_ = true;
-  const int ni = int(n);
+  nsw_ = B; sel_ = 0;
+  n_sw_.assign(n, n + B);
   hipStream_t s = stream_;
-  in_.reserve(n); ring_cloud_.reserve(n); ring_intensity_.reserve(n); azi_.reserve(n); curv_.reserve(n); mask_.reserve(n); label_.reserve(n);
-  keys_.reserve(n); less_flat_.reserve(n);
-  const int nblocks = cdiv(ni, PP_BIN_THREADS);
-  ring_table_.reserve(size_t(rings_) * nblocks); ring_total_.reserve(rings_);
-  if (!d_counts_p_) {
-    static_assert(sizeof(PPDeviceCounts) % sizeof(int) == 0 && offsetof(HostOut, ring_offsets) == sizeof(PPDeviceCounts), "device state mirrors HostOut");
-    const size_t nc_ints = sizeof(PPDeviceCounts) / sizeof(int);
-    d_state_.reserve(nc_ints + LIO_PP_MAX_RINGS + 1 + 4);
-    d_counts_p_ = reinterpret_cast<PPDeviceCounts *>(d_state_.p);
-    d_ring_offsets_p_ = d_state_.p + nc_ints;
-    first_valid_p_ = d_ring_offsets_p_ + LIO_PP_MAX_RINGS + 1;
-    end_ori_p_ = first_valid_p_ + 2;
-  }
+  ReserveHost(B);
+  const size_t stride = (n_max + PP_BIN_THREADS - 1) / PP_BIN_THREADS * PP_BIN_THREADS, tot = stride * size_t(B);
+  pts_stride_ = stride;
+  in_.reserve(tot); ring_cloud_.reserve(tot); ring_intensity_.reserve(tot); azi_.reserve(tot); curv_.reserve(tot); mask_.reserve(tot); label_.reserve(tot);
+  keys_.reserve(tot); less_flat_.reserve(tot); lf_tmp_.reserve(tot);
+  const int nblocks = int(stride / PP_BIN_THREADS);
+  ring_table_.reserve(size_t(B) * rings_ * nblocks); ring_total_.reserve(size_t(B) * LIO_PP_MAX_RINGS); lf_ring_count_.reserve(size_t(B) * LIO_PP_MAX_RINGS);
+  d_state_.reserve(size_t(B) * state_stride_);
+  PPDeviceCounts *d_counts = reinterpret_cast<PPDeviceCounts *>(d_state_.p);
+  int *d_ring_offsets = d_state_.p + kCountInts, *first_valid = d_state_.p + kOffFirstValid, *end_ori = first_valid + 2;
   PickCfg pc{rings_, cfg_.num_curvature_regions, cfg_.num_scan_subregions, cfg_.max_corner_sharp, cfg_.max_corner_less_sharp,
              cfg_.max_surf_flat, cfg_.surf_curv_th};
   const int cap_sharp = pc.ns * pc.max_sharp, cap_less = pc.ns * pc.max_less_sharp, cap_flat = pc.ns * pc.max_flat;
   const int cap_all = cap_sharp + cap_less + cap_flat;
   const int cap_total = rings_ * std::max(cap_less, std::max(cap_sharp, cap_flat));
-  pick_idx_.reserve(size_t(rings_) * cap_all); pick_cnt_.reserve(size_t(rings_) * 3);
-  class_ring_.reserve(size_t(3) * cap_total); class_idx_.reserve(size_t(3) * cap_total);
-  for (int cidx = 1; cidx <= 3; ++cidx) class_cloud_[cidx].reserve(cap_total);
+  cls_stride_ = size_t(cap_total);
+  pick_idx_.reserve(size_t(B) * rings_ * cap_all); pick_cnt_.reserve(size_t(B) * 3 * LIO_PP_MAX_RINGS);
+  class_ring_.reserve(size_t(B) * 3 * cap_total); class_idx_.reserve(size_t(B) * 3 * cap_total);
+  for (int cidx = 1; cidx <= 3; ++cidx) class_cloud_[cidx].reserve(size_t(B) * cap_total);
+  const PPStrides st{int(stride), rings_ * nblocks, state_stride_, rings_ * cap_all, cap_total};
 
   static const bool dbg = std::getenv("LIO_DEBUG_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  LIO_HIP(hipMemcpyAsync(in_.p, xyzi, n * sizeof(float4), hipMemcpyHostToDevice, s));
+  const hipMemcpyKind up = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  bool any_ring = false;
+  const float4 *const *d_in_table = nullptr;
+  if (on_device) {
+    // the two kernels that read the input take it where it lies: one table of B pointers goes up instead of B device-to-device copies
+    d_in_table_.reserve(B);
+    for (int k = 0; k < B; ++k) h_ptr_[k] = reinterpret_cast<const float4 *>(xyzi[k]);
+    LIO_HIP(hipMemcpyAsync(d_in_table_.p, h_ptr_, size_t(B) * sizeof(const float4 *), hipMemcpyHostToDevice, s));
+    d_in_table = d_in_table_.p;
+  }
+  for (int k = 0; k < B; ++k) {
+    if (n[k] && !on_device) LIO_HIP(hipMemcpyAsync(in_.p + size_t(k) * stride, xyzi[k], n[k] * sizeof(float4), up, s));
+    if (ring && ring[k]) any_ring = true;
+  }
   if (dbg) {
     LIO_HIP(hipStreamSynchronize(s));
-    std::fprintf(stderr, "[lio_hip pp timing] H2D of %zu points %.1f us\n", n,
+    std::fprintf(stderr, "[lio_hip pp timing] H2D of %d sweep(s), %zu points the largest, %.1f us\n", B, n_max,
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
-  hipLaunchKernelGGL(k_pp_init, dim3(1), dim3(64), 0, s, d_state_.p, int(sizeof(PPDeviceCounts) / sizeof(int)), first_valid_p_, end_ori_p_);
+  // points per sweep: a kernel argument for one sweep, a small device array for several
+  const int *d_n = nullptr;
+  if (B > 1) {
+    d_n_.reserve(B);
+    int *h_n = h_state_;   // (the landing zone is idle until the chain's last copy; the upload below reads it before that copy is enqueued ... by stream order)
+    for (int k = 0; k < B; ++k) h_n[k] = int(n[k]);
+    LIO_HIP(hipMemcpyAsync(d_n_.p, h_n, size_t(B) * sizeof(int), hipMemcpyHostToDevice, s));
+    d_n = d_n_.p;
+  }
+  const int ni = int(n_max);
+  hipLaunchKernelGGL(k_pp_init, dim3(1, 1, B), dim3(64), 0, s, d_state_.p, kCountInts, first_valid, end_ori, st);
   const uint16_t *d_ring = nullptr;
-  if (ring) {
-    ring_in_.reserve(n);
-    LIO_HIP(hipMemcpyAsync(ring_in_.p, ring, n * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+  if (any_ring) {
+    ring_in_.reserve(tot);
+    for (int k = 0; k < B; ++k) {
+      if (!ring[k] && n[k]) throw std::runtime_error("PointProcessor: a batch mixes sweeps with and without a ring field");
+      if (n[k]) LIO_HIP(hipMemcpyAsync(ring_in_.p + size_t(k) * stride, ring[k], n[k] * sizeof(uint16_t), up, s));
+    }
     // end_ori_ = 0 (:439): k_pp_init
     d_ring = ring_in_.p;
   }
-  hipLaunchKernelGGL(k_ring_bin, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, azi_.p, ring_table_.p,
-                     nblocks, first_valid_p_);
-  if (ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256)), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid_p_, end_ori_p_);
-  hipLaunchKernelGGL(k_ring_scan, dim3(rings_), dim3(256), 0, s, ring_table_.p, nblocks, ring_total_.p);
+  hipLaunchKernelGGL(k_ring_bin, dim3(nblocks, 1, B), dim3(PP_BIN_THREADS), 0, s, in_.p, d_ring, ni, lower_, factor_, rings_, keys_.p, azi_.p, ring_table_.p,
+                     nblocks, first_valid, st, d_n, d_in_table);
+  if (d_ring) hipLaunchKernelGGL(k_ring_end_ori, dim3(cdiv(ni, 256), 1, B), dim3(256), 0, s, keys_.p, azi_.p, ni, rings_, first_valid, end_ori, st, d_n);
+  hipLaunchKernelGGL(k_ring_scan, dim3(rings_, 1, B), dim3(256), 0, s, ring_table_.p, nblocks, ring_total_.p, st);
   const float *d_override = nullptr;
   processed_ = true; start_ori_known_ = false;
-  if (cfg_.infer_start_ori && !ring) {
-    // :348-387 — ten lines of host state between the two passes of PointToRing; costs one round trip, only when enabled
-    start_ori_dev_.reserve(3);
-    hipLaunchKernelGGL(k_start_ori_probe, dim3(1), dim3(1), 0, s, azi_.p, first_valid_p_, start_ori_dev_.p);
-    LIO_HIP(hipMemcpyAsync(h_out_->start_ori_probe, start_ori_dev_.p, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (cfg_.infer_start_ori && !d_ring) {
+    // :348-387 — ten lines of host state between the two passes of PointToRing; costs one round trip, only when enabled.  Sweep k's
+    // probe goes through the history it belongs to (filters[k]: the handle it came in through)
+    start_ori_dev_.reserve(size_t(3) * B);
+    hipLaunchKernelGGL(k_start_ori_probe, dim3(1, 1, B), dim3(1), 0, s, azi_.p, first_valid, start_ori_dev_.p, st);
+    LIO_HIP(hipMemcpyAsync(h_ori_, start_ori_dev_.p, size_t(2) * B * sizeof(float), hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));
-    h_out_->start_ori_probe[2] = start_ori_filter_.Update(h_out_->start_ori_probe[0], h_out_->start_ori_probe[1], cfg_.rad_diff);
-    LIO_HIP(hipMemcpyAsync(start_ori_dev_.p + 2, h_out_->start_ori_probe + 2, sizeof(float), hipMemcpyHostToDevice, s));
-    d_override = start_ori_dev_.p + 2;
+    for (int k = B - 1; k >= 0; --k) {   // (probe pairs -> (probe, probe, used) triples in place: the last sweep first)
+      const float measured = h_ori_[2 * k], ring0 = h_ori_[2 * k + 1];
+      h_ori_[3 * k] = measured; h_ori_[3 * k + 1] = ring0;
+    }
+    float *h_used = reinterpret_cast<float *>(h_state_);   // (staging of the B values on their way up; the landing zone is idle)
+    for (int k = 0; k < B; ++k) {
+      StartOriFilter *f = (filters && filters[k]) ? filters[k] : &start_ori_filter_;
+      h_ori_[3 * k + 2] = n[k] ? f->Update(h_ori_[3 * k], h_ori_[3 * k + 1], cfg_.rad_diff) : std::nanf("");
+      h_used[B + k] = h_ori_[3 * k + 2];
+    }
+    LIO_HIP(hipMemcpyAsync(start_ori_dev_.p + size_t(2) * B, h_used + B, size_t(B) * sizeof(float), hipMemcpyHostToDevice, s));
+    d_override = start_ori_dev_.p + size_t(2) * B;
     start_ori_known_ = true;
+  } else {
+    start_ori_dev_.reserve(size_t(3) * B);
   }
-  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets_p_,
-                     first_valid_p_, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring_intensity_.p, ring ? end_ori_p_ : nullptr);
-  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(LIO_PP_MAX_RING_POINTS + 64) * (4 * sizeof(float) + 6) + size_t(8) * PP_WMASK +
+  hipLaunchKernelGGL(k_ring_scatter, dim3(nblocks, 1, B), dim3(PP_BIN_THREADS), 0, s, in_.p, keys_.p, azi_.p, ring_table_.p, nblocks, ni, ring_total_.p, d_ring_offsets,
+                     first_valid, d_override, rings_, cfg_.scan_period, ring_cloud_.p, ring_intensity_.p, d_ring ? end_ori : nullptr, st, d_n, d_in_table);
+  // The two per-ring kernels keep a ring in LDS.  One sweep: sized for the longest ring the handle takes (no host round trip in front of
+  // the launch).  A batch: the host reads the rings' lengths first (one small copy + wait per batch, nothing against B sweeps of work)
+  // and asks for what the longest ring of THIS batch needs — at HDL-64E ring lengths two workgroups per compute unit instead of one.
+  int ring_cap = LIO_PP_MAX_RING_POINTS;
+  if (B >= kSizedLdsFromSweeps) {
+    int *h_tot = h_state_;   // (the landing zone is idle until the chain's last copy)
+    LIO_HIP(hipMemcpyAsync(h_tot, ring_total_.p, size_t(B) * LIO_PP_MAX_RINGS * sizeof(int), hipMemcpyDeviceToHost, s));
+    LIO_HIP(hipStreamSynchronize(s));
+    int mx = 0;
+    for (int k = 0; k < B; ++k)
+      for (int r = 0; r < rings_; ++r) mx = std::max(mx, h_tot[size_t(k) * LIO_PP_MAX_RINGS + r]);
+    ring_cap = std::min(LIO_PP_MAX_RING_POINTS, (std::max(mx, 64) + 63) & ~63);   // (a longer ring raises the overflow flag, as ever)
+  }
+  const size_t lds = size_t(8) * PP_SORT_SLOTS * 8 + size_t(ring_cap + 64) * (3 * sizeof(float) + 6) + size_t(8) * PP_WMASK +
                      size_t(8) * PP_WSEL * sizeof(int) + 24 * sizeof(int) + size_t(cap_all) * sizeof(int) + 64;
-  hipLaunchKernelGGL(k_ring_pick, dim3(rings_), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets_p_, pc, curv_.p, mask_.p, label_.p,
-                     pick_idx_.p, pick_cnt_.p, d_counts_p_);
+  hipLaunchKernelGGL(k_ring_pick, dim3(rings_, 1, B), dim3(PP_PICK_THREADS), lds, s, ring_cloud_.p, d_ring_offsets, pc, curv_.p, mask_.p, label_.p,
+                     pick_idx_.p, pick_cnt_.p, d_counts, st, ring_cap);
   // less-flat
   const float inv_leaf = 1.0f / cfg_.less_flat_filter_size;
-  lf_tmp_.reserve(n); lf_ring_count_.reserve(rings_);
-  const size_t lf_lds = size_t(4096) * 8 + size_t(4096) * 16 + size_t(4096) * 4;
-  hipLaunchKernelGGL(k_lf_ring, dim3(rings_), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets_p_, label_.p, inv_leaf, azi_.p,
-                     first_valid_p_, d_override, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p);
-  hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets_p_, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
-                     class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts_p_);
+  int sort_cap = 128;
+  while (sort_cap < ring_cap) sort_cap <<= 1;
+  const size_t lf_lds = size_t(sort_cap) * 8 + size_t(ring_cap) * 16 + size_t(sort_cap) * 2;
+  hipLaunchKernelGGL(k_lf_ring, dim3(rings_, 1, B), dim3(PP_LF_THREADS), lf_lds, s, ring_cloud_.p, d_ring_offsets, label_.p, inv_leaf, azi_.p,
+                     first_valid, d_override, cfg_.scan_period, lf_tmp_.p, lf_ring_count_.p, st, ring_cap, sort_cap);
+  hipLaunchKernelGGL(k_pp_pack, dim3(rings_, 2, B), dim3(256), 0, s, ring_cloud_.p, d_ring_offsets, pick_idx_.p, pick_cnt_.p, pc, class_ring_.p, class_idx_.p,
+                     class_cloud_[1].p, class_cloud_[2].p, class_cloud_[3].p, cap_total, lf_tmp_.p, lf_ring_count_.p, less_flat_.p, d_counts, st);
   LIO_HIP(hipGetLastError());
   // results come back through pinned memory: a D2H into pageable memory blocks the host per copy (20 us between the two)
-  LIO_HIP(hipMemcpyAsync(&h_out_->counts, d_counts_p_, sizeof(PPDeviceCounts) + sizeof(int) * (rings_ + 1), hipMemcpyDeviceToHost, s));   // counts + ring offsets
+  LIO_HIP(hipMemcpyAsync(h_state_, d_state_.p, size_t(B) * state_stride_ * sizeof(int), hipMemcpyDeviceToHost, s));   // every sweep's counts + ring offsets
   t_begin_ = t_begin;
 }
 
@@ -875,16 +995,29 @@ void PointProcessorDev::ProcessFinish() {
   const auto t_begin = t_begin_;
   LIO_HIP(hipStreamSynchronize(stream_));
   if (dbg) {
-    std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us\n",
-                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
-    const long long *st = h_out_->counts.pick_stamps;
+    std::fprintf(stderr, "[lio_hip pp timing] process total %.1f us (%d sweep(s))\n",
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), nsw_);
+    const long long *st = reinterpret_cast<const PPDeviceCounts *>(h_record(0))->pick_stamps;
     std::fprintf(stderr, "[lio_hip pp timing] k_ring_pick ring %d, 10 ns ticks: load %lld, PrepareRing+reach %lld, curvature+keys %lld, sort %lld, picks %lld, lists + mask merge %lld, write-back %lld\n",
                  PP_STAMP_RING, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6]);
   }
-  counts_ = h_out_->counts;
-  std::copy(h_out_->ring_offsets, h_out_->ring_offsets + rings_ + 1, ring_offsets_.begin());
+  for (int k = 0; k < nsw_; ++k)
+    if (reinterpret_cast<const PPDeviceCounts *>(h_record(k))->overflow) { SelectSweep(0); throw std::runtime_error("PointProcessor: a ring exceeds LIO_PP_MAX_RING_POINTS"); }
+  SelectSweep(0);
+}
+
+void PointProcessorDev::SelectSweep(int k) {
+  if (last_empty_) {   // (a batch of empty sweeps launched nothing)
+    std::memset(&counts_, 0, sizeof(counts_));
+    std::fill(ring_offsets_.begin(), ring_offsets_.end(), 0);
+    return;
+  }
+  if (k < 0 || k >= nsw_) throw std::runtime_error("PointProcessor: no such sweep in the last batch");
+  sel_ = k;
+  std::memcpy(&counts_, h_record(k), sizeof(counts_));
+  const int *off = h_record(k) + kCountInts;
+  std::copy(off, off + rings_ + 1, ring_offsets_.begin());
   counts_.n_ring_points = ring_offsets_[rings_];
-  if (counts_.overflow) throw std::runtime_error("PointProcessor: a ring exceeds LIO_PP_MAX_RING_POINTS");
 }
 
 size_t PointProcessorDev::Count(int which) const {
@@ -897,17 +1030,17 @@ size_t PointProcessorDev::Count(int which) const {
 void PointProcessorDev::GetCloud(int which, float *out) {
   size_t n = Count(which);
   if (!n) return;
-  const float4 *src = which == LIO_PP_RINGS ? ring_cloud_.p : (which == LIO_PP_LESS_FLAT ? less_flat_.p : class_cloud_[which].p);
+  const float4 *src = which == LIO_PP_RINGS ? ring_cloud_.p + sel_ * pts_stride_
+                                            : (which == LIO_PP_LESS_FLAT ? less_flat_.p + sel_ * pts_stride_ : class_cloud_[which].p + sel_ * cls_stride_);
   LIO_HIP(hipMemcpyAsync(out, src, n * sizeof(float4), hipMemcpyDeviceToHost, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
 }
 void PointProcessorDev::GetIndices(int which, int32_t *ring, int32_t *idx) {
   size_t n = Count(which);
   if (!n) return;
-  const int cap_total = rings_ * std::max(cfg_.num_scan_subregions * cfg_.max_corner_less_sharp,
-                                          std::max(cfg_.num_scan_subregions * cfg_.max_corner_sharp, cfg_.num_scan_subregions * cfg_.max_surf_flat));
-  LIO_HIP(hipMemcpyAsync(ring, class_ring_.p + size_t(which - 1) * cap_total, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  LIO_HIP(hipMemcpyAsync(idx, class_idx_.p + size_t(which - 1) * cap_total, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  const size_t base = (size_t(sel_) * 3 + size_t(which - 1)) * cls_stride_;
+  LIO_HIP(hipMemcpyAsync(ring, class_ring_.p + base, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(idx, class_idx_.p + base, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
 }
 void PointProcessorDev::GetRingOffsets(int32_t *out) {
@@ -916,14 +1049,14 @@ void PointProcessorDev::GetRingOffsets(int32_t *out) {
 void PointProcessorDev::GetRingIntensity(float *out) {
   const size_t n = size_t(counts_.n_ring_points);
   if (!n || !out) return;
-  LIO_HIP(hipMemcpyAsync(out, ring_intensity_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  LIO_HIP(hipMemcpyAsync(out, ring_intensity_.p + sel_ * pts_stride_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
 }
 void PointProcessorDev::GetCurvature(float *curv, int32_t *mask) {
   size_t n = size_t(counts_.n_ring_points);
   if (!n) return;
-  if (curv) LIO_HIP(hipMemcpyAsync(curv, curv_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
-  if (mask) LIO_HIP(hipMemcpyAsync(mask, mask_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  if (curv) LIO_HIP(hipMemcpyAsync(curv, curv_.p + sel_ * pts_stride_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if (mask) LIO_HIP(hipMemcpyAsync(mask, mask_.p + sel_ * pts_stride_, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
   LIO_HIP(hipStreamSynchronize(stream_));
 }
 

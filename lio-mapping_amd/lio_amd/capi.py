@@ -144,6 +144,7 @@ _SIGS = {
     "lio_bench_voxel_grid": (C.c_int, [c_float_p, C.c_size_t, C.c_float, C.c_int, c_double_p, C.POINTER(C.c_size_t)]),
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_float_p), C.POINTER(C.c_size_t), C.c_int]),
+    "lio_pp_process_batch_device": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
@@ -521,6 +522,18 @@ class PointProcessor:
         ptrs = (c_float_p * B)(*[_fp(a) for a in arrs])
         ns = (C.c_size_t * B)(*[a.shape[0] for a in arrs])
         _chk(processors[0].lib.dll.lio_pp_process_batch(hs, ptrs, ns, B), "lio_pp_process_batch")
+
+    @staticmethod
+    def process_batch_device(processors, device_ptrs, counts):
+        """lio_pp_process_batch_device: the sweeps are already in device memory (device_ptrs[k]: address of counts[k] x 4 floats)."""
+        B = len(processors)
+        assert B == len(device_ptrs) == len(counts)
+        if B == 0:
+            return
+        hs = (C.c_void_p * B)(*[p.h for p in processors])
+        ptrs = (C.c_void_p * B)(*[int(a) for a in device_ptrs])
+        ns = (C.c_size_t * B)(*[int(c) for c in counts])
+        _chk(processors[0].lib.dll.lio_pp_process_batch_device(hs, ptrs, ns, B), "lio_pp_process_batch_device")
 
     def process(self, xyzi, ring=None):
         """ring (uint16 per point) selects the PointIR overload of PointToRing (uneven sensors, PointProcessor.cc:428-536)."""

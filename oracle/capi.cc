@@ -75,6 +75,9 @@ int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const
   for (int k = 0; k < n_sweeps && rc == LIO_OK; ++k) rc = lio_pp_process(handles[k], xyzi[k], n[k]);
   return rc;
 }
+int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
+  return lio_pp_process_batch(handles, xyzi, n, n_sweeps);   // (no device here: the pointers are host memory)
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   h->pp.Process(xyzi, n, ring);

@@ -237,11 +237,11 @@ void EstimatorBatch::StageDigest(int stage, unsigned long long *out) {
         const std::vector<double> pm = fetch(slab_.p + size_t(w) * lay_.total + lay_.prior[1 - win_[w].cur], ds_prior_mats_size(h_mg_[w].n));
         h = fnv1a(pm.data(), pm.size() * sizeof(double), mix64(h_mg_[w].n));
         if (std::getenv("LIO_DEBUG_DIGEST") && (w == 0 || w == B - 1))
-          std::fprintf(stderr, "[digest] window %d marginalization: m %d n %d sweeps %g / %g; shader clocks: assembly %.0f, Amm eig %.0f, pinv + T + S %.0f, S eig %.0f, factors out %.0f, J^T J %.0f\n",
+          std::fprintf(stderr, "[digest] window %d marginalization: m %d n %d QL sweeps %g / %g; shader clocks: assembly %.0f, Amm eig %.0f, pinv + T + S %.0f, S eig %.0f, factors out %.0f, J^T J %.0f\n",
                        w, h_mg_[w].m, h_mg_[w].n, mi[0], mi[1], mi[MARG_MAX_N + 9] - mi[MARG_MAX_N + 8], mi[MARG_MAX_N + 10] - mi[MARG_MAX_N + 9], mi[MARG_MAX_N + 11] - mi[MARG_MAX_N + 10], mi[MARG_MAX_N + 12] - mi[MARG_MAX_N + 11],
                        mi[MARG_MAX_N + 13] - mi[MARG_MAX_N + 12], mi[MARG_MAX_N + 14] - mi[MARG_MAX_N + 13]);
         if (std::getenv("LIO_DEBUG_DIGEST") && w == 0 && mi[MARG_MAX_N + 16] != 0.0)
-          std::fprintf(stderr, "[digest] S eig, thread 0, summed over the steps: angles %.0f, barrier %.0f, blocks %.0f, barrier %.0f\n", mi[MARG_MAX_N + 16], mi[MARG_MAX_N + 17], mi[MARG_MAX_N + 18], mi[MARG_MAX_N + 19]);
+          std::fprintf(stderr, "[digest] S eig, thread 0: reduction %.0f, QL %.0f of which wave 0's recurrence %.0f, its waits at the sweeps' barriers %.0f\n", mi[MARG_MAX_N + 16], mi[MARG_MAX_N + 19], mi[MARG_MAX_N + 17], mi[MARG_MAX_N + 18]);
         break;
       }
       case 7: { const std::vector<DevState> o = fetch(d_st_.p + w, 1); h = fnv1a(o[0].scale, sizeof(o[0].scale)); break; }

@@ -6,11 +6,10 @@
 //   S     = V2 diag(s) V2^T                                  (:293)
 //   linearized_jacobians = diag(sqrt(s_k > eps ? s_k : 0)) V2^T,  linearized_residuals = diag(1/sqrt(s_k) or 0) V2^T bs   (:294-302)
 //
-// The eigensolver is the cyclic two-sided Jacobi method in the round-robin ordering: n / 2 disjoint rotations per step, every
-// step three block barriers (rotation angles; rows; columns of S and of the eigenvector matrix).  It is the textbook choice
-// for one workgroup — no serial QL sweep — and it resolves the small eigenvalues of the badly graded S (entries from 1e9 down
-// to 1e-4) at least as well as the tridiagonal QL iteration the host uses; which eigenvalues fall on which side of the absolute
-// 1e-8 cut is rounding noise on either path (tests/golden/README.md).
+// The eigensolver is the Householder + implicit-QL pair (tridiag_ql_lds below): the method of the host path and of the reference's
+// Eigen::SelfAdjointEigenSolver.  Which eigenvalues of the badly graded S (entries from 1e9 down to 1e-4) fall on which side of the
+// absolute 1e-8 cut is rounding noise on every such path (tests/golden/README.md); the tests pin the invariants (J^T J, J^T r, r^T r, the
+// kept spectrum), not single eigenvectors.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -30,140 +29,254 @@ namespace lio {
 #endif
 #define MARG_AUX_THREADS 256   // the aux row (256 VGPRs per lane: one wave per SIMD)
 
-// cyclic Jacobi on the symmetric np x np matrix S (leading dimension ld, np even; a padding row / column must be zero),
-// eigenvectors accumulated in the columns of V (identity on entry).  cs: np doubles of scratch (16-byte aligned), flag: two ints.
-//
-// A step applies np / 2 disjoint rotations J (round-robin pairing): S <- J^T S J, V <- V J.  The pairs partition the indices, so
-// S falls into (np / 2)^2 blocks of 2 x 2 — rows of pair P, columns of pair Q — and a block's new value depends on its old value and
-// the two angles only: one thread rotates a block's rows and then its columns in registers and stores it and its transpose (S stays
-// exactly symmetric; only one block of every unordered pair {P, Q} is computed).  Two barriers per step: angles | blocks and
-// eigenvector rows.  Where the time went (n = 45, 12 sweeps x 45 steps, shader clocks per step, profiles/r6_b_marg_phases.txt):
-// round 5's form — a row pass and a column pass over the whole matrix, four barriers — 9.3 k; the fused block form with correctly
-// rounded divides / square roots in the angles and a division per item 6.1 k; hardware reciprocal / rsqrt + Newton, division-free
-// item map, 512 threads 3.3 k, of which 2.5 k were vector-instruction ISSUE (selects, address products, the identity row rotation of
-// the eigenvector items) — not LDS latency and not arithmetic (a step is 8.6 k fp64 operations per workgroup).  This form: triangle of
-// blocks, eigenvector rows on their own, fused multiply-adds.
-__device__ __forceinline__ double jac_rcp(double d) {   // 1 / d: hardware estimate + two Newton steps (<= 1 ulp)
+// Symmetric eigendecomposition in LDS by one workgroup: Householder reduction to tridiagonal form, then the implicit QL iteration with
+// Wilkinson-type shifts — the tred2 / tql2 pair, i.e. the method of the host path (hlinalg.h: sym_eig) and of the reference's
+// Eigen::SelfAdjointEigenSolver (MarginalizationFactor.cc:276, :293).  Rounds 5-6 ran a cyclic Jacobi here (n / 2 rotations per step, all
+// threads busy): 12 sweeps x 45 steps x 3.1 k clocks = 1.7 M clocks at n = 45 however it was tuned (profiles/r6_b_marg_phases.txt) — the
+// work is O(sweeps x n^3) behind 1 080 block barriers.  This form does O(n^3) once:
+//   reduction   n - 2 reflectors H = I - u u^T / h, each three barriers: the reflector (one wave: two sums, a square root);  A u and Z u
+//               (8 lanes per row);  the rank-2 update of A's leading block and the rank-1 update of Z = H_{n-1} .. H_2 — accumulated as
+//               the reduction goes, not in a second pass;
+//   QL          a serial recurrence (the rotations of one sweep depend on each other through p, c, s): wave 0 runs it with the diagonal
+//               and sub-diagonal in REGISTERS (lane k holds d_k, e_k, d_{k+64}, e_{k+64}; element i is a v_readlane with a uniform
+//               index, no LDS round trip on the chain) and leaves the sweep's (c, s) pairs in LDS; the other waves apply the PREVIOUS
+//               sweep's rotations to Z (one thread per row, the running column in a register) at the same time.  One barrier per sweep.
+// A: n x n (leading dimension ld), symmetric on entry, destroyed; its diagonal holds the eigenvalues on return (not sorted).
+// Z: n x n (ld), eigenvectors as COLUMNS (column k belongs to A[k][k]).  work: 9 n + 16 doubles.  n <= 128.  Returns the number of QL sweeps.
+// wave-wide sum on DPP moves and four v_readlane (a shuffle through the LDS crossbar costs ~120 clocks per step, and two of these sums
+// sit on the critical path of every reflector): quad swaps, two rotations inside the rows of 16, then the four row sums
+template <int CTRL> __device__ __forceinline__ double eig_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double eig_quad_sum(double v) {   // every lane: the sum over its quad
+  v += eig_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += eig_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  return v;
+}
+__device__ __forceinline__ double eig_wsum(double v) {
+  v = eig_quad_sum(v);
+  v += eig_dpp<0x124>(v);   // row_ror:4
+  v += eig_dpp<0x128>(v);   // row_ror:8
+  return (ds_bcast_lane(v, 0) + ds_bcast_lane(v, 16)) + (ds_bcast_lane(v, 32) + ds_bcast_lane(v, 48));
+}
+__device__ __forceinline__ double eig_rsqrt(double d) {  // 1 / sqrt(d): hardware estimate + two Newton steps (<= 1 ulp) — a correctly rounded divide and square root are ~80 instructions on the serial chain
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y * __builtin_fma(-h * y, y, 1.5);
+}
+__device__ __forceinline__ double eig_rcp(double d) {   // 1 / d likewise
   double y = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, y, 1.0);
   y = __builtin_fma(y, e, y);
   e = __builtin_fma(-d, y, 1.0);
   return __builtin_fma(y, e, y);
 }
-__device__ __forceinline__ double jac_rsqrt(double d) {  // 1 / sqrt(d) likewise
-  double y = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  y = y * __builtin_fma(-h * y, y, 1.5);
-  return y * __builtin_fma(-h * y, y, 1.5);
+__device__ __forceinline__ void eig_wave_sync() {   // orders this wave's LDS traffic for the compiler (the hardware runs a wave's DS operations in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ int jacobi_eig_lds(double *S, double *V, int np, int ld, double *cs, int *flag, double *jprof = nullptr) {
-  const int tid = threadIdx.x, half = np / 2, nm1 = np - 1;
-#if defined(LIO_MARG_PROF)
-  long long tA = 0, tB1 = 0, tB = 0, tB2 = 0;
-#endif
-  // round-robin pairing of step r: index np - 1 stays, the others rotate; pair t = (r + t, r - t) mod (np - 1), pair 0 = (np - 1, r)
-  // (both sums lie in [0, 2 (np - 1)): no division; every thread derives the pairs it needs — a pair table in LDS cost a round trip)
-  auto pair_of = [&](int r, int t, int &p, int &q) {
-    p = r + t; q = r - t + nm1;
-    p = p >= nm1 ? p - nm1 : p; q = q >= nm1 ? q - nm1 : q;
-    if (t == 0) { p = nm1; q = r; }
-    if (p > q) { const int x = p; p = q; q = x; }
-  };
-  // A thread keeps ONE pair index cq = tid mod half and a row offset rp0 = tid / half:
-  //   blocks of S: pair P = cq against pair Q = cq + j (mod half), j = rp0, rp0 + rstep, ... <= half / 2 — every unordered {P, Q} once
-  //                (for even half the distance half / 2 would come twice: only P < half / 2 takes it);
-  //   eigenvectors: column pair cq of rows k = rp0, rp0 + rstep, ...
-  const int cq = tid % half, rp0 = tid / half, rstep = MARG_THREADS / half;
-  const bool worker = rp0 < rstep;
-  const int jmax = half / 2;
-  const bool even_half = (half & 1) == 0;
-  const double2 *cs2 = reinterpret_cast<const double2 *>(cs);   // (c, s) of pair t
-  int sweeps = 0;
-  for (; sweeps < 40; ++sweeps) {
-    if (tid == 0) flag[0] = 0;
-    __syncthreads();
-    for (int r = 0; r < nm1; ++r) {
-#if defined(LIO_MARG_PROF)
-      const long long c0 = clock64();
-#endif
-      if (tid < half) {   // (one wave: its stores to the step's flag are ordered)
-        if (tid == 0) flag[1] = 0;
-        int p, q;
-        pair_of(r, tid, p, q);
-        const double app = S[p * ld + p], aqq = S[q * ld + q], apq = S[p * ld + q];
-        double c = 1.0, s = 0.0;
-        // |apq| > 2.3e-16 sqrt(|app aqq|), compared in squares (an apq whose square underflows counts as zero)
-        if (fabs(apq) > 1e-300 && apq * apq > 5.29e-32 * fabs(app * aqq)) {
-          const double tau = (aqq - app) * jac_rcp(2.0 * apq);
-          const double w = __builtin_fma(tau, tau, 1.0);
-          const double t = (tau >= 0 ? 1.0 : -1.0) * jac_rcp(fabs(tau) + w * jac_rsqrt(w));
-          c = jac_rsqrt(__builtin_fma(t, t, 1.0));
-          s = t * c;
-          flag[0] = 1; flag[1] = 1;
-        }
-        cs[2 * tid] = c; cs[2 * tid + 1] = s;
+__device__ int tridiag_ql_lds(double *A, double *Z, int n, int ld, double *work, double *prof = nullptr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = MARG_THREADS / 64;
+  const long long t_in = clock64();
+  double *u = work, *praw = work + n, *zv = work + 2 * n, *cs = work + 3 * n /* 2 x 2 n */, *ee = work + 7 * n, *dd = work + 8 * n, *sc = work + 9 * n;
+  int *cmd = reinterpret_cast<int *>(sc + 4);   // 2 x (l, m, done, -)
+  for (int r = wave; r < n; r += NW)
+    for (int c = lane; c < n; c += 64) Z[r * ld + c] = r == c ? 1.0 : 0.0;
+  if (tid < n) ee[tid] = 0.0;
+  __syncthreads();
+  // ---------------- reduction to tridiagonal form, rows n - 1 .. 2
+  for (int i = n - 1; i >= 2; --i) {
+    if (wave == 0) {
+      const double *row = A + i * ld;
+      double p_all = 0.0, p_excl = 0.0;
+      for (int k = lane; k < i; k += 64) { const double x = row[k]; p_all += x * x; p_excl += (k != i - 1) ? x * x : 0.0; }
+      const double sigma = eig_wsum(p_all), excl = eig_wsum(p_excl);
+      const double f = row[i - 1];
+      if (excl == 0.0) {   // nothing left of the sub-diagonal: no reflector
+        if (lane == 0) { sc[2] = 0.0; ee[i] = f; }
+      } else {
+        const double rs = eig_rsqrt(sigma), nrm = sigma * rs, g = f > 0 ? -nrm : nrm, h = sigma - f * g;
+        for (int k = lane; k < i; k += 64) u[k] = (k == i - 1) ? f - g : row[k];
+        if (lane == 0) { sc[0] = h; sc[1] = eig_rcp(h); sc[2] = 1.0; ee[i] = g; }
       }
-#if defined(LIO_MARG_PROF)
-      const long long c1_ = clock64();
-#endif
-      __syncthreads();
-#if defined(LIO_MARG_PROF)
-      const long long c2_ = clock64();
-#endif
-      if (worker && flag[1]) {   // (a step without a rotation — the last sweep is made of them — leaves everything as it is)
-        const double2 aq = cs2[cq];
-        int pc, qc;
-        pair_of(r, cq, pc, qc);
-        // ---- blocks of S: rows of pair P = cq, columns of pair Q
-        for (int j = rp0; j <= jmax; j += rstep) {
-          if (even_half && j == jmax && cq >= jmax) break;
-          int tq = cq + j;
-          tq = tq >= half ? tq - half : tq;
-          const double2 bq = cs2[tq];
-          int p2, q2;
-          pair_of(r, tq, p2, q2);
-          const double c1 = aq.x, s1 = aq.y, c2 = bq.x, s2 = bq.y;
-          const int ra = pc * ld, rb = qc * ld;
-          const double a = S[ra + p2], b = S[ra + q2], c = S[rb + p2], d = S[rb + q2];
-          // rows pc, qc <- J_P^T (rows), then columns p2, q2 <- (columns) J_Q
-          const double a1 = __builtin_fma(c1, a, -(s1 * c)), c1r = __builtin_fma(s1, a, c1 * c), b1 = __builtin_fma(c1, b, -(s1 * d)), d1 = __builtin_fma(s1, b, c1 * d);
-          double ao = __builtin_fma(c2, a1, -(s2 * b1)), bo = __builtin_fma(s2, a1, c2 * b1), co = __builtin_fma(c2, c1r, -(s2 * d1)), dd = __builtin_fma(s2, c1r, c2 * d1);
-          if (j == 0 && s1 != 0.0) { bo = 0.0; co = 0.0; }   // the rotated pair is exactly decoupled
-          S[ra + p2] = ao; S[ra + q2] = bo; S[rb + p2] = co; S[rb + q2] = dd;
-          if (j != 0) { S[p2 * ld + pc] = ao; S[q2 * ld + pc] = bo; S[p2 * ld + qc] = co; S[q2 * ld + qc] = dd; }   // the transposed block
+    }
+    __syncthreads();
+    if (sc[2] != 0.0) {
+      {  // A u (rows < i) and Z u (all rows): four lanes per row (columns q, q + 4, ...), the quad's sum on DPP
+        // (measured and dropped, profiles/r6_g_marg_ql.txt: both passes' loads batched six columns at a time from clamped indices — the
+        // index arithmetic per load costs more issue slots than the LDS round trips it saves: 335 k -> 481 k clocks for the reduction)
+        const int q4 = tid & 3, rows_per_pass = MARG_THREADS / 4;
+        for (int rr0 = 0; rr0 < i + n; rr0 += rows_per_pass) {   // (uniform trip count: the quad moves need every lane of the wave)
+          const int rr = rr0 + (tid >> 2);
+          const bool on = rr < i + n, is_a = rr < i;
+          const int r = on ? (is_a ? rr : rr - i) : 0;
+          const double *row = (is_a ? A : Z) + r * ld;
+          double acc = 0.0;
+          for (int k = q4; k < i; k += 4) acc += row[k] * u[k];
+          acc = eig_quad_sum(acc);
+          if (on && q4 == 0) (is_a ? praw : zv)[r] = acc;
         }
-        // ---- eigenvectors: V <- V J, columns of pair cq
-        if (aq.y != 0.0) {
-          const double c2 = aq.x, s2 = aq.y;
-          for (int k0 = rp0; k0 < np; k0 += 4 * rstep) {
-            double u[4], w[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int k = k0 + e * rstep, kc = k < np ? k : rp0; u[e] = V[kc * ld + pc]; w[e] = V[kc * ld + qc]; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int k = k0 + e * rstep;
-              if (k < np) { V[k * ld + pc] = __builtin_fma(c2, u[e], -(s2 * w[e])); V[k * ld + qc] = __builtin_fma(s2, u[e], c2 * w[e]); }
-            }
+      }
+      __syncthreads();
+      {  // q = A u / h - K u with K = u^T A u / (2 h^2): every wave sums K itself (no barrier for one scalar)
+        double part = 0.0;
+        for (int k = lane; k < i; k += 64) part += u[k] * praw[k];
+        const double hinv = sc[1];
+        const double K = eig_wsum(part) * (0.5 * hinv * hinv);
+        // this lane's columns (n <= 128: two), their u and q
+        const int c0 = lane, c1 = lane + 64;
+        const bool on0 = c0 < i, on1 = c1 < i;
+        const double u0 = on0 ? u[c0] : 0.0, u1 = on1 ? u[c1] : 0.0;
+        const double q0 = on0 ? praw[c0] * hinv - K * u0 : 0.0, q1 = on1 ? praw[c1] * hinv - K * u1 : 0.0;
+        for (int r = wave; r < n; r += NW) {
+          const double zr = zv[r] * hinv;
+          const bool in_a = r < i;
+          const double ur = in_a ? u[r] : 0.0, qr = in_a ? praw[r] * hinv - K * ur : 0.0;
+          if (on0) {
+            Z[r * ld + c0] -= zr * u0;
+            if (in_a) A[r * ld + c0] -= ur * q0 + qr * u0;
+          }
+          if (on1) {
+            Z[r * ld + c1] -= zr * u1;
+            if (in_a) A[r * ld + c1] -= ur * q1 + qr * u1;
           }
         }
       }
-#if defined(LIO_MARG_PROF)
-      const long long c3_ = clock64();
-#endif
-      __syncthreads();
-#if defined(LIO_MARG_PROF)
-      const long long c4_ = clock64();
-      tA += c1_ - c0; tB1 += c2_ - c1_; tB += c3_ - c2_; tB2 += c4_ - c3_;
-#endif
     }
-    const int any = flag[0];
     __syncthreads();
-    if (!any) break;
   }
-#if defined(LIO_MARG_PROF)
-  if (jprof && tid == 0) { jprof[0] = double(tA); jprof[1] = double(tB1); jprof[2] = double(tB); jprof[3] = double(tB2); }
-#endif
-  return sweeps;
+  const long long t_red = clock64();
+  long long t_prod = 0, t_wait = 0;
+  // ---------------- implicit QL on (d, e), rotations accumulated into Z.  d and e live in LDS, touched by wave 0 only; every lane of
+  // wave 0 runs the same recurrence (reads of one address are a broadcast), lane 0 stores
+  int l = 0, m = 0, iter = 0, sweeps = 0;
+  bool in_loop = false;
+  double fsh = 0.0, tst1 = 0.0;
+  const double eps = 2.220446049250313e-16;
+  if (wave == 0) {
+    for (int k = lane; k < n; k += 64) { dd[k] = A[k * ld + k]; }
+    const double e1 = n > 1 ? A[1 * ld + 0] : 0.0;
+    eig_wave_sync();
+    // e shifted down by one (tql2: e[i - 1] = e[i]), e[n - 1] = 0; entry 1 of the reduction's e is A[1][0]
+    double sh0 = 0.0, sh1 = 0.0;
+    if (lane + 1 < n) sh0 = lane + 1 == 1 ? e1 : ee[lane + 1];
+    if (lane + 65 < n) sh1 = ee[lane + 65];
+    eig_wave_sync();
+    if (lane < n) ee[lane] = sh0;
+    if (lane + 64 < n) ee[lane + 64] = sh1;
+    eig_wave_sync();
+  }
+  // wave 0: the next sweep's rotations into cs buffer `buf`, its range into cmd[buf]
+  auto produce = [&](int buf) {
+    double *cb = cs + buf * 2 * n;
+    int *cm = cmd + buf * 4;
+    for (;;) {
+      if (!in_loop) {
+        if (l >= n) { if (lane == 0) { cm[0] = 0; cm[1] = 0; cm[2] = 1; } return; }
+        const double dl = dd[l], el = ee[l];
+        tst1 = fmax(tst1, fabs(dl) + fabs(el));
+        // first m >= l with |e_m| <= eps tst1 (e_{n-1} = 0: it exists)
+        const double thr = eps * tst1;
+        const double e_lo = lane < n ? ee[lane] : 0.0, e_hi = lane + 64 < n ? ee[lane + 64] : 0.0;
+        const unsigned long long blo = __ballot(lane >= l && lane < n && fabs(e_lo) <= thr);
+        const unsigned long long bhi = __ballot(lane + 64 >= l && lane + 64 < n && fabs(e_hi) <= thr);
+        m = blo ? __ffsll((long long)blo) - 1 : (bhi ? 64 + __ffsll((long long)bhi) - 1 : n - 1);
+        m = __builtin_amdgcn_readfirstlane(m);
+        if (m == l) {
+          if (lane == 0) { dd[l] = dl + fsh; ee[l] = 0.0; }
+          eig_wave_sync();
+          ++l; continue;
+        }
+        in_loop = true; iter = 0;
+      }
+      ++iter; ++sweeps;
+      double g = dd[l];
+      const double el = ee[l];
+      double p = (dd[l + 1] - g) * eig_rcp(2.0 * el);
+      const double w1 = __builtin_fma(p, p, 1.0);
+      double r = w1 * eig_rsqrt(w1);
+      if (p < 0) r = -r;
+      const double d_l = el * eig_rcp(p + r), dl1 = el * (p + r);
+      double h = g - d_l;
+      const double el1 = ee[l + 1];
+      const double pm = dd[m];
+      double ei = ee[m - 1], di = dd[m - 1];          // first rotation's operands (m - 1 >= l; index l + 1 > m - 1 only when m == l + 1: then di below is d[l], replaced)
+      eig_wave_sync();                                 // (every read of the old values above, before the stores below)
+      if (lane == 0) { dd[l] = d_l; dd[l + 1] = dl1; }
+      for (int k = lane; k < n; k += 64) if (k >= l + 2) dd[k] -= h;
+      eig_wave_sync();
+      fsh += h;
+      // operands read before the shift: correct them (d[m] and d[m - 1] were shifted by h when their index is >= l + 2; d[l], d[l + 1] were replaced)
+      p = (m >= l + 2) ? pm - h : (m == l + 1 ? dl1 : d_l);
+      di = (m - 1 >= l + 2) ? di - h : (m - 1 == l + 1 ? dl1 : d_l);
+      double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+      for (int i = m - 1; i >= l; --i) {
+        // the next rotation's operands, requested now (they are not written before they are used: rotation i stores e[i + 1], d[i + 1])
+        double ein = 0.0, din = 0.0;
+        if (i > l) { ein = ee[i - 1]; din = dd[i - 1]; }
+        c3 = c2; c2 = c; s2 = s;
+        g = c * ei;
+        h = c * p;
+        const double rr2 = __builtin_fma(p, p, ei * ei);
+        const double rinv = eig_rsqrt(rr2);   // (rr2 > 0: |e_i| is above the deflation threshold for l <= i < m)
+        r = rr2 * rinv;
+        const double e_up = s * r;
+        s = ei * rinv;
+        c = p * rinv;
+        p = __builtin_fma(c, di, -(s * g));
+        const double d_up = h + s * __builtin_fma(c, g, s * di);
+        if (lane == 0) { ee[i + 1] = e_up; dd[i + 1] = d_up; cb[2 * i] = c; cb[2 * i + 1] = s; }
+        ei = ein; di = din;
+      }
+      p = -s * s2 * c3 * el1 * el * eig_rcp(dl1);   // (e[l] is not written inside the sweep)
+      const double e_l = s * p, d_new = c * p;
+      const bool conv = !(fabs(e_l) > eps * tst1) || iter >= 200;   // the sweep that converged l (or the cap): close it
+      eig_wave_sync();
+      if (lane == 0) { ee[l] = conv ? 0.0 : e_l; dd[l] = conv ? d_new + fsh : d_new; cm[0] = l; cm[1] = m; cm[2] = 0; }
+      eig_wave_sync();
+      if (conv) { ++l; in_loop = false; }
+      return;
+    }
+  };
+  int buf = 0;
+  if (wave == 0) produce(0);
+  __syncthreads();
+  for (;;) {
+    if (cmd[buf * 4 + 2]) break;
+    if (wave == 0) {
+      const long long c0 = clock64();
+      produce(buf ^ 1);
+      t_prod += clock64() - c0;
+    } else {
+      const int r = tid - 64, cl = cmd[buf * 4], cm_ = cmd[buf * 4 + 1];
+      if (r < n) {
+        const double *cb = cs + buf * 2 * n;
+        double *zr = Z + r * ld;
+        double carry = zr[cm_];
+        for (int i = cm_ - 1; i >= cl; --i) {
+          const double c = cb[2 * i], s = cb[2 * i + 1], zi = zr[i];
+          zr[i + 1] = s * zi + c * carry;
+          carry = c * zi - s * carry;
+        }
+        zr[cl] = carry;
+      }
+    }
+    const long long c1 = clock64();
+    __syncthreads();
+    t_wait += clock64() - c1;
+    buf ^= 1;
+  }
+  if (wave == 0)
+    for (int k = lane; k < n; k += 64) A[k * ld + k] = dd[k];
+  __syncthreads();
+  if (prof && tid == 0) { prof[0] = double(t_red - t_in); prof[1] = double(t_prod); prof[2] = double(t_wait); prof[3] = double(clock64() - t_red); }
+  return sweeps;   // (wave 0's count; thread 0 reports it)
 }
 
 struct MargLds {
@@ -172,6 +285,7 @@ struct MargLds {
   double *ainv;       // 16 x 16
   double *T;          // n x 16
   double *bs, *ev, *w, *cs;
+  double *work;       // the eigensolver's vectors: 9 max(n, 16) + 16
   int *ord, *flag;
 };
 
@@ -192,7 +306,8 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
   L.bs = ptr; ptr += np2;
   L.ev = ptr; ptr += np2;
   L.w = ptr; ptr += np2;
-  L.cs = ptr; ptr += np2 + 16;        // (c, s) of the step's np2 / 2 rotations, 16-byte aligned
+  L.cs = ptr; ptr += np2 + 16;
+  L.work = ptr; ptr += 9 * (n > 16 ? n : 16) + 16;
   L.ord = reinterpret_cast<int *>(ptr); ptr += (np2 + 1) / 2 + 1;
   L.flag = reinterpret_cast<int *>(ptr);
 
@@ -208,7 +323,7 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
     if (i == j) L.v1[i * 17 + j] = 1.0;
   }
   __syncthreads();
-  const int sweeps1 = jacobi_eig_lds(L.a1, L.v1, 16, 17, L.cs, L.flag);
+  const int sweeps1 = tridiag_ql_lds(L.a1, L.v1, m, 17, L.work);
   stamp(2);
   for (int e = tid; e < 16 * 16; e += MARG_THREADS) {
     const int i = e >> 4, j = e & 15;
@@ -270,7 +385,7 @@ __device__ void marg_schur_body(const double *__restrict__ A, const double *__re
   }
   __syncthreads();
   stamp(3);
-  const int sweeps2 = jacobi_eig_lds(L.S, L.V, np2, ld2, L.cs, L.flag, stamps ? stamps + 8 : nullptr);
+  const int sweeps2 = tridiag_ql_lds(L.S, L.V, n, ld2, L.work, stamps ? stamps + 8 : nullptr);
   stamp(4);
   // ---- ascending eigenvalues (rank sort; ties by index), then the square-root factors
   for (int i = tid; i < n; i += MARG_THREADS) L.ev[i] = L.S[i * ld2 + i];
@@ -318,7 +433,7 @@ __global__ void __launch_bounds__(MARG_THREADS) k_marg_schur(const double *__res
 
 static size_t marg_lds_doubles(int n) {
   const int np2 = (n + 1) & ~1, ld2 = np2 + 1;
-  return size_t(2) * np2 * ld2 + 2 * 16 * 17 + 16 * 16 + size_t(n) * 16 + 3 * np2 + np2 + 16 + (np2 + 1) / 2 + 1 + 2;
+  return size_t(2) * np2 * ld2 + 2 * 16 * 17 + 16 * 16 + size_t(n) * 16 + 3 * np2 + np2 + 16 + 9 * size_t(n > 16 ? n : 16) + 16 + (np2 + 1) / 2 + 1 + 2;
 }
 static size_t marg_lds_bytes(int n) { return marg_lds_doubles(n) * sizeof(double); }
 

@@ -95,3 +95,11 @@ def test_point_processor_batch_equals_one_by_one(oracle):
     with pytest.raises(capi.LioError):
         capi.PointProcessor.process_batch([batch[0], batch[0]], [ds.frames[0].scan] * 2)
     capi.PointProcessor.process_batch([], [])          # nothing to do is not an error
+    # lio_pp_process_batch_device through the oracle: it has no device, so the "device" pointers are host memory — same results
+    again = [capi.PointProcessor(oracle, lid.lower_deg, lid.upper_deg, lid.rings) for _ in ds.frames]
+    arrs = [np.ascontiguousarray(f.scan, np.float32) for f in ds.frames]
+    capi.PointProcessor.process_batch_device(again, [a.ctypes.data for a in arrs], [a.shape[0] for a in arrs])
+    for a, b in zip(again, single):
+        for which in range(5):
+            np.testing.assert_array_equal(a.cloud(which), b.cloud(which))
+        np.testing.assert_array_equal(a.indices(2)[1], b.indices(2)[1])

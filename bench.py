@@ -699,6 +699,13 @@ def main():
     # N > 1: the two modes with a real exchange step, measured in the same run on every rank (collective), reported by rank 0 in
     # the same line.  They come LAST and under a watchdog: if a rank fails or a collective never completes, rank 0 still prints the
     # line it has (the weak-scaling measurement) with the failure noted, instead of hanging the whole run.
+    if rank == 0 and thr is None and world == 1 and isinstance(out.get("batched"), dict) and out["batched"].get("points"):
+        # N = 1: the same throughput mode as the N > 1 line's value, from the `batched` extra at --rank-windows windows — the figure an
+        # N-GPU `value` is to be compared with (the headline here stays the single window: SURVEY.md 8(d)(i))
+        pt = [p for p in out["batched"]["points"] if p.get("windows") == args.rank_windows] or [out["batched"]["points"][-1]]
+        out["throughput_mode"] = {"windows_per_rank": pt[0].get("windows"), "ranks": 1, "value": pt[0].get("value"), "unit": "solves/s", "ms_per_step": pt[0].get("ms_per_batch_step"),
+                                  "parity": pt[0].get("parity"), "note": "lio_est_batch, the mode `bench.py --gpus N` (N > 1) reports as its `value`: compare an N-GPU value with N x this; details in batched.points"}
+        out["single_window"] = {"value": out["value"], "unit": "solves/s", "ms_per_step": out["ms_per_step"], "note": "the line's value at N = 1: one latency-bound window"}
     if rank == 0 and thr is not None:
         # N > 1: the throughput mode leads the line; the N one-window-per-rank figure measured above stays beside it
         out["single_window"] = {"value": out["value"], "unit": "solves/s", "ms_per_step": out["ms_per_step"], "timing": out["timing"],

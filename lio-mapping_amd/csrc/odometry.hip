@@ -102,46 +102,68 @@ __global__ void __launch_bounds__(64) k_odo_corr(OdoArgs a, const OdomState *__r
     const int cs = int(cloud[closest].w);
     float d2 = 25.f, d3 = 25.f;     // best "second" / "third" squared distances so far
     int k2 = INT_MAX, k3 = INT_MAX;  // their scan-order keys
-    // upward scan, chunks of 64; scan-order key = j - closest (1, 2, ...)
-    for (int base = closest + 1; base < n; base += 64) {
-      int j = base + lane;
-      bool in = j < n;
-      int ring = in ? int(cloud[j].w) : INT_MAX;
-      bool viol = in && (double(ring) > double(cs) + 2.5);
-      unsigned long long vm = __ballot(viol);
-      int first_viol = vm ? (__ffsll((long long)vm) - 1) : 64;
-      if (in && lane < first_viol) {
-        float d = odo_sqdiff(cloud[j], sel);
-        int key = j - closest;
-        if (corner) {
-          if (ring > cs && (d < d2 || (d == d2 && key < k2 && d < 25.f))) { d2 = d; k2 = key; }
-        } else {
-          if (ring <= cs) { if (d < d2 || (d == d2 && key < k2 && d < 25.f)) { d2 = d; k2 = key; } }
-          else { if (d < d3 || (d == d3 && key < k3 && d < 25.f)) { d3 = d; k3 = key; } }
+    // The two window scans walk up to 2.5 rings (~1 500 points of an HDL-64E sweep) in chunks of 64.  A chunk's decision to go on depends
+    // on its rings, but its LOADS do not: four chunks' points are requested together and then examined in scan order, stopping at the
+    // first ring violation as before (one memory round trip per 256 candidates instead of one per 64: the scan was a chain of ~48
+    // dependent L2 round trips per query).
+    // upward scan; scan-order key = j - closest (1, 2, ...)
+    for (int base4 = closest + 1; base4 < n; base4 += 256) {
+      float4 pj[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int j = base4 + 64 * q + lane; pj[q] = cloud[j < n ? j : n - 1]; }
+      bool stop = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (stop || base4 + 64 * q >= n) continue;   // (uniform)
+        const int j = base4 + 64 * q + lane;
+        const bool in = j < n;
+        const int ring = in ? int(pj[q].w) : INT_MAX;
+        const bool viol = in && (double(ring) > double(cs) + 2.5);
+        const unsigned long long vm = __ballot(viol);
+        const int first_viol = vm ? (__ffsll((long long)vm) - 1) : 64;
+        if (in && lane < first_viol) {
+          const float d = odo_sqdiff(pj[q], sel);
+          const int key = j - closest;
+          if (corner) {
+            if (ring > cs && (d < d2 || (d == d2 && key < k2 && d < 25.f))) { d2 = d; k2 = key; }
+          } else {
+            if (ring <= cs) { if (d < d2 || (d == d2 && key < k2 && d < 25.f)) { d2 = d; k2 = key; } }
+            else { if (d < d3 || (d == d3 && key < k3 && d < 25.f)) { d3 = d; k3 = key; } }
+          }
         }
+        if (vm) stop = true;
       }
-      if (vm) break;
+      if (stop) break;
     }
     // downward scan; keys continue after every possible upward key
     const int KOFF = 1 << 24;
-    for (int base = closest - 1; base >= 0; base -= 64) {
-      int j = base - lane;
-      bool in = j >= 0;
-      int ring = in ? int(cloud[j].w) : INT_MIN;
-      bool viol = in && (double(ring) < double(cs) - 2.5);
-      unsigned long long vm = __ballot(viol);
-      int first_viol = vm ? (__ffsll((long long)vm) - 1) : 64;
-      if (in && lane < first_viol) {
-        float d = odo_sqdiff(cloud[j], sel);
-        int key = KOFF + (closest - j);
-        if (corner) {
-          if (ring < cs && (d < d2 || (d == d2 && key < k2 && d < 25.f))) { d2 = d; k2 = key; }
-        } else {
-          if (ring >= cs) { if (d < d2 || (d == d2 && key < k2 && d < 25.f)) { d2 = d; k2 = key; } }
-          else { if (d < d3 || (d == d3 && key < k3 && d < 25.f)) { d3 = d; k3 = key; } }
+    for (int base4 = closest - 1; base4 >= 0; base4 -= 256) {
+      float4 pj[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int j = base4 - 64 * q - lane; pj[q] = cloud[j >= 0 ? j : 0]; }
+      bool stop = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (stop || base4 - 64 * q < 0) continue;   // (uniform)
+        const int j = base4 - 64 * q - lane;
+        const bool in = j >= 0;
+        const int ring = in ? int(pj[q].w) : INT_MIN;
+        const bool viol = in && (double(ring) < double(cs) - 2.5);
+        const unsigned long long vm = __ballot(viol);
+        const int first_viol = vm ? (__ffsll((long long)vm) - 1) : 64;
+        if (in && lane < first_viol) {
+          const float d = odo_sqdiff(pj[q], sel);
+          const int key = KOFF + (closest - j);
+          if (corner) {
+            if (ring < cs && (d < d2 || (d == d2 && key < k2 && d < 25.f))) { d2 = d; k2 = key; }
+          } else {
+            if (ring >= cs) { if (d < d2 || (d == d2 && key < k2 && d < 25.f)) { d2 = d; k2 = key; } }
+            else { if (d < d3 || (d == d3 && key < k3 && d < 25.f)) { d3 = d; k3 = key; } }
+          }
         }
+        if (vm) stop = true;
       }
-      if (vm) break;
+      if (stop) break;
     }
     wave_argmin(d2, k2);
     if (k2 != INT_MAX && d2 < 25.f) second = k2 < KOFF ? closest + k2 : closest - (k2 - KOFF);

@@ -90,7 +90,9 @@ int lio_pp_wait(lio_pp *);
  * HDL-64 sweep fills 64 of the 256 compute units in the pick stage), and one copy brings all counts back.  Every handle then answers
  * the accessors below for ITS sweep, bit for bit what lio_pp_process gives (the same kernels: one sweep is the B = 1 case); with
  * infer_start_ori a sweep's start azimuth goes through its own handle's ten-sweep history.  The results live in storage the handles of
- * the call share until a handle's next process call: read them from one thread at a time.  Handles that differ in their arguments (or
+ * the call share until a handle's next process call: read them from one thread at a time; a later batch call that reuses the storage for
+ * OTHER handles (it is kept by the first handle of a call) invalidates them — the accessors of a handle left out then return
+ * LIO_ERR_STATE (counts 0) instead of another sweep's data.  Handles that differ in their arguments (or
  * B = 1) run lio_pp_process_async on every handle, then lio_pp_wait on every handle; the first failing code is returned after all
  * handles have been waited for.  A handle may appear once. */
 int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps);

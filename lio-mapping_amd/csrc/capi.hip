@@ -26,8 +26,10 @@ struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<Ma
 struct lio_est_batch { std::unique_ptr<EstimatorBatch> b; std::vector<lio_est *> members; };
 // lio_pp_process_batch runs its sweeps through ONE multi-sweep processor shared by the handles of the call (`pool`); a handle whose last
 // sweep went that way reads its results from sweep `pool_sweep` of it.  The pool is shared state: its users take `mu`.
-struct lio_pp_pool { PointProcessorDev pp; std::mutex mu; lio_pp_pool(float lo, float up, int r, const lio_pp_config &c) : pp(lo, up, r, c) {} };
-struct lio_pp { std::unique_ptr<PointProcessorDev> pp; std::shared_ptr<lio_pp_pool> pool; int pool_sweep = -1; };
+// `gen` counts the pool's batches: a handle whose results a LATER batch of other handles overwrote (same pool, its own sweep not among them)
+// is told so instead of being handed somebody else's sweep.
+struct lio_pp_pool { PointProcessorDev pp; std::mutex mu; unsigned long gen = 0; lio_pp_pool(float lo, float up, int r, const lio_pp_config &c) : pp(lo, up, r, c) {} };
+struct lio_pp { std::unique_ptr<PointProcessorDev> pp; std::shared_ptr<lio_pp_pool> pool; int pool_sweep = -1; unsigned long pool_gen = 0; };
 struct lio_odom { std::unique_ptr<OdometryDev> o; };
 struct lio_map { std::unique_ptr<MappingDev> m; };
 
@@ -57,6 +59,7 @@ template <typename F> static int pp_read(const lio_pp *h, F &&f) {
   return guarded([&] {
     if (h->pool && h->pool_sweep >= 0) {
       std::lock_guard<std::mutex> lk(h->pool->mu);
+      if (h->pool_gen != h->pool->gen) throw std::runtime_error("lio_pp: this handle's batch results were overwritten by a later lio_pp_process_batch on the storage it shared");
       h->pool->pp.ProcessFinish();
       h->pool->pp.SelectSweep(h->pool_sweep);
       f(h->pool->pp);
@@ -153,12 +156,13 @@ static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, co
         pool = std::make_shared<lio_pp_pool>(a.lower(), a.upper(), a.rings(), a.config());
       }
       std::vector<StartOriFilter *> filters(static_cast<size_t>(n_sweeps));
+      std::lock_guard<std::mutex> lk(pool->mu);
+      ++pool->gen;
       for (int k = 0; k < n_sweeps; ++k) {
         handles[k]->pp->ProcessFinish();
-        handles[k]->pool = pool; handles[k]->pool_sweep = k;
+        handles[k]->pool = pool; handles[k]->pool_sweep = k; handles[k]->pool_gen = pool->gen;
         filters[size_t(k)] = &handles[k]->pp->start_ori_filter();
       }
-      std::lock_guard<std::mutex> lk(pool->mu);
       pool->pp.ProcessLaunchBatch(xyzi, nullptr, n, n_sweeps, on_device, filters.data());
       pool->pp.ProcessFinish();
       return LIO_OK;

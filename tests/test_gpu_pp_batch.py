@@ -68,6 +68,16 @@ def test_one_chain_equals_one_by_one(hip, hdl_sweeps):
         for a, b, x in zip(batch, single, ins):
             _same(a, b, start_ori=x.shape[0] > 0)     # (an empty sweep alone keeps the handle's last start azimuth, as the reference's member does; in a batch it reads NaN)
             assert a.cloud(0).shape[0] == (0 if x.shape[0] == 0 else b.cloud(0).shape[0])
+    # a later batch that reuses the shared storage without one of the earlier handles: that handle is told so (no other sweep's data)
+    capi.PointProcessor.process_batch([batch[0], batch[2]], [sweeps[0], sweeps[1]])
+    assert batch[3].cloud(0).shape[0] == 0
+    with pytest.raises(capi.LioError):
+        batch[3].ring_offsets()
+    batch[3].process(sweeps[3])
+    single[3].process(sweeps[3])
+    _same(batch[3], single[3])
+    single[0].process(sweeps[0]); single[2].process(sweeps[1])
+    _same(batch[0], single[0]); _same(batch[2], single[2])
     # a handle of the batch used on its own again answers for its own sweep
     batch[1].process(sweeps[2])
     single[1].process(sweeps[2])

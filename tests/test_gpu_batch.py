@@ -86,8 +86,11 @@ def test_every_window_of_a_batch_equals_the_window_alone(hip):
     batch.close()
 
 
-@pytest.mark.parametrize("kind,W,Wo,frame_dt", [("indoor", 4, 2, 0.2), ("outdoor", 6, 3, 0.3)])
-def test_batch_matches_the_oracle(hip, oracle, kind, W, Wo, frame_dt):
+# (10 / 6: the largest problem the device loop takes — 111 unknowns in a 112 x 112 H in LDS, a 51-column prior.  12 / 7: the reference's
+# indoor_test_config.yaml — 126 unknowns do not fit the LDS-resident factorisation: the batch solves such windows by the single-window
+# path inside the same call, same parity bar)
+@pytest.mark.parametrize("kind,W,Wo,frame_dt,min_device", [("indoor", 4, 2, 0.2, 4), ("outdoor", 6, 3, 0.3, 4), ("indoor", 10, 6, 0.2, 4), ("indoor", 12, 7, 0.2, 0)])
+def test_batch_matches_the_oracle(hip, oracle, kind, W, Wo, frame_dt, min_device):
     """Two windows of one batch (the same scene from two perturbed starts) against two oracle estimators, teacher-forced before
     every step (states, extrinsic, prior): equal convergence flags and iteration counts, windows within 1e-4 m / 1e-4 rad on every
     step, the priors each side produced itself within 1e-6 relative."""
@@ -124,7 +127,9 @@ def test_batch_matches_the_oracle(hip, oracle, kind, W, Wo, frame_dt):
                 assert_priors_close(ea, eb, a, b, rel_floor=1e-5)
             ea.slide(); eb.slide()
     print(f"batch vs oracle ({kind} {W}/{Wo}): worst |dP| over the teacher-forced steps {worst:.2e} m; {on_device} window-solves on the device loop")
-    assert on_device >= 4
+    assert on_device >= min_device
+    if min_device == 0:
+        assert on_device == 0          # (every solve of these windows went through the single-window path)
     batch.close()
 
 

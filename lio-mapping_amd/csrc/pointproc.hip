@@ -858,6 +858,10 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   // nothing to do: every count reads zero; the start azimuth stays the last sweep's, as the reference's member does (PointProcessor.cc:261-264)
   last_empty_ = (B <= 0 || n_max == 0);
   if (last_empty_) return;
+  bool any_ring = false;
+  for (int k = 0; k < B; ++k) any_ring = any_ring || (ring && ring[k] && n[k]);
+  for (int k = 0; k < B && any_ring; ++k)
+    if (n[k] && !ring[k]) throw std::runtime_error("PointProcessor: a batch mixes sweeps with and without a ring field");
   in_flight_ = true;
   nsw_ = B; sel_ = 0;
   n_sw_.assign(n, n + B);
@@ -865,7 +869,8 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   ReserveHost(B);
   const size_t stride = (n_max + PP_BIN_THREADS - 1) / PP_BIN_THREADS * PP_BIN_THREADS, tot = stride * size_t(B);
   pts_stride_ = stride;
-  in_.reserve(tot); ring_cloud_.reserve(tot); ring_intensity_.reserve(tot); azi_.reserve(tot); curv_.reserve(tot); mask_.reserve(tot); label_.reserve(tot);
+  if (!on_device) in_.reserve(tot);   // (sweeps that already lie in device memory are read where they are)
+  ring_cloud_.reserve(tot); ring_intensity_.reserve(tot); azi_.reserve(tot); curv_.reserve(tot); mask_.reserve(tot); label_.reserve(tot);
   keys_.reserve(tot); less_flat_.reserve(tot); lf_tmp_.reserve(tot);
   const int nblocks = int(stride / PP_BIN_THREADS);
   ring_table_.reserve(size_t(B) * rings_ * nblocks); ring_total_.reserve(size_t(B) * LIO_PP_MAX_RINGS); lf_ring_count_.reserve(size_t(B) * LIO_PP_MAX_RINGS);
@@ -886,7 +891,6 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   static const bool dbg = std::getenv("LIO_DEBUG_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   const hipMemcpyKind up = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  bool any_ring = false;
   const float4 *const *d_in_table = nullptr;
   if (on_device) {
     // the two kernels that read the input take it where it lies: one table of B pointers goes up instead of B device-to-device copies
@@ -897,7 +901,6 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   }
   for (int k = 0; k < B; ++k) {
     if (n[k] && !on_device) LIO_HIP(hipMemcpyAsync(in_.p + size_t(k) * stride, xyzi[k], n[k] * sizeof(float4), up, s));
-    if (ring && ring[k]) any_ring = true;
   }
   if (dbg) {
     LIO_HIP(hipStreamSynchronize(s));
@@ -908,7 +911,7 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   const int *d_n = nullptr;
   if (B > 1) {
     d_n_.reserve(B);
-    int *h_n = h_state_;   // (the landing zone is idle until the chain's last copy; the upload below reads it before that copy is enqueued ... by stream order)
+    int *h_n = h_state_;   // (staged in the landing zone, which nothing else touches before this upload has run: the chain's later copies follow it on the stream)
     for (int k = 0; k < B; ++k) h_n[k] = int(n[k]);
     LIO_HIP(hipMemcpyAsync(d_n_.p, h_n, size_t(B) * sizeof(int), hipMemcpyHostToDevice, s));
     d_n = d_n_.p;
@@ -918,10 +921,8 @@ void PointProcessorDev::ProcessLaunchBatch(const float *const *xyzi, const uint1
   const uint16_t *d_ring = nullptr;
   if (any_ring) {
     ring_in_.reserve(tot);
-    for (int k = 0; k < B; ++k) {
-      if (!ring[k] && n[k]) throw std::runtime_error("PointProcessor: a batch mixes sweeps with and without a ring field");
+    for (int k = 0; k < B; ++k)
       if (n[k]) LIO_HIP(hipMemcpyAsync(ring_in_.p + size_t(k) * stride, ring[k], n[k] * sizeof(uint16_t), up, s));
-    }
     // end_ori_ = 0 (:439): k_pp_init
     d_ring = ring_in_.p;
   }

@@ -104,6 +104,9 @@ int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *d_xy
  * PointProcessor.cc:428-536): the ring of each point comes from its `ring` field (points whose ring is outside
  * [0, rings) are dropped) and rel_time = scan_period * (unwrapped azimuth - start_ori) / (end_ori - start_ori). */
 int lio_pp_process_rings(lio_pp *, const float *xyzi, const uint16_t *ring, size_t n);
+/* lio_pp_process_batch with that overload: B sweeps of ring-field sensors (ring[k]: one ring per point of sweep k) through one launch
+ * chain; same rules as lio_pp_process_batch. */
+int lio_pp_process_rings_batch(lio_pp *const *handles, const float *const *xyzi, const uint16_t *const *ring, const size_t *n, int n_sweeps);
 /* start_ori_ the last process call used (after the inference when infer_start_ori is set); NaN before the first call */
 float lio_pp_start_ori(const lio_pp *);
 size_t lio_pp_count(const lio_pp *, int which);

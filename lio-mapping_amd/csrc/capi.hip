@@ -137,11 +137,12 @@ int lio_pp_wait(lio_pp *h) {
   if (!h) return LIO_ERR_ARG;
   return guarded([&] { h->pp->ProcessFinish(); return LIO_OK; });
 }
-static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps, bool on_device) {
+static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps, bool on_device,
+                            const uint16_t *const *ring = nullptr) {
   if (n_sweeps < 0 || (n_sweeps > 0 && (!handles || !xyzi || !n))) return LIO_ERR_ARG;
   bool same = true;
   for (int k = 0; k < n_sweeps; ++k) {
-    if (!handles[k] || (!xyzi[k] && n[k])) return LIO_ERR_ARG;
+    if (!handles[k] || (!xyzi[k] && n[k]) || (ring && !ring[k] && n[k])) return LIO_ERR_ARG;
     for (int j = 0; j < k; ++j) if (handles[j] == handles[k]) return LIO_ERR_ARG;
     same = same && handles[k]->pp->SameSensor(*handles[0]->pp);
   }
@@ -163,7 +164,7 @@ static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, co
         handles[k]->pool = pool; handles[k]->pool_sweep = k; handles[k]->pool_gen = pool->gen;
         filters[size_t(k)] = &handles[k]->pp->start_ori_filter();
       }
-      pool->pp.ProcessLaunchBatch(xyzi, nullptr, n, n_sweeps, on_device, filters.data());
+      pool->pp.ProcessLaunchBatch(xyzi, ring, n, n_sweeps, on_device, filters.data());
       pool->pp.ProcessFinish();
       return LIO_OK;
     });
@@ -175,7 +176,7 @@ static int pp_process_batch(lio_pp *const *handles, const float *const *xyzi, co
     h->pool_sweep = -1;
     rc = guarded([&] {
       StartOriFilter *f = &h->pp->start_ori_filter();
-      h->pp->ProcessLaunchBatch(&xyzi[launched], nullptr, &n[launched], 1, on_device, &f);
+      h->pp->ProcessLaunchBatch(&xyzi[launched], ring ? &ring[launched] : nullptr, &n[launched], 1, on_device, &f);
       return LIO_OK;
     });
   }
@@ -188,6 +189,10 @@ int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const
 }
 int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *d_xyzi, const size_t *n, int n_sweeps) {
   return pp_process_batch(handles, d_xyzi, n, n_sweeps, true);
+}
+int lio_pp_process_rings_batch(lio_pp *const *handles, const float *const *xyzi, const uint16_t *const *ring, const size_t *n, int n_sweeps) {
+  if (n_sweeps > 0 && !ring) return LIO_ERR_ARG;
+  return pp_process_batch(handles, xyzi, n, n_sweeps, false, ring);
 }
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;

@@ -145,6 +145,7 @@ _SIGS = {
     "lio_pp_process_async": (C.c_int, [C.c_void_p, c_float_p, C.c_size_t]),
     "lio_pp_process_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_float_p), C.POINTER(C.c_size_t), C.c_int]),
     "lio_pp_process_batch_device": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+    "lio_pp_process_rings_batch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(c_float_p), C.POINTER(c_uint16_p), C.POINTER(C.c_size_t), C.c_int]),
     "lio_pp_wait": (C.c_int, [C.c_void_p]),
     "lio_pp_start_ori": (C.c_float, [C.c_void_p]),
     "lio_pp_count": (C.c_size_t, [C.c_void_p, C.c_int]),
@@ -522,6 +523,21 @@ class PointProcessor:
         ptrs = (c_float_p * B)(*[_fp(a) for a in arrs])
         ns = (C.c_size_t * B)(*[a.shape[0] for a in arrs])
         _chk(processors[0].lib.dll.lio_pp_process_batch(hs, ptrs, ns, B), "lio_pp_process_batch")
+
+    @staticmethod
+    def process_rings_batch(processors, sweeps, rings):
+        """lio_pp_process_rings_batch: the PointIR overload (a ring per point) for B sweeps in one call."""
+        B = len(processors)
+        assert B == len(sweeps) == len(rings)
+        if B == 0:
+            return
+        arrs = [_f32(x).reshape(-1, 4) for x in sweeps]
+        rgs = [np.ascontiguousarray(r, dtype=np.uint16) for r in rings]
+        hs = (C.c_void_p * B)(*[p.h for p in processors])
+        ptrs = (c_float_p * B)(*[_fp(a) for a in arrs])
+        rptrs = (c_uint16_p * B)(*[r.ctypes.data_as(c_uint16_p) for r in rgs])
+        ns = (C.c_size_t * B)(*[a.shape[0] for a in arrs])
+        _chk(processors[0].lib.dll.lio_pp_process_rings_batch(hs, ptrs, rptrs, ns, B), "lio_pp_process_rings_batch")
 
     @staticmethod
     def process_batch_device(processors, device_ptrs, counts):

@@ -78,6 +78,15 @@ int lio_pp_process_batch(lio_pp *const *handles, const float *const *xyzi, const
 int lio_pp_process_batch_device(lio_pp *const *handles, const float *const *xyzi, const size_t *n, int n_sweeps) {
   return lio_pp_process_batch(handles, xyzi, n, n_sweeps);   // (no device here: the pointers are host memory)
 }
+int lio_pp_process_rings_batch(lio_pp *const *handles, const float *const *xyzi, const uint16_t *const *ring, const size_t *n, int n_sweeps) {
+  if (n_sweeps < 0 || (n_sweeps > 0 && (!handles || !xyzi || !ring || !n))) return LIO_ERR_ARG;
+  for (int k = 0; k < n_sweeps; ++k) {
+    if (!handles[k] || ((!xyzi[k] || !ring[k]) && n[k])) return LIO_ERR_ARG;
+    for (int j = 0; j < k; ++j) if (handles[j] == handles[k]) return LIO_ERR_ARG;
+  }
+  for (int k = 0; k < n_sweeps; ++k) handles[k]->pp.Process(xyzi[k], n[k], ring[k]);
+  return LIO_OK;
+}
 int lio_pp_process_rings(lio_pp *h, const float *xyzi, const uint16_t *ring, size_t n) {
   if (!h || ((!xyzi || !ring) && n)) return LIO_ERR_ARG;
   h->pp.Process(xyzi, n, ring);

@@ -131,6 +131,36 @@ def test_one_chain_follows_the_reference(hip, oracle, case):
             np.testing.assert_array_equal(hs[j].indices(which)[1], orc.indices(which)[1])
 
 
+RING = [c for c in cases() if any(r is not None for _, r in c[3])]
+
+
+@pytest.mark.parametrize("case", RING, ids=[c[0] for c in RING])
+def test_one_chain_of_ring_field_sweeps_follows_the_reference(hip, oracle, case):
+    """lio_pp_process_rings_batch: the PointIR overload of PointToRing (PointProcessor.cc:428-536; the two ring-field cases of the reference
+    digests) for three sweeps in one chain — the case's sweep, the same sweep cut short, the sweep again: equal to single calls bit for
+    bit, and to the oracle / the reference's digests like the single-sweep test."""
+    name, lid, over, sweeps = case
+    over = {k: v for k, v in over.items() if k != "uneven"}
+    scan, ring = sweeps[0]
+    m = scan.shape[0] * 3 // 4
+    ins = [(scan, ring), (scan[:m].copy(), ring[:m].copy()), (scan, ring)]
+    hs = [_pp(hip, lid, **over) for _ in ins]
+    single = [_pp(hip, lid, **over) for _ in ins]
+    capi.PointProcessor.process_rings_batch(hs, [s for s, _ in ins], [r for _, r in ins])
+    for h, (s, r) in zip(single, ins):
+        h.process(s, r)
+    for a, b in zip(hs, single):
+        _same(a, b)
+    orc = _pp(oracle, lid, **over)
+    orc.process(scan, ring)
+    for c, w in zip(CLOUDS, ORDER):
+        a, b = hs[2].cloud(w), orc.cloud(w)
+        assert digest(b) == GOLD[name][0][c]
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(a[:, :3], b[:, :3])
+        np.testing.assert_allclose(a[:, 3], b[:, 3], atol=8e-6)
+
+
 def test_one_chain_keeps_every_handles_start_azimuth_history(hip, oracle):
     """infer_start_ori (PointProcessor.cc:348-387) in a batch: three sensors, each with its own ten-sweep history, 24 rounds of one batch
     call; sensor j sees the reference case's sweeps shifted by 5 j.  Equal to three handles fed one call at a time, bit for bit, and

@@ -43,7 +43,7 @@ struct BatchGrid { GridDesc g; int cell_off; int n_filtered; };
 struct BatchKnobs {
   int lanes_per_query = 0;   // 1 / 2 / 4 / 8 lanes per query of the search kernels (LIO_BW_LPQ); by size: 1 from 100 k queries, 4 from 15 k, else 8
   int occupancy = -1;        // 0 / 6 / 8 waves per SIMD of the one-lane-per-query kernels (LIO_BW_OCC); by default features 8, rounds as compiled
-  int loop_groups = 0;       // 1 .. 4 launch chains of the trust-region loop side by side (LIO_BW_GROUPS); by size: 2 from 32 windows
+  int loop_groups = 0;       // 1 .. 4 launch chains of the trust-region loop side by side (LIO_BW_GROUPS); by size: 4 from 32 windows, 2 from 256
   int aux_threads = 0;       // 64 / 128 / 256 threads per block of the aux row (LIO_BW_AUX_THREADS); by size: 64 from 128 windows per launch
   int aux_stream = 0;        // 1: the aux row on a side stream (LIO_BW_AUX_STREAM; measured slower)
   int finish_threads = 0;    // 1 .. 8 host threads of the write-back; by size: 4 from 128 windows

@@ -90,9 +90,9 @@ class EstimatorBatch {
   // overlaps the next solve's filter, features and rounds.
   static constexpr int kGroups = 4;
   // (LIO_BW_AUX_STREAM=1, an experiment kept for re-measurement: the aux row of an iteration on a side stream beside the moments pass.)
-  hipStream_t stream_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_aux_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, stream_marg_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_aux_[kGroups] = {nullptr, nullptr, nullptr, nullptr},
-             ev_step_[kGroups] = {nullptr, nullptr, nullptr, nullptr}, ev_marg_ = nullptr;
+  hipStream_t stream_grp_[kGroups] = {}, stream_aux_[kGroups] = {}, stream_marg_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_grp_[kGroups] = {}, ev_aux_[kGroups] = {},
+             ev_step_[kGroups] = {}, ev_marg_ = nullptr;
   bool marg_in_flight_ = false;
   BatchKnobs knobs_;
   std::vector<char> ok_;

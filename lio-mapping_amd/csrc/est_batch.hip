@@ -508,54 +508,70 @@ int EstimatorBatch::Solve(lio_solve_report *reps) {
   if (n_dev > 0) {
     // iteration k evaluates candidate k (k = 0: the initial point); a window that is done costs its blocks one load each.
     // Groups of windows run their chains side by side (see est_batch.h); one group below 32 windows.
-    const int G = knobs_.loop_groups ? std::min(knobs_.loop_groups, B) : (B >= 32 ? 2 : 1);   // measured at 64 windows (profiles/r5_b_groups.txt): one chain 3.53 ms, two 2.93, four 5.14 (they share hardware queues)
+    // Groups by size, measured with the interleaved enqueue below (profiles/r6_m_loop_groups.txt; loop ms at 1 / 2 / 4 / 8 groups): 32 windows
+    // 1.86 / 1.84 / 1.78 / 1.79, 64: 2.51 / 2.10 / 2.08 / 2.15, 128: 3.46 / 3.23 / 2.77 / 3.21 (four chains = four hardware queues), 256: 5.60 /
+    // 5.05 / 5.28 / 5.04, 512: 10.3 / 9.6 / 9.6 / 9.6.
+    const int G = knobs_.loop_groups ? std::min(knobs_.loop_groups, B) : (B >= 32 ? (B < 256 ? 4 : 2) : 1);
     // knobs_.aux_stream: the aux row on a side stream beside the moments.  Measured slower on the MI355X (two events per iteration cost
     // more than the 41 us they hide: loop 2.92 ms against 2.68 at 64 windows, profiles/r5_e_aux_stream_ab_and_step_phases.txt): off.
     const BatchBases bases{slab_.p, partials_.p, d_st_.p, d_pb_.p, d_mg_.p};
     const bool side_aux = knobs_.aux_stream != 0;
     static const int prof_it = [] { const char *e = std::getenv("LIO_DEBUG_TIMING_IT"); return e ? std::atoi(e) : 3; }();
     if (G > 1 || side_aux) LIO_HIP(hipEventRecord(ev_fork_, s));
+    // The groups' chains are enqueued INTERLEAVED, iteration by iteration: a group's chain is 3 x (max_iterations + 1) launches, ~130 us of
+    // host enqueue time — enqueued one whole chain after the other, group g started that much behind group g - 1 and the loop ended that
+    // much later (at 64 windows the loop is one chain's latency, not throughput).
+    struct Grp { int w0, w1, bpf, wo, npad, it, n; hipStream_t sg, sa; };
+    Grp grp[kGroups];
+    int it_max = 0;
     for (int g = 0; g < G; ++g) {
-      const int w0 = int((long long)B * g / G), w1 = int((long long)B * (g + 1) / G);
-      hipStream_t sg = G > 1 ? stream_grp_[g] : s, sa = stream_aux_[g];
-      if (G > 1) LIO_HIP(hipStreamWaitEvent(sg, ev_fork_, 0));
-      int g_bpf = 1, g_wo = 1, g_npad = DS_NB, g_it = 0, g_n = 0;
-      for (int w = w0; w < w1; ++w) {
+      Grp &q = grp[g];
+      q.w0 = int((long long)B * g / G); q.w1 = int((long long)B * (g + 1) / G);
+      q.sg = G > 1 ? stream_grp_[g] : s; q.sa = stream_aux_[g];
+      if (G > 1) LIO_HIP(hipStreamWaitEvent(q.sg, ev_fork_, 0));
+      q.bpf = 1; q.wo = 1; q.npad = DS_NB; q.it = 0; q.n = 0;
+      for (int w = q.w0; w < q.w1; ++w) {
         if (!win_[w].device) continue;
         const Estimator *e = win_[w].e;
-        g_bpf = std::max(g_bpf, win_[w].bpf); g_wo = std::max(g_wo, e->Wo_); g_npad = std::max(g_npad, h_pb_[w].n_pad);
-        g_it = std::max(g_it, e->cfg_.max_num_iterations); ++g_n;
+        q.bpf = std::max(q.bpf, win_[w].bpf); q.wo = std::max(q.wo, e->Wo_); q.npad = std::max(q.npad, h_pb_[w].n_pad);
+        q.it = std::max(q.it, e->cfg_.max_num_iterations); ++q.n;
       }
-      if (g_n > 0)
-        for (int k = 0; k <= g_it; ++k) {
-          const BatchSolve *gb = d_bs_.p + w0;
-          if (side_aux) {   // aux row beside the moments; the step kernel joins the two
-            LIO_HIP(hipStreamWaitEvent(sa, k == 0 ? ev_fork_ : ev_step_[g], 0));
-            launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sa);
-            LIO_HIP(hipEventRecord(ev_aux_[g], sa));
-            launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
-            LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
-            launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
-            if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
-          } else if (knobs_.time_kernels) {   // measurement run: the three launches bracketed by events on their stream
-            while (ev_k_.size() < size_t(ev_k_used_ + 4)) { hipEvent_t e = nullptr; LIO_HIP(hipEventCreate(&e)); ev_k_.push_back(e); }
-            hipEvent_t *ek = ev_k_.data() + ev_k_used_;
-            ev_k_used_ += 4;
-            LIO_HIP(hipEventRecord(ek[0], sg));
-            launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sg);
-            LIO_HIP(hipEventRecord(ek[1], sg));
-            launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
-            LIO_HIP(hipEventRecord(ek[2], sg));
-            launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
-            LIO_HIP(hipEventRecord(ek[3], sg));
-          } else {
-            launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, knobs_.aux_threads, valid_all_.p, coef_all_.p, sg);
-          }
-          if (h_bs_[0].prof && w0 == 0 && k == prof_it)   // LIO_DEBUG_TIMING: keep the stamps of this iteration's launch B beside the last one's
-            LIO_HIP(hipMemcpyAsync(h_bs_[0].prof + 32, h_bs_[0].prof, 32 * sizeof(long long), hipMemcpyDeviceToDevice, sg));
-        }
-      if (G > 1) { LIO_HIP(hipEventRecord(ev_grp_[g], sg)); LIO_HIP(hipStreamWaitEvent(s, ev_grp_[g], 0)); }
+      if (q.n > 0) it_max = std::max(it_max, q.it);
     }
+    for (int k = 0; k <= it_max; ++k)
+      for (int g = 0; g < G; ++g) {
+        const Grp &q = grp[g];
+        if (q.n == 0 || k > q.it) continue;
+        const int w0 = q.w0, w1 = q.w1, g_bpf = q.bpf, g_wo = q.wo, g_npad = q.npad, g_it = q.it;
+        hipStream_t sg = q.sg, sa = q.sa;
+        const BatchSolve *gb = d_bs_.p + w0;
+        if (side_aux) {   // aux row beside the moments; the step kernel joins the two
+          LIO_HIP(hipStreamWaitEvent(sa, k == 0 ? ev_fork_ : ev_step_[g], 0));
+          launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sa);
+          LIO_HIP(hipEventRecord(ev_aux_[g], sa));
+          launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
+          LIO_HIP(hipStreamWaitEvent(sg, ev_aux_[g], 0));
+          launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
+          if (k < g_it) LIO_HIP(hipEventRecord(ev_step_[g], sg));
+        } else if (knobs_.time_kernels) {   // measurement run: the three launches bracketed by events on their stream
+          while (ev_k_.size() < size_t(ev_k_used_ + 4)) { hipEvent_t e = nullptr; LIO_HIP(hipEventCreate(&e)); ev_k_.push_back(e); }
+          hipEvent_t *ek = ev_k_.data() + ev_k_used_;
+          ev_k_used_ += 4;
+          LIO_HIP(hipEventRecord(ek[0], sg));
+          launch_bw_aux(gb, bases, w1 - w0, g_wo, knobs_.aux_threads, sg);
+          LIO_HIP(hipEventRecord(ek[1], sg));
+          launch_bw_moments(gb, bases, w1 - w0, g_bpf, g_wo, valid_all_.p, coef_all_.p, sg);
+          LIO_HIP(hipEventRecord(ek[2], sg));
+          launch_bw_step(gb, bases, w1 - w0, g_wo, g_npad, sg);
+          LIO_HIP(hipEventRecord(ek[3], sg));
+        } else {
+          launch_bw_solve_iteration(gb, bases, w1 - w0, g_bpf, g_wo, g_npad, knobs_.aux_threads, valid_all_.p, coef_all_.p, sg);
+        }
+        if (h_bs_[0].prof && w0 == 0 && k == prof_it)   // LIO_DEBUG_TIMING: keep the stamps of this iteration's launch B beside the last one's
+          LIO_HIP(hipMemcpyAsync(h_bs_[0].prof + 32, h_bs_[0].prof, 32 * sizeof(long long), hipMemcpyDeviceToDevice, sg));
+      }
+    if (G > 1)
+      for (int g = 0; g < G; ++g) { LIO_HIP(hipEventRecord(ev_grp_[g], grp[g].sg)); LIO_HIP(hipStreamWaitEvent(s, ev_grp_[g], 0)); }
     LIO_HIP(hipEventRecord(ev_[5], s));
     LIO_HIP(hipMemcpyAsync(h_st_, d_st_.p, sizeof(DevState) * B, hipMemcpyDeviceToHost, s));
     LIO_HIP(hipStreamSynchronize(s));

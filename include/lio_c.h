@@ -549,7 +549,9 @@ int lio_est_batch_get_clock(const lio_est_batch *, double *out24);
  * (occupancy: -1) = chosen by the size of the launch, the default.  "lanes_per_query" 1 | 2 | 4 | 8 (search kernels of
  * CalculateFeatures / CalculateLaserOdom), "occupancy" 0 | 6 | 8 waves per SIMD of their one-lane-per-query forms, "loop_groups"
  * 1 .. 4 launch chains of the trust-region loop side by side, "aux_threads" 64 | 128 | 256 threads per block of the IMU / prior
- * row, "aux_stream" 0 | 1, "finish_threads" 1 .. 8 host threads of the write-back, "time_kernels" 0 | 1 (lio_est_batch_get_clock).  The environment variables LIO_BW_LPQ,
+ * row, "aux_stream" 0 | 1, "finish_threads" 1 .. 8 host threads of the write-back, "parts" 1 | 2 (a batch of at least 96 windows is solved
+ * as two halves side by side from two host threads — one half's host phases and latency-bound stages fill with the other's kernels; the
+ * clock then gives the longer half's host times and the SUM of the halves' device times), "time_kernels" 0 | 1 (lio_est_batch_get_clock).  The environment variables LIO_BW_LPQ,
  * LIO_BW_OCC, LIO_BW_GROUPS, LIO_BW_AUX_THREADS, LIO_BW_AUX_STREAM, LIO_BW_FINISH_THREADS set a new batch's defaults (read once
  * at lio_est_batch_create).  LIO_ERR_ARG: unknown name or value.  The oracle accepts and ignores them. */
 int lio_est_batch_set_option(lio_est_batch *, const char *name, int value);

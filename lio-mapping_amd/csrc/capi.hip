@@ -13,6 +13,8 @@
 #include "host_init.h"
 #include "kf_batch.h"
 #include <mutex>
+#include <thread>
+#include <atomic>
 
 #include "mapping.h"
 #include "odometry.h"
@@ -23,7 +25,19 @@ using namespace lio;
 struct lio_pim { std::shared_ptr<Preintegration> p; };
 // (members are destroyed in reverse order: the batch of one that serves lio_est_config.device_solve goes before the estimator it adopted)
 struct lio_est { std::unique_ptr<Estimator> e; EstConfig cfg; std::unique_ptr<MappingDev> map; lio_map_config map_cfg; std::unique_ptr<EstimatorBatch> solo; bool adopted = false; struct lio_est_batch *owner = nullptr; };
-struct lio_est_batch { std::unique_ptr<EstimatorBatch> b; std::vector<lio_est *> members; };
+// A batch of at least kBatchSplitFrom windows is TWO EstimatorBatch objects (the first and the second half of the windows) solved side by
+// side from two host threads: one part's host phases (describe, pack, write-back), syncs and latency-bound stages fill with the other
+// part's kernels (tools/batches_in_flight.py: 2 x 256 windows 20.1 k solves/s against 19.0 k for 1 x 512, 2 x 64 17.4 k against 16.1 k).
+// Every window's results are those of the window alone whatever the partition (the batch's contract), so the split is an execution
+// choice like the others ("parts", lio_est_batch_set_option).
+struct lio_est_batch {
+  std::unique_ptr<EstimatorBatch> b, b2;   // b2: the second part (null: one part)
+  int n1 = 0;                              // windows of b
+  int parts_opt = 0;                       // 0: by size, 1, 2
+  std::vector<std::pair<std::string, int>> options;   // what lio_est_batch_set_option has set, re-applied when the partition changes
+  std::vector<lio_est *> members;
+};
+static constexpr int kBatchSplitFrom = 96;    // measured (profiles/r6_n_batch_parts.txt): 16 .. 64 windows within noise, 96: + 4 %, 128 .. 512: + 7-8 %
 // lio_pp_process_batch runs its sweeps through ONE multi-sweep processor shared by the handles of the call (`pool`); a handle whose last
 // sweep went that way reads its results from sweep `pool_sweep` of it.  The pool is shared state: its users take `mu`.
 // `gen` counts the pool's batches: a handle whose results a LATER batch of other handles overwrote (same pool, its own sweep not among them)
@@ -69,6 +83,18 @@ template <typename F> static int pp_read(const lio_pp *h, F &&f) {
     }
     return LIO_OK;
   });
+}
+
+// f(part, first window of the part) on every part — two parts on two host threads
+template <typename F> static void batch_for_parts(lio_est_batch *h, F &&f) {
+  if (!h->b2) { f(*h->b, 0); return; }
+  std::exception_ptr err2;
+  std::thread t2([&] { try { f(*h->b2, h->n1); } catch (...) { err2 = std::current_exception(); } });
+  std::exception_ptr err1;
+  try { f(*h->b, 0); } catch (...) { err1 = std::current_exception(); }
+  t2.join();
+  if (err1) std::rethrow_exception(err1);
+  if (err2) std::rethrow_exception(err2);
 }
 
 extern "C" {
@@ -947,6 +973,31 @@ int lio_est_solve_restored(lio_est *h, int steps, lio_solve_report *rep) {
 }
 
 // ---------------------------------------------------------------- batched windows
+// (re)builds the batch's EstimatorBatch objects for its partition and re-applies the options set so far
+static void batch_build_parts(lio_est_batch *h) {
+  h->b.reset(); h->b2.reset();   // (a part's destructor brings its device-resident priors back to the host objects)
+  const int n = int(h->members.size());
+  static const int env_parts = [] { const char *e = std::getenv("LIO_BW_PARTS"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 2) ? v : 0; }();
+  const int want = h->parts_opt ? h->parts_opt : (env_parts ? env_parts : (n >= kBatchSplitFrom ? 2 : 1));
+  const int parts = (want == 2 && n >= 2) ? 2 : 1;
+  h->n1 = parts == 2 ? (n + 1) / 2 : n;
+  std::vector<Estimator *> es;
+  for (int i = 0; i < h->n1; ++i) es.push_back(h->members[size_t(i)]->e.get());
+  h->b.reset(new EstimatorBatch(es));
+  if (parts == 2) {
+    es.clear();
+    for (int i = h->n1; i < n; ++i) es.push_back(h->members[size_t(i)]->e.get());
+    h->b2.reset(new EstimatorBatch(es));
+  }
+  bool groups_set = false;
+  for (const auto &o : h->options) {
+    if (o.first == "loop_groups" && o.second != 0) groups_set = true;
+    h->b->SetOption(o.first.c_str(), o.second);
+    if (h->b2) h->b2->SetOption(o.first.c_str(), o.second);
+  }
+  // two parts side by side are two launch chains already: one loop group each unless the caller asked for a number
+  if (h->b2 && !groups_set) { h->b->SetOption("loop_groups", 1); h->b2->SetOption("loop_groups", 1); }
+}
 lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
   if (!windows || n < 1 || n > 65535) return nullptr;
   for (int i = 0; i < n; ++i) {
@@ -955,18 +1006,14 @@ lio_est_batch *lio_est_batch_create(lio_est *const *windows, int n) {
   }
   lio_est_batch *h = new (std::nothrow) lio_est_batch;
   if (!h) return nullptr;
-  int rc = guarded([&] {
-    std::vector<Estimator *> es;
-    for (int i = 0; i < n; ++i) es.push_back(windows[i]->e.get());
-    h->b.reset(new EstimatorBatch(es));
-    return LIO_OK;
-  });
-  if (rc != LIO_OK) { delete h; return nullptr; }
-  for (int i = 0; i < n; ++i) { windows[i]->adopted = true; windows[i]->owner = h; h->members.push_back(windows[i]); }
+  for (int i = 0; i < n; ++i) h->members.push_back(windows[i]);
+  int rc = guarded([&] { batch_build_parts(h); return LIO_OK; });
+  if (rc != LIO_OK) { (void)guarded([&] { h->b.reset(); h->b2.reset(); return LIO_OK; }); delete h; return nullptr; }
+  for (int i = 0; i < n; ++i) { windows[i]->adopted = true; windows[i]->owner = h; }
   return h;
 }
 static void dissolve_batch(lio_est_batch *B) {
-  (void)guarded([&] { B->b.reset(); return LIO_OK; });
+  (void)guarded([&] { B->b.reset(); B->b2.reset(); return LIO_OK; });
   for (lio_est *m : B->members) { m->adopted = false; m->owner = nullptr; }
   B->members.clear();
 }
@@ -975,35 +1022,51 @@ void lio_est_batch_destroy(lio_est_batch *h) {
   dissolve_batch(h);
   delete h;
 }
-int lio_est_batch_size(const lio_est_batch *h) { return (h && h->b) ? h->b->size() : 0; }
+int lio_est_batch_size(const lio_est_batch *h) { return (h && h->b) ? h->b->size() + (h->b2 ? h->b2->size() : 0) : 0; }
 int lio_est_batch_solve(lio_est_batch *h, lio_solve_report *reps) {
   if (!h) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
   for (lio_est *m : h->members) if (!m->e->inited_) return LIO_ERR_STATE;
-  return guarded([&] { h->b->Solve(reps); return LIO_OK; });
+  return guarded([&] { batch_for_parts(h, [&](EstimatorBatch &b, int w0) { b.Solve(reps ? reps + w0 : nullptr); }); return LIO_OK; });
 }
 int lio_est_batch_set_option(lio_est_batch *h, const char *name, int value) {
   if (!h || !name) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
-  return h->b->SetOption(name, value) ? LIO_OK : LIO_ERR_ARG;
+  if (std::string(name) == "parts") {   // the partition: 0 by size (two parts from kBatchSplitFrom windows), 1, 2
+    if (value < 0 || value > 2) return LIO_ERR_ARG;
+    if (value == h->parts_opt) return LIO_OK;
+    h->parts_opt = value;
+    return guarded([&] { batch_build_parts(h); return LIO_OK; });
+  }
+  if (!h->b->SetOption(name, value)) return LIO_ERR_ARG;
+  if (h->b2) h->b2->SetOption(name, value);
+  bool found = false;
+  for (auto &o : h->options) if (o.first == name) { o.second = value; found = true; }
+  if (!found) h->options.emplace_back(name, value);
+  if (h->b2 && std::string(name) == "loop_groups" && value == 0) { h->b->SetOption("loop_groups", 1); h->b2->SetOption("loop_groups", 1); }
+  return LIO_OK;
 }
 int lio_est_batch_solve_restored(lio_est_batch *h, int steps, lio_solve_report *reps) {
   if (!h || steps < 0) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
   return guarded([&] {
-    for (int k = 0; k < steps; ++k) {
-      for (lio_est *m : h->members) if (!m->e->Restore()) return int(LIO_ERR_STATE);
-      for (lio_est *m : h->members) if (!m->e->inited_) return int(LIO_ERR_STATE);
-      h->b->Solve(reps);
-    }
-    h->b->Sync();
-    return int(LIO_OK);
+    std::atomic<int> bad{0};
+    batch_for_parts(h, [&](EstimatorBatch &b, int w0) {   // (every part loops on its own: nothing ties the parts' steps together)
+      const int w1 = w0 + b.size();
+      for (int k = 0; k < steps && !bad.load(); ++k) {
+        for (int w = w0; w < w1; ++w) if (!h->members[size_t(w)]->e->Restore()) { bad.store(1); return; }
+        for (int w = w0; w < w1; ++w) if (!h->members[size_t(w)]->e->inited_) { bad.store(1); return; }
+        b.Solve(reps ? reps + w0 : nullptr);
+      }
+      b.Sync();
+    });
+    return bad.load() ? int(LIO_ERR_STATE) : int(LIO_OK);
   });
 }
 int lio_est_batch_sync(lio_est_batch *h) {
   if (!h) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
-  return guarded([&] { h->b->Sync(); return LIO_OK; });
+  return guarded([&] { h->b->Sync(); if (h->b2) h->b2->Sync(); return LIO_OK; });
 }
 int lio_seg_sort_pairs(const unsigned *keys, const unsigned *vals, size_t n_total, const int *seg_off, const int *seg_n, int nseg, int bits, int passes, unsigned *keys_out,
                        unsigned *vals_out) {
@@ -1012,13 +1075,28 @@ int lio_seg_sort_pairs(const unsigned *keys, const unsigned *vals, size_t n_tota
 int lio_est_batch_stage_digest(lio_est_batch *h, int stage, unsigned long long *out) {
   if (!h || !out || stage < 0 || stage > 9) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
-  return guarded([&] { h->b->StageDigest(stage, out); return LIO_OK; });
+  return guarded([&] { h->b->StageDigest(stage, out); if (h->b2) h->b2->StageDigest(stage, out + h->n1); return LIO_OK; });
 }
 int lio_est_batch_get_clock(const lio_est_batch *h, double *out) {
   if (!h || !out) return LIO_ERR_ARG;
   if (!h->b) return LIO_ERR_STATE;
   BatchClock c;
-  const int rc = guarded([&] { c = const_cast<lio_est_batch *>(h)->b->clock(); return LIO_OK; });
+  const int rc = guarded([&] {
+    c = const_cast<lio_est_batch *>(h)->b->clock();
+    if (h->b2) {
+      // two parts: host phases ran side by side (the longer one counts); device times, counts and launches add up — the parts' stages
+      // overlap on the GPU, so the summed device times exceed the wall time and every rate derived from them is a lower bound
+      const BatchClock d = const_cast<lio_est_batch *>(h)->b2->clock();
+      c.describe = std::max(c.describe, d.describe); c.map = std::max(c.map, d.map); c.grid_features = std::max(c.grid_features, d.grid_features);
+      c.pack = std::max(c.pack, d.pack); c.solve = std::max(c.solve, d.solve); c.finish = std::max(c.finish, d.finish);
+      c.fallback = std::max(c.fallback, d.fallback); c.total = std::max(c.total, d.total);
+      c.n_device += d.n_device; c.n_host += d.n_host; c.rounds = std::max(c.rounds, d.rounds);
+      for (int k = 0; k < 6; ++k) c.dev[k] += d.dev[k];
+      c.dev_marg_wait += d.dev_marg_wait;
+      for (int k = 0; k < 3; ++k) { c.kernel_ms[k] += d.kernel_ms[k]; c.kernel_launches[k] += d.kernel_launches[k]; }
+    }
+    return LIO_OK;
+  });
   if (rc != LIO_OK) return rc;
   for (int k = 0; k < 6; ++k) out[10 + k] = c.dev[k];
   out[0] = c.describe; out[1] = c.map; out[2] = c.grid_features; out[3] = c.pack; out[4] = c.solve; out[5] = c.finish; out[6] = c.fallback; out[7] = c.total;

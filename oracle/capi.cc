@@ -841,7 +841,7 @@ int lio_est_batch_set_option(lio_est_batch *b, const char *name, int value) {   
   if (!b || !name) return LIO_ERR_ARG;
   if (b->dissolved) return LIO_ERR_STATE;
   (void)value;
-  for (const char *k : {"lanes_per_query", "occupancy", "loop_groups", "aux_threads", "aux_stream", "finish_threads", "time_kernels"})
+  for (const char *k : {"lanes_per_query", "occupancy", "loop_groups", "aux_threads", "aux_stream", "finish_threads", "time_kernels", "parts"})
     if (std::strcmp(name, k) == 0) return LIO_OK;
   return LIO_ERR_ARG;
 }

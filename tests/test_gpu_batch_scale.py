@@ -64,14 +64,14 @@ def _assert_same_state(a, b, what):
             np.testing.assert_array_equal(x[2], y[2], err_msg=f"{what}: window {k} prior")
 
 
-OPTION_SETS = [   # (lanes_per_query, occupancy, loop_groups, aux_threads, finish_threads)
-    (8, -1, 1, 256, 1),       # what a small batch takes by itself
-    (4, -1, 1, 256, 1),
-    (2, -1, 2, 128, 2),
-    (1, 0, 2, 64, 1),         # one lane per query as compiled
-    (1, 6, 3, 64, 3),
-    (1, 8, 2, 64, 4),         # the forms a batch of 512 headline windows runs
-    (0, -1, 0, 0, 0),         # everything by size again
+OPTION_SETS = [   # (lanes_per_query, occupancy, loop_groups, aux_threads, finish_threads, parts)
+    (8, -1, 1, 256, 1, 1),       # what a small batch takes by itself
+    (4, -1, 1, 256, 1, 2),       # ... as two parts on two host threads (2 + 1 windows)
+    (2, -1, 2, 128, 2, 1),
+    (1, 0, 2, 64, 1, 2),         # one lane per query as compiled
+    (1, 6, 3, 64, 3, 1),
+    (1, 8, 0, 64, 8, 2),         # the forms a batch of 512 headline windows runs
+    (0, -1, 0, 0, 0, 0),         # everything by size again
 ]
 
 
@@ -98,8 +98,8 @@ def test_execution_choices_do_not_change_a_bit(hip):
     for _, _, _, est in runs:
         est.snapshot()
     first = None
-    for lpq, occ, groups, aux, fin in OPTION_SETS:
-        for name, v in (("lanes_per_query", lpq), ("occupancy", occ), ("loop_groups", groups), ("aux_threads", aux), ("finish_threads", fin)):
+    for lpq, occ, groups, aux, fin, parts in OPTION_SETS:
+        for name, v in (("parts", parts), ("lanes_per_query", lpq), ("occupancy", occ), ("loop_groups", groups), ("aux_threads", aux), ("finish_threads", fin)):
             batch.set_option(name, v)
         reps = batch.solve_restored(1)
         assert int(batch.clock()["n_device"]) == len(runs)
@@ -115,7 +115,7 @@ def test_execution_choices_do_not_change_a_bit(hip):
             first = (dg, st1, dg2, st2)
             assert all(k[0][8] == 1 for k in st1), "the compared step must marginalise (the prior of the second step comes from the device)"
             continue
-        what = f"options {(lpq, occ, groups, aux, fin)}"
+        what = f"options {(lpq, occ, groups, aux, fin, parts)}"
         np.testing.assert_array_equal(dg, first[0], err_msg=what)
         np.testing.assert_array_equal(dg2, first[2], err_msg=what + " (second step)")
         _assert_same_state(st1, first[1], what)
